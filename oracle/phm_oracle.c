@@ -1,0 +1,748 @@
+/*
+ * phm_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).  See phm_oracle.h.
+ *
+ * Plain-C restatement of the hot path of vnminin/phylomap, src/phylomap.cpp.
+ * "parity unpinned": the reference has no tests/golden vectors and cannot be built here.
+ *
+ * Arithmetic contract (DESIGN.md "Arithmetic spec"; the HIP kernels restate the same):
+ *   - IEEE binary64, round-to-nearest, NO fused multiply-add (build with -ffp-contract=off);
+ *   - mat-vec  y_i = ((M_i0*x_0 + M_i1*x_1) + M_i2*x_2) + ...   left to right
+ *     (what Armadillo's gemv_emul_tinysq does for n<=4 on a default R build);
+ *   - categorical draw: first j with u*sum(p) <= p_0+..+p_j (index order, no sort; see
+ *     sample_cat below for why RcppArmadillo's descending sort is not restated);
+ *   - Exp(rate r) gap = (1/r) * (-phm_log(u))   (Rcpp::rexp(n,rate) multiplies by scale=1/rate);
+ *   - uniforms from Philox4x32-10 keyed (seed) with counter (block, entity, iteration, replica).
+ */
+#include "phm_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------ */
+/* Philox4x32-10 (Salmon et al. 2011, Random123).  Pinned by Random123's kat_vectors.          */
+/* ------------------------------------------------------------------------------------------ */
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+  uint32_t k0 = key[0], k1 = key[1];
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* 64 random bits -> double in the OPEN interval (0,1): ((x>>12)+0.5)*2^-52, exact. */
+double orc_u01(uint32_t lo, uint32_t hi) {
+  uint64_t x = ((uint64_t)hi << 32) | lo;
+  uint64_t k = ((x >> 12) << 1) | 1u;               /* odd, < 2^53: exact in a double */
+  return (double)k * 1.1102230246251565404e-16;     /* 2^-53 */
+}
+
+/* draw number `draw` of stream (replica, iter, entity): Philox block draw/2, words (0,1) or (2,3) */
+double orc_stream_u(uint32_t seed_lo, uint32_t seed_hi, uint32_t replica, uint32_t iter,
+                    uint32_t entity, uint32_t draw) {
+  uint32_t ctr[4] = { draw >> 1, entity, iter, replica };
+  uint32_t key[2] = { seed_lo, seed_hi };
+  uint32_t o[4];
+  orc_philox4x32_10(ctr, key, o);
+  return (draw & 1u) ? orc_u01(o[2], o[3]) : orc_u01(o[0], o[1]);
+}
+
+/* entity tags (top two bits of the entity word) */
+#define ENT_NODE   0u            /* node-state draw: entity = node id (0-based), draw 0 */
+#define ENT_BSTATE (1u << 30)    /* branch interior-state uniforms: draw i-1 for position i */
+#define ENT_BEXP   (2u << 30)    /* branch virtual-jump exponentials: sequential */
+#define ENT_BUNIF  (3u << 30)    /* EXP path newunifSample draws: sequential */
+
+/* ------------------------------------------------------------------------------------------ */
+/* phm_log / phm_exp: deterministic elementary functions (fdlibm-style argument reduction and   */
+/* minimax polynomials, one code path, basic IEEE operations only) so CPU and GPU agree bitwise. */
+/* Pinned against libm in tests (<= 2 ulp).                                                    */
+/* ------------------------------------------------------------------------------------------ */
+static inline uint64_t d2u(double x) { uint64_t u; memcpy(&u, &x, 8); return u; }
+static inline double   u2d(uint64_t u) { double x; memcpy(&x, &u, 8); return x; }
+
+double orc_log(double x) {
+  static const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+    Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+    Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+    Lg7 = 1.479819860511658591e-01;
+  if (!(x > 0.0)) return (x == 0.0) ? -INFINITY : NAN;
+  if (isinf(x)) return x;
+  int k = 0;
+  if (x < 2.2250738585072014e-308) { x *= 18014398509481984.0; k -= 54; }   /* subnormal: *2^54 */
+  uint64_t ux = d2u(x);
+  uint32_t hx = (uint32_t)(ux >> 32);
+  k += (int)(hx >> 20) - 1023;
+  hx &= 0x000fffffu;
+  uint32_t i = (hx + 0x95f64u) & 0x100000u;          /* mantissa >= sqrt(2): use x/2 */
+  ux = ((uint64_t)(hx | (i ^ 0x3ff00000u)) << 32) | (ux & 0xffffffffu);
+  k += (int)(i >> 20);
+  double f = u2d(ux) - 1.0;
+  double dk = (double)k;
+  double s = f / (2.0 + f);
+  double z = s * s;
+  double w = z * z;
+  double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+  double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+  double R = t2 + t1;
+  double hfsq = 0.5 * f * f;
+  return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+}
+
+double orc_exp(double x) {
+  static const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
+    invln2 = 1.44269504088896338700e+00,
+    P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+    P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+  if (x != x) return x;
+  if (x > 7.09782712893383973096e+02) return INFINITY;
+  if (x < -7.45133219101941108420e+02) return 0.0;
+  double hi = x, lo = 0.0;
+  int k = 0;
+  if (fabs(x) > 0.34657359027997264) {               /* 0.5*ln2 */
+    k = (int)(invln2 * x + (x < 0.0 ? -0.5 : 0.5));
+    double t = (double)k;
+    hi = x - t * ln2HI;
+    lo = t * ln2LO;
+  }
+  double r = hi - lo;
+  double t = r * r;
+  double c = r - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+  double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+  return ldexp(y, k);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* RNG front end                                                                               */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct { orc_rng* r; int err; } rngctx;
+
+static double draw_u(rngctx* c, uint32_t iter, uint32_t entity, uint32_t draw) {
+  orc_rng* r = c->r;
+  if (r->mode == 1) {
+    if (r->pos_u >= r->n_u) { c->err |= ORC_ERR_TAPE; return 0.5; }
+    return r->tape_u[r->pos_u++];
+  }
+  return orc_stream_u(r->seed_lo, r->seed_hi, r->replica, iter, entity, draw);
+}
+/* standard exponential: -log(u) (R's exp_rand is Ahrens-Dieter; not restated in Philox mode) */
+static double draw_e(rngctx* c, uint32_t iter, uint32_t entity, uint32_t draw) {
+  orc_rng* r = c->r;
+  if (r->mode == 1) {
+    if (r->pos_e >= r->n_e) { c->err |= ORC_ERR_TAPE; return 1.0; }
+    return r->tape_e[r->pos_e++];
+  }
+  return -orc_log(orc_stream_u(r->seed_lo, r->seed_hi, r->replica, iter, entity, draw));
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* small dense helpers; all matrices row-major here                                             */
+/* ------------------------------------------------------------------------------------------ */
+/* y = M x  -- arma `(*B2)*(*vec)` at src/phylomap.cpp:448 (mmmmvFORpl), :290 */
+static void matvec(const double* M, const double* x, double* y, int n) {
+  for (int i = 0; i < n; ++i) {
+    double acc = M[i * n] * x[0];
+    for (int j = 1; j < n; ++j) acc += M[i * n + j] * x[j];
+    y[i] = acc;
+  }
+}
+/* y = M^T x -- `(*B4)*vec` with B4 = trans(B2), src/phylomap.cpp:434 (Tvmmp), :918 */
+static void matTvec(const double* M, const double* x, double* y, int n) {
+  for (int c = 0; c < n; ++c) {
+    double acc = M[c] * x[0];
+    for (int r = 1; r < n; ++r) acc += M[r * n + c] * x[r];
+    y[c] = acc;
+  }
+}
+/* v <- M^k v : mmmmvFORpl / spmmmmvFORpl, src/phylomap.cpp:446-457 */
+static void chain(const double* M, double* v, int k, int n, double* tmp) {
+  for (int i = 0; i < k; ++i) { matvec(M, v, tmp, n); memcpy(v, tmp, sizeof(double) * n); }
+}
+/* v <- (M^T)^k v : Tvmmp / spvmmmm, src/phylomap.cpp:431-444 */
+static void chainT(const double* M, double* v, int k, int n, double* tmp) {
+  for (int i = 0; i < k; ++i) { matTvec(M, v, tmp, n); memcpy(v, tmp, sizeof(double) * n); }
+}
+
+/*
+ * Categorical draw.  Replaces RcppArmadillo::sample(sts,1,TRUE,p) (src/phylomap.cpp:304,627,655...).
+ * RcppArmadillo normalises p, sorts it DESCENDING (tie order implementation-defined, so it cannot be
+ * pinned), then inverse-CDF with `u <= cum`.  The sort changes which index a given u maps to but not the
+ * distribution; with a counter-based stream there is no R stream to stay aligned with, so the oracle
+ * uses index order, keeps the `<=`, and compares u*sum(p) with the running sum instead of dividing
+ * every p_j.  All-zero / non-finite p (RcppArmadillo throws) raises ORC_ERR_ZERO_PROB.
+ */
+static int sample_cat(const double* p, int n, double u, int* err) {
+  double total = p[0];
+  for (int j = 1; j < n; ++j) total += p[j];
+  if (!(total > 0.0) || isinf(total)) { *err |= ORC_ERR_ZERO_PROB; return 0; }
+  double thr = u * total;
+  double cum = p[0];
+  if (thr <= cum) return 0;
+  for (int j = 1; j < n; ++j) { cum += p[j]; if (thr <= cum) return j; }
+  int last = n - 1;
+  while (last > 0 && !(p[last] > 0.0)) --last;
+  return last;
+}
+
+/* sampleOnce, src/phylomap.cpp:81-90: no sort, per-element division, strict `<`; may run off the end */
+static int sampleOnce(const double* w, int n, double u, int* err) {
+  double total = w[0];
+  for (int j = 1; j < n; ++j) total += w[j];
+  double cum = 0.0;
+  int i;
+  for (i = 0; i < n; ++i) { cum += w[i] / total; if (u < cum) break; }
+  if (i >= n) { *err |= ORC_ERR_SAMPLEONCE; i = n - 1; }   /* reference would index out of range */
+  return i;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Branch container: struct Branch + makeabranch, src/phylomap.cpp:18-34                        */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct { double* d; int32_t* s; int m, cap; } Branch;
+
+static void br_reserve(Branch* b, int need) {
+  if (need <= b->cap) return;
+  int nc = b->cap ? b->cap : 8;
+  while (nc < need) nc *= 2;
+  b->d = (double*)realloc(b->d, sizeof(double) * nc);
+  b->s = (int32_t*)realloc(b->s, sizeof(int32_t) * nc);
+  b->cap = nc;
+}
+static void makeabranch(Branch* b, const double* maps, const int32_t* names, int m) {
+  b->d = NULL; b->s = NULL; b->cap = 0; b->m = 0;
+  br_reserve(b, m > 0 ? m : 1);
+  for (int i = 0; i < m; ++i) { b->d[i] = maps[i]; b->s[i] = names[i] - 1; }   /* :29 1-based -> 0-based */
+  b->m = m;
+}
+
+/* shortener, src/phylomap.cpp:44-73: merge equal neighbours, then count a->b (a != b) transitions */
+static int shortener_arr(double* d, int32_t* s, int m, int n, double* stats, int64_t stride, int iter) {
+  int w = 0;
+  for (int i = 1; i < m; ++i) {
+    if (s[i] != s[w]) { ++w; d[w] = d[i]; s[w] = s[i]; }
+    else d[w] = d[w] + d[i];                                   /* :54 */
+  }
+  int mm = (m > 0) ? w + 1 : 0;
+  for (int i = 1; i < mm; ++i) {
+    int a = s[i - 1], b = s[i];
+    if (a < b) stats[(int64_t)(n + a * (n - 1) + b - 1) * stride + iter] += 1.0;   /* :65 */
+    if (a > b) stats[(int64_t)(n + a * (n - 1) + b) * stride + iter] += 1.0;       /* :66 */
+  }
+  return mm;
+}
+int orc_shortener(double* d, int32_t* s, int m, int n, double* stats_row) {
+  return shortener_arr(d, s, m, n, stats_row, 1, 0);
+}
+
+/* matTospmat, src/phylomap.cpp:801-816: keep entries > 1e-7 only */
+void orc_matTospmat(const double* B, int n, double* out) {
+  for (int i = 0; i < n * n; ++i) out[i] = (B[i] > 1e-7) ? B[i] : 0.0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* resamplebranchstates, src/phylomap.cpp:264-308 (SPARSE twin :218-261)                        */
+/*   Bchain: matrix of the backward recursion (B2, or the thresholded B3 in the SPARSE variant)  */
+/*   Brow:   matrix whose rows give the forward step (always the dense B2, :254/:301)            */
+/* ------------------------------------------------------------------------------------------ */
+static void resamplebranchstates(Branch* br, const double* Bchain, const double* Brow, int n,
+                                 rngctx* rc, uint32_t iter, uint32_t branch_id, double* scratch) {
+  int ss = br->m;
+  if (ss <= 2) return;                                         /* :269-270 */
+  double* bpws = scratch;                                      /* n x ss, column j at bpws + j*n */
+  double* p = scratch + (size_t)n * ss;
+  for (int i = 0; i < n; ++i) bpws[i] = 0.0;
+  bpws[br->s[ss - 1]] = 1.0;                                   /* :280 */
+  for (int j = 1; j < ss - 1; ++j) matvec(Bchain, bpws + (size_t)(j - 1) * n, bpws + (size_t)j * n, n);   /* :290 */
+  for (int i = 1; i < ss - 1; ++i) {
+    const double* row = Brow + (size_t)br->s[i - 1] * n;
+    const double* beta = bpws + (size_t)(ss - i - 1) * n;
+    for (int c = 0; c < n; ++c) p[c] = row[c] * beta[c];       /* :301 */
+    double u = draw_u(rc, iter, ENT_BSTATE | branch_id, (uint32_t)(i - 1));
+    br->s[i] = sample_cat(p, n, u, &rc->err);                  /* :304 */
+  }
+}
+
+/* sampleabranch, src/phylomap.cpp:370-413 (SPARSE twin :318-364) */
+static void sampleabranch(Branch* br, const double* Bchain, const double* Brow, double Omega,
+                          const double* Qdiag, int n, double* stats, int64_t stride, int iter,
+                          rngctx* rc, uint32_t branch_id, double** scratch, size_t* scratch_len,
+                          Branch* tmp) {
+  size_t need = (size_t)n * (br->m + 2);
+  if (need > *scratch_len) { *scratch = (double*)realloc(*scratch, sizeof(double) * need); *scratch_len = need; }
+  resamplebranchstates(br, Bchain, Brow, n, rc, (uint32_t)iter, branch_id, *scratch);   /* :376 */
+  br->m = shortener_arr(br->d, br->s, br->m, n, stats, stride, iter);                   /* :377 */
+  /* re-insert virtual jumps: gaps ~ Exp(rate Omega + Q[s,s]) until the segment is used up (:391-410) */
+  tmp->m = 0;
+  uint32_t edraw = 0;
+  int stuck = 0;
+  for (int i = 0; i < br->m; ++i) {
+    double segmentlength = br->d[i];
+    double totallengthinserted = 0.0;
+    int s = br->s[i];
+    /* A merged segment whose length is not > 0 skips the while loop WITHOUT advancing the list
+       iterators (:397, :405-406), so the reference's remaining for-iterations all look at that same
+       element: it and every later segment are left untouched. */
+    if (stuck || !(0.0 < segmentlength)) {
+      stuck = 1;
+      br_reserve(tmp, tmp->m + 1);
+      tmp->d[tmp->m] = segmentlength; tmp->s[tmp->m] = s; tmp->m++;
+      continue;
+    }
+    double r = Omega + Qdiag[s];                               /* :395 */
+    double scale = 1.0 / r;                                    /* Rcpp::rexp(n, rate): scale = 1/rate */
+    while (totallengthinserted < segmentlength) {
+      double rl = scale * draw_e(rc, (uint32_t)iter, ENT_BEXP | branch_id, edraw++);   /* :398 */
+      br_reserve(tmp, tmp->m + 1);
+      if ((totallengthinserted + rl) < segmentlength) {
+        tmp->d[tmp->m] = rl; tmp->s[tmp->m] = s; tmp->m++;
+        totallengthinserted += rl;
+      } else {
+        tmp->d[tmp->m] = segmentlength - totallengthinserted; tmp->s[tmp->m] = s; tmp->m++;
+        totallengthinserted = segmentlength;
+      }
+    }
+  }
+  br_reserve(br, tmp->m);
+  memcpy(br->d, tmp->d, sizeof(double) * tmp->m);
+  memcpy(br->s, tmp->s, sizeof(int32_t) * tmp->m);
+  br->m = tmp->m;
+}
+
+/* updatedwelltimes, src/phylomap.cpp:745-757 */
+static void updatedwelltimes(int iter, const Branch* br, double* stats, int64_t stride) {
+  for (int i = 0; i < br->m; ++i) stats[(int64_t)br->s[i] * stride + iter] += br->d[i];
+}
+
+/* updatenodestates, src/phylomap.cpp:460-475: rm is 1-based states per node */
+static void updatenodestates(Branch* brs, const int32_t* edge1, const int32_t* edge2, int E, const int32_t* rm) {
+  for (int i = 0; i < E; ++i) {
+    brs[i].s[0] = rm[edge1[i] - 1] - 1;                        /* :469 */
+    brs[i].s[brs[i].m - 1] = rm[edge2[i] - 1] - 1;             /* :472 (m==1: child wins) */
+  }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Pruning sweeps                                                                              */
+/* ------------------------------------------------------------------------------------------ */
+static int check_tree(const orc_tree* x) {
+  if (!x || x->n_tips < 2 || x->n_node != x->n_tips - 1 || x->n_edge != 2 * x->n_tips - 2) return ORC_ERR_BAD_INPUT;
+  return 0;
+}
+
+/* makePLrcpp :503-514 / makePLrcpp_bigtree :516-529 / SPARSEmakePLrcpp :490-501 */
+static void makePL(const int32_t* edge1, const int32_t* edge2, int Nnode, double* PL, const int32_t* ne,
+                   const double* Bchain, const int32_t* branchlengths, int normalise, int n, double* w) {
+  double* first = w; double* second = w + n; double* tmp = w + 2 * n;
+  for (int i = 0; i < Nnode; ++i) {
+    int ea = ne[2 * i] - 1, eb = ne[2 * i + 1] - 1;
+    memcpy(first, PL + (size_t)(edge2[eb] - 1) * n, sizeof(double) * n);     /* :508 */
+    memcpy(second, PL + (size_t)(edge2[ea] - 1) * n, sizeof(double) * n);    /* :509 */
+    chain(Bchain, first, branchlengths[eb] - 1, n, tmp);
+    chain(Bchain, second, branchlengths[ea] - 1, n, tmp);
+    double* row = PL + (size_t)(edge1[ea] - 1) * n;
+    for (int c = 0; c < n; ++c) row[c] = first[c] * second[c];               /* :510 */
+    if (normalise) {                                                         /* :525 */
+      double s = row[0];
+      for (int c = 1; c < n; ++c) s += row[c];
+      for (int c = 0; c < n; ++c) row[c] = row[c] / s;
+    }
+  }
+}
+
+int orc_makePL(const orc_tree* x, int n, const double* Bchain, const int32_t* nen,
+               const int32_t* seg_count, int normalise, double* PL) {
+  int e = check_tree(x); if (e) return e;
+  int E = x->n_edge, T = x->n_tips;
+  const int32_t* edge1 = x->edge; const int32_t* edge2 = x->edge + E;
+  memset(PL, 0, sizeof(double) * (size_t)(2 * x->n_node + 1) * n);
+  for (int i = 0; i < T; ++i) PL[(size_t)i * n + (x->states[i] - 1)] = 1.0;  /* :912-914 */
+  double* w = (double*)malloc(sizeof(double) * 3 * n);
+  makePL(edge1, edge2, x->n_node, PL, nen, Bchain, seg_count, normalise, n, w);
+  free(w);
+  return 0;
+}
+
+/* makePLold :2877-2895 / makePLexp :2899-2906: P_b = TransProb.slice(b), row-major n x n per edge */
+static void makePLexp(const int32_t* edge1, const int32_t* edge2, int Nnode, double* PL, const int32_t* ne,
+                      const double* P, int n, double* w) {
+  double* a = w; double* b = w + n;
+  for (int i = 0; i < Nnode; ++i) {
+    int ea = ne[2 * i] - 1, eb = ne[2 * i + 1] - 1;
+    matvec(P + (size_t)ea * n * n, PL + (size_t)(edge2[ea] - 1) * n, a, n);
+    matvec(P + (size_t)eb * n * n, PL + (size_t)(edge2[eb] - 1) * n, b, n);
+    double* row = PL + (size_t)(edge1[ea] - 1) * n;
+    for (int c = 0; c < n; ++c) row[c] = a[c] * b[c];                        /* :2903 */
+  }
+}
+int orc_makePLexp(const orc_tree* x, int n, const double* P, const int32_t* nen, double* PL) {
+  int e = check_tree(x); if (e) return e;
+  int E = x->n_edge, T = x->n_tips;
+  memset(PL, 0, sizeof(double) * (size_t)(2 * x->n_node + 1) * n);
+  for (int i = 0; i < T; ++i) PL[(size_t)i * n + (x->states[i] - 1)] = 1.0;
+  double* w = (double*)malloc(sizeof(double) * 2 * n);
+  makePLexp(x->edge, x->edge + E, x->n_node, PL, nen, P, n, w);
+  free(w);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* sampleinternalnodesMCMC :591-663 (_bigtree :666-738, SPARSE :535-587)                        */
+/* ------------------------------------------------------------------------------------------ */
+static void sampleinternalnodesMCMC(Branch* brs, int E, double* PL, const double* pid, const double* Bchain,
+                                    int root, const int32_t* nodelist, int nll, const int32_t* ne,
+                                    const int32_t* edge1, const int32_t* edge2, int Nnode,
+                                    const int32_t* states, int T, int normalise, int n,
+                                    int faithful_search, const int32_t* edge_of_child,
+                                    rngctx* rc, uint32_t iter, int32_t* rm, int32_t* branchlengths, double* w) {
+  for (int i = 0; i < E; ++i) branchlengths[i] = brs[i].m;                   /* :598-599 */
+  for (int i = 0; i < 2 * T - 1; ++i) rm[i] = 0;
+  for (int i = 0; i < T; ++i) rm[i] = states[i] - 1;                         /* :612 */
+  makePL(edge1, edge2, Nnode, PL, ne, Bchain, branchlengths, normalise, n, w);   /* :616 */
+  double* p = w; double* vecc = w + n; double* tmp = w + 2 * n;
+  for (int c = 0; c < n; ++c) p[c] = pid[c] * PL[(size_t)(root - 1) * n + c];    /* :618 */
+  rm[root - 1] = sample_cat(p, n, draw_u(rc, iter, ENT_NODE | (uint32_t)(root - 1), 0), &rc->err);   /* :627 */
+  for (int i = 0; i < nll; ++i) {
+    int cn = nodelist[i] - 1;                                                /* :641 */
+    int j = 0;
+    if (faithful_search) { while (edge2[j] != nodelist[i]) j++; }            /* :643, O(E) per node */
+    else j = edge_of_child[cn];
+    int pn = edge1[j] - 1;
+    int ps = rm[pn];
+    for (int c = 0; c < n; ++c) vecc[c] = 0.0;
+    vecc[ps] = 1.0;                                                          /* :650 */
+    chainT(Bchain, vecc, branchlengths[j] - 1, n, tmp);                      /* :651 Tvmmp / :576 spvmmmm */
+    for (int c = 0; c < n; ++c) p[c] = vecc[c] * PL[(size_t)cn * n + c];
+    rm[cn] = sample_cat(p, n, draw_u(rc, iter, ENT_NODE | (uint32_t)cn, 0), &rc->err);   /* :655 */
+  }
+  for (int i = 0; i < 2 * T - 1; ++i) rm[i] = rm[i] + 1;                     /* :659 */
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* maketreelistMCMC :891-935, _bigtree :942-986, SPARSE :822-870; per-iteration sweep =         */
+/* treesample :775-785 / treesample_bigtree :787-797 / SPARSEtreesample :761-770                */
+/* ------------------------------------------------------------------------------------------ */
+static void fill_dump(orc_dump* dump, const Branch* brs, int E, const int32_t* rm, int nn, const double* PL, size_t pl_len) {
+  if (!dump) return;
+  if (dump->node_states && rm) memcpy(dump->node_states, rm, sizeof(int32_t) * nn);
+  if (dump->seg_count) for (int i = 0; i < E; ++i) dump->seg_count[i] = brs[i].m;
+  if (dump->seg_dwell && dump->seg_state) {
+    for (int i = 0; i < E; ++i) {
+      int m = brs[i].m < dump->seg_cap ? brs[i].m : dump->seg_cap;
+      for (int j = 0; j < m; ++j) {
+        dump->seg_dwell[(size_t)i * dump->seg_cap + j] = brs[i].d[j];
+        dump->seg_state[(size_t)i * dump->seg_cap + j] = brs[i].s[j];
+      }
+    }
+  }
+  if (dump->PL && PL) memcpy(dump->PL, PL, sizeof(double) * pl_len);
+}
+
+int orc_maketreelistMCMC(const orc_tree* x, int n, const double* Q_cm, const double* pid,
+                         const double* B_cm, double Omega, const int32_t* nen,
+                         const int32_t* nodelist, int32_t root, int32_t N, int variant,
+                         int faithful_search, orc_rng* rng, double* out, orc_dump* dump) {
+  int e = check_tree(x); if (e) return e;
+  if (n < 2 || N < 0) return ORC_ERR_BAD_INPUT;
+  int E = x->n_edge, T = x->n_tips, Nnode = x->n_node;
+  const int32_t* edge1 = x->edge; const int32_t* edge2 = x->edge + E;
+  int cols = n + n * (n - 1);
+  rngctx rc = { rng, 0 };
+
+  double* B2 = (double*)malloc(sizeof(double) * n * n);       /* row-major copies */
+  double* Bc = (double*)malloc(sizeof(double) * n * n);
+  double* Qd = (double*)malloc(sizeof(double) * n);
+  for (int i = 0; i < n; ++i) { Qd[i] = Q_cm[i + (size_t)i * n]; for (int j = 0; j < n; ++j) B2[i * n + j] = B_cm[i + (size_t)j * n]; }
+  if (variant == ORC_MCMC_SPARSE) orc_matTospmat(B2, n, Bc);  /* :848 */
+  else memcpy(Bc, B2, sizeof(double) * n * n);
+  int normalise = (variant == ORC_MCMC_BIGTREE);
+
+  Branch* brs = (Branch*)calloc(E, sizeof(Branch));
+  for (int i = 0; i < E; ++i) {
+    int o = x->map_off[i], m = x->map_off[i + 1] - o;
+    if (m < 1) { e = ORC_ERR_BAD_INPUT; m = 0; }
+    makeabranch(&brs[i], x->maps + o, x->mapnames + o, m);    /* :901 */
+  }
+  size_t pl_len = (size_t)(2 * Nnode + 1) * n;
+  double* PL = (double*)calloc(pl_len, sizeof(double));
+  for (int i = 0; i < T; ++i) PL[(size_t)i * n + (x->states[i] - 1)] = 1.0;   /* :914 */
+  int32_t* rm = (int32_t*)calloc(2 * T - 1, sizeof(int32_t));
+  int32_t* bl = (int32_t*)calloc(E, sizeof(int32_t));
+  int32_t* eoc = (int32_t*)calloc(2 * T - 1, sizeof(int32_t));
+  for (int i = 0; i < E; ++i) eoc[edge2[i] - 1] = i;
+  double* w = (double*)malloc(sizeof(double) * 3 * n);
+  double* scratch = NULL; size_t scratch_len = 0;
+  Branch tmp = { NULL, NULL, 0, 0 };
+  memset(out, 0, sizeof(double) * (size_t)N * cols);          /* :926 */
+
+  if (!e) for (int it = 0; it < N; ++it) {
+    sampleinternalnodesMCMC(brs, E, PL, pid, Bc, root, nodelist, Nnode - 1, nen, edge1, edge2, Nnode,
+                            x->states, T, normalise, n, faithful_search, eoc, &rc, (uint32_t)it, rm, bl, w);
+    updatenodestates(brs, edge1, edge2, E, rm);                                              /* :779 */
+    for (int i = 0; i < E; ++i)                                                              /* :781 */
+      sampleabranch(&brs[i], Bc, B2, Omega, Qd, n, out, N, it, &rc, (uint32_t)i, &scratch, &scratch_len, &tmp);
+    for (int i = 0; i < E; ++i) updatedwelltimes(it, &brs[i], out, N);                       /* :782 */
+  }
+  fill_dump(dump, brs, E, rm, 2 * T - 1, PL, pl_len);
+  for (int i = 0; i < E; ++i) { free(brs[i].d); free(brs[i].s); }
+  free(tmp.d); free(tmp.s); free(scratch); free(w); free(eoc); free(bl); free(rm); free(PL); free(brs);
+  free(Qd); free(Bc); free(B2);
+  return e | rc.err;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* EXP path                                                                                    */
+/* ------------------------------------------------------------------------------------------ */
+/* matexp :2964-2968 followed by abs() (:2980, :3042).  D is diagonal, so (left*D)[i][k] = L[i][k]*exp(d_k t)
+ * (the other products are exact zeros), then the second GEMM sums left to right. */
+void orc_matexp(const double* L, const double* R, const double* dvals, int n, double t, double* P) {
+  double ex[256];
+  double* e = (n <= 256) ? ex : (double*)malloc(sizeof(double) * n);
+  for (int k = 0; k < n; ++k) e[k] = orc_exp(dvals[k] * t);                  /* :2966 */
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) {
+      double acc = (L[i * n] * e[0]) * R[j];
+      for (int k = 1; k < n; ++k) acc += (L[i * n + k] * e[k]) * R[k * n + j];
+      P[i * n + j] = fabs(acc);
+    }
+  if (e != ex) free(e);
+}
+
+/* arma::expmat (call sites src/phylomap.cpp:3226,3243,3359,3383): Pade approximant of degree 6 with
+ * scaling 2^s and s squarings.  Armadillo is not under /root/reference; this restates its published
+ * algorithm: s from frexp(log2(||A||_inf)), E = sum c_i A^i, D = sum (-1)^i c_i A^i, solve(D,E)
+ * by LU with partial pivoting, then s squarings. */
+static void gemm_rm(const double* A, const double* B, double* C, int n) {
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) {
+      double acc = A[i * n] * B[j];
+      for (int k = 1; k < n; ++k) acc += A[i * n + k] * B[k * n + j];
+      C[i * n + j] = acc;
+    }
+}
+int orc_expmat_pade(const double* A_in, int n, double* out) {
+  size_t nn = (size_t)n * n;
+  double* A = (double*)malloc(sizeof(double) * nn * 5);
+  double *Em = A + nn, *Dm = A + 2 * nn, *X = A + 3 * nn, *T2 = A + 4 * nn;
+  double norm = 0.0;
+  for (int i = 0; i < n; ++i) { double r = 0.0; for (int j = 0; j < n; ++j) r += fabs(A_in[i * n + j]); if (r > norm) norm = r; }
+  double log2v = (norm > 0.0) ? log2(norm) : 0.0;
+  int ex = 0; (void)frexp(log2v, &ex);
+  int s = ex + 1; if (s < 0) s = 0;
+  double sc = ldexp(1.0, s);
+  for (size_t i = 0; i < nn; ++i) A[i] = A_in[i] / sc;
+  double c = 0.5;
+  for (size_t i = 0; i < nn; ++i) { Em[i] = c * A[i]; Dm[i] = -(c * A[i]); X[i] = A[i]; }
+  for (int i = 0; i < n; ++i) { Em[i * n + i] += 1.0; Dm[i * n + i] += 1.0; }
+  int positive = 1;
+  const int NP = 6;
+  for (int i = 2; i <= NP; ++i) {
+    c = c * (double)(NP - i + 1) / (double)(i * (2 * NP - i + 1));
+    gemm_rm(A, X, T2, n); memcpy(X, T2, sizeof(double) * nn);
+    for (size_t k = 0; k < nn; ++k) { Em[k] += c * X[k]; if (positive) Dm[k] += c * X[k]; else Dm[k] -= c * X[k]; }
+    positive = !positive;
+  }
+  /* solve D * out = E : Gaussian elimination, partial pivoting */
+  int err = 0;
+  for (int col = 0; col < n; ++col) {
+    int piv = col; double best = fabs(Dm[col * n + col]);
+    for (int r = col + 1; r < n; ++r) { double v = fabs(Dm[r * n + col]); if (v > best) { best = v; piv = r; } }
+    if (!(best > 0.0)) { err = ORC_ERR_BAD_INPUT; break; }
+    if (piv != col) for (int k = 0; k < n; ++k) {
+      double t = Dm[col * n + k]; Dm[col * n + k] = Dm[piv * n + k]; Dm[piv * n + k] = t;
+      t = Em[col * n + k]; Em[col * n + k] = Em[piv * n + k]; Em[piv * n + k] = t;
+    }
+    for (int r = col + 1; r < n; ++r) {
+      double f = Dm[r * n + col] / Dm[col * n + col];
+      for (int k = col; k < n; ++k) Dm[r * n + k] -= f * Dm[col * n + k];
+      for (int k = 0; k < n; ++k) Em[r * n + k] -= f * Em[col * n + k];
+    }
+  }
+  if (!err) {
+    for (int r = n - 1; r >= 0; --r)
+      for (int k = 0; k < n; ++k) {
+        double acc = Em[r * n + k];
+        for (int j = r + 1; j < n; ++j) acc -= Dm[r * n + j] * X[j * n + k];   /* X reused as the solution */
+        X[r * n + k] = acc / Dm[r * n + r];
+      }
+    for (int i = 0; i < s; ++i) { gemm_rm(X, X, T2, n); memcpy(X, T2, sizeof(double) * nn); }
+    memcpy(out, X, sizeof(double) * nn);
+  }
+  free(A);
+  return err;
+}
+
+/* sampleinternalnodesEXP :2910-2961 */
+static void sampleinternalnodesEXP(const int32_t* edge1, const int32_t* edge2, const int32_t* states, int T,
+                                   const double* PL, const double* pid, int root, const int32_t* nodelist, int nll,
+                                   const double* P, int n, int faithful_search, const int32_t* edge_of_child,
+                                   rngctx* rc, uint32_t iter, int32_t* rm, double* w) {
+  for (int i = 0; i < 2 * T - 1; ++i) rm[i] = 0;
+  for (int i = 0; i < T; ++i) rm[i] = states[i] - 1;                         /* :2923 */
+  double* p = w;
+  for (int c = 0; c < n; ++c) p[c] = pid[c] * PL[(size_t)(root - 1) * n + c];    /* :2926 */
+  rm[root - 1] = sample_cat(p, n, draw_u(rc, iter, ENT_NODE | (uint32_t)(root - 1), 0), &rc->err);
+  for (int i = 0; i < nll; ++i) {
+    int cn = nodelist[i] - 1;
+    int j = 0;
+    if (faithful_search) { while (edge2[j] != nodelist[i]) j++; }            /* :2947 */
+    else j = edge_of_child[cn];
+    int ps = rm[edge1[j] - 1];
+    const double* row = P + (size_t)j * n * n + (size_t)ps * n;
+    for (int c = 0; c < n; ++c) p[c] = row[c] * PL[(size_t)cn * n + c];      /* :2953 */
+    rm[cn] = sample_cat(p, n, draw_u(rc, iter, ENT_NODE | (uint32_t)cn, 0), &rc->err);
+  }
+  for (int i = 0; i < 2 * T - 1; ++i) rm[i] = rm[i] + 1;
+}
+
+/* dpois(k; lam) by the recurrence p_0 = exp(-lam), p_k = p_{k-1}*lam/k.  The reference calls R's
+ * Rf_dpois (saddle-point dpois_raw, src/phylomap.cpp:107,128) which is not under /root/reference;
+ * the two agree to a few ulp.  */
+
+/* newunifSample, src/phylomap.cpp:93-208.  Returns 1 when the 300-jump cap was hit (:120-125). */
+static int newunifSample(int startState, int endState, double elapsedTime, double transProb, Branch* out,
+                         double* stats, int64_t stride, int iteration, int n, double poissonRate,
+                         const double* B2, rngctx* rc, uint32_t branch_id, double* bpws, double* times, int32_t* dom) {
+  uint32_t dr = 0;
+  uint32_t ent = ENT_BUNIF | branch_id;
+  for (int i = 0; i < n; ++i) bpws[i] = 0.0;
+  bpws[endState] = 1.0;                                                      /* :100 */
+  double rU = draw_u(rc, (uint32_t)iteration, ent, dr++);                    /* :103 */
+  double lam = poissonRate * elapsedTime;
+  double pk = orc_exp(-lam);                                                 /* dpois(0) */
+  double cum = 0.0;
+  if (startState == endState) cum = pk / transProb;                          /* :107 */
+  int notExceed = !(cum > rU);
+  int numJumps = 0;
+  while (notExceed) {
+    numJumps++;
+    if (numJumps > 300) return 1;                                            /* :120 */
+    matvec(B2, bpws + (size_t)(numJumps - 1) * n, bpws + (size_t)numJumps * n, n);   /* :127 */
+    pk = pk * lam / (double)numJumps;
+    double nextProb = pk * bpws[(size_t)numJumps * n + startState] / transProb;      /* :128 */
+    cum += nextProb;
+    if (cum > rU) notExceed = 0;
+  }
+  out->m = 0;
+  if (numJumps == 0 || (numJumps == 1 && startState == endState)) {          /* :138 */
+    br_reserve(out, 1);
+    out->d[0] = elapsedTime - 0.0; out->s[0] = startState; out->m = 1;
+  } else if (numJumps == 1) {                                                /* :144 */
+    double tj = elapsedTime * draw_u(rc, (uint32_t)iteration, ent, dr++);    /* :147 */
+    br_reserve(out, 2);
+    out->d[0] = tj - 0.0; out->s[0] = startState;
+    out->d[1] = elapsedTime - tj; out->s[1] = endState; out->m = 2;
+  } else {
+    for (int i = 0; i < numJumps; ++i) times[i] = elapsedTime * draw_u(rc, (uint32_t)iteration, ent, dr++);   /* :151 */
+    for (int i = 1; i < numJumps; ++i) {                                     /* :152 ascending sort */
+      double v = times[i]; int j = i - 1;
+      while (j >= 0 && times[j] > v) { times[j + 1] = times[j]; --j; }
+      times[j + 1] = v;
+    }
+    dom[0] = startState; dom[numJumps] = endState;
+    double* p = bpws + (size_t)(numJumps + 1) * n;
+    for (int i = 1; i < numJumps; ++i) {                                     /* :158-160 */
+      const double* row = B2 + (size_t)dom[i - 1] * n;
+      const double* beta = bpws + (size_t)(numJumps - i) * n;
+      for (int c = 0; c < n; ++c) p[c] = row[c] * beta[c];
+      dom[i] = sampleOnce(p, n, draw_u(rc, (uint32_t)iteration, ent, dr++), &rc->err);
+    }
+    /* remove virtual substitutions :163-176, then durations = diff(times) :186-190 */
+    br_reserve(out, numJumps + 1);
+    double tprev = 0.0; int sprev = startState;
+    for (int i = 1; i <= numJumps; ++i) {
+      if (dom[i - 1] != dom[i]) {
+        out->d[out->m] = times[i - 1] - tprev; out->s[out->m] = sprev; out->m++;
+        tprev = times[i - 1]; sprev = dom[i];
+      }
+    }
+    out->d[out->m] = elapsedTime - tprev; out->s[out->m] = sprev; out->m++;
+  }
+  for (int i = 1; i < out->m; ++i) {                                         /* :194-204 */
+    int a = out->s[i - 1], b = out->s[i];
+    if (a < b) stats[(int64_t)(n + a * (n - 1) + b - 1) * stride + iteration] += 1.0;
+    if (a > b) stats[(int64_t)(n + a * (n - 1) + b) * stride + iteration] += 1.0;
+  }
+  return 0;
+}
+
+/* maketreelistEXP :3001-3051 with treesampleEXP :2977-2996 */
+int orc_maketreelistEXP(const orc_tree* x, int n, const double* Q_cm, const double* pid,
+                        const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
+                        const double* lefts_cm, const double* rights_cm, const double* d_cm,
+                        int faithful_search, int recompute_expm_each_iter,
+                        orc_rng* rng, double* out, orc_dump* dump) {
+  int e = check_tree(x); if (e) return e;
+  if (n < 2 || N < 0 || !x->edge_length) return ORC_ERR_BAD_INPUT;
+  int E = x->n_edge, T = x->n_tips, Nnode = x->n_node;
+  const int32_t* edge1 = x->edge; const int32_t* edge2 = x->edge + E;
+  int cols = n + n * (n - 1);
+  size_t nn = (size_t)n * n;
+  rngctx rc = { rng, 0 };
+
+  double* L = (double*)malloc(sizeof(double) * nn * 3);
+  double *R = L + nn, *B2 = L + 2 * nn;
+  double* dv = (double*)malloc(sizeof(double) * n);
+  double minq = Q_cm[0];
+  for (int i = 0; i < n; ++i) { double q = Q_cm[i + (size_t)i * n]; if (q < minq) minq = q; dv[i] = d_cm[i + (size_t)i * n]; }
+  double poissonRate = -1.0 * minq;                                          /* :3008 */
+  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) {
+    L[i * n + j] = lefts_cm[i + (size_t)j * n]; R[i * n + j] = rights_cm[i + (size_t)j * n];
+    B2[i * n + j] = ((i == j) ? 1.0 : 0.0) + Q_cm[i + (size_t)j * n] / poissonRate;   /* :3011 */
+  }
+  Branch* brs = (Branch*)calloc(E, sizeof(Branch));
+  for (int i = 0; i < E; ++i) {
+    int o = x->map_off[i], m = x->map_off[i + 1] - o;
+    if (m < 1) { e = ORC_ERR_BAD_INPUT; m = 0; }
+    makeabranch(&brs[i], x->maps + o, x->mapnames + o, m);
+  }
+  double* P = (double*)malloc(sizeof(double) * nn * E);
+  for (int i = 0; i < E; ++i) orc_matexp(L, R, dv, n, x->edge_length[i], P + nn * i);   /* :3042 */
+  size_t pl_len = (size_t)(2 * Nnode + 1) * n;
+  double* PL = (double*)calloc(pl_len, sizeof(double));
+  for (int i = 0; i < T; ++i) PL[(size_t)i * n + (x->states[i] - 1)] = 1.0;
+  double* w = (double*)malloc(sizeof(double) * 2 * n);
+  makePLexp(edge1, edge2, Nnode, PL, nen, P, n, w);                          /* :3043 */
+  int32_t* rm = (int32_t*)calloc(2 * T - 1, sizeof(int32_t));
+  int32_t* eoc = (int32_t*)calloc(2 * T - 1, sizeof(int32_t));
+  for (int i = 0; i < E; ++i) eoc[edge2[i] - 1] = i;
+  double* bpws = (double*)malloc(sizeof(double) * n * 303);
+  double* times = (double*)malloc(sizeof(double) * 301);
+  int32_t* dom = (int32_t*)malloc(sizeof(int32_t) * 302);
+  Branch tmp = { NULL, NULL, 0, 0 };
+  memset(out, 0, sizeof(double) * (size_t)N * cols);
+
+  if (!e) for (int it = 0; it < N; ++it) {
+    if (recompute_expm_each_iter) {                                          /* :2980-2981 (Q never changes) */
+      for (int i = 0; i < E; ++i) orc_matexp(L, R, dv, n, x->edge_length[i], P + nn * i);
+      makePLexp(edge1, edge2, Nnode, PL, nen, P, n, w);
+    }
+    sampleinternalnodesEXP(edge1, edge2, x->states, T, PL, pid, root, nodelist, Nnode - 1, P, n,
+                           faithful_search, eoc, &rc, (uint32_t)it, rm, w);
+    updatenodestates(brs, edge1, edge2, E, rm);                              /* :2983 */
+    for (int i = 0; i < E; ++i) {                                            /* :2988-2993 */
+      int a = rm[edge1[i] - 1] - 1, b = rm[edge2[i] - 1] - 1;
+      int capped = newunifSample(a, b, x->edge_length[i], P[nn * i + (size_t)a * n + b], &tmp, out, N, it, n,
+                                 poissonRate, B2, &rc, (uint32_t)i, bpws, times, dom);
+      if (capped) rc.err |= ORC_ERR_UNIF_CAP;    /* reference keeps the stale branch and carries on */
+      else {
+        br_reserve(&brs[i], tmp.m);
+        memcpy(brs[i].d, tmp.d, sizeof(double) * tmp.m); memcpy(brs[i].s, tmp.s, sizeof(int32_t) * tmp.m);
+        brs[i].m = tmp.m;
+      }
+      updatedwelltimes(it, &brs[i], out, N);
+    }
+  }
+  fill_dump(dump, brs, E, rm, 2 * T - 1, PL, pl_len);
+  for (int i = 0; i < E; ++i) { free(brs[i].d); free(brs[i].s); }
+  free(tmp.d); free(tmp.s); free(dom); free(times); free(bpws); free(eoc); free(rm); free(w); free(PL); free(P);
+  free(brs); free(dv); free(L);
+  return e | rc.err;
+}
