@@ -1,0 +1,22 @@
+# Builds the HIP library (C-ABI: include/phylomap_hip.h) and the CPU oracle.
+# -ffp-contract=off is part of the arithmetic spec (no fused multiply-add on either side).
+HIPCC   ?= /opt/rocm/bin/hipcc
+ARCH    ?= gfx950
+CSRC    := phylomap_amd/csrc
+LIB     := phylomap_amd/libphylomap_hip.so
+SRCS    := $(CSRC)/phm_api.cpp $(CSRC)/phm_sched.cpp $(CSRC)/phm_mcmc.hip $(CSRC)/phm_exp.hip
+HDRS    := $(wildcard $(CSRC)/*.h) include/phylomap_hip.h
+FLAGS   := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function
+
+all: $(LIB) oracle
+
+$(LIB): $(SRCS) $(HDRS)
+	$(HIPCC) $(FLAGS) -x hip -shared -o $@ $(SRCS)
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -f $(LIB); $(MAKE) -C oracle clean
+
+.PHONY: all oracle clean

@@ -1,0 +1,160 @@
+/*
+ * phylomap_hip.h -- C-ABI of the MI355X-native stochastic-mapping engine.
+ *
+ * This is the drop-in boundary for the hot path of vnminin/phylomap: the `.Call` layer
+ * (src/RcppExports.cpp:9-259, R/RcppExports.R:4-50) binds `phylomap_maketreelist*`; an Rcpp shim
+ *  unpacks the SEXPs into the plain structs below and calls the `phm_maketreelist*`
+ * entry points, which replace the C++ drivers of src/phylomap.cpp one for one.
+ *
+ * Conventions
+ *  - plain C: pointers + sizes, no C++/R/torch types;
+ *  - all inputs are HOST buffers owned by the caller, read-only (the reference aliases and, in the
+ *    Q-updating variants, mutates R's memory -- src/phylomap.cpp:917,1212-1217; this library copies);
+ *  - matrices follow R's layout (COLUMN-major): Q, B, lefts, rights, d, edge, and the result;
+ *  - every call returns a phm_status; phm_last_error() gives a thread-local message
+ *    (the reference throws through BEGIN_RCPP/END_RCPP, src/RcppExports.cpp:35,53);
+ *  - randomness: Philox4x32-10 keyed by phm_options.seed, counter (block, entity, iteration,
+ *    replica); the Rcpp shim draws the seed from R's stream inside its RNGScope
+ *    (src/RcppExports.cpp:38) so set.seed() still controls results;
+ *  - there is NO CPU fallback: without a usable HIP device every compute call returns
+ *    PHM_ERR_NO_DEVICE.
+ */
+#ifndef PHYLOMAP_HIP_H
+#define PHYLOMAP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PHM_VERSION 100
+
+typedef enum phm_status {
+  PHM_OK = 0,
+  PHM_ERR_BAD_INPUT = 1,      /* malformed tree / model / sizes (reference: no validation at all) */
+  PHM_ERR_UNSUPPORTED = 2,    /* e.g. a state count this build has no kernel for */
+  PHM_ERR_NO_DEVICE = 3,      /* no HIP device, or a HIP call failed */
+  PHM_ERR_OOM = 4,            /* device memory */
+  PHM_ERR_ZERO_PROB = 5,      /* all-zero / non-finite probability vector (RcppArmadillo::sample throws) */
+  PHM_ERR_CAPACITY = 6,       /* a branch outgrew its slot capacity (std::list in the reference is unbounded) */
+  PHM_ERR_UNIF_CAP = 7,       /* newunifSample needed > 300 jumps (src/phylomap.cpp:120-125) */
+  PHM_ERR_STATE = 8           /* API misuse (engine not created, iteration range, ...) */
+} phm_status;
+
+/* which exported driver of src/phylomap.cpp the engine stands in for */
+typedef enum phm_variant {
+  PHM_MCMC = 0,               /* maketreelistMCMC          src/phylomap.cpp:891-935  */
+  PHM_MCMC_BIGTREE = 1,       /* maketreelistMCMC_bigtree  src/phylomap.cpp:942-986  (row-normalised PL, :525) */
+  PHM_MCMC_SPARSE = 2         /* SPARSEmaketreelistMCMC    src/phylomap.cpp:822-870  (B entries <= 1e-7 dropped, :811) */
+} phm_variant;
+
+/* The phylomap tree object `x` (fields read at src/phylomap.cpp:896-910 and :3034). */
+typedef struct phm_tree {
+  int32_t n_tips;              /* length(x$states) */
+  int32_t n_node;              /* x$Nnode (= n_tips-1: strictly bifurcating, :508-510) */
+  int32_t n_edge;              /* nrow(x$edge) */
+  const int32_t* edge;         /* n_edge x 2 column-major, 1-based (parent, child); tips are 1..n_tips (:904) */
+  const double*  edge_length;  /* x$edge.length (:3034); EXP only, may be NULL for MCMC */
+  const int32_t* states;       /* x$states, 1-based (:910); n_tips values, or n_replicas*n_tips when
+                                  phm_options.tips_per_replica != 0 (replica-major) */
+  const int32_t* map_off;      /* n_edge+1 offsets into maps/mapnames */
+  const double*  maps;         /* x$maps flattened: dwell times per segment (:896) */
+  const int32_t* mapnames;     /* x$mapnames flattened: 1-based states (:897, :29) */
+} phm_tree;
+
+typedef struct phm_model {
+  int32_t n_states;            /* n = nrow(Q) */
+  const double* Q;             /* n x n rate matrix, column-major */
+  const double* pid;           /* n root prior */
+  const double* B;             /* n x n, I + Q/Omega (R/sumstatMCMC.R:25), column-major; NULL -> computed */
+  double Omega;                /* dominating rate; must exceed every |q_ii| (man/sumstatMCMC.Rd:14) */
+  int32_t variant;             /* phm_variant */
+} phm_model;
+
+typedef struct phm_options {
+  uint64_t seed;               /* Philox key */
+  int32_t n_replicas;          /* S: independent chains / sites run side by side (>=1; 0 -> 1) */
+  int32_t replica_offset;      /* global id of this device's first replica (multi-GPU sharding) */
+  int32_t reduce;              /* 0: statistics per replica; 1: summed over replicas per iteration */
+  int32_t tips_per_replica;    /* 0: all replicas share x$states; 1: one tip vector per replica (sites) */
+  int32_t device;              /* HIP device ordinal; -1 = current device */
+  int32_t iters_per_launch;    /* MCMC iterations fused into one kernel launch; 0 -> default */
+  double  cap_tail;            /* per-branch capacity = Poisson(Omega*t_b) quantile at this tail; 0 -> 1e-16 */
+  int32_t reserved[6];
+} phm_options;
+
+typedef struct phm_info {
+  int32_t n_states, n_edge, n_replicas, n_replicas_padded, n_cols, max_iters;
+  int64_t device_bytes;        /* HBM held by the engine */
+  int64_t rows_per_replica;    /* sum of per-branch slot capacities */
+  int64_t seg_read, seg_written; /* sum over branches x replicas x iterations of m_b and m'_b */
+  double  last_run_ms;         /* HIP-event time of the last phm_engine_run (all its launches) */
+  int32_t last_run_launches;
+  int32_t iters_done;
+} phm_info;
+
+typedef struct phm_engine phm_engine;
+
+/* ---- library ---- */
+int32_t     phm_version(void);
+int32_t     phm_device_count(void);
+const char* phm_last_error(void);
+const char* phm_status_string(int32_t status);
+
+/* ---- reference-shaped one-shot entry points (what the Rcpp shim binds) ----
+ * Each mirrors the argument list of the exported C++ driver it replaces; `out` is the caller-allocated
+ * N x (n + n(n-1)) column-major result (allocMatrix(REALSXP, N, cols) in the shim).  With
+ * opt->n_replicas = S > 1 and reduce = 0, `out` holds S such matrices back to back.
+ * nen / nodelist / root (R/sumstatMCMC.R:1-18) are checked for consistency with `x->edge`
+ * and otherwise unused: the engine derives its own O(E) sweep schedules. */
+int32_t phm_maketreelistMCMC(         /* src/phylomap.cpp:891, src/RcppExports.cpp:34 */
+    const phm_tree* x, int32_t n_states, const double* Q, const double* pid, const double* B, double Omega,
+    const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
+    const phm_options* opt, double* out);
+int32_t phm_maketreelistMCMC_bigtree( /* src/phylomap.cpp:942, src/RcppExports.cpp:57 */
+    const phm_tree* x, int32_t n_states, const double* Q, const double* pid, const double* B, double Omega,
+    const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
+    const phm_options* opt, double* out);
+int32_t phm_SPARSEmaketreelistMCMC(   /* src/phylomap.cpp:822, src/RcppExports.cpp:11 */
+    const phm_tree* x, int32_t n_states, const double* Q, const double* pid, const double* B, double Omega,
+    const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
+    const phm_options* opt, double* out);
+int32_t phm_maketreelistEXP(          /* src/phylomap.cpp:3001, src/RcppExports.cpp:80 */
+    const phm_tree* x, int32_t n_states, const double* Q, const double* pid,
+    const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
+    const double* lefts, const double* rights, const double* d,
+    const phm_options* opt, double* out);
+
+/* ---- batched transition matrices (K1 / K1') ----
+ * phm_expm_eigen: P_b = |L diag(exp(d_i t_b)) R|  (matexp, src/phylomap.cpp:2964-2968 + abs at :2980,:3042)
+ * phm_expm_pade : P_b = expmat(Q t_b), Pade(6) scaling-and-squaring (arma::expmat call sites :3226,:3243,:3359,:3383)
+ * out: n_t matrices, each n x n ROW-major (out[b*n*n + i*n + j]). */
+int32_t phm_expm_eigen(int32_t n_states, const double* lefts, const double* rights, const double* d,
+                       const double* t, int32_t n_t, int32_t device, double* out, double* kernel_ms);
+int32_t phm_expm_pade(int32_t n_states, const double* Q, const double* t, int32_t n_t, int32_t device,
+                      double* out, double* kernel_ms);
+
+/* ---- resident engine (inputs stay in HBM between calls; what bench.py times) ---- */
+int32_t phm_engine_create(const phm_tree* x, const phm_model* model, const phm_options* opt,
+                          int32_t max_iters, phm_engine** out);
+/* enqueue iterations [iters_done, iters_done + n_iters) on `hip_stream` (a hipStream_t, NULL = default
+ * stream); asynchronous */
+int32_t phm_engine_run(phm_engine* e, int32_t n_iters, void* hip_stream);
+/* wait for the stream, collect the device error word, fill timing */
+int32_t phm_engine_sync(phm_engine* e);
+/* copy statistics of iterations [iter0, iter0+n) to host.
+ * reduce = 0: out[r][ (col)*n + (i-iter0) ] for replica r (n x cols column-major per replica)
+ * reduce = 1: one n x cols column-major matrix (sum over replicas) */
+int32_t phm_engine_read_stats(phm_engine* e, int32_t iter0, int32_t n, double* out);
+/* chain state of one replica after the last iteration (tests): any pointer may be NULL.
+ * seg_dwell: n_edge * seg_cap; node_states: 2*n_tips-1, 1-based; PL: (2*n_tips-1) x n row-major */
+int32_t phm_engine_dump(phm_engine* e, int32_t replica, int32_t* seg_count, double* seg_dwell, int32_t seg_cap,
+                        int32_t* node_states, double* PL);
+int32_t phm_engine_info(phm_engine* e, phm_info* info);
+void    phm_engine_destroy(phm_engine* e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

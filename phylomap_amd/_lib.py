@@ -1,0 +1,203 @@
+"""ctypes binding of the C-ABI (include/phylomap_hip.h).  The library is built in-tree by
+``__graft_entry__.build()`` / ``make``; there is no fallback when it is missing."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libphylomap_hip.so")
+
+PHM_OK = 0
+STATUS = {0: "PHM_OK", 1: "PHM_ERR_BAD_INPUT", 2: "PHM_ERR_UNSUPPORTED", 3: "PHM_ERR_NO_DEVICE", 4: "PHM_ERR_OOM",
+          5: "PHM_ERR_ZERO_PROB", 6: "PHM_ERR_CAPACITY", 7: "PHM_ERR_UNIF_CAP", 8: "PHM_ERR_STATE"}
+PHM_MCMC, PHM_MCMC_BIGTREE, PHM_MCMC_SPARSE = 0, 1, 2
+
+EXPORTS = [
+    "phm_version", "phm_device_count", "phm_last_error", "phm_status_string",
+    "phm_maketreelistMCMC", "phm_maketreelistMCMC_bigtree", "phm_SPARSEmaketreelistMCMC", "phm_maketreelistEXP",
+    "phm_expm_eigen", "phm_expm_pade",
+    "phm_engine_create", "phm_engine_run", "phm_engine_sync", "phm_engine_read_stats", "phm_engine_dump",
+    "phm_engine_info", "phm_engine_destroy",
+]
+
+
+class PhmError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"{STATUS.get(status, status)}: {message}")
+        self.status = status
+
+
+class Tree(C.Structure):
+    _fields_ = [("n_tips", C.c_int32), ("n_node", C.c_int32), ("n_edge", C.c_int32),
+                ("edge", C.POINTER(C.c_int32)), ("edge_length", C.POINTER(C.c_double)),
+                ("states", C.POINTER(C.c_int32)), ("map_off", C.POINTER(C.c_int32)),
+                ("maps", C.POINTER(C.c_double)), ("mapnames", C.POINTER(C.c_int32))]
+
+
+class Model(C.Structure):
+    _fields_ = [("n_states", C.c_int32), ("Q", C.POINTER(C.c_double)), ("pid", C.POINTER(C.c_double)),
+                ("B", C.POINTER(C.c_double)), ("Omega", C.c_double), ("variant", C.c_int32)]
+
+
+class Options(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("n_replicas", C.c_int32), ("replica_offset", C.c_int32),
+                ("reduce", C.c_int32), ("tips_per_replica", C.c_int32), ("device", C.c_int32),
+                ("iters_per_launch", C.c_int32), ("cap_tail", C.c_double), ("reserved", C.c_int32 * 6)]
+
+
+class Info(C.Structure):
+    _fields_ = [("n_states", C.c_int32), ("n_edge", C.c_int32), ("n_replicas", C.c_int32),
+                ("n_replicas_padded", C.c_int32), ("n_cols", C.c_int32), ("max_iters", C.c_int32),
+                ("device_bytes", C.c_int64), ("rows_per_replica", C.c_int64), ("seg_read", C.c_int64),
+                ("seg_written", C.c_int64), ("last_run_ms", C.c_double), ("last_run_launches", C.c_int32),
+                ("iters_done", C.c_int32)]
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+
+_lib = None
+
+
+def load():
+    """Load libphylomap_hip.so; raises if it has not been built (no CPU fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "or `make`; phylomap_amd has no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.phm_last_error.restype = C.c_char_p
+        L.phm_status_string.restype = C.c_char_p
+        L.phm_status_string.argtypes = [C.c_int32]
+        L.phm_engine_create.argtypes = [C.POINTER(Tree), C.POINTER(Model), C.POINTER(Options), C.c_int32,
+                                        C.POINTER(C.c_void_p)]
+        L.phm_engine_run.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        L.phm_engine_sync.argtypes = [C.c_void_p]
+        L.phm_engine_read_stats.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
+        L.phm_engine_dump.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_int32,
+                                      C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+        L.phm_engine_info.argtypes = [C.c_void_p, C.POINTER(Info)]
+        L.phm_engine_destroy.argtypes = [C.c_void_p]
+        L.phm_engine_destroy.restype = None
+        mc = [C.POINTER(Tree), C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+              C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.POINTER(Options),
+              C.POINTER(C.c_double)]
+        L.phm_maketreelistMCMC.argtypes = mc
+        L.phm_maketreelistMCMC_bigtree.argtypes = mc
+        L.phm_SPARSEmaketreelistMCMC.argtypes = mc
+        L.phm_maketreelistEXP.argtypes = [C.POINTER(Tree), C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                          C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, C.c_int32,
+                                          C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                          C.POINTER(Options), C.POINTER(C.c_double)]
+        L.phm_expm_eigen.argtypes = [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                     C.POINTER(C.c_double), C.c_int32, C.c_int32, C.POINTER(C.c_double),
+                                     C.POINTER(C.c_double)]
+        L.phm_expm_pade.argtypes = [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32, C.c_int32,
+                                    C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        _lib = L
+    return _lib
+
+
+def check(status):
+    if status != PHM_OK:
+        raise PhmError(status, load().phm_last_error().decode())
+
+
+class FlatTree:
+    """Flattens the R-list-shaped tree object ``z`` into the plain arrays of ``phm_tree`` (and keeps them alive)."""
+
+    def __init__(self, z, states=None):
+        edge = np.asarray(z["edge"], dtype=np.int32)
+        if edge.ndim != 2 or edge.shape[1] != 2:
+            raise ValueError("z['edge'] must be E x 2")
+        self.E = edge.shape[0]
+        st = z["states"] if states is None else states
+        self.states = np.ascontiguousarray(np.asarray(st).round(), dtype=np.int32)   # R may hand doubles (:910)
+        self.T = int(np.asarray(z["states"]).shape[-1])
+        self.edge = np.asfortranarray(edge).reshape(-1, order="F").copy()
+        el = z.get("edge.length")
+        self.edge_length = None if el is None else np.ascontiguousarray(el, dtype=np.float64)
+        lens = [len(m) for m in z["maps"]]
+        self.map_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        self.maps = np.ascontiguousarray(np.concatenate([np.asarray(m, dtype=np.float64) for m in z["maps"]]))
+        self.mapnames = np.ascontiguousarray(np.concatenate([np.asarray(m) for m in z["mapnames"]]), dtype=np.int32)
+        self.c = Tree(self.T, int(z["Nnode"]), self.E, _p(self.edge, C.c_int32), _p(self.edge_length, C.c_double),
+                      _p(self.states.reshape(-1), C.c_int32), _p(self.map_off, C.c_int32), _p(self.maps, C.c_double),
+                      _p(self.mapnames, C.c_int32))
+
+
+def make_options(seed=0, n_replicas=1, replica_offset=0, reduce=False, tips_per_replica=False, device=-1,
+                 iters_per_launch=0, cap_tail=0.0):
+    o = Options()
+    o.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    o.n_replicas, o.replica_offset, o.reduce = int(n_replicas), int(replica_offset), int(bool(reduce))
+    o.tips_per_replica, o.device, o.iters_per_launch, o.cap_tail = int(bool(tips_per_replica)), int(device), int(iters_per_launch), float(cap_tail)
+    return o
+
+
+class Engine:
+    """Resident engine: tree, model and chain state stay in HBM between run() calls."""
+
+    def __init__(self, z, Q, pid, Omega, max_iters, variant=PHM_MCMC, B=None, states=None, **opt):
+        L = load()
+        self.Q = np.asfortranarray(np.asarray(Q, dtype=np.float64))
+        self.n = self.Q.shape[0]
+        self.pid = np.ascontiguousarray(pid, dtype=np.float64)
+        self.B = None if B is None else np.asfortranarray(np.asarray(B, dtype=np.float64))
+        self.ft = FlatTree(z, states)
+        self.opt = make_options(**opt)
+        self.model = Model(self.n, _p(self.Q, C.c_double), _p(self.pid, C.c_double), _p(self.B, C.c_double),
+                           float(Omega), int(variant))
+        self.h = C.c_void_p()
+        check(L.phm_engine_create(C.byref(self.ft.c), C.byref(self.model), C.byref(self.opt), int(max_iters),
+                                  C.byref(self.h)))
+        self.cols = self.n + self.n * (self.n - 1)
+        self.S = max(1, int(self.opt.n_replicas))
+        self.reduce = bool(self.opt.reduce)
+
+    def run(self, n_iters, stream=None):
+        check(load().phm_engine_run(self.h, int(n_iters), C.c_void_p(stream) if stream else None))
+
+    def sync(self):
+        check(load().phm_engine_sync(self.h))
+
+    def info(self):
+        i = Info()
+        check(load().phm_engine_info(self.h, C.byref(i)))
+        return i
+
+    def stats(self, iter0, n):
+        """reduce: (n, cols); else (S, n, cols).  Memory is R's column-major per matrix."""
+        if self.reduce:
+            out = np.zeros((n, self.cols), order="F")
+            check(load().phm_engine_read_stats(self.h, int(iter0), int(n), _p(out, C.c_double)))
+            return out
+        buf = np.zeros((self.S, self.cols, n))
+        check(load().phm_engine_read_stats(self.h, int(iter0), int(n), _p(buf, C.c_double)))
+        return buf.transpose(0, 2, 1)
+
+    def dump(self, replica=0, seg_cap=512):
+        E, T, n = self.ft.E, self.ft.T, self.n
+        seg_count = np.zeros(E, dtype=np.int32)
+        seg_dwell = np.zeros((E, seg_cap))
+        node_states = np.zeros(2 * T - 1, dtype=np.int32)
+        PL = np.zeros((2 * T - 1, n))
+        check(load().phm_engine_dump(self.h, int(replica), _p(seg_count, C.c_int32), _p(seg_dwell, C.c_double),
+                                     int(seg_cap), _p(node_states, C.c_int32), _p(PL, C.c_double)))
+        return {"seg_count": seg_count, "seg_dwell": seg_dwell, "node_states": node_states, "PL": PL}
+
+    def close(self):
+        if self.h:
+            load().phm_engine_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

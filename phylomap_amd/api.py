@@ -1,0 +1,114 @@
+"""R-level API of phylomap, mirrored in Python (the reference's R toolchain is not available here).
+
+Same names, argument order and meaning as the R wrappers: ``sumstatMCMC(z,Q,pid,Omega,N)``
+(R/sumstatMCMC.R:21-29), ``sumstatMCMC_bigtree`` (R/sumstatMCMC_bigtree.R), ``SPARSEsumstatMCMC``
+(R/SPARSEsumstatMCMC.R:21-29) and ``sumstatEXP(z,Q,pid,N)`` (R/sumstatEXP.R:21-33).  Each computes the
+derived arguments exactly where the R wrapper does (``nen``, ``nodelist``, ``root``, ``B``; EXP:
+``eigen``/``solve``) and then calls the C-ABI entry point that replaces the corresponding ``.Call``
+(R/RcppExports.R:4-22).  Returns the N x (n + n(n-1)) matrix of man/sumstatMCMC.Rd:18.
+
+Extra keyword arguments (``seed``, ``n_replicas``, ...) map onto ``phm_options``; with the defaults a
+call is a drop-in for the R function (one chain, one tip vector).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .treeorder import makenodelist, myreorder, pruningwiseedgeorder
+
+
+def _mcmc(fn_name, z, Q, pid, Omega, N, **opt):
+    L = _lib.load()
+    Q = np.asfortranarray(np.asarray(Q, dtype=np.float64))
+    n = Q.shape[0]
+    nen = np.ascontiguousarray(pruningwiseedgeorder(z), dtype=np.int32)      # R/sumstatMCMC.R:22
+    nodelist = np.ascontiguousarray(makenodelist(z), dtype=np.int32)          # :23
+    root = int(myreorder(z))                                                  # :24
+    B = np.asfortranarray(np.eye(n) + Q / Omega)                              # :25
+    pid = np.ascontiguousarray(pid, dtype=np.float64)
+    ft = _lib.FlatTree(z)
+    o = _lib.make_options(**opt)
+    S = max(1, int(o.n_replicas))
+    cols = n + n * (n - 1)
+    single = bool(o.reduce) or S == 1
+    out = np.zeros((N, cols), order="F") if single else np.zeros((S, cols, N))
+    st = getattr(L, fn_name)(C.byref(ft.c), n, _lib._p(Q, C.c_double), _lib._p(pid, C.c_double),
+                             _lib._p(B, C.c_double), float(Omega), _lib._p(nen, C.c_int32),
+                             _lib._p(nodelist, C.c_int32), root, int(N), C.byref(o), _lib._p(out, C.c_double))
+    _lib.check(st)
+    return out if single else out.transpose(0, 2, 1)
+
+
+def sumstatMCMC(z, Q, pid, Omega, N, **opt):
+    """R/sumstatMCMC.R:21-29 -> phm_maketreelistMCMC."""
+    return _mcmc("phm_maketreelistMCMC", z, Q, pid, Omega, N, **opt)
+
+
+def sumstatMCMC_bigtree(z, Q, pid, Omega, N, **opt):
+    """R/sumstatMCMC_bigtree.R -> phm_maketreelistMCMC_bigtree (row-normalised partial likelihoods)."""
+    return _mcmc("phm_maketreelistMCMC_bigtree", z, Q, pid, Omega, N, **opt)
+
+
+def SPARSEsumstatMCMC(z, Q, pid, Omega, N, **opt):
+    """R/SPARSEsumstatMCMC.R:21-29 -> phm_SPARSEmaketreelistMCMC."""
+    return _mcmc("phm_SPARSEmaketreelistMCMC", z, Q, pid, Omega, N, **opt)
+
+
+def eigen_decompose(Q):
+    """R/sumstatEXP.R:26-29: lefts = eigen(Q)$vectors, rights = solve(lefts), d = diag(values) (real spectrum only)."""
+    vals, vecs = np.linalg.eig(np.asarray(Q, dtype=np.float64))
+    if np.max(np.abs(np.imag(vals))) > 0:
+        raise ValueError("Q has complex eigenvalues; the reference's matexp handles a real spectrum only")
+    lefts = np.real(vecs)
+    rights = np.linalg.solve(lefts, np.eye(lefts.shape[0]))
+    return lefts, rights, np.diag(np.real(vals))
+
+
+def sumstatEXP(z, Q, pid, N, **opt):
+    """R/sumstatEXP.R:21-33 -> phm_maketreelistEXP."""
+    L = _lib.load()
+    Q = np.asfortranarray(np.asarray(Q, dtype=np.float64))
+    n = Q.shape[0]
+    nen = np.ascontiguousarray(pruningwiseedgeorder(z), dtype=np.int32)
+    nodelist = np.ascontiguousarray(makenodelist(z), dtype=np.int32)
+    root = int(myreorder(z))
+    lefts, rights, d = (np.asfortranarray(a) for a in eigen_decompose(Q))
+    pid = np.ascontiguousarray(pid, dtype=np.float64)
+    ft = _lib.FlatTree(z)
+    o = _lib.make_options(**opt)
+    out = np.zeros((N, n + n * (n - 1)), order="F")
+    st = L.phm_maketreelistEXP(C.byref(ft.c), n, _lib._p(Q, C.c_double), _lib._p(pid, C.c_double),
+                               _lib._p(nen, C.c_int32), _lib._p(nodelist, C.c_int32), root, int(N),
+                               _lib._p(lefts, C.c_double), _lib._p(rights, C.c_double), _lib._p(d, C.c_double),
+                               C.byref(o), _lib._p(out, C.c_double))
+    _lib.check(st)
+    return out
+
+
+def expm_eigen(lefts, rights, d, t, device=-1):
+    """Batched P_b = |L diag(exp(d t_b)) R| (matexp, src/phylomap.cpp:2964-2968). Returns (P[n_t,n,n], kernel_ms)."""
+    L = _lib.load()
+    lefts, rights, d = (np.asfortranarray(np.asarray(a, dtype=np.float64)) for a in (lefts, rights, d))
+    t = np.ascontiguousarray(t, dtype=np.float64)
+    n = lefts.shape[0]
+    out = np.zeros((t.size, n, n))
+    ms = C.c_double(0.0)
+    _lib.check(L.phm_expm_eigen(n, _lib._p(lefts, C.c_double), _lib._p(rights, C.c_double), _lib._p(d, C.c_double),
+                                _lib._p(t, C.c_double), int(t.size), int(device), _lib._p(out, C.c_double), C.byref(ms)))
+    return out, ms.value
+
+
+def expm_pade(Q, t, device=-1):
+    """Batched expmat(Q t_b), Pade(6) scaling-and-squaring. Returns (P[n_t,n,n], kernel_ms)."""
+    L = _lib.load()
+    Q = np.asfortranarray(np.asarray(Q, dtype=np.float64))
+    t = np.ascontiguousarray(t, dtype=np.float64)
+    n = Q.shape[0]
+    out = np.zeros((t.size, n, n))
+    ms = C.c_double(0.0)
+    _lib.check(L.phm_expm_pade(n, _lib._p(Q, C.c_double), _lib._p(t, C.c_double), int(t.size), int(device),
+                               _lib._p(out, C.c_double), C.byref(ms)))
+    return out, ms.value

@@ -1,0 +1,668 @@
+// phm_api.cpp -- C-ABI of the engine (include/phylomap_hip.h): input validation, HBM layout, launches.
+//
+// Host-side counterpart of the exported drivers maketreelistMCMC / _bigtree / SPARSE
+// (src/phylomap.cpp:891-986, 822-870): unpack `x`, set up B, allocate the statistics matrix, run N sweeps.
+// Built with -ffp-contract=off: the B^k chain tables computed here must carry exactly the bits the
+// kernels (and the oracle) would produce by running the chains themselves.
+#include "../../include/phylomap_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "phm_exp.h"
+#include "phm_mcmc.h"
+#include "phm_sched.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int32_t fail(int32_t st, const std::string& msg) { g_err = msg; return st; }
+
+#define HIPCHK(call)                                                                              \
+  do {                                                                                            \
+    hipError_t _e = (call);                                                                       \
+    if (_e != hipSuccess) {                                                                       \
+      int32_t _st = (_e == hipErrorOutOfMemory) ? PHM_ERR_OOM : PHM_ERR_NO_DEVICE;                \
+      return fail(_st, std::string(#call) + ": " + hipGetErrorString(_e));                        \
+    }                                                                                             \
+  } while (0)
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t n) { bytes = n; return hipMalloc(&p, n ? n : 16); }
+  template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+int32_t select_device(int32_t device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(PHM_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+  if (device >= 0) {
+    if (device >= n) return fail(PHM_ERR_NO_DEVICE, "device ordinal out of range");
+    HIPCHK(hipSetDevice(device));
+  }
+  return PHM_OK;
+}
+
+int32_t device_status(uint32_t derr) {
+  if (derr & phm::DERR_ZERO_PROB) return fail(PHM_ERR_ZERO_PROB, "all-zero or non-finite probability vector while sampling a state (RcppArmadillo::sample would throw)");
+  if (derr & phm::DERR_CAPACITY) return fail(PHM_ERR_CAPACITY, "a branch outgrew its slot capacity; lower phm_options.cap_tail");
+  if (derr & phm::DERR_UNIF_CAP) return fail(PHM_ERR_UNIF_CAP, "newunifSample needed more than 300 jumps on a branch (src/phylomap.cpp:120)");
+  if (derr & phm::DERR_SAMPLEONCE) return fail(PHM_ERR_ZERO_PROB, "sampleOnce ran past the last state (src/phylomap.cpp:85-89)");
+  return PHM_OK;
+}
+
+}  // namespace
+
+// -------------------------------------------------------------------------------------------------
+struct phm_engine {
+  int n = 0, cols = 0, variant = 0;
+  int S = 0, S_pad = 0, tiles = 0, max_iters = 0, iters_done = 0, ipl = 0;
+  int reduce = 0, device = 0;
+  phm::Schedule sched;
+  std::vector<uint8_t> tips_host;      // 0-based, [n_tips] or [S][n_tips]
+  bool tips_per_replica = false;
+  int64_t rows = 0;
+  DevBuf d_up, d_down, d_col, d_row, d_tips, d_mcount, d_dw0, d_dw1, d_PL, d_nstate, d_stats, d_err, d_seg, d_red;
+  phm::McmcParams<2> p2;
+  phm::McmcParams<3> p3;
+  phm::McmcParams<4> p4;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipStream_t last_stream = nullptr;
+  bool timing_pending = false;
+  double last_ms = 0.0;
+  int last_launches = 0;
+  int64_t bytes = 0;
+  unsigned long long seg_total = 0;
+  ~phm_engine() {
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+  }
+};
+
+namespace {
+
+template <int NS>
+void fill_params(phm_engine* e, phm::McmcParams<NS>& p, const double* B2, const double* Bc, const double* scale,
+                 const double* pid, const phm_options& o) {
+  p.n_tips = e->sched.n_tips; p.n_node = e->sched.n_node; p.n_edge = e->sched.n_edge; p.root = e->sched.root;
+  p.n_tiles = e->tiles; p.n_rep = e->S; p.n_rep_pad = e->S_pad; p.replica_offset = o.replica_offset;
+  p.normalise = (e->variant == PHM_MCMC_BIGTREE); p.tips_per_replica = e->tips_per_replica ? 1 : 0;
+  p.reduce = e->reduce; p.n_cols = e->cols; p.ktab = phm::MCMC_KTAB;
+  p.seed_lo = (uint32_t)(o.seed & 0xFFFFFFFFull); p.seed_hi = (uint32_t)(o.seed >> 32);
+  p.rows = e->rows;
+  for (int i = 0; i < NS * NS; ++i) { p.B2[i] = B2[i]; p.Bc[i] = Bc[i]; }
+  for (int i = 0; i < NS; ++i) { p.scale[i] = scale[i]; p.pid[i] = pid[i]; }
+  p.up = e->d_up.as<phm::UpStep>(); p.down = e->d_down.as<phm::DownStep>();
+  p.colpow = e->d_col.as<double>(); p.rowpow = e->d_row.as<double>();
+  p.tips = e->d_tips.as<uint8_t>(); p.mcount = e->d_mcount.as<uint16_t>();
+  p.dwell0 = e->d_dw0.as<double>(); p.dwell1 = e->d_dw1.as<double>();
+  p.PL = e->d_PL.as<double>(); p.nstate = e->d_nstate.as<uint8_t>(); p.stats = e->d_stats.as<double>();
+  p.err = e->d_err.as<uint32_t>(); p.segcnt = e->d_seg.as<unsigned long long>();
+}
+
+// chain tables: col[k][j][:] = Bc^k e_j  (v <- Bc v), row[k][j][:] = (Bc^T)^k e_j (w <- Bc^T w);
+// same left-to-right unfused sums as the kernels' matvec_u, so entries are bit-identical to running the chain.
+void build_chain_tables(const double* Bc, int n, int ktab, std::vector<double>& col, std::vector<double>& row) {
+  col.assign((size_t)ktab * n * n, 0.0);
+  row.assign((size_t)ktab * n * n, 0.0);
+  for (int j = 0; j < n; ++j) { col[(size_t)j * n + j] = 1.0; row[(size_t)j * n + j] = 1.0; }
+  for (int k = 1; k < ktab; ++k)
+    for (int j = 0; j < n; ++j) {
+      const double* v = &col[((size_t)(k - 1) * n + j) * n];
+      double* y = &col[((size_t)k * n + j) * n];
+      for (int i = 0; i < n; ++i) {
+        double acc = Bc[i * n] * v[0];
+        for (int c = 1; c < n; ++c) acc += Bc[i * n + c] * v[c];
+        y[i] = acc;
+      }
+      const double* w = &row[((size_t)(k - 1) * n + j) * n];
+      double* z = &row[((size_t)k * n + j) * n];
+      for (int c = 0; c < n; ++c) {
+        double acc = Bc[c] * w[0];
+        for (int r = 1; r < n; ++r) acc += Bc[r * n + c] * w[r];
+        z[c] = acc;
+      }
+    }
+}
+
+int32_t validate_tree_paths(const phm_tree* x, int n, int n_tip_vectors) {
+  if (!x || !x->edge || !x->states || !x->map_off || !x->maps || !x->mapnames) return fail(PHM_ERR_BAD_INPUT, "tree: missing field");
+  for (int64_t i = 0; i < (int64_t)n_tip_vectors * x->n_tips; ++i)
+    if (x->states[i] < 1 || x->states[i] > n) return fail(PHM_ERR_BAD_INPUT, "x$states must be in 1..n");
+  if (x->map_off[0] != 0) return fail(PHM_ERR_BAD_INPUT, "map_off[0] must be 0");
+  for (int b = 0; b < x->n_edge; ++b) {
+    int m = x->map_off[b + 1] - x->map_off[b];
+    if (m < 1) return fail(PHM_ERR_BAD_INPUT, "every branch needs at least one segment in x$maps");
+    if (m > 50000) return fail(PHM_ERR_BAD_INPUT, "more than 50000 segments on one branch");
+    for (int i = x->map_off[b]; i < x->map_off[b + 1]; ++i) {
+      if (x->mapnames[i] < 1 || x->mapnames[i] > n) return fail(PHM_ERR_BAD_INPUT, "x$mapnames must be in 1..n");
+      if (!std::isfinite(x->maps[i]) || x->maps[i] < 0.0) return fail(PHM_ERR_BAD_INPUT, "x$maps must be finite and non-negative");
+    }
+  }
+  return PHM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t phm_version(void) { return PHM_VERSION; }
+
+int32_t phm_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char* phm_last_error(void) { return g_err.c_str(); }
+
+const char* phm_status_string(int32_t s) {
+  switch (s) {
+    case PHM_OK: return "ok";
+    case PHM_ERR_BAD_INPUT: return "bad input";
+    case PHM_ERR_UNSUPPORTED: return "unsupported";
+    case PHM_ERR_NO_DEVICE: return "no HIP device / HIP failure";
+    case PHM_ERR_OOM: return "out of device memory";
+    case PHM_ERR_ZERO_PROB: return "zero probability vector";
+    case PHM_ERR_CAPACITY: return "branch capacity exceeded";
+    case PHM_ERR_UNIF_CAP: return "uniformisation jump cap exceeded";
+    case PHM_ERR_STATE: return "invalid engine state";
+    default: return "unknown";
+  }
+}
+
+int32_t phm_engine_create(const phm_tree* x, const phm_model* model, const phm_options* opt_in, int32_t max_iters,
+                          phm_engine** out) {
+  if (!out) return fail(PHM_ERR_BAD_INPUT, "out is NULL");
+  *out = nullptr;
+  if (!x || !model) return fail(PHM_ERR_BAD_INPUT, "tree/model is NULL");
+  phm_options o;
+  std::memset(&o, 0, sizeof(o));
+  o.device = -1;
+  if (opt_in) o = *opt_in;
+  if (o.n_replicas <= 0) o.n_replicas = 1;
+  const int n = model->n_states;
+  if (n < 2) return fail(PHM_ERR_BAD_INPUT, "n_states must be >= 2");
+  if (n > 4) return fail(PHM_ERR_UNSUPPORTED, "this build has MCMC kernels for n_states in {2,3,4} only");
+  if (!model->Q || !model->pid) return fail(PHM_ERR_BAD_INPUT, "model: Q/pid missing");
+  if (model->variant < PHM_MCMC || model->variant > PHM_MCMC_SPARSE) return fail(PHM_ERR_BAD_INPUT, "unknown variant");
+  if (max_iters < 1) return fail(PHM_ERR_BAD_INPUT, "max_iters must be >= 1");
+  if (!(model->Omega > 0.0) || !std::isfinite(model->Omega)) return fail(PHM_ERR_BAD_INPUT, "Omega must be positive");
+  int32_t st = validate_tree_paths(x, n, o.tips_per_replica ? o.n_replicas : 1);
+  if (st) return st;
+
+  // model matrices, row-major copies (inputs are R's column-major)
+  double B2[16], Bc[16], scale[4], pid[4];
+  for (int i = 0; i < n; ++i) {
+    double q = model->Q[i + (size_t)i * n];
+    double r = model->Omega + q;
+    if (!(r >= 0.0)) return fail(PHM_ERR_BAD_INPUT, "Omega must be at least |q_ii| for every state (man/sumstatMCMC.Rd:14)");
+    scale[i] = 1.0 / r;
+    pid[i] = model->pid[i];
+    if (!(pid[i] >= 0.0) || !std::isfinite(pid[i])) return fail(PHM_ERR_BAD_INPUT, "pid must be non-negative");
+    for (int j = 0; j < n; ++j) {
+      double b = model->B ? model->B[i + (size_t)j * n]
+                          : ((i == j ? 1.0 : 0.0) + model->Q[i + (size_t)j * n] / model->Omega);   // R/sumstatMCMC.R:25
+      if (!(b >= 0.0) || !std::isfinite(b)) return fail(PHM_ERR_BAD_INPUT, "B = I + Q/Omega must be non-negative");
+      B2[i * n + j] = b;
+      Bc[i * n + j] = (model->variant == PHM_MCMC_SPARSE) ? (b > 1e-7 ? b : 0.0) : b;            // matTospmat :811
+    }
+  }
+
+  st = select_device(o.device);
+  if (st) return st;
+
+  phm_engine* e = new phm_engine();
+  std::unique_ptr<phm_engine> guard(e);
+  e->n = n; e->cols = n + n * (n - 1); e->variant = model->variant;
+  e->S = o.n_replicas; e->tiles = (e->S + 63) / 64; e->S_pad = e->tiles * 64;
+  e->max_iters = max_iters; e->reduce = o.reduce ? 1 : 0;
+  e->ipl = o.iters_per_launch > 0 ? o.iters_per_launch : 8;
+  e->tips_per_replica = o.tips_per_replica != 0;
+  HIPCHK(hipGetDevice(&e->device));
+
+  std::string serr;
+  if (!phm::build_schedule(x->n_tips, x->n_node, x->n_edge, x->edge, e->sched, serr)) return fail(PHM_ERR_BAD_INPUT, "tree: " + serr);
+  phm::Schedule& s = e->sched;
+  const int E = s.n_edge, T = s.n_tips;
+
+  // slot capacities: t_b = sum(x$maps[[b]]); segments ~ 1 + Poisson(Omega t_b)
+  int64_t rows = 0;
+  for (int k = 0; k < E; ++k) {
+    phm::DownStep& d = s.down[k];
+    double tb = 0.0;
+    for (int i = x->map_off[d.edge]; i < x->map_off[d.edge + 1]; ++i) tb += x->maps[i];
+    int m0 = x->map_off[d.edge + 1] - x->map_off[d.edge];
+    int cap = phm::poisson_capacity(model->Omega * tb, o.cap_tail);
+    cap = std::max(cap, m0 + 2);
+    d.row_off = (int32_t)rows; d.cap = cap;
+    rows += cap;
+    s.max_cap = std::max(s.max_cap, cap);
+    if (rows * 64 > 0x7fffff00ll) return fail(PHM_ERR_UNSUPPORTED, "tree too large: dwell rows per replica tile exceed 32-bit indexing");
+  }
+  s.total_rows = rows; e->rows = rows;
+
+  // tips (0-based u8)
+  if (e->tips_per_replica) {
+    e->tips_host.assign((size_t)e->tiles * T * 64, 0);
+    for (int r = 0; r < e->S_pad; ++r) {
+      int src = r < e->S ? r : e->S - 1;
+      for (int t = 0; t < T; ++t) e->tips_host[((size_t)(r / 64) * T + t) * 64 + (r % 64)] = (uint8_t)(x->states[(size_t)src * T + t] - 1);
+    }
+  } else {
+    e->tips_host.resize(T);
+    for (int t = 0; t < T; ++t) e->tips_host[t] = (uint8_t)(x->states[t] - 1);
+  }
+
+  std::vector<double> col, row;
+  build_chain_tables(Bc, n, phm::MCMC_KTAB, col, row);
+
+  const size_t stats_bytes = e->reduce ? sizeof(double) * (size_t)max_iters * e->tiles * e->cols
+                                       : sizeof(double) * (size_t)max_iters * e->cols * e->S_pad;
+  const size_t dw_bytes = sizeof(double) * (size_t)e->tiles * rows * 64;
+  size_t need = 2 * dw_bytes + stats_bytes + sizeof(double) * (size_t)e->tiles * s.n_node * n * 64 +
+                (size_t)e->tiles * (s.n_node + 2 * (size_t)E) * 64 + e->tips_host.size();
+  size_t free_b = 0, total_b = 0;
+  HIPCHK(hipMemGetInfo(&free_b, &total_b));
+  if (need + (64u << 20) > free_b) {
+    char buf[256];
+    std::snprintf(buf, sizeof buf, "engine needs %.2f GiB of HBM, %.2f GiB free (reduce n_replicas or max_iters)", need / 1073741824.0, free_b / 1073741824.0);
+    return fail(PHM_ERR_OOM, buf);
+  }
+  HIPCHK(e->d_up.alloc(sizeof(phm::UpStep) * s.up.size()));
+  HIPCHK(e->d_down.alloc(sizeof(phm::DownStep) * s.down.size()));
+  HIPCHK(e->d_col.alloc(sizeof(double) * col.size()));
+  HIPCHK(e->d_row.alloc(sizeof(double) * row.size()));
+  HIPCHK(e->d_tips.alloc(e->tips_host.size()));
+  HIPCHK(e->d_mcount.alloc(sizeof(uint16_t) * (size_t)e->tiles * E * 64));
+  HIPCHK(e->d_dw0.alloc(dw_bytes));
+  HIPCHK(e->d_dw1.alloc(dw_bytes));
+  HIPCHK(e->d_PL.alloc(sizeof(double) * (size_t)e->tiles * s.n_node * n * 64));
+  HIPCHK(e->d_nstate.alloc((size_t)e->tiles * s.n_node * 64));
+  HIPCHK(e->d_stats.alloc(stats_bytes));
+  HIPCHK(e->d_err.alloc(sizeof(uint32_t)));
+  HIPCHK(e->d_seg.alloc(sizeof(unsigned long long)));
+  if (e->reduce) HIPCHK(e->d_red.alloc(sizeof(double) * (size_t)max_iters * e->cols));
+  e->bytes = (int64_t)(e->d_up.bytes + e->d_down.bytes + e->d_col.bytes + e->d_row.bytes + e->d_tips.bytes + e->d_mcount.bytes +
+                       e->d_dw0.bytes + e->d_dw1.bytes + e->d_PL.bytes + e->d_nstate.bytes + e->d_stats.bytes + e->d_red.bytes);
+
+  HIPCHK(hipMemcpy(e->d_up.p, s.up.data(), e->d_up.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(e->d_down.p, s.down.data(), e->d_down.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(e->d_col.p, col.data(), e->d_col.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(e->d_row.p, row.data(), e->d_row.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(e->d_tips.p, e->tips_host.data(), e->tips_host.size(), hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(e->d_err.p, 0, sizeof(uint32_t)));
+  HIPCHK(hipMemset(e->d_seg.p, 0, sizeof(unsigned long long)));
+  HIPCHK(hipMemset(e->d_stats.p, 0, stats_bytes));
+  HIPCHK(hipMemset(e->d_nstate.p, 0, e->d_nstate.bytes));
+
+  {   // initial paths -> every replica (makeabranch, src/phylomap.cpp:24-34, :901)
+    DevBuf d_off, d_maps;
+    HIPCHK(d_off.alloc(sizeof(int32_t) * (E + 1)));
+    HIPCHK(d_maps.alloc(sizeof(double) * (size_t)x->map_off[E]));
+    HIPCHK(hipMemcpy(d_off.p, x->map_off, d_off.bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_maps.p, x->maps, d_maps.bytes, hipMemcpyHostToDevice));
+    HIPCHK(phm::launch_mcmc_init(E, e->tiles, rows, e->d_down.as<phm::DownStep>(), d_off.as<int32_t>(), d_maps.as<double>(),
+                                 e->d_dw0.as<double>(), e->d_mcount.as<uint16_t>(), nullptr));
+    HIPCHK(hipDeviceSynchronize());
+  }
+
+  if (n == 2) fill_params<2>(e, e->p2, B2, Bc, scale, pid, o);
+  if (n == 3) fill_params<3>(e, e->p3, B2, Bc, scale, pid, o);
+  if (n == 4) fill_params<4>(e, e->p4, B2, Bc, scale, pid, o);
+  HIPCHK(hipEventCreate(&e->ev0));
+  HIPCHK(hipEventCreate(&e->ev1));
+  *out = guard.release();
+  return PHM_OK;
+}
+
+int32_t phm_engine_run(phm_engine* e, int32_t n_iters, void* hip_stream) {
+  if (!e) return fail(PHM_ERR_STATE, "engine is NULL");
+  if (n_iters < 0 || e->iters_done + n_iters > e->max_iters) return fail(PHM_ERR_STATE, "iteration range exceeds max_iters");
+  HIPCHK(hipSetDevice(e->device));
+  hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
+  HIPCHK(hipEventRecord(e->ev0, stream));
+  int launches = 0;
+  for (int done = 0; done < n_iters;) {
+    int chunk = std::min(e->ipl, n_iters - done);
+    hipError_t le = hipSuccess;
+    if (e->n == 2) le = phm::launch_mcmc<2>(e->p2, e->iters_done + done, chunk, stream);
+    if (e->n == 3) le = phm::launch_mcmc<3>(e->p3, e->iters_done + done, chunk, stream);
+    if (e->n == 4) le = phm::launch_mcmc<4>(e->p4, e->iters_done + done, chunk, stream);
+    HIPCHK(le);
+    done += chunk;
+    ++launches;
+  }
+  HIPCHK(hipEventRecord(e->ev1, stream));
+  e->iters_done += n_iters;
+  e->last_stream = stream;
+  e->timing_pending = true;
+  e->last_launches = launches;
+  return PHM_OK;
+}
+
+int32_t phm_engine_sync(phm_engine* e) {
+  if (!e) return fail(PHM_ERR_STATE, "engine is NULL");
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipStreamSynchronize(e->last_stream));
+  if (e->timing_pending) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+    e->last_ms = ms;
+    e->timing_pending = false;
+  }
+  uint32_t derr = 0;
+  HIPCHK(hipMemcpy(&derr, e->d_err.p, sizeof derr, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&e->seg_total, e->d_seg.p, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return device_status(derr);
+}
+
+int32_t phm_engine_read_stats(phm_engine* e, int32_t iter0, int32_t n, double* out) {
+  if (!e || !out) return fail(PHM_ERR_STATE, "engine/out is NULL");
+  if (iter0 < 0 || n < 0 || iter0 + n > e->iters_done) return fail(PHM_ERR_STATE, "statistics requested for iterations that have not run");
+  if (n == 0) return PHM_OK;
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipStreamSynchronize(e->last_stream));
+  const int cols = e->cols;
+  if (e->reduce) {
+    HIPCHK(phm::launch_stats_reduce(e->d_stats.as<double>() + (size_t)iter0 * e->tiles * cols, n, e->tiles, cols,
+                                    e->d_red.as<double>(), e->last_stream));
+    std::vector<double> h((size_t)n * cols);
+    HIPCHK(hipMemcpyAsync(h.data(), e->d_red.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, e->last_stream));
+    HIPCHK(hipStreamSynchronize(e->last_stream));
+    for (int i = 0; i < n; ++i)
+      for (int c = 0; c < cols; ++c) out[(size_t)c * n + i] = h[(size_t)i * cols + c];
+  } else {
+    std::vector<double> h((size_t)n * cols * e->S_pad);
+    HIPCHK(hipMemcpy(h.data(), e->d_stats.as<double>() + (size_t)iter0 * cols * e->S_pad, sizeof(double) * h.size(), hipMemcpyDeviceToHost));
+    for (int r = 0; r < e->S; ++r)
+      for (int c = 0; c < cols; ++c)
+        for (int i = 0; i < n; ++i) out[((size_t)r * cols + c) * n + i] = h[((size_t)i * cols + c) * e->S_pad + r];
+  }
+  return PHM_OK;
+}
+
+int32_t phm_engine_dump(phm_engine* e, int32_t replica, int32_t* seg_count, double* seg_dwell, int32_t seg_cap,
+                        int32_t* node_states, double* PL) {
+  if (!e) return fail(PHM_ERR_STATE, "engine is NULL");
+  if (replica < 0 || replica >= e->S) return fail(PHM_ERR_BAD_INPUT, "replica out of range");
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipStreamSynchronize(e->last_stream));
+  const phm::Schedule& s = e->sched;
+  const int E = s.n_edge, T = s.n_tips, n = e->n, tile = replica / 64, lane = replica % 64;
+  std::vector<uint16_t> mc((size_t)E * 64);
+  HIPCHK(hipMemcpy(mc.data(), e->d_mcount.as<uint16_t>() + (size_t)tile * E * 64, sizeof(uint16_t) * mc.size(), hipMemcpyDeviceToHost));
+  if (seg_count) for (int b = 0; b < E; ++b) seg_count[b] = mc[(size_t)b * 64 + lane];
+  if (seg_dwell) {
+    std::vector<double> dw((size_t)e->rows * 64);
+    const double* src = ((e->iters_done & 1) ? e->d_dw1.as<double>() : e->d_dw0.as<double>()) + (size_t)tile * e->rows * 64;
+    HIPCHK(hipMemcpy(dw.data(), src, sizeof(double) * dw.size(), hipMemcpyDeviceToHost));
+    for (int k = 0; k < E; ++k) {
+      const phm::DownStep& d = s.down[k];
+      int m = std::min<int>(mc[(size_t)d.edge * 64 + lane], seg_cap);
+      for (int i = 0; i < m; ++i) seg_dwell[(size_t)d.edge * seg_cap + i] = dw[((size_t)d.row_off + i) * 64 + lane];
+    }
+  }
+  auto tip_state = [&](int t) -> int {
+    return e->tips_per_replica ? e->tips_host[((size_t)tile * T + t) * 64 + lane] : e->tips_host[t];
+  };
+  if (node_states) {
+    std::vector<uint8_t> ns((size_t)s.n_node * 64);
+    HIPCHK(hipMemcpy(ns.data(), e->d_nstate.as<uint8_t>() + (size_t)tile * s.n_node * 64, ns.size(), hipMemcpyDeviceToHost));
+    for (int t = 0; t < T; ++t) node_states[t] = tip_state(t) + 1;
+    for (int v = 0; v < s.n_node; ++v) node_states[T + v] = ns[(size_t)v * 64 + lane] + 1;
+  }
+  if (PL) {
+    std::vector<double> pl((size_t)s.n_node * n * 64);
+    HIPCHK(hipMemcpy(pl.data(), e->d_PL.as<double>() + (size_t)tile * s.n_node * n * 64, sizeof(double) * pl.size(), hipMemcpyDeviceToHost));
+    for (int t = 0; t < T; ++t)
+      for (int c = 0; c < n; ++c) PL[(size_t)t * n + c] = (c == tip_state(t)) ? 1.0 : 0.0;
+    for (int v = 0; v < s.n_node; ++v)
+      for (int c = 0; c < n; ++c) PL[(size_t)(T + v) * n + c] = pl[((size_t)v * n + c) * 64 + lane];
+  }
+  return PHM_OK;
+}
+
+int32_t phm_engine_info(phm_engine* e, phm_info* info) {
+  if (!e || !info) return fail(PHM_ERR_STATE, "engine/info is NULL");
+  std::memset(info, 0, sizeof(*info));
+  info->n_states = e->n; info->n_edge = e->sched.n_edge; info->n_replicas = e->S; info->n_replicas_padded = e->S_pad;
+  info->n_cols = e->cols; info->max_iters = e->max_iters; info->device_bytes = e->bytes;
+  info->rows_per_replica = e->rows;
+  info->seg_read = (int64_t)e->seg_total; info->seg_written = 0;
+  info->last_run_ms = e->last_ms; info->last_run_launches = e->last_launches; info->iters_done = e->iters_done;
+  return PHM_OK;
+}
+
+void phm_engine_destroy(phm_engine* e) { delete e; }
+
+// ---- reference-shaped one-shot drivers -------------------------------------------------------------
+static int32_t run_mcmc_oneshot(int variant, const phm_tree* x, int32_t n, const double* Q, const double* pid,
+                                const double* B, double Omega, const int32_t* nen, const int32_t* nodelist, int32_t root,
+                                int32_t N, const phm_options* opt, double* out) {
+  if (!out) return fail(PHM_ERR_BAD_INPUT, "out is NULL");
+  if (N < 1) return fail(PHM_ERR_BAD_INPUT, "N must be >= 1");
+  phm_model model;
+  model.n_states = n; model.Q = Q; model.pid = pid; model.B = B; model.Omega = Omega; model.variant = variant;
+  phm_engine* e = nullptr;
+  int32_t st = phm_engine_create(x, &model, opt, N, &e);
+  if (st) return st;
+  std::string serr;
+  if (!phm::check_reference_orders(e->sched, x->edge, nen, nodelist, root, serr)) { phm_engine_destroy(e); return fail(PHM_ERR_BAD_INPUT, serr); }
+  st = phm_engine_run(e, N, nullptr);
+  if (!st) st = phm_engine_sync(e);
+  if (!st) st = phm_engine_read_stats(e, 0, N, out);
+  phm_engine_destroy(e);
+  return st;
+}
+
+int32_t phm_maketreelistMCMC(const phm_tree* x, int32_t n, const double* Q, const double* pid, const double* B, double Omega,
+                             const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N, const phm_options* opt,
+                             double* out) {
+  return run_mcmc_oneshot(PHM_MCMC, x, n, Q, pid, B, Omega, nen, nodelist, root, N, opt, out);
+}
+int32_t phm_maketreelistMCMC_bigtree(const phm_tree* x, int32_t n, const double* Q, const double* pid, const double* B,
+                                     double Omega, const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
+                                     const phm_options* opt, double* out) {
+  return run_mcmc_oneshot(PHM_MCMC_BIGTREE, x, n, Q, pid, B, Omega, nen, nodelist, root, N, opt, out);
+}
+int32_t phm_SPARSEmaketreelistMCMC(const phm_tree* x, int32_t n, const double* Q, const double* pid, const double* B,
+                                   double Omega, const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
+                                   const phm_options* opt, double* out) {
+  return run_mcmc_oneshot(PHM_MCMC_SPARSE, x, n, Q, pid, B, Omega, nen, nodelist, root, N, opt, out);
+}
+
+}  // extern "C"
+
+// ---- batched transition matrices -------------------------------------------------------------------
+namespace {
+
+void cm_to_rm(const double* cm, int n, std::vector<double>& rm) {
+  rm.resize((size_t)n * n);
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) rm[(size_t)i * n + j] = cm[i + (size_t)j * n];
+}
+
+struct Timer {
+  hipEvent_t a = nullptr, b = nullptr;
+  ~Timer() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+};
+
+// squaring count of arma::expmat: s = max(0, exponent(frexp(log2 ||A||_inf)) + 1)
+int pade_squarings(const double* Q_rm, int n, double t) {
+  double norm = 0.0;
+  for (int i = 0; i < n; ++i) {
+    double r = 0.0;
+    for (int j = 0; j < n; ++j) r += std::fabs(Q_rm[(size_t)i * n + j] * t);
+    if (r > norm) norm = r;
+  }
+  double l2 = (norm > 0.0) ? std::log2(norm) : 0.0;
+  int ex = 0;
+  (void)std::frexp(l2, &ex);
+  return std::max(0, ex + 1);
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t phm_expm_eigen(int32_t n, const double* lefts, const double* rights, const double* d, const double* t,
+                       int32_t n_t, int32_t device, double* out, double* kernel_ms) {
+  if (n < 1 || n > 256 || !lefts || !rights || !d || !t || !out || n_t < 0) return fail(PHM_ERR_BAD_INPUT, "phm_expm_eigen: bad arguments");
+  int32_t st = select_device(device);
+  if (st) return st;
+  if (n_t == 0) return PHM_OK;
+  std::vector<double> L, R, dv(n);
+  cm_to_rm(lefts, n, L); cm_to_rm(rights, n, R);
+  for (int i = 0; i < n; ++i) dv[i] = d[i + (size_t)i * n];
+  const size_t nn = (size_t)n * n;
+  DevBuf dL, dR, dd, dt, dout;
+  HIPCHK(dL.alloc(sizeof(double) * nn)); HIPCHK(dR.alloc(sizeof(double) * nn)); HIPCHK(dd.alloc(sizeof(double) * n));
+  HIPCHK(dt.alloc(sizeof(double) * n_t)); HIPCHK(dout.alloc(sizeof(double) * nn * n_t));
+  HIPCHK(hipMemcpy(dL.p, L.data(), dL.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dR.p, R.data(), dR.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dd.p, dv.data(), dd.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dt.p, t, dt.bytes, hipMemcpyHostToDevice));
+  Timer tm;
+  HIPCHK(hipEventCreate(&tm.a)); HIPCHK(hipEventCreate(&tm.b));
+  HIPCHK(hipEventRecord(tm.a, nullptr));
+  HIPCHK(phm::launch_expm_eigen(n, dL.as<double>(), dR.as<double>(), dd.as<double>(), dt.as<double>(), n_t, dout.as<double>(), nullptr));
+  HIPCHK(hipEventRecord(tm.b, nullptr));
+  HIPCHK(hipMemcpy(out, dout.p, dout.bytes, hipMemcpyDeviceToHost));
+  if (kernel_ms) { float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, tm.a, tm.b)); *kernel_ms = ms; }
+  return PHM_OK;
+}
+
+int32_t phm_expm_pade(int32_t n, const double* Q, const double* t, int32_t n_t, int32_t device, double* out,
+                      double* kernel_ms) {
+  if (n < 1 || n > 128 || !Q || !t || !out || n_t < 0) return fail(PHM_ERR_BAD_INPUT, "phm_expm_pade: bad arguments (n <= 128)");
+  int32_t st = select_device(device);
+  if (st) return st;
+  if (n_t == 0) return PHM_OK;
+  std::vector<double> Qr;
+  cm_to_rm(Q, n, Qr);
+  std::vector<int32_t> sq(n_t);
+  for (int b = 0; b < n_t; ++b) sq[b] = pade_squarings(Qr.data(), n, t[b]);
+  const size_t nn = (size_t)n * n;
+  DevBuf dQ, dt, ds, dwork, dout, derr;
+  HIPCHK(dQ.alloc(sizeof(double) * nn)); HIPCHK(dt.alloc(sizeof(double) * n_t)); HIPCHK(ds.alloc(sizeof(int32_t) * n_t));
+  HIPCHK(dwork.alloc(sizeof(double) * nn * 5 * n_t)); HIPCHK(dout.alloc(sizeof(double) * nn * n_t)); HIPCHK(derr.alloc(sizeof(uint32_t)));
+  HIPCHK(hipMemcpy(dQ.p, Qr.data(), dQ.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dt.p, t, dt.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(ds.p, sq.data(), ds.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(derr.p, 0, sizeof(uint32_t)));
+  Timer tm;
+  HIPCHK(hipEventCreate(&tm.a)); HIPCHK(hipEventCreate(&tm.b));
+  HIPCHK(hipEventRecord(tm.a, nullptr));
+  HIPCHK(phm::launch_expm_pade(n, dQ.as<double>(), dt.as<double>(), ds.as<int32_t>(), n_t, dwork.as<double>(), dout.as<double>(), derr.as<uint32_t>(), nullptr));
+  HIPCHK(hipEventRecord(tm.b, nullptr));
+  HIPCHK(hipMemcpy(out, dout.p, dout.bytes, hipMemcpyDeviceToHost));
+  uint32_t derrh = 0;
+  HIPCHK(hipMemcpy(&derrh, derr.p, sizeof derrh, hipMemcpyDeviceToHost));
+  if (kernel_ms) { float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, tm.a, tm.b)); *kernel_ms = ms; }
+  if (derrh) return fail(PHM_ERR_BAD_INPUT, "phm_expm_pade: singular Pade denominator");
+  return PHM_OK;
+}
+
+// maketreelistEXP, src/phylomap.cpp:3001-3051.  P(t_b) and the pruning pass are computed ONCE (the reference
+// recomputes both every iteration although Q never changes, :2980-2981).
+int32_t phm_maketreelistEXP(const phm_tree* x, int32_t n, const double* Q, const double* pid, const int32_t* nen,
+                            const int32_t* nodelist, int32_t root, int32_t N, const double* lefts, const double* rights,
+                            const double* d, const phm_options* opt_in, double* out) {
+  if (!x || !Q || !pid || !lefts || !rights || !d || !out) return fail(PHM_ERR_BAD_INPUT, "phm_maketreelistEXP: NULL argument");
+  if (N < 1) return fail(PHM_ERR_BAD_INPUT, "N must be >= 1");
+  if (n < 2) return fail(PHM_ERR_BAD_INPUT, "n_states must be >= 2");
+  if (n > 4) return fail(PHM_ERR_UNSUPPORTED, "this build has EXP kernels for n_states in {2,3,4} only");
+  if (!x->edge_length) return fail(PHM_ERR_BAD_INPUT, "x$edge.length is required (src/phylomap.cpp:3034)");
+  phm_options o;
+  std::memset(&o, 0, sizeof(o));
+  o.device = -1;
+  if (opt_in) o = *opt_in;
+  int32_t st = validate_tree_paths(x, n, 1);
+  if (st) return st;
+  phm::Schedule s;
+  std::string serr;
+  if (!phm::build_schedule(x->n_tips, x->n_node, x->n_edge, x->edge, s, serr)) return fail(PHM_ERR_BAD_INPUT, "tree: " + serr);
+  if (!phm::check_reference_orders(s, x->edge, nen, nodelist, root, serr)) return fail(PHM_ERR_BAD_INPUT, serr);
+  const int E = s.n_edge, T = s.n_tips;
+  for (int b = 0; b < E; ++b)
+    if (!std::isfinite(x->edge_length[b]) || x->edge_length[b] < 0.0) return fail(PHM_ERR_BAD_INPUT, "edge.length must be finite and non-negative");
+
+  std::vector<double> L, R, dv(n), B2((size_t)n * n);
+  cm_to_rm(lefts, n, L); cm_to_rm(rights, n, R);
+  double minq = Q[0];
+  for (int i = 0; i < n; ++i) { dv[i] = d[i + (size_t)i * n]; minq = std::min(minq, Q[i + (size_t)i * n]); }
+  const double rate = -1.0 * minq;                                             // :3008
+  if (!(rate > 0.0)) return fail(PHM_ERR_BAD_INPUT, "Q must have a negative diagonal entry");
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) {
+      double b = ((i == j) ? 1.0 : 0.0) + Q[i + (size_t)j * n] / rate;          // :3011
+      if (!(b >= 0.0)) return fail(PHM_ERR_BAD_INPUT, "I + Q/poissonRate must be non-negative");
+      B2[(size_t)i * n + j] = b;
+    }
+  std::vector<double> col, rowtab;
+  build_chain_tables(B2.data(), n, phm::UNIF_CAP + 1, col, rowtab);
+
+  st = select_device(o.device);
+  if (st) return st;
+  const size_t nn = (size_t)n * n;
+  const int tiles = (N + 63) / 64;
+  const int cols = n + n * (n - 1);
+  DevBuf dL, dR, dd, dt, dP, dPL, dup, ddown, dcol, dB2, dtips, dnst, dtimes, dout, derr;
+  HIPCHK(dL.alloc(sizeof(double) * nn)); HIPCHK(dR.alloc(sizeof(double) * nn)); HIPCHK(dd.alloc(sizeof(double) * n));
+  HIPCHK(dt.alloc(sizeof(double) * E)); HIPCHK(dP.alloc(sizeof(double) * nn * E));
+  HIPCHK(dPL.alloc(sizeof(double) * (size_t)(2 * T - 1) * n));
+  HIPCHK(dup.alloc(sizeof(phm::UpStep) * s.up.size())); HIPCHK(ddown.alloc(sizeof(phm::DownStep) * s.down.size()));
+  HIPCHK(dcol.alloc(sizeof(double) * col.size())); HIPCHK(dB2.alloc(sizeof(double) * nn)); HIPCHK(dtips.alloc(T));
+  HIPCHK(dnst.alloc((size_t)tiles * s.n_node * 64)); HIPCHK(dtimes.alloc(sizeof(double) * (size_t)tiles * phm::UNIF_CAP * 64));
+  HIPCHK(dout.alloc(sizeof(double) * (size_t)N * cols)); HIPCHK(derr.alloc(sizeof(uint32_t)));
+  std::vector<double> PLh((size_t)(2 * T - 1) * n, 0.0);
+  std::vector<uint8_t> tips(T);
+  for (int t = 0; t < T; ++t) { tips[t] = (uint8_t)(x->states[t] - 1); PLh[(size_t)t * n + tips[t]] = 1.0; }   // :2883
+  HIPCHK(hipMemcpy(dL.p, L.data(), dL.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dR.p, R.data(), dR.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dd.p, dv.data(), dd.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dt.p, x->edge_length, dt.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dPL.p, PLh.data(), dPL.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dup.p, s.up.data(), dup.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(ddown.p, s.down.data(), ddown.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dcol.p, col.data(), dcol.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dB2.p, B2.data(), dB2.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dtips.p, tips.data(), T, hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(derr.p, 0, sizeof(uint32_t)));
+  HIPCHK(hipMemset(dnst.p, 0, dnst.bytes));
+
+  HIPCHK(phm::launch_expm_eigen(n, dL.as<double>(), dR.as<double>(), dd.as<double>(), dt.as<double>(), E, dP.as<double>(), nullptr));   // :3042
+  HIPCHK(phm::launch_exp_pl(n, s.n_node, T, dup.as<phm::UpStep>(), dP.as<double>(), dPL.as<double>(), nullptr));                       // :3043
+
+  auto fill = [&](auto& p) {
+    p.n_tips = T; p.n_node = s.n_node; p.n_edge = E; p.root = s.root; p.N = N; p.n_tiles = tiles;
+    p.seed_lo = (uint32_t)(o.seed & 0xFFFFFFFFull); p.seed_hi = (uint32_t)(o.seed >> 32); p.replica = (uint32_t)o.replica_offset;
+    p.poisson_rate = rate;
+    for (int i = 0; i < n; ++i) p.pid[i] = pid[i];
+    p.down = ddown.as<phm::DownStep>(); p.P = dP.as<double>(); p.PL = dPL.as<double>(); p.edge_length = dt.as<double>();
+    p.colpow = dcol.as<double>(); p.B2 = dB2.as<double>(); p.tips = dtips.as<uint8_t>(); p.nstate = dnst.as<uint8_t>();
+    p.times = dtimes.as<double>(); p.out = dout.as<double>(); p.err = derr.as<uint32_t>();
+  };
+  hipError_t le = hipSuccess;
+  if (n == 2) { phm::ExpParams<2> p; fill(p); le = phm::launch_exp_sample<2>(p, nullptr); }
+  if (n == 3) { phm::ExpParams<3> p; fill(p); le = phm::launch_exp_sample<3>(p, nullptr); }
+  if (n == 4) { phm::ExpParams<4> p; fill(p); le = phm::launch_exp_sample<4>(p, nullptr); }
+  HIPCHK(le);
+  HIPCHK(hipMemcpy(out, dout.p, dout.bytes, hipMemcpyDeviceToHost));
+  uint32_t derrh = 0;
+  HIPCHK(hipMemcpy(&derrh, derr.p, sizeof derrh, hipMemcpyDeviceToHost));
+  return device_status(derrh);
+}
+
+}  // extern "C"

@@ -1,0 +1,144 @@
+// phm_device.h -- device-side scalar building blocks shared by every kernel.
+//
+// These restate, independently of oracle/phm_oracle.c, the arithmetic spec of DESIGN.md:
+// Philox4x32-10 counter streams, the (0,1) map of 64 random bits, and the deterministic
+// log/exp (basic IEEE-754 binary64 operations only, no FMA contraction: the library is built
+// with -ffp-contract=off) so that the CPU oracle and the GPU agree bit for bit.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace phm {
+
+// device error bits -> phm_status (phm_api.cpp)
+constexpr uint32_t DERR_ZERO_PROB = 1u;   // all-zero / non-finite probability vector
+constexpr uint32_t DERR_CAPACITY  = 2u;   // branch outgrew its slot capacity
+constexpr uint32_t DERR_UNIF_CAP  = 4u;   // newunifSample > 300 jumps (src/phylomap.cpp:120)
+constexpr uint32_t DERR_SAMPLEONCE = 8u;  // sampleOnce ran off the end (src/phylomap.cpp:85-89)
+
+// entity tags: top two bits of Philox counter word 1
+constexpr uint32_t ENT_NODE   = 0u;
+constexpr uint32_t ENT_BSTATE = 1u << 30;
+constexpr uint32_t ENT_BEXP   = 2u << 30;
+constexpr uint32_t ENT_BUNIF  = 3u << 30;
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t (&o)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+
+// 64 random bits -> double in the open interval (0,1): ((x>>12)+0.5)*2^-52, exact
+__device__ __forceinline__ double u01(uint32_t lo, uint32_t hi) {
+  uint64_t x = ((uint64_t)hi << 32) | lo;
+  uint64_t k = ((x >> 12) << 1) | 1ull;
+  return (double)k * 1.1102230246251565404e-16;
+}
+
+// Sequential draws of one stream (replica, iteration, entity): draw d lives in Philox block d>>1.
+struct Stream {
+  uint32_t ent, iter, rep, k0, k1;
+  uint32_t blk;
+  double u0, u1;
+  __device__ __forceinline__ void open(uint32_t entity, uint32_t iteration, uint32_t replica, uint32_t seed_lo,
+                                       uint32_t seed_hi) {
+    ent = entity; iter = iteration; rep = replica; k0 = seed_lo; k1 = seed_hi; blk = 0xFFFFFFFFu; u0 = 0.5; u1 = 0.5;
+  }
+  __device__ __forceinline__ double draw(uint32_t d) {
+    uint32_t b = d >> 1;
+    if (b != blk) {
+      uint32_t o[4];
+      philox4x32_10(b, ent, iter, rep, k0, k1, o);
+      u0 = u01(o[0], o[1]);
+      u1 = u01(o[2], o[3]);
+      blk = b;
+    }
+    return (d & 1u) ? u1 : u0;
+  }
+};
+
+// one-off draw (node states)
+__device__ __forceinline__ double stream_u(uint32_t seed_lo, uint32_t seed_hi, uint32_t rep, uint32_t iter,
+                                           uint32_t ent, uint32_t d) {
+  uint32_t o[4];
+  philox4x32_10(d >> 1, ent, iter, rep, seed_lo, seed_hi, o);
+  return (d & 1u) ? u01(o[2], o[3]) : u01(o[0], o[1]);
+}
+
+// natural log for normal positive finite x (all callers pass u in (0,1) or validated positives)
+__device__ __forceinline__ double phm_log(double x) {
+  const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+               Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+               Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+               Lg7 = 1.479819860511658591e-01;
+  int k = 0;
+  if (x < 2.2250738585072014e-308) { x *= 18014398509481984.0; k -= 54; }
+  uint64_t ux = (uint64_t)__double_as_longlong(x);
+  uint32_t hx = (uint32_t)(ux >> 32);
+  k += (int)(hx >> 20) - 1023;
+  hx &= 0x000fffffu;
+  uint32_t i = (hx + 0x95f64u) & 0x100000u;
+  ux = ((uint64_t)(hx | (i ^ 0x3ff00000u)) << 32) | (ux & 0xffffffffull);
+  k += (int)(i >> 20);
+  double f = __longlong_as_double((long long)ux) - 1.0;
+  double dk = (double)k;
+  double s = f / (2.0 + f);
+  double z = s * s;
+  double w = z * z;
+  double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+  double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+  double R = t2 + t1;
+  double hfsq = 0.5 * f * f;
+  return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+}
+
+__device__ __forceinline__ double phm_exp(double x) {
+  const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
+               invln2 = 1.44269504088896338700e+00, P1 = 1.66666666666666019037e-01,
+               P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+               P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+  if (x != x) return x;
+  if (x > 7.09782712893383973096e+02) return __longlong_as_double(0x7ff0000000000000ll);
+  if (x < -7.45133219101941108420e+02) return 0.0;
+  double hi = x, lo = 0.0;
+  int k = 0;
+  if (fabs(x) > 0.34657359027997264) {
+    k = (int)(invln2 * x + (x < 0.0 ? -0.5 : 0.5));
+    double t = (double)k;
+    hi = x - t * ln2HI;
+    lo = t * ln2LO;
+  }
+  double r = hi - lo;
+  double t = r * r;
+  double c = r - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+  double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+  return ldexp(y, k);
+}
+
+// first j with u*sum(p) <= p_0+..+p_j, index order (categorical draw)
+template <int NS>
+__device__ __forceinline__ int sample_cat(const double (&p)[NS], double u, uint32_t& err) {
+  double total = p[0];
+#pragma unroll
+  for (int j = 1; j < NS; ++j) total += p[j];
+  if (!(total > 0.0) || isinf(total)) err |= DERR_ZERO_PROB;
+  double thr = u * total;
+  double cum = p[0];
+  int idx = (thr <= cum) ? 0 : 1;
+#pragma unroll
+  for (int j = 1; j < NS; ++j) { cum += p[j]; idx += (thr <= cum) ? 0 : 1; }
+  return idx < NS ? idx : NS - 1;
+}
+
+}  // namespace phm

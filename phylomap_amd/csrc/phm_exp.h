@@ -1,0 +1,52 @@
+// phm_exp.h -- launchers of the matrix-exponentiation path (sumstatEXP): batched transition matrices
+// (K1 eigen route, K1' Pade scaling-and-squaring), pruning with P(t_b), and the per-sample sweep with the
+// end-point-conditioned uniformisation sampler (phm_exp.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "phm_device.h"
+#include "phm_sched.h"
+
+namespace phm {
+
+constexpr int UNIF_CAP = 300;     // newunifSample gives up beyond 300 jumps (src/phylomap.cpp:120)
+constexpr int EXP_BLOCK = 256;
+
+// P_b = | L diag(exp(d_k t_b)) R |, all row-major; out[b][i][j]
+hipError_t launch_expm_eigen(int n, const double* L, const double* R, const double* dvals, const double* t, int n_t,
+                             double* out, hipStream_t stream);
+
+// P_b = expmat(Q t_b): Pade(6) + s_b squarings; `s` holds the squaring counts, `work` 5*n*n doubles per matrix
+hipError_t launch_expm_pade(int n, const double* Q, const double* t, const int32_t* s, int n_t, double* work,
+                            double* out, uint32_t* err, hipStream_t stream);
+
+// PL[parent] = (P_a PL[child_a]) (.) (P_b PL[child_b]); PL is (2T-1) x n row-major, tips pre-filled one-hot
+hipError_t launch_exp_pl(int n, int n_node, int n_tips, const UpStep* up, const double* P, double* PL,
+                         hipStream_t stream);
+
+template <int NS>
+struct ExpParams {
+  int32_t n_tips, n_node, n_edge, root;      // root: internal index
+  int32_t N;                                 // samples
+  int32_t n_tiles;
+  uint32_t seed_lo, seed_hi, replica;
+  double poisson_rate;                       // -min diag(Q), src/phylomap.cpp:3008
+  double pid[NS];
+  const DownStep* down;
+  const double* P;                           // [n_edge][NS][NS]
+  const double* PL;                          // [2T-1][NS]
+  const double* edge_length;                 // [n_edge]
+  const double* colpow;                      // [UNIF_CAP+1][NS][NS]: (B^k e_j)[r], B = I + Q/poisson_rate
+  const double* B2;                          // [NS][NS]
+  const uint8_t* tips;                       // [n_tips] 0-based
+  uint8_t* nstate;                           // [tile][n_node][64]
+  double* times;                             // [tile][UNIF_CAP][64] jump-time scratch
+  double* out;                               // N x cols column-major
+  uint32_t* err;
+};
+
+template <int NS> hipError_t launch_exp_sample(const ExpParams<NS>& p, hipStream_t stream);
+
+}  // namespace phm

@@ -1,0 +1,345 @@
+// phm_exp.hip -- the matrix-exponentiation path (sumstatEXP, src/phylomap.cpp:2877-3051).
+//
+//   K1  expm_eigen_kernel : P_b = |L diag(exp(d_k t_b)) R|          matexp :2964-2968, abs :2980/:3042
+//   K1' expm_pade_kernel  : P_b = expmat(Q t_b), Pade(6) + squarings arma::expmat at :3226,:3243,:3359,:3383
+//   K2e exp_pl_kernel     : pruning with P(t_b)                      makePLold :2877-2895 / makePLexp :2899-2906
+//   K5  exp_sample_kernel : per sample: node states top-down (sampleinternalnodesEXP :2910-2961) and the
+//                           end-point-conditioned uniformisation sampler (newunifSample :93-208);
+//                           one LANE per i.i.d. sample, topology wave-uniform, B^k e_j table in LDS.
+// Summation orders follow the arithmetic spec, so results match the CPU oracle bit for bit.
+#include "phm_exp.h"
+
+namespace phm {
+
+// ------------------------------------------------------------------------------------------------
+// K1: eigen route.  Several small matrices share a workgroup; one thread per output element.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(EXP_BLOCK) void expm_eigen_kernel(int n, const double* __restrict__ L,
+                                                               const double* __restrict__ R,
+                                                               const double* __restrict__ dvals,
+                                                               const double* __restrict__ t, int n_t, int mpb,
+                                                               double* __restrict__ out) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  double* ex = reinterpret_cast<double*>(smem);          // [mpb][n]  exp(d_k t_b)
+  const int nn = n * n;
+  const int b0 = blockIdx.x * mpb;
+  for (int i = threadIdx.x; i < mpb * n; i += EXP_BLOCK) {
+    int q = i / n, k = i - q * n;
+    if (b0 + q < n_t) ex[i] = phm_exp(dvals[k] * t[b0 + q]);               // :2966
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < mpb * nn; idx += EXP_BLOCK) {
+    int q = idx / nn, e = idx - q * nn;
+    if (b0 + q >= n_t) continue;
+    int i = e / n, j = e - i * n;
+    const double* eq = ex + q * n;
+    double acc = (L[i * n] * eq[0]) * R[j];
+    for (int k = 1; k < n; ++k) acc += (L[i * n + k] * eq[k]) * R[k * n + j];
+    out[(size_t)(b0 + q) * nn + e] = fabs(acc);
+  }
+}
+
+hipError_t launch_expm_eigen(int n, const double* L, const double* R, const double* dvals, const double* t, int n_t,
+                             double* out, hipStream_t stream) {
+  int mpb = EXP_BLOCK / (n * n);
+  if (mpb < 1) mpb = 1;
+  int grid = (n_t + mpb - 1) / mpb;
+  hipLaunchKernelGGL(expm_eigen_kernel, dim3(grid), dim3(EXP_BLOCK), sizeof(double) * mpb * n, stream, n, L, R, dvals,
+                     t, n_t, mpb, out);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1': Pade(6) scaling-and-squaring, one workgroup per matrix, operands in a global workspace.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void block_gemm(const double* A, const double* B, double* C, int n) {
+  for (int e = threadIdx.x; e < n * n; e += EXP_BLOCK) {
+    int i = e / n, j = e - i * n;
+    double acc = A[i * n] * B[j];
+    for (int k = 1; k < n; ++k) acc += A[i * n + k] * B[k * n + j];
+    C[e] = acc;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(EXP_BLOCK) void expm_pade_kernel(int n, const double* __restrict__ Q,
+                                                              const double* __restrict__ t,
+                                                              const int32_t* __restrict__ sq, double* __restrict__ work,
+                                                              double* __restrict__ out, uint32_t* err) {
+  __shared__ double fv[128];
+  __shared__ int s_piv;
+  const int nn = n * n;
+  const int b = blockIdx.x;
+  double* A = work + (size_t)b * 5 * nn;
+  double *Em = A + nn, *Dm = A + 2 * nn, *X = A + 3 * nn, *T2 = A + 4 * nn;
+  const double tb = t[b];
+  const int s = sq[b];
+  const double sc = ldexp(1.0, s);
+  double c = 0.5;
+  for (int e = threadIdx.x; e < nn; e += EXP_BLOCK) {
+    double a = (Q[e] * tb) / sc;
+    int i = e / n, j = e - i * n;
+    A[e] = a; X[e] = a;
+    double ca = c * a;
+    Em[e] = (i == j) ? ca + 1.0 : ca;
+    Dm[e] = (i == j) ? -ca + 1.0 : -ca;
+  }
+  __syncthreads();
+  bool positive = true;
+  for (int i = 2; i <= 6; ++i) {
+    c = c * (double)(6 - i + 1) / (double)(i * (2 * 6 - i + 1));
+    block_gemm(A, X, T2, n);
+    for (int e = threadIdx.x; e < nn; e += EXP_BLOCK) {
+      double x = T2[e];
+      X[e] = x;
+      Em[e] += c * x;
+      if (positive) Dm[e] += c * x; else Dm[e] -= c * x;
+    }
+    __syncthreads();
+    positive = !positive;
+  }
+  // solve Dm * Xsol = Em (partial pivoting), Xsol written into X
+  for (int col = 0; col < n; ++col) {
+    if (threadIdx.x == 0) {
+      int piv = col; double best = fabs(Dm[col * n + col]);
+      for (int r = col + 1; r < n; ++r) { double v = fabs(Dm[r * n + col]); if (v > best) { best = v; piv = r; } }
+      if (!(best > 0.0)) atomicOr(err, DERR_ZERO_PROB);
+      s_piv = piv;
+    }
+    __syncthreads();
+    int piv = s_piv;
+    if (piv != col) {
+      for (int k = threadIdx.x; k < n; k += EXP_BLOCK) {
+        double a = Dm[col * n + k]; Dm[col * n + k] = Dm[piv * n + k]; Dm[piv * n + k] = a;
+        a = Em[col * n + k]; Em[col * n + k] = Em[piv * n + k]; Em[piv * n + k] = a;
+      }
+      __syncthreads();
+    }
+    for (int r = col + 1 + threadIdx.x; r < n; r += EXP_BLOCK) fv[r] = Dm[r * n + col] / Dm[col * n + col];
+    __syncthreads();
+    const int nr = n - col - 1;
+    for (int e = threadIdx.x; e < nr * n; e += EXP_BLOCK) {
+      int r = col + 1 + e / n, k = e % n;
+      double f = fv[r];
+      if (k >= col) Dm[r * n + k] -= f * Dm[col * n + k];
+      Em[r * n + k] -= f * Em[col * n + k];
+    }
+    __syncthreads();
+  }
+  for (int r = n - 1; r >= 0; --r) {
+    for (int k = threadIdx.x; k < n; k += EXP_BLOCK) {
+      double acc = Em[r * n + k];
+      for (int j = r + 1; j < n; ++j) acc -= Dm[r * n + j] * X[j * n + k];
+      X[r * n + k] = acc / Dm[r * n + r];
+    }
+    __syncthreads();
+  }
+  for (int i = 0; i < s; ++i) {
+    block_gemm(X, X, T2, n);
+    for (int e = threadIdx.x; e < nn; e += EXP_BLOCK) X[e] = T2[e];
+    __syncthreads();
+  }
+  for (int e = threadIdx.x; e < nn; e += EXP_BLOCK) out[(size_t)b * nn + e] = X[e];
+}
+
+hipError_t launch_expm_pade(int n, const double* Q, const double* t, const int32_t* s, int n_t, double* work,
+                            double* out, uint32_t* err, hipStream_t stream) {
+  hipLaunchKernelGGL(expm_pade_kernel, dim3(n_t), dim3(EXP_BLOCK), 0, stream, n, Q, t, s, work, out, err);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2e: pruning with P(t_b); the result is shared by every sample, so one thread walks the tree once.
+// ------------------------------------------------------------------------------------------------
+__global__ void exp_pl_kernel(int n, int n_node, int n_tips, const UpStep* __restrict__ up, const double* __restrict__ P,
+                              double* __restrict__ PL) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  for (int k = 0; k < n_node; ++k) {
+    const UpStep st = up[k];
+    const int ca = st.child[0] >= 0 ? st.child[0] + n_tips : ~st.child[0];
+    const int cb = st.child[1] >= 0 ? st.child[1] + n_tips : ~st.child[1];
+    const double* Pa = P + (size_t)st.edge[0] * n * n;
+    const double* Pb = P + (size_t)st.edge[1] * n * n;
+    const double* va = PL + (size_t)ca * n;
+    const double* vb = PL + (size_t)cb * n;
+    double* dst = PL + (size_t)(st.parent + n_tips) * n;
+    for (int i = 0; i < n; ++i) {
+      double a = Pa[i * n] * va[0];
+      for (int j = 1; j < n; ++j) a += Pa[i * n + j] * va[j];
+      double b = Pb[i * n] * vb[0];
+      for (int j = 1; j < n; ++j) b += Pb[i * n + j] * vb[j];
+      dst[i] = a * b;                                                           // :2903
+    }
+  }
+}
+
+hipError_t launch_exp_pl(int n, int n_node, int n_tips, const UpStep* up, const double* P, double* PL,
+                         hipStream_t stream) {
+  hipLaunchKernelGGL(exp_pl_kernel, dim3(1), dim3(64), 0, stream, n, n_node, n_tips, up, P, PL);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5: one lane per i.i.d. sample (treesampleEXP :2977-2996)
+// ------------------------------------------------------------------------------------------------
+// sampleOnce, src/phylomap.cpp:81-90: no sort, per-element division, strict '<'
+template <int NS>
+__device__ __forceinline__ int sample_once(const double (&w)[NS], double u, uint32_t& err) {
+  double total = w[0];
+#pragma unroll
+  for (int j = 1; j < NS; ++j) total += w[j];
+  double cum = 0.0;
+  int idx = NS;
+  bool found = false;
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+    cum += w[j] / total;
+    if (!found && u < cum) { idx = j; found = true; }
+  }
+  if (!found) { err |= DERR_SAMPLEONCE; idx = NS - 1; }
+  return idx;
+}
+
+template <int NS>
+__global__ __launch_bounds__(EXP_BLOCK) void exp_sample_kernel(ExpParams<NS> p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  constexpr int NCNT = NS * (NS - 1);
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int tile = blockIdx.x * (EXP_BLOCK / 64) + wave;
+  double* s_col = reinterpret_cast<double*>(smem);                       // [UNIF_CAP+1][NS][NS]
+  double* s_B2 = s_col + (UNIF_CAP + 1) * NS * NS;                       // [NS][NS]
+  double* s_dw = s_B2 + NS * NS + (size_t)wave * NS * 64;                // [NS][64]
+  uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_B2 + NS * NS + (size_t)(EXP_BLOCK / 64) * NS * 64) +
+                    (size_t)wave * NCNT * 64;
+  for (int i = threadIdx.x; i < (UNIF_CAP + 1) * NS * NS; i += EXP_BLOCK) s_col[i] = p.colpow[i];
+  if (threadIdx.x < NS * NS) s_B2[threadIdx.x] = p.B2[threadIdx.x];
+  __syncthreads();
+  if (tile >= p.n_tiles) return;
+
+  const int it = tile * 64 + lane;           // sample index = RNG iteration word
+  const bool valid = it < p.N;
+  uint32_t err = 0;
+  uint8_t* __restrict__ nst = p.nstate + (size_t)tile * p.n_node * 64;
+  double* __restrict__ tms = p.times + (size_t)tile * UNIF_CAP * 64;
+#pragma unroll
+  for (int c = 0; c < NS; ++c) s_dw[c * 64 + lane] = 0.0;
+#pragma unroll
+  for (int c = 0; c < NCNT; ++c) s_cnt[c * 64 + lane] = 0u;
+
+  {
+    double pr[NS];
+    const double* plr = p.PL + (size_t)(p.root + p.n_tips) * NS;
+#pragma unroll
+    for (int c = 0; c < NS; ++c) pr[c] = p.pid[c] * plr[c];                   // :2926
+    double u = stream_u(p.seed_lo, p.seed_hi, p.replica, (uint32_t)it, ENT_NODE | (uint32_t)(p.root + p.n_tips), 0);
+    nst[p.root * 64 + lane] = (uint8_t)sample_cat<NS>(pr, u, err);            // :2934
+  }
+
+  for (int k = 0; k < p.n_edge; ++k) {
+    const DownStep ds = p.down[k];
+    const int b = ds.edge;
+    const int a = nst[ds.parent * 64 + lane];
+    const double* Pb = p.P + (size_t)b * NS * NS;
+    int e;
+    if (ds.child >= 0) {
+      double pr[NS];
+      const double* plc = p.PL + (size_t)(ds.child + p.n_tips) * NS;
+#pragma unroll
+      for (int c = 0; c < NS; ++c) pr[c] = Pb[a * NS + c] * plc[c];           // :2953
+      double u = stream_u(p.seed_lo, p.seed_hi, p.replica, (uint32_t)it, ENT_NODE | (uint32_t)(ds.child + p.n_tips), 0);
+      e = sample_cat<NS>(pr, u, err);                                         // :2956
+      nst[ds.child * 64 + lane] = (uint8_t)e;
+    } else {
+      e = p.tips[~ds.child];
+    }
+
+    // ---- newunifSample(a, e, t_b, P_b[a,e]) :93-208 ----
+    const double tb = p.edge_length[b];
+    const double transProb = Pb[a * NS + e];
+    Stream sr;
+    sr.open(ENT_BUNIF | (uint32_t)b, (uint32_t)it, p.replica, p.seed_lo, p.seed_hi);
+    uint32_t dr = 0;
+    const double rU = sr.draw(dr++);                                          // :103
+    const double lam = p.poisson_rate * tb;
+    double pk = phm_exp(-lam);
+    double cum = 0.0;
+    if (a == e) cum = pk / transProb;                                         // :107
+    bool notExceed = !(cum > rU);
+    int nj = 0;
+    bool capped = false;
+    while (notExceed) {
+      nj++;
+      if (nj > UNIF_CAP) { capped = true; break; }                            // :120
+      pk = pk * lam / (double)nj;
+      double nextProb = pk * s_col[(nj * NS + e) * NS + a] / transProb;       // :127-128
+      cum += nextProb;
+      if (cum > rU) notExceed = false;
+    }
+    if (capped) { err |= DERR_UNIF_CAP; continue; }
+    if (nj == 0 || (nj == 1 && a == e)) {                                     // :138
+      s_dw[a * 64 + lane] += tb - 0.0;
+    } else if (nj == 1) {                                                     // :144
+      double tj = tb * sr.draw(dr++);                                         // :147
+      s_dw[a * 64 + lane] += tj - 0.0;
+      s_dw[e * 64 + lane] += tb - tj;
+      s_cnt[(a * (NS - 1) + (e > a ? e - 1 : e)) * 64 + lane] += 1u;
+    } else {
+      for (int i = 0; i < nj; ++i) {                                          // :151-152 jump times, ascending
+        double v = tb * sr.draw(dr++);
+        int j = i - 1;
+        while (j >= 0) {
+          double tj = tms[j * 64 + lane];
+          if (!(tj > v)) break;
+          tms[(j + 1) * 64 + lane] = tj;
+          --j;
+        }
+        tms[(j + 1) * 64 + lane] = v;
+      }
+      int prev = a, sprev = a;
+      double tprev = 0.0;
+      for (int i = 1; i <= nj; ++i) {
+        int di = e;
+        if (i < nj) {                                                         // :158-160
+          double pr[NS];
+          const double* beta = s_col + ((nj - i) * NS + e) * NS;
+          const double* row = s_B2 + prev * NS;
+#pragma unroll
+          for (int c = 0; c < NS; ++c) pr[c] = row[c] * beta[c];
+          di = sample_once<NS>(pr, sr.draw(dr++), err);
+        }
+        if (prev != di) {                                                     // :168-173 drop virtual jumps
+          double ti = tms[(i - 1) * 64 + lane];
+          s_dw[sprev * 64 + lane] += ti - tprev;
+          s_cnt[(sprev * (NS - 1) + (di > sprev ? di - 1 : di)) * 64 + lane] += 1u;
+          tprev = ti; sprev = di;
+        }
+        prev = di;
+      }
+      s_dw[sprev * 64 + lane] += tb - tprev;
+    }
+  }
+
+  if (valid) {
+#pragma unroll
+    for (int c = 0; c < NS; ++c) p.out[(size_t)c * p.N + it] = s_dw[c * 64 + lane];
+#pragma unroll
+    for (int c = 0; c < NCNT; ++c) p.out[(size_t)(NS + c) * p.N + it] = (double)s_cnt[c * 64 + lane];
+    if (err) atomicOr(p.err, err);
+  }
+}
+
+template <int NS>
+hipError_t launch_exp_sample(const ExpParams<NS>& p, hipStream_t stream) {
+  constexpr int W = EXP_BLOCK / 64;
+  size_t lds = sizeof(double) * ((size_t)(UNIF_CAP + 1) * NS * NS + NS * NS + (size_t)W * NS * 64) +
+               sizeof(uint32_t) * (size_t)W * NS * (NS - 1) * 64;
+  hipLaunchKernelGGL(exp_sample_kernel<NS>, dim3((p.n_tiles + W - 1) / W), dim3(EXP_BLOCK), lds, stream, p);
+  return hipGetLastError();
+}
+
+template hipError_t launch_exp_sample<2>(const ExpParams<2>&, hipStream_t);
+template hipError_t launch_exp_sample<3>(const ExpParams<3>&, hipStream_t);
+template hipError_t launch_exp_sample<4>(const ExpParams<4>&, hipStream_t);
+
+}  // namespace phm

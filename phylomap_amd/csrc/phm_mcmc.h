@@ -1,0 +1,51 @@
+// phm_mcmc.h -- kernel parameter block and launchers of the fixed-Q MCMC sweep (phm_mcmc.hip)
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "phm_device.h"
+#include "phm_sched.h"
+
+namespace phm {
+
+constexpr int MCMC_BLOCK = 256;   // 4 wavefronts share one copy of the LDS tables
+constexpr int MCMC_KTAB = 64;     // chain tables hold B^k e_j for k < KTAB; longer chains continue from the last entry
+
+// Passed by value: lives in the kernarg segment, so B / pid are read through scalar loads.
+template <int NS>
+struct McmcParams {
+  int32_t n_tips, n_node, n_edge, root;      // root: internal index
+  int32_t n_tiles, n_rep, n_rep_pad, replica_offset;
+  int32_t normalise, tips_per_replica, reduce, n_cols;
+  int32_t ktab;
+  uint32_t seed_lo, seed_hi;
+  int64_t rows;                              // dwell rows per replica tile
+  double B2[NS * NS];                        // dense B = I + Q/Omega, row-major
+  double Bc[NS * NS];                        // chain matrix: B, or B with entries <= 1e-7 dropped (SPARSE)
+  double scale[NS];                          // 1/(Omega + q_ss): Rcpp::rexp(n, rate) multiplies by 1/rate
+  double pid[NS];
+  const UpStep* up;
+  const DownStep* down;
+  const double* colpow;                      // [ktab][NS][NS]: (Bc^k e_j)[r]
+  const double* rowpow;                      // [ktab][NS][NS]: ((Bc^T)^k e_j)[c]
+  const uint8_t* tips;                       // 0-based tip states: [n_tips] or [tile][n_tips][64]
+  uint16_t* mcount;                          // [tile][n_edge][64] segments per branch
+  double* dwell0;                            // [tile][rows][64] ping
+  double* dwell1;                            //                  pong
+  double* PL;                                // [tile][n_node][NS][64] internal nodes only
+  uint8_t* nstate;                           // [tile][n_node][64] sampled internal-node states
+  double* stats;                             // reduce: [iter][tile][cols]; else [iter][cols][n_rep_pad]
+  uint32_t* err;
+  unsigned long long* segcnt;
+};
+
+template <int NS> size_t mcmc_lds_bytes(int ktab);
+template <int NS> hipError_t launch_mcmc(const McmcParams<NS>& p, int iter0, int n_iters, hipStream_t stream);
+
+hipError_t launch_mcmc_init(int n_edge, int n_tiles, int64_t rows, const DownStep* down, const int32_t* map_off,
+                            const double* maps, double* dwell0, uint16_t* mcount, hipStream_t stream);
+hipError_t launch_stats_reduce(const double* partial, int n_iters, int n_tiles, int n_cols, double* out,
+                               hipStream_t stream);
+
+}  // namespace phm

@@ -1,0 +1,340 @@
+// phm_mcmc.hip -- the fixed-Q MCMC sweep (sumstatMCMC / sumstatMCMC_bigtree / SPARSEsumstatMCMC)
+// as one CDNA4 kernel.
+//
+// Mapping (DESIGN.md "Kernel K-MCMC"): one LANE owns one replica (an independent chain / site); the 64
+// lanes of a wavefront walk the SAME tree in lock step, so
+//   * the topology (schedules) is wave-uniform -> scalar loads, no divergence from the tree shape;
+//   * every per-replica array is laid out [entity][state|slot][64 lanes] -> each access is one fully
+//     coalesced 512-B (f64) row of HBM;
+//   * no inter-lane or inter-workgroup communication exists: a replica never leaves its lane, so the
+//     whole N-loop runs on the device without grid synchronisation.
+// Q-derived tables (B, B^k e_j chains, rexp scales) are staged in LDS once per workgroup.
+//
+// What one iteration does for a replica (reference call stack: treesample, src/phylomap.cpp:775-785):
+//   up   : Felsenstein pruning with B^(m_b-1)           makePLrcpp :503-514 (_bigtree :516-529)
+//   root : root ~ pid (.) PL[root]                       sampleinternalnodesMCMC :618-627
+//   down : per branch in pre-order: child ~ row_ps(B^(m-1)) (.) PL[child]   :640-657
+//          write endpoints                               updatenodestates :460-475
+//          resample interior states                      resamplebranchstates :264-308
+//          drop self transitions, count transitions      shortener :44-73
+//          re-insert virtual jumps ~ Exp(Omega+q_ss)     sampleabranch :391-410
+//          accumulate dwell per state                    updatedwelltimes :745-757
+#include "phm_mcmc.h"
+
+namespace phm {
+
+template <int NS>
+__device__ __forceinline__ void matvec_u(const double* __restrict__ M, double (&v)[NS]) {
+  // v <- M v, left-to-right, unfused; M is wave-uniform (kernel argument -> SGPRs)
+  double y[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    double acc = M[i * NS] * v[0];
+#pragma unroll
+    for (int j = 1; j < NS; ++j) acc += M[i * NS + j] * v[j];
+    y[i] = acc;
+  }
+#pragma unroll
+  for (int i = 0; i < NS; ++i) v[i] = y[i];
+}
+
+// B^k applied to a child's partial-likelihood vector (mmmmvFORpl, src/phylomap.cpp:446-450)
+template <int NS>
+__device__ __forceinline__ void child_vector(const McmcParams<NS>& p, const double* __restrict__ s_col,
+                                             const double* __restrict__ PLt, const uint8_t* __restrict__ tips_t,
+                                             int child, int k, int lane, double (&v)[NS]) {
+  if (child < 0) {
+    // tip: PL is one-hot, so the chain is column `state` of the B^k table (bit-identical to running it)
+    int tip = ~child;
+    int st = p.tips_per_replica ? tips_t[tip * 64 + lane] : p.tips[tip];
+    int kt = k < p.ktab ? k : p.ktab - 1;
+    const double* src = s_col + (kt * NS + st) * NS;
+#pragma unroll
+    for (int c = 0; c < NS; ++c) v[c] = src[c];
+    for (int i = kt; i < k; ++i) matvec_u<NS>(p.Bc, v);
+  } else {
+#pragma unroll
+    for (int c = 0; c < NS; ++c) v[c] = PLt[(child * NS + c) * 64 + lane];
+    for (int i = 0; i < k; ++i) matvec_u<NS>(p.Bc, v);
+  }
+}
+
+template <int NS>
+__global__ __launch_bounds__(MCMC_BLOCK) void mcmc_sweep_kernel(McmcParams<NS> p, int iter0, int n_iters) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int tile = blockIdx.x * (MCMC_BLOCK / 64) + wave;
+  constexpr int NCNT = NS * (NS - 1);
+
+  // ---- LDS carve-up: tables shared by the workgroup, accumulators private to each lane ----
+  double* s_col = reinterpret_cast<double*>(smem);            // [ktab][NS][NS]  B^k e_j      (column chains)
+  double* s_row = s_col + p.ktab * NS * NS;                   // [ktab][NS][NS]  (B^T)^k e_j  (row chains)
+  double* s_B2 = s_row + p.ktab * NS * NS;                    // [NS][NS] dense B, rows for the forward step
+  double* s_scale = s_B2 + NS * NS;                           // [NS] 1/(Omega+q_ss)
+  double* s_dw = s_scale + NS + (size_t)wave * NS * 64;       // [NS][64] dwell accumulators of this wave
+  uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_scale + NS + (size_t)(MCMC_BLOCK / 64) * NS * 64) +
+                    (size_t)wave * NCNT * 64;                 // [NCNT][64] transition counters of this wave
+  for (int i = threadIdx.x; i < p.ktab * NS * NS; i += MCMC_BLOCK) { s_col[i] = p.colpow[i]; s_row[i] = p.rowpow[i]; }
+  if (threadIdx.x < NS * NS) s_B2[threadIdx.x] = p.B2[threadIdx.x];
+  if (threadIdx.x < NS) s_scale[threadIdx.x] = p.scale[threadIdx.x];
+  __syncthreads();
+  if (tile >= p.n_tiles) return;     // whole waves only; no barrier below this line
+
+  const int rep_local = tile * 64 + lane;
+  const uint32_t rep = (uint32_t)(p.replica_offset + rep_local);
+  const bool valid = rep_local < p.n_rep;
+  uint32_t err = 0;
+
+  double* __restrict__ PLt = p.PL + (size_t)tile * p.n_node * NS * 64;
+  uint8_t* __restrict__ nst = p.nstate + (size_t)tile * p.n_node * 64;
+  uint16_t* __restrict__ mct = p.mcount + (size_t)tile * p.n_edge * 64;
+  const uint8_t* __restrict__ tips_t = p.tips_per_replica ? p.tips + (size_t)tile * p.n_tips * 64 : p.tips;
+
+  for (int it = iter0; it < iter0 + n_iters; ++it) {
+    const double* __restrict__ dw_in = ((it & 1) ? p.dwell1 : p.dwell0) + (size_t)tile * p.rows * 64;
+    double* __restrict__ dw_out = ((it & 1) ? p.dwell0 : p.dwell1) + (size_t)tile * p.rows * 64;
+#pragma unroll
+    for (int c = 0; c < NS; ++c) s_dw[c * 64 + lane] = 0.0;
+#pragma unroll
+    for (int c = 0; c < NCNT; ++c) s_cnt[c * 64 + lane] = 0u;
+    uint32_t seg_rw = 0;
+
+    // ------------------------------ up sweep: partial likelihoods ------------------------------
+    for (int k = 0; k < p.n_node; ++k) {
+      const UpStep st = p.up[k];
+      double x[NS], y[NS];
+      int ma = mct[st.edge[0] * 64 + lane];
+      int mb = mct[st.edge[1] * 64 + lane];
+      child_vector<NS>(p, s_col, PLt, tips_t, st.child[1], mb - 1, lane, x);   // "first"  (:508)
+      child_vector<NS>(p, s_col, PLt, tips_t, st.child[0], ma - 1, lane, y);   // "second" (:509)
+#pragma unroll
+      for (int c = 0; c < NS; ++c) x[c] = x[c] * y[c];                         // :510
+      if (p.normalise) {                                                       // :525
+        double s = x[0];
+#pragma unroll
+        for (int c = 1; c < NS; ++c) s += x[c];
+#pragma unroll
+        for (int c = 0; c < NS; ++c) x[c] = x[c] / s;
+      }
+#pragma unroll
+      for (int c = 0; c < NS; ++c) PLt[(st.parent * NS + c) * 64 + lane] = x[c];
+    }
+
+    // ------------------------------ root state ------------------------------
+    {
+      double pr[NS];
+#pragma unroll
+      for (int c = 0; c < NS; ++c) pr[c] = p.pid[c] * PLt[(p.root * NS + c) * 64 + lane];   // :618
+      double u = stream_u(p.seed_lo, p.seed_hi, rep, (uint32_t)it, ENT_NODE | (uint32_t)(p.root + p.n_tips), 0);
+      nst[p.root * 64 + lane] = (uint8_t)sample_cat<NS>(pr, u, err);                        // :627
+    }
+
+    // ------------------------------ down sweep: node states + branch paths ------------------------------
+    for (int k = 0; k < p.n_edge; ++k) {
+      const DownStep ds = p.down[k];
+      const int b = ds.edge;
+      const int m = mct[b * 64 + lane];
+      const int ps = nst[ds.parent * 64 + lane];
+      int cs;
+      if (ds.child >= 0) {
+        // child ~ e_ps^T B^(m-1) (.) PL[child]   (Tvmmp :431-436, :651)
+        double w[NS];
+        int kk = m - 1;
+        int kt = kk < p.ktab ? kk : p.ktab - 1;
+        const double* src = s_row + (kt * NS + ps) * NS;
+#pragma unroll
+        for (int c = 0; c < NS; ++c) w[c] = src[c];
+        for (int i = kt; i < kk; ++i) {           // beyond the table: continue the same chain, w <- B^T w
+          double yv[NS];
+#pragma unroll
+          for (int c = 0; c < NS; ++c) {
+            double acc = p.Bc[c] * w[0];
+#pragma unroll
+            for (int r = 1; r < NS; ++r) acc += p.Bc[r * NS + c] * w[r];
+            yv[c] = acc;
+          }
+#pragma unroll
+          for (int c = 0; c < NS; ++c) w[c] = yv[c];
+        }
+#pragma unroll
+        for (int c = 0; c < NS; ++c) w[c] = w[c] * PLt[(ds.child * NS + c) * 64 + lane];
+        double u = stream_u(p.seed_lo, p.seed_hi, rep, (uint32_t)it, ENT_NODE | (uint32_t)(ds.child + p.n_tips), 0);
+        cs = sample_cat<NS>(w, u, err);                                        // :655
+        nst[ds.child * 64 + lane] = (uint8_t)cs;
+      } else {
+        int tip = ~ds.child;
+        cs = p.tips_per_replica ? tips_t[tip * 64 + lane] : p.tips[tip];        // :612
+      }
+
+      // ---- branch path: resample states, merge, count, re-insert virtual jumps ----
+      Stream su, se;
+      su.open(ENT_BSTATE | (uint32_t)b, (uint32_t)it, rep, p.seed_lo, p.seed_hi);
+      se.open(ENT_BEXP | (uint32_t)b, (uint32_t)it, rep, p.seed_lo, p.seed_hi);
+      uint32_t edraw = 0;
+      int outj = 0;          // next free slot of the new path
+      int mnew = 0;          // pieces emitted
+      bool stuck = false;
+      const int roff = ds.row_off;
+      const int cap = ds.cap;
+
+      auto finalize = [&](int s, double len) {
+        // virtual jumps on one merged segment (:391-410)
+        if (stuck || !(0.0 < len)) {
+          stuck = true;
+          dw_out[(roff + outj) * 64 + lane] = len;
+          s_dw[s * 64 + lane] += len;
+          ++mnew; if (outj + 1 < cap) ++outj; else err |= DERR_CAPACITY;
+          return;
+        }
+        const double scale = s_scale[s];
+        double tot = 0.0;
+        double acc = s_dw[s * 64 + lane];
+        while (tot < len) {
+          double rl = scale * (-phm_log(se.draw(edraw++)));                   // :398
+          double piece;
+          if ((tot + rl) < len) { piece = rl; tot += rl; }
+          else { piece = len - tot; tot = len; }
+          dw_out[(roff + outj) * 64 + lane] = piece;
+          acc += piece;                                                        // updatedwelltimes :752
+          ++mnew; if (outj + 1 < cap) ++outj; else err |= DERR_CAPACITY;
+        }
+        s_dw[s * 64 + lane] = acc;
+      };
+
+      int cur_s = (m == 1) ? cs : ps;            // updatenodestates :469-472 (m==1: child wins)
+      double cur_len = dw_in[roff * 64 + lane];
+      for (int i = 1; i <= m; ++i) {              // i == m: sentinel that flushes the last merged segment
+        int si = -1;
+        double di = 0.0;
+        if (i < m) {
+          if (i == m - 1) si = cs;
+          else {
+            // s_i ~ B[s_{i-1},:] (.) B^(m-i-1) e_end          (:290, :301-304)
+            int kk = m - i - 1;
+            double pr[NS];
+            if (kk < p.ktab) {
+              const double* beta = s_col + (kk * NS + cs) * NS;
+#pragma unroll
+              for (int c = 0; c < NS; ++c) pr[c] = beta[c];
+            } else {
+              const double* beta = s_col + ((p.ktab - 1) * NS + cs) * NS;
+#pragma unroll
+              for (int c = 0; c < NS; ++c) pr[c] = beta[c];
+              for (int q = p.ktab - 1; q < kk; ++q) matvec_u<NS>(p.Bc, pr);
+            }
+            const double* row = s_B2 + cur_s * NS;   // cur_s == s_{i-1}
+#pragma unroll
+            for (int c = 0; c < NS; ++c) pr[c] = row[c] * pr[c];
+            si = sample_cat<NS>(pr, su.draw((uint32_t)(i - 1)), err);
+          }
+          di = dw_in[(roff + i) * 64 + lane];
+        }
+        if (si == cur_s) cur_len = cur_len + di;                               // shortener :54
+        else {
+          finalize(cur_s, cur_len);
+          if (si >= 0) {
+            int col = cur_s * (NS - 1) + (si > cur_s ? si - 1 : si);           // shortener :65-66
+            s_cnt[col * 64 + lane] += 1u;
+          }
+          cur_s = si; cur_len = di;
+        }
+      }
+      mct[b * 64 + lane] = (uint16_t)(mnew < cap ? mnew : cap);
+      seg_rw += (uint32_t)(m + mnew);
+    }
+
+    // ------------------------------ statistics row of this iteration ------------------------------
+    if (p.reduce) {
+      double* dst = p.stats + ((size_t)it * p.n_tiles + tile) * p.n_cols;
+#pragma unroll
+      for (int c = 0; c < NS + NCNT; ++c) {
+        double v = 0.0;
+        if (valid) v = (c < NS) ? s_dw[c * 64 + lane] : (double)s_cnt[(c - NS) * 64 + lane];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == c) dst[c] = v;
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < NS + NCNT; ++c) {
+        double v = (c < NS) ? s_dw[c * 64 + lane] : (double)s_cnt[(c - NS) * 64 + lane];
+        p.stats[((size_t)it * p.n_cols + c) * p.n_rep_pad + rep_local] = v;
+      }
+    }
+    {
+      uint32_t v = valid ? seg_rw : 0u;
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane == 0) atomicAdd(p.segcnt, (unsigned long long)v);
+    }
+  }
+  if (err) atomicOr(p.err, err);
+}
+
+// Load the caller's initial paths (x$maps, makeabranch src/phylomap.cpp:24-34) into every replica.
+__global__ void mcmc_init_kernel(int n_edge, int n_tiles, int64_t rows, const DownStep* __restrict__ down,
+                                 const int32_t* __restrict__ map_off, const double* __restrict__ maps,
+                                 double* __restrict__ dwell0, uint16_t* __restrict__ mcount) {
+  const int lane = threadIdx.x & 63;
+  const int tile = blockIdx.y;
+  for (int k = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6); k < n_edge; k += gridDim.x * (blockDim.x / 64)) {
+    const DownStep ds = down[k];
+    const int o = map_off[ds.edge];
+    const int m = map_off[ds.edge + 1] - o;
+    double* dst = dwell0 + ((size_t)tile * rows + ds.row_off) * 64;
+    for (int i = 0; i < m; ++i) dst[i * 64 + lane] = maps[o + i];
+    mcount[((size_t)tile * n_edge + ds.edge) * 64 + lane] = (uint16_t)m;
+  }
+}
+
+// reduce mode: out[it][col] = sum over tiles of the per-wave partials, fixed order
+__global__ void stats_reduce_kernel(const double* __restrict__ partial, int n_iters, int n_tiles, int n_cols,
+                                    double* __restrict__ out) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_iters * n_cols) return;
+  int it = idx / n_cols, c = idx - it * n_cols;
+  double acc = 0.0;
+  for (int t = 0; t < n_tiles; ++t) acc += partial[((size_t)it * n_tiles + t) * n_cols + c];
+  out[idx] = acc;
+}
+
+template <int NS>
+size_t mcmc_lds_bytes(int ktab) {
+  return sizeof(double) * ((size_t)2 * ktab * NS * NS + NS * NS + NS + (size_t)(MCMC_BLOCK / 64) * NS * 64) +
+         sizeof(uint32_t) * (size_t)(MCMC_BLOCK / 64) * NS * (NS - 1) * 64;
+}
+
+template <int NS>
+hipError_t launch_mcmc(const McmcParams<NS>& p, int iter0, int n_iters, hipStream_t stream) {
+  const int waves_per_block = MCMC_BLOCK / 64;
+  dim3 grid((p.n_tiles + waves_per_block - 1) / waves_per_block);
+  size_t lds = mcmc_lds_bytes<NS>(p.ktab);
+  hipLaunchKernelGGL(mcmc_sweep_kernel<NS>, grid, dim3(MCMC_BLOCK), lds, stream, p, iter0, n_iters);
+  return hipGetLastError();
+}
+
+template hipError_t launch_mcmc<2>(const McmcParams<2>&, int, int, hipStream_t);
+template hipError_t launch_mcmc<3>(const McmcParams<3>&, int, int, hipStream_t);
+template hipError_t launch_mcmc<4>(const McmcParams<4>&, int, int, hipStream_t);
+template size_t mcmc_lds_bytes<2>(int);
+template size_t mcmc_lds_bytes<3>(int);
+template size_t mcmc_lds_bytes<4>(int);
+
+hipError_t launch_mcmc_init(int n_edge, int n_tiles, int64_t rows, const DownStep* down, const int32_t* map_off,
+                            const double* maps, double* dwell0, uint16_t* mcount, hipStream_t stream) {
+  dim3 grid(64, n_tiles);
+  hipLaunchKernelGGL(mcmc_init_kernel, grid, dim3(256), 0, stream, n_edge, n_tiles, rows, down, map_off, maps, dwell0,
+                     mcount);
+  return hipGetLastError();
+}
+
+hipError_t launch_stats_reduce(const double* partial, int n_iters, int n_tiles, int n_cols, double* out,
+                               hipStream_t stream) {
+  int total = n_iters * n_cols;
+  hipLaunchKernelGGL(stats_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, partial, n_iters, n_tiles,
+                     n_cols, out);
+  return hipGetLastError();
+}
+
+}  // namespace phm

@@ -1,0 +1,146 @@
+// phm_sched.cpp -- see phm_sched.h
+#include "phm_sched.h"
+
+#include <cmath>
+
+namespace phm {
+
+bool build_schedule(int32_t T, int32_t n_node, int32_t E, const int32_t* edge, Schedule& s, std::string& err) {
+  if (T < 2 || n_node != T - 1 || E != 2 * T - 2) {
+    err = "tree must be strictly bifurcating: Nnode = n_tips-1 and nrow(edge) = 2*n_tips-2";
+    return false;
+  }
+  const int32_t nn = 2 * T - 1;
+  const int32_t* e1 = edge;
+  const int32_t* e2 = edge + E;
+  s.n_tips = T; s.n_node = n_node; s.n_edge = E;
+  s.edge_of_child.assign(nn, -1);
+  std::vector<int32_t> kids(2 * (size_t)n_node, -1);
+  for (int32_t r = 0; r < E; ++r) {
+    int32_t p = e1[r], c = e2[r];
+    if (p <= T || p > nn || c < 1 || c > nn || c == p) { err = "edge row " + std::to_string(r + 1) + ": node id out of range"; return false; }
+    if (s.edge_of_child[c - 1] != -1) { err = "node " + std::to_string(c) + " has two parents"; return false; }
+    s.edge_of_child[c - 1] = r;
+    int32_t pi = p - T - 1;
+    if (kids[2 * pi] == -1) kids[2 * pi] = r;
+    else if (kids[2 * pi + 1] == -1) kids[2 * pi + 1] = r;
+    else { err = "node " + std::to_string(p) + " has more than two children"; return false; }
+  }
+  int32_t root = -1;
+  for (int32_t v = T; v < nn; ++v) {
+    if (kids[2 * (v - T) + 1] == -1) { err = "internal node " + std::to_string(v + 1) + " does not have two children"; return false; }
+    if (s.edge_of_child[v] == -1) {
+      if (root != -1) { err = "tree has more than one root"; return false; }
+      root = v - T;
+    }
+  }
+  if (root == -1) { err = "tree has no root"; return false; }
+  s.root = root;
+
+  // Is the edge table already a pre-order (every parent seen as a child earlier, or the root)?
+  std::vector<char> seen(nn, 0);
+  seen[root + T] = 1;
+  bool row_order = true;
+  for (int32_t r = 0; r < E && row_order; ++r) {
+    if (!seen[e1[r] - 1]) row_order = false;
+    seen[e2[r] - 1] = 1;
+  }
+  std::vector<int32_t> order;
+  order.reserve(E);
+  if (row_order) {
+    for (int32_t r = 0; r < E; ++r) order.push_back(r);
+  } else {
+    std::vector<int32_t> stack;
+    stack.push_back(kids[2 * root + 1]);
+    stack.push_back(kids[2 * root]);
+    while (!stack.empty()) {
+      int32_t r = stack.back(); stack.pop_back();
+      order.push_back(r);
+      int32_t c = e2[r];
+      if (c > T) { stack.push_back(kids[2 * (c - T - 1) + 1]); stack.push_back(kids[2 * (c - T - 1)]); }
+    }
+  }
+  if ((int32_t)order.size() != E) { err = "edge table is not a connected tree"; return false; }
+  s.down_is_row_order = row_order;
+
+  s.down.resize(E);
+  std::vector<int32_t> internal_order;   // internal nodes in the order the down sweep reaches them
+  internal_order.reserve(n_node);
+  internal_order.push_back(root);
+  std::vector<char> reached(nn, 0);
+  reached[root + T] = 1;
+  for (int32_t k = 0; k < E; ++k) {
+    int32_t r = order[k];
+    if (!reached[e1[r] - 1]) { err = "edge table is not a connected tree"; return false; }
+    reached[e2[r] - 1] = 1;
+    DownStep& d = s.down[k];
+    d.edge = r;
+    d.parent = e1[r] - T - 1;
+    d.child = (e2[r] > T) ? (e2[r] - T - 1) : ~(e2[r] - 1);
+    d.row_off = 0; d.cap = 0;
+    if (e2[r] > T) internal_order.push_back(e2[r] - T - 1);
+  }
+  s.up.resize(n_node);
+  for (int32_t k = 0; k < n_node; ++k) {     // reverse pre-order: children always before parents
+    int32_t v = internal_order[n_node - 1 - k];
+    UpStep& u = s.up[k];
+    u.parent = v;
+    for (int j = 0; j < 2; ++j) {
+      int32_t r = kids[2 * v + j];
+      u.edge[j] = r;
+      u.child[j] = (e2[r] > T) ? (e2[r] - T - 1) : ~(e2[r] - 1);
+    }
+  }
+  return true;
+}
+
+bool check_reference_orders(const Schedule& s, const int32_t* edge, const int32_t* nen,
+                            const int32_t* nodelist, int32_t root, std::string& err) {
+  const int32_t T = s.n_tips, E = s.n_edge, nn = 2 * T - 1;
+  const int32_t* e1 = edge;
+  const int32_t* e2 = edge + E;
+  if (root != s.root + T + 1) { err = "root does not match the edge table"; return false; }
+  if (nen) {
+    std::vector<char> used(E, 0), done(nn, 0);
+    for (int32_t v = 0; v < T; ++v) done[v] = 1;
+    for (int32_t i = 0; i < s.n_node; ++i) {
+      int32_t a = nen[2 * i] - 1, b = nen[2 * i + 1] - 1;
+      if (a < 0 || a >= E || b < 0 || b >= E || used[a] || used[b] || a == b) { err = "nen is not a permutation of the edge rows"; return false; }
+      used[a] = used[b] = 1;
+      if (e1[a] != e1[b]) { err = "nen: edges at positions " + std::to_string(2 * i + 1) + "," + std::to_string(2 * i + 2) + " are not siblings"; return false; }
+      if (!done[e2[a] - 1] || !done[e2[b] - 1]) { err = "nen: a parent is pruned before its children"; return false; }
+      done[e1[a] - 1] = 1;
+    }
+  }
+  if (nodelist) {
+    std::vector<char> have(nn, 0);
+    have[root - 1] = 1;
+    for (int32_t i = 0; i < s.n_node - 1; ++i) {
+      int32_t v = nodelist[i];
+      if (v <= T || v > nn || have[v - 1]) { err = "nodelist must list every non-root internal node once"; return false; }
+      int32_t r = s.edge_of_child[v - 1];
+      if (r < 0 || !have[e1[r] - 1]) { err = "nodelist: a node comes before its parent"; return false; }
+      have[v - 1] = 1;
+    }
+  }
+  return true;
+}
+
+int32_t poisson_capacity(double lambda, double tail) {
+  if (!(lambda > 0.0)) return 4;
+  if (!(tail > 0.0)) tail = 1e-16;
+  const double ltail = std::log(tail);
+  // P(X >= c) <= pmf(c) / (1 - lambda/(c+1)) for c+1 > lambda
+  int64_t c = (int64_t)std::ceil(lambda) + 1;
+  for (;; ++c) {
+    double lp = -lambda + (double)c * std::log(lambda) - std::lgamma((double)c + 1.0);
+    double ratio = lambda / ((double)c + 1.0);
+    if (ratio < 1.0 && lp - std::log1p(-ratio) < ltail) break;
+    if (c > (int64_t)(lambda * 4 + 4096)) break;
+  }
+  int64_t cap = c + 1 /* base segment */ + 2;
+  if (cap > 60000) cap = 60000;
+  return (int32_t)cap;
+}
+
+}  // namespace phm

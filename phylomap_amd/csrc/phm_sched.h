@@ -1,0 +1,54 @@
+// phm_sched.h -- host-side tree validation and sweep schedules.
+//
+// Replaces, in O(E), what the reference gets from R: the pruningwise edge order `nen`, the top-down
+// `nodelist` and `root` (R/sumstatMCMC.R:1-18, interpreted O(E^2) loops), plus the per-node linear edge
+// search inside the C++ node sweep (src/phylomap.cpp:643).
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace phm {
+
+struct UpStep {        // one internal node of the post-order (tips-to-root) sweep
+  int32_t parent;      // internal index (node id - n_tips - 1)
+  int32_t child[2];    // >= 0: internal index; < 0: ~tip (tip index 0-based)
+  int32_t edge[2];     // edge rows (0-based) leading to child[0], child[1]
+};
+
+struct DownStep {      // one branch of the pre-order (root-to-tips) sweep
+  int32_t edge;        // edge row (0-based)
+  int32_t parent;      // internal index of the parent node
+  int32_t child;       // >= 0 internal index; < 0: ~tip
+  int32_t row_off;     // first dwell row of this branch inside a replica tile
+  int32_t cap;         // slot capacity of this branch
+};
+
+struct Schedule {
+  int32_t n_tips = 0, n_node = 0, n_edge = 0;
+  int32_t root = 0;                 // internal index of the root
+  std::vector<UpStep> up;           // n_node entries, children before parents
+  std::vector<DownStep> down;       // n_edge entries, parents before children
+  std::vector<int32_t> edge_of_child;  // node id (0-based) -> edge row, -1 for the root
+  bool down_is_row_order = false;   // true when x$edge already is a valid pre-order (e.g. ape cladewise)
+  int64_t total_rows = 0;
+  int32_t max_cap = 0;
+};
+
+// Validates a strictly bifurcating rooted tree (src/phylomap.cpp:508-510 assumes it) and builds the
+// sweeps. `edge` is n_edge x 2 column-major, 1-based. Returns false and fills `err` on malformed input.
+bool build_schedule(int32_t n_tips, int32_t n_node, int32_t n_edge, const int32_t* edge, Schedule& s,
+                    std::string& err);
+
+// Checks that the caller's nen / nodelist / root (R/sumstatMCMC.R:1-18) describe this tree:
+// nen a permutation with sibling edges adjacent and children before parents, nodelist parents before
+// children, root the node that is nobody's child.
+bool check_reference_orders(const Schedule& s, const int32_t* edge, const int32_t* nen,
+                            const int32_t* nodelist, int32_t root, std::string& err);
+
+// Slot capacity for a branch whose segment count is 1 + Poisson(lambda) in stationarity:
+// smallest c with P(Poisson(lambda) >= c) < tail, plus the base segment and a margin of 2.
+int32_t poisson_capacity(double lambda, double tail);
+
+}  // namespace phm

@@ -1,0 +1,206 @@
+"""GPU parity: the HIP path (through the C-ABI) against the CPU oracle on the same seeded inputs.
+
+Bar (BASELINE.json north_star): transition counts bit-exact under a fixed seed, dwell times within 1e-10
+relative.  On cladewise trees the summation orders coincide and the dwell columns are bit-identical too."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from phylomap_amd import _lib, api, synth, treeorder
+
+pytestmark = pytest.mark.gpu
+
+
+def _orders(z):
+    return treeorder.pruningwiseedgeorder(z), treeorder.makenodelist(z), treeorder.myreorder(z)
+
+
+def _problem(n, tips, seed, omega_factor=1.25):
+    Q = {2: synth.config_Q(1), 3: np.array([[-.3, .2, .1], [.05, -.15, .1], [.2, .2, -.4]]), 4: synth.config_Q(2)}[n]
+    Omega = omega_factor * float(np.max(np.abs(np.diag(Q))))
+    pid = np.full(n, 1.0 / n)
+    z = synth.make_tree(tips, Q, Omega, seed, pid)
+    return z, Q, pid, Omega
+
+
+VARIANTS = [("sumstatMCMC", O.PLAIN), ("sumstatMCMC_bigtree", O.BIGTREE), ("SPARSEsumstatMCMC", O.SPARSE)]
+
+
+@pytest.mark.parametrize("n", [2, 3, 4])
+@pytest.mark.parametrize("fn,variant", VARIANTS)
+def test_mcmc_matches_oracle_small(n, fn, variant):
+    z, Q, pid, Omega = _problem(n, 24, 1234 + n)
+    nen, nodelist, root = _orders(z)
+    B = np.eye(n) + Q / Omega
+    N, S, seed = 40, 3, 0xC0FFEE
+    got = getattr(api, fn)(z, Q, pid, Omega, N, seed=seed, n_replicas=S)
+    assert got.shape == (S, N, n + n * (n - 1))
+    for r in range(S):
+        want, rc = O.maketreelistMCMC(z, Q, pid, B, Omega, nen, nodelist, root, N, variant=variant, seed=seed, replica=r)
+        assert rc == 0
+        np.testing.assert_array_equal(got[r][:, n:], want[:, n:])          # counts: bit-exact
+        np.testing.assert_array_equal(got[r][:, :n], want[:, :n])          # dwell: same summation order here
+        np.testing.assert_allclose(got[r][:, :n].sum(1), z["edge.length"].sum(), rtol=1e-12)
+
+
+def test_mcmc_single_chain_is_drop_in_shape():
+    z, Q, pid, Omega = _problem(4, 16, 77)
+    nen, nodelist, root = _orders(z)
+    got = api.sumstatMCMC(z, Q, pid, Omega, 25, seed=5)
+    want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(4) + Q / Omega, Omega, nen, nodelist, root, 25, seed=5)
+    assert rc == 0 and got.shape == (25, 16)
+    np.testing.assert_array_equal(got, want)
+
+
+def test_mcmc_chain_state_matches_oracle():
+    z, Q, pid, Omega = _problem(4, 40, 99)
+    nen, nodelist, root = _orders(z)
+    N, seed = 15, 42
+    eng = _lib.Engine(z, Q, pid, Omega, N, variant=_lib.PHM_MCMC_BIGTREE, seed=seed, n_replicas=70)
+    eng.run(7); eng.run(N - 7); eng.sync()
+    for r in (0, 63, 69):
+        want, rc, dump = O.maketreelistMCMC(z, Q, pid, np.eye(4) + Q / Omega, Omega, nen, nodelist, root, N,
+                                            variant=O.BIGTREE, seed=seed, replica=r, dump=True)
+        assert rc == 0
+        got = eng.dump(r)
+        np.testing.assert_array_equal(got["seg_count"], dump.seg_count)
+        np.testing.assert_array_equal(got["node_states"], dump.node_states)
+        for b in range(len(dump.seg_count)):
+            m = dump.seg_count[b]
+            np.testing.assert_array_equal(got["seg_dwell"][b, :m], dump.seg_dwell[b, :m])
+        np.testing.assert_array_equal(got["PL"], dump.PL)
+        np.testing.assert_array_equal(eng.stats(0, N)[r], want)
+    eng.close()
+
+
+def test_mcmc_non_cladewise_edge_order():
+    """Edge rows shuffled: the engine derives its own sweeps; counts stay exact, dwell within 1e-10."""
+    z, Q, pid, Omega = _problem(4, 30, 5)
+    perm = np.random.default_rng(3).permutation(len(z["maps"]))
+    z2 = dict(z)
+    z2["edge"] = z["edge"][perm]
+    z2["edge.length"] = z["edge.length"][perm]
+    z2["maps"] = [z["maps"][i] for i in perm]
+    z2["mapnames"] = [z["mapnames"][i] for i in perm]
+    z2["node.states"] = z["node.states"][perm]
+    nen, nodelist, root = _orders(z2)
+    got = api.sumstatMCMC(z2, Q, pid, Omega, 30, seed=9)
+    want, rc = O.maketreelistMCMC(z2, Q, pid, np.eye(4) + Q / Omega, Omega, nen, nodelist, root, 30, seed=9)
+    assert rc == 0
+    np.testing.assert_array_equal(got[:, 4:], want[:, 4:])
+    np.testing.assert_allclose(got[:, :4], want[:, :4], rtol=1e-10)
+
+
+def test_mcmc_config2_shape_matches_oracle():
+    """BASELINE config C2 (4 states, 1000 tips), a few iterations, first and last lane of a tile."""
+    z, Q, pid, Omega = synth.config_problem(2)
+    nen, nodelist, root = _orders(z)
+    N, seed = 12, 2024
+    eng = _lib.Engine(z, Q, pid, Omega, N, seed=seed, n_replicas=128)
+    eng.run(N); eng.sync()
+    st = eng.stats(0, N)
+    for r in (0, 63, 127):
+        want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(4) + Q / Omega, Omega, nen, nodelist, root, N, seed=seed, replica=r)
+        assert rc == 0
+        np.testing.assert_array_equal(st[r], want)
+    eng.close()
+
+
+def test_mcmc_per_site_tips_and_reduce():
+    z, Q, pid, Omega = _problem(4, 20, 8)
+    nen, nodelist, root = _orders(z)
+    S, N, seed = 5, 20, 11
+    rs = np.random.default_rng(0)
+    sites = rs.integers(1, 5, size=(S, 20)).astype(np.int32)
+    eng = _lib.Engine(z, Q, pid, Omega, N, seed=seed, n_replicas=S, tips_per_replica=True, states=sites)
+    eng.run(N); eng.sync()
+    per = eng.stats(0, N)
+    eng.close()
+    total = np.zeros((N, 16))
+    for r in range(S):
+        zr = dict(z); zr["states"] = sites[r]
+        want, rc = O.maketreelistMCMC(zr, Q, pid, np.eye(4) + Q / Omega, Omega, nen, nodelist, root, N, seed=seed, replica=r)
+        assert rc == 0
+        np.testing.assert_array_equal(per[r], want)
+        total += want
+    eng = _lib.Engine(z, Q, pid, Omega, N, seed=seed, n_replicas=S, tips_per_replica=True, states=sites, reduce=True)
+    eng.run(N); eng.sync()
+    red = eng.stats(0, N)
+    eng.close()
+    np.testing.assert_array_equal(red[:, 4:], total[:, 4:])
+    np.testing.assert_allclose(red[:, :4], total[:, :4], rtol=1e-12)
+
+
+def test_replica_offset_shards_like_one_device():
+    z, Q, pid, Omega = _problem(2, 18, 4)
+    a = api.sumstatMCMC(z, Q, pid, Omega, 10, seed=3, n_replicas=4)
+    b = api.sumstatMCMC(z, Q, pid, Omega, 10, seed=3, n_replicas=2, replica_offset=2)
+    np.testing.assert_array_equal(a[2:], b)
+
+
+@pytest.mark.parametrize("n", [2, 4])
+def test_exp_matches_oracle(n):
+    z, Q, pid, Omega = _problem(n, 30, 321 + n)
+    nen, nodelist, root = _orders(z)
+    lefts, rights, d = api.eigen_decompose(Q)
+    N, seed = 200, 17
+    got = api.sumstatEXP(z, Q, pid, N, seed=seed)
+    want, rc = O.maketreelistEXP(z, Q, pid, nen, nodelist, root, N, lefts, rights, d, seed=seed)
+    assert rc == 0
+    np.testing.assert_array_equal(got[:, n:], want[:, n:])
+    np.testing.assert_allclose(got[:, :n], want[:, :n], rtol=1e-10)
+    np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("n", [2, 4, 20, 61])
+def test_expm_routes(n):
+    from scipy.linalg import expm
+    Q = {2: synth.config_Q(1), 4: synth.config_Q(2), 20: synth.config_Q(5), 61: synth.config_Q(4)}[n]
+    t = np.concatenate([[0.0, 1e-6], np.random.default_rng(n).exponential(3.0, 37)])
+    P2, _ = api.expm_pade(Q, t)
+    for b in range(t.size):
+        want, rc = O.expmat_pade(Q * t[b])
+        assert rc == 0
+        np.testing.assert_array_equal(P2[b], want)
+        np.testing.assert_allclose(P2[b], expm(Q * t[b]), atol=1e-12)
+    if n != 4:     # make2sQ's Q is not symmetric but has a real spectrum; keep all four
+        pass
+    lefts, rights, d = api.eigen_decompose(Q)
+    P1, _ = api.expm_eigen(lefts, rights, d, t)
+    for b in range(t.size):
+        np.testing.assert_array_equal(P1[b], O.matexp(lefts, rights, np.diag(d), t[b]))
+        np.testing.assert_allclose(P1[b], expm(Q * t[b]), atol=1e-10)
+    np.testing.assert_allclose(P1, P2, atol=1e-10)
+
+
+def test_full_size_invariants():
+    """BASELINE sizes, size-independent properties: dwell row sums = tree length; counts are integers;
+    a second engine with the same seed reproduces the first bit for bit."""
+    z, Q, pid, Omega = synth.config_problem(2)
+    N = 30
+    outs = []
+    for _ in range(2):
+        eng = _lib.Engine(z, Q, pid, Omega, N, variant=_lib.PHM_MCMC_BIGTREE, seed=7, n_replicas=1024, reduce=True)
+        eng.run(N); eng.sync()
+        outs.append(eng.stats(0, N))
+        info = eng.info()
+        eng.close()
+    np.testing.assert_array_equal(outs[0], outs[1])
+    np.testing.assert_allclose(outs[0][:, :4].sum(1), 1024 * z["edge.length"].sum(), rtol=1e-11)
+    assert np.all(outs[0][:, 4:] == np.round(outs[0][:, 4:]))
+    assert info.seg_read > 0
+
+
+def test_errors_are_loud():
+    z, Q, pid, Omega = _problem(4, 12, 1)
+    with pytest.raises(_lib.PhmError) as e:
+        api.sumstatMCMC(z, Q, pid, 0.5 * Omega, 5)          # Omega below |q_ii|
+    assert e.value.status == 1
+    zbad = dict(z); zbad["edge"] = z["edge"].copy(); zbad["edge"][3, 0] = zbad["edge"][0, 0]
+    with pytest.raises((_lib.PhmError, ValueError)):
+        api.sumstatMCMC(zbad, Q, pid, Omega, 5)
+    Q5 = synth.tridiagonal_Q(5, 0.1)
+    z5 = synth.make_tree(10, Q5, 0.5, 3)
+    with pytest.raises(_lib.PhmError) as e:
+        api.sumstatMCMC(z5, Q5, np.full(5, .2), 0.5, 5)
+    assert e.value.status == 2
