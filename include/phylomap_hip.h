@@ -80,7 +80,8 @@ typedef struct phm_options {
   int32_t tips_per_replica;    /* 0: all replicas share x$states; 1: one tip vector per replica (sites) */
   int32_t device;              /* HIP device ordinal; -1 = current device */
   int32_t iters_per_launch;    /* MCMC iterations fused into one kernel launch; 0 -> default */
-  double  cap_tail;            /* per-branch capacity = Poisson(Omega*t_b) quantile at this tail; 0 -> 1e-16 */
+  double  cap_tail;            /* dwell-stream capacity of a 64-replica tile = sum over branches of the
+                                  1+Poisson(Omega*t_b) quantile at this tail; 0 -> 1e-3 */
   int32_t reserved[6];
 } phm_options;
 

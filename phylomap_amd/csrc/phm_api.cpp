@@ -55,7 +55,7 @@ int32_t select_device(int32_t device) {
 
 int32_t device_status(uint32_t derr) {
   if (derr & phm::DERR_ZERO_PROB) return fail(PHM_ERR_ZERO_PROB, "all-zero or non-finite probability vector while sampling a state (RcppArmadillo::sample would throw)");
-  if (derr & phm::DERR_CAPACITY) return fail(PHM_ERR_CAPACITY, "a branch outgrew its slot capacity; lower phm_options.cap_tail");
+  if (derr & phm::DERR_CAPACITY) return fail(PHM_ERR_CAPACITY, "a replica tile outgrew its dwell-stream capacity; lower phm_options.cap_tail");
   if (derr & phm::DERR_UNIF_CAP) return fail(PHM_ERR_UNIF_CAP, "newunifSample needed more than 300 jumps on a branch (src/phylomap.cpp:120)");
   if (derr & phm::DERR_SAMPLEONCE) return fail(PHM_ERR_ZERO_PROB, "sampleOnce ran past the last state (src/phylomap.cpp:85-89)");
   return PHM_OK;
@@ -236,21 +236,24 @@ int32_t phm_engine_create(const phm_tree* x, const phm_model* model, const phm_o
   phm::Schedule& s = e->sched;
   const int E = s.n_edge, T = s.n_tips;
 
-  // slot capacities: t_b = sum(x$maps[[b]]); segments ~ 1 + Poisson(Omega t_b)
+  // Capacity of a tile's dwell stream.  Branch b holds 1 + Poisson(Omega t_b) segments in stationarity
+  // (t_b = sum(x$maps[[b]])) and occupies max-over-64-lanes rows; provision the per-branch quantile at
+  // `cap_tail` (default 1e-3, i.e. beyond the expected maximum of 64 draws) and check at run time.
   int64_t rows = 0;
+  std::vector<int32_t> init_row(E);
+  int64_t init_rows = 0;
   for (int k = 0; k < E; ++k) {
-    phm::DownStep& d = s.down[k];
+    const phm::DownStep& d = s.down[k];
     double tb = 0.0;
     for (int i = x->map_off[d.edge]; i < x->map_off[d.edge + 1]; ++i) tb += x->maps[i];
     int m0 = x->map_off[d.edge + 1] - x->map_off[d.edge];
-    int cap = phm::poisson_capacity(model->Omega * tb, o.cap_tail);
-    cap = std::max(cap, m0 + 2);
-    d.row_off = (int32_t)rows; d.cap = cap;
-    rows += cap;
-    s.max_cap = std::max(s.max_cap, cap);
-    if (rows * 64 > 0x7fffff00ll) return fail(PHM_ERR_UNSUPPORTED, "tree too large: dwell rows per replica tile exceed 32-bit indexing");
+    init_row[k] = (int32_t)init_rows;
+    init_rows += m0;
+    rows += phm::poisson_capacity(model->Omega * tb, o.cap_tail > 0.0 ? o.cap_tail : 1e-3);
   }
-  s.total_rows = rows; e->rows = rows;
+  rows = std::max(rows + 64, init_rows);
+  if (rows * 64 > 0x7fffff00ll) return fail(PHM_ERR_UNSUPPORTED, "tree too large: dwell rows per replica tile exceed 32-bit indexing");
+  e->rows = rows;
 
   // tips (0-based u8)
   if (e->tips_per_replica) {
@@ -307,12 +310,14 @@ int32_t phm_engine_create(const phm_tree* x, const phm_model* model, const phm_o
   HIPCHK(hipMemset(e->d_nstate.p, 0, e->d_nstate.bytes));
 
   {   // initial paths -> every replica (makeabranch, src/phylomap.cpp:24-34, :901)
-    DevBuf d_off, d_maps;
+    DevBuf d_off, d_maps, d_irow;
+    HIPCHK(d_irow.alloc(sizeof(int32_t) * E));
+    HIPCHK(hipMemcpy(d_irow.p, init_row.data(), d_irow.bytes, hipMemcpyHostToDevice));
     HIPCHK(d_off.alloc(sizeof(int32_t) * (E + 1)));
     HIPCHK(d_maps.alloc(sizeof(double) * (size_t)x->map_off[E]));
     HIPCHK(hipMemcpy(d_off.p, x->map_off, d_off.bytes, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_maps.p, x->maps, d_maps.bytes, hipMemcpyHostToDevice));
-    HIPCHK(phm::launch_mcmc_init(E, e->tiles, rows, e->d_down.as<phm::DownStep>(), d_off.as<int32_t>(), d_maps.as<double>(),
+    HIPCHK(phm::launch_mcmc_init(E, e->tiles, rows, e->d_down.as<phm::DownStep>(), d_irow.as<int32_t>(), d_off.as<int32_t>(), d_maps.as<double>(),
                                  e->d_dw0.as<double>(), e->d_mcount.as<uint16_t>(), nullptr));
     HIPCHK(hipDeviceSynchronize());
   }
@@ -407,10 +412,14 @@ int32_t phm_engine_dump(phm_engine* e, int32_t replica, int32_t* seg_count, doub
     std::vector<double> dw((size_t)e->rows * 64);
     const double* src = ((e->iters_done & 1) ? e->d_dw1.as<double>() : e->d_dw0.as<double>()) + (size_t)tile * e->rows * 64;
     HIPCHK(hipMemcpy(dw.data(), src, sizeof(double) * dw.size(), hipMemcpyDeviceToHost));
+    size_t row = 0;     // replay the stream layout: branch down[k] occupies max-over-lanes(m) rows
     for (int k = 0; k < E; ++k) {
       const phm::DownStep& d = s.down[k];
       int m = std::min<int>(mc[(size_t)d.edge * 64 + lane], seg_cap);
-      for (int i = 0; i < m; ++i) seg_dwell[(size_t)d.edge * seg_cap + i] = dw[((size_t)d.row_off + i) * 64 + lane];
+      for (int i = 0; i < m; ++i) seg_dwell[(size_t)d.edge * seg_cap + i] = dw[(row + i) * 64 + lane];
+      int mx = 0;
+      for (int l = 0; l < 64; ++l) mx = std::max<int>(mx, mc[(size_t)d.edge * 64 + l]);
+      row += mx;
     }
   }
   auto tip_state = [&](int t) -> int {

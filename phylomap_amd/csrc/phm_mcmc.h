@@ -20,7 +20,7 @@ struct McmcParams {
   int32_t normalise, tips_per_replica, reduce, n_cols;
   int32_t ktab;
   uint32_t seed_lo, seed_hi;
-  int64_t rows;                              // dwell rows per replica tile
+  int64_t rows;                              // capacity (64-lane rows) of one tile's dwell stream
   double B2[NS * NS];                        // dense B = I + Q/Omega, row-major
   double Bc[NS * NS];                        // chain matrix: B, or B with entries <= 1e-7 dropped (SPARSE)
   double scale[NS];                          // 1/(Omega + q_ss): Rcpp::rexp(n, rate) multiplies by 1/rate
@@ -31,7 +31,7 @@ struct McmcParams {
   const double* rowpow;                      // [ktab][NS][NS]: ((Bc^T)^k e_j)[c]
   const uint8_t* tips;                       // 0-based tip states: [n_tips] or [tile][n_tips][64]
   uint16_t* mcount;                          // [tile][n_edge][64] segments per branch
-  double* dwell0;                            // [tile][rows][64] ping
+  double* dwell0;                            // [tile][rows][64] sequential dwell stream, ping
   double* dwell1;                            //                  pong
   double* PL;                                // [tile][n_node][NS][64] internal nodes only
   uint8_t* nstate;                           // [tile][n_node][64] sampled internal-node states
@@ -43,8 +43,9 @@ struct McmcParams {
 template <int NS> size_t mcmc_lds_bytes(int ktab);
 template <int NS> hipError_t launch_mcmc(const McmcParams<NS>& p, int iter0, int n_iters, hipStream_t stream);
 
-hipError_t launch_mcmc_init(int n_edge, int n_tiles, int64_t rows, const DownStep* down, const int32_t* map_off,
-                            const double* maps, double* dwell0, uint16_t* mcount, hipStream_t stream);
+hipError_t launch_mcmc_init(int n_edge, int n_tiles, int64_t rows, const DownStep* down, const int32_t* init_row,
+                            const int32_t* map_off, const double* maps, double* dwell0, uint16_t* mcount,
+                            hipStream_t stream);
 hipError_t launch_stats_reduce(const double* partial, int n_iters, int n_tiles, int n_cols, double* out,
                                hipStream_t stream);
 

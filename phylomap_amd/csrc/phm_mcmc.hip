@@ -38,6 +38,13 @@ __device__ __forceinline__ void matvec_u(const double* __restrict__ M, double (&
   for (int i = 0; i < NS; ++i) v[i] = y[i];
 }
 
+// wave-uniform maximum of a per-lane count (all 64 lanes active at the call sites)
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { int o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
+  return __builtin_amdgcn_readfirstlane(v);
+}
+
 // B^k applied to a child's partial-likelihood vector (mmmmvFORpl, src/phylomap.cpp:446-450)
 template <int NS>
 __device__ __forceinline__ void child_vector(const McmcParams<NS>& p, const double* __restrict__ s_col,
@@ -99,6 +106,7 @@ __global__ __launch_bounds__(MCMC_BLOCK) void mcmc_sweep_kernel(McmcParams<NS> p
 #pragma unroll
     for (int c = 0; c < NCNT; ++c) s_cnt[c * 64 + lane] = 0u;
     uint32_t seg_rw = 0;
+    int in_row = 0, out_row = 0;     // wave-uniform cursors into the sequential dwell streams
 
     // ------------------------------ up sweep: partial likelihoods ------------------------------
     for (int k = 0; k < p.n_node; ++k) {
@@ -175,16 +183,19 @@ __global__ __launch_bounds__(MCMC_BLOCK) void mcmc_sweep_kernel(McmcParams<NS> p
       int outj = 0;          // next free slot of the new path
       int mnew = 0;          // pieces emitted
       bool stuck = false;
-      const int roff = ds.row_off;
-      const int cap = ds.cap;
+      // The dwell lists of a tile form one sequential stream of 64-lane rows in sweep order: branch k
+      // occupies wave_max(m) rows of the input stream and wave_max(m') rows of the output stream.
+      const int roff = in_row;
+      const int woff = out_row;
+      const int cap = (int)p.rows - out_row;     // rows left in the output stream
 
       auto finalize = [&](int s, double len) {
         // virtual jumps on one merged segment (:391-410)
         if (stuck || !(0.0 < len)) {
           stuck = true;
-          dw_out[(roff + outj) * 64 + lane] = len;
+          if (outj < cap) dw_out[(woff + outj) * 64 + lane] = len; else err |= DERR_CAPACITY;
           s_dw[s * 64 + lane] += len;
-          ++mnew; if (outj + 1 < cap) ++outj; else err |= DERR_CAPACITY;
+          ++mnew; ++outj;
           return;
         }
         const double scale = s_scale[s];
@@ -195,9 +206,9 @@ __global__ __launch_bounds__(MCMC_BLOCK) void mcmc_sweep_kernel(McmcParams<NS> p
           double piece;
           if ((tot + rl) < len) { piece = rl; tot += rl; }
           else { piece = len - tot; tot = len; }
-          dw_out[(roff + outj) * 64 + lane] = piece;
+          if (outj < cap) dw_out[(woff + outj) * 64 + lane] = piece; else err |= DERR_CAPACITY;
           acc += piece;                                                        // updatedwelltimes :752
-          ++mnew; if (outj + 1 < cap) ++outj; else err |= DERR_CAPACITY;
+          ++mnew; ++outj;
         }
         s_dw[s * 64 + lane] = acc;
       };
@@ -240,8 +251,12 @@ __global__ __launch_bounds__(MCMC_BLOCK) void mcmc_sweep_kernel(McmcParams<NS> p
           cur_s = si; cur_len = di;
         }
       }
-      mct[b * 64 + lane] = (uint16_t)(mnew < cap ? mnew : cap);
+      if (mnew > 65535) { err |= DERR_CAPACITY; mnew = 65535; }
+      mct[b * 64 + lane] = (uint16_t)mnew;
       seg_rw += (uint32_t)(m + mnew);
+      in_row += wave_max(m);
+      out_row += wave_max(mnew);
+      if (out_row > (int)p.rows) out_row = (int)p.rows;
     }
 
     // ------------------------------ statistics row of this iteration ------------------------------
@@ -272,17 +287,19 @@ __global__ __launch_bounds__(MCMC_BLOCK) void mcmc_sweep_kernel(McmcParams<NS> p
   if (err) atomicOr(p.err, err);
 }
 
-// Load the caller's initial paths (x$maps, makeabranch src/phylomap.cpp:24-34) into every replica.
+// Load the caller's initial paths (x$maps, makeabranch src/phylomap.cpp:24-34) into every replica:
+// one sequential stream per tile in sweep order, init_row[k] = first row of branch down[k].
 __global__ void mcmc_init_kernel(int n_edge, int n_tiles, int64_t rows, const DownStep* __restrict__ down,
-                                 const int32_t* __restrict__ map_off, const double* __restrict__ maps,
-                                 double* __restrict__ dwell0, uint16_t* __restrict__ mcount) {
+                                 const int32_t* __restrict__ init_row, const int32_t* __restrict__ map_off,
+                                 const double* __restrict__ maps, double* __restrict__ dwell0,
+                                 uint16_t* __restrict__ mcount) {
   const int lane = threadIdx.x & 63;
   const int tile = blockIdx.y;
   for (int k = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6); k < n_edge; k += gridDim.x * (blockDim.x / 64)) {
     const DownStep ds = down[k];
     const int o = map_off[ds.edge];
     const int m = map_off[ds.edge + 1] - o;
-    double* dst = dwell0 + ((size_t)tile * rows + ds.row_off) * 64;
+    double* dst = dwell0 + ((size_t)tile * rows + init_row[k]) * 64;
     for (int i = 0; i < m; ++i) dst[i * 64 + lane] = maps[o + i];
     mcount[((size_t)tile * n_edge + ds.edge) * 64 + lane] = (uint16_t)m;
   }
@@ -321,11 +338,12 @@ template size_t mcmc_lds_bytes<2>(int);
 template size_t mcmc_lds_bytes<3>(int);
 template size_t mcmc_lds_bytes<4>(int);
 
-hipError_t launch_mcmc_init(int n_edge, int n_tiles, int64_t rows, const DownStep* down, const int32_t* map_off,
-                            const double* maps, double* dwell0, uint16_t* mcount, hipStream_t stream) {
+hipError_t launch_mcmc_init(int n_edge, int n_tiles, int64_t rows, const DownStep* down, const int32_t* init_row,
+                            const int32_t* map_off, const double* maps, double* dwell0, uint16_t* mcount,
+                            hipStream_t stream) {
   dim3 grid(64, n_tiles);
-  hipLaunchKernelGGL(mcmc_init_kernel, grid, dim3(256), 0, stream, n_edge, n_tiles, rows, down, map_off, maps, dwell0,
-                     mcount);
+  hipLaunchKernelGGL(mcmc_init_kernel, grid, dim3(256), 0, stream, n_edge, n_tiles, rows, down, init_row, map_off, maps,
+                     dwell0, mcount);
   return hipGetLastError();
 }
 

@@ -77,7 +77,7 @@ bool build_schedule(int32_t T, int32_t n_node, int32_t E, const int32_t* edge, S
     d.edge = r;
     d.parent = e1[r] - T - 1;
     d.child = (e2[r] > T) ? (e2[r] - T - 1) : ~(e2[r] - 1);
-    d.row_off = 0; d.cap = 0;
+    d.pad = 0;
     if (e2[r] > T) internal_order.push_back(e2[r] - T - 1);
   }
   s.up.resize(n_node);
@@ -127,7 +127,7 @@ bool check_reference_orders(const Schedule& s, const int32_t* edge, const int32_
 }
 
 int32_t poisson_capacity(double lambda, double tail) {
-  if (!(lambda > 0.0)) return 4;
+  if (!(lambda > 0.0)) return 1;
   if (!(tail > 0.0)) tail = 1e-16;
   const double ltail = std::log(tail);
   // P(X >= c) <= pmf(c) / (1 - lambda/(c+1)) for c+1 > lambda
@@ -138,7 +138,7 @@ int32_t poisson_capacity(double lambda, double tail) {
     if (ratio < 1.0 && lp - std::log1p(-ratio) < ltail) break;
     if (c > (int64_t)(lambda * 4 + 4096)) break;
   }
-  int64_t cap = c + 1 /* base segment */ + 2;
+  int64_t cap = c + 1 /* base segment */;
   if (cap > 60000) cap = 60000;
   return (int32_t)cap;
 }

@@ -21,8 +21,7 @@ struct DownStep {      // one branch of the pre-order (root-to-tips) sweep
   int32_t edge;        // edge row (0-based)
   int32_t parent;      // internal index of the parent node
   int32_t child;       // >= 0 internal index; < 0: ~tip
-  int32_t row_off;     // first dwell row of this branch inside a replica tile
-  int32_t cap;         // slot capacity of this branch
+  int32_t pad;
 };
 
 struct Schedule {
@@ -32,8 +31,6 @@ struct Schedule {
   std::vector<DownStep> down;       // n_edge entries, parents before children
   std::vector<int32_t> edge_of_child;  // node id (0-based) -> edge row, -1 for the root
   bool down_is_row_order = false;   // true when x$edge already is a valid pre-order (e.g. ape cladewise)
-  int64_t total_rows = 0;
-  int32_t max_cap = 0;
 };
 
 // Validates a strictly bifurcating rooted tree (src/phylomap.cpp:508-510 assumes it) and builds the
@@ -47,8 +44,8 @@ bool build_schedule(int32_t n_tips, int32_t n_node, int32_t n_edge, const int32_
 bool check_reference_orders(const Schedule& s, const int32_t* edge, const int32_t* nen,
                             const int32_t* nodelist, int32_t root, std::string& err);
 
-// Slot capacity for a branch whose segment count is 1 + Poisson(lambda) in stationarity:
-// smallest c with P(Poisson(lambda) >= c) < tail, plus the base segment and a margin of 2.
+// Upper quantile of the segment count 1 + Poisson(lambda) of a branch in stationarity:
+// 1 + smallest c with P(Poisson(lambda) >= c) < tail.
 int32_t poisson_capacity(double lambda, double tail);
 
 }  // namespace phm

@@ -96,14 +96,27 @@ def test_mcmc_config2_shape_matches_oracle():
     z, Q, pid, Omega = synth.config_problem(2)
     nen, nodelist, root = _orders(z)
     N, seed = 12, 2024
-    eng = _lib.Engine(z, Q, pid, Omega, N, seed=seed, n_replicas=128)
+    eng = _lib.Engine(z, Q, pid, Omega, N, variant=_lib.PHM_MCMC_BIGTREE, seed=seed, n_replicas=128)
     eng.run(N); eng.sync()
     st = eng.stats(0, N)
     for r in (0, 63, 127):
-        want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(4) + Q / Omega, Omega, nen, nodelist, root, N, seed=seed, replica=r)
+        want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(4) + Q / Omega, Omega, nen, nodelist, root, N,
+                                      variant=O.BIGTREE, seed=seed, replica=r)
         assert rc == 0
         np.testing.assert_array_equal(st[r], want)
     eng.close()
+
+
+def test_plain_variant_underflows_like_the_reference():
+    """sumstatMCMC does not rescale partial likelihoods (src/phylomap.cpp:510 vs :525): on a 1000-tip tree the
+    root vector underflows to zero and RcppArmadillo::sample throws; oracle and GPU both report it."""
+    z, Q, pid, Omega = synth.config_problem(2)
+    nen, nodelist, root = _orders(z)
+    _, rc = O.maketreelistMCMC(z, Q, pid, np.eye(4) + Q / Omega, Omega, nen, nodelist, root, 2, seed=1)
+    assert rc & O.ERR_ZERO_PROB
+    with pytest.raises(_lib.PhmError) as e:
+        api.sumstatMCMC(z, Q, pid, Omega, 2, seed=1)
+    assert e.value.status == 5
 
 
 def test_mcmc_per_site_tips_and_reduce():
@@ -156,6 +169,10 @@ def test_exp_matches_oracle(n):
 def test_expm_routes(n):
     from scipy.linalg import expm
     Q = {2: synth.config_Q(1), 4: synth.config_Q(2), 20: synth.config_Q(5), 61: synth.config_Q(4)}[n]
+    if n == 61:    # matexp handles a real spectrum only (R/sumstatEXP.R:26-29): use a reversible Q there
+        Q = (Q + Q.T) / 2
+        np.fill_diagonal(Q, 0.0)
+        np.fill_diagonal(Q, -Q.sum(1))
     t = np.concatenate([[0.0, 1e-6], np.random.default_rng(n).exponential(3.0, 37)])
     P2, _ = api.expm_pade(Q, t)
     for b in range(t.size):
@@ -163,8 +180,6 @@ def test_expm_routes(n):
         assert rc == 0
         np.testing.assert_array_equal(P2[b], want)
         np.testing.assert_allclose(P2[b], expm(Q * t[b]), atol=1e-12)
-    if n != 4:     # make2sQ's Q is not symmetric but has a real spectrum; keep all four
-        pass
     lefts, rights, d = api.eigen_decompose(Q)
     P1, _ = api.expm_eigen(lefts, rights, d, t)
     for b in range(t.size):
