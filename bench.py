@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Headline benchmark: stochastic-map realisations/s (branch x site paths sampled per second).
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches one rank per GPU with
+torch.distributed.run.  A *step* is one full MCMC sweep (pruning + node sampling + branch path resampling +
+sufficient statistics) over every replica resident on the GPU.  Workload at N = 1: BASELINE.json configs[1]
+(C2: 4-state Q = make2sQ(.1,.1,.2,.2,10), 1000-tip synthetic tree, sumstatMCMC), run with row-normalised
+partial likelihoods (the `_bigtree` arithmetic) because the plain variant underflows at 1000 tips in the
+reference as well.  Replicas (independent chains / sites) are sharded across ranks with no
+data-path collective; the only exchange is one RCCL all-reduce of the K x cols statistics at the end.
+Inputs are resident in HBM before the timed region starts.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (about 6.3 TB/s achievable)
+
+
+def cpu_baseline(z, Q, pid, Omega, target_s=12.0):
+    """The CPU oracle (oracle/phm_oracle.c, a restatement of src/phylomap.cpp) timed on one host core."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    from phylomap_amd import treeorder
+    nen, nodelist, root = treeorder.pruningwiseedgeorder(z), treeorder.makenodelist(z), treeorder.myreorder(z)
+    B = np.eye(Q.shape[0]) + Q / Omega
+    E = z["edge"].shape[0]
+
+    def run(n_it, faithful):
+        t0 = time.perf_counter()
+        _, rc = O.maketreelistMCMC(z, Q, pid, B, Omega, nen, nodelist, root, n_it, variant=O.BIGTREE, seed=1,
+                                   faithful_search=faithful)
+        dt = time.perf_counter() - t0
+        assert rc == 0
+        return dt
+
+    probe = run(100, False)
+    n_it = max(100, int(target_s / (probe / 100)))
+    dt = run(n_it, False)
+    n_f = max(50, n_it // 4)
+    dtf = run(n_f, True)
+    return {"value": E * n_it / dt, "unit": "branch-site realisations/s", "cores": 1, "kind": "port",
+            "sample": f"same C2 tree and Q, 1 chain, {n_it} sweeps (edge lookup table); "
+                      f"with the reference's O(E) edge search per node (src/phylomap.cpp:643): "
+                      f"{E * n_f / dtf:.4g}/s over {n_f} sweeps",
+            "faithful_value": E * n_f / dtf}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=240)
+    ap.add_argument("--warmup", type=int, default=24)
+    ap.add_argument("--replicas", type=int, default=0, help="replicas per GPU (0: sized from free HBM, max 262144)")
+    ap.add_argument("--config", type=int, default=2)
+    ap.add_argument("--ipl", type=int, default=8, help="sweeps fused per kernel launch")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    import torch
+    import torch.distributed as dist
+    from phylomap_amd import _lib, api, synth
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    z, Q, pid, Omega = synth.config_problem(args.config)
+    n = Q.shape[0]
+    E = z["edge"].shape[0]
+    cols = n + n * (n - 1)
+    K, W = args.steps, args.warmup
+
+    S = args.replicas
+    if S <= 0:
+        free_b, _ = torch.cuda.mem_get_info()
+        probe = _lib.Engine(z, Q, pid, Omega, 1, variant=_lib.PHM_MCMC_BIGTREE, seed=1, n_replicas=64, reduce=True,
+                            device=local_rank)
+        per_tile = probe.info().device_bytes
+        probe.close()
+        S = int(min(262144, (0.80 * free_b) // per_tile * 64))
+        S = max(64, S // 16384 * 16384 if S >= 16384 else S // 64 * 64)
+
+    eng = _lib.Engine(z, Q, pid, Omega, K + W, variant=_lib.PHM_MCMC_BIGTREE, seed=0x5EED0000 + args.config,
+                      n_replicas=S, replica_offset=rank * S, reduce=True, device=local_rank,
+                      iters_per_launch=args.ipl)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    eng.run(W, stream)
+    eng.sync()
+    seg0 = eng.info().seg_read
+
+    barrier()
+    t0 = time.perf_counter()
+    eng.run(K, stream)                                   # the hot path: K sweeps, N-loop on the device
+    red_ptr = eng.reduced_stats_device(W, K, stream)     # fixed-order reduction over this GPU's replicas
+    if world > 1:                                        # the only collective: K x cols f64 over RCCL/xGMI
+        class _Dev:
+            __cuda_array_interface__ = {"shape": (K, cols), "typestr": "<f8", "data": (red_ptr, False), "version": 3}
+        total = torch.as_tensor(_Dev(), device=torch.device("cuda", local_rank))
+        dist.all_reduce(total, op=dist.ReduceOp.SUM)
+    eng.sync()
+    barrier()
+    dt = time.perf_counter() - t0
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    info = eng.info()
+    units_rank = E * S * K                                # branch x replica paths sampled by this rank
+    seg = (info.seg_read - seg0) / units_rank             # measured mean (m_b + m'_b)
+    b_alg = 16 * n + 12 * seg + 26                        # algorithmic bytes per branch x replica x sweep
+    kernel_s = info.last_run_ms / 1e3
+    achieved = units_rank * b_alg / kernel_s / 1e9
+
+    stats = eng.stats(W, K) if world == 1 else None
+    if stats is not None:                                 # sanity: dwell row sums = S x tree length
+        assert np.allclose(stats[:, :n].sum(1), S * z["edge.length"].sum(), rtol=1e-9)
+
+    out = None
+    if rank == 0:
+        value = units_rank * world / dt
+        out = {
+            "metric": "stochastic-map realisations/sec (branches x sites sampled/s)",
+            "value": value, "unit": "branch-site realisations/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"C{args.config}: sumstatMCMC sweep (row-normalised PL), {n}-state Q, "
+                                   f"{z['states'].size}-tip synthetic tree, Omega*mean(t_b)=4",
+                       "n_states": n, "n_tips": int(z["states"].size), "branches": E,
+                       "replicas_per_gpu": S, "sweeps_per_launch": args.ipl,
+                       "parallelism": f"replica-sharded x{world}, one RCCL all-reduce of the statistics"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "mcmc_sweep_kernel<4>", "launches": info.last_run_launches,
+                         "avg_launch_ms": info.last_run_ms / max(1, info.last_run_launches),
+                         "alg_bytes_per_unit": b_alg, "mean_segments_read_plus_written": seg,
+                         "units_per_launch": E * S * args.ipl},
+            "hbm_bytes_resident": int(info.device_bytes),
+        }
+    eng.close()
+
+    if rank == 0:
+        # secondary metric of BASELINE.json: expm(Q t)/s (batched 4x4 transition matrices, kernel time)
+        t = np.random.default_rng(0).exponential(4.0 / Omega, 1 << 20)
+        lefts, rights, d = api.eigen_decompose(Q)
+        _, ms_e = api.expm_eigen(lefts, rights, d, t, device=local_rank)
+        _, ms_e = api.expm_eigen(lefts, rights, d, t, device=local_rank)
+        _, ms_p = api.expm_pade(Q, t[: 1 << 18], device=local_rank)
+        _, ms_p = api.expm_pade(Q, t[: 1 << 18], device=local_rank)
+        out["expm_per_s"] = {"eigen_route": t.size / (ms_e / 1e3), "pade_route": (1 << 18) / (ms_p / 1e3), "n_states": n}
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(z, Q, pid, Omega)
+            out["speedup_vs_cpu_1core"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -148,6 +148,9 @@ int32_t phm_engine_sync(phm_engine* e);
  * reduce = 0: out[r][ (col)*n + (i-iter0) ] for replica r (n x cols column-major per replica)
  * reduce = 1: one n x cols column-major matrix (sum over replicas) */
 int32_t phm_engine_read_stats(phm_engine* e, int32_t iter0, int32_t n, double* out);
+/* reduce = 1 only: run the tile reduction on `hip_stream` and return a DEVICE pointer to n x cols doubles,
+ * row-major [iteration][column] (for handing to RCCL without a host round trip); valid until the next call */
+int32_t phm_engine_reduced_stats_device(phm_engine* e, int32_t iter0, int32_t n, void* hip_stream, void** out_dev);
 /* chain state of one replica after the last iteration (tests): any pointer may be NULL.
  * seg_dwell: n_edge * seg_cap; node_states: 2*n_tips-1, 1-based; PL: (2*n_tips-1) x n row-major */
 int32_t phm_engine_dump(phm_engine* e, int32_t replica, int32_t* seg_count, double* seg_dwell, int32_t seg_cap,

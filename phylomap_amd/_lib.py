@@ -20,7 +20,7 @@ EXPORTS = [
     "phm_maketreelistMCMC", "phm_maketreelistMCMC_bigtree", "phm_SPARSEmaketreelistMCMC", "phm_maketreelistEXP",
     "phm_expm_eigen", "phm_expm_pade",
     "phm_engine_create", "phm_engine_run", "phm_engine_sync", "phm_engine_read_stats", "phm_engine_dump",
-    "phm_engine_info", "phm_engine_destroy",
+    "phm_engine_info", "phm_engine_destroy", "phm_engine_reduced_stats_device",
 ]
 
 
@@ -82,6 +82,8 @@ def load():
         L.phm_engine_dump.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_int32,
                                       C.POINTER(C.c_int32), C.POINTER(C.c_double)]
         L.phm_engine_info.argtypes = [C.c_void_p, C.POINTER(Info)]
+        L.phm_engine_reduced_stats_device.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                                      C.POINTER(C.c_void_p)]
         L.phm_engine_destroy.argtypes = [C.c_void_p]
         L.phm_engine_destroy.restype = None
         mc = [C.POINTER(Tree), C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
@@ -180,6 +182,13 @@ class Engine:
         buf = np.zeros((self.S, self.cols, n))
         check(load().phm_engine_read_stats(self.h, int(iter0), int(n), _p(buf, C.c_double)))
         return buf.transpose(0, 2, 1)
+
+    def reduced_stats_device(self, iter0, n, stream=None):
+        """Device pointer (int) to the (n, cols) row-major reduced statistics; see phm_engine_reduced_stats_device."""
+        ptr = C.c_void_p()
+        check(load().phm_engine_reduced_stats_device(self.h, int(iter0), int(n), C.c_void_p(stream) if stream else None,
+                                                     C.byref(ptr)))
+        return ptr.value
 
     def dump(self, replica=0, seg_cap=512):
         E, T, n = self.ft.E, self.ft.T, self.n

@@ -675,3 +675,18 @@ int32_t phm_maketreelistEXP(const phm_tree* x, int32_t n, const double* Q, const
 }
 
 }  // extern "C"
+
+// Device-resident reduced statistics (reduce mode): runs the fixed-order tile reduction on `hip_stream` and
+// returns a DEVICE pointer to n x cols doubles, row-major [iteration][column].  For multi-GPU callers that
+// hand the buffer to RCCL without a host round trip.  Valid until the next call on this engine.
+extern "C" int32_t phm_engine_reduced_stats_device(phm_engine* e, int32_t iter0, int32_t n, void* hip_stream,
+                                                   void** out_dev) {
+  if (!e || !out_dev) return fail(PHM_ERR_STATE, "engine/out is NULL");
+  if (!e->reduce) return fail(PHM_ERR_STATE, "engine was not created with reduce = 1");
+  if (iter0 < 0 || n < 1 || iter0 + n > e->iters_done) return fail(PHM_ERR_STATE, "statistics requested for iterations that have not run");
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(phm::launch_stats_reduce(e->d_stats.as<double>() + (size_t)iter0 * e->tiles * e->cols, n, e->tiles, e->cols,
+                                  e->d_red.as<double>(), reinterpret_cast<hipStream_t>(hip_stream)));
+  *out_dev = e->d_red.p;
+  return PHM_OK;
+}
