@@ -65,20 +65,17 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     import torch
     import torch.distributed as dist
-    from phylomap_amd import _lib, api, synth
+    from phylomap_amd import _lib, api, parallel, synth
 
+    rank, world, local_rank = parallel.env_rank()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    parallel.init_process_group("nccl")
 
     z, Q, pid, Omega = synth.config_problem(args.config)
     n = Q.shape[0]
@@ -97,7 +94,7 @@ def main():
         S = max(64, S // 16384 * 16384 if S >= 16384 else S // 64 * 64)
 
     eng = _lib.Engine(z, Q, pid, Omega, K + W, variant=_lib.PHM_MCMC_BIGTREE, seed=0x5EED0000 + args.config,
-                      n_replicas=S, replica_offset=rank * S, reduce=True, device=local_rank,
+                      n_replicas=S, replica_offset=parallel.weak_shard(S, rank)[0], reduce=True, device=local_rank,
                       iters_per_launch=args.ipl)
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -119,7 +116,7 @@ def main():
         class _Dev:
             __cuda_array_interface__ = {"shape": (K, cols), "typestr": "<f8", "data": (red_ptr, False), "version": 3}
         total = torch.as_tensor(_Dev(), device=torch.device("cuda", local_rank))
-        dist.all_reduce(total, op=dist.ReduceOp.SUM)
+        parallel.allreduce_stats(total)
     eng.sync()
     barrier()
     dt = time.perf_counter() - t0

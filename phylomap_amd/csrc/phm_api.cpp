@@ -219,9 +219,6 @@ int32_t phm_engine_create(const phm_tree* x, const phm_model* model, const phm_o
     }
   }
 
-  st = select_device(o.device);
-  if (st) return st;
-
   phm_engine* e = new phm_engine();
   std::unique_ptr<phm_engine> guard(e);
   e->n = n; e->cols = n + n * (n - 1); e->variant = model->variant;
@@ -229,11 +226,13 @@ int32_t phm_engine_create(const phm_tree* x, const phm_model* model, const phm_o
   e->max_iters = max_iters; e->reduce = o.reduce ? 1 : 0;
   e->ipl = o.iters_per_launch > 0 ? o.iters_per_launch : 8;
   e->tips_per_replica = o.tips_per_replica != 0;
-  HIPCHK(hipGetDevice(&e->device));
 
   std::string serr;
   if (!phm::build_schedule(x->n_tips, x->n_node, x->n_edge, x->edge, e->sched, serr)) return fail(PHM_ERR_BAD_INPUT, "tree: " + serr);
   phm::Schedule& s = e->sched;
+  st = select_device(o.device);          // every input check above runs without a device
+  if (st) return st;
+  HIPCHK(hipGetDevice(&e->device));
   const int E = s.n_edge, T = s.n_tips;
 
   // Capacity of a tile's dwell stream.  Branch b holds 1 + Poisson(Omega t_b) segments in stationarity

@@ -201,8 +201,11 @@ def simulate_tips(edge, edge_length, Q, pid, seed: int):
     return (node_state[1:T + 1] + 1).astype(np.int32)
 
 
-def make_tree(n_tips: int, Q, Omega: float, seed: int, pid=None, states=None):
-    """Full phylomap tree object with two-half-segment initial paths (R/simulate_2_state_tree.R:19-24)."""
+def make_tree(n_tips: int, Q, Omega: float, seed: int, pid=None, states=None, init_segments: int = 2):
+    """Full phylomap tree object.  Initial paths: ``init_segments`` equal pieces per branch, all in state 1 except
+    the last piece of a tip branch (two half-length pieces as in R/simulate_2_state_tree.R:19-24; 100 equal pieces
+    in R/Squamate_tree_setup.R:57).  With a banded Q the initial segment count must let B^(m-1) connect the
+    observed tip states, e.g. init_segments = n for a tridiagonal Q."""
     Q = np.asarray(Q, dtype=float)
     n = Q.shape[0]
     pid = np.full(n, 1.0 / n) if pid is None else np.asarray(pid, dtype=float)
@@ -217,8 +220,8 @@ def make_tree(n_tips: int, Q, Omega: float, seed: int, pid=None, states=None):
     for r in range(E):
         child = int(edge[r, 1])
         end = int(states[child - 1]) if child <= n_tips else 1
-        maps.append(np.array([lens[r] / 2, lens[r] / 2]))
-        mapnames.append(np.array([1, end], dtype=np.int32))
+        maps.append(np.full(init_segments, lens[r] / init_segments))
+        mapnames.append(np.array([1] * (init_segments - 1) + [end], dtype=np.int32))
         node_states[r, 1] = end
     return {"edge": edge, "Nnode": n_tips - 1, "edge.length": lens, "states": states,
             "maps": maps, "mapnames": mapnames, "node.states": node_states}
@@ -231,5 +234,5 @@ def config_problem(config: int, n_tips: int | None = None):
     Omega = 1.25 * float(np.max(np.abs(np.diag(Q))))
     n = Q.shape[0]
     pid = np.full(n, 1.0 / n)
-    z = make_tree(tips, Q, Omega, 0x5EED0000 + config, pid)
+    z = make_tree(tips, Q, Omega, 0x5EED0000 + config, pid, init_segments=(n if config == 5 else 2))
     return z, Q, pid, Omega

@@ -1,0 +1,145 @@
+"""CPU tests of the host logic and of the C-ABI surface (no compute calls: there is no GPU here)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from phylomap_amd import _lib, api, synth, treeorder
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _ape_pruningwise_scan(edge, ntip):
+    """Literal restatement of ape's published neworder_pruningwise scan (repeated passes over the cladewise edge
+    table collecting nodes whose child edges are all ready).  Input must already be cladewise."""
+    e1, e2 = [int(v) for v in edge[:, 0]], [int(v) for v in edge[:, 1]]
+    E = len(e1)
+    deg = {}
+    for p in e1:
+        deg[p] = deg.get(p, 0) + 1
+    ready = [c <= ntip for c in e2]
+    order = []
+    root_deg = deg[ntip + 1]
+    guard = 0
+    while len(order) < E - root_deg:
+        guard += 1
+        assert guard < 10 * E
+        n, node = 0, None
+        for i in range(E):
+            if not ready[i]:
+                continue
+            if n == 0:
+                node, n = e1[i], 1
+            elif e1[i] == node:
+                n += 1
+            else:
+                node, n = e1[i], 1
+            if n == deg[node] and node != ntip + 1:
+                for j in range(i + 1):
+                    if e2[j] == node:
+                        ready[j] = True
+                    if e1[j] == node and ready[j]:
+                        order.append(j)
+                        ready[j] = False
+                n = 0
+    order += [i for i in range(E) if ready[i]]
+    return np.asarray(order)
+
+
+@pytest.mark.parametrize("tips,seed", [(2, 1), (3, 2), (7, 3), (40, 4), (257, 5)])
+def test_pruningwise_order_properties_and_scan_twin(tips, seed):
+    edge, _ = synth.random_tree(tips, 1.0, seed)
+    z = {"edge": edge, "Nnode": tips - 1}
+    rows = treeorder.pruningwise_rows(edge)
+    E = edge.shape[0]
+    assert sorted(rows) == list(range(E))
+    done = set(range(1, tips + 1))
+    for i in range(tips - 1):                              # sibling pairs, children before parents (:503-514)
+        a, b = rows[2 * i], rows[2 * i + 1]
+        assert edge[a, 0] == edge[b, 0] and edge[a, 1] in done and edge[b, 1] in done
+        done.add(int(edge[a, 0]))
+    assert treeorder.myreorder(z) == tips + 1 == edge[rows[-1], 0]
+    nl = treeorder.makenodelist(z)
+    assert len(nl) == tips - 2 and len(set(nl)) == len(nl)
+    seen = {tips + 1}
+    parent = {int(c): int(p) for p, c in edge}
+    for v in nl:                                           # parents before children (:640-657)
+        assert parent[int(v)] in seen
+        seen.add(int(v))
+    np.testing.assert_array_equal(rows, _ape_pruningwise_scan(edge, tips))
+
+
+def test_pruningwise_on_shuffled_rows_maps_back():
+    edge, _ = synth.random_tree(30, 1.0, 9)
+    perm = np.random.default_rng(0).permutation(edge.shape[0])
+    e2 = edge[perm]
+    rows = treeorder.pruningwise_rows(e2)
+    for i in range(29):
+        assert e2[rows[2 * i], 0] == e2[rows[2 * i + 1], 0]
+    assert e2[rows[-1], 0] == 31
+
+
+def test_make2sQ_matches_definition():
+    Q = synth.make2sQ(.1, .1, .2, .2, 10)
+    want = np.array([[-.3, .1, .2, 0], [.1, -.3, 0, .2], [.2, 0, -1.2, 1.0], [0, .2, 1.0, -1.2]])
+    np.testing.assert_allclose(Q, want, atol=1e-15)
+    Q6 = synth.make2sQ(.1, .3, [.2, .4], [.5, .6], [2, 3])
+    assert Q6.shape == (6, 6) and np.allclose(Q6.sum(1), 0)
+    assert Q6[2, 4] == .4 and Q6[4, 2] == .6 and Q6[4, 5] == 3 * .1 and Q6[5, 4] == 3 * .3
+
+
+def test_synthetic_configs_are_deterministic():
+    z1, Q, pid, Om = synth.config_problem(2, n_tips=50)
+    z2, *_ = synth.config_problem(2, n_tips=50)
+    np.testing.assert_array_equal(z1["edge"], z2["edge"])
+    np.testing.assert_array_equal(z1["edge.length"], z2["edge.length"])
+    np.testing.assert_array_equal(z1["states"], z2["states"])
+    assert z1["edge"][0, 0] == 51 and z1["edge"].shape == (98, 2)
+    assert abs(Om - 1.25 * 1.2) < 1e-15
+    assert all(len(m) == 2 for m in z1["maps"])
+
+
+def test_cabi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "phylomap_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(phm_[A-Za-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 17
+    L = _lib.load()
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/phylomap_hip.h but not exported"
+    assert sorted(_lib.EXPORTS) == declared
+    assert L.phm_version() == 100
+    assert L.phm_status_string(6).decode() == "branch capacity exceeded"
+
+
+def test_no_cpu_fallback():
+    """Without a GPU every compute entry point must fail loudly, never compute on the host."""
+    if _lib.load().phm_device_count() > 0:
+        pytest.skip("GPU present")
+    z, Q, pid, Om = synth.config_problem(1, n_tips=8)
+    for fn in (api.sumstatMCMC, api.sumstatMCMC_bigtree, api.SPARSEsumstatMCMC):
+        with pytest.raises(_lib.PhmError) as e:
+            fn(z, Q, pid, Om, 3)
+        assert e.value.status == 3
+    with pytest.raises(_lib.PhmError):
+        api.sumstatEXP(z, Q, pid, 3)
+    with pytest.raises(_lib.PhmError):
+        api.expm_pade(Q, [1.0])
+
+
+def test_input_validation_happens_before_the_device():
+    z, Q, pid, Om = synth.config_problem(1, n_tips=8)
+    with pytest.raises(_lib.PhmError) as e:
+        api.sumstatMCMC(z, Q, pid, 0.01, 3)                 # Omega < |q_ii|
+    assert e.value.status == 1
+    zb = dict(z)
+    zb["states"] = z["states"].copy()
+    zb["states"][0] = 7
+    with pytest.raises(_lib.PhmError) as e:
+        api.sumstatMCMC(zb, Q, pid, Om, 3)
+    assert e.value.status == 1
+    zb = dict(z)
+    zb["edge"] = z["edge"].copy()
+    zb["edge"][2, 0] = zb["edge"][0, 0]                     # three children on one node
+    with pytest.raises((_lib.PhmError, ValueError)):
+        api.sumstatMCMC(zb, Q, pid, Om, 3)

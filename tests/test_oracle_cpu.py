@@ -1,0 +1,260 @@
+"""CPU tests of the oracle: known-answer vectors, the independent Python restatement, golden fixtures and the
+reference's own validation idea (EXP == MCMC == SPARSE in distribution, vignettes/phylomap_tutorial.Rnw:113-134)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+from scipy.linalg import expm
+
+import oracle_lib as O
+import pyref
+from phylomap_amd import api, synth, treeorder
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _orders(z):
+    return treeorder.pruningwiseedgeorder(z), treeorder.makenodelist(z), treeorder.myreorder(z)
+
+
+# ---- RNG and elementary functions ---------------------------------------------------------------------
+def test_philox_random123_known_answers():
+    assert O.philox([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert O.philox([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert O.philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    ctr = np.array([[1, 2, 3, 4], [0xdeadbeef, 5, 6, 7]], dtype=np.uint32)
+    got = synth.philox4x32_10(ctr, (11, 22))
+    for i in range(2):
+        assert list(got[i]) == O.philox([int(v) for v in ctr[i]], [11, 22])
+        assert list(pyref.philox(tuple(int(v) for v in ctr[i]), (11, 22))) == O.philox([int(v) for v in ctr[i]], [11, 22])
+
+
+def test_u01_is_open_interval_and_exact():
+    L = O.lib()
+    assert L.orc_u01(0, 0) == 2.0 ** -53
+    assert L.orc_u01(0xffffffff, 0xffffffff) == 1.0 - 2.0 ** -53
+    assert L.orc_u01(0x12345678, 0x9abcdef0) == pyref.u01(0x12345678, 0x9abcdef0)
+    # stream layout: draw d -> block d>>1, words (0,1) or (2,3)
+    o = O.philox([3, 7, 9, 2], [5, 6])
+    assert L.orc_stream_u(5, 6, 2, 9, 7, 6) == L.orc_u01(o[0], o[1])
+    assert L.orc_stream_u(5, 6, 2, 9, 7, 7) == L.orc_u01(o[2], o[3])
+
+
+def test_log_exp_accuracy_and_python_twin():
+    L = O.lib()
+    rs = np.random.default_rng(0)
+    xs = np.concatenate([np.exp(rs.uniform(-40, 0, 20000)), rs.uniform(0, 1, 20000), [2.0 ** -53, 1 - 2.0 ** -53, 0.5, 1.0]])
+    mine = np.array([L.orc_log(float(v)) for v in xs])
+    ref = np.log(xs)
+    ok = ref != 0
+    assert np.max(np.abs(mine[ok] - ref[ok]) / np.spacing(np.abs(ref[ok]))) <= 2.0
+    assert L.orc_log(1.0) == 0.0
+    for v in xs[:2000]:
+        assert L.orc_log(float(v)) == pyref.plog(float(v))
+    xe = np.concatenate([rs.uniform(-700, 5, 20000), rs.uniform(-1, 1, 20000), [0.0, -0.0, -745.0, -800.0]])
+    mine = np.array([L.orc_exp(float(v)) for v in xe])
+    ref = np.exp(xe)
+    ok = ref > 1e-300
+    assert np.max(np.abs(mine[ok] - ref[ok]) / np.spacing(ref[ok])) <= 2.0
+    assert L.orc_exp(0.0) == 1.0 and L.orc_exp(-800.0) == 0.0
+    for v in xe[:2000]:
+        assert L.orc_exp(float(v)) == pyref.pexp(float(v))
+
+
+# ---- per-function known answers (hand-derived) ---------------------------------------------------------
+def test_shortener_merges_and_counts():
+    # states 0,0,2,2,1,0 with n=3: merged 0(1.5) 2(3.0) 1(4.0) 0(8.0); transitions 0->2, 2->1, 1->0
+    d, s, row = O.shortener([1.0, 0.5, 1.0, 2.0, 4.0, 8.0], [0, 0, 2, 2, 1, 0], 3)
+    np.testing.assert_array_equal(d, [1.5, 3.0, 4.0, 8.0])
+    np.testing.assert_array_equal(s, [0, 2, 1, 0])
+    want = np.zeros(9)
+    want[3 + 0 * 2 + 1] = 1      # 0->2 : n + from(n-1) + (to-1)   (src/phylomap.cpp:65)
+    want[3 + 2 * 2 + 1] = 1      # 2->1 : n + from(n-1) + to       (:66)
+    want[3 + 1 * 2 + 0] = 1      # 1->0
+    np.testing.assert_array_equal(row, want)
+
+
+def test_mattospmat_threshold():
+    B = np.array([[0.5, 1e-7, 2e-7], [-0.1, 0.0, 1.0], [1e-8, 0.3, 0.7]])
+    out = np.zeros((3, 3))
+    import ctypes as C
+    O.lib().orc_matTospmat(B.ctypes.data_as(C.POINTER(C.c_double)), 3, out.ctypes.data_as(C.POINTER(C.c_double)))
+    np.testing.assert_array_equal(out, [[0.5, 0.0, 2e-7], [0.0, 0.0, 1.0], [0.0, 0.3, 0.7]])
+
+
+def _three_tip_tree(states, m=(2, 2, 2, 2)):
+    # ((t1,t2)n5,t3)n4 ; cladewise rows: 4->5, 5->1, 5->2, 4->3
+    edge = np.array([[4, 5], [5, 1], [5, 2], [4, 3]], dtype=np.int32)
+    lens = np.array([1.0, 2.0, 3.0, 4.0])
+    maps = [np.full(k, lens[i] / k) for i, k in enumerate(m)]
+    mapnames = [np.ones(k, dtype=np.int32) for k in m]
+    return {"edge": edge, "Nnode": 2, "edge.length": lens, "states": np.asarray(states, dtype=np.int32),
+            "maps": maps, "mapnames": mapnames, "node.states": np.ones((4, 2), dtype=np.int32)}
+
+
+def test_pruning_three_tips_by_hand():
+    z = _three_tip_tree([1, 2, 2], m=(3, 2, 1, 2))
+    B = np.array([[0.9, 0.1], [0.2, 0.8]])
+    nen, nodelist, root = _orders(z)
+    assert root == 4 and list(nodelist) == [5]
+    PL, rc = O.makePL(z, 2, B, nen, [3, 2, 1, 2], False)
+    assert rc == 0
+    e1, e2 = np.array([1.0, 0.0]), np.array([0.0, 1.0])
+    pl5 = (B @ e1) * e2                                   # t1 through B^1, t2 through B^0
+    pl4 = (B @ (B @ pl5)) * (B @ e2)                      # n5 through B^2, t3 through B^1
+    np.testing.assert_allclose(PL[4], pl5, rtol=1e-15)
+    np.testing.assert_allclose(PL[3], pl4, rtol=1e-15)
+    PLn, _ = O.makePL(z, 2, B, nen, [3, 2, 1, 2], True)
+    np.testing.assert_allclose(PLn[4], pl5 / pl5.sum(), rtol=1e-15)
+    assert abs(PLn[3].sum() - 1) < 1e-15
+
+
+def test_sweep_with_scripted_tape_by_hand():
+    """One sumstatMCMC sweep on the 3-tip tree with scripted draws, checked against a hand walk-through."""
+    z = _three_tip_tree([1, 1, 2], m=(1, 3, 2, 2))
+    Q = np.array([[-1.0, 1.0], [1.0, -1.0]])
+    Omega = 2.0
+    B = np.eye(2) + Q / Omega                             # all entries 0.5
+    pid = np.array([0.5, 0.5])
+    nen, nodelist, root = _orders(z)
+    # uniforms in reference order: root, node 5, then branch-state draws (only branch 2 has m=3 -> one draw)
+    tape_u = [0.1, 0.1, 0.9]
+    # exponentials: every merged segment draws until it overshoots; make each first draw overshoot
+    tape_e = [100.0] * 16
+    out, rc = O.maketreelistMCMC(z, Q, pid, B, Omega, nen, nodelist, root, 1, tape_u=tape_u, tape_e=tape_e)
+    assert rc == 0
+    # root: p = pid*PL[root] with u = .1 -> state 0 (first index whose cumulative share >= .1);
+    # node 5 likewise state 0.  branch 1 (5->t1, m=3): middle state ~ B[0,:]*B e_0 = (.25,.25), u=.9 -> state 1,
+    # so the path 0,1,0 has two transitions; every other branch has none except 4->t3 (0 -> 1).
+    row = out[0]
+    assert row[2] == 2.0 and row[3] == 1.0                # 0->1 twice (branch 1 and branch 4->t3), 1->0 once
+    np.testing.assert_allclose(row[:2].sum(), 10.0, rtol=1e-15)
+    # dwell in state 1: middle third of branch 5->t1 (2/3) + second half of 4->t3 (2.0)
+    np.testing.assert_allclose(row[1], 2.0 / 3 + 2.0, rtol=1e-15)
+
+
+def test_matexp_and_pade_against_scipy():
+    for Q in (synth.config_Q(1), synth.config_Q(2), synth.config_Q(5)):
+        lefts, rights, d = api.eigen_decompose(Q)
+        for t in (0.0, 0.3, 2.5, 40.0):
+            P = O.matexp(lefts, rights, np.diag(d), t)
+            np.testing.assert_allclose(P, expm(Q * t), atol=1e-11)
+            P2, rc = O.expmat_pade(Q * t)
+            assert rc == 0
+            np.testing.assert_allclose(P2, expm(Q * t), atol=1e-12)
+    Q = synth.config_Q(4)
+    P2, rc = O.expmat_pade(Q * 1.7)
+    np.testing.assert_allclose(P2, expm(Q * 1.7), atol=1e-12)
+    P = np.array(pyref.matexp(*[a.tolist() for a in api.eigen_decompose(synth.config_Q(2))[:2]],
+                              np.diag(api.eigen_decompose(synth.config_Q(2))[2]).tolist(), 0.7))
+    l, r, d = api.eigen_decompose(synth.config_Q(2))
+    np.testing.assert_array_equal(P, O.matexp(l, r, np.diag(d), 0.7))
+
+
+# ---- independent restatement: bit-for-bit -----------------------------------------------------------------
+@pytest.mark.parametrize("n,variant,ov", [(2, "plain", O.PLAIN), (4, "plain", O.PLAIN), (4, "bigtree", O.BIGTREE),
+                                          (4, "sparse", O.SPARSE), (3, "bigtree", O.BIGTREE)])
+def test_mcmc_oracle_equals_python_restatement(n, variant, ov):
+    Q = {2: synth.config_Q(1), 3: np.array([[-.3, .2, .1], [.05, -.15, .1], [.2, .2, -.4]]), 4: synth.config_Q(2)}[n]
+    Omega = 1.25 * float(np.max(np.abs(np.diag(Q))))
+    pid = np.full(n, 1.0 / n)
+    z = synth.make_tree(10, Q, Omega, 700 + n)
+    nen, nodelist, root = _orders(z)
+    N, seed, rep = 6, 99, 3
+    got, rc = O.maketreelistMCMC(z, Q, pid, np.eye(n) + Q / Omega, Omega, nen, nodelist, root, N, variant=ov, seed=seed, replica=rep)
+    assert rc == 0
+    want = pyref.sumstatMCMC(z, Q.tolist(), pid.tolist(), Omega, N, [int(v) for v in nen], [int(v) for v in nodelist],
+                             root, seed, rep, variant)
+    np.testing.assert_array_equal(got, np.array(want))
+    # the O(E) edge search of the reference (src/phylomap.cpp:643) changes cost, never results
+    got2, _ = O.maketreelistMCMC(z, Q, pid, np.eye(n) + Q / Omega, Omega, nen, nodelist, root, N, variant=ov, seed=seed,
+                                 replica=rep, faithful_search=True)
+    np.testing.assert_array_equal(got, got2)
+
+
+@pytest.mark.parametrize("n", [2, 4])
+def test_exp_oracle_equals_python_restatement(n):
+    Q = {2: synth.config_Q(1), 4: synth.config_Q(2)}[n]
+    Omega = 1.25 * float(np.max(np.abs(np.diag(Q))))
+    pid = np.full(n, 1.0 / n)
+    z = synth.make_tree(9, Q, Omega, 800 + n)
+    nen, nodelist, root = _orders(z)
+    lefts, rights, d = api.eigen_decompose(Q)
+    N, seed = 12, 5
+    got, rc = O.maketreelistEXP(z, Q, pid, nen, nodelist, root, N, lefts, rights, d, seed=seed, replica=1)
+    assert rc == 0
+    want = pyref.sumstatEXP(z, Q.tolist(), pid.tolist(), N, [int(v) for v in nen], [int(v) for v in nodelist], root,
+                            lefts.tolist(), rights.tolist(), np.diag(d).tolist(), seed, 1)
+    np.testing.assert_array_equal(got, np.array(want))
+    got2, _ = O.maketreelistEXP(z, Q, pid, nen, nodelist, root, N, lefts, rights, d, seed=seed, replica=1, recompute=True,
+                                faithful_search=True)
+    np.testing.assert_array_equal(got, got2)      # re-exponentiating every iteration (:2980) changes nothing
+
+
+# ---- golden fixtures --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "*.npz"))))
+def test_oracle_reproduces_golden(path):
+    from golden.make_golden import unpack_tree
+    g = np.load(path)
+    z = unpack_tree(g)
+    Q, pid, Omega, seed = g["Q"], g["pid"], float(g["Omega"]), int(g["seed"])
+    n = Q.shape[0]
+    B = np.eye(n) + Q / Omega
+    np.testing.assert_array_equal(treeorder.pruningwiseedgeorder(z), g["nen"])
+    for key, var in (("mcmc", O.PLAIN), ("bigtree", O.BIGTREE), ("sparse", O.SPARSE)):
+        for r in (0, 5):
+            out, rc = O.maketreelistMCMC(z, Q, pid, B, Omega, g["nen"], g["nodelist"], int(g["root"]), 24, variant=var,
+                                         seed=seed, replica=r)
+            assert rc == 0
+            np.testing.assert_array_equal(out, g[f"{key}_r{r}"])
+    out, rc = O.maketreelistEXP(z, Q, pid, g["nen"], g["nodelist"], int(g["root"]), 48, g["lefts"], g["rights"], g["d"], seed=seed)
+    assert rc == 0
+    np.testing.assert_array_equal(out, g["exp_r0"])
+
+
+# ---- invariants and the reference's statistical cross-check ------------------------------------------------
+def test_invariants():
+    z, Q, pid, Omega = synth.config_problem(2, n_tips=60)
+    nen, nodelist, root = _orders(z)
+    out, rc, dump = O.maketreelistMCMC(z, Q, pid, np.eye(4) + Q / Omega, Omega, nen, nodelist, root, 30, variant=O.BIGTREE,
+                                       seed=4, dump=True)
+    assert rc == 0
+    np.testing.assert_allclose(out[:, :4].sum(1), z["edge.length"].sum(), rtol=1e-12)
+    assert np.all(out[:, 4:] == np.round(out[:, 4:])) and np.all(out >= 0)
+    np.testing.assert_array_equal(dump.node_states[:60], z["states"])                      # tips never change (:612)
+    for b in range(len(dump.seg_count)):                                                   # endpoints = node states (:468-472)
+        m = dump.seg_count[b]
+        assert dump.seg_state[b, 0] + 1 == dump.node_states[z["edge"][b, 0] - 1] or m == 1
+        assert dump.seg_state[b, m - 1] + 1 == dump.node_states[z["edge"][b, 1] - 1]
+        np.testing.assert_allclose(dump.seg_dwell[b, :m].sum(), z["edge.length"][b], rtol=1e-12)
+    # positive rescaling of PL rows does not change the sampler (:525 vs :510): plain == bigtree on a small tree
+    a, _ = O.maketreelistMCMC(z, Q, pid, np.eye(4) + Q / Omega, Omega, nen, nodelist, root, 5, variant=O.PLAIN, seed=4)
+    np.testing.assert_array_equal(a[:, 4:], out[:5, 4:])
+
+
+def test_exp_mcmc_sparse_agree_in_distribution():
+    """vignettes/phylomap_tutorial.Rnw:113-134: total jump counts from EXP, MCMC and SPARSE must agree."""
+    Q = synth.tridiagonal_Q(6, 0.05)
+    Omega = 0.2
+    pid = np.full(6, 1 / 6)
+    z = synth.make_tree(14, Q, 1.0, 31, pid, init_segments=6)
+    nen, nodelist, root = _orders(z)
+    lefts, rights, d = api.eigen_decompose(Q)
+    B = np.eye(6) + Q / Omega
+    ex, rc = O.maketreelistEXP(z, Q, pid, nen, nodelist, root, 6000, lefts, rights, d, seed=1)
+    assert rc == 0
+    chains = {}
+    for name, var in (("mcmc", O.PLAIN), ("sparse", O.SPARSE)):
+        out, rc = O.maketreelistMCMC(z, Q, pid, B, Omega, nen, nodelist, root, 12000, variant=var, seed=2)
+        assert rc == 0
+        chains[name] = out[2000:]
+    je = ex[:, 6:].sum(1)
+    se = je.std() / np.sqrt(je.size)
+    for name, out in chains.items():
+        jm = out[:, 6:].sum(1)
+        # chain is autocorrelated: allow a generous 6 sigma of the (inflated) standard error
+        sm = 4 * jm.std() / np.sqrt(jm.size)
+        assert abs(jm.mean() - je.mean()) < 6 * np.hypot(se, sm), (name, jm.mean(), je.mean())
+        np.testing.assert_allclose(out[:, :6].mean(0), ex[:, :6].mean(0), rtol=0.1, atol=0.5)
