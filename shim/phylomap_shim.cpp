@@ -1,0 +1,127 @@
+// phylomap_shim.cpp -- the ONLY file that includes R headers.  Replaces src/RcppExports.cpp for the hot-path
+// symbols: same `.Call` names, same argument order (src/RcppExports.cpp:11,34,57,80; R/RcppExports.R:4-22), so
+// R/sumstat*.R and user code run unchanged.  Each export unpacks the SEXPs into the plain structs of
+// include/phylomap_hip.h, calls the C-ABI, and returns a fresh N x cols numeric matrix.
+//
+// NOT compiled in this repository's CI: R / Rcpp are not installed in the build image.  Build inside the
+// phylomap package with  PKG_CPPFLAGS=-I<repo>/include  PKG_LIBS=-L<repo>/phylomap_amd -lphylomap_hip.
+#include <Rcpp.h>
+
+#include <vector>
+
+#include "phylomap_hip.h"
+
+using namespace Rcpp;
+
+namespace {
+
+struct FlatTree {
+  std::vector<int32_t> edge, states, map_off, mapnames;
+  std::vector<double> edge_length, maps;
+  phm_tree t;
+  explicit FlatTree(List x) {
+    IntegerMatrix e = as<IntegerMatrix>(x["edge"]);                 // src/phylomap.cpp:904
+    IntegerVector st = as<IntegerVector>(x["states"]);              // :910 (REALSXP in the shipped RDS: coerced)
+    List m = x["maps"], mn = x["mapnames"];                         // :896-897
+    edge.assign(e.begin(), e.end());                                // column-major, 1-based
+    states.assign(st.begin(), st.end());
+    map_off.push_back(0);
+    for (int b = 0; b < m.size(); ++b) {
+      NumericVector d = as<NumericVector>(m[b]);
+      IntegerVector s = as<IntegerVector>(mn[b]);
+      if (d.size() != s.size()) stop("maps[[%d]] and mapnames[[%d]] differ in length", b + 1, b + 1);
+      maps.insert(maps.end(), d.begin(), d.end());
+      mapnames.insert(mapnames.end(), s.begin(), s.end());
+      map_off.push_back((int32_t)maps.size());
+    }
+    if (x.containsElementNamed("edge.length")) {                    // :3034
+      NumericVector el = as<NumericVector>(x["edge.length"]);
+      edge_length.assign(el.begin(), el.end());
+    }
+    t.n_tips = (int32_t)states.size();
+    t.n_node = as<int>(x["Nnode"]);                                 // :907
+    t.n_edge = e.nrow();
+    t.edge = edge.data();
+    t.edge_length = edge_length.empty() ? nullptr : edge_length.data();
+    t.states = states.data();
+    t.map_off = map_off.data();
+    t.maps = maps.data();
+    t.mapnames = mapnames.data();
+  }
+};
+
+// Called inside the RNGScope (src/RcppExports.cpp:38): two draws from R's stream seed Philox, so
+// set.seed() keeps controlling the result.  options(phylomap.hip.replicas=, phylomap.hip.device=) are optional.
+phm_options options_from_R() {
+  phm_options o = {};
+  uint64_t hi = (uint64_t)(unif_rand() * 4294967296.0), lo = (uint64_t)(unif_rand() * 4294967296.0);
+  o.seed = (hi << 32) | lo;
+  o.n_replicas = 1;
+  o.device = -1;
+  Environment base("package:base");
+  Function getOption = base["getOption"];
+  o.device = as<int>(getOption("phylomap.hip.device", -1));
+  return o;
+}
+
+void check(int32_t st) {
+  if (st != PHM_OK) stop("phylomap_hip: %s: %s", phm_status_string(st), phm_last_error());   // END_RCPP turns it into an R error
+}
+
+typedef int32_t (*mcmc_fn)(const phm_tree*, int32_t, const double*, const double*, const double*, double,
+                           const int32_t*, const int32_t*, int32_t, int32_t, const phm_options*, double*);
+
+SEXP run_mcmc(mcmc_fn fn, SEXP xSEXP, SEXP QSEXP, SEXP pidSEXP, SEXP BSEXP, SEXP OmegaSEXP, SEXP nenSEXP,
+              SEXP nodelistSEXP, SEXP rootSEXP, SEXP NSEXP) {
+  RNGScope scope;
+  FlatTree ft(as<List>(xSEXP));
+  NumericMatrix Q(QSEXP), B(BSEXP);
+  NumericVector pid(pidSEXP);
+  IntegerVector nen(nenSEXP), nodelist(nodelistSEXP);
+  const int n = Q.nrow(), N = as<int>(NSEXP);
+  NumericMatrix out(N, n + n * (n - 1));                            // :926
+  phm_options o = options_from_R();
+  check(fn(&ft.t, n, Q.begin(), pid.begin(), B.begin(), as<double>(OmegaSEXP), nen.begin(), nodelist.begin(),
+           as<int>(rootSEXP), N, &o, out.begin()));
+  return out;
+}
+
+}  // namespace
+
+RcppExport SEXP phylomap_maketreelistMCMC(SEXP x, SEXP Q, SEXP pid, SEXP B, SEXP Omega, SEXP nen, SEXP nodelist,
+                                          SEXP root, SEXP N) {
+  BEGIN_RCPP
+  return run_mcmc(phm_maketreelistMCMC, x, Q, pid, B, Omega, nen, nodelist, root, N);
+  END_RCPP
+}
+
+RcppExport SEXP phylomap_maketreelistMCMC_bigtree(SEXP x, SEXP Q, SEXP pid, SEXP B, SEXP Omega, SEXP nen,
+                                                  SEXP nodelist, SEXP root, SEXP N) {
+  BEGIN_RCPP
+  return run_mcmc(phm_maketreelistMCMC_bigtree, x, Q, pid, B, Omega, nen, nodelist, root, N);
+  END_RCPP
+}
+
+RcppExport SEXP phylomap_SPARSEmaketreelistMCMC(SEXP x, SEXP Q, SEXP pid, SEXP B, SEXP Omega, SEXP nen,
+                                                SEXP nodelist, SEXP root, SEXP N) {
+  BEGIN_RCPP
+  return run_mcmc(phm_SPARSEmaketreelistMCMC, x, Q, pid, B, Omega, nen, nodelist, root, N);
+  END_RCPP
+}
+
+RcppExport SEXP phylomap_maketreelistEXP(SEXP xSEXP, SEXP QSEXP, SEXP pidSEXP, SEXP nenSEXP, SEXP nodelistSEXP,
+                                         SEXP rootSEXP, SEXP NSEXP, SEXP leftsSEXP, SEXP rightsSEXP, SEXP dSEXP) {
+  BEGIN_RCPP
+  RNGScope scope;
+  FlatTree ft(as<List>(xSEXP));
+  NumericMatrix Q(QSEXP), lefts(leftsSEXP), rights(rightsSEXP), d(dSEXP);
+  NumericVector pid(pidSEXP);
+  IntegerVector nen(nenSEXP), nodelist(nodelistSEXP);
+  const int n = Q.nrow(), N = as<int>(NSEXP);
+  NumericMatrix out(N, n + n * (n - 1));                            // :3031
+  phm_options o = options_from_R();
+  check(phm_maketreelistEXP(&ft.t, n, Q.begin(), pid.begin(), nen.begin(), nodelist.begin(), as<int>(rootSEXP), N,
+                            lefts.begin(), rights.begin(), d.begin(), &o, out.begin()));
+  return out;
+  END_RCPP
+}
