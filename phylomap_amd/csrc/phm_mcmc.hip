@@ -99,8 +99,8 @@ __global__ __launch_bounds__(MCMC_BLOCK) void mcmc_sweep_kernel(McmcParams<NS> p
   const uint8_t* __restrict__ tips_t = p.tips_per_replica ? p.tips + (size_t)tile * p.n_tips * 64 : p.tips;
 
   for (int it = iter0; it < iter0 + n_iters; ++it) {
-    const double* __restrict__ dw_in = ((it & 1) ? p.dwell1 : p.dwell0) + (size_t)tile * p.rows * 64;
-    double* __restrict__ dw_out = ((it & 1) ? p.dwell0 : p.dwell1) + (size_t)tile * p.rows * 64;
+    double* dw_in = ((it & 1) ? p.dwell1 : p.dwell0) + (size_t)tile * p.rows * 64;   // consumed AND reused as scratch
+    double* dw_out = ((it & 1) ? p.dwell0 : p.dwell1) + (size_t)tile * p.rows * 64;
 #pragma unroll
     for (int c = 0; c < NS; ++c) s_dw[c * 64 + lane] = 0.0;
 #pragma unroll
@@ -176,85 +176,143 @@ __global__ __launch_bounds__(MCMC_BLOCK) void mcmc_sweep_kernel(McmcParams<NS> p
       }
 
       // ---- branch path: resample states, merge, count, re-insert virtual jumps ----
+      // The dwell lists of a tile form one sequential stream of 64-lane rows in sweep order: branch k
+      // occupies wave_max(m) rows of the input stream and wave_max(m') rows of the output stream.
       Stream su, se;
       su.open(ENT_BSTATE | (uint32_t)b, (uint32_t)it, rep, p.seed_lo, p.seed_hi);
       se.open(ENT_BEXP | (uint32_t)b, (uint32_t)it, rep, p.seed_lo, p.seed_hi);
-      uint32_t edraw = 0;
-      int outj = 0;          // next free slot of the new path
-      int mnew = 0;          // pieces emitted
-      bool stuck = false;
-      // The dwell lists of a tile form one sequential stream of 64-lane rows in sweep order: branch k
-      // occupies wave_max(m) rows of the input stream and wave_max(m') rows of the output stream.
       const int roff = in_row;
       const int woff = out_row;
       const int cap = (int)p.rows - out_row;     // rows left in the output stream
+      const int mmax = wave_max(m);
+      int mnew = 0;                              // pieces emitted = new segment count
 
-      auto finalize = [&](int s, double len) {
-        // virtual jumps on one merged segment (:391-410)
-        if (stuck || !(0.0 < len)) {
-          stuck = true;
-          if (outj < cap) dw_out[(woff + outj) * 64 + lane] = len; else err |= DERR_CAPACITY;
-          s_dw[s * 64 + lane] += len;
-          ++mnew; ++outj;
-          return;
-        }
-        const double scale = s_scale[s];
-        double tot = 0.0;
-        double acc = s_dw[s * 64 + lane];
-        while (tot < len) {
-          double rl = scale * (-phm_log(se.draw(edraw++)));                   // :398
-          double piece;
-          if ((tot + rl) < len) { piece = rl; tot += rl; }
-          else { piece = len - tot; tot = len; }
-          if (outj < cap) dw_out[(woff + outj) * 64 + lane] = piece; else err |= DERR_CAPACITY;
-          acc += piece;                                                        // updatedwelltimes :752
-          ++mnew; ++outj;
-        }
-        s_dw[s * 64 + lane] = acc;
+      // s_i ~ B[s_{i-1},:] (.) B^(m-i-1) e_end          (resamplebranchstates :290, :301-304)
+      auto draw_state = [&](int i, int sprev) -> int {
+        int kk = m - i - 1;
+        double pr[NS];
+        int kt = kk < p.ktab ? kk : p.ktab - 1;
+        const double* beta = s_col + (kt * NS + cs) * NS;
+#pragma unroll
+        for (int c = 0; c < NS; ++c) pr[c] = beta[c];
+        for (int q = kt; q < kk; ++q) matvec_u<NS>(p.Bc, pr);
+        const double* row = s_B2 + sprev * NS;
+#pragma unroll
+        for (int c = 0; c < NS; ++c) pr[c] = row[c] * pr[c];
+        return sample_cat<NS>(pr, su.draw((uint32_t)(i - 1)), err);
       };
 
-      int cur_s = (m == 1) ? cs : ps;            // updatenodestates :469-472 (m==1: child wins)
-      double cur_len = dw_in[roff * 64 + lane];
-      for (int i = 1; i <= m; ++i) {              // i == m: sentinel that flushes the last merged segment
-        int si = -1;
-        double di = 0.0;
-        if (i < m) {
-          if (i == m - 1) si = cs;
-          else {
-            // s_i ~ B[s_{i-1},:] (.) B^(m-i-1) e_end          (:290, :301-304)
-            int kk = m - i - 1;
-            double pr[NS];
-            if (kk < p.ktab) {
-              const double* beta = s_col + (kk * NS + cs) * NS;
-#pragma unroll
-              for (int c = 0; c < NS; ++c) pr[c] = beta[c];
-            } else {
-              const double* beta = s_col + ((p.ktab - 1) * NS + cs) * NS;
-#pragma unroll
-              for (int c = 0; c < NS; ++c) pr[c] = beta[c];
-              for (int q = p.ktab - 1; q < kk; ++q) matvec_u<NS>(p.Bc, pr);
+      if (mmax <= 64 && NS <= 4) {
+        // Two flat passes, so that a wave pays max-over-lanes ONCE per pass instead of once per nesting level.
+        // Pass A: one old segment per step for every lane; merged segments are written back in place over the
+        // consumed part of the input stream, their states packed 2 bits apiece into two registers.
+        uint64_t pk0 = 0, pk1 = 0;
+        int w = 0;
+        int cur_s = (m == 1) ? cs : ps;            // updatenodestates :469-472 (m==1: child wins)
+        double cur_len = dw_in[roff * 64 + lane];
+        double dnext = (m > 1) ? dw_in[(roff + 1) * 64 + lane] : 0.0;
+        for (int i = 1; i < mmax; ++i) {
+          if (i < m) {
+            int si = (i == m - 1) ? cs : draw_state(i, cur_s);
+            double di = dnext;
+            if (i + 1 < m) dnext = dw_in[(roff + i + 1) * 64 + lane];
+            if (si == cur_s) cur_len = cur_len + di;                           // shortener :54
+            else {
+              dw_in[(roff + w) * 64 + lane] = cur_len;
+              if (w < 32) pk0 |= (uint64_t)cur_s << (2 * w); else pk1 |= (uint64_t)cur_s << (2 * (w - 32));
+              int col = cur_s * (NS - 1) + (si > cur_s ? si - 1 : si);         // shortener :65-66
+              s_cnt[col * 64 + lane] += 1u;
+              ++w; cur_s = si; cur_len = di;
             }
-            const double* row = s_B2 + cur_s * NS;   // cur_s == s_{i-1}
-#pragma unroll
-            for (int c = 0; c < NS; ++c) pr[c] = row[c] * pr[c];
-            si = sample_cat<NS>(pr, su.draw((uint32_t)(i - 1)), err);
           }
-          di = dw_in[(roff + i) * 64 + lane];
         }
-        if (si == cur_s) cur_len = cur_len + di;                               // shortener :54
-        else {
-          finalize(cur_s, cur_len);
-          if (si >= 0) {
-            int col = cur_s * (NS - 1) + (si > cur_s ? si - 1 : si);           // shortener :65-66
-            s_cnt[col * 64 + lane] += 1u;
+        if (w < 32) pk0 |= (uint64_t)cur_s << (2 * w); else pk1 |= (uint64_t)cur_s << (2 * (w - 32));
+        const int nmerged = w + 1;
+        const double len0 = (w == 0) ? cur_len : dw_in[roff * 64 + lane];
+        if (w > 0) dw_in[(roff + w) * 64 + lane] = cur_len;
+
+        // Pass B: one new piece per step for every lane (virtual jumps :391-410, dwell sums :745-757).
+        int j = 0;
+        int s = (int)(pk0 & 3u);
+        double len = len0;
+        double lnext = (nmerged > 1) ? ((w == 1) ? cur_len : dw_in[(roff + 1) * 64 + lane]) : 0.0;
+        double tot = 0.0, scale = s_scale[s], acc = s_dw[s * 64 + lane];
+        uint32_t edraw = 0;
+        bool stuck = false, done = false;
+        while (!done) {
+          double piece;
+          bool adv;
+          if (stuck || !(0.0 < len)) { stuck = true; piece = len; adv = true; }
+          else {
+            double rl = scale * (-phm_log(se.draw(edraw++)));                  // :398
+            if ((tot + rl) < len) { piece = rl; tot += rl; adv = false; }
+            else { piece = len - tot; adv = true; }
           }
-          cur_s = si; cur_len = di;
+          if (mnew < cap) dw_out[(woff + mnew) * 64 + lane] = piece; else err |= DERR_CAPACITY;
+          acc += piece;                                                        // updatedwelltimes :752
+          ++mnew;
+          if (adv) {
+            s_dw[s * 64 + lane] = acc;
+            ++j;
+            if (j >= nmerged) done = true;
+            else {
+              len = lnext;
+              if (j + 1 < nmerged) lnext = dw_in[(roff + j + 1) * 64 + lane];
+              s = (int)(((j < 32) ? (pk0 >> (2 * j)) : (pk1 >> (2 * (j - 32)))) & 3u);
+              scale = s_scale[s]; tot = 0.0; acc = s_dw[s * 64 + lane];
+            }
+          }
+        }
+      } else {
+        // General path (a lane with more than 64 segments on this branch): the reference's loop nest as written.
+        uint32_t edraw = 0;
+        bool stuck = false;
+        auto finalize = [&](int s, double len) {
+          if (stuck || !(0.0 < len)) {
+            stuck = true;
+            if (mnew < cap) dw_out[(woff + mnew) * 64 + lane] = len; else err |= DERR_CAPACITY;
+            s_dw[s * 64 + lane] += len;
+            ++mnew;
+            return;
+          }
+          const double scale = s_scale[s];
+          double tot = 0.0;
+          double acc = s_dw[s * 64 + lane];
+          while (tot < len) {
+            double rl = scale * (-phm_log(se.draw(edraw++)));
+            double piece;
+            if ((tot + rl) < len) { piece = rl; tot += rl; }
+            else { piece = len - tot; tot = len; }
+            if (mnew < cap) dw_out[(woff + mnew) * 64 + lane] = piece; else err |= DERR_CAPACITY;
+            acc += piece;
+            ++mnew;
+          }
+          s_dw[s * 64 + lane] = acc;
+        };
+        int cur_s = (m == 1) ? cs : ps;
+        double cur_len = dw_in[roff * 64 + lane];
+        for (int i = 1; i <= m; ++i) {              // i == m: sentinel that flushes the last merged segment
+          int si = -1;
+          double di = 0.0;
+          if (i < m) {
+            si = (i == m - 1) ? cs : draw_state(i, cur_s);
+            di = dw_in[(roff + i) * 64 + lane];
+          }
+          if (si == cur_s) cur_len = cur_len + di;
+          else {
+            finalize(cur_s, cur_len);
+            if (si >= 0) {
+              int col = cur_s * (NS - 1) + (si > cur_s ? si - 1 : si);
+              s_cnt[col * 64 + lane] += 1u;
+            }
+            cur_s = si; cur_len = di;
+          }
         }
       }
       if (mnew > 65535) { err |= DERR_CAPACITY; mnew = 65535; }
       mct[b * 64 + lane] = (uint16_t)mnew;
       seg_rw += (uint32_t)(m + mnew);
-      in_row += wave_max(m);
+      in_row += mmax;
       out_row += wave_max(mnew);
       if (out_row > (int)p.rows) out_row = (int)p.rows;
     }

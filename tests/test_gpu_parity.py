@@ -73,6 +73,21 @@ def test_mcmc_chain_state_matches_oracle():
     eng.close()
 
 
+def test_mcmc_long_initial_paths_take_the_general_branch_path():
+    """100 equal segments per branch (R/Squamate_tree_setup.R:57): exercises the > 64-segment code path and the
+    hand-over to the packed two-pass path once the chain has shrunk the paths."""
+    Q = synth.config_Q(2)
+    Omega = 1.25 * float(np.max(np.abs(np.diag(Q))))
+    pid = np.full(4, 0.25)
+    z = synth.make_tree(14, Q, Omega, 21, pid, init_segments=100)
+    nen, nodelist, root = _orders(z)
+    got = api.sumstatMCMC(z, Q, pid, Omega, 12, seed=13, n_replicas=2)
+    for r in range(2):
+        want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(4) + Q / Omega, Omega, nen, nodelist, root, 12, seed=13, replica=r)
+        assert rc == 0
+        np.testing.assert_array_equal(got[r], want)
+
+
 def test_mcmc_non_cladewise_edge_order():
     """Edge rows shuffled: the engine derives its own sweeps; counts stay exact, dwell within 1e-10."""
     z, Q, pid, Omega = _problem(4, 30, 5)
