@@ -59,7 +59,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=240)
     ap.add_argument("--warmup", type=int, default=24)
-    ap.add_argument("--replicas", type=int, default=0, help="replicas per GPU (0: sized from free HBM, max 262144)")
+    ap.add_argument("--replicas", type=int, default=0, help="replicas per GPU (0: sized from free HBM, max 327680 = 5 waves per SIMD)")
     ap.add_argument("--config", type=int, default=2)
     ap.add_argument("--ipl", type=int, default=8, help="sweeps fused per kernel launch")
     ap.add_argument("--no-cpu", action="store_true")
@@ -90,7 +90,7 @@ def main():
                             device=local_rank)
         per_tile = probe.info().device_bytes
         probe.close()
-        S = int(min(262144, (0.80 * free_b) // per_tile * 64))
+        S = int(min(327680, (0.80 * free_b) // per_tile * 64))
         S = max(64, S // 16384 * 16384 if S >= 16384 else S // 64 * 64)
 
     eng = _lib.Engine(z, Q, pid, Omega, K + W, variant=_lib.PHM_MCMC_BIGTREE, seed=0x5EED0000 + args.config,
@@ -137,6 +137,13 @@ def main():
     if stats is not None:                                 # sanity: dwell row sums = S x tree length
         assert np.allclose(stats[:, :n].sum(1), S * z["edge.length"].sum(), rtol=1e-9)
 
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if os.path.exists(tfile):          # HBM bytes per unit from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+        tj = json.load(open(tfile))
+        if tj.get("config") == args.config:
+            traffic = tj["hbm_bytes_per_unit"] * E * S * args.ipl
+
     out = None
     if rank == 0:
         value = units_rank * world / dt
@@ -152,7 +159,7 @@ def main():
                        "replicas_per_gpu": S, "sweeps_per_launch": args.ipl,
                        "parallelism": f"replica-sharded x{world}, one RCCL all-reduce of the statistics"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "mcmc_sweep_kernel<4>", "launches": info.last_run_launches,
                          "avg_launch_ms": info.last_run_ms / max(1, info.last_run_launches),
                          "alg_bytes_per_unit": b_alg, "mean_segments_read_plus_written": seg,

@@ -10,7 +10,7 @@
 namespace phm {
 
 constexpr int MCMC_BLOCK = 256;   // 4 wavefronts share one copy of the LDS tables
-constexpr int MCMC_KTAB = 64;     // chain tables hold B^k e_j for k < KTAB; longer chains continue from the last entry
+constexpr int MCMC_KTAB = 32;     // chain tables hold B^k e_j for k < KTAB; longer chains continue from the last entry
 
 // Passed by value: lives in the kernarg segment, so B / pid are read through scalar loads.
 template <int NS>

@@ -67,7 +67,7 @@ __device__ __forceinline__ void child_vector(const McmcParams<NS>& p, const doub
 }
 
 template <int NS>
-__global__ __launch_bounds__(MCMC_BLOCK) void mcmc_sweep_kernel(McmcParams<NS> p, int iter0, int n_iters) {
+__global__ __launch_bounds__(MCMC_BLOCK, 5) void mcmc_sweep_kernel(McmcParams<NS> p, int iter0, int n_iters) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
