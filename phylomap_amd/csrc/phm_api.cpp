@@ -19,6 +19,7 @@
 #include "phm_exp.h"
 #include "phm_mcmc.h"
 #include "phm_sched.h"
+#include "phm_wide.h"
 
 namespace {
 
@@ -76,6 +77,9 @@ struct phm_engine {
   phm::McmcParams<2> p2;
   phm::McmcParams<3> p3;
   phm::McmcParams<4> p4;
+  bool wide = false;                   // 5..64 states: phm_wide.hip
+  phm::WideParams pw;
+  DevBuf d_B2, d_Bc, d_scale, d_pid;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipStream_t last_stream = nullptr;
   bool timing_pending = false;
@@ -193,7 +197,7 @@ int32_t phm_engine_create(const phm_tree* x, const phm_model* model, const phm_o
   if (o.n_replicas <= 0) o.n_replicas = 1;
   const int n = model->n_states;
   if (n < 2) return fail(PHM_ERR_BAD_INPUT, "n_states must be >= 2");
-  if (n > 4) return fail(PHM_ERR_UNSUPPORTED, "this build has MCMC kernels for n_states in {2,3,4} only");
+  if (n > 64) return fail(PHM_ERR_UNSUPPORTED, "this build has MCMC kernels for n_states <= 64 only");
   if (!model->Q || !model->pid) return fail(PHM_ERR_BAD_INPUT, "model: Q/pid missing");
   if (model->variant < PHM_MCMC || model->variant > PHM_MCMC_SPARSE) return fail(PHM_ERR_BAD_INPUT, "unknown variant");
   if (max_iters < 1) return fail(PHM_ERR_BAD_INPUT, "max_iters must be >= 1");
@@ -202,7 +206,8 @@ int32_t phm_engine_create(const phm_tree* x, const phm_model* model, const phm_o
   if (st) return st;
 
   // model matrices, row-major copies (inputs are R's column-major)
-  double B2[16], Bc[16], scale[4], pid[4];
+  std::vector<double> B2v((size_t)n * n), Bcv((size_t)n * n), scalev(n), pidv(n);
+  double *B2 = B2v.data(), *Bc = Bcv.data(), *scale = scalev.data(), *pid = pidv.data();
   for (int i = 0; i < n; ++i) {
     double q = model->Q[i + (size_t)i * n];
     double r = model->Omega + q;
@@ -222,6 +227,7 @@ int32_t phm_engine_create(const phm_tree* x, const phm_model* model, const phm_o
   phm_engine* e = new phm_engine();
   std::unique_ptr<phm_engine> guard(e);
   e->n = n; e->cols = n + n * (n - 1); e->variant = model->variant;
+  e->wide = n > 4;
   e->S = o.n_replicas; e->tiles = (e->S + 63) / 64; e->S_pad = e->tiles * 64;
   e->max_iters = max_iters; e->reduce = o.reduce ? 1 : 0;
   e->ipl = o.iters_per_launch > 0 ? o.iters_per_launch : 8;
@@ -248,9 +254,12 @@ int32_t phm_engine_create(const phm_tree* x, const phm_model* model, const phm_o
     int m0 = x->map_off[d.edge + 1] - x->map_off[d.edge];
     init_row[k] = (int32_t)init_rows;
     init_rows += m0;
-    rows += phm::poisson_capacity(model->Omega * tb, o.cap_tail > 0.0 ? o.cap_tail : 1e-3);
+    // a sweep keeps at most the m merged segments it was given and adds Poisson(<= Omega t_b) virtual jumps, so a
+    // caller-supplied path longer than the stationary quantile (e.g. 100 equal pieces) needs m0 + that quantile
+    int q = phm::poisson_capacity(model->Omega * tb, o.cap_tail > 0.0 ? o.cap_tail : 1e-3);
+    rows += std::max(q, m0 + q - 1);
   }
-  rows = std::max(rows + 64, init_rows);
+  rows = std::max(rows, init_rows) + 64;
   if (rows * 64 > 0x7fffff00ll) return fail(PHM_ERR_UNSUPPORTED, "tree too large: dwell rows per replica tile exceed 32-bit indexing");
   e->rows = rows;
 
@@ -267,9 +276,9 @@ int32_t phm_engine_create(const phm_tree* x, const phm_model* model, const phm_o
   }
 
   std::vector<double> col, row;
-  build_chain_tables(Bc, n, phm::MCMC_KTAB, col, row);
+  build_chain_tables(Bc, n, e->wide ? phm::WIDE_KTAB : phm::MCMC_KTAB, col, row);
 
-  const size_t stats_bytes = e->reduce ? sizeof(double) * (size_t)max_iters * e->tiles * e->cols
+  const size_t stats_bytes = (e->reduce && !e->wide) ? sizeof(double) * (size_t)max_iters * e->tiles * e->cols
                                        : sizeof(double) * (size_t)max_iters * e->cols * e->S_pad;
   const size_t dw_bytes = sizeof(double) * (size_t)e->tiles * rows * 64;
   size_t need = 2 * dw_bytes + stats_bytes + sizeof(double) * (size_t)e->tiles * s.n_node * n * 64 +
@@ -321,6 +330,28 @@ int32_t phm_engine_create(const phm_tree* x, const phm_model* model, const phm_o
     HIPCHK(hipDeviceSynchronize());
   }
 
+  if (e->wide) {
+    HIPCHK(e->d_B2.alloc(sizeof(double) * n * n)); HIPCHK(e->d_Bc.alloc(sizeof(double) * n * n));
+    HIPCHK(e->d_scale.alloc(sizeof(double) * n)); HIPCHK(e->d_pid.alloc(sizeof(double) * n));
+    HIPCHK(hipMemcpy(e->d_B2.p, B2, e->d_B2.bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_Bc.p, Bc, e->d_Bc.bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_scale.p, scale, e->d_scale.bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_pid.p, pid, e->d_pid.bytes, hipMemcpyHostToDevice));
+    phm::WideParams& p = e->pw;
+    p.n_states = n; p.n_tips = s.n_tips; p.n_node = s.n_node; p.n_edge = s.n_edge; p.root = s.root;
+    p.n_tiles = e->tiles; p.n_rep = e->S; p.n_rep_pad = e->S_pad; p.replica_offset = o.replica_offset;
+    p.normalise = (e->variant == PHM_MCMC_BIGTREE); p.tips_per_replica = e->tips_per_replica ? 1 : 0;
+    p.n_cols = e->cols; p.ktab = phm::WIDE_KTAB; p.count_self = 0;
+    p.seed_lo = (uint32_t)(o.seed & 0xFFFFFFFFull); p.seed_hi = (uint32_t)(o.seed >> 32);
+    p.rows = e->rows;
+    p.B2 = e->d_B2.as<double>(); p.Bc = e->d_Bc.as<double>(); p.scale = e->d_scale.as<double>(); p.pid = e->d_pid.as<double>();
+    p.up = e->d_up.as<phm::UpStep>(); p.down = e->d_down.as<phm::DownStep>();
+    p.colpow = e->d_col.as<double>(); p.rowpow = e->d_row.as<double>();
+    p.tips = e->d_tips.as<uint8_t>(); p.mcount = e->d_mcount.as<uint16_t>();
+    p.dwell0 = e->d_dw0.as<double>(); p.dwell1 = e->d_dw1.as<double>();
+    p.PL = e->d_PL.as<double>(); p.nstate = e->d_nstate.as<uint8_t>(); p.stats = e->d_stats.as<double>();
+    p.err = e->d_err.as<uint32_t>(); p.segcnt = e->d_seg.as<unsigned long long>();
+  }
   if (n == 2) fill_params<2>(e, e->p2, B2, Bc, scale, pid, o);
   if (n == 3) fill_params<3>(e, e->p3, B2, Bc, scale, pid, o);
   if (n == 4) fill_params<4>(e, e->p4, B2, Bc, scale, pid, o);
@@ -343,6 +374,7 @@ int32_t phm_engine_run(phm_engine* e, int32_t n_iters, void* hip_stream) {
     if (e->n == 2) le = phm::launch_mcmc<2>(e->p2, e->iters_done + done, chunk, stream);
     if (e->n == 3) le = phm::launch_mcmc<3>(e->p3, e->iters_done + done, chunk, stream);
     if (e->n == 4) le = phm::launch_mcmc<4>(e->p4, e->iters_done + done, chunk, stream);
+    if (e->wide) le = phm::launch_mcmc_wide(e->pw, e->iters_done + done, chunk, stream);
     HIPCHK(le);
     done += chunk;
     ++launches;
@@ -379,8 +411,12 @@ int32_t phm_engine_read_stats(phm_engine* e, int32_t iter0, int32_t n, double* o
   HIPCHK(hipStreamSynchronize(e->last_stream));
   const int cols = e->cols;
   if (e->reduce) {
-    HIPCHK(phm::launch_stats_reduce(e->d_stats.as<double>() + (size_t)iter0 * e->tiles * cols, n, e->tiles, cols,
-                                    e->d_red.as<double>(), e->last_stream));
+    if (e->wide)
+      HIPCHK(phm::launch_stats_reduce_replicas(e->d_stats.as<double>() + (size_t)iter0 * cols * e->S_pad, n, cols, e->S,
+                                               e->S_pad, e->d_red.as<double>(), e->last_stream));
+    else
+      HIPCHK(phm::launch_stats_reduce(e->d_stats.as<double>() + (size_t)iter0 * e->tiles * cols, n, e->tiles, cols,
+                                      e->d_red.as<double>(), e->last_stream));
     std::vector<double> h((size_t)n * cols);
     HIPCHK(hipMemcpyAsync(h.data(), e->d_red.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, e->last_stream));
     HIPCHK(hipStreamSynchronize(e->last_stream));
@@ -436,7 +472,8 @@ int32_t phm_engine_dump(phm_engine* e, int32_t replica, int32_t* seg_count, doub
     for (int t = 0; t < T; ++t)
       for (int c = 0; c < n; ++c) PL[(size_t)t * n + c] = (c == tip_state(t)) ? 1.0 : 0.0;
     for (int v = 0; v < s.n_node; ++v)
-      for (int c = 0; c < n; ++c) PL[(size_t)(T + v) * n + c] = pl[((size_t)v * n + c) * 64 + lane];
+      for (int c = 0; c < n; ++c)
+        PL[(size_t)(T + v) * n + c] = e->wide ? pl[((size_t)v * 64 + lane) * n + c] : pl[((size_t)v * n + c) * 64 + lane];
   }
   return PHM_OK;
 }
@@ -684,8 +721,12 @@ extern "C" int32_t phm_engine_reduced_stats_device(phm_engine* e, int32_t iter0,
   if (!e->reduce) return fail(PHM_ERR_STATE, "engine was not created with reduce = 1");
   if (iter0 < 0 || n < 1 || iter0 + n > e->iters_done) return fail(PHM_ERR_STATE, "statistics requested for iterations that have not run");
   HIPCHK(hipSetDevice(e->device));
-  HIPCHK(phm::launch_stats_reduce(e->d_stats.as<double>() + (size_t)iter0 * e->tiles * e->cols, n, e->tiles, e->cols,
-                                  e->d_red.as<double>(), reinterpret_cast<hipStream_t>(hip_stream)));
+  if (e->wide)
+    HIPCHK(phm::launch_stats_reduce_replicas(e->d_stats.as<double>() + (size_t)iter0 * e->cols * e->S_pad, n, e->cols, e->S,
+                                             e->S_pad, e->d_red.as<double>(), reinterpret_cast<hipStream_t>(hip_stream)));
+  else
+    HIPCHK(phm::launch_stats_reduce(e->d_stats.as<double>() + (size_t)iter0 * e->tiles * e->cols, n, e->tiles, e->cols,
+                                    e->d_red.as<double>(), reinterpret_cast<hipStream_t>(hip_stream)));
   *out_dev = e->d_red.p;
   return PHM_OK;
 }

@@ -1,0 +1,48 @@
+// phm_wide.h -- parameter block and launchers of the 5..64-state MCMC sweep (phm_wide.hip)
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "phm_device.h"
+#include "phm_sched.h"
+
+namespace phm {
+
+constexpr int WIDE_BLOCK = 256;     // 4 wavefronts share the LDS copies of B
+constexpr int WIDE_KTAB = 16;       // B^k e_j tables in global memory for k < KTAB
+constexpr int WIDE_MAXSEG = 128;    // most segments one branch of one replica may hold (LDS state scratch)
+
+struct WideParams {
+  int32_t n_states;
+  int32_t n_tips, n_node, n_edge, root;
+  int32_t n_tiles, n_rep, n_rep_pad, replica_offset;
+  int32_t normalise, tips_per_replica, n_cols, ktab;
+  int32_t count_self;                        // 1: n x n transition counts incl. self pairs (shortenerbf :1010-1014)
+  uint32_t seed_lo, seed_hi;
+  int64_t rows;
+  const double* B2;                          // [n][n] dense B, row-major
+  const double* Bc;                          // [n][n] chain matrix (B, or thresholded B for SPARSE)
+  const double* scale;                       // [n] 1/(Omega+q_ss)
+  const double* pid;                         // [n]
+  const UpStep* up;
+  const DownStep* down;
+  const double* colpow;                      // [ktab][n][n]
+  const double* rowpow;                      // [ktab][n][n]
+  const uint8_t* tips;
+  uint16_t* mcount;                          // [tile][n_edge][64]
+  double* dwell0;                            // [tile][rows][64]
+  double* dwell1;
+  double* PL;                                // [tile][n_node][64][n]  (a replica's vector is contiguous)
+  uint8_t* nstate;                           // [tile][n_node][64]
+  double* stats;                             // [iter][cols][n_rep_pad], accumulated in place (zeroed at create)
+  uint32_t* err;
+  unsigned long long* segcnt;
+};
+
+size_t wide_lds_bytes(int n);
+hipError_t launch_mcmc_wide(const WideParams& p, int iter0, int n_iters, hipStream_t stream);
+hipError_t launch_stats_reduce_replicas(const double* stats, int n_iters, int n_cols, int n_rep, int n_rep_pad,
+                                        double* out, hipStream_t stream);
+
+}  // namespace phm

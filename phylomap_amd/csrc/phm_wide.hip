@@ -1,0 +1,328 @@
+// phm_wide.hip -- the fixed-Q MCMC sweep for 5 <= n <= 64 states (C4: dense 61-state Q, C5: sparse 20-state Q).
+//
+// Same per-replica algorithm, HBM streams and RNG keys as phm_mcmc.hip; what changes is who does the n-vector
+// arithmetic.  A wavefront still owns 64 replicas and the scalar work (segment bookkeeping, merging, virtual
+// jumps, Philox, log) still runs one replica per LANE.  The n-vector work of a replica -- B^k chains,
+// PL products, row normalisation, categorical draws -- is done by the whole wave with one STATE per lane,
+// the 64 replicas taking turns (their scalars are broadcast with v_readlane, results handed back to the owning
+// lane).  Summation orders are the spec's left-to-right ones, so results equal the oracle bit for bit:
+//   y_c = ((B_c0 x_0 + B_c1 x_1) + ...)   lane c accumulates while x_j is broadcast, j ascending;
+//   prefix sums of a probability vector are formed in index order by the same broadcast loop.
+// B (row-major and transposed) and the dense forward rows are staged in LDS; the B^k e_j tables
+// (k < WIDE_KTAB) stay in global memory / L2, read coalesced ([k][j][lane]).
+#include "phm_wide.h"
+
+namespace phm {
+
+__device__ __forceinline__ double readlane_f64(double v, int l) {   // l must be wave-uniform
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, l);
+  hi = __builtin_amdgcn_readlane(hi, l);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ int wave_max_w(int v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { int o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
+  return __builtin_amdgcn_readfirstlane(v);
+}
+
+// y <- M y with lanes over rows: Mt is M transposed in LDS ([j][c]), so lane c reads M[c][j] conflict-free
+__device__ __forceinline__ double coop_matvec(const double* __restrict__ Mt, double v, int n, int c) {
+  double acc = Mt[c] * readlane_f64(v, 0);
+  for (int j = 1; j < n; ++j) acc += Mt[j * n + c] * readlane_f64(v, j);
+  return acc;
+}
+
+// first j with u*sum(p) <= p_0+..+p_j (index order); lanes >= n carry p = 0 and never count
+__device__ __forceinline__ int coop_sample(double p, double u, int n, int lane, uint32_t& err) {
+  double run = readlane_f64(p, 0);
+  double mycum = run;
+  for (int j = 1; j < n; ++j) {
+    run += readlane_f64(p, j);
+    if (lane == j) mycum = run;
+  }
+  if (!(run > 0.0) || isinf(run)) err |= DERR_ZERO_PROB;
+  const double thr = u * run;
+  const bool fail = (lane < n) && !(thr <= mycum);
+  int idx = (int)__popcll(__ballot(fail));
+  return idx < n ? idx : n - 1;
+}
+
+__device__ __forceinline__ double coop_sum(double x, int n) {
+  double run = readlane_f64(x, 0);
+  for (int j = 1; j < n; ++j) run += readlane_f64(x, j);
+  return run;
+}
+
+// wave-uniform uniform draw d of stream (rep, it, ent)
+__device__ __forceinline__ double uni_draw(const WideParams& p, uint32_t rep, uint32_t it, uint32_t ent, uint32_t d) {
+  return stream_u(p.seed_lo, p.seed_hi, rep, it, ent, d);
+}
+
+__global__ __launch_bounds__(WIDE_BLOCK) void mcmc_wide_kernel(WideParams p, int iter0, int n_iters) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int n = p.n_states;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int tile = blockIdx.x * (WIDE_BLOCK / 64) + wave;
+  const int c = lane < n ? lane : n - 1;       // clamped state index of this lane
+
+  double* s_Bc = reinterpret_cast<double*>(smem);     // [r][c] chain matrix, row-major   (w <- Bc^T w)
+  double* s_Bct = s_Bc + n * n;                       // [j][c] = Bc[c][j]                (v <- Bc v)
+  double* s_B2 = s_Bct + n * n;                       // [r][c] dense B rows              (forward step)
+  double* s_scale = s_B2 + n * n;                     // [n]
+  uint8_t* s_st = reinterpret_cast<uint8_t*>(s_scale + n) + (size_t)wave * WIDE_MAXSEG * 64;   // [slot][replica]
+  for (int i = threadIdx.x; i < n * n; i += WIDE_BLOCK) {
+    int r = i / n, cc = i - r * n;
+    s_Bc[i] = p.Bc[i];
+    s_Bct[cc * n + r] = p.Bc[i];
+    s_B2[i] = p.B2[i];
+  }
+  if ((int)threadIdx.x < n) s_scale[threadIdx.x] = p.scale[threadIdx.x];
+  __syncthreads();
+  if (tile >= p.n_tiles) return;
+
+  const int rep_local = tile * 64 + lane;
+  const uint32_t rep0 = (uint32_t)(p.replica_offset + tile * 64);
+  const uint32_t rep = rep0 + (uint32_t)lane;
+  const bool valid = rep_local < p.n_rep;
+  uint32_t err = 0;
+  const double pid_c = p.pid[c];
+
+  double* __restrict__ PLt = p.PL + (size_t)tile * p.n_node * 64 * n;      // [node][replica][n]
+  uint8_t* __restrict__ nst = p.nstate + (size_t)tile * p.n_node * 64;
+  uint16_t* __restrict__ mct = p.mcount + (size_t)tile * p.n_edge * 64;
+  const uint8_t* __restrict__ tips_t = p.tips_per_replica ? p.tips + (size_t)tile * p.n_tips * 64 : p.tips;
+
+  // B^k applied to the PL vector of `child` for replica r (lanes = states): tips via the chain table
+  auto child_vec = [&](int child, int k, int r, int tipstate_r) -> double {
+    double v;
+    int done;
+    if (child < 0) {
+      int kt = k < p.ktab ? k : p.ktab - 1;
+      v = p.colpow[((size_t)kt * n + tipstate_r) * n + c];
+      done = kt;
+    } else {
+      v = PLt[((size_t)child * 64 + r) * n + c];
+      done = 0;
+    }
+    for (int i = done; i < k; ++i) v = coop_matvec(s_Bct, v, n, c);
+    return v;
+  };
+
+  for (int it = iter0; it < iter0 + n_iters; ++it) {
+    double* dw_in = ((it & 1) ? p.dwell1 : p.dwell0) + (size_t)tile * p.rows * 64;
+    double* dw_out = ((it & 1) ? p.dwell0 : p.dwell1) + (size_t)tile * p.rows * 64;
+    double* srow = p.stats + (size_t)it * p.n_cols * p.n_rep_pad + rep_local;   // + col * n_rep_pad
+    uint32_t seg_rw = 0;
+    int in_row = 0, out_row = 0;
+
+    // ------------------------------ up sweep ------------------------------
+    for (int k = 0; k < p.n_node; ++k) {
+      const UpStep st = p.up[k];
+      const int ma = mct[st.edge[0] * 64 + lane];
+      const int mb = mct[st.edge[1] * 64 + lane];
+      int ta = 0, tb = 0;
+      if (st.child[0] < 0) ta = p.tips_per_replica ? tips_t[(~st.child[0]) * 64 + lane] : p.tips[~st.child[0]];
+      if (st.child[1] < 0) tb = p.tips_per_replica ? tips_t[(~st.child[1]) * 64 + lane] : p.tips[~st.child[1]];
+      for (int r = 0; r < 64; ++r) {
+        const int mar = __builtin_amdgcn_readlane(ma, r), mbr = __builtin_amdgcn_readlane(mb, r);
+        const int tar = __builtin_amdgcn_readlane(ta, r), tbr = __builtin_amdgcn_readlane(tb, r);
+        double x = child_vec(st.child[1], mbr - 1, r, tbr);        // "first"  (:508)
+        double y = child_vec(st.child[0], mar - 1, r, tar);        // "second" (:509)
+        x = x * y;                                                  // :510
+        if (p.normalise) x = x / coop_sum(x, n);                    // :525
+        if (lane < n) PLt[((size_t)st.parent * 64 + r) * n + lane] = x;
+      }
+    }
+
+    // ------------------------------ root ------------------------------
+    {
+      int mine = 0;
+      for (int r = 0; r < 64; ++r) {
+        double pr = (lane < n) ? pid_c * PLt[((size_t)p.root * 64 + r) * n + c] : 0.0;     // :618
+        double u = uni_draw(p, rep0 + r, (uint32_t)it, ENT_NODE | (uint32_t)(p.root + p.n_tips), 0);
+        int rs = coop_sample(pr, u, n, lane, err);                                         // :627
+        if (lane == r) mine = rs;
+      }
+      nst[p.root * 64 + lane] = (uint8_t)mine;
+    }
+
+    // ------------------------------ down sweep ------------------------------
+    for (int k = 0; k < p.n_edge; ++k) {
+      const DownStep ds = p.down[k];
+      const int b = ds.edge;
+      int m = mct[b * 64 + lane];
+      const int ps = nst[ds.parent * 64 + lane];
+      int mmax = wave_max_w(m);
+      int cs = 0;
+      if (ds.child < 0) cs = p.tips_per_replica ? tips_t[(~ds.child) * 64 + lane] : p.tips[~ds.child];
+      if (mmax > WIDE_MAXSEG) {      // LDS state scratch is WIDE_MAXSEG slots per replica: report, stay memory-safe
+        err |= DERR_CAPACITY;
+        m = m < WIDE_MAXSEG ? m : WIDE_MAXSEG;
+        mmax = WIDE_MAXSEG;
+      }
+
+      // ---- n-vector work, replicas in turn: child state, then the interior states of the branch ----
+      for (int r = 0; r < 64; ++r) {
+        const int mr = __builtin_amdgcn_readlane(m, r);
+        const int psr = __builtin_amdgcn_readlane(ps, r);
+        int csr;
+        if (ds.child >= 0) {
+          // child ~ e_ps^T B^(m-1) (.) PL[child]     (Tvmmp :431-436, :651-655)
+          int kk = mr - 1;
+          int kt = kk < p.ktab ? kk : p.ktab - 1;
+          double w = p.rowpow[((size_t)kt * n + psr) * n + c];
+          for (int i = kt; i < kk; ++i) {
+            double acc = s_Bc[c] * readlane_f64(w, 0);
+            for (int q = 1; q < n; ++q) acc += s_Bc[q * n + c] * readlane_f64(w, q);
+            w = acc;
+          }
+          w = (lane < n) ? w * PLt[((size_t)ds.child * 64 + r) * n + c] : 0.0;
+          double u = uni_draw(p, rep0 + r, (uint32_t)it, ENT_NODE | (uint32_t)(ds.child + p.n_tips), 0);
+          csr = coop_sample(w, u, n, lane, err);
+          if (lane == r) cs = csr;
+        } else {
+          csr = __builtin_amdgcn_readlane(cs, r);
+        }
+        // interior states s_i ~ B[s_{i-1},:] (.) B^(m-i-1) e_end     (resamplebranchstates :290, :301-304)
+        int prev = psr;
+        for (int i = 1; i < mr - 1; ++i) {
+          int kk = mr - i - 1;
+          int kt = kk < p.ktab ? kk : p.ktab - 1;
+          double beta = p.colpow[((size_t)kt * n + csr) * n + c];
+          for (int q = kt; q < kk; ++q) beta = coop_matvec(s_Bct, beta, n, c);
+          double pr = (lane < n) ? s_B2[prev * n + c] * beta : 0.0;
+          double u = uni_draw(p, rep0 + r, (uint32_t)it, ENT_BSTATE | (uint32_t)b, (uint32_t)(i - 1));
+          int si = coop_sample(pr, u, n, lane, err);
+          if (lane == 0) s_st[(i - 1) * 64 + r] = (uint8_t)si;
+          prev = si;
+        }
+      }
+      if (ds.child >= 0) nst[ds.child * 64 + lane] = (uint8_t)cs;
+
+      // ---- scalar work, one replica per lane: merge, count, virtual jumps, dwell sums ----
+      Stream se;
+      se.open(ENT_BEXP | (uint32_t)b, (uint32_t)it, rep, p.seed_lo, p.seed_hi);
+      const int roff = in_row, woff = out_row;
+      const int cap = (int)p.rows - out_row;
+      int mnew = 0;
+      {
+        // pass A: merged segments written back in place (lengths into the consumed input rows, states into s_st)
+        int w = 0;
+        int cur_s = (m == 1) ? cs : ps;                              // updatenodestates :469-472
+        double cur_len = dw_in[roff * 64 + lane];
+        double dnext = (m > 1) ? dw_in[(roff + 1) * 64 + lane] : 0.0;
+        for (int i = 1; i < mmax; ++i) {
+          if (i < m) {
+            int si = (i == m - 1) ? cs : (int)s_st[(i - 1) * 64 + lane];
+            double di = dnext;
+            if (i + 1 < m) dnext = dw_in[(roff + i + 1) * 64 + lane];
+            if (p.count_self) srow[(size_t)(n + cur_s * n + si) * p.n_rep_pad] += 1.0;   // shortenerbf :1010-1014
+            if (si == cur_s) cur_len = cur_len + di;                 // shortener :54
+            else {
+              dw_in[(roff + w) * 64 + lane] = cur_len;
+              s_st[w * 64 + lane] = (uint8_t)cur_s;                  // w <= i-1: slot already consumed
+              if (!p.count_self) {
+                int col = cur_s * (n - 1) + (si > cur_s ? si - 1 : si);                        // shortener :65-66
+                srow[(size_t)(n + col) * p.n_rep_pad] += 1.0;
+              }
+              ++w; cur_s = si; cur_len = di;
+            }
+          }
+        }
+        const int nmerged = w + 1;
+        const double len0 = (w == 0) ? cur_len : dw_in[roff * 64 + lane];
+        const int s0 = (w == 0) ? cur_s : (int)s_st[lane];
+        if (w > 0) { dw_in[(roff + w) * 64 + lane] = cur_len; s_st[w * 64 + lane] = (uint8_t)cur_s; }
+
+        // pass B: one new piece per step per lane (virtual jumps :391-410, updatedwelltimes :745-757)
+        int j = 0, s = s0;
+        double len = len0;
+        double lnext = (nmerged > 1) ? ((w == 1) ? cur_len : dw_in[(roff + 1) * 64 + lane]) : 0.0;
+        double tot = 0.0, scale = s_scale[s];
+        double* gacc = srow + (size_t)s * p.n_rep_pad;
+        double acc = *gacc;
+        uint32_t edraw = 0;
+        bool stuck = false, done = false;
+        while (!done) {
+          double piece;
+          bool adv;
+          if (stuck || !(0.0 < len)) { stuck = true; piece = len; adv = true; }
+          else {
+            double rl = scale * (-phm_log(se.draw(edraw++)));        // :398
+            if ((tot + rl) < len) { piece = rl; tot += rl; adv = false; }
+            else { piece = len - tot; adv = true; }
+          }
+          if (mnew < cap) dw_out[(woff + mnew) * 64 + lane] = piece; else err |= DERR_CAPACITY;
+          acc += piece;
+          ++mnew;
+          if (adv) {
+            *gacc = acc;
+            ++j;
+            if (j >= nmerged) done = true;
+            else {
+              len = lnext;
+              if (j + 1 < nmerged) lnext = dw_in[(roff + j + 1) * 64 + lane];
+              s = (int)s_st[j * 64 + lane];
+              scale = s_scale[s]; tot = 0.0;
+              gacc = srow + (size_t)s * p.n_rep_pad;
+              acc = *gacc;
+            }
+          }
+        }
+      }
+      if (mnew > 65535) { err |= DERR_CAPACITY; mnew = 65535; }
+      mct[b * 64 + lane] = (uint16_t)mnew;
+      seg_rw += (uint32_t)(m + mnew);
+      in_row += mmax;
+      out_row += wave_max_w(mnew);
+      if (out_row > (int)p.rows) out_row = (int)p.rows;
+    }
+    {
+      uint32_t v = valid ? seg_rw : 0u;
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane == 0) atomicAdd(p.segcnt, (unsigned long long)v);
+    }
+  }
+  if (err) atomicOr(p.err, err);
+}
+
+// sum the per-replica statistics over the valid replicas, replica order: out[it][col]
+__global__ void stats_reduce_replicas_kernel(const double* __restrict__ stats, int n_iters, int n_cols, int n_rep,
+                                             int n_rep_pad, double* __restrict__ out) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_iters * n_cols) return;
+  const double* src = stats + (size_t)idx * n_rep_pad;
+  double acc = 0.0;
+  for (int r = 0; r < n_rep; ++r) acc += src[r];
+  out[idx] = acc;
+}
+
+size_t wide_lds_bytes(int n) {
+  return sizeof(double) * ((size_t)3 * n * n + n) + (size_t)(WIDE_BLOCK / 64) * WIDE_MAXSEG * 64;
+}
+
+hipError_t launch_mcmc_wide(const WideParams& p, int iter0, int n_iters, hipStream_t stream) {
+  const int wpb = WIDE_BLOCK / 64;
+  size_t lds = wide_lds_bytes(p.n_states);
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mcmc_wide_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(mcmc_wide_kernel, dim3((p.n_tiles + wpb - 1) / wpb), dim3(WIDE_BLOCK), lds, stream, p, iter0, n_iters);
+  return hipGetLastError();
+}
+
+hipError_t launch_stats_reduce_replicas(const double* stats, int n_iters, int n_cols, int n_rep, int n_rep_pad, double* out,
+                                        hipStream_t stream) {
+  int total = n_iters * n_cols;
+  hipLaunchKernelGGL(stats_reduce_replicas_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, stats, n_iters, n_cols,
+                     n_rep, n_rep_pad, out);
+  return hipGetLastError();
+}
+
+}  // namespace phm

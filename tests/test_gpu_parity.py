@@ -159,6 +159,55 @@ def test_mcmc_per_site_tips_and_reduce():
     np.testing.assert_allclose(red[:, :4], total[:, :4], rtol=1e-12)
 
 
+@pytest.mark.parametrize("n,fn,variant", [(20, "sumstatMCMC", O.PLAIN), (20, "SPARSEsumstatMCMC", O.SPARSE),
+                                          (20, "sumstatMCMC_bigtree", O.BIGTREE), (5, "sumstatMCMC", O.PLAIN),
+                                          (61, "sumstatMCMC_bigtree", O.BIGTREE), (64, "sumstatMCMC", O.PLAIN)])
+def test_wide_kernel_matches_oracle(n, fn, variant):
+    """5..64 states (C4: dense 61-state Q; C5: sparse 20-state tridiagonal Q): states-over-lanes kernel."""
+    if n == 20:
+        Q = synth.config_Q(5)
+    elif n == 61:
+        Q = synth.config_Q(4)
+    else:
+        Q = synth.dense_Q(n, 0.02, 0.08, seed=n)
+    Omega = 1.25 * float(np.max(np.abs(np.diag(Q))))
+    pid = np.full(n, 1.0 / n)
+    tips = 14 if n < 61 else 9
+    z = synth.make_tree(tips, Q, Omega, 400 + n, pid, init_segments=(n if n == 20 else 2))
+    nen, nodelist, root = _orders(z)
+    N, S, seed = 10, 3, 31
+    got = getattr(api, fn)(z, Q, pid, Omega, N, seed=seed, n_replicas=S)
+    for r in range(S):
+        want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(n) + Q / Omega, Omega, nen, nodelist, root, N, variant=variant,
+                                      seed=seed, replica=r)
+        assert rc == 0
+        np.testing.assert_array_equal(got[r][:, n:], want[:, n:])
+        np.testing.assert_array_equal(got[r][:, :n], want[:, :n])
+    red = getattr(api, fn)(z, Q, pid, Omega, N, seed=seed, n_replicas=S, reduce=True)
+    np.testing.assert_array_equal(red[:, n:], got.sum(0)[:, n:])
+    np.testing.assert_allclose(red[:, :n], got.sum(0)[:, :n], rtol=1e-12)
+
+
+def test_wide_kernel_chain_state_and_golden():
+    from golden.make_golden import unpack_tree
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "n20_t12.npz"))
+    z = unpack_tree(g)
+    Q, pid, Omega, seed = g["Q"], g["pid"], float(g["Omega"]), int(g["seed"])
+    got = api.SPARSEsumstatMCMC(z, Q, pid, Omega, 24, seed=seed, n_replicas=6)
+    np.testing.assert_array_equal(got[0], g["sparse_r0"])
+    np.testing.assert_array_equal(got[5], g["sparse_r5"])
+    eng = _lib.Engine(z, Q, pid, Omega, 9, variant=_lib.PHM_MCMC_BIGTREE, seed=seed, n_replicas=2)
+    eng.run(9); eng.sync()
+    want, rc, dump = O.maketreelistMCMC(z, Q, pid, np.eye(20) + Q / Omega, Omega, g["nen"], g["nodelist"], int(g["root"]), 9,
+                                        variant=O.BIGTREE, seed=seed, replica=1, dump=True)
+    d = eng.dump(1)
+    eng.close()
+    np.testing.assert_array_equal(d["seg_count"], dump.seg_count)
+    np.testing.assert_array_equal(d["node_states"], dump.node_states)
+    np.testing.assert_array_equal(d["PL"], dump.PL)
+
+
 def test_replica_offset_shards_like_one_device():
     z, Q, pid, Omega = _problem(2, 18, 4)
     a = api.sumstatMCMC(z, Q, pid, Omega, 10, seed=3, n_replicas=4)
@@ -229,8 +278,8 @@ def test_errors_are_loud():
     zbad = dict(z); zbad["edge"] = z["edge"].copy(); zbad["edge"][3, 0] = zbad["edge"][0, 0]
     with pytest.raises((_lib.PhmError, ValueError)):
         api.sumstatMCMC(zbad, Q, pid, Omega, 5)
-    Q5 = synth.tridiagonal_Q(5, 0.1)
-    z5 = synth.make_tree(10, Q5, 0.5, 3)
+    Q65 = synth.dense_Q(65, 0.001, 0.002, seed=1)
+    z65 = synth.make_tree(6, Q65, 1.0, 3)
     with pytest.raises(_lib.PhmError) as e:
-        api.sumstatMCMC(z5, Q5, np.full(5, .2), 0.5, 5)
+        api.sumstatMCMC(z65, Q65, np.full(65, 1 / 65), 1.0, 2)
     assert e.value.status == 2
