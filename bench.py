@@ -133,6 +133,7 @@ def main():
     kernel_s = info.last_run_ms / 1e3
     achieved = units_rank * b_alg / kernel_s / 1e9
 
+    prune_ms = eng.time_pruning(8, stream) / 8.0           # the pruning sweep alone (12n+12 B per branch)
     stats = eng.stats(W, K) if world == 1 else None
     if stats is not None:                                 # sanity: dwell row sums = S x tree length
         assert np.allclose(stats[:, :n].sum(1), S * z["edge.length"].sum(), rtol=1e-9)
@@ -164,6 +165,10 @@ def main():
                          "avg_launch_ms": info.last_run_ms / max(1, info.last_run_launches),
                          "alg_bytes_per_unit": b_alg, "mean_segments_read_plus_written": seg,
                          "units_per_launch": E * S * args.ipl},
+            "pruning_sweep": {"kernel": "mcmc_sweep_kernel<4> (up sweep only)", "ms_per_sweep": prune_ms,
+                              "alg_bytes_per_unit": 12 * n + 12,
+                              "achieved": E * S * (12 * n + 12) / (prune_ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS,
+                              "unit": "GB/s", "frac": E * S * (12 * n + 12) / (prune_ms / 1e3) / 1e9 / HBM_PEAK_GBS},
             "hbm_bytes_resident": int(info.device_bytes),
         }
     eng.close()

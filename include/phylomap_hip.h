@@ -127,6 +127,13 @@ int32_t phm_maketreelistEXP(          /* src/phylomap.cpp:3001, src/RcppExports.
     const double* lefts, const double* rights, const double* d,
     const phm_options* opt, double* out);
 
+/* ---- host-side traversal orders (no device needed) ----
+ * O(E) native replacement of the R helper preamble pruningwiseedgeorder / makenodelist / myreorder
+ * (R/sumstatMCMC.R:1-18, interpreted O(E^2) loops around ape::reorder(x,"pruningwise")).
+ * edge: n_edge x 2 column-major, 1-based.  nen: n_edge rows (1-based); nodelist: Nnode-1 node ids; root: node id. */
+int32_t phm_tree_orders(int32_t n_tips, int32_t n_edge, const int32_t* edge, int32_t* nen, int32_t* nodelist,
+                        int32_t* root);
+
 /* ---- batched transition matrices (K1 / K1') ----
  * phm_expm_eigen: P_b = |L diag(exp(d_i t_b)) R|  (matexp, src/phylomap.cpp:2964-2968 + abs at :2980,:3042)
  * phm_expm_pade : P_b = expmat(Q t_b), Pade(6) scaling-and-squaring (arma::expmat call sites :3226,:3243,:3359,:3383)
@@ -151,6 +158,9 @@ int32_t phm_engine_read_stats(phm_engine* e, int32_t iter0, int32_t n, double* o
 /* reduce = 1 only: run the tile reduction on `hip_stream` and return a DEVICE pointer to n x cols doubles,
  * row-major [iteration][column] (for handing to RCCL without a host round trip); valid until the next call */
 int32_t phm_engine_reduced_stats_device(phm_engine* e, int32_t iter0, int32_t n, void* hip_stream, void** out_dev);
+/* measurement aid: HIP-event time (ms) of n_iters repetitions of the pruning sweep alone (makePLrcpp*,
+ * src/phylomap.cpp:503-529) on the current chain state; segment counts and paths are not modified */
+int32_t phm_engine_time_pruning(phm_engine* e, int32_t n_iters, void* hip_stream, double* ms_out);
 /* chain state of one replica after the last iteration (tests): any pointer may be NULL.
  * seg_dwell: n_edge * seg_cap; node_states: 2*n_tips-1, 1-based; PL: (2*n_tips-1) x n row-major */
 int32_t phm_engine_dump(phm_engine* e, int32_t replica, int32_t* seg_count, double* seg_dwell, int32_t seg_cap,

@@ -21,6 +21,7 @@ EXPORTS = [
     "phm_expm_eigen", "phm_expm_pade",
     "phm_engine_create", "phm_engine_run", "phm_engine_sync", "phm_engine_read_stats", "phm_engine_dump",
     "phm_engine_info", "phm_engine_destroy", "phm_engine_reduced_stats_device",
+    "phm_engine_time_pruning", "phm_tree_orders",
 ]
 
 
@@ -82,6 +83,9 @@ def load():
         L.phm_engine_dump.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_int32,
                                       C.POINTER(C.c_int32), C.POINTER(C.c_double)]
         L.phm_engine_info.argtypes = [C.c_void_p, C.POINTER(Info)]
+        L.phm_tree_orders.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                      C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.phm_engine_time_pruning.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_double)]
         L.phm_engine_reduced_stats_device.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                                       C.POINTER(C.c_void_p)]
         L.phm_engine_destroy.argtypes = [C.c_void_p]
@@ -131,6 +135,19 @@ class FlatTree:
         self.c = Tree(self.T, int(z["Nnode"]), self.E, _p(self.edge, C.c_int32), _p(self.edge_length, C.c_double),
                       _p(self.states.reshape(-1), C.c_int32), _p(self.map_off, C.c_int32), _p(self.maps, C.c_double),
                       _p(self.mapnames, C.c_int32))
+
+
+def tree_orders(z):
+    """(nen, nodelist, root) computed natively in O(E): phm_tree_orders, the replacement of R/sumstatMCMC.R:1-18."""
+    edge = np.asarray(z["edge"], dtype=np.int32)
+    E = edge.shape[0]
+    flat = np.asfortranarray(edge).reshape(-1, order="F").copy()
+    T = int(z["Nnode"]) + 1
+    nen = np.zeros(E, dtype=np.int32)
+    nodelist = np.zeros(max(int(z["Nnode"]) - 1, 1), dtype=np.int32)
+    root = C.c_int32(0)
+    check(load().phm_tree_orders(T, E, _p(flat, C.c_int32), _p(nen, C.c_int32), _p(nodelist, C.c_int32), C.byref(root)))
+    return nen, nodelist[: int(z["Nnode"]) - 1], int(root.value)
 
 
 def make_options(seed=0, n_replicas=1, replica_offset=0, reduce=False, tips_per_replica=False, device=-1,
@@ -189,6 +206,12 @@ class Engine:
         check(load().phm_engine_reduced_stats_device(self.h, int(iter0), int(n), C.c_void_p(stream) if stream else None,
                                                      C.byref(ptr)))
         return ptr.value
+
+    def time_pruning(self, n_iters, stream=None):
+        """HIP-event milliseconds for n_iters repetitions of the pruning sweep alone (chain state untouched)."""
+        ms = C.c_double(0.0)
+        check(load().phm_engine_time_pruning(self.h, int(n_iters), C.c_void_p(stream) if stream else None, C.byref(ms)))
+        return ms.value
 
     def dump(self, replica=0, seg_cap=512):
         E, T, n = self.ft.E, self.ft.T, self.n

@@ -17,16 +17,14 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from .treeorder import makenodelist, myreorder, pruningwiseedgeorder
+from .treeorder import makenodelist, myreorder, pruningwiseedgeorder  # noqa: F401  (Python twins of phm_tree_orders)
 
 
 def _mcmc(fn_name, z, Q, pid, Omega, N, **opt):
     L = _lib.load()
     Q = np.asfortranarray(np.asarray(Q, dtype=np.float64))
     n = Q.shape[0]
-    nen = np.ascontiguousarray(pruningwiseedgeorder(z), dtype=np.int32)      # R/sumstatMCMC.R:22
-    nodelist = np.ascontiguousarray(makenodelist(z), dtype=np.int32)          # :23
-    root = int(myreorder(z))                                                  # :24
+    nen, nodelist, root = _lib.tree_orders(z)                                 # R/sumstatMCMC.R:22-24, native O(E)
     B = np.asfortranarray(np.eye(n) + Q / Omega)                              # :25
     pid = np.ascontiguousarray(pid, dtype=np.float64)
     ft = _lib.FlatTree(z)
@@ -72,9 +70,7 @@ def sumstatEXP(z, Q, pid, N, **opt):
     L = _lib.load()
     Q = np.asfortranarray(np.asarray(Q, dtype=np.float64))
     n = Q.shape[0]
-    nen = np.ascontiguousarray(pruningwiseedgeorder(z), dtype=np.int32)
-    nodelist = np.ascontiguousarray(makenodelist(z), dtype=np.int32)
-    root = int(myreorder(z))
+    nen, nodelist, root = _lib.tree_orders(z)
     lefts, rights, d = (np.asfortranarray(a) for a in eigen_decompose(Q))
     pid = np.ascontiguousarray(pid, dtype=np.float64)
     ft = _lib.FlatTree(z)

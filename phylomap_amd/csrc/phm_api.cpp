@@ -101,7 +101,7 @@ void fill_params(phm_engine* e, phm::McmcParams<NS>& p, const double* B2, const 
   p.n_tips = e->sched.n_tips; p.n_node = e->sched.n_node; p.n_edge = e->sched.n_edge; p.root = e->sched.root;
   p.n_tiles = e->tiles; p.n_rep = e->S; p.n_rep_pad = e->S_pad; p.replica_offset = o.replica_offset;
   p.normalise = (e->variant == PHM_MCMC_BIGTREE); p.tips_per_replica = e->tips_per_replica ? 1 : 0;
-  p.reduce = e->reduce; p.n_cols = e->cols; p.ktab = phm::MCMC_KTAB;
+  p.reduce = e->reduce; p.n_cols = e->cols; p.ktab = phm::MCMC_KTAB; p.prune_only = 0;
   p.seed_lo = (uint32_t)(o.seed & 0xFFFFFFFFull); p.seed_hi = (uint32_t)(o.seed >> 32);
   p.rows = e->rows;
   for (int i = 0; i < NS * NS; ++i) { p.B2[i] = B2[i]; p.Bc[i] = Bc[i]; }
@@ -728,5 +728,40 @@ extern "C" int32_t phm_engine_reduced_stats_device(phm_engine* e, int32_t iter0,
     HIPCHK(phm::launch_stats_reduce(e->d_stats.as<double>() + (size_t)iter0 * e->tiles * e->cols, n, e->tiles, e->cols,
                                     e->d_red.as<double>(), reinterpret_cast<hipStream_t>(hip_stream)));
   *out_dev = e->d_red.p;
+  return PHM_OK;
+}
+
+// Measurement aid: time `n_iters` repetitions of the pruning (up) sweep alone -- makePLrcpp*, src/phylomap.cpp:503-529 --
+// on the engine's current chain state (segment counts are left untouched, so every repetition does the same work).
+// Returns the HIP-event time in milliseconds.  n <= 4 kernels only.
+extern "C" int32_t phm_engine_time_pruning(phm_engine* e, int32_t n_iters, void* hip_stream, double* ms_out) {
+  if (!e || !ms_out) return fail(PHM_ERR_STATE, "engine/ms_out is NULL");
+  if (e->wide) return fail(PHM_ERR_UNSUPPORTED, "pruning-only timing is implemented for n_states <= 4");
+  if (n_iters < 1) return fail(PHM_ERR_BAD_INPUT, "n_iters must be >= 1");
+  HIPCHK(hipSetDevice(e->device));
+  hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
+  HIPCHK(hipEventRecord(e->ev0, stream));
+  hipError_t le = hipSuccess;
+  // iteration index = iters_done keeps the dwell ping-pong parity; nothing but PL is written
+  if (e->n == 2) { auto p = e->p2; p.prune_only = 1; for (int i = 0; i < n_iters && le == hipSuccess; ++i) le = phm::launch_mcmc<2>(p, e->iters_done, 1, stream); }
+  if (e->n == 3) { auto p = e->p3; p.prune_only = 1; for (int i = 0; i < n_iters && le == hipSuccess; ++i) le = phm::launch_mcmc<3>(p, e->iters_done, 1, stream); }
+  if (e->n == 4) { auto p = e->p4; p.prune_only = 1; for (int i = 0; i < n_iters && le == hipSuccess; ++i) le = phm::launch_mcmc<4>(p, e->iters_done, 1, stream); }
+  HIPCHK(le);
+  HIPCHK(hipEventRecord(e->ev1, stream));
+  HIPCHK(hipStreamSynchronize(stream));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+  *ms_out = ms;
+  e->last_stream = stream;
+  e->timing_pending = false;
+  return PHM_OK;
+}
+
+// Native O(E) replacement of pruningwiseedgeorder / makenodelist / myreorder (R/sumstatMCMC.R:1-18); pure host code.
+extern "C" int32_t phm_tree_orders(int32_t n_tips, int32_t n_edge, const int32_t* edge, int32_t* nen, int32_t* nodelist,
+                                   int32_t* root) {
+  if (!edge || !nen || !nodelist || !root) return fail(PHM_ERR_BAD_INPUT, "phm_tree_orders: NULL argument");
+  std::string serr;
+  if (!phm::pruningwise_orders(n_tips, n_edge, edge, nen, nodelist, root, serr)) return fail(PHM_ERR_BAD_INPUT, serr);
   return PHM_OK;
 }

@@ -19,6 +19,7 @@ struct McmcParams {
   int32_t n_tiles, n_rep, n_rep_pad, replica_offset;
   int32_t normalise, tips_per_replica, reduce, n_cols;
   int32_t ktab;
+  int32_t prune_only;                        // measurement aid: run only the pruning (up) sweep of each iteration
   uint32_t seed_lo, seed_hi;
   int64_t rows;                              // capacity (64-lane rows) of one tile's dwell stream
   double B2[NS * NS];                        // dense B = I + Q/Omega, row-major

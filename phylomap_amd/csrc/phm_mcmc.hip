@@ -129,6 +129,8 @@ __global__ __launch_bounds__(MCMC_BLOCK, 5) void mcmc_sweep_kernel(McmcParams<NS
       for (int c = 0; c < NS; ++c) PLt[(st.parent * NS + c) * 64 + lane] = x[c];
     }
 
+    if (p.prune_only) continue;      // wave-uniform: the pruning sweep alone (bench.py "pruning" roofline)
+
     // ------------------------------ root state ------------------------------
     {
       double pr[NS];

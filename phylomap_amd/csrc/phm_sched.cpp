@@ -1,6 +1,7 @@
 // phm_sched.cpp -- see phm_sched.h
 #include "phm_sched.h"
 
+#include <algorithm>
 #include <cmath>
 
 namespace phm {
@@ -123,6 +124,59 @@ bool check_reference_orders(const Schedule& s, const int32_t* edge, const int32_
       have[v - 1] = 1;
     }
   }
+  return true;
+}
+
+bool pruningwise_orders(int32_t T, int32_t E, const int32_t* edge, int32_t* nen, int32_t* nodelist, int32_t* root_out,
+                        std::string& err) {
+  if (T < 2 || E < 2 || !edge) { err = "bad tree"; return false; }
+  const int32_t* e1 = edge;
+  const int32_t* e2 = edge + E;
+  int32_t nn = 0;
+  for (int32_t r = 0; r < E; ++r) { nn = std::max(nn, std::max(e1[r], e2[r])); if (e1[r] < 1 || e2[r] < 1) { err = "node ids must be >= 1"; return false; } }
+  std::vector<std::vector<int32_t>> kids(nn + 1);
+  std::vector<char> is_child(nn + 1, 0);
+  for (int32_t r = 0; r < E; ++r) { kids[e1[r]].push_back(r); is_child[e2[r]] = 1; }
+  int32_t root = -1;
+  for (int32_t v = 1; v <= nn; ++v)
+    if (!kids[v].empty() && !is_child[v]) { if (root != -1) { err = "tree has more than one root"; return false; } root = v; }
+  if (root == -1) { err = "tree has no root"; return false; }
+  // cladewise position of every edge: pre-order, children in row order
+  std::vector<int32_t> pos(E, -1), by_pos;
+  by_pos.reserve(E);
+  std::vector<int32_t> stack(kids[root].rbegin(), kids[root].rend());
+  while (!stack.empty()) {
+    int32_t r = stack.back(); stack.pop_back();
+    if (pos[r] != -1) { err = "edge table is not a tree"; return false; }
+    pos[r] = (int32_t)by_pos.size();
+    by_pos.push_back(r);
+    const auto& k = kids[e2[r]];
+    for (auto it = k.rbegin(); it != k.rend(); ++it) stack.push_back(*it);
+  }
+  if ((int32_t)by_pos.size() != E) { err = "edge table is not a connected rooted tree"; return false; }
+  std::vector<int32_t> height(nn + 1, 0), lastpos(nn + 1, -1);
+  for (int32_t i = E - 1; i >= 0; --i) {
+    int32_t r = by_pos[i];
+    height[e1[r]] = std::max(height[e1[r]], height[e2[r]] + 1);
+    lastpos[e1[r]] = std::max(lastpos[e1[r]], pos[r]);
+  }
+  std::vector<int32_t> internal;
+  for (int32_t v = 1; v <= nn; ++v) if (!kids[v].empty() && v != root) internal.push_back(v);
+  std::sort(internal.begin(), internal.end(), [&](int32_t a, int32_t b) {
+    return height[a] != height[b] ? height[a] < height[b] : lastpos[a] < lastpos[b];
+  });
+  internal.push_back(root);
+  std::vector<int32_t> rows;
+  rows.reserve(E);
+  for (int32_t v : internal) {
+    std::vector<int32_t> k = kids[v];
+    std::sort(k.begin(), k.end(), [&](int32_t a, int32_t b) { return pos[a] < pos[b]; });
+    for (int32_t r : k) rows.push_back(r);
+  }
+  for (int32_t i = 0; i < E; ++i) nen[i] = rows[i] + 1;
+  const int32_t n_node = (int32_t)internal.size();
+  for (int32_t i = 1; i < n_node; ++i) nodelist[i - 1] = e1[rows[E - 2 * i - 1]];     // R/sumstatMCMC.R:11-17
+  *root_out = e1[rows[E - 1]];                                                          // :18
   return true;
 }
 

@@ -44,6 +44,13 @@ bool build_schedule(int32_t n_tips, int32_t n_node, int32_t n_edge, const int32_
 bool check_reference_orders(const Schedule& s, const int32_t* edge, const int32_t* nen,
                             const int32_t* nodelist, int32_t root, std::string& err);
 
+// O(E) native replacement of the R helper preamble (R/sumstatMCMC.R:1-18): pruningwiseedgeorder(), makenodelist(),
+// myreorder().  ape's "pruningwise" order restated from its published scan algorithm: a node is collected in scan
+// number height(node); within one scan, in the order its last child edge is met in the cladewise edge table.
+// nen: n_edge 1-based rows; nodelist: n_node-1 node ids (root side first); root: node id.
+bool pruningwise_orders(int32_t n_tips, int32_t n_edge, const int32_t* edge, int32_t* nen, int32_t* nodelist,
+                        int32_t* root, std::string& err);
+
 // Upper quantile of the segment count 1 + Poisson(lambda) of a branch in stationarity:
 // 1 + smallest c with P(Poisson(lambda) >= c) < tail.
 int32_t poisson_capacity(double lambda, double tail);

@@ -70,6 +70,18 @@ def test_pruningwise_order_properties_and_scan_twin(tips, seed):
     np.testing.assert_array_equal(rows, _ape_pruningwise_scan(edge, tips))
 
 
+@pytest.mark.parametrize("tips,seed,shuffle", [(2, 1, False), (9, 2, False), (300, 3, False), (50, 4, True), (2000, 5, True)])
+def test_native_tree_orders_equal_python_twin(tips, seed, shuffle):
+    edge, _ = synth.random_tree(tips, 1.0, seed)
+    if shuffle:
+        edge = edge[np.random.default_rng(seed).permutation(edge.shape[0])]
+    z = {"edge": edge, "Nnode": tips - 1}
+    nen, nodelist, root = _lib.tree_orders(z)
+    np.testing.assert_array_equal(nen, treeorder.pruningwiseedgeorder(z))
+    np.testing.assert_array_equal(nodelist, treeorder.makenodelist(z))
+    assert root == treeorder.myreorder(z)
+
+
 def test_pruningwise_on_shuffled_rows_maps_back():
     edge, _ = synth.random_tree(30, 1.0, 9)
     perm = np.random.default_rng(0).permutation(edge.shape[0])
