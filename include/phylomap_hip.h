@@ -46,7 +46,13 @@ typedef enum phm_status {
 typedef enum phm_variant {
   PHM_MCMC = 0,               /* maketreelistMCMC          src/phylomap.cpp:891-935  */
   PHM_MCMC_BIGTREE = 1,       /* maketreelistMCMC_bigtree  src/phylomap.cpp:942-986  (row-normalised PL, :525) */
-  PHM_MCMC_SPARSE = 2         /* SPARSEmaketreelistMCMC    src/phylomap.cpp:822-870  (B entries <= 1e-7 dropped, :811) */
+  PHM_MCMC_SPARSE = 2,        /* SPARSEmaketreelistMCMC    src/phylomap.cpp:822-870  (B entries <= 1e-7 dropped, :811) */
+  PHM_MCMC_KS = 3             /* the TREE SWEEP of maketreelistMCMCks (treesampleks :1422-1432) with Q held fixed: hidden-rates
+                                 Q of even size n = 2k+2, parity tip masks (:1838-1845), tips re-sampled (:1384-1397), all
+                                 consecutive state pairs counted into n x n counters (shortenerbf :1010-1014).  Result layout
+                                 man/sumstatMCMCks.Rd:19: N x (n + n*n + 2 + 3k + 1): dwell, counts (row-major from,to),
+                                 l01, l10, rkappas, lkappas, gammas (recordQks :1789-1798), root state (0-based).
+                                 The per-iteration Gibbs/MH updates of Q (:1862-1866) are host glue that is not built yet. */
 } phm_variant;
 
 /* The phylomap tree object `x` (fields read at src/phylomap.cpp:896-910 and :3034). */
@@ -118,6 +124,11 @@ int32_t phm_maketreelistMCMC_bigtree( /* src/phylomap.cpp:942, src/RcppExports.c
     const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
     const phm_options* opt, double* out);
 int32_t phm_SPARSEmaketreelistMCMC(   /* src/phylomap.cpp:822, src/RcppExports.cpp:11 */
+    const phm_tree* x, int32_t n_states, const double* Q, const double* pid, const double* B, double Omega,
+    const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
+    const phm_options* opt, double* out);
+/* Tree sweep of sumstatMCMCks with Q held fixed (see PHM_MCMC_KS); out: N x (n + n*n + 2 + 3k + 1) column-major. */
+int32_t phm_maketreelistMCMCks_sweep( /* src/phylomap.cpp:1802 minus the Q updates of :1862-1866 */
     const phm_tree* x, int32_t n_states, const double* Q, const double* pid, const double* B, double Omega,
     const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
     const phm_options* opt, double* out);

@@ -225,6 +225,16 @@ static void makeabranch(Branch* b, const double* maps, const int32_t* names, int
 
 /* shortener, src/phylomap.cpp:44-73: merge equal neighbours, then count a->b (a != b) transitions */
 static int shortener_arr(double* d, int32_t* s, int m, int n, double* stats, int64_t stride, int iter) {
+  if (n < 0) {                 /* shortenerbf, src/phylomap.cpp:997-1028: count EVERY consecutive pair, self pairs */
+    n = -n;                    /* included, into n + a*n + b BEFORE merging (:1010-1014); then merge as usual  */
+    for (int i = 1; i < m; ++i) stats[(int64_t)(n + s[i - 1] * n + s[i]) * stride + iter] += 1.0;
+    int w2 = 0;
+    for (int i = 1; i < m; ++i) {
+      if (s[i] != s[w2]) { ++w2; d[w2] = d[i]; s[w2] = s[i]; }
+      else d[w2] = d[w2] + d[i];
+    }
+    return (m > 0) ? w2 + 1 : 0;
+  }
   int w = 0;
   for (int i = 1; i < m; ++i) {
     if (s[i] != s[w]) { ++w; d[w] = d[i]; s[w] = s[i]; }
@@ -272,13 +282,14 @@ static void resamplebranchstates(Branch* br, const double* Bchain, const double*
 
 /* sampleabranch, src/phylomap.cpp:370-413 (SPARSE twin :318-364) */
 static void sampleabranch(Branch* br, const double* Bchain, const double* Brow, double Omega,
-                          const double* Qdiag, int n, double* stats, int64_t stride, int iter,
+                          const double* Qdiag, int n_signed, double* stats, int64_t stride, int iter,
                           rngctx* rc, uint32_t branch_id, double** scratch, size_t* scratch_len,
                           Branch* tmp) {
+  const int n = n_signed < 0 ? -n_signed : n_signed;       /* negative: sampleabranchbf :1031-1074 (bf counting) */
   size_t need = (size_t)n * (br->m + 2);
   if (need > *scratch_len) { *scratch = (double*)realloc(*scratch, sizeof(double) * need); *scratch_len = need; }
   resamplebranchstates(br, Bchain, Brow, n, rc, (uint32_t)iter, branch_id, *scratch);   /* :376 */
-  br->m = shortener_arr(br->d, br->s, br->m, n, stats, stride, iter);                   /* :377 */
+  br->m = shortener_arr(br->d, br->s, br->m, n_signed, stats, stride, iter);            /* :377 / :1038 */
   /* re-insert virtual jumps: gaps ~ Exp(rate Omega + Q[s,s]) until the segment is used up (:391-410) */
   tmp->m = 0;
   uint32_t edraw = 0;
@@ -401,7 +412,8 @@ static void sampleinternalnodesMCMC(Branch* brs, int E, double* PL, const double
                                     const int32_t* edge1, const int32_t* edge2, int Nnode,
                                     const int32_t* states, int T, int normalise, int n,
                                     int faithful_search, const int32_t* edge_of_child,
-                                    rngctx* rc, uint32_t iter, int32_t* rm, int32_t* branchlengths, double* w) {
+                                    rngctx* rc, uint32_t iter, int32_t* rm, int32_t* branchlengths, double* w,
+                                    int ks, double* root_out) {
   for (int i = 0; i < E; ++i) branchlengths[i] = brs[i].m;                   /* :598-599 */
   for (int i = 0; i < 2 * T - 1; ++i) rm[i] = 0;
   for (int i = 0; i < T; ++i) rm[i] = states[i] - 1;                         /* :612 */
@@ -409,6 +421,7 @@ static void sampleinternalnodesMCMC(Branch* brs, int E, double* PL, const double
   double* p = w; double* vecc = w + n; double* tmp = w + 2 * n;
   for (int c = 0; c < n; ++c) p[c] = pid[c] * PL[(size_t)(root - 1) * n + c];    /* :618 */
   rm[root - 1] = sample_cat(p, n, draw_u(rc, iter, ENT_NODE | (uint32_t)(root - 1), 0), &rc->err);   /* :627 */
+  (void)root_out;
   for (int i = 0; i < nll; ++i) {
     int cn = nodelist[i] - 1;                                                /* :641 */
     int j = 0;
@@ -421,6 +434,19 @@ static void sampleinternalnodesMCMC(Branch* brs, int E, double* PL, const double
     chainT(Bchain, vecc, branchlengths[j] - 1, n, tmp);                      /* :651 Tvmmp / :576 spvmmmm */
     for (int c = 0; c < n; ++c) p[c] = vecc[c] * PL[(size_t)cn * n + c];
     rm[cn] = sample_cat(p, n, draw_u(rc, iter, ENT_NODE | (uint32_t)cn, 0), &rc->err);   /* :655 */
+  }
+  if (ks) {
+    *root_out = (double)rm[root - 1];                                        /* :1350-1352, 0-based */
+    for (int i = 0; i < E; ++i) {                                            /* tips "don't remain the same" :1384-1397 */
+      if (edge2[i] <= T) {
+        int cn = edge2[i] - 1, ps = rm[edge1[i] - 1];
+        for (int c = 0; c < n; ++c) vecc[c] = 0.0;
+        vecc[ps] = 1.0;
+        chainT(Bchain, vecc, branchlengths[i] - 1, n, tmp);
+        for (int c = 0; c < n; ++c) p[c] = vecc[c] * PL[(size_t)cn * n + c];
+        rm[cn] = sample_cat(p, n, draw_u(rc, iter, ENT_NODE | (uint32_t)cn, 0), &rc->err);
+      }
+    }
   }
   for (int i = 0; i < 2 * T - 1; ++i) rm[i] = rm[i] + 1;                     /* :659 */
 }
@@ -453,7 +479,10 @@ int orc_maketreelistMCMC(const orc_tree* x, int n, const double* Q_cm, const dou
   if (n < 2 || N < 0) return ORC_ERR_BAD_INPUT;
   int E = x->n_edge, T = x->n_tips, Nnode = x->n_node;
   const int32_t* edge1 = x->edge; const int32_t* edge2 = x->edge + E;
-  int cols = n + n * (n - 1);
+  const int ks = (variant == ORC_MCMC_KS);
+  if (ks && (n & 1)) return ORC_ERR_BAD_INPUT;                /* hidden-rates structure: n = 2k+2 (:1820) */
+  const int kk = n / 2 - 1;
+  int cols = ks ? n + n * n + 2 + 3 * kk + 1 : n + n * (n - 1);
   rngctx rc = { rng, 0 };
 
   double* B2 = (double*)malloc(sizeof(double) * n * n);       /* row-major copies */
@@ -462,7 +491,7 @@ int orc_maketreelistMCMC(const orc_tree* x, int n, const double* Q_cm, const dou
   for (int i = 0; i < n; ++i) { Qd[i] = Q_cm[i + (size_t)i * n]; for (int j = 0; j < n; ++j) B2[i * n + j] = B_cm[i + (size_t)j * n]; }
   if (variant == ORC_MCMC_SPARSE) orc_matTospmat(B2, n, Bc);  /* :848 */
   else memcpy(Bc, B2, sizeof(double) * n * n);
-  int normalise = (variant == ORC_MCMC_BIGTREE);
+  int normalise = (variant == ORC_MCMC_BIGTREE) || ks;        /* makePLnormalized :1085 */
 
   Branch* brs = (Branch*)calloc(E, sizeof(Branch));
   for (int i = 0; i < E; ++i) {
@@ -472,7 +501,9 @@ int orc_maketreelistMCMC(const orc_tree* x, int n, const double* Q_cm, const dou
   }
   size_t pl_len = (size_t)(2 * Nnode + 1) * n;
   double* PL = (double*)calloc(pl_len, sizeof(double));
-  for (int i = 0; i < T; ++i) PL[(size_t)i * n + (x->states[i] - 1)] = 1.0;   /* :914 */
+  if (!ks) for (int i = 0; i < T; ++i) PL[(size_t)i * n + (x->states[i] - 1)] = 1.0;   /* :914 */
+  else for (int i = 0; i < T; ++i)                            /* only the binary trait is observed :1838-1845 */
+    for (int j = (x->states[i] % 2 == 0) ? 1 : 0; j < n; j += 2) PL[(size_t)i * n + j] = 1.0;
   int32_t* rm = (int32_t*)calloc(2 * T - 1, sizeof(int32_t));
   int32_t* bl = (int32_t*)calloc(E, sizeof(int32_t));
   int32_t* eoc = (int32_t*)calloc(2 * T - 1, sizeof(int32_t));
@@ -483,11 +514,23 @@ int orc_maketreelistMCMC(const orc_tree* x, int n, const double* Q_cm, const dou
   memset(out, 0, sizeof(double) * (size_t)N * cols);          /* :926 */
 
   if (!e) for (int it = 0; it < N; ++it) {
+    double rootst = 0.0;
+    if (ks) {                                                 /* recordQks :1789-1798 (Q is row i, col j = Q_cm[i + j*n]) */
+      int base = n + n * n;
+      out[(int64_t)base * N + it] = Q_cm[0 + (size_t)1 * n];
+      out[(int64_t)(base + 1) * N + it] = Q_cm[1 + (size_t)0 * n];
+      for (int i = 0; i < kk; ++i) {
+        out[(int64_t)(base + 2 + i) * N + it] = Q_cm[(2 * i) + (size_t)(2 * i + 2) * n];
+        out[(int64_t)(base + 2 + kk + i) * N + it] = Q_cm[(2 * i + 2) + (size_t)(2 * i) * n];
+        out[(int64_t)(base + 2 + 2 * kk + i) * N + it] = Q_cm[(2 * (i + 1)) + (size_t)(2 * (i + 1) + 1) * n] / Q_cm[0 + (size_t)1 * n];
+      }
+    }
     sampleinternalnodesMCMC(brs, E, PL, pid, Bc, root, nodelist, Nnode - 1, nen, edge1, edge2, Nnode,
-                            x->states, T, normalise, n, faithful_search, eoc, &rc, (uint32_t)it, rm, bl, w);
-    updatenodestates(brs, edge1, edge2, E, rm);                                              /* :779 */
-    for (int i = 0; i < E; ++i)                                                              /* :781 */
-      sampleabranch(&brs[i], Bc, B2, Omega, Qd, n, out, N, it, &rc, (uint32_t)i, &scratch, &scratch_len, &tmp);
+                            x->states, T, normalise, n, faithful_search, eoc, &rc, (uint32_t)it, rm, bl, w, ks, &rootst);
+    if (ks) out[(int64_t)(n + n * n + 2 + 3 * kk) * N + it] = rootst;
+    updatenodestates(brs, edge1, edge2, E, rm);                                              /* :779 / :1426 */
+    for (int i = 0; i < E; ++i)                                                              /* :781 / :1428 */
+      sampleabranch(&brs[i], Bc, B2, Omega, Qd, ks ? -n : n, out, N, it, &rc, (uint32_t)i, &scratch, &scratch_len, &tmp);
     for (int i = 0; i < E; ++i) updatedwelltimes(it, &brs[i], out, N);                       /* :782 */
   }
   fill_dump(dump, brs, E, rm, 2 * T - 1, PL, pl_len);

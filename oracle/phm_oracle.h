@@ -35,6 +35,10 @@ extern "C" {
 #define ORC_MCMC_PLAIN    0   /* maketreelistMCMC          src/phylomap.cpp:891-935 */
 #define ORC_MCMC_BIGTREE  1   /* maketreelistMCMC_bigtree  src/phylomap.cpp:942-986 */
 #define ORC_MCMC_SPARSE   2   /* SPARSEmaketreelistMCMC    src/phylomap.cpp:822-870 */
+#define ORC_MCMC_KS       3   /* tree sweep of maketreelistMCMCks src/phylomap.cpp:1802-1872 with Q held fixed:
+                                 parity tip masks :1838-1845, makePLnormalized :1077-1088, tip re-sampling :1384-1397,
+                                 shortenerbf counts :1010-1014, recordQks :1789-1798, root state :1350-1352;
+                                 the Gibbs/MH updates of Q (:1862-1866) are NOT run.  out: N x (n+n*n+2+3k+1) */
 
 /* RNG: mode 0 = counter-based Philox4x32-10 streams (the mode the GPU matches bit for bit);
  *      mode 1 = scripted tapes consumed in the reference's draw order (for hand KATs). */

@@ -13,11 +13,12 @@ LIB_PATH = os.path.join(_HERE, "libphylomap_hip.so")
 PHM_OK = 0
 STATUS = {0: "PHM_OK", 1: "PHM_ERR_BAD_INPUT", 2: "PHM_ERR_UNSUPPORTED", 3: "PHM_ERR_NO_DEVICE", 4: "PHM_ERR_OOM",
           5: "PHM_ERR_ZERO_PROB", 6: "PHM_ERR_CAPACITY", 7: "PHM_ERR_UNIF_CAP", 8: "PHM_ERR_STATE"}
-PHM_MCMC, PHM_MCMC_BIGTREE, PHM_MCMC_SPARSE = 0, 1, 2
+PHM_MCMC, PHM_MCMC_BIGTREE, PHM_MCMC_SPARSE, PHM_MCMC_KS = 0, 1, 2, 3
 
 EXPORTS = [
     "phm_version", "phm_device_count", "phm_last_error", "phm_status_string",
     "phm_maketreelistMCMC", "phm_maketreelistMCMC_bigtree", "phm_SPARSEmaketreelistMCMC", "phm_maketreelistEXP",
+    "phm_maketreelistMCMCks_sweep",
     "phm_expm_eigen", "phm_expm_pade",
     "phm_engine_create", "phm_engine_run", "phm_engine_sync", "phm_engine_read_stats", "phm_engine_dump",
     "phm_engine_info", "phm_engine_destroy", "phm_engine_reduced_stats_device",
@@ -96,6 +97,7 @@ def load():
         L.phm_maketreelistMCMC.argtypes = mc
         L.phm_maketreelistMCMC_bigtree.argtypes = mc
         L.phm_SPARSEmaketreelistMCMC.argtypes = mc
+        L.phm_maketreelistMCMCks_sweep.argtypes = mc
         L.phm_maketreelistEXP.argtypes = [C.POINTER(Tree), C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                           C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, C.c_int32,
                                           C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
@@ -176,6 +178,8 @@ class Engine:
         check(L.phm_engine_create(C.byref(self.ft.c), C.byref(self.model), C.byref(self.opt), int(max_iters),
                                   C.byref(self.h)))
         self.cols = self.n + self.n * (self.n - 1)
+        if int(variant) == PHM_MCMC_KS:
+            self.cols = self.n + self.n * self.n + 2 + 3 * (self.n // 2 - 1) + 1
         self.S = max(1, int(self.opt.n_replicas))
         self.reduce = bool(self.opt.reduce)
 

@@ -31,6 +31,8 @@ def _mcmc(fn_name, z, Q, pid, Omega, N, **opt):
     o = _lib.make_options(**opt)
     S = max(1, int(o.n_replicas))
     cols = n + n * (n - 1)
+    if fn_name == "phm_maketreelistMCMCks_sweep":
+        cols = n + n * n + 2 + 3 * (n // 2 - 1) + 1                         # man/sumstatMCMCks.Rd:19
     single = bool(o.reduce) or S == 1
     out = np.zeros((N, cols), order="F") if single else np.zeros((S, cols, N))
     st = getattr(L, fn_name)(C.byref(ft.c), n, _lib._p(Q, C.c_double), _lib._p(pid, C.c_double),
@@ -53,6 +55,15 @@ def sumstatMCMC_bigtree(z, Q, pid, Omega, N, **opt):
 def SPARSEsumstatMCMC(z, Q, pid, Omega, N, **opt):
     """R/SPARSEsumstatMCMC.R:21-29 -> phm_SPARSEmaketreelistMCMC."""
     return _mcmc("phm_SPARSEmaketreelistMCMC", z, Q, pid, Omega, N, **opt)
+
+
+def sumstatMCMCks_sweep(z, Q, pid, Omega, N, **opt):
+    """The tree sweep of ``sumstatMCMCks`` (R/sumstatMCMCks.R, src/phylomap.cpp:1802-1872) with Q held FIXED:
+    hidden-rates Q of even size (``synth.make2sQ``), tips observed only up to parity and re-sampled every sweep,
+    n x n transition counters including self pairs, result layout of man/sumstatMCMCks.Rd:19.  The per-iteration
+    Gibbs/MH updates of Q driven by ``prior`` (src/phylomap.cpp:1862-1866) are host glue that is not built yet, so
+    this is not yet a drop-in for ``sumstatMCMCks(z,Q,pid,Omega,N,prior)``."""
+    return _mcmc("phm_maketreelistMCMCks_sweep", z, Q, pid, Omega, N, **opt)
 
 
 def eigen_decompose(Q):

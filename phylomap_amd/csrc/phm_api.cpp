@@ -66,13 +66,15 @@ int32_t device_status(uint32_t derr) {
 
 // -------------------------------------------------------------------------------------------------
 struct phm_engine {
-  int n = 0, cols = 0, variant = 0;
+  int n = 0, cols = 0, dcols = 0, variant = 0;   // cols: result columns; dcols: columns kept on the device
+  std::vector<double> qparams;                     // ks: l01, l10, rkappas, lkappas, gammas (recordQks :1789-1798)
   int S = 0, S_pad = 0, tiles = 0, max_iters = 0, iters_done = 0, ipl = 0;
   int reduce = 0, device = 0;
   phm::Schedule sched;
   std::vector<uint8_t> tips_host;      // 0-based, [n_tips] or [S][n_tips]
   bool tips_per_replica = false;
   int64_t rows = 0;
+  DevBuf d_mask;
   DevBuf d_up, d_down, d_col, d_row, d_tips, d_mcount, d_dw0, d_dw1, d_PL, d_nstate, d_stats, d_err, d_seg, d_red;
   phm::McmcParams<2> p2;
   phm::McmcParams<3> p3;
@@ -100,8 +102,9 @@ void fill_params(phm_engine* e, phm::McmcParams<NS>& p, const double* B2, const 
                  const double* pid, const phm_options& o) {
   p.n_tips = e->sched.n_tips; p.n_node = e->sched.n_node; p.n_edge = e->sched.n_edge; p.root = e->sched.root;
   p.n_tiles = e->tiles; p.n_rep = e->S; p.n_rep_pad = e->S_pad; p.replica_offset = o.replica_offset;
-  p.normalise = (e->variant == PHM_MCMC_BIGTREE); p.tips_per_replica = e->tips_per_replica ? 1 : 0;
-  p.reduce = e->reduce; p.n_cols = e->cols; p.ktab = phm::MCMC_KTAB; p.prune_only = 0;
+  p.normalise = (e->variant == PHM_MCMC_BIGTREE || e->variant == PHM_MCMC_KS); p.tips_per_replica = e->tips_per_replica ? 1 : 0;
+  p.reduce = e->reduce; p.n_cols = e->dcols; p.ktab = phm::MCMC_KTAB; p.prune_only = 0;
+  p.ks = (e->variant == PHM_MCMC_KS); p.maskpow = e->d_mask.as<double>();
   p.seed_lo = (uint32_t)(o.seed & 0xFFFFFFFFull); p.seed_hi = (uint32_t)(o.seed >> 32);
   p.rows = e->rows;
   for (int i = 0; i < NS * NS; ++i) { p.B2[i] = B2[i]; p.Bc[i] = Bc[i]; }
@@ -199,7 +202,8 @@ int32_t phm_engine_create(const phm_tree* x, const phm_model* model, const phm_o
   if (n < 2) return fail(PHM_ERR_BAD_INPUT, "n_states must be >= 2");
   if (n > 64) return fail(PHM_ERR_UNSUPPORTED, "this build has MCMC kernels for n_states <= 64 only");
   if (!model->Q || !model->pid) return fail(PHM_ERR_BAD_INPUT, "model: Q/pid missing");
-  if (model->variant < PHM_MCMC || model->variant > PHM_MCMC_SPARSE) return fail(PHM_ERR_BAD_INPUT, "unknown variant");
+  if (model->variant < PHM_MCMC || model->variant > PHM_MCMC_KS) return fail(PHM_ERR_BAD_INPUT, "unknown variant");
+  if (model->variant == PHM_MCMC_KS && (n & 1)) return fail(PHM_ERR_BAD_INPUT, "sumstatMCMCks needs a hidden-rates Q of even size n = 2k+2 (src/phylomap.cpp:1820)");
   if (max_iters < 1) return fail(PHM_ERR_BAD_INPUT, "max_iters must be >= 1");
   if (!(model->Omega > 0.0) || !std::isfinite(model->Omega)) return fail(PHM_ERR_BAD_INPUT, "Omega must be positive");
   int32_t st = validate_tree_paths(x, n, o.tips_per_replica ? o.n_replicas : 1);
@@ -227,7 +231,19 @@ int32_t phm_engine_create(const phm_tree* x, const phm_model* model, const phm_o
   phm_engine* e = new phm_engine();
   std::unique_ptr<phm_engine> guard(e);
   e->n = n; e->cols = n + n * (n - 1); e->variant = model->variant;
+  e->dcols = e->cols;
   e->wide = n > 4;
+  if (e->variant == PHM_MCMC_KS) {
+    const int k = n / 2 - 1;
+    e->cols = n + n * n + 2 + 3 * k + 1;
+    e->dcols = n + n * n + 1;
+    auto Qe = [&](int i, int j) { return model->Q[i + (size_t)j * n]; };
+    e->qparams.push_back(Qe(0, 1));
+    e->qparams.push_back(Qe(1, 0));
+    for (int i = 0; i < k; ++i) e->qparams.push_back(Qe(2 * i, 2 * i + 2));
+    for (int i = 0; i < k; ++i) e->qparams.push_back(Qe(2 * i + 2, 2 * i));
+    for (int i = 0; i < k; ++i) e->qparams.push_back(Qe(2 * (i + 1), 2 * (i + 1) + 1) / Qe(0, 1));
+  }
   e->S = o.n_replicas; e->tiles = (e->S + 63) / 64; e->S_pad = e->tiles * 64;
   e->max_iters = max_iters; e->reduce = o.reduce ? 1 : 0;
   e->ipl = o.iters_per_launch > 0 ? o.iters_per_launch : 8;
@@ -276,10 +292,24 @@ int32_t phm_engine_create(const phm_tree* x, const phm_model* model, const phm_o
   }
 
   std::vector<double> col, row;
-  build_chain_tables(Bc, n, e->wide ? phm::WIDE_KTAB : phm::MCMC_KTAB, col, row);
+  const int ktab = e->wide ? phm::WIDE_KTAB : phm::MCMC_KTAB;
+  build_chain_tables(Bc, n, ktab, col, row);
+  std::vector<double> maskpow((size_t)ktab * 2 * n, 0.0);      // ks: Bc^k applied to the even / odd state masks (:1838-1845)
+  for (int par = 0; par < 2; ++par) {
+    for (int c = 0; c < n; ++c) maskpow[(size_t)par * n + c] = ((c & 1) == par) ? 1.0 : 0.0;
+    for (int k = 1; k < ktab; ++k) {
+      const double* v = &maskpow[((size_t)(k - 1) * 2 + par) * n];
+      double* y = &maskpow[((size_t)k * 2 + par) * n];
+      for (int i = 0; i < n; ++i) {
+        double acc = Bc[i * n] * v[0];
+        for (int c = 1; c < n; ++c) acc += Bc[i * n + c] * v[c];
+        y[i] = acc;
+      }
+    }
+  }
 
-  const size_t stats_bytes = (e->reduce && !e->wide) ? sizeof(double) * (size_t)max_iters * e->tiles * e->cols
-                                       : sizeof(double) * (size_t)max_iters * e->cols * e->S_pad;
+  const size_t stats_bytes = (e->reduce && !e->wide) ? sizeof(double) * (size_t)max_iters * e->tiles * e->dcols
+                                                     : sizeof(double) * (size_t)max_iters * e->dcols * e->S_pad;
   const size_t dw_bytes = sizeof(double) * (size_t)e->tiles * rows * 64;
   size_t need = 2 * dw_bytes + stats_bytes + sizeof(double) * (size_t)e->tiles * s.n_node * n * 64 +
                 (size_t)e->tiles * (s.n_node + 2 * (size_t)E) * 64 + e->tips_host.size();
@@ -294,6 +324,8 @@ int32_t phm_engine_create(const phm_tree* x, const phm_model* model, const phm_o
   HIPCHK(e->d_down.alloc(sizeof(phm::DownStep) * s.down.size()));
   HIPCHK(e->d_col.alloc(sizeof(double) * col.size()));
   HIPCHK(e->d_row.alloc(sizeof(double) * row.size()));
+  HIPCHK(e->d_mask.alloc(sizeof(double) * maskpow.size()));
+  HIPCHK(hipMemcpy(e->d_mask.p, maskpow.data(), e->d_mask.bytes, hipMemcpyHostToDevice));
   HIPCHK(e->d_tips.alloc(e->tips_host.size()));
   HIPCHK(e->d_mcount.alloc(sizeof(uint16_t) * (size_t)e->tiles * E * 64));
   HIPCHK(e->d_dw0.alloc(dw_bytes));
@@ -303,7 +335,7 @@ int32_t phm_engine_create(const phm_tree* x, const phm_model* model, const phm_o
   HIPCHK(e->d_stats.alloc(stats_bytes));
   HIPCHK(e->d_err.alloc(sizeof(uint32_t)));
   HIPCHK(e->d_seg.alloc(sizeof(unsigned long long)));
-  if (e->reduce) HIPCHK(e->d_red.alloc(sizeof(double) * (size_t)max_iters * e->cols));
+  if (e->reduce) HIPCHK(e->d_red.alloc(sizeof(double) * (size_t)max_iters * e->dcols));
   e->bytes = (int64_t)(e->d_up.bytes + e->d_down.bytes + e->d_col.bytes + e->d_row.bytes + e->d_tips.bytes + e->d_mcount.bytes +
                        e->d_dw0.bytes + e->d_dw1.bytes + e->d_PL.bytes + e->d_nstate.bytes + e->d_stats.bytes + e->d_red.bytes);
 
@@ -340,8 +372,9 @@ int32_t phm_engine_create(const phm_tree* x, const phm_model* model, const phm_o
     phm::WideParams& p = e->pw;
     p.n_states = n; p.n_tips = s.n_tips; p.n_node = s.n_node; p.n_edge = s.n_edge; p.root = s.root;
     p.n_tiles = e->tiles; p.n_rep = e->S; p.n_rep_pad = e->S_pad; p.replica_offset = o.replica_offset;
-    p.normalise = (e->variant == PHM_MCMC_BIGTREE); p.tips_per_replica = e->tips_per_replica ? 1 : 0;
-    p.n_cols = e->cols; p.ktab = phm::WIDE_KTAB; p.count_self = 0;
+    p.normalise = (e->variant == PHM_MCMC_BIGTREE || e->variant == PHM_MCMC_KS); p.tips_per_replica = e->tips_per_replica ? 1 : 0;
+    p.n_cols = e->dcols; p.ktab = phm::WIDE_KTAB; p.ks = (e->variant == PHM_MCMC_KS); p.count_self = p.ks;
+    p.maskpow = e->d_mask.as<double>();
     p.seed_lo = (uint32_t)(o.seed & 0xFFFFFFFFull); p.seed_hi = (uint32_t)(o.seed >> 32);
     p.rows = e->rows;
     p.B2 = e->d_B2.as<double>(); p.Bc = e->d_Bc.as<double>(); p.scale = e->d_scale.as<double>(); p.pid = e->d_pid.as<double>();
@@ -409,25 +442,36 @@ int32_t phm_engine_read_stats(phm_engine* e, int32_t iter0, int32_t n, double* o
   if (n == 0) return PHM_OK;
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipStreamSynchronize(e->last_stream));
-  const int cols = e->cols;
+  const int cols = e->cols, dcols = e->dcols;
+  // device column -> result column: identical except for ks, whose parameter columns (recordQks) sit between the
+  // counters and the root state and are constants of the fixed Q
+  auto out_col = [&](int dc) { return (dcols != cols && dc == dcols - 1) ? cols - 1 : dc; };
+  auto fill_params = [&](double* mat) {      // mat: n x cols column-major
+    if (dcols == cols) return;
+    for (size_t q = 0; q < e->qparams.size(); ++q)
+      for (int i = 0; i < n; ++i) mat[(size_t)(dcols - 1 + q) * n + i] = e->qparams[q];
+  };
   if (e->reduce) {
     if (e->wide)
-      HIPCHK(phm::launch_stats_reduce_replicas(e->d_stats.as<double>() + (size_t)iter0 * cols * e->S_pad, n, cols, e->S,
+      HIPCHK(phm::launch_stats_reduce_replicas(e->d_stats.as<double>() + (size_t)iter0 * dcols * e->S_pad, n, dcols, e->S,
                                                e->S_pad, e->d_red.as<double>(), e->last_stream));
     else
-      HIPCHK(phm::launch_stats_reduce(e->d_stats.as<double>() + (size_t)iter0 * e->tiles * cols, n, e->tiles, cols,
+      HIPCHK(phm::launch_stats_reduce(e->d_stats.as<double>() + (size_t)iter0 * e->tiles * dcols, n, e->tiles, dcols,
                                       e->d_red.as<double>(), e->last_stream));
-    std::vector<double> h((size_t)n * cols);
+    std::vector<double> h((size_t)n * dcols);
     HIPCHK(hipMemcpyAsync(h.data(), e->d_red.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, e->last_stream));
     HIPCHK(hipStreamSynchronize(e->last_stream));
     for (int i = 0; i < n; ++i)
-      for (int c = 0; c < cols; ++c) out[(size_t)c * n + i] = h[(size_t)i * cols + c];
+      for (int c = 0; c < dcols; ++c) out[(size_t)out_col(c) * n + i] = h[(size_t)i * dcols + c];
+    fill_params(out);
   } else {
-    std::vector<double> h((size_t)n * cols * e->S_pad);
-    HIPCHK(hipMemcpy(h.data(), e->d_stats.as<double>() + (size_t)iter0 * cols * e->S_pad, sizeof(double) * h.size(), hipMemcpyDeviceToHost));
-    for (int r = 0; r < e->S; ++r)
-      for (int c = 0; c < cols; ++c)
-        for (int i = 0; i < n; ++i) out[((size_t)r * cols + c) * n + i] = h[((size_t)i * cols + c) * e->S_pad + r];
+    std::vector<double> h((size_t)n * dcols * e->S_pad);
+    HIPCHK(hipMemcpy(h.data(), e->d_stats.as<double>() + (size_t)iter0 * dcols * e->S_pad, sizeof(double) * h.size(), hipMemcpyDeviceToHost));
+    for (int r = 0; r < e->S; ++r) {
+      for (int c = 0; c < dcols; ++c)
+        for (int i = 0; i < n; ++i) out[((size_t)r * cols + out_col(c)) * n + i] = h[((size_t)i * dcols + c) * e->S_pad + r];
+      fill_params(out + (size_t)r * cols * n);
+    }
   }
   return PHM_OK;
 }
@@ -520,6 +564,11 @@ int32_t phm_maketreelistMCMC_bigtree(const phm_tree* x, int32_t n, const double*
                                      double Omega, const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
                                      const phm_options* opt, double* out) {
   return run_mcmc_oneshot(PHM_MCMC_BIGTREE, x, n, Q, pid, B, Omega, nen, nodelist, root, N, opt, out);
+}
+int32_t phm_maketreelistMCMCks_sweep(const phm_tree* x, int32_t n, const double* Q, const double* pid, const double* B,
+                                     double Omega, const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
+                                     const phm_options* opt, double* out) {
+  return run_mcmc_oneshot(PHM_MCMC_KS, x, n, Q, pid, B, Omega, nen, nodelist, root, N, opt, out);
 }
 int32_t phm_SPARSEmaketreelistMCMC(const phm_tree* x, int32_t n, const double* Q, const double* pid, const double* B,
                                    double Omega, const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
@@ -722,10 +771,10 @@ extern "C" int32_t phm_engine_reduced_stats_device(phm_engine* e, int32_t iter0,
   if (iter0 < 0 || n < 1 || iter0 + n > e->iters_done) return fail(PHM_ERR_STATE, "statistics requested for iterations that have not run");
   HIPCHK(hipSetDevice(e->device));
   if (e->wide)
-    HIPCHK(phm::launch_stats_reduce_replicas(e->d_stats.as<double>() + (size_t)iter0 * e->cols * e->S_pad, n, e->cols, e->S,
+    HIPCHK(phm::launch_stats_reduce_replicas(e->d_stats.as<double>() + (size_t)iter0 * e->dcols * e->S_pad, n, e->dcols, e->S,
                                              e->S_pad, e->d_red.as<double>(), reinterpret_cast<hipStream_t>(hip_stream)));
   else
-    HIPCHK(phm::launch_stats_reduce(e->d_stats.as<double>() + (size_t)iter0 * e->tiles * e->cols, n, e->tiles, e->cols,
+    HIPCHK(phm::launch_stats_reduce(e->d_stats.as<double>() + (size_t)iter0 * e->tiles * e->dcols, n, e->tiles, e->dcols,
                                     e->d_red.as<double>(), reinterpret_cast<hipStream_t>(hip_stream)));
   *out_dev = e->d_red.p;
   return PHM_OK;

@@ -19,6 +19,7 @@ struct McmcParams {
   int32_t n_tiles, n_rep, n_rep_pad, replica_offset;
   int32_t normalise, tips_per_replica, reduce, n_cols;
   int32_t ktab;
+  int32_t ks;                                // 1: sumstatMCMCks tree sweep (parity tip masks, n x n counts, root column)
   int32_t prune_only;                        // measurement aid: run only the pruning (up) sweep of each iteration
   uint32_t seed_lo, seed_hi;
   int64_t rows;                              // capacity (64-lane rows) of one tile's dwell stream
@@ -30,6 +31,7 @@ struct McmcParams {
   const DownStep* down;
   const double* colpow;                      // [ktab][NS][NS]: (Bc^k e_j)[r]
   const double* rowpow;                      // [ktab][NS][NS]: ((Bc^T)^k e_j)[c]
+  const double* maskpow;                     // [ktab][2][NS]: Bc^k applied to the even / odd state mask (ks only)
   const uint8_t* tips;                       // 0-based tip states: [n_tips] or [tile][n_tips][64]
   uint16_t* mcount;                          // [tile][n_edge][64] segments per branch
   double* dwell0;                            // [tile][rows][64] sequential dwell stream, ping

@@ -46,16 +46,18 @@ __device__ __forceinline__ int wave_max(int v) {
 }
 
 // B^k applied to a child's partial-likelihood vector (mmmmvFORpl, src/phylomap.cpp:446-450)
-template <int NS>
+template <int NS, bool KS>
 __device__ __forceinline__ void child_vector(const McmcParams<NS>& p, const double* __restrict__ s_col,
-                                             const double* __restrict__ PLt, const uint8_t* __restrict__ tips_t,
-                                             int child, int k, int lane, double (&v)[NS]) {
+                                             const double* __restrict__ s_mask, const double* __restrict__ PLt,
+                                             const uint8_t* __restrict__ tips_t, int child, int k, int lane,
+                                             double (&v)[NS]) {
   if (child < 0) {
-    // tip: PL is one-hot, so the chain is column `state` of the B^k table (bit-identical to running it)
+    // tip: the chain started from the tip's PL row is a table entry (bit-identical to running it):
+    // one-hot row -> column `state` of B^k; ks: parity mask row (:1838-1845) -> B^k applied to that mask
     int tip = ~child;
     int st = p.tips_per_replica ? tips_t[tip * 64 + lane] : p.tips[tip];
     int kt = k < p.ktab ? k : p.ktab - 1;
-    const double* src = s_col + (kt * NS + st) * NS;
+    const double* src = KS ? s_mask + (kt * 2 + (st & 1)) * NS : s_col + (kt * NS + st) * NS;
 #pragma unroll
     for (int c = 0; c < NS; ++c) v[c] = src[c];
     for (int i = kt; i < k; ++i) matvec_u<NS>(p.Bc, v);
@@ -66,13 +68,16 @@ __device__ __forceinline__ void child_vector(const McmcParams<NS>& p, const doub
   }
 }
 
-template <int NS>
+// KS = the tree sweep of sumstatMCMCks (treesampleks, src/phylomap.cpp:1422-1432) with Q held fixed: parity tip masks,
+// hidden tip states re-sampled every sweep (:1384-1397), every consecutive state pair counted, self pairs included,
+// into n x n counters (shortenerbf :1010-1014), root state recorded (:1350-1352).
+template <int NS, bool KS>
 __global__ __launch_bounds__(MCMC_BLOCK, 5) void mcmc_sweep_kernel(McmcParams<NS> p, int iter0, int n_iters) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int tile = blockIdx.x * (MCMC_BLOCK / 64) + wave;
-  constexpr int NCNT = NS * (NS - 1);
+  constexpr int NCNT = KS ? NS * NS : NS * (NS - 1);
 
   // ---- LDS carve-up: tables shared by the workgroup, accumulators private to each lane ----
   double* s_col = reinterpret_cast<double*>(smem);            // [ktab][NS][NS]  B^k e_j      (column chains)
@@ -82,7 +87,10 @@ __global__ __launch_bounds__(MCMC_BLOCK, 5) void mcmc_sweep_kernel(McmcParams<NS
   double* s_dw = s_scale + NS + (size_t)wave * NS * 64;       // [NS][64] dwell accumulators of this wave
   uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_scale + NS + (size_t)(MCMC_BLOCK / 64) * NS * 64) +
                     (size_t)wave * NCNT * 64;                 // [NCNT][64] transition counters of this wave
+  double* s_mask = reinterpret_cast<double*>(reinterpret_cast<uint32_t*>(s_scale + NS + (size_t)(MCMC_BLOCK / 64) * NS * 64) +
+                                             (size_t)(MCMC_BLOCK / 64) * NS * NS * 64);   // [ktab][2][NS] (ks only)
   for (int i = threadIdx.x; i < p.ktab * NS * NS; i += MCMC_BLOCK) { s_col[i] = p.colpow[i]; s_row[i] = p.rowpow[i]; }
+  if (KS) for (int i = threadIdx.x; i < p.ktab * 2 * NS; i += MCMC_BLOCK) s_mask[i] = p.maskpow[i];
   if (threadIdx.x < NS * NS) s_B2[threadIdx.x] = p.B2[threadIdx.x];
   if (threadIdx.x < NS) s_scale[threadIdx.x] = p.scale[threadIdx.x];
   __syncthreads();
@@ -114,8 +122,8 @@ __global__ __launch_bounds__(MCMC_BLOCK, 5) void mcmc_sweep_kernel(McmcParams<NS
       double x[NS], y[NS];
       int ma = mct[st.edge[0] * 64 + lane];
       int mb = mct[st.edge[1] * 64 + lane];
-      child_vector<NS>(p, s_col, PLt, tips_t, st.child[1], mb - 1, lane, x);   // "first"  (:508)
-      child_vector<NS>(p, s_col, PLt, tips_t, st.child[0], ma - 1, lane, y);   // "second" (:509)
+      child_vector<NS, KS>(p, s_col, s_mask, PLt, tips_t, st.child[1], mb - 1, lane, x);   // "first"  (:508)
+      child_vector<NS, KS>(p, s_col, s_mask, PLt, tips_t, st.child[0], ma - 1, lane, y);   // "second" (:509)
 #pragma unroll
       for (int c = 0; c < NS; ++c) x[c] = x[c] * y[c];                         // :510
       if (p.normalise) {                                                       // :525
@@ -132,12 +140,14 @@ __global__ __launch_bounds__(MCMC_BLOCK, 5) void mcmc_sweep_kernel(McmcParams<NS
     if (p.prune_only) continue;      // wave-uniform: the pruning sweep alone (bench.py "pruning" roofline)
 
     // ------------------------------ root state ------------------------------
+    int my_root = 0;
     {
       double pr[NS];
 #pragma unroll
       for (int c = 0; c < NS; ++c) pr[c] = p.pid[c] * PLt[(p.root * NS + c) * 64 + lane];   // :618
       double u = stream_u(p.seed_lo, p.seed_hi, rep, (uint32_t)it, ENT_NODE | (uint32_t)(p.root + p.n_tips), 0);
-      nst[p.root * 64 + lane] = (uint8_t)sample_cat<NS>(pr, u, err);                        // :627
+      my_root = sample_cat<NS>(pr, u, err);                                                 // :627
+      nst[p.root * 64 + lane] = (uint8_t)my_root;
     }
 
     // ------------------------------ down sweep: node states + branch paths ------------------------------
@@ -147,8 +157,8 @@ __global__ __launch_bounds__(MCMC_BLOCK, 5) void mcmc_sweep_kernel(McmcParams<NS
       const int m = mct[b * 64 + lane];
       const int ps = nst[ds.parent * 64 + lane];
       int cs;
-      if (ds.child >= 0) {
-        // child ~ e_ps^T B^(m-1) (.) PL[child]   (Tvmmp :431-436, :651)
+      if (ds.child >= 0 || KS) {
+        // child ~ e_ps^T B^(m-1) (.) PL[child]   (Tvmmp :431-436, :651); ks: tips too, against their mask (:1384-1397)
         double w[NS];
         int kk = m - 1;
         int kt = kk < p.ktab ? kk : p.ktab - 1;
@@ -167,11 +177,21 @@ __global__ __launch_bounds__(MCMC_BLOCK, 5) void mcmc_sweep_kernel(McmcParams<NS
 #pragma unroll
           for (int c = 0; c < NS; ++c) w[c] = yv[c];
         }
+        uint32_t node_id;
+        if (ds.child >= 0) {
 #pragma unroll
-        for (int c = 0; c < NS; ++c) w[c] = w[c] * PLt[(ds.child * NS + c) * 64 + lane];
-        double u = stream_u(p.seed_lo, p.seed_hi, rep, (uint32_t)it, ENT_NODE | (uint32_t)(ds.child + p.n_tips), 0);
+          for (int c = 0; c < NS; ++c) w[c] = w[c] * PLt[(ds.child * NS + c) * 64 + lane];
+          node_id = (uint32_t)(ds.child + p.n_tips);
+        } else {
+          int tip = ~ds.child;
+          int par = (p.tips_per_replica ? tips_t[tip * 64 + lane] : p.tips[tip]) & 1;
+#pragma unroll
+          for (int c = 0; c < NS; ++c) w[c] = w[c] * (((c & 1) == par) ? 1.0 : 0.0);
+          node_id = (uint32_t)tip;
+        }
+        double u = stream_u(p.seed_lo, p.seed_hi, rep, (uint32_t)it, ENT_NODE | node_id, 0);
         cs = sample_cat<NS>(w, u, err);                                        // :655
-        nst[ds.child * 64 + lane] = (uint8_t)cs;
+        if (ds.child >= 0) nst[ds.child * 64 + lane] = (uint8_t)cs;
       } else {
         int tip = ~ds.child;
         cs = p.tips_per_replica ? tips_t[tip * 64 + lane] : p.tips[tip];        // :612
@@ -218,12 +238,15 @@ __global__ __launch_bounds__(MCMC_BLOCK, 5) void mcmc_sweep_kernel(McmcParams<NS
             int si = (i == m - 1) ? cs : draw_state(i, cur_s);
             double di = dnext;
             if (i + 1 < m) dnext = dw_in[(roff + i + 1) * 64 + lane];
+            if (KS) s_cnt[(cur_s * NS + si) * 64 + lane] += 1u;               // shortenerbf :1010-1014
             if (si == cur_s) cur_len = cur_len + di;                           // shortener :54
             else {
               dw_in[(roff + w) * 64 + lane] = cur_len;
               if (w < 32) pk0 |= (uint64_t)cur_s << (2 * w); else pk1 |= (uint64_t)cur_s << (2 * (w - 32));
-              int col = cur_s * (NS - 1) + (si > cur_s ? si - 1 : si);         // shortener :65-66
-              s_cnt[col * 64 + lane] += 1u;
+              if (!KS) {
+                int col = cur_s * (NS - 1) + (si > cur_s ? si - 1 : si);       // shortener :65-66
+                s_cnt[col * 64 + lane] += 1u;
+              }
               ++w; cur_s = si; cur_len = di;
             }
           }
@@ -300,10 +323,11 @@ __global__ __launch_bounds__(MCMC_BLOCK, 5) void mcmc_sweep_kernel(McmcParams<NS
             si = (i == m - 1) ? cs : draw_state(i, cur_s);
             di = dw_in[(roff + i) * 64 + lane];
           }
+          if (KS && si >= 0) s_cnt[(cur_s * NS + si) * 64 + lane] += 1u;
           if (si == cur_s) cur_len = cur_len + di;
           else {
             finalize(cur_s, cur_len);
-            if (si >= 0) {
+            if (!KS && si >= 0) {
               int col = cur_s * (NS - 1) + (si > cur_s ? si - 1 : si);
               s_cnt[col * 64 + lane] += 1u;
             }
@@ -320,20 +344,22 @@ __global__ __launch_bounds__(MCMC_BLOCK, 5) void mcmc_sweep_kernel(McmcParams<NS
     }
 
     // ------------------------------ statistics row of this iteration ------------------------------
+    // columns: n dwell sums, NCNT transition counters, then (ks) the root state, 0-based (:1350-1352)
+    constexpr int DCOLS = NS + NCNT + (KS ? 1 : 0);
     if (p.reduce) {
       double* dst = p.stats + ((size_t)it * p.n_tiles + tile) * p.n_cols;
 #pragma unroll
-      for (int c = 0; c < NS + NCNT; ++c) {
+      for (int c = 0; c < DCOLS; ++c) {
         double v = 0.0;
-        if (valid) v = (c < NS) ? s_dw[c * 64 + lane] : (double)s_cnt[(c - NS) * 64 + lane];
+        if (valid) v = (c < NS) ? s_dw[c * 64 + lane] : (c < NS + NCNT) ? (double)s_cnt[(c - NS) * 64 + lane] : (double)my_root;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
         if (lane == c) dst[c] = v;
       }
     } else {
 #pragma unroll
-      for (int c = 0; c < NS + NCNT; ++c) {
-        double v = (c < NS) ? s_dw[c * 64 + lane] : (double)s_cnt[(c - NS) * 64 + lane];
+      for (int c = 0; c < DCOLS; ++c) {
+        double v = (c < NS) ? s_dw[c * 64 + lane] : (c < NS + NCNT) ? (double)s_cnt[(c - NS) * 64 + lane] : (double)my_root;
         p.stats[((size_t)it * p.n_cols + c) * p.n_rep_pad + rep_local] = v;
       }
     }
@@ -377,9 +403,9 @@ __global__ void stats_reduce_kernel(const double* __restrict__ partial, int n_it
 }
 
 template <int NS>
-size_t mcmc_lds_bytes(int ktab) {
+size_t mcmc_lds_bytes(int ktab) {     // sized for the ks layout (n x n counters + mask chains); the plain layout fits inside
   return sizeof(double) * ((size_t)2 * ktab * NS * NS + NS * NS + NS + (size_t)(MCMC_BLOCK / 64) * NS * 64) +
-         sizeof(uint32_t) * (size_t)(MCMC_BLOCK / 64) * NS * (NS - 1) * 64;
+         sizeof(uint32_t) * (size_t)(MCMC_BLOCK / 64) * NS * NS * 64 + sizeof(double) * (size_t)ktab * 2 * NS;
 }
 
 template <int NS>
@@ -387,7 +413,8 @@ hipError_t launch_mcmc(const McmcParams<NS>& p, int iter0, int n_iters, hipStrea
   const int waves_per_block = MCMC_BLOCK / 64;
   dim3 grid((p.n_tiles + waves_per_block - 1) / waves_per_block);
   size_t lds = mcmc_lds_bytes<NS>(p.ktab);
-  hipLaunchKernelGGL(mcmc_sweep_kernel<NS>, grid, dim3(MCMC_BLOCK), lds, stream, p, iter0, n_iters);
+  if (p.ks) hipLaunchKernelGGL((mcmc_sweep_kernel<NS, true>), grid, dim3(MCMC_BLOCK), lds, stream, p, iter0, n_iters);
+  else hipLaunchKernelGGL((mcmc_sweep_kernel<NS, false>), grid, dim3(MCMC_BLOCK), lds, stream, p, iter0, n_iters);
   return hipGetLastError();
 }
 

@@ -18,6 +18,7 @@ struct WideParams {
   int32_t n_tips, n_node, n_edge, root;
   int32_t n_tiles, n_rep, n_rep_pad, replica_offset;
   int32_t normalise, tips_per_replica, n_cols, ktab;
+  int32_t ks;                                // 1: sumstatMCMCks tree sweep (tip masks, tips re-sampled, root column)
   int32_t count_self;                        // 1: n x n transition counts incl. self pairs (shortenerbf :1010-1014)
   uint32_t seed_lo, seed_hi;
   int64_t rows;
@@ -29,6 +30,7 @@ struct WideParams {
   const DownStep* down;
   const double* colpow;                      // [ktab][n][n]
   const double* rowpow;                      // [ktab][n][n]
+  const double* maskpow;                     // [ktab][2][n] (ks)
   const uint8_t* tips;
   uint16_t* mcount;                          // [tile][n_edge][64]
   double* dwell0;                            // [tile][rows][64]

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) void mcmc_wide_kernel(WideParams p, int
     int done;
     if (child < 0) {
       int kt = k < p.ktab ? k : p.ktab - 1;
-      v = p.colpow[((size_t)kt * n + tipstate_r) * n + c];
+      v = p.ks ? p.maskpow[((size_t)kt * 2 + (tipstate_r & 1)) * n + c] : p.colpow[((size_t)kt * n + tipstate_r) * n + c];
       done = kt;
     } else {
       v = PLt[((size_t)child * 64 + r) * n + c];
@@ -147,6 +147,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) void mcmc_wide_kernel(WideParams p, int
         if (lane == r) mine = rs;
       }
       nst[p.root * 64 + lane] = (uint8_t)mine;
+      if (p.ks) srow[(size_t)(n + n * n) * p.n_rep_pad] = (double)mine;                     // :1350-1352
     }
 
     // ------------------------------ down sweep ------------------------------
@@ -158,6 +159,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) void mcmc_wide_kernel(WideParams p, int
       int mmax = wave_max_w(m);
       int cs = 0;
       if (ds.child < 0) cs = p.tips_per_replica ? tips_t[(~ds.child) * 64 + lane] : p.tips[~ds.child];
+      const int tobs = cs;                         // observed tip state (ks keeps only its parity)
       if (mmax > WIDE_MAXSEG) {      // LDS state scratch is WIDE_MAXSEG slots per replica: report, stay memory-safe
         err |= DERR_CAPACITY;
         m = m < WIDE_MAXSEG ? m : WIDE_MAXSEG;
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) void mcmc_wide_kernel(WideParams p, int
         const int mr = __builtin_amdgcn_readlane(m, r);
         const int psr = __builtin_amdgcn_readlane(ps, r);
         int csr;
-        if (ds.child >= 0) {
+        if (ds.child >= 0 || p.ks) {
           // child ~ e_ps^T B^(m-1) (.) PL[child]     (Tvmmp :431-436, :651-655)
           int kk = mr - 1;
           int kt = kk < p.ktab ? kk : p.ktab - 1;
@@ -179,8 +181,16 @@ __global__ __launch_bounds__(WIDE_BLOCK) void mcmc_wide_kernel(WideParams p, int
             for (int q = 1; q < n; ++q) acc += s_Bc[q * n + c] * readlane_f64(w, q);
             w = acc;
           }
-          w = (lane < n) ? w * PLt[((size_t)ds.child * 64 + r) * n + c] : 0.0;
-          double u = uni_draw(p, rep0 + r, (uint32_t)it, ENT_NODE | (uint32_t)(ds.child + p.n_tips), 0);
+          uint32_t node_id;
+          if (ds.child >= 0) {
+            w = (lane < n) ? w * PLt[((size_t)ds.child * 64 + r) * n + c] : 0.0;
+            node_id = (uint32_t)(ds.child + p.n_tips);
+          } else {                                  // ks: hidden tip state against the parity mask (:1384-1397)
+            const int par = __builtin_amdgcn_readlane(tobs, r) & 1;
+            w = (lane < n) ? w * (((c & 1) == par) ? 1.0 : 0.0) : 0.0;
+            node_id = (uint32_t)(~ds.child);
+          }
+          double u = uni_draw(p, rep0 + r, (uint32_t)it, ENT_NODE | node_id, 0);
           csr = coop_sample(w, u, n, lane, err);
           if (lane == r) cs = csr;
         } else {

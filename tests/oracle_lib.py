@@ -11,7 +11,7 @@ _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _SO = os.path.join(_ROOT, "oracle", "_build", "libphm_oracle.so")
 
 ERR_ZERO_PROB, ERR_UNIF_CAP, ERR_BAD_INPUT, ERR_TAPE, ERR_SAMPLEONCE = 1, 2, 4, 8, 16
-PLAIN, BIGTREE, SPARSE = 0, 1, 2
+PLAIN, BIGTREE, SPARSE, KS = 0, 1, 2, 3
 
 
 class Rng(C.Structure):
@@ -124,7 +124,7 @@ def maketreelistMCMC(z, Q, pid, B, Omega, nen, nodelist, root, N, variant=PLAIN,
     pid = np.ascontiguousarray(pid, dtype=np.float64)
     nen = np.ascontiguousarray(nen, dtype=np.int32)
     nodelist = np.ascontiguousarray(nodelist, dtype=np.int32)
-    cols = n + n * (n - 1)
+    cols = n + n * (n - 1) if variant != KS else n + n * n + 2 + 3 * (n // 2 - 1) + 1
     out = np.zeros((N, cols), order="F")
     rng, keep = make_rng(seed, replica, tape_u, tape_e)
     db = DumpBuf(ft, n) if dump else None

@@ -142,11 +142,24 @@ def sumstatMCMC(z, Q, pid, Omega, N, nen, nodelist, root, seed, replica, variant
     dw = [[float(x) for x in z["maps"][b]] for b in range(E)]
     st = [[int(x) - 1 for x in z["mapnames"][b]] for b in range(E)]                              # :29
     PL = [[0.0] * n for _ in range(2 * T - 1)]
+    ks = variant == "ks"                                   # treesampleks :1422-1432 with Q fixed (maketreelistMCMCks :1802-1872)
+    kk = n // 2 - 1
     for i in range(T):
-        PL[i][int(z["states"][i]) - 1] = 1.0                                                    # :914
-    cols = n + n * (n - 1)
+        if not ks:
+            PL[i][int(z["states"][i]) - 1] = 1.0                                                # :914
+        else:                                                                                   # :1838-1845
+            for j in range(1 if int(z["states"][i]) % 2 == 0 else 0, n, 2):
+                PL[i][j] = 1.0
+    cols = n + n * n + 2 + 3 * kk + 1 if ks else n + n * (n - 1)
     out = [[0.0] * cols for _ in range(N)]
     for it in range(N):
+        if ks:                                                                                  # recordQks :1789-1798
+            base = n + n * n
+            out[it][base], out[it][base + 1] = Q[0][1], Q[1][0]
+            for i in range(kk):
+                out[it][base + 2 + i] = Q[2 * i][2 * i + 2]
+                out[it][base + 2 + kk + i] = Q[2 * i + 2][2 * i]
+                out[it][base + 2 + 2 * kk + i] = Q[2 * (i + 1)][2 * (i + 1) + 1] / Q[0][1]
         m = [len(d) for d in dw]                                                                # :598-599
         for i in range(T - 1):                                                                  # makePLrcpp :503-514
             ea, eb = nen[2 * i] - 1, nen[2 * i + 1] - 1
@@ -157,7 +170,7 @@ def sumstatMCMC(z, Q, pid, Omega, N, nen, nodelist, root, seed, replica, variant
             for _ in range(m[ea] - 1):
                 second = matvec(Bc, second)
             row = [first[c] * second[c] for c in range(n)]
-            if variant == "bigtree":                                                            # :525
+            if variant == "bigtree" or ks:                                                      # :525 / :1085
                 s = row[0]
                 for c in range(1, n):
                     s += row[c]
@@ -175,6 +188,16 @@ def sumstatMCMC(z, Q, pid, Omega, N, nen, nodelist, root, seed, replica, variant
             for _ in range(m[j] - 1):
                 v = matTvec(Bc, v)
             rm[node - 1] = sample([v[c] * PL[node - 1][c] for c in range(n)], rng.u(it, ENT_NODE | (node - 1), 0))
+        if ks:
+            out[it][cols - 1] = float(rm[root - 1])                                             # :1350-1352
+            for b in range(E):                                                                  # :1384-1397
+                if e2[b] <= T:
+                    ps = rm[e1[b] - 1]
+                    v = [0.0] * n
+                    v[ps] = 1.0
+                    for _ in range(m[b] - 1):
+                        v = matTvec(Bc, v)
+                    rm[e2[b] - 1] = sample([v[c] * PL[e2[b] - 1][c] for c in range(n)], rng.u(it, ENT_NODE | (e2[b] - 1), 0))
         for b in range(E):                                                                      # updatenodestates :460-475
             st[b][0] = rm[e1[b] - 1]
             st[b][-1] = rm[e2[b] - 1]
@@ -188,6 +211,9 @@ def sumstatMCMC(z, Q, pid, Omega, N, nen, nodelist, root, seed, replica, variant
                 for i in range(1, ss - 1):
                     p = [B2[st[b][i - 1]][c] * beta[ss - i - 1][c] for c in range(n)]
                     st[b][i] = sample(p, rng.u(it, ENT_BSTATE | b, i - 1))
+            if ks:                                                                              # shortenerbf :1010-1014
+                for i in range(1, ss):
+                    out[it][n + st[b][i - 1] * n + st[b][i]] += 1.0
             nd, ns = [dw[b][0]], [st[b][0]]                                                     # shortener :44-73
             for i in range(1, ss):
                 if st[b][i] != ns[-1]:
@@ -196,7 +222,8 @@ def sumstatMCMC(z, Q, pid, Omega, N, nen, nodelist, root, seed, replica, variant
                     nd[-1] = nd[-1] + dw[b][i]
             for i in range(1, len(ns)):
                 a, c = ns[i - 1], ns[i]
-                out[it][n + a * (n - 1) + (c - 1 if a < c else c)] += 1.0
+                if not ks:
+                    out[it][n + a * (n - 1) + (c - 1 if a < c else c)] += 1.0
             fd, fs, ed = [], [], 0                                                              # virtual jumps :391-410
             for seglen, s in zip(nd, ns):
                 scale = 1.0 / (Omega + Q[s][s])

@@ -208,6 +208,34 @@ def test_wide_kernel_chain_state_and_golden():
     np.testing.assert_array_equal(d["PL"], dump.PL)
 
 
+@pytest.mark.parametrize("n", [2, 4, 6])
+def test_ks_sweep_matches_oracle(n):
+    """Tree sweep of sumstatMCMCks with Q fixed (hidden-rates Q = make2sQ, binary trait observed): n<=4 kernel and,
+    for k=2 (n=6), the wide kernel."""
+    Q = {2: synth.config_Q(1), 4: synth.make2sQ(.1, .1, .2, .2, 10), 6: synth.make2sQ(.1, .3, [.2, .4], [.5, .6], [2, 3])}[n]
+    Omega = 1.25 * float(np.max(np.abs(np.diag(Q))))
+    pid = np.full(n, 1.0 / n)
+    z = synth.make_tree(20, Q, Omega, 900 + n, pid)
+    z["states"] = ((z["states"] - 1) % 2 + 1).astype(np.int32)          # only the binary trait is observed
+    for b, (p_, c_) in enumerate(z["edge"]):
+        if c_ <= 20:
+            z["mapnames"][b][-1] = z["states"][c_ - 1]
+    nen, nodelist, root = _orders(z)
+    N, S, seed = 15, 3, 77
+    got = api.sumstatMCMCks_sweep(z, Q, pid, Omega, N, seed=seed, n_replicas=S)
+    k = n // 2 - 1
+    assert got.shape == (S, N, n + n * n + 2 + 3 * k + 1)
+    for r in range(S):
+        want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(n) + Q / Omega, Omega, nen, nodelist, root, N, variant=O.KS,
+                                      seed=seed, replica=r)
+        assert rc == 0
+        np.testing.assert_array_equal(got[r], want)
+    red = api.sumstatMCMCks_sweep(z, Q, pid, Omega, N, seed=seed, n_replicas=S, reduce=True)
+    np.testing.assert_array_equal(red[:, n:n + n * n], got.sum(0)[:, n:n + n * n])
+    np.testing.assert_array_equal(red[:, n + n * n:-1], got[0][:, n + n * n:-1])     # parameter columns: plain values
+    np.testing.assert_array_equal(red[:, -1], got.sum(0)[:, -1])
+
+
 def test_replica_offset_shards_like_one_device():
     z, Q, pid, Omega = _problem(2, 18, 4)
     a = api.sumstatMCMC(z, Q, pid, Omega, 10, seed=3, n_replicas=4)

@@ -174,6 +174,31 @@ def test_mcmc_oracle_equals_python_restatement(n, variant, ov):
     np.testing.assert_array_equal(got, got2)
 
 
+@pytest.mark.parametrize("n", [2, 4, 6])
+def test_ks_sweep_oracle_equals_python_restatement(n):
+    Q = {2: synth.config_Q(1), 4: synth.make2sQ(.1, .1, .2, .2, 10), 6: synth.make2sQ(.1, .3, [.2, .4], [.5, .6], [2, 3])}[n]
+    Omega = 1.25 * float(np.max(np.abs(np.diag(Q))))
+    pid = np.full(n, 1.0 / n)
+    z = synth.make_tree(9, Q, Omega, 650 + n)
+    z["states"] = ((z["states"] - 1) % 2 + 1).astype(np.int32)
+    nen, nodelist, root = _orders(z)
+    N, seed, rep = 5, 12, 2
+    got, rc = O.maketreelistMCMC(z, Q, pid, np.eye(n) + Q / Omega, Omega, nen, nodelist, root, N, variant=O.KS, seed=seed, replica=rep)
+    assert rc == 0
+    want = np.array(pyref.sumstatMCMC(z, Q.tolist(), pid.tolist(), Omega, N, [int(v) for v in nen], [int(v) for v in nodelist],
+                                      root, seed, rep, "ks"))
+    np.testing.assert_array_equal(got, want)
+    k = n // 2 - 1
+    np.testing.assert_allclose(got[:, :n].sum(1), z["edge.length"].sum(), rtol=1e-12)
+    assert got.shape[1] == n + n * n + 2 + 3 * k + 1                       # man/sumstatMCMCks.Rd:19
+    assert np.all(got[:, n + n * n] == Q[0, 1]) and np.all(got[:, n + n * n + 1] == Q[1, 0])
+    assert np.all((got[:, -1] >= 0) & (got[:, -1] < n))
+    with pytest.raises(AssertionError):
+        Qodd = np.array([[-.3, .2, .1], [.05, -.15, .1], [.2, .2, -.4]])
+        _, rc = O.maketreelistMCMC(z, Qodd, np.full(3, 1 / 3), np.eye(3) + Qodd / .5, .5, nen, nodelist, root, 2, variant=O.KS)
+        assert rc == 0
+
+
 @pytest.mark.parametrize("n", [2, 4])
 def test_exp_oracle_equals_python_restatement(n):
     Q = {2: synth.config_Q(1), 4: synth.config_Q(2)}[n]
