@@ -43,7 +43,7 @@ struct McmcParams {
   unsigned long long* segcnt;
 };
 
-template <int NS> size_t mcmc_lds_bytes(int ktab);
+template <int NS> size_t mcmc_lds_bytes(int ktab, bool ks);
 template <int NS> hipError_t launch_mcmc(const McmcParams<NS>& p, int iter0, int n_iters, hipStream_t stream);
 
 hipError_t launch_mcmc_init(int n_edge, int n_tiles, int64_t rows, const DownStep* down, const int32_t* init_row,

@@ -403,16 +403,19 @@ __global__ void stats_reduce_kernel(const double* __restrict__ partial, int n_it
 }
 
 template <int NS>
-size_t mcmc_lds_bytes(int ktab) {     // sized for the ks layout (n x n counters + mask chains); the plain layout fits inside
+size_t mcmc_lds_bytes(int ktab, bool ks) {
+  const size_t ncnt = ks ? NS * NS : NS * (NS - 1);
+  // the mask-chain table sits behind a full n x n counter block (kernel carve-up), so ks reserves that much
   return sizeof(double) * ((size_t)2 * ktab * NS * NS + NS * NS + NS + (size_t)(MCMC_BLOCK / 64) * NS * 64) +
-         sizeof(uint32_t) * (size_t)(MCMC_BLOCK / 64) * NS * NS * 64 + sizeof(double) * (size_t)ktab * 2 * NS;
+         sizeof(uint32_t) * (size_t)(MCMC_BLOCK / 64) * (ks ? NS * NS : ncnt) * 64 +
+         (ks ? sizeof(double) * (size_t)ktab * 2 * NS : 0);
 }
 
 template <int NS>
 hipError_t launch_mcmc(const McmcParams<NS>& p, int iter0, int n_iters, hipStream_t stream) {
   const int waves_per_block = MCMC_BLOCK / 64;
   dim3 grid((p.n_tiles + waves_per_block - 1) / waves_per_block);
-  size_t lds = mcmc_lds_bytes<NS>(p.ktab);
+  size_t lds = mcmc_lds_bytes<NS>(p.ktab, p.ks != 0);
   if (p.ks) hipLaunchKernelGGL((mcmc_sweep_kernel<NS, true>), grid, dim3(MCMC_BLOCK), lds, stream, p, iter0, n_iters);
   else hipLaunchKernelGGL((mcmc_sweep_kernel<NS, false>), grid, dim3(MCMC_BLOCK), lds, stream, p, iter0, n_iters);
   return hipGetLastError();
@@ -421,9 +424,9 @@ hipError_t launch_mcmc(const McmcParams<NS>& p, int iter0, int n_iters, hipStrea
 template hipError_t launch_mcmc<2>(const McmcParams<2>&, int, int, hipStream_t);
 template hipError_t launch_mcmc<3>(const McmcParams<3>&, int, int, hipStream_t);
 template hipError_t launch_mcmc<4>(const McmcParams<4>&, int, int, hipStream_t);
-template size_t mcmc_lds_bytes<2>(int);
-template size_t mcmc_lds_bytes<3>(int);
-template size_t mcmc_lds_bytes<4>(int);
+template size_t mcmc_lds_bytes<2>(int, bool);
+template size_t mcmc_lds_bytes<3>(int, bool);
+template size_t mcmc_lds_bytes<4>(int, bool);
 
 hipError_t launch_mcmc_init(int n_edge, int n_tiles, int64_t rows, const DownStep* down, const int32_t* init_row,
                             const int32_t* map_off, const double* maps, double* dwell0, uint16_t* mcount,
