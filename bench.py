@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--config", type=int, default=2)
     ap.add_argument("--ipl", type=int, default=8, help="sweeps fused per kernel launch")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--force-collective", action="store_true", help="exercise the statistics hand-over to torch at N=1")
     args = ap.parse_args()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -112,11 +113,16 @@ def main():
     t0 = time.perf_counter()
     eng.run(K, stream)                                   # the hot path: K sweeps, N-loop on the device
     red_ptr = eng.reduced_stats_device(W, K, stream)     # fixed-order reduction over this GPU's replicas
-    if world > 1:                                        # the only collective: K x cols f64 over RCCL/xGMI
-        class _Dev:
-            __cuda_array_interface__ = {"shape": (K, cols), "typestr": "<f8", "data": (red_ptr, False), "version": 3}
-        total = torch.as_tensor(_Dev(), device=torch.device("cuda", local_rank))
+    if world > 1 or args.force_collective:               # the only collective: K x cols f64 over RCCL/xGMI
+        try:
+            class _Dev:
+                __cuda_array_interface__ = {"shape": (K, cols), "typestr": "<f8", "data": (red_ptr, False), "version": 3}
+            total = torch.as_tensor(_Dev(), device=torch.device("cuda", local_rank))
+        except Exception:                                # no zero-copy view: one 30 KB host round trip instead
+            eng.sync()
+            total = torch.from_numpy(np.ascontiguousarray(eng.stats(W, K))).to(torch.device("cuda", local_rank))
         parallel.allreduce_stats(total)
+        torch.cuda.synchronize()
     eng.sync()
     barrier()
     dt = time.perf_counter() - t0
@@ -134,9 +140,14 @@ def main():
     achieved = units_rank * b_alg / kernel_s / 1e9
 
     prune_ms = eng.time_pruning(8, stream) / 8.0           # the pruning sweep alone (12n+12 B per branch)
-    stats = eng.stats(W, K) if world == 1 else None
-    if stats is not None:                                 # sanity: dwell row sums = S x tree length
-        assert np.allclose(stats[:, :n].sum(1), S * z["edge.length"].sum(), rtol=1e-9)
+    stats = eng.stats(W, K)
+    # sanity: dwell row sums = S x tree length; the tensor handed to RCCL is the same matrix (x world)
+    assert np.allclose(stats[:, :n].sum(1), S * z["edge.length"].sum(), rtol=1e-9)
+    if world > 1 or args.force_collective:
+        tot = total.cpu().numpy()
+        assert np.allclose(tot[:, :n].sum(1), world * S * z["edge.length"].sum(), rtol=1e-9)
+        if world == 1:
+            assert np.array_equal(tot, stats)
 
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "r01_traffic.json")
