@@ -192,7 +192,21 @@ def main():
         _, ms_e = api.expm_eigen(lefts, rights, d, t, device=local_rank)
         _, ms_p = api.expm_pade(Q, t[: 1 << 18], device=local_rank)
         _, ms_p = api.expm_pade(Q, t[: 1 << 18], device=local_rank)
-        out["expm_per_s"] = {"eigen_route": t.size / (ms_e / 1e3), "pade_route": (1 << 18) / (ms_p / 1e3), "n_states": n}
+        out["expm_per_s"] = {"n_states": n, "eigen_route": t.size / (ms_e / 1e3), "pade_route": (1 << 18) / (ms_p / 1e3)}
+        # the same metric on the dense 61-state shape of C4, where the products fill MFMA f64 tiles
+        Q61 = synth.config_Q(4)
+        Q61 = (Q61 + Q61.T) / 2                      # matexp handles a real spectrum only (R/sumstatEXP.R:26-29)
+        np.fill_diagonal(Q61, 0.0)
+        np.fill_diagonal(Q61, -Q61.sum(1))
+        l61, r61, d61 = api.eigen_decompose(Q61)
+        t61 = t[: 1 << 16]
+        api.expm_eigen(l61, r61, d61, t61, device=local_rank, mfma=True)
+        _, ms_m = api.expm_eigen(l61, r61, d61, t61, device=local_rank, mfma=True)
+        _, ms_x = api.expm_eigen(l61, r61, d61, t61, device=local_rank)
+        out["expm_per_s"]["n61_eigen_route_mfma"] = t61.size / (ms_m / 1e3)
+        out["expm_per_s"]["n61_eigen_route_exact"] = t61.size / (ms_x / 1e3)
+        out["expm_per_s"]["n61_mfma_tflops"] = 2 * 61 ** 3 * t61.size / (ms_m / 1e3) / 1e12
+        out["expm_per_s"]["mfma_f64_peak_tflops"] = 78.6
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(z, Q, pid, Omega)
             out["speedup_vs_cpu_1core"] = out["value"] / out["cpu_baseline"]["value"]

@@ -151,6 +151,10 @@ int32_t phm_tree_orders(int32_t n_tips, int32_t n_edge, const int32_t* edge, int
  * out: n_t matrices, each n x n ROW-major (out[b*n*n + i*n + j]). */
 int32_t phm_expm_eigen(int32_t n_states, const double* lefts, const double* rights, const double* d,
                        const double* t, int32_t n_t, int32_t device, double* out, double* kernel_ms);
+/* phm_expm_eigen on the matrix cores (v_mfma_f64_16x16x4_f64), 16 < n_states <= 64: same product, fused k-slices, so the
+ * last bits differ from phm_expm_eigen; the sumstatEXP sampler keeps the exact kernel. */
+int32_t phm_expm_eigen_mfma(int32_t n_states, const double* lefts, const double* rights, const double* d,
+                            const double* t, int32_t n_t, int32_t device, double* out, double* kernel_ms);
 int32_t phm_expm_pade(int32_t n_states, const double* Q, const double* t, int32_t n_t, int32_t device,
                       double* out, double* kernel_ms);
 

@@ -558,6 +558,20 @@ void orc_matexp(const double* L, const double* R, const double* dvals, int n, do
   if (e != ex) free(e);
 }
 
+/* The same product with a k-ordered fused multiply-add chain per entry: what an MFMA f64 16x16x4 pipeline computes if,
+ * like the f32 forms, it is bit-for-bit an fma chain.  Pins the matrix-core variant of K1 (phm_expm_eigen_mfma). */
+void orc_matexp_fma(const double* L, const double* R, const double* dvals, int n, double t, double* P) {
+  double* e = (double*)malloc(sizeof(double) * n);
+  for (int k = 0; k < n; ++k) e[k] = orc_exp(dvals[k] * t);
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) {
+      double acc = 0.0;
+      for (int k = 0; k < n; ++k) acc = fma(L[i * n + k] * e[k], R[k * n + j], acc);
+      P[i * n + j] = fabs(acc);
+    }
+  free(e);
+}
+
 /* arma::expmat (call sites src/phylomap.cpp:3226,3243,3359,3383): Pade approximant of degree 6 with
  * scaling 2^s and s squarings.  Armadillo is not under /root/reference; this restates its published
  * algorithm: s from frexp(log2(||A||_inf)), E = sum c_i A^i, D = sum (-1)^i c_i A^i, solve(D,E)

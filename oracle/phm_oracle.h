@@ -88,6 +88,8 @@ int  orc_shortener(double* d, int32_t* s, int m, int n, double* stats_row);
 void orc_matTospmat(const double* B_rm, int n, double* out_rm);
 /* matexp src/phylomap.cpp:2964-2968 + abs() at :2980/:3042; all matrices row-major */
 void orc_matexp(const double* L_rm, const double* R_rm, const double* dvals, int n, double t, double* P_rm);
+/* same product as orc_matexp with a k-ordered fma chain per entry (model of the MFMA f64 pipeline) */
+void orc_matexp_fma(const double* L_rm, const double* R_rm, const double* dvals, int n, double t, double* P_rm);
 /* arma::expmat call sites src/phylomap.cpp:3226,3243,3359,3383: Pade(6) scaling-and-squaring */
 int  orc_expmat_pade(const double* A_rm, int n, double* out_rm);
 /* Felsenstein pruning with B^(m-1): makePLrcpp :503-514, _bigtree :516-529, SPARSE :490-501 */

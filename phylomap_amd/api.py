@@ -95,15 +95,17 @@ def sumstatEXP(z, Q, pid, N, **opt):
     return out
 
 
-def expm_eigen(lefts, rights, d, t, device=-1):
-    """Batched P_b = |L diag(exp(d t_b)) R| (matexp, src/phylomap.cpp:2964-2968). Returns (P[n_t,n,n], kernel_ms)."""
+def expm_eigen(lefts, rights, d, t, device=-1, mfma=False):
+    """Batched P_b = |L diag(exp(d t_b)) R| (matexp, src/phylomap.cpp:2964-2968). Returns (P[n_t,n,n], kernel_ms).
+    ``mfma=True`` (16 < n <= 64) runs the product on the matrix cores (last-bit differences)."""
     L = _lib.load()
     lefts, rights, d = (np.asfortranarray(np.asarray(a, dtype=np.float64)) for a in (lefts, rights, d))
     t = np.ascontiguousarray(t, dtype=np.float64)
     n = lefts.shape[0]
     out = np.zeros((t.size, n, n))
     ms = C.c_double(0.0)
-    _lib.check(L.phm_expm_eigen(n, _lib._p(lefts, C.c_double), _lib._p(rights, C.c_double), _lib._p(d, C.c_double),
+    fn = L.phm_expm_eigen_mfma if mfma else L.phm_expm_eigen
+    _lib.check(fn(n, _lib._p(lefts, C.c_double), _lib._p(rights, C.c_double), _lib._p(d, C.c_double),
                                 _lib._p(t, C.c_double), int(t.size), int(device), _lib._p(out, C.c_double), C.byref(ms)))
     return out, ms.value
 

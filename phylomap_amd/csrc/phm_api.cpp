@@ -610,8 +610,8 @@ int pade_squarings(const double* Q_rm, int n, double t) {
 
 extern "C" {
 
-int32_t phm_expm_eigen(int32_t n, const double* lefts, const double* rights, const double* d, const double* t,
-                       int32_t n_t, int32_t device, double* out, double* kernel_ms) {
+static int32_t expm_eigen_impl(bool mfma, int32_t n, const double* lefts, const double* rights, const double* d, const double* t,
+                               int32_t n_t, int32_t device, double* out, double* kernel_ms) {
   if (n < 1 || n > 256 || !lefts || !rights || !d || !t || !out || n_t < 0) return fail(PHM_ERR_BAD_INPUT, "phm_expm_eigen: bad arguments");
   int32_t st = select_device(device);
   if (st) return st;
@@ -630,11 +630,23 @@ int32_t phm_expm_eigen(int32_t n, const double* lefts, const double* rights, con
   Timer tm;
   HIPCHK(hipEventCreate(&tm.a)); HIPCHK(hipEventCreate(&tm.b));
   HIPCHK(hipEventRecord(tm.a, nullptr));
-  HIPCHK(phm::launch_expm_eigen(n, dL.as<double>(), dR.as<double>(), dd.as<double>(), dt.as<double>(), n_t, dout.as<double>(), nullptr));
+  if (mfma) HIPCHK(phm::launch_expm_eigen_mfma(n, dL.as<double>(), dR.as<double>(), dd.as<double>(), dt.as<double>(), n_t, dout.as<double>(), nullptr));
+  else HIPCHK(phm::launch_expm_eigen(n, dL.as<double>(), dR.as<double>(), dd.as<double>(), dt.as<double>(), n_t, dout.as<double>(), nullptr));
   HIPCHK(hipEventRecord(tm.b, nullptr));
   HIPCHK(hipMemcpy(out, dout.p, dout.bytes, hipMemcpyDeviceToHost));
   if (kernel_ms) { float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, tm.a, tm.b)); *kernel_ms = ms; }
   return PHM_OK;
+}
+
+int32_t phm_expm_eigen(int32_t n, const double* lefts, const double* rights, const double* d, const double* t,
+                       int32_t n_t, int32_t device, double* out, double* kernel_ms) {
+  return expm_eigen_impl(false, n, lefts, rights, d, t, n_t, device, out, kernel_ms);
+}
+
+int32_t phm_expm_eigen_mfma(int32_t n, const double* lefts, const double* rights, const double* d, const double* t,
+                            int32_t n_t, int32_t device, double* out, double* kernel_ms) {
+  if (n <= 16 || n > 64) return fail(PHM_ERR_UNSUPPORTED, "phm_expm_eigen_mfma: 16 < n_states <= 64 (smaller matrices do not fill an MFMA tile)");
+  return expm_eigen_impl(true, n, lefts, rights, d, t, n_t, device, out, kernel_ms);
 }
 
 int32_t phm_expm_pade(int32_t n, const double* Q, const double* t, int32_t n_t, int32_t device, double* out,

@@ -18,6 +18,10 @@ constexpr int EXP_BLOCK = 256;
 hipError_t launch_expm_eigen(int n, const double* L, const double* R, const double* dvals, const double* t, int n_t,
                              double* out, hipStream_t stream);
 
+// same product on the matrix cores (v_mfma_f64_16x16x4), 16 < n <= 64; last-bit differences from the exact kernel
+hipError_t launch_expm_eigen_mfma(int n, const double* L, const double* R, const double* dvals, const double* t, int n_t,
+                                  double* out, hipStream_t stream);
+
 // P_b = expmat(Q t_b): Pade(6) + s_b squarings; `s` holds the squaring counts, `work` 5*n*n doubles per matrix
 hipError_t launch_expm_pade(int n, const double* Q, const double* t, const int32_t* s, int n_t, double* work,
                             double* out, uint32_t* err, hipStream_t stream);

@@ -342,4 +342,69 @@ template hipError_t launch_exp_sample<2>(const ExpParams<2>&, hipStream_t);
 template hipError_t launch_exp_sample<3>(const ExpParams<3>&, hipStream_t);
 template hipError_t launch_exp_sample<4>(const ExpParams<4>&, hipStream_t);
 
+// ------------------------------------------------------------------------------------------------
+// K1 on the matrix cores: P_b = |(L diag(exp(d t_b))) R| as a batched small GEMM with MFMA f64 16x16x4.
+// For 16 < n <= 64 (C4's 61-state Q pads to 64).  R and L are the same for every branch, so each wave keeps its
+// MFMA fragments of both in registers for the whole batch (R: its 16-column block; L: all four row blocks) and a
+// matrix costs 64 exp() + 64 v_mfma per wave.  Fragment maps (cdna_hip_programming.md section 3, f64 form):
+//   A: lane l holds A[row = l&15][k = l>>4];  B: lane l holds B[k = l>>4][col = l&15];
+//   C/D: col = l&15, row = (l>>4) + 4*reg.
+// The MFMA accumulates each 4-deep k-slice with fused multiply-adds, so results differ from the exact kernel
+// (unfused left-to-right sums) in the last bits: use expm_eigen_kernel where bit-parity with the oracle matters
+// (the sumstatEXP sampler does); this kernel is the throughput path of phm_expm_eigen_mfma.
+// ------------------------------------------------------------------------------------------------
+using d4_t = __attribute__((ext_vector_type(4))) double;
+
+__global__ __launch_bounds__(256) void expm_eigen_mfma_kernel(int n, const double* __restrict__ L,
+                                                              const double* __restrict__ R,
+                                                              const double* __restrict__ dvals,
+                                                              const double* __restrict__ t, int n_t,
+                                                              double* __restrict__ out) {
+  __shared__ double s_e[64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int rb = (n + 15) >> 4;                 // 16-wide row / column blocks in use (1..4)
+  const int lr = lane & 15, lk = lane >> 4;
+  double Lf[4][16], Rf[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    const int k = 4 * s + lk, col = 16 * w + lr;
+    Rf[s] = (k < n && col < n) ? R[k * n + col] : 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = 16 * i + lr;
+      Lf[i][s] = (row < n && k < n) ? L[row * n + k] : 0.0;
+    }
+  }
+  for (int b = blockIdx.x; b < n_t; b += gridDim.x) {
+    __syncthreads();
+    if (threadIdx.x < 64) s_e[threadIdx.x] = ((int)threadIdx.x < n) ? phm_exp(dvals[threadIdx.x] * t[b]) : 0.0;   // :2966
+    __syncthreads();
+    if (w < rb) {
+      double ek[16];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) ek[s] = s_e[4 * s + lk];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (i < rb) {
+          d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Lf[i][s] * ek[s], Rf[s], acc, 0, 0, 0);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int row = 16 * i + lk + 4 * q, col = 16 * w + lr;
+            if (row < n && col < n) out[(size_t)b * n * n + row * n + col] = fabs(acc[q]);
+          }
+        }
+      }
+    }
+  }
+}
+
+hipError_t launch_expm_eigen_mfma(int n, const double* L, const double* R, const double* dvals, const double* t, int n_t,
+                                  double* out, hipStream_t stream) {
+  int grid = n_t < 2048 ? n_t : 2048;
+  hipLaunchKernelGGL(expm_eigen_mfma_kernel, dim3(grid), dim3(256), 0, stream, n, L, R, dvals, t, n_t, out);
+  return hipGetLastError();
+}
+
 }  // namespace phm

@@ -171,6 +171,17 @@ def matexp(L, R, dvals, t):
     return P
 
 
+def matexp_fma(L, R, dvals, t):
+    L = np.ascontiguousarray(L, dtype=np.float64)
+    R = np.ascontiguousarray(R, dtype=np.float64)
+    dv = np.ascontiguousarray(dvals, dtype=np.float64)
+    n = L.shape[0]
+    P = np.zeros((n, n))
+    lib().orc_matexp_fma(_ptr(L, C.c_double), _ptr(R, C.c_double), _ptr(dv, C.c_double), n, C.c_double(t),
+                         _ptr(P, C.c_double))
+    return P
+
+
 def expmat_pade(A):
     A = np.ascontiguousarray(A, dtype=np.float64)
     n = A.shape[0]

@@ -280,6 +280,26 @@ def test_expm_routes(n):
     np.testing.assert_allclose(P1, P2, atol=1e-10)
 
 
+@pytest.mark.parametrize("n", [20, 61, 64])
+def test_expm_eigen_on_matrix_cores(n):
+    """K1 as an MFMA f64 batched GEMM: agrees with the exact kernel to rounding, with scipy to 1e-10, and is
+    bit-for-bit a k-ordered fma chain (oracle model orc_matexp_fma)."""
+    from scipy.linalg import expm
+    Q = synth.config_Q(5) if n == 20 else synth.dense_Q(n, 0.005, 0.015, seed=n)
+    Q = (Q + Q.T) / 2
+    np.fill_diagonal(Q, 0.0)
+    np.fill_diagonal(Q, -Q.sum(1))
+    lefts, rights, d = api.eigen_decompose(Q)
+    t = np.concatenate([[0.0, 1e-6], np.random.default_rng(n).exponential(3.0, 70)])
+    P_exact, _ = api.expm_eigen(lefts, rights, d, t)
+    P_mfma, ms = api.expm_eigen(lefts, rights, d, t, mfma=True)
+    np.testing.assert_allclose(P_mfma, P_exact, rtol=0, atol=1e-13)
+    for b in (0, 1, 5, 71):
+        np.testing.assert_allclose(P_mfma[b], expm(Q * t[b]), atol=1e-10)
+        model = O.matexp_fma(lefts, rights, np.diag(d), t[b])
+        assert np.array_equal(P_mfma[b], model), np.abs(P_mfma[b] - model).max()
+
+
 def test_full_size_invariants():
     """BASELINE sizes, size-independent properties: dwell row sums = tree length; counts are integers;
     a second engine with the same seed reproduces the first bit for bit."""
