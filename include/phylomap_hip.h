@@ -158,6 +158,10 @@ int32_t phm_expm_eigen_mfma(int32_t n_states, const double* lefts, const double*
 int32_t phm_expm_pade(int32_t n_states, const double* Q, const double* t, int32_t n_t, int32_t device,
                       double* out, double* kernel_ms);
 
+/* phm_expm_pade with every matrix product on the matrix cores (v_mfma_f64_16x16x4_f64), 16 < n_states <= 64 */
+int32_t phm_expm_pade_mfma(int32_t n_states, const double* Q, const double* t, int32_t n_t, int32_t device,
+                           double* out, double* kernel_ms);
+
 /* ---- resident engine (inputs stay in HBM between calls; what bench.py times) ---- */
 int32_t phm_engine_create(const phm_tree* x, const phm_model* model, const phm_options* opt,
                           int32_t max_iters, phm_engine** out);

@@ -19,7 +19,7 @@ EXPORTS = [
     "phm_version", "phm_device_count", "phm_last_error", "phm_status_string",
     "phm_maketreelistMCMC", "phm_maketreelistMCMC_bigtree", "phm_SPARSEmaketreelistMCMC", "phm_maketreelistEXP",
     "phm_maketreelistMCMCks_sweep",
-    "phm_expm_eigen", "phm_expm_eigen_mfma", "phm_expm_pade",
+    "phm_expm_eigen", "phm_expm_eigen_mfma", "phm_expm_pade", "phm_expm_pade_mfma",
     "phm_engine_create", "phm_engine_run", "phm_engine_sync", "phm_engine_read_stats", "phm_engine_dump",
     "phm_engine_info", "phm_engine_destroy", "phm_engine_reduced_stats_device",
     "phm_engine_time_pruning", "phm_tree_orders",
@@ -106,6 +106,8 @@ def load():
                                      C.POINTER(C.c_double), C.c_int32, C.c_int32, C.POINTER(C.c_double),
                                      C.POINTER(C.c_double)]
         L.phm_expm_eigen_mfma.argtypes = L.phm_expm_eigen.argtypes
+        L.phm_expm_pade_mfma.argtypes = [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32, C.c_int32,
+                                         C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.phm_expm_pade.argtypes = [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32, C.c_int32,
                                     C.POINTER(C.c_double), C.POINTER(C.c_double)]
         _lib = L

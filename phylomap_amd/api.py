@@ -110,14 +110,16 @@ def expm_eigen(lefts, rights, d, t, device=-1, mfma=False):
     return out, ms.value
 
 
-def expm_pade(Q, t, device=-1):
-    """Batched expmat(Q t_b), Pade(6) scaling-and-squaring. Returns (P[n_t,n,n], kernel_ms)."""
+def expm_pade(Q, t, device=-1, mfma=False):
+    """Batched expmat(Q t_b), Pade(6) scaling-and-squaring. Returns (P[n_t,n,n], kernel_ms).
+    ``mfma=True`` (16 < n <= 64): every matrix product on the matrix cores (agrees to rounding, not bit for bit)."""
     L = _lib.load()
     Q = np.asfortranarray(np.asarray(Q, dtype=np.float64))
     t = np.ascontiguousarray(t, dtype=np.float64)
     n = Q.shape[0]
     out = np.zeros((t.size, n, n))
     ms = C.c_double(0.0)
-    _lib.check(L.phm_expm_pade(n, _lib._p(Q, C.c_double), _lib._p(t, C.c_double), int(t.size), int(device),
+    fn = L.phm_expm_pade_mfma if mfma else L.phm_expm_pade
+    _lib.check(fn(n, _lib._p(Q, C.c_double), _lib._p(t, C.c_double), int(t.size), int(device),
                                _lib._p(out, C.c_double), C.byref(ms)))
     return out, ms.value

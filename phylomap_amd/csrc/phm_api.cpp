@@ -649,8 +649,8 @@ int32_t phm_expm_eigen_mfma(int32_t n, const double* lefts, const double* rights
   return expm_eigen_impl(true, n, lefts, rights, d, t, n_t, device, out, kernel_ms);
 }
 
-int32_t phm_expm_pade(int32_t n, const double* Q, const double* t, int32_t n_t, int32_t device, double* out,
-                      double* kernel_ms) {
+static int32_t expm_pade_impl(bool mfma, int32_t n, const double* Q, const double* t, int32_t n_t, int32_t device, double* out,
+                              double* kernel_ms) {
   if (n < 1 || n > 128 || !Q || !t || !out || n_t < 0) return fail(PHM_ERR_BAD_INPUT, "phm_expm_pade: bad arguments (n <= 128)");
   int32_t st = select_device(device);
   if (st) return st;
@@ -662,7 +662,7 @@ int32_t phm_expm_pade(int32_t n, const double* Q, const double* t, int32_t n_t, 
   const size_t nn = (size_t)n * n;
   DevBuf dQ, dt, ds, dwork, dout, derr;
   HIPCHK(dQ.alloc(sizeof(double) * nn)); HIPCHK(dt.alloc(sizeof(double) * n_t)); HIPCHK(ds.alloc(sizeof(int32_t) * n_t));
-  HIPCHK(dwork.alloc(sizeof(double) * nn * 5 * n_t)); HIPCHK(dout.alloc(sizeof(double) * nn * n_t)); HIPCHK(derr.alloc(sizeof(uint32_t)));
+  HIPCHK(dwork.alloc(mfma ? 16 : sizeof(double) * nn * 5 * n_t)); HIPCHK(dout.alloc(sizeof(double) * nn * n_t)); HIPCHK(derr.alloc(sizeof(uint32_t)));
   HIPCHK(hipMemcpy(dQ.p, Qr.data(), dQ.bytes, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(dt.p, t, dt.bytes, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(ds.p, sq.data(), ds.bytes, hipMemcpyHostToDevice));
@@ -670,7 +670,8 @@ int32_t phm_expm_pade(int32_t n, const double* Q, const double* t, int32_t n_t, 
   Timer tm;
   HIPCHK(hipEventCreate(&tm.a)); HIPCHK(hipEventCreate(&tm.b));
   HIPCHK(hipEventRecord(tm.a, nullptr));
-  HIPCHK(phm::launch_expm_pade(n, dQ.as<double>(), dt.as<double>(), ds.as<int32_t>(), n_t, dwork.as<double>(), dout.as<double>(), derr.as<uint32_t>(), nullptr));
+  if (mfma) HIPCHK(phm::launch_expm_pade_mfma(n, dQ.as<double>(), dt.as<double>(), ds.as<int32_t>(), n_t, dout.as<double>(), derr.as<uint32_t>(), nullptr));
+  else HIPCHK(phm::launch_expm_pade(n, dQ.as<double>(), dt.as<double>(), ds.as<int32_t>(), n_t, dwork.as<double>(), dout.as<double>(), derr.as<uint32_t>(), nullptr));
   HIPCHK(hipEventRecord(tm.b, nullptr));
   HIPCHK(hipMemcpy(out, dout.p, dout.bytes, hipMemcpyDeviceToHost));
   uint32_t derrh = 0;
@@ -678,6 +679,16 @@ int32_t phm_expm_pade(int32_t n, const double* Q, const double* t, int32_t n_t, 
   if (kernel_ms) { float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, tm.a, tm.b)); *kernel_ms = ms; }
   if (derrh) return fail(PHM_ERR_BAD_INPUT, "phm_expm_pade: singular Pade denominator");
   return PHM_OK;
+}
+
+int32_t phm_expm_pade(int32_t n, const double* Q, const double* t, int32_t n_t, int32_t device, double* out, double* kernel_ms) {
+  return expm_pade_impl(false, n, Q, t, n_t, device, out, kernel_ms);
+}
+
+int32_t phm_expm_pade_mfma(int32_t n, const double* Q, const double* t, int32_t n_t, int32_t device, double* out,
+                           double* kernel_ms) {
+  if (n <= 16 || n > 64) return fail(PHM_ERR_UNSUPPORTED, "phm_expm_pade_mfma: 16 < n_states <= 64 (smaller matrices do not fill an MFMA tile)");
+  return expm_pade_impl(true, n, Q, t, n_t, device, out, kernel_ms);
 }
 
 // maketreelistEXP, src/phylomap.cpp:3001-3051.  P(t_b) and the pruning pass are computed ONCE (the reference

@@ -26,6 +26,10 @@ hipError_t launch_expm_eigen_mfma(int n, const double* L, const double* R, const
 hipError_t launch_expm_pade(int n, const double* Q, const double* t, const int32_t* s, int n_t, double* work,
                             double* out, uint32_t* err, hipStream_t stream);
 
+// the same on the matrix cores (16 < n <= 64): Pade powers and squarings as MFMA f64 products, solve(D,E) in LDS
+hipError_t launch_expm_pade_mfma(int n, const double* Q, const double* t, const int32_t* s, int n_t, double* out,
+                                 uint32_t* err, hipStream_t stream);
+
 // PL[parent] = (P_a PL[child_a]) (.) (P_b PL[child_b]); PL is (2T-1) x n row-major, tips pre-filled one-hot
 hipError_t launch_exp_pl(int n, int n_node, int n_tips, const UpStep* up, const double* P, double* PL,
                          hipStream_t stream);

@@ -400,6 +400,179 @@ __global__ __launch_bounds__(256) void expm_eigen_mfma_kernel(int n, const doubl
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K1' on the matrix cores: expmat(Q t_b) = Pade(6) + s squarings as a batched small GEMM chain (16 < n <= 64).
+// One workgroup (4 waves) per matrix; wave w owns the 16-column block w of every intermediate.  With A as the left
+// operand, the powers X <- A X never leave registers: an MFMA result tile (col = l&15, row = (l>>4) + 4 reg) is
+// exactly the B-operand slice layout (k = 4 s + (l>>4)), so register `reg` of row block kb feeds k-step 4 kb + reg.
+// solve(D, E) runs in LDS (partial pivoting), the squarings re-read the result from LDS in both operand layouts.
+// Fused k-slices: agrees with the exact kernel to rounding (tests: <= 1e-13), not bit for bit.
+// ------------------------------------------------------------------------------------------------
+constexpr int PADE_LDP = 65;      // padded LDS row stride (doubles)
+
+__global__ __launch_bounds__(256) void expm_pade_mfma_kernel(int n, const double* __restrict__ Q,
+                                                             const double* __restrict__ t,
+                                                             const int32_t* __restrict__ sq, int n_t,
+                                                             double* __restrict__ out, uint32_t* err) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  double* sD = reinterpret_cast<double*>(smem);                  // [64][PADE_LDP]
+  double* sE = sD + 64 * PADE_LDP;                               // [64][PADE_LDP]  (E, then the solution Y)
+  __shared__ double fv[64];
+  __shared__ int s_piv;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, tid = threadIdx.x;
+  const int rb = (n + 15) >> 4;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int mycol = 16 * w + lr;
+
+  for (int b = blockIdx.x; b < n_t; b += gridDim.x) {
+    const double tb = t[b];
+    const int s = sq[b];
+    const double inv_sc = ldexp(1.0, -s);
+    d4_t X[4], Em[4], Dm[4], T[4];
+    if (w < rb) {
+      double Af[4][16];                                          // A = Q t / 2^s, A-operand fragments
+#pragma unroll
+      for (int sI = 0; sI < 16; ++sI) {
+        const int k = 4 * sI + lk;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = 16 * i + lr;
+          Af[i][sI] = (row < n && k < n) ? (Q[row * n + k] * tb) * inv_sc : 0.0;
+        }
+      }
+      double c = 0.5;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = 16 * i + lk + 4 * q;
+          const double a = (row < n && mycol < n) ? (Q[row * n + mycol] * tb) * inv_sc : 0.0;
+          const double dg = (row == mycol) ? 1.0 : 0.0;
+          X[i][q] = a;
+          Em[i][q] = c * a + dg;
+          Dm[i][q] = dg - c * a;
+        }
+      bool positive = true;
+      for (int pw = 2; pw <= 6; ++pw) {
+        c = c * (double)(6 - pw + 1) / (double)(pw * (2 * 6 - pw + 1));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          d4_t acc = {0.0, 0.0, 0.0, 0.0};
+          if (i < rb) {
+#pragma unroll
+            for (int sI = 0; sI < 16; ++sI) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Af[i][sI], X[sI >> 2][sI & 3], acc, 0, 0, 0);
+          }
+          T[i] = acc;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          X[i] = T[i];
+          Em[i] += c * T[i];
+          if (positive) Dm[i] += c * T[i]; else Dm[i] -= c * T[i];
+        }
+        positive = !positive;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = 16 * i + lk + 4 * q;
+          sD[row * PADE_LDP + mycol] = Dm[i][q];
+          sE[row * PADE_LDP + mycol] = Em[i][q];
+        }
+    }
+    __syncthreads();
+
+    // ---- solve D Y = E in LDS: elimination with partial pivoting, then column-oriented back substitution ----
+    for (int col = 0; col < n; ++col) {
+      if (w == 0) {
+        double v = (lane >= col && lane < n) ? fabs(sD[lane * PADE_LDP + col]) : -1.0;
+        int idx = lane;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+          double ov = __shfl_xor(v, off, 64);
+          int oi = __shfl_xor(idx, off, 64);
+          if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+        }
+        if (lane == 0) { s_piv = idx; if (!(v > 0.0)) atomicOr(err, DERR_ZERO_PROB); }
+      }
+      __syncthreads();
+      const int piv = s_piv;
+      if (piv != col) {
+        if (tid < 64) { double a = sD[col * PADE_LDP + tid]; sD[col * PADE_LDP + tid] = sD[piv * PADE_LDP + tid]; sD[piv * PADE_LDP + tid] = a; }
+        else if (tid < 128) { int k = tid - 64; double a = sE[col * PADE_LDP + k]; sE[col * PADE_LDP + k] = sE[piv * PADE_LDP + k]; sE[piv * PADE_LDP + k] = a; }
+        __syncthreads();
+      }
+      if (tid > col && tid < n) fv[tid] = sD[tid * PADE_LDP + col] / sD[col * PADE_LDP + col];
+      __syncthreads();
+      const int nr = n - col - 1;
+      for (int e = tid; e < nr * 64; e += 256) {
+        const int r = col + 1 + (e >> 6), k = e & 63;
+        if (k < n) {
+          const double f = fv[r];
+          if (k >= col) sD[r * PADE_LDP + k] -= f * sD[col * PADE_LDP + k];
+          sE[r * PADE_LDP + k] -= f * sE[col * PADE_LDP + k];
+        }
+      }
+      __syncthreads();
+    }
+    for (int r = n - 1; r >= 0; --r) {
+      if (tid < n) sE[r * PADE_LDP + tid] = sE[r * PADE_LDP + tid] / sD[r * PADE_LDP + r];
+      __syncthreads();
+      for (int e = tid; e < r * 64; e += 256) {
+        const int i = e >> 6, k = e & 63;
+        if (k < n) sE[i * PADE_LDP + k] -= sD[i * PADE_LDP + r] * sE[r * PADE_LDP + k];
+      }
+      __syncthreads();
+    }
+
+    // ---- s squarings: Y <- Y Y, operands re-read from LDS in A- and B-slice layouts ----
+    for (int it = 0; it < s; ++it) {
+      if (w < rb) {
+        d4_t Yb[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) Yb[kb][q] = sE[(16 * kb + lk + 4 * q) * PADE_LDP + mycol];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          d4_t acc = {0.0, 0.0, 0.0, 0.0};
+          if (i < rb) {
+#pragma unroll
+            for (int sI = 0; sI < 16; ++sI)
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sE[(16 * i + lr) * PADE_LDP + 4 * sI + lk], Yb[sI >> 2][sI & 3], acc, 0, 0, 0);
+          }
+          T[i] = acc;
+        }
+      }
+      __syncthreads();
+      if (w < rb) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) sE[(16 * i + lk + 4 * q) * PADE_LDP + mycol] = T[i][q];
+      }
+      __syncthreads();
+    }
+    for (int e = tid; e < n * n; e += 256) {
+      const int r = e / n, k = e - r * n;
+      out[(size_t)b * n * n + e] = sE[r * PADE_LDP + k];
+    }
+    __syncthreads();
+  }
+}
+
+hipError_t launch_expm_pade_mfma(int n, const double* Q, const double* t, const int32_t* s, int n_t, double* out,
+                                 uint32_t* err, hipStream_t stream) {
+  size_t lds = sizeof(double) * 2 * 64 * PADE_LDP;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(expm_pade_mfma_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  int grid = n_t < 1024 ? n_t : 1024;
+  hipLaunchKernelGGL(expm_pade_mfma_kernel, dim3(grid), dim3(256), lds, stream, n, Q, t, s, n_t, out, err);
+  return hipGetLastError();
+}
+
 hipError_t launch_expm_eigen_mfma(int n, const double* L, const double* R, const double* dvals, const double* t, int n_t,
                                   double* out, hipStream_t stream) {
   int grid = n_t < 2048 ? n_t : 2048;

@@ -300,6 +300,19 @@ def test_expm_eigen_on_matrix_cores(n):
         assert np.array_equal(P_mfma[b], model), np.abs(P_mfma[b] - model).max()
 
 
+@pytest.mark.parametrize("n", [20, 61, 64])
+def test_expm_pade_on_matrix_cores(n):
+    from scipy.linalg import expm
+    Q = synth.config_Q(5) if n == 20 else synth.dense_Q(n, 0.005, 0.015, seed=n)
+    t = np.concatenate([[0.0, 1e-6, 200.0], np.random.default_rng(n).exponential(3.0, 40)])
+    P_exact, _ = api.expm_pade(Q, t)
+    P_mfma, _ = api.expm_pade(Q, t, mfma=True)
+    np.testing.assert_allclose(P_mfma, P_exact, rtol=0, atol=2e-13)
+    for b in (0, 1, 2, 7, 42):
+        np.testing.assert_allclose(P_mfma[b], expm(Q * t[b]), atol=1e-12)
+        np.testing.assert_allclose(P_mfma[b].sum(1), 1.0, atol=1e-12)
+
+
 def test_full_size_invariants():
     """BASELINE sizes, size-independent properties: dwell row sums = tree length; counts are integers;
     a second engine with the same seed reproduces the first bit for bit."""

@@ -8,8 +8,9 @@ Q = synth.dense_Q(n, 0.005, 0.015, seed=n); Q = (Q + Q.T) / 2; np.fill_diagonal(
 l, r, d = api.eigen_decompose(Q)
 t = np.random.default_rng(0).exponential(3.0, nt)
 for name, fn in (("eigen exact", lambda: api.expm_eigen(l, r, d, t)), ("eigen mfma", lambda: api.expm_eigen(l, r, d, t, mfma=True)),
-                 ("pade exact", lambda: api.expm_pade(Q, t[: max(1, nt // 8)]))):
-    if name == "eigen mfma" and not (16 < n <= 64): continue
+                 ("pade exact", lambda: api.expm_pade(Q, t[: max(1, nt // 8)])),
+                 ("pade mfma", lambda: api.expm_pade(Q, t[: max(1, nt // 8)], mfma=True))):
+    if name.endswith("mfma") and not (16 < n <= 64): continue
     fn(); _, ms = fn()
     cnt = nt if "eigen" in name else max(1, nt // 8)
     fl = 2 * n ** 3 * cnt / (ms / 1e3) / 1e12
