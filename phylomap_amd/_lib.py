@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libphylomap_hip.so")
+LIB_PATH = os.environ.get("PHM_LIB", os.path.join(_HERE, "libphylomap_hip.so"))   # PHM_LIB: developer override
 
 PHM_OK = 0
 STATUS = {0: "PHM_OK", 1: "PHM_ERR_BAD_INPUT", 2: "PHM_ERR_UNSUPPORTED", 3: "PHM_ERR_NO_DEVICE", 4: "PHM_ERR_OOM",
