@@ -88,6 +88,68 @@ def test_mcmc_long_initial_paths_take_the_general_branch_path():
         np.testing.assert_array_equal(got[r], want)
 
 
+def _two_tip_tree(states, lens=(1.5, 0.7), segs=(1, 1)):
+    edge = np.array([[3, 1], [3, 2]], dtype=np.int32)
+    maps = [np.full(segs[i], lens[i] / segs[i]) for i in range(2)]
+    mapnames = [np.array([1] * (segs[i] - 1) + [states[i]], dtype=np.int32) for i in range(2)]
+    return {"edge": edge, "Nnode": 1, "edge.length": np.asarray(lens, dtype=float), "states": np.asarray(states, dtype=np.int32),
+            "maps": maps, "mapnames": mapnames, "node.states": np.ones((2, 2), dtype=np.int32)}
+
+
+@pytest.mark.parametrize("segs", [(1, 1), (1, 3), (2, 2)])
+def test_edge_case_smallest_tree_and_single_segment_branches(segs):
+    """Two tips, one internal node (no nodelist), branches that start with ONE segment: updatenodestates then writes the
+    single segment twice and the child wins (src/phylomap.cpp:468-472)."""
+    Q = synth.config_Q(2)
+    Omega = 1.5
+    pid = np.array([.1, .2, .3, .4])
+    z = _two_tip_tree([3, 3] if segs == (1, 1) else [2, 4], segs=segs)    # B^0 = I: single-segment branches need equal tips
+    nen, nodelist, root = _orders(z)
+    assert len(nodelist) == 0 and root == 3
+    for fn, var in VARIANTS:
+        got = getattr(api, fn)(z, Q, pid, Omega, 30, seed=8, n_replicas=2)
+        for r in range(2):
+            want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(4) + Q / Omega, Omega, nen, nodelist, root, 30, variant=var, seed=8, replica=r)
+            assert rc == 0
+            np.testing.assert_array_equal(got[r], want)
+    lefts, rights, d = api.eigen_decompose(Q)
+    got = api.sumstatEXP(z, Q, pid, 100, seed=8)
+    want, rc = O.maketreelistEXP(z, Q, pid, nen, nodelist, root, 100, lefts, rights, d, seed=8)
+    assert rc == 0
+    np.testing.assert_array_equal(got, want)
+
+
+def test_edge_case_zero_length_segments_and_omega_on_the_boundary():
+    """A zero-length input segment stops the virtual-jump loop for the rest of that branch (list iterators are not
+    advanced, src/phylomap.cpp:397,405-406); Omega == |q_ii| for one state gives rate 0 = no virtual jumps there."""
+    Q = np.array([[-1.0, 1.0], [0.25, -0.25]])
+    Omega = 1.0                                            # Omega + q_00 == 0
+    pid = np.array([.5, .5])
+    z = synth.make_tree(12, Q, Omega, 55, pid)
+    z["maps"] = [np.array([m[0], 0.0, m[1]]) if i % 3 == 0 else m for i, m in enumerate(z["maps"])]
+    z["mapnames"] = [np.array([n_[0], n_[0], n_[1]], dtype=np.int32) if i % 3 == 0 else n_ for i, n_ in enumerate(z["mapnames"])]
+    nen, nodelist, root = _orders(z)
+    got = api.sumstatMCMC(z, Q, pid, Omega, 25, seed=21, n_replicas=3)
+    for r in range(3):
+        want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(2) + Q / Omega, Omega, nen, nodelist, root, 25, seed=21, replica=r)
+        assert rc == 0
+        np.testing.assert_array_equal(got[r], want)
+
+
+def test_edge_case_impossible_data_raises_like_the_sampler():
+    """Tip data that the jump structure cannot produce (absorbing state, one segment per branch) give an all-zero weight
+    vector: RcppArmadillo::sample throws; oracle and GPU report PHM_ERR_ZERO_PROB."""
+    Q = np.array([[-0.5, 0.5], [0.0, 0.0]])                # state 2 is absorbing
+    Omega = 1.0
+    z = _two_tip_tree([1, 2], segs=(1, 1))                 # B^0 = I cannot connect a root state to both tips
+    nen, nodelist, root = _orders(z)
+    _, rc = O.maketreelistMCMC(z, Q, np.array([.5, .5]), np.eye(2) + Q / Omega, Omega, nen, nodelist, root, 3, seed=1)
+    assert rc & O.ERR_ZERO_PROB
+    with pytest.raises(_lib.PhmError) as e:
+        api.sumstatMCMC(z, Q, np.array([.5, .5]), Omega, 3, seed=1)
+    assert e.value.status == 5
+
+
 def test_mcmc_non_cladewise_edge_order():
     """Edge rows shuffled: the engine derives its own sweeps; counts stay exact, dwell within 1e-10."""
     z, Q, pid, Omega = _problem(4, 30, 5)
