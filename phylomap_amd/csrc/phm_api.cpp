@@ -308,7 +308,7 @@ int32_t phm_engine_create(const phm_tree* x, const phm_model* model, const phm_o
     }
   }
 
-  const size_t stats_bytes = (e->reduce && !e->wide) ? sizeof(double) * (size_t)max_iters * e->tiles * e->dcols
+  const size_t stats_bytes = e->reduce ? sizeof(double) * (size_t)max_iters * e->tiles * e->dcols
                                                      : sizeof(double) * (size_t)max_iters * e->dcols * e->S_pad;
   const size_t dw_bytes = sizeof(double) * (size_t)e->tiles * rows * 64;
   size_t need = 2 * dw_bytes + stats_bytes + sizeof(double) * (size_t)e->tiles * s.n_node * n * 64 +
@@ -373,7 +373,7 @@ int32_t phm_engine_create(const phm_tree* x, const phm_model* model, const phm_o
     p.n_states = n; p.n_tips = s.n_tips; p.n_node = s.n_node; p.n_edge = s.n_edge; p.root = s.root;
     p.n_tiles = e->tiles; p.n_rep = e->S; p.n_rep_pad = e->S_pad; p.replica_offset = o.replica_offset;
     p.normalise = (e->variant == PHM_MCMC_BIGTREE || e->variant == PHM_MCMC_KS); p.tips_per_replica = e->tips_per_replica ? 1 : 0;
-    p.n_cols = e->dcols; p.ktab = phm::WIDE_KTAB; p.ks = (e->variant == PHM_MCMC_KS); p.count_self = p.ks;
+    p.reduce = e->reduce; p.n_cols = e->dcols; p.ktab = phm::WIDE_KTAB; p.sparse = (e->variant == PHM_MCMC_SPARSE); p.ks = (e->variant == PHM_MCMC_KS); p.count_self = p.ks;
     p.maskpow = e->d_mask.as<double>();
     p.seed_lo = (uint32_t)(o.seed & 0xFFFFFFFFull); p.seed_hi = (uint32_t)(o.seed >> 32);
     p.rows = e->rows;
@@ -452,11 +452,7 @@ int32_t phm_engine_read_stats(phm_engine* e, int32_t iter0, int32_t n, double* o
       for (int i = 0; i < n; ++i) mat[(size_t)(dcols - 1 + q) * n + i] = e->qparams[q];
   };
   if (e->reduce) {
-    if (e->wide)
-      HIPCHK(phm::launch_stats_reduce_replicas(e->d_stats.as<double>() + (size_t)iter0 * dcols * e->S_pad, n, dcols, e->S,
-                                               e->S_pad, e->d_red.as<double>(), e->last_stream));
-    else
-      HIPCHK(phm::launch_stats_reduce(e->d_stats.as<double>() + (size_t)iter0 * e->tiles * dcols, n, e->tiles, dcols,
+    HIPCHK(phm::launch_stats_reduce(e->d_stats.as<double>() + (size_t)iter0 * e->tiles * dcols, n, e->tiles, dcols,
                                       e->d_red.as<double>(), e->last_stream));
     std::vector<double> h((size_t)n * dcols);
     HIPCHK(hipMemcpyAsync(h.data(), e->d_red.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, e->last_stream));
@@ -793,11 +789,7 @@ extern "C" int32_t phm_engine_reduced_stats_device(phm_engine* e, int32_t iter0,
   if (!e->reduce) return fail(PHM_ERR_STATE, "engine was not created with reduce = 1");
   if (iter0 < 0 || n < 1 || iter0 + n > e->iters_done) return fail(PHM_ERR_STATE, "statistics requested for iterations that have not run");
   HIPCHK(hipSetDevice(e->device));
-  if (e->wide)
-    HIPCHK(phm::launch_stats_reduce_replicas(e->d_stats.as<double>() + (size_t)iter0 * e->dcols * e->S_pad, n, e->dcols, e->S,
-                                             e->S_pad, e->d_red.as<double>(), reinterpret_cast<hipStream_t>(hip_stream)));
-  else
-    HIPCHK(phm::launch_stats_reduce(e->d_stats.as<double>() + (size_t)iter0 * e->tiles * e->dcols, n, e->tiles, e->dcols,
+  HIPCHK(phm::launch_stats_reduce(e->d_stats.as<double>() + (size_t)iter0 * e->tiles * e->dcols, n, e->tiles, e->dcols,
                                     e->d_red.as<double>(), reinterpret_cast<hipStream_t>(hip_stream)));
   *out_dev = e->d_red.p;
   return PHM_OK;

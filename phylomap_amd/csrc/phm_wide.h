@@ -9,15 +9,18 @@
 
 namespace phm {
 
-constexpr int WIDE_BLOCK = 256;     // 4 wavefronts share the LDS copies of B
+constexpr int WIDE_BLOCK = 384;     // 6 wavefronts share the LDS copy of B (two workgroups per CU at n = 61)
 constexpr int WIDE_KTAB = 16;       // B^k e_j tables in global memory for k < KTAB
-constexpr int WIDE_MAXSEG = 128;    // most segments one branch of one replica may hold (LDS state scratch)
+constexpr int WIDE_MAXSEG = 128;    // most segments one branch of one replica may hold (LDS state scratch) ...
+constexpr int WIDE_MAXSEG_BIG_N = 128;
+inline int wide_maxseg(int n) { return n > 40 ? WIDE_MAXSEG_BIG_N : WIDE_MAXSEG; }
 
 struct WideParams {
   int32_t n_states;
   int32_t n_tips, n_node, n_edge, root;
   int32_t n_tiles, n_rep, n_rep_pad, replica_offset;
-  int32_t normalise, tips_per_replica, n_cols, ktab;
+  int32_t normalise, tips_per_replica, reduce, n_cols, ktab;
+  int32_t sparse;                            // 1: Bc != B2 (SPARSE variant), both staged in LDS
   int32_t ks;                                // 1: sumstatMCMCks tree sweep (tip masks, tips re-sampled, root column)
   int32_t count_self;                        // 1: n x n transition counts incl. self pairs (shortenerbf :1010-1014)
   uint32_t seed_lo, seed_hi;
@@ -37,12 +40,12 @@ struct WideParams {
   double* dwell1;
   double* PL;                                // [tile][n_node][64][n]  (a replica's vector is contiguous)
   uint8_t* nstate;                           // [tile][n_node][64]
-  double* stats;                             // [iter][cols][n_rep_pad], accumulated in place (zeroed at create)
+  double* stats;                             // reduce: [iter][tile][cols] (atomics); else [iter][cols][n_rep_pad]; zeroed at create
   uint32_t* err;
   unsigned long long* segcnt;
 };
 
-size_t wide_lds_bytes(int n);
+size_t wide_lds_bytes(int n, bool sparse);
 hipError_t launch_mcmc_wide(const WideParams& p, int iter0, int n_iters, hipStream_t stream);
 hipError_t launch_stats_reduce_replicas(const double* stats, int n_iters, int n_cols, int n_rep, int n_rep_pad,
                                         double* out, hipStream_t stream);

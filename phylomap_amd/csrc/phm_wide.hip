@@ -27,10 +27,12 @@ __device__ __forceinline__ int wave_max_w(int v) {
   return __builtin_amdgcn_readfirstlane(v);
 }
 
-// y <- M y with lanes over rows: Mt is M transposed in LDS ([j][c]), so lane c reads M[c][j] conflict-free
-__device__ __forceinline__ double coop_matvec(const double* __restrict__ Mt, double v, int n, int c) {
-  double acc = Mt[c] * readlane_f64(v, 0);
-  for (int j = 1; j < n; ++j) acc += Mt[j * n + c] * readlane_f64(v, j);
+// y <- M y with lanes over rows: M row-major in LDS with an ODD row stride ldn, so the 64 lanes reading M[c][j]
+// (stride ldn doubles) fall on distinct banks, and the transposed access M[q][c] is contiguous anyway
+__device__ __forceinline__ double coop_matvec(const double* __restrict__ M, double v, int n, int ldn, int c) {
+  const double* row = M + c * ldn;
+  double acc = row[0] * readlane_f64(v, 0);
+  for (int j = 1; j < n; ++j) acc += row[j] * readlane_f64(v, j);
   return acc;
 }
 
@@ -68,16 +70,16 @@ __global__ __launch_bounds__(WIDE_BLOCK) void mcmc_wide_kernel(WideParams p, int
   const int tile = blockIdx.x * (WIDE_BLOCK / 64) + wave;
   const int c = lane < n ? lane : n - 1;       // clamped state index of this lane
 
-  double* s_Bc = reinterpret_cast<double*>(smem);     // [r][c] chain matrix, row-major   (w <- Bc^T w)
-  double* s_Bct = s_Bc + n * n;                       // [j][c] = Bc[c][j]                (v <- Bc v)
-  double* s_B2 = s_Bct + n * n;                       // [r][c] dense B rows              (forward step)
-  double* s_scale = s_B2 + n * n;                     // [n]
-  uint8_t* s_st = reinterpret_cast<uint8_t*>(s_scale + n) + (size_t)wave * WIDE_MAXSEG * 64;   // [slot][replica]
+  const int ldn = n | 1;                              // odd row stride: conflict-free column AND row access
+  double* s_Bc = reinterpret_cast<double*>(smem);     // [r][ldn] chain matrix (v <- Bc v and w <- Bc^T w)
+  double* s_B2 = p.sparse ? s_Bc + n * ldn : s_Bc;    // [r][ldn] dense B rows for the forward step (= Bc unless SPARSE)
+  double* s_scale = s_Bc + (p.sparse ? 2 : 1) * n * ldn;   // [n]
+  const int maxseg = n > 40 ? WIDE_MAXSEG_BIG_N : WIDE_MAXSEG;
+  uint8_t* s_st = reinterpret_cast<uint8_t*>(s_scale + n) + (size_t)wave * maxseg * 64;   // [slot][replica]
   for (int i = threadIdx.x; i < n * n; i += WIDE_BLOCK) {
     int r = i / n, cc = i - r * n;
-    s_Bc[i] = p.Bc[i];
-    s_Bct[cc * n + r] = p.Bc[i];
-    s_B2[i] = p.B2[i];
+    s_Bc[r * ldn + cc] = p.Bc[i];
+    if (p.sparse) s_B2[r * ldn + cc] = p.B2[i];
   }
   if ((int)threadIdx.x < n) s_scale[threadIdx.x] = p.scale[threadIdx.x];
   __syncthreads();
@@ -107,14 +109,24 @@ __global__ __launch_bounds__(WIDE_BLOCK) void mcmc_wide_kernel(WideParams p, int
       v = PLt[((size_t)child * 64 + r) * n + c];
       done = 0;
     }
-    for (int i = done; i < k; ++i) v = coop_matvec(s_Bct, v, n, c);
+    for (int i = done; i < k; ++i) v = coop_matvec(s_Bc, v, n, ldn, c);
     return v;
   };
 
   for (int it = iter0; it < iter0 + n_iters; ++it) {
     double* dw_in = ((it & 1) ? p.dwell1 : p.dwell0) + (size_t)tile * p.rows * 64;
     double* dw_out = ((it & 1) ? p.dwell0 : p.dwell1) + (size_t)tile * p.rows * 64;
-    double* srow = p.stats + (size_t)it * p.n_cols * p.n_rep_pad + rep_local;   // + col * n_rep_pad
+    // statistics: reduce = 0 -> [iter][col][replica], plain read-modify-write by the owning lane;
+    //             reduce = 1 -> [iter][tile][col] shared by the 64 lanes of the wave, f64 atomics (counts are exact
+    //             in any order; dwell sums agree to rounding) -- n(n-1) columns per replica would not fit for n = 61
+    const bool red = p.reduce != 0;
+    double* srow = red ? p.stats + ((size_t)it * p.n_tiles + tile) * p.n_cols
+                       : p.stats + (size_t)it * p.n_cols * p.n_rep_pad + rep_local;
+    const size_t cstride = red ? 1 : (size_t)p.n_rep_pad;
+    auto stat_add = [&](int col, double v) {
+      if (red) { if (valid) atomicAdd(srow + col, v); }
+      else srow[(size_t)col * cstride] += v;
+    };
     uint32_t seg_rw = 0;
     int in_row = 0, out_row = 0;
 
@@ -147,7 +159,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) void mcmc_wide_kernel(WideParams p, int
         if (lane == r) mine = rs;
       }
       nst[p.root * 64 + lane] = (uint8_t)mine;
-      if (p.ks) srow[(size_t)(n + n * n) * p.n_rep_pad] = (double)mine;                     // :1350-1352
+      if (p.ks) stat_add(n + n * n, (double)mine);                                           // :1350-1352
     }
 
     // ------------------------------ down sweep ------------------------------
@@ -160,10 +172,10 @@ __global__ __launch_bounds__(WIDE_BLOCK) void mcmc_wide_kernel(WideParams p, int
       int cs = 0;
       if (ds.child < 0) cs = p.tips_per_replica ? tips_t[(~ds.child) * 64 + lane] : p.tips[~ds.child];
       const int tobs = cs;                         // observed tip state (ks keeps only its parity)
-      if (mmax > WIDE_MAXSEG) {      // LDS state scratch is WIDE_MAXSEG slots per replica: report, stay memory-safe
+      if (mmax > maxseg) {           // LDS state scratch is `maxseg` slots per replica: report, stay memory-safe
         err |= DERR_CAPACITY;
-        m = m < WIDE_MAXSEG ? m : WIDE_MAXSEG;
-        mmax = WIDE_MAXSEG;
+        m = m < maxseg ? m : maxseg;
+        mmax = maxseg;
       }
 
       // ---- n-vector work, replicas in turn: child state, then the interior states of the branch ----
@@ -178,7 +190,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) void mcmc_wide_kernel(WideParams p, int
           double w = p.rowpow[((size_t)kt * n + psr) * n + c];
           for (int i = kt; i < kk; ++i) {
             double acc = s_Bc[c] * readlane_f64(w, 0);
-            for (int q = 1; q < n; ++q) acc += s_Bc[q * n + c] * readlane_f64(w, q);
+            for (int q = 1; q < n; ++q) acc += s_Bc[q * ldn + c] * readlane_f64(w, q);
             w = acc;
           }
           uint32_t node_id;
@@ -202,8 +214,8 @@ __global__ __launch_bounds__(WIDE_BLOCK) void mcmc_wide_kernel(WideParams p, int
           int kk = mr - i - 1;
           int kt = kk < p.ktab ? kk : p.ktab - 1;
           double beta = p.colpow[((size_t)kt * n + csr) * n + c];
-          for (int q = kt; q < kk; ++q) beta = coop_matvec(s_Bct, beta, n, c);
-          double pr = (lane < n) ? s_B2[prev * n + c] * beta : 0.0;
+          for (int q = kt; q < kk; ++q) beta = coop_matvec(s_Bc, beta, n, ldn, c);
+          double pr = (lane < n) ? s_B2[prev * ldn + c] * beta : 0.0;
           double u = uni_draw(p, rep0 + r, (uint32_t)it, ENT_BSTATE | (uint32_t)b, (uint32_t)(i - 1));
           int si = coop_sample(pr, u, n, lane, err);
           if (lane == 0) s_st[(i - 1) * 64 + r] = (uint8_t)si;
@@ -229,14 +241,14 @@ __global__ __launch_bounds__(WIDE_BLOCK) void mcmc_wide_kernel(WideParams p, int
             int si = (i == m - 1) ? cs : (int)s_st[(i - 1) * 64 + lane];
             double di = dnext;
             if (i + 1 < m) dnext = dw_in[(roff + i + 1) * 64 + lane];
-            if (p.count_self) srow[(size_t)(n + cur_s * n + si) * p.n_rep_pad] += 1.0;   // shortenerbf :1010-1014
+            if (p.count_self) stat_add(n + cur_s * n + si, 1.0);                            // shortenerbf :1010-1014
             if (si == cur_s) cur_len = cur_len + di;                 // shortener :54
             else {
               dw_in[(roff + w) * 64 + lane] = cur_len;
               s_st[w * 64 + lane] = (uint8_t)cur_s;                  // w <= i-1: slot already consumed
               if (!p.count_self) {
                 int col = cur_s * (n - 1) + (si > cur_s ? si - 1 : si);                        // shortener :65-66
-                srow[(size_t)(n + col) * p.n_rep_pad] += 1.0;
+                stat_add(n + col, 1.0);
               }
               ++w; cur_s = si; cur_len = di;
             }
@@ -252,8 +264,9 @@ __global__ __launch_bounds__(WIDE_BLOCK) void mcmc_wide_kernel(WideParams p, int
         double len = len0;
         double lnext = (nmerged > 1) ? ((w == 1) ? cur_len : dw_in[(roff + 1) * 64 + lane]) : 0.0;
         double tot = 0.0, scale = s_scale[s];
-        double* gacc = srow + (size_t)s * p.n_rep_pad;
-        double acc = *gacc;
+        // running dwell sum of state s: continued piece by piece from the stored total (the reference's order,
+        // :752) when statistics are per replica; a fresh partial handed to one atomic when they are summed
+        double acc = red ? 0.0 : srow[(size_t)s * cstride];
         uint32_t edraw = 0;
         bool stuck = false, done = false;
         while (!done) {
@@ -269,7 +282,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) void mcmc_wide_kernel(WideParams p, int
           acc += piece;
           ++mnew;
           if (adv) {
-            *gacc = acc;
+            if (red) { if (valid) atomicAdd(srow + s, acc); } else srow[(size_t)s * cstride] = acc;
             ++j;
             if (j >= nmerged) done = true;
             else {
@@ -277,8 +290,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) void mcmc_wide_kernel(WideParams p, int
               if (j + 1 < nmerged) lnext = dw_in[(roff + j + 1) * 64 + lane];
               s = (int)s_st[j * 64 + lane];
               scale = s_scale[s]; tot = 0.0;
-              gacc = srow + (size_t)s * p.n_rep_pad;
-              acc = *gacc;
+              acc = red ? 0.0 : srow[(size_t)s * cstride];
             }
           }
         }
@@ -311,13 +323,13 @@ __global__ void stats_reduce_replicas_kernel(const double* __restrict__ stats, i
   out[idx] = acc;
 }
 
-size_t wide_lds_bytes(int n) {
-  return sizeof(double) * ((size_t)3 * n * n + n) + (size_t)(WIDE_BLOCK / 64) * WIDE_MAXSEG * 64;
+size_t wide_lds_bytes(int n, bool sparse) {
+  return sizeof(double) * ((size_t)(sparse ? 2 : 1) * n * (n | 1) + n) + (size_t)(WIDE_BLOCK / 64) * wide_maxseg(n) * 64;
 }
 
 hipError_t launch_mcmc_wide(const WideParams& p, int iter0, int n_iters, hipStream_t stream) {
   const int wpb = WIDE_BLOCK / 64;
-  size_t lds = wide_lds_bytes(p.n_states);
+  size_t lds = wide_lds_bytes(p.n_states, p.sparse != 0);
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mcmc_wide_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
