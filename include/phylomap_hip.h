@@ -53,6 +53,9 @@ typedef enum phm_variant {
                                  man/sumstatMCMCks.Rd:19: N x (n + n*n + 2 + 3k + 1): dwell, counts (row-major from,to),
                                  l01, l10, rkappas, lkappas, gammas (recordQks :1789-1798), root state (0-based).
                                  The per-iteration Gibbs/MH updates of Q (:1862-1866) are host glue that is not built yet. */
+  ,
+  PHM_MCMC_BF = 4             /* tree sweep of maketreelistMCMCbf (treesamplebf :1169-1179): two states, tips observed, n x n counts
+                                 incl. self pairs, layout time0,time1,n00,n01,n10,n11,l01,l10,root_state (R/sumstatMCMCbf.R:33) */
 } phm_variant;
 
 /* The phylomap tree object `x` (fields read at src/phylomap.cpp:896-910 and :3034). */
@@ -180,6 +183,9 @@ int32_t phm_engine_reduced_stats_device(phm_engine* e, int32_t iter0, int32_t n,
 /* measurement aid: HIP-event time (ms) of n_iters repetitions of the pruning sweep alone (makePLrcpp*,
  * src/phylomap.cpp:503-529) on the current chain state; segment counts and paths are not modified */
 int32_t phm_engine_time_pruning(phm_engine* e, int32_t n_iters, void* hip_stream, double* ms_out);
+/* replace the rate matrix between sweeps (Q-updating variants, src/phylomap.cpp:1212-1217, :1862-1866); Q column-major,
+ * B = I + Q/Omega recomputed, chain state kept; the bf/ks parameter columns record the Q in force at each sweep */
+int32_t phm_engine_set_model(phm_engine* e, const double* Q);
 /* chain state of one replica after the last iteration (tests): any pointer may be NULL.
  * seg_dwell: n_edge * seg_cap; node_states: 2*n_tips-1, 1-based; PL: (2*n_tips-1) x n row-major */
 int32_t phm_engine_dump(phm_engine* e, int32_t replica, int32_t* seg_count, double* seg_dwell, int32_t seg_cap,

@@ -67,7 +67,10 @@ int32_t device_status(uint32_t derr) {
 // -------------------------------------------------------------------------------------------------
 struct phm_engine {
   int n = 0, cols = 0, dcols = 0, variant = 0;   // cols: result columns; dcols: columns kept on the device
-  std::vector<double> qparams;                     // ks: l01, l10, rkappas, lkappas, gammas (recordQks :1789-1798)
+  std::vector<double> qparams;                     // bf/ks: l01, l10, rkappas, lkappas, gammas of the CURRENT Q (recordQks :1789-1798)
+  std::vector<std::vector<double>> qhist;          // ... as recorded at the start of every iteration that has run
+  double Omega = 0.0;
+  std::vector<double> hB2, hBc, hscale, hpid;      // current model, row-major
   int S = 0, S_pad = 0, tiles = 0, max_iters = 0, iters_done = 0, ipl = 0;
   int reduce = 0, device = 0;
   phm::Schedule sched;
@@ -102,9 +105,10 @@ void fill_params(phm_engine* e, phm::McmcParams<NS>& p, const double* B2, const 
                  const double* pid, const phm_options& o) {
   p.n_tips = e->sched.n_tips; p.n_node = e->sched.n_node; p.n_edge = e->sched.n_edge; p.root = e->sched.root;
   p.n_tiles = e->tiles; p.n_rep = e->S; p.n_rep_pad = e->S_pad; p.replica_offset = o.replica_offset;
-  p.normalise = (e->variant == PHM_MCMC_BIGTREE || e->variant == PHM_MCMC_KS); p.tips_per_replica = e->tips_per_replica ? 1 : 0;
+  p.normalise = (e->variant == PHM_MCMC_BIGTREE || e->variant == PHM_MCMC_KS || e->variant == PHM_MCMC_BF); p.tips_per_replica = e->tips_per_replica ? 1 : 0;
   p.reduce = e->reduce; p.n_cols = e->dcols; p.ktab = phm::MCMC_KTAB; p.prune_only = 0;
-  p.ks = (e->variant == PHM_MCMC_KS); p.maskpow = e->d_mask.as<double>();
+  p.ks = (e->variant == PHM_MCMC_KS || e->variant == PHM_MCMC_BF); p.tip_masks = (e->variant == PHM_MCMC_KS);
+  p.maskpow = e->d_mask.as<double>();
   p.seed_lo = (uint32_t)(o.seed & 0xFFFFFFFFull); p.seed_hi = (uint32_t)(o.seed >> 32);
   p.rows = e->rows;
   for (int i = 0; i < NS * NS; ++i) { p.B2[i] = B2[i]; p.Bc[i] = Bc[i]; }
@@ -159,6 +163,74 @@ int32_t validate_tree_paths(const phm_tree* x, int n, int n_tip_vectors) {
   return PHM_OK;
 }
 
+
+// Model matrices from R's column-major Q / B: dense B2, chain matrix Bc (thresholded for SPARSE), rexp scales, and the
+// parameter columns recordQ / recordQks write (src/phylomap.cpp:1181-1185, :1789-1798).
+int32_t compute_model(int variant, int n, const double* Q, const double* B, double Omega, std::vector<double>& B2,
+                      std::vector<double>& Bc, std::vector<double>& scale, std::vector<double>& qparams) {
+  B2.assign((size_t)n * n, 0.0); Bc.assign((size_t)n * n, 0.0); scale.assign(n, 0.0);
+  for (int i = 0; i < n; ++i) {
+    double r = Omega + Q[i + (size_t)i * n];
+    if (!(r >= 0.0)) return fail(PHM_ERR_BAD_INPUT, "Omega must be at least |q_ii| for every state (man/sumstatMCMC.Rd:14)");
+    scale[i] = 1.0 / r;
+    for (int j = 0; j < n; ++j) {
+      double b = B ? B[i + (size_t)j * n] : ((i == j ? 1.0 : 0.0) + Q[i + (size_t)j * n] / Omega);   // R/sumstatMCMC.R:25
+      if (!(b >= 0.0) || !std::isfinite(b)) return fail(PHM_ERR_BAD_INPUT, "B = I + Q/Omega must be non-negative");
+      B2[(size_t)i * n + j] = b;
+      Bc[(size_t)i * n + j] = (variant == PHM_MCMC_SPARSE) ? (b > 1e-7 ? b : 0.0) : b;              // matTospmat :811
+    }
+  }
+  qparams.clear();
+  if (variant == PHM_MCMC_KS || variant == PHM_MCMC_BF) {
+    const int k = (variant == PHM_MCMC_KS) ? n / 2 - 1 : 0;
+    auto Qe = [&](int i, int j) { return Q[i + (size_t)j * n]; };
+    qparams.push_back(Qe(0, 1));
+    qparams.push_back(Qe(1, 0));
+    for (int i = 0; i < k; ++i) qparams.push_back(Qe(2 * i, 2 * i + 2));
+    for (int i = 0; i < k; ++i) qparams.push_back(Qe(2 * i + 2, 2 * i));
+    for (int i = 0; i < k; ++i) qparams.push_back(Qe(2 * (i + 1), 2 * (i + 1) + 1) / Qe(0, 1));
+  }
+  return PHM_OK;
+}
+
+// chain tables for the current model -> device; refresh the by-value kernel parameter blocks
+int32_t upload_model(phm_engine* e) {
+  const int n = e->n;
+  const int ktab = e->wide ? phm::WIDE_KTAB : phm::MCMC_KTAB;
+  const double* Bc = e->hBc.data();
+  std::vector<double> col, row;
+  build_chain_tables(Bc, n, ktab, col, row);
+  std::vector<double> maskpow((size_t)ktab * 2 * n, 0.0);      // ks: Bc^k applied to the even / odd state masks (:1838-1845)
+  for (int par = 0; par < 2; ++par) {
+    for (int c = 0; c < n; ++c) maskpow[(size_t)par * n + c] = ((c & 1) == par) ? 1.0 : 0.0;
+    for (int k = 1; k < ktab; ++k) {
+      const double* v = &maskpow[((size_t)(k - 1) * 2 + par) * n];
+      double* y = &maskpow[((size_t)k * 2 + par) * n];
+      for (int i = 0; i < n; ++i) {
+        double acc = Bc[i * n] * v[0];
+        for (int c = 1; c < n; ++c) acc += Bc[i * n + c] * v[c];
+        y[i] = acc;
+      }
+    }
+  }
+  HIPCHK(hipMemcpy(e->d_col.p, col.data(), sizeof(double) * col.size(), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(e->d_row.p, row.data(), sizeof(double) * row.size(), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(e->d_mask.p, maskpow.data(), sizeof(double) * maskpow.size(), hipMemcpyHostToDevice));
+  if (e->wide) {
+    HIPCHK(hipMemcpy(e->d_B2.p, e->hB2.data(), sizeof(double) * n * n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_Bc.p, e->hBc.data(), sizeof(double) * n * n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_scale.p, e->hscale.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+  }
+  auto refresh = [&](auto& p) {
+    for (int i = 0; i < n * n; ++i) { p.B2[i] = e->hB2[i]; p.Bc[i] = e->hBc[i]; }
+    for (int i = 0; i < n; ++i) p.scale[i] = e->hscale[i];
+  };
+  if (n == 2) refresh(e->p2);
+  if (n == 3) refresh(e->p3);
+  if (n == 4) refresh(e->p4);
+  return PHM_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -202,48 +274,37 @@ int32_t phm_engine_create(const phm_tree* x, const phm_model* model, const phm_o
   if (n < 2) return fail(PHM_ERR_BAD_INPUT, "n_states must be >= 2");
   if (n > 64) return fail(PHM_ERR_UNSUPPORTED, "this build has MCMC kernels for n_states <= 64 only");
   if (!model->Q || !model->pid) return fail(PHM_ERR_BAD_INPUT, "model: Q/pid missing");
-  if (model->variant < PHM_MCMC || model->variant > PHM_MCMC_KS) return fail(PHM_ERR_BAD_INPUT, "unknown variant");
+  if (model->variant < PHM_MCMC || model->variant > PHM_MCMC_BF) return fail(PHM_ERR_BAD_INPUT, "unknown variant");
   if (model->variant == PHM_MCMC_KS && (n & 1)) return fail(PHM_ERR_BAD_INPUT, "sumstatMCMCks needs a hidden-rates Q of even size n = 2k+2 (src/phylomap.cpp:1820)");
+  if (model->variant == PHM_MCMC_BF && n != 2) return fail(PHM_ERR_BAD_INPUT, "sumstatMCMCbf is the two-state model (hard-wired columns, src/phylomap.cpp:1181-1185)");
   if (max_iters < 1) return fail(PHM_ERR_BAD_INPUT, "max_iters must be >= 1");
   if (!(model->Omega > 0.0) || !std::isfinite(model->Omega)) return fail(PHM_ERR_BAD_INPUT, "Omega must be positive");
   int32_t st = validate_tree_paths(x, n, o.tips_per_replica ? o.n_replicas : 1);
   if (st) return st;
 
   // model matrices, row-major copies (inputs are R's column-major)
-  std::vector<double> B2v((size_t)n * n), Bcv((size_t)n * n), scalev(n), pidv(n);
-  double *B2 = B2v.data(), *Bc = Bcv.data(), *scale = scalev.data(), *pid = pidv.data();
+  std::vector<double> B2v, Bcv, scalev, pidv(n), qp;
+  st = compute_model(model->variant, n, model->Q, model->B, model->Omega, B2v, Bcv, scalev, qp);
+  if (st) return st;
   for (int i = 0; i < n; ++i) {
-    double q = model->Q[i + (size_t)i * n];
-    double r = model->Omega + q;
-    if (!(r >= 0.0)) return fail(PHM_ERR_BAD_INPUT, "Omega must be at least |q_ii| for every state (man/sumstatMCMC.Rd:14)");
-    scale[i] = 1.0 / r;
-    pid[i] = model->pid[i];
-    if (!(pid[i] >= 0.0) || !std::isfinite(pid[i])) return fail(PHM_ERR_BAD_INPUT, "pid must be non-negative");
-    for (int j = 0; j < n; ++j) {
-      double b = model->B ? model->B[i + (size_t)j * n]
-                          : ((i == j ? 1.0 : 0.0) + model->Q[i + (size_t)j * n] / model->Omega);   // R/sumstatMCMC.R:25
-      if (!(b >= 0.0) || !std::isfinite(b)) return fail(PHM_ERR_BAD_INPUT, "B = I + Q/Omega must be non-negative");
-      B2[i * n + j] = b;
-      Bc[i * n + j] = (model->variant == PHM_MCMC_SPARSE) ? (b > 1e-7 ? b : 0.0) : b;            // matTospmat :811
-    }
+    pidv[i] = model->pid[i];
+    if (!(pidv[i] >= 0.0) || !std::isfinite(pidv[i])) return fail(PHM_ERR_BAD_INPUT, "pid must be non-negative");
   }
+  double *B2 = B2v.data(), *Bc = Bcv.data(), *scale = scalev.data(), *pid = pidv.data();
 
   phm_engine* e = new phm_engine();
   std::unique_ptr<phm_engine> guard(e);
   e->n = n; e->cols = n + n * (n - 1); e->variant = model->variant;
   e->dcols = e->cols;
   e->wide = n > 4;
-  if (e->variant == PHM_MCMC_KS) {
-    const int k = n / 2 - 1;
-    e->cols = n + n * n + 2 + 3 * k + 1;
+  if (e->variant == PHM_MCMC_KS || e->variant == PHM_MCMC_BF) {
+    const int k = (e->variant == PHM_MCMC_KS) ? n / 2 - 1 : 0;
+    e->cols = n + n * n + 2 + 3 * k + 1;        // man/sumstatMCMCks.Rd:19; bf: src/phylomap.cpp:1293
     e->dcols = n + n * n + 1;
-    auto Qe = [&](int i, int j) { return model->Q[i + (size_t)j * n]; };
-    e->qparams.push_back(Qe(0, 1));
-    e->qparams.push_back(Qe(1, 0));
-    for (int i = 0; i < k; ++i) e->qparams.push_back(Qe(2 * i, 2 * i + 2));
-    for (int i = 0; i < k; ++i) e->qparams.push_back(Qe(2 * i + 2, 2 * i));
-    for (int i = 0; i < k; ++i) e->qparams.push_back(Qe(2 * (i + 1), 2 * (i + 1) + 1) / Qe(0, 1));
   }
+  e->qparams = qp;
+  e->Omega = model->Omega;
+  e->hB2 = B2v; e->hBc = Bcv; e->hscale = scalev; e->hpid = pidv;
   e->S = o.n_replicas; e->tiles = (e->S + 63) / 64; e->S_pad = e->tiles * 64;
   e->max_iters = max_iters; e->reduce = o.reduce ? 1 : 0;
   e->ipl = o.iters_per_launch > 0 ? o.iters_per_launch : 8;
@@ -293,20 +354,8 @@ int32_t phm_engine_create(const phm_tree* x, const phm_model* model, const phm_o
 
   std::vector<double> col, row;
   const int ktab = e->wide ? phm::WIDE_KTAB : phm::MCMC_KTAB;
-  build_chain_tables(Bc, n, ktab, col, row);
-  std::vector<double> maskpow((size_t)ktab * 2 * n, 0.0);      // ks: Bc^k applied to the even / odd state masks (:1838-1845)
-  for (int par = 0; par < 2; ++par) {
-    for (int c = 0; c < n; ++c) maskpow[(size_t)par * n + c] = ((c & 1) == par) ? 1.0 : 0.0;
-    for (int k = 1; k < ktab; ++k) {
-      const double* v = &maskpow[((size_t)(k - 1) * 2 + par) * n];
-      double* y = &maskpow[((size_t)k * 2 + par) * n];
-      for (int i = 0; i < n; ++i) {
-        double acc = Bc[i * n] * v[0];
-        for (int c = 1; c < n; ++c) acc += Bc[i * n + c] * v[c];
-        y[i] = acc;
-      }
-    }
-  }
+  col.assign((size_t)ktab * n * n, 0.0); row.assign((size_t)ktab * n * n, 0.0);     // sizes only; filled by upload_model
+  std::vector<double> maskpow((size_t)ktab * 2 * n, 0.0);
 
   const size_t stats_bytes = e->reduce ? sizeof(double) * (size_t)max_iters * e->tiles * e->dcols
                                                      : sizeof(double) * (size_t)max_iters * e->dcols * e->S_pad;
@@ -325,7 +374,7 @@ int32_t phm_engine_create(const phm_tree* x, const phm_model* model, const phm_o
   HIPCHK(e->d_col.alloc(sizeof(double) * col.size()));
   HIPCHK(e->d_row.alloc(sizeof(double) * row.size()));
   HIPCHK(e->d_mask.alloc(sizeof(double) * maskpow.size()));
-  HIPCHK(hipMemcpy(e->d_mask.p, maskpow.data(), e->d_mask.bytes, hipMemcpyHostToDevice));
+
   HIPCHK(e->d_tips.alloc(e->tips_host.size()));
   HIPCHK(e->d_mcount.alloc(sizeof(uint16_t) * (size_t)e->tiles * E * 64));
   HIPCHK(e->d_dw0.alloc(dw_bytes));
@@ -341,8 +390,6 @@ int32_t phm_engine_create(const phm_tree* x, const phm_model* model, const phm_o
 
   HIPCHK(hipMemcpy(e->d_up.p, s.up.data(), e->d_up.bytes, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(e->d_down.p, s.down.data(), e->d_down.bytes, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(e->d_col.p, col.data(), e->d_col.bytes, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(e->d_row.p, row.data(), e->d_row.bytes, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(e->d_tips.p, e->tips_host.data(), e->tips_host.size(), hipMemcpyHostToDevice));
   HIPCHK(hipMemset(e->d_err.p, 0, sizeof(uint32_t)));
   HIPCHK(hipMemset(e->d_seg.p, 0, sizeof(unsigned long long)));
@@ -372,8 +419,8 @@ int32_t phm_engine_create(const phm_tree* x, const phm_model* model, const phm_o
     phm::WideParams& p = e->pw;
     p.n_states = n; p.n_tips = s.n_tips; p.n_node = s.n_node; p.n_edge = s.n_edge; p.root = s.root;
     p.n_tiles = e->tiles; p.n_rep = e->S; p.n_rep_pad = e->S_pad; p.replica_offset = o.replica_offset;
-    p.normalise = (e->variant == PHM_MCMC_BIGTREE || e->variant == PHM_MCMC_KS); p.tips_per_replica = e->tips_per_replica ? 1 : 0;
-    p.reduce = e->reduce; p.n_cols = e->dcols; p.ktab = phm::WIDE_KTAB; p.sparse = (e->variant == PHM_MCMC_SPARSE); p.ks = (e->variant == PHM_MCMC_KS); p.count_self = p.ks;
+    p.normalise = (e->variant == PHM_MCMC_BIGTREE || e->variant == PHM_MCMC_KS || e->variant == PHM_MCMC_BF); p.tips_per_replica = e->tips_per_replica ? 1 : 0;
+    p.reduce = e->reduce; p.n_cols = e->dcols; p.ktab = phm::WIDE_KTAB; p.sparse = (e->variant == PHM_MCMC_SPARSE); p.ks = (e->variant == PHM_MCMC_KS || e->variant == PHM_MCMC_BF); p.count_self = p.ks; p.tip_masks = (e->variant == PHM_MCMC_KS);
     p.maskpow = e->d_mask.as<double>();
     p.seed_lo = (uint32_t)(o.seed & 0xFFFFFFFFull); p.seed_hi = (uint32_t)(o.seed >> 32);
     p.rows = e->rows;
@@ -388,6 +435,8 @@ int32_t phm_engine_create(const phm_tree* x, const phm_model* model, const phm_o
   if (n == 2) fill_params<2>(e, e->p2, B2, Bc, scale, pid, o);
   if (n == 3) fill_params<3>(e, e->p3, B2, Bc, scale, pid, o);
   if (n == 4) fill_params<4>(e, e->p4, B2, Bc, scale, pid, o);
+  st = upload_model(e);
+  if (st) return st;
   HIPCHK(hipEventCreate(&e->ev0));
   HIPCHK(hipEventCreate(&e->ev1));
   *out = guard.release();
@@ -413,6 +462,7 @@ int32_t phm_engine_run(phm_engine* e, int32_t n_iters, void* hip_stream) {
     ++launches;
   }
   HIPCHK(hipEventRecord(e->ev1, stream));
+  for (int i = 0; i < n_iters; ++i) e->qhist.push_back(e->qparams);      // recordQ / recordQks at the start of each sweep
   e->iters_done += n_iters;
   e->last_stream = stream;
   e->timing_pending = true;
@@ -448,8 +498,10 @@ int32_t phm_engine_read_stats(phm_engine* e, int32_t iter0, int32_t n, double* o
   auto out_col = [&](int dc) { return (dcols != cols && dc == dcols - 1) ? cols - 1 : dc; };
   auto fill_params = [&](double* mat) {      // mat: n x cols column-major
     if (dcols == cols) return;
-    for (size_t q = 0; q < e->qparams.size(); ++q)
-      for (int i = 0; i < n; ++i) mat[(size_t)(dcols - 1 + q) * n + i] = e->qparams[q];
+    for (int i = 0; i < n; ++i) {
+      const std::vector<double>& qp = e->qhist[iter0 + i];
+      for (size_t q = 0; q < qp.size(); ++q) mat[(size_t)(dcols - 1 + q) * n + i] = qp[q];
+    }
   };
   if (e->reduce) {
     HIPCHK(phm::launch_stats_reduce(e->d_stats.as<double>() + (size_t)iter0 * e->tiles * dcols, n, e->tiles, dcols,
@@ -828,4 +880,17 @@ extern "C" int32_t phm_tree_orders(int32_t n_tips, int32_t n_edge, const int32_t
   std::string serr;
   if (!phm::pruningwise_orders(n_tips, n_edge, edge, nen, nodelist, root, serr)) return fail(PHM_ERR_BAD_INPUT, serr);
   return PHM_OK;
+}
+
+// Replace the rate matrix between sweeps (the Q-updating variants edit Q and B after every iteration,
+// src/phylomap.cpp:1212-1217, :1862-1866).  Q column-major; B = I + Q/Omega is recomputed.  The chain state is kept.
+extern "C" int32_t phm_engine_set_model(phm_engine* e, const double* Q) {
+  if (!e || !Q) return fail(PHM_ERR_STATE, "engine/Q is NULL");
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipStreamSynchronize(e->last_stream));
+  std::vector<double> B2, Bc, scale, qp;
+  int32_t st = compute_model(e->variant, e->n, Q, nullptr, e->Omega, B2, Bc, scale, qp);
+  if (st) return st;
+  e->hB2 = B2; e->hBc = Bc; e->hscale = scale; e->qparams = qp;
+  return upload_model(e);
 }

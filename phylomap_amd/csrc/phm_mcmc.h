@@ -19,7 +19,8 @@ struct McmcParams {
   int32_t n_tiles, n_rep, n_rep_pad, replica_offset;
   int32_t normalise, tips_per_replica, reduce, n_cols;
   int32_t ktab;
-  int32_t ks;                                // 1: sumstatMCMCks tree sweep (parity tip masks, n x n counts, root column)
+  int32_t ks;                                // 1: bf/ks layout: n x n counts incl. self pairs (shortenerbf), root-state column
+  int32_t tip_masks;                         // 1 (ks): tips observed up to parity and re-sampled; 0 (bf): tips observed
   int32_t prune_only;                        // measurement aid: run only the pruning (up) sweep of each iteration
   uint32_t seed_lo, seed_hi;
   int64_t rows;                              // capacity (64-lane rows) of one tile's dwell stream

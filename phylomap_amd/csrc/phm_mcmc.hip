@@ -57,7 +57,7 @@ __device__ __forceinline__ void child_vector(const McmcParams<NS>& p, const doub
     int tip = ~child;
     int st = p.tips_per_replica ? tips_t[tip * 64 + lane] : p.tips[tip];
     int kt = k < p.ktab ? k : p.ktab - 1;
-    const double* src = KS ? s_mask + (kt * 2 + (st & 1)) * NS : s_col + (kt * NS + st) * NS;
+    const double* src = (KS && p.tip_masks) ? s_mask + (kt * 2 + (st & 1)) * NS : s_col + (kt * NS + st) * NS;
 #pragma unroll
     for (int c = 0; c < NS; ++c) v[c] = src[c];
     for (int i = kt; i < k; ++i) matvec_u<NS>(p.Bc, v);
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(MCMC_BLOCK, 5) void mcmc_sweep_kernel(McmcParams<NS
   double* s_mask = reinterpret_cast<double*>(reinterpret_cast<uint32_t*>(s_scale + NS + (size_t)(MCMC_BLOCK / 64) * NS * 64) +
                                              (size_t)(MCMC_BLOCK / 64) * NS * NS * 64);   // [ktab][2][NS] (ks only)
   for (int i = threadIdx.x; i < p.ktab * NS * NS; i += MCMC_BLOCK) { s_col[i] = p.colpow[i]; s_row[i] = p.rowpow[i]; }
-  if (KS) for (int i = threadIdx.x; i < p.ktab * 2 * NS; i += MCMC_BLOCK) s_mask[i] = p.maskpow[i];
+  if (KS && p.tip_masks) for (int i = threadIdx.x; i < p.ktab * 2 * NS; i += MCMC_BLOCK) s_mask[i] = p.maskpow[i];
   if (threadIdx.x < NS * NS) s_B2[threadIdx.x] = p.B2[threadIdx.x];
   if (threadIdx.x < NS) s_scale[threadIdx.x] = p.scale[threadIdx.x];
   __syncthreads();
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(MCMC_BLOCK, 5) void mcmc_sweep_kernel(McmcParams<NS
       const int m = mct[b * 64 + lane];
       const int ps = nst[ds.parent * 64 + lane];
       int cs;
-      if (ds.child >= 0 || KS) {
+      if (ds.child >= 0 || (KS && p.tip_masks)) {
         // child ~ e_ps^T B^(m-1) (.) PL[child]   (Tvmmp :431-436, :651); ks: tips too, against their mask (:1384-1397)
         double w[NS];
         int kk = m - 1;

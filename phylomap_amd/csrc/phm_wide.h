@@ -21,7 +21,8 @@ struct WideParams {
   int32_t n_tiles, n_rep, n_rep_pad, replica_offset;
   int32_t normalise, tips_per_replica, reduce, n_cols, ktab;
   int32_t sparse;                            // 1: Bc != B2 (SPARSE variant), both staged in LDS
-  int32_t ks;                                // 1: sumstatMCMCks tree sweep (tip masks, tips re-sampled, root column)
+  int32_t ks;                                // 1: bf/ks layout (n x n counts incl. self pairs, root-state column)
+  int32_t tip_masks;                         // 1 (ks): parity tip masks, tips re-sampled
   int32_t count_self;                        // 1: n x n transition counts incl. self pairs (shortenerbf :1010-1014)
   uint32_t seed_lo, seed_hi;
   int64_t rows;

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) void mcmc_wide_kernel(WideParams p, int
     int done;
     if (child < 0) {
       int kt = k < p.ktab ? k : p.ktab - 1;
-      v = p.ks ? p.maskpow[((size_t)kt * 2 + (tipstate_r & 1)) * n + c] : p.colpow[((size_t)kt * n + tipstate_r) * n + c];
+      v = p.tip_masks ? p.maskpow[((size_t)kt * 2 + (tipstate_r & 1)) * n + c] : p.colpow[((size_t)kt * n + tipstate_r) * n + c];
       done = kt;
     } else {
       v = PLt[((size_t)child * 64 + r) * n + c];
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) void mcmc_wide_kernel(WideParams p, int
         const int mr = __builtin_amdgcn_readlane(m, r);
         const int psr = __builtin_amdgcn_readlane(ps, r);
         int csr;
-        if (ds.child >= 0 || p.ks) {
+        if (ds.child >= 0 || p.tip_masks) {
           // child ~ e_ps^T B^(m-1) (.) PL[child]     (Tvmmp :431-436, :651-655)
           int kk = mr - 1;
           int kt = kk < p.ktab ? kk : p.ktab - 1;
