@@ -52,7 +52,7 @@ typedef enum phm_variant {
                                  consecutive state pairs counted into n x n counters (shortenerbf :1010-1014).  Result layout
                                  man/sumstatMCMCks.Rd:19: N x (n + n*n + 2 + 3k + 1): dwell, counts (row-major from,to),
                                  l01, l10, rkappas, lkappas, gammas (recordQks :1789-1798), root state (0-based).
-                                 The per-iteration Gibbs/MH updates of Q (:1862-1866) are host glue that is not built yet. */
+                                 The per-iteration Gibbs/MH updates of Q (:1862-1866) run in phm_maketreelistMCMCks. */
   ,
   PHM_MCMC_BF = 4             /* tree sweep of maketreelistMCMCbf (treesamplebf :1169-1179): two states, tips observed, n x n counts
                                  incl. self pairs, layout time0,time1,n00,n01,n10,n11,l01,l10,root_state (R/sumstatMCMCbf.R:33) */
@@ -135,11 +135,31 @@ int32_t phm_maketreelistMCMCks_sweep( /* src/phylomap.cpp:1802 minus the Q updat
     const phm_tree* x, int32_t n_states, const double* Q, const double* pid, const double* B, double Omega,
     const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
     const phm_options* opt, double* out);
+/* The Q-updating drivers: tree sweep on the device + Gibbs/MH update of the rate matrix on the host, every iteration.
+ * bf: two states, prior = c(a01,b01,a10,b10), out N x 9 (R/sumstatMCMCbf.R:33).  ks: n = 2k+2 >= 4,
+ * prior = c(a_l,b_l,a_k,b_k,a_g,b_g), out N x (n+n*n+2+3k+1) (man/sumstatMCMCks.Rd:19).  Inputs are never written
+ * (the reference edits the caller's Q and B in place, src/phylomap.cpp:1212-1217).  Gamma variates: Marsaglia-Tsang on the
+ * Philox stream (R's Rf_rgamma is third-party code).  With S > 1 replicas (sites sharing Q) the updates see, and `out`
+ * holds, the statistics summed over sites. */
+int32_t phm_maketreelistMCMCbf(       /* src/phylomap.cpp:1258, src/RcppExports.cpp:106 */
+    const phm_tree* x, int32_t n_states, const double* Q, const double* pid, const double* B, double Omega,
+    const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N, const double* prior, int32_t n_prior,
+    const phm_options* opt, double* out);
+int32_t phm_maketreelistMCMCks(       /* src/phylomap.cpp:1802, src/RcppExports.cpp:132 */
+    const phm_tree* x, int32_t n_states, const double* Q, const double* pid, const double* B, double Omega,
+    const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N, const double* prior, int32_t n_prior,
+    const phm_options* opt, double* out);
 int32_t phm_maketreelistEXP(          /* src/phylomap.cpp:3001, src/RcppExports.cpp:80 */
     const phm_tree* x, int32_t n_states, const double* Q, const double* pid,
     const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
     const double* lefts, const double* rights, const double* d,
     const phm_options* opt, double* out);
+
+/* ---- host-side rate-matrix update of the Q-updating variants (no device needed) ----
+ * One iteration of updatel01/l10 (bf) or updateksl01/l10, updaterkappas, updatelkappas, updategammas (ks) applied to Q
+ * (column-major, edited in place) given a statistics row: n dwell sums then n*n counts, row-major (from,to). */
+int32_t phm_qupdate_apply(int32_t variant, int32_t n_states, double* Q, double Omega, const double* prior, int32_t n_prior,
+                          const double* row, uint64_t seed, uint32_t iter);
 
 /* ---- host-side traversal orders (no device needed) ----
  * O(E) native replacement of the R helper preamble pruningwiseedgeorder / makenodelist / myreorder

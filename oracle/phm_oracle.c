@@ -436,8 +436,8 @@ static void sampleinternalnodesMCMC(Branch* brs, int E, double* PL, const double
     rm[cn] = sample_cat(p, n, draw_u(rc, iter, ENT_NODE | (uint32_t)cn, 0), &rc->err);   /* :655 */
   }
   if (ks) {
-    *root_out = (double)rm[root - 1];                                        /* :1350-1352, 0-based */
-    for (int i = 0; i < E; ++i) {                                            /* tips "don't remain the same" :1384-1397 */
+    *root_out = (double)rm[root - 1];                                        /* :1350-1352 / :1123, 0-based */
+    for (int i = 0; i < E && ks == 1; ++i) {                                 /* ks: tips "don't remain the same" :1384-1397 */
       if (edge2[i] <= T) {
         int cn = edge2[i] - 1, ps = rm[edge1[i] - 1];
         for (int c = 0; c < n; ++c) vecc[c] = 0.0;
@@ -471,18 +471,193 @@ static void fill_dump(orc_dump* dump, const Branch* brs, int E, const int32_t* r
   if (dump->PL && PL) memcpy(dump->PL, PL, sizeof(double) * pl_len);
 }
 
-int orc_maketreelistMCMC(const orc_tree* x, int n, const double* Q_cm, const double* pid,
+
+/* ------------------------------------------------------------------------------------------ */
+/* Rate-matrix updates of the Q-updating variants (host-side scalar work, one call per sweep)   */
+/* ------------------------------------------------------------------------------------------ */
+/* Host draws use the Philox stream (replica word 0xFFFFFFFF, entity 0xFFFFFF00 | update id); Rf_rgamma is R's
+ * Ahrens-Dieter generator, which is third-party code outside /root/reference, so the gamma variate is
+ * Marsaglia & Tsang (2000) with a Box-Muller normal -- same distribution, different stream. */
+typedef struct { rngctx* rc; uint32_t iter; uint32_t ent; uint32_t d; } hstream;
+static double hs_u(hstream* h) {
+  orc_rng* r = h->rc->r;
+  if (r->mode == 1) return draw_u(h->rc, h->iter, h->ent, h->d++);
+  return orc_stream_u(r->seed_lo, r->seed_hi, 0xFFFFFFFFu, h->iter, h->ent, h->d++);
+}
+static double hs_rgamma(hstream* h, double a, double scale) {
+  double boost = 1.0;
+  if (a < 1.0) { double u = hs_u(h); boost = pow(u, 1.0 / a); a += 1.0; }
+  const double d = a - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+  for (;;) {
+    double u1 = hs_u(h), u2 = hs_u(h);
+    double xn = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+    double v = 1.0 + c * xn;
+    if (v <= 0.0) continue;
+    v = v * v * v;
+    double u = hs_u(h);
+    if (log(u) < 0.5 * xn * xn + d - d * v + d * log(v)) return d * v * boost * scale;
+  }
+}
+
+#define QQ(i, j) Q[(size_t)(i) * n + (j)]
+#define TC(idx) stats[(int64_t)(n + (idx)) * stride + it]      /* transitioncounts(idx) = dwelltimes(iteration, n+idx) */
+#define SJ(i) stats[(int64_t)(i) * stride + it]                /* sojourntimes(i) */
+
+/* updatel01 / updatel10, src/phylomap.cpp:1189-1253 (two states; `accept` is computed and never tested there) */
+static void updatel01(double* Q, int n, double Omega, const double* prior, const double* stats, int64_t stride, int it, hstream* h) {
+  int n01 = (int)stats[(int64_t)3 * stride + it];
+  double t0 = stats[(int64_t)0 * stride + it];
+  double newl01 = hs_rgamma(h, prior[0] + n01, 1 / (prior[1] + t0));       /* :1202 */
+  if (newl01 > Omega) return;                                             /* :1205 */
+  (void)hs_u(h);                                                          /* compare, :1210 (unused) */
+  QQ(0, 0) = -newl01; QQ(0, 1) = newl01;                                  /* :1212-1213 */
+}
+static void updatel10(double* Q, int n, double Omega, const double* prior, const double* stats, int64_t stride, int it, hstream* h) {
+  int n10 = (int)stats[(int64_t)4 * stride + it];
+  double t1 = stats[(int64_t)1 * stride + it];
+  double newl10 = hs_rgamma(h, prior[2] + n10, 1 / (prior[3] + t1));       /* :1235 */
+  if (newl10 > Omega) return;
+  (void)hs_u(h);
+  QQ(1, 0) = newl10; QQ(1, 1) = -newl10;                                  /* :1244-1245 */
+}
+
+/* parameters as every ks update re-reads them from Q (e.g. :1441-1450) */
+static void ks_params(const double* Q, int n, int k, double* lambdas, double* rk, double* lk, double* gm) {
+  lambdas[0] = QQ(0, 1); lambdas[1] = QQ(1, 0);
+  for (int i = 0; i < k; ++i) rk[i] = QQ(2 * i, 2 * i + 2);
+  for (int i = 0; i < k; ++i) lk[i] = QQ(2 * i + 2, 2 * i);
+  gm[0] = 1;
+  for (int i = 1; i <= k; ++i) gm[i] = QQ(2 * i, 2 * i + 1) / lambdas[0];
+}
+
+/* updateksl01 :1435-1505 (side = 0) and updateksl10 :1509-1578 (side = 1) */
+static void updateksl(int side, double* Q, int n, double Omega, const double* prior, const double* stats, int64_t stride, int it, hstream* h) {
+  int k = n / 2 - 1, i;
+  double lambdas[2], rk[32], lk[32], gm[33];
+  ks_params(Q, n, k, lambdas, rk, lk, gm);
+  double alphaprime = prior[0];
+  for (i = 0; i <= k; ++i) alphaprime = alphaprime + (side == 0 ? TC(2 * i * n + 2 * i + 1) : TC((2 * i + 1) * n + 2 * i));
+  double betaprime = prior[1];
+  for (i = 0; i <= k; ++i) betaprime = betaprime + gm[i] * SJ(2 * i + side);
+  double newl = hs_rgamma(h, alphaprime, 1 / betaprime);
+  double old = lambdas[side];
+  double gammatimes = betaprime - prior[1];
+  double logaccept = (newl - old) * gammatimes;
+  logaccept = logaccept + (side == 0 ? TC(0) : TC(n + 1)) * log((Omega - rk[0] - gm[0] * newl) / (Omega - rk[0] - gm[0] * old));
+  for (i = 1; i < k; ++i)
+    logaccept = logaccept + (side == 0 ? TC(2 * i * n + 2 * i) : TC((2 * i + 1) * n + 2 * i + 1)) *
+                log((Omega - rk[i] - lk[i - 1] - gm[i] * newl) / (Omega - rk[i] - lk[i - 1] - gm[i] * old));
+  logaccept = logaccept + (side == 0 ? TC(2 * k * n + 2 * k) : TC((2 * k + 1) * n + 2 * k + 1)) *
+              log((Omega - lk[k - 1] - gm[k] * newl) / (Omega - lk[k - 1] - gm[k] * old));
+  double compare = hs_u(h);
+  if (newl + rk[0] > Omega) return;
+  for (i = 1; i < k; ++i) if (gm[i] * newl + rk[i] + lk[i - 1] > Omega) return;
+  if (gm[k] * newl + lk[k - 1] > Omega) return;
+  if (newl < 1e-300) return;
+  if (logaccept < log(compare)) return;
+  int a = side, b = 1 - side;                                              /* row a, column b of each 2x2 block */
+  QQ(a, a) = -rk[0] - gm[0] * newl; QQ(a, b) = gm[0] * newl;
+  for (i = 1; i < k; ++i) { QQ(2 * i + a, 2 * i + a) = -lk[i - 1] - rk[i] - gm[i] * newl; QQ(2 * i + a, 2 * i + b) = gm[i] * newl; }
+  QQ(2 * k + a, 2 * k + a) = -lk[k - 1] - gm[k] * newl; QQ(2 * k + a, 2 * k + b) = gm[k] * newl;
+}
+
+/* updaterkappas :1582-1644 */
+static void updaterkappas(double* Q, int n, double Omega, const double* prior, const double* stats, int64_t stride, int it, hstream* h, int j) {
+  int k = n / 2 - 1;
+  double lambdas[2], rk[32], lk[32], gm[33];
+  ks_params(Q, n, k, lambdas, rk, lk, gm);
+  double alphaprime = prior[2] + TC((2 * j) * n + 2 * j + 2) + TC((2 * j + 1) * n + 2 * j + 3);
+  double betaprime = prior[3] + SJ(2 * j) + SJ(2 * j + 1);
+  double nw = hs_rgamma(h, alphaprime, 1 / betaprime);
+  double logaccept = (nw - rk[j]) * (SJ(2 * j) + SJ(2 * j + 1));
+  double lkp = (j > 0) ? lk[j - 1] : 0.0;
+  if (j == 0) {
+    logaccept = logaccept + TC((2 * j) * n + 2 * j) * log((Omega - nw - gm[j] * lambdas[0]) / (Omega - rk[j] - gm[j] * lambdas[0]));
+    logaccept = logaccept + TC((2 * j + 1) * n + 2 * j + 1) * log((Omega - nw - gm[j] * lambdas[1]) / (Omega - rk[j] - gm[j] * lambdas[1]));
+  } else {
+    logaccept = logaccept + TC((2 * j) * n + 2 * j) * log((Omega - lk[j - 1] - nw - gm[j] * lambdas[0]) / (Omega - lk[j - 1] - rk[j] - gm[j] * lambdas[0]));
+    logaccept = logaccept + TC((2 * j + 1) * n + 2 * j + 1) * log((Omega - lk[j - 1] - nw - gm[j] * lambdas[1]) / (Omega - lk[j - 1] - rk[j] - gm[j] * lambdas[1]));
+  }
+  double compare = hs_u(h);
+  if (j == 0) { if (nw + gm[j] * lambdas[0] > Omega) return; if (nw + gm[j] * lambdas[1] > Omega) return; }
+  else { if (nw + gm[j] * lambdas[0] + lk[j - 1] > Omega) return; if (nw + gm[j] * lambdas[1] + lk[j - 1] > Omega) return; }
+  if (nw < 1e-300) return;
+  if (logaccept < log(compare)) return;
+  QQ(2 * j, 2 * j + 2) = nw; QQ(2 * j + 1, 2 * j + 3) = nw;
+  if (j == 0) { QQ(0, 0) = -nw - gm[j] * lambdas[0]; QQ(1, 1) = -nw - gm[j] * lambdas[1]; }
+  else { QQ(2 * j, 2 * j) = -nw - lkp - gm[j] * lambdas[0]; QQ(2 * j + 1, 2 * j + 1) = -nw - lkp - gm[j] * lambdas[1]; }
+}
+
+/* updatelkappas :1648-1710 */
+static void updatelkappas(double* Q, int n, double Omega, const double* prior, const double* stats, int64_t stride, int it, hstream* h, int j) {
+  int k = n / 2 - 1;
+  double lambdas[2], rk[32], lk[32], gm[33];
+  ks_params(Q, n, k, lambdas, rk, lk, gm);
+  double alphaprime = prior[2] + TC((2 * j) * n + 2 * j - 2) + TC((2 * j + 1) * n + 2 * j - 1);
+  double betaprime = prior[3] + SJ(2 * j) + SJ(2 * j + 1);
+  double nw = hs_rgamma(h, alphaprime, 1 / betaprime);
+  double logaccept = (nw - lk[j - 1]) * (SJ(2 * j) + SJ(2 * j + 1));
+  if (j == k) {
+    logaccept = logaccept + TC((2 * j) * n + 2 * j) * log((Omega - nw - gm[j] * lambdas[0]) / (Omega - lk[j - 1] - gm[j] * lambdas[0]));
+    logaccept = logaccept + TC((2 * j + 1) * n + 2 * j + 1) * log((Omega - nw - gm[j] * lambdas[1]) / (Omega - lk[j - 1] - gm[j] * lambdas[1]));
+  } else {
+    logaccept = logaccept + TC((2 * j) * n + 2 * j) * log((Omega - rk[j] - nw - gm[j] * lambdas[0]) / (Omega - rk[j] - lk[j - 1] - gm[j] * lambdas[0]));
+    logaccept = logaccept + TC((2 * j + 1) * n + 2 * j + 1) * log((Omega - rk[j] - nw - gm[j] * lambdas[1]) / (Omega - rk[j] - lk[j - 1] - gm[j] * lambdas[1]));
+  }
+  double compare = hs_u(h);
+  if (j == k) { if (nw + gm[j] * lambdas[0] > Omega) return; if (nw + gm[j] * lambdas[1] > Omega) return; }
+  else { if (nw + gm[j] * lambdas[0] + rk[j] > Omega) return; if (nw + gm[j] * lambdas[1] + rk[j] > Omega) return; }
+  if (nw < 1e-300) return;
+  if (logaccept < log(compare)) return;
+  QQ(2 * j, 2 * j - 2) = nw; QQ(2 * j + 1, 2 * j - 1) = nw;
+  if (j == k) { QQ(2 * j, 2 * j) = -nw - gm[j] * lambdas[0]; QQ(2 * j + 1, 2 * j + 1) = -nw - gm[j] * lambdas[1]; }
+  else { QQ(2 * j, 2 * j) = -nw - rk[j] - gm[j] * lambdas[0]; QQ(2 * j + 1, 2 * j + 1) = -nw - rk[j] - gm[j] * lambdas[1]; }
+}
+
+/* updategammas :1714-1785 */
+static void updategammas(double* Q, int n, double Omega, const double* prior, const double* stats, int64_t stride, int it, hstream* h, int j) {
+  int k = n / 2 - 1;
+  double lambdas[2], rk[32], lk[32], gm[33];
+  ks_params(Q, n, k, lambdas, rk, lk, gm);
+  double alphaprime = prior[4] + TC((2 * j) * n + 2 * j + 1) + TC((2 * j + 1) * n + 2 * j);
+  double betaprime = prior[5] + SJ(2 * j) * lambdas[0] + SJ(2 * j + 1) * lambdas[1];
+  double nw = hs_rgamma(h, alphaprime, 1 / betaprime);
+  double logaccept = (nw - gm[j]) * (SJ(2 * j) * lambdas[0] + SJ(2 * j + 1) * lambdas[1]);
+  if (j == k) {
+    logaccept = logaccept + TC((2 * j) * n + 2 * j) * log((Omega - lk[j - 1] - nw * lambdas[0]) / (Omega - lk[j - 1] - gm[j] * lambdas[0]));
+    logaccept = logaccept + TC((2 * j + 1) * n + 2 * j + 1) * log((Omega - lk[j - 1] - nw * lambdas[1]) / (Omega - lk[j - 1] - gm[j] * lambdas[1]));
+  } else {
+    logaccept = logaccept + TC((2 * j) * n + 2 * j) * log((Omega - lk[j - 1] - rk[j] - nw * lambdas[0]) / (Omega - rk[j] - lk[j - 1] - gm[j] * lambdas[0]));
+    logaccept = logaccept + TC((2 * j + 1) * n + 2 * j + 1) * log((Omega - lk[j - 1] - rk[j] - nw * lambdas[1]) / (Omega - rk[j] - lk[j - 1] - gm[j] * lambdas[1]));
+  }
+  double compare = hs_u(h);
+  if (j == k) { if (lk[j - 1] + nw * lambdas[0] > Omega) return; if (lk[j - 1] + nw * lambdas[1] > Omega) return; }
+  else { if (lk[j - 1] + nw * lambdas[0] + rk[j] > Omega) return; if (lk[j - 1] + nw * lambdas[1] + rk[j] > Omega) return; }
+  if (nw < 1e-300) return;
+  if (logaccept < log(compare)) return;
+  QQ(2 * j, 2 * j + 1) = nw * lambdas[0]; QQ(2 * j + 1, 2 * j) = nw * lambdas[1];
+  if (j == k) { QQ(2 * j, 2 * j) = -lk[j - 1] - nw * lambdas[0]; QQ(2 * j + 1, 2 * j + 1) = -lk[j - 1] - nw * lambdas[1]; }
+  else { QQ(2 * j, 2 * j) = -lk[j - 1] - rk[j] - nw * lambdas[0]; QQ(2 * j + 1, 2 * j + 1) = -lk[j - 1] - rk[j] - nw * lambdas[1]; }
+}
+#undef TC
+#undef SJ
+
+static int mcmc_driver(const orc_tree* x, int n, const double* Q_cm, const double* pid,
                          const double* B_cm, double Omega, const int32_t* nen,
                          const int32_t* nodelist, int32_t root, int32_t N, int variant,
-                         int faithful_search, orc_rng* rng, double* out, orc_dump* dump) {
+                         int faithful_search, orc_rng* rng, double* out, orc_dump* dump, const double* prior) {
   int e = check_tree(x); if (e) return e;
   if (n < 2 || N < 0) return ORC_ERR_BAD_INPUT;
   int E = x->n_edge, T = x->n_tips, Nnode = x->n_node;
   const int32_t* edge1 = x->edge; const int32_t* edge2 = x->edge + E;
-  const int ks = (variant == ORC_MCMC_KS);
-  if (ks && (n & 1)) return ORC_ERR_BAD_INPUT;                /* hidden-rates structure: n = 2k+2 (:1820) */
-  const int kk = n / 2 - 1;
+  const int ks = (variant == ORC_MCMC_KS) ? 1 : (variant == ORC_MCMC_BF) ? 2 : 0;   /* 1: ks sweep, 2: bf sweep */
+  if (ks == 1 && (n & 1)) return ORC_ERR_BAD_INPUT;           /* hidden-rates structure: n = 2k+2 (:1820) */
+  if (ks == 2 && n != 2) return ORC_ERR_BAD_INPUT;            /* recordQ / updatel01 hard-wire two states (:1181-1185) */
+  if (prior && (!ks || (ks == 1 && n < 4) || n > 64)) return ORC_ERR_BAD_INPUT;
+  const int kk = (ks == 1) ? n / 2 - 1 : 0;
   int cols = ks ? n + n * n + 2 + 3 * kk + 1 : n + n * (n - 1);
+  double* Q = (double*)malloc(sizeof(double) * n * n);        /* row-major working copy; the updates edit it */
+  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) QQ(i, j) = Q_cm[i + (size_t)j * n];
   rngctx rc = { rng, 0 };
 
   double* B2 = (double*)malloc(sizeof(double) * n * n);       /* row-major copies */
@@ -501,7 +676,7 @@ int orc_maketreelistMCMC(const orc_tree* x, int n, const double* Q_cm, const dou
   }
   size_t pl_len = (size_t)(2 * Nnode + 1) * n;
   double* PL = (double*)calloc(pl_len, sizeof(double));
-  if (!ks) for (int i = 0; i < T; ++i) PL[(size_t)i * n + (x->states[i] - 1)] = 1.0;   /* :914 */
+  if (ks != 1) for (int i = 0; i < T; ++i) PL[(size_t)i * n + (x->states[i] - 1)] = 1.0;   /* :914 */
   else for (int i = 0; i < T; ++i)                            /* only the binary trait is observed :1838-1845 */
     for (int j = (x->states[i] % 2 == 0) ? 1 : 0; j < n; j += 2) PL[(size_t)i * n + j] = 1.0;
   int32_t* rm = (int32_t*)calloc(2 * T - 1, sizeof(int32_t));
@@ -515,14 +690,14 @@ int orc_maketreelistMCMC(const orc_tree* x, int n, const double* Q_cm, const dou
 
   if (!e) for (int it = 0; it < N; ++it) {
     double rootst = 0.0;
-    if (ks) {                                                 /* recordQks :1789-1798 (Q is row i, col j = Q_cm[i + j*n]) */
+    if (ks) {                                                 /* recordQks :1789-1798 / recordQ :1181-1185 */
       int base = n + n * n;
-      out[(int64_t)base * N + it] = Q_cm[0 + (size_t)1 * n];
-      out[(int64_t)(base + 1) * N + it] = Q_cm[1 + (size_t)0 * n];
+      out[(int64_t)base * N + it] = QQ(0, 1);
+      out[(int64_t)(base + 1) * N + it] = QQ(1, 0);
       for (int i = 0; i < kk; ++i) {
-        out[(int64_t)(base + 2 + i) * N + it] = Q_cm[(2 * i) + (size_t)(2 * i + 2) * n];
-        out[(int64_t)(base + 2 + kk + i) * N + it] = Q_cm[(2 * i + 2) + (size_t)(2 * i) * n];
-        out[(int64_t)(base + 2 + 2 * kk + i) * N + it] = Q_cm[(2 * (i + 1)) + (size_t)(2 * (i + 1) + 1) * n] / Q_cm[0 + (size_t)1 * n];
+        out[(int64_t)(base + 2 + i) * N + it] = QQ(2 * i, 2 * i + 2);
+        out[(int64_t)(base + 2 + kk + i) * N + it] = QQ(2 * i + 2, 2 * i);
+        out[(int64_t)(base + 2 + 2 * kk + i) * N + it] = QQ(2 * (i + 1), 2 * (i + 1) + 1) / QQ(0, 1);
       }
     }
     sampleinternalnodesMCMC(brs, E, PL, pid, Bc, root, nodelist, Nnode - 1, nen, edge1, edge2, Nnode,
@@ -532,12 +707,75 @@ int orc_maketreelistMCMC(const orc_tree* x, int n, const double* Q_cm, const dou
     for (int i = 0; i < E; ++i)                                                              /* :781 / :1428 */
       sampleabranch(&brs[i], Bc, B2, Omega, Qd, ks ? -n : n, out, N, it, &rc, (uint32_t)i, &scratch, &scratch_len, &tmp);
     for (int i = 0; i < E; ++i) updatedwelltimes(it, &brs[i], out, N);                       /* :782 */
+    if (prior) {                                              /* maketreelistMCMCbf :1299-1300 / maketreelistMCMCks :1862-1866 */
+      hstream h = { &rc, (uint32_t)it, 0, 0 };
+#define HS(id) (h.ent = 0xFFFFFF00u | (uint32_t)(id), h.d = 0, &h)
+      if (ks == 2) {
+        updatel01(Q, n, Omega, prior, out, N, it, HS(0));
+        updatel10(Q, n, Omega, prior, out, N, it, HS(1));
+      } else {
+        updateksl(0, Q, n, Omega, prior, out, N, it, HS(0));
+        updateksl(1, Q, n, Omega, prior, out, N, it, HS(1));
+        for (int j = 0; j < kk; ++j) updaterkappas(Q, n, Omega, prior, out, N, it, HS(2 + j), j);
+        for (int j = 1; j <= kk; ++j) updatelkappas(Q, n, Omega, prior, out, N, it, HS(2 + kk + j), j);
+        for (int j = 1; j <= kk; ++j) updategammas(Q, n, Omega, prior, out, N, it, HS(2 + 2 * kk + j), j);
+      }
+#undef HS
+      for (int i = 0; i < n; ++i) {                           /* B2 = I + Q/Omega entry by entry, as the updates write it */
+        Qd[i] = QQ(i, i);
+        for (int j = 0; j < n; ++j) B2[i * n + j] = (i == j) ? 1 + QQ(i, j) / Omega : QQ(i, j) / Omega;
+      }
+      memcpy(Bc, B2, sizeof(double) * n * n);
+    }
   }
+  free(Q);
   fill_dump(dump, brs, E, rm, 2 * T - 1, PL, pl_len);
   for (int i = 0; i < E; ++i) { free(brs[i].d); free(brs[i].s); }
   free(tmp.d); free(tmp.s); free(scratch); free(w); free(eoc); free(bl); free(rm); free(PL); free(brs);
   free(Qd); free(Bc); free(B2);
   return e | rc.err;
+}
+
+#undef QQ
+
+int orc_maketreelistMCMC(const orc_tree* x, int n, const double* Q_cm, const double* pid, const double* B_cm, double Omega,
+                         const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N, int variant,
+                         int faithful_search, orc_rng* rng, double* out, orc_dump* dump) {
+  return mcmc_driver(x, n, Q_cm, pid, B_cm, Omega, nen, nodelist, root, N, variant, faithful_search, rng, out, dump, NULL);
+}
+
+/* maketreelistMCMCbf :1258-1305 (variant ORC_MCMC_BF, prior = 4 numbers) and maketreelistMCMCks :1802-1872
+ * (variant ORC_MCMC_KS, prior = 6 numbers): the sweep followed by the rate-matrix updates, every iteration. */
+int orc_maketreelistMCMC_qupdate(const orc_tree* x, int n, const double* Q_cm, const double* pid, const double* B_cm,
+                                 double Omega, const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
+                                 int variant, const double* prior, int faithful_search, orc_rng* rng, double* out,
+                                 orc_dump* dump) {
+  if (!prior) return ORC_ERR_BAD_INPUT;
+  return mcmc_driver(x, n, Q_cm, pid, B_cm, Omega, nen, nodelist, root, N, variant, faithful_search, rng, out, dump, prior);
+}
+
+/* one iteration's updates applied to a row-major Q given a statistics row (test entry point) */
+int orc_qupdate_apply(int variant, int n, double* Q_rm, double Omega, const double* prior, const double* row,
+                      uint32_t seed_lo, uint32_t seed_hi, uint32_t iter) {
+  orc_rng r; memset(&r, 0, sizeof r); r.mode = 0; r.seed_lo = seed_lo; r.seed_hi = seed_hi;
+  rngctx rc = { &r, 0 };
+  hstream h = { &rc, iter, 0, 0 };
+  const int kk = n / 2 - 1;
+#define HS(id) (h.ent = 0xFFFFFF00u | (uint32_t)(id), h.d = 0, &h)
+  if (variant == ORC_MCMC_BF) {
+    if (n != 2) return ORC_ERR_BAD_INPUT;
+    updatel01(Q_rm, n, Omega, prior, row, 1, 0, HS(0));
+    updatel10(Q_rm, n, Omega, prior, row, 1, 0, HS(1));
+  } else if (variant == ORC_MCMC_KS) {
+    if (n < 4 || (n & 1) || n > 64) return ORC_ERR_BAD_INPUT;
+    updateksl(0, Q_rm, n, Omega, prior, row, 1, 0, HS(0));
+    updateksl(1, Q_rm, n, Omega, prior, row, 1, 0, HS(1));
+    for (int j = 0; j < kk; ++j) updaterkappas(Q_rm, n, Omega, prior, row, 1, 0, HS(2 + j), j);
+    for (int j = 1; j <= kk; ++j) updatelkappas(Q_rm, n, Omega, prior, row, 1, 0, HS(2 + kk + j), j);
+    for (int j = 1; j <= kk; ++j) updategammas(Q_rm, n, Omega, prior, row, 1, 0, HS(2 + 2 * kk + j), j);
+  } else return ORC_ERR_BAD_INPUT;
+#undef HS
+  return 0;
 }
 
 /* ------------------------------------------------------------------------------------------ */

@@ -40,6 +40,9 @@ extern "C" {
                                  shortenerbf counts :1010-1014, recordQks :1789-1798, root state :1350-1352;
                                  the Gibbs/MH updates of Q (:1862-1866) are NOT run.  out: N x (n+n*n+2+3k+1) */
 
+#define ORC_MCMC_BF       4   /* tree sweep of maketreelistMCMCbf src/phylomap.cpp:1258-1305 (two states, tips observed,
+                                 shortenerbf counts, columns l01 l10 root); out: N x 9 */
+
 /* RNG: mode 0 = counter-based Philox4x32-10 streams (the mode the GPU matches bit for bit);
  *      mode 1 = scripted tapes consumed in the reference's draw order (for hand KATs). */
 typedef struct orc_rng {
@@ -104,6 +107,15 @@ int orc_maketreelistMCMC(const orc_tree* x, int n, const double* Q_cm, const dou
                          const double* B_cm, double Omega, const int32_t* nen,
                          const int32_t* nodelist, int32_t root, int32_t N, int variant,
                          int faithful_search, orc_rng* rng, double* out_cm, orc_dump* dump);
+
+/* the Q-updating drivers: sweep + Gibbs/MH updates of the rate matrix each iteration (bf: prior[4], ks: prior[6]) */
+int orc_maketreelistMCMC_qupdate(const orc_tree* x, int n, const double* Q_cm, const double* pid, const double* B_cm,
+                                 double Omega, const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
+                                 int variant, const double* prior, int faithful_search, orc_rng* rng, double* out_cm,
+                                 orc_dump* dump);
+
+int orc_qupdate_apply(int variant, int n, double* Q_rm, double Omega, const double* prior, const double* row,
+                      uint32_t seed_lo, uint32_t seed_hi, uint32_t iter);
 
 /* maketreelistEXP src/phylomap.cpp:3001-3051. lefts/rights column-major, d = n x n col-major (diag used). */
 int orc_maketreelistEXP(const orc_tree* x, int n, const double* Q_cm, const double* pid,

@@ -13,12 +13,12 @@ LIB_PATH = os.environ.get("PHM_LIB", os.path.join(_HERE, "libphylomap_hip.so")) 
 PHM_OK = 0
 STATUS = {0: "PHM_OK", 1: "PHM_ERR_BAD_INPUT", 2: "PHM_ERR_UNSUPPORTED", 3: "PHM_ERR_NO_DEVICE", 4: "PHM_ERR_OOM",
           5: "PHM_ERR_ZERO_PROB", 6: "PHM_ERR_CAPACITY", 7: "PHM_ERR_UNIF_CAP", 8: "PHM_ERR_STATE"}
-PHM_MCMC, PHM_MCMC_BIGTREE, PHM_MCMC_SPARSE, PHM_MCMC_KS = 0, 1, 2, 3
+PHM_MCMC, PHM_MCMC_BIGTREE, PHM_MCMC_SPARSE, PHM_MCMC_KS, PHM_MCMC_BF = 0, 1, 2, 3, 4
 
 EXPORTS = [
     "phm_version", "phm_device_count", "phm_last_error", "phm_status_string",
     "phm_maketreelistMCMC", "phm_maketreelistMCMC_bigtree", "phm_SPARSEmaketreelistMCMC", "phm_maketreelistEXP",
-    "phm_maketreelistMCMCks_sweep",
+    "phm_maketreelistMCMCks_sweep", "phm_maketreelistMCMCbf", "phm_maketreelistMCMCks", "phm_engine_set_model", "phm_qupdate_apply",
     "phm_expm_eigen", "phm_expm_eigen_mfma", "phm_expm_pade", "phm_expm_pade_mfma",
     "phm_engine_create", "phm_engine_run", "phm_engine_sync", "phm_engine_read_stats", "phm_engine_dump",
     "phm_engine_info", "phm_engine_destroy", "phm_engine_reduced_stats_device",
@@ -98,6 +98,12 @@ def load():
         L.phm_maketreelistMCMC_bigtree.argtypes = mc
         L.phm_SPARSEmaketreelistMCMC.argtypes = mc
         L.phm_maketreelistMCMCks_sweep.argtypes = mc
+        mcq = mc[:10] + [C.POINTER(C.c_double), C.c_int32] + mc[10:]
+        L.phm_maketreelistMCMCbf.argtypes = mcq
+        L.phm_maketreelistMCMCks.argtypes = mcq
+        L.phm_engine_set_model.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        L.phm_qupdate_apply.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_double),
+                                        C.c_int32, C.POINTER(C.c_double), C.c_uint64, C.c_uint32]
         L.phm_maketreelistEXP.argtypes = [C.POINTER(Tree), C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                           C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, C.c_int32,
                                           C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
@@ -183,11 +189,18 @@ class Engine:
         self.cols = self.n + self.n * (self.n - 1)
         if int(variant) == PHM_MCMC_KS:
             self.cols = self.n + self.n * self.n + 2 + 3 * (self.n // 2 - 1) + 1
+        if int(variant) == PHM_MCMC_BF:
+            self.cols = 9
         self.S = max(1, int(self.opt.n_replicas))
         self.reduce = bool(self.opt.reduce)
 
     def run(self, n_iters, stream=None):
         check(load().phm_engine_run(self.h, int(n_iters), C.c_void_p(stream) if stream else None))
+
+    def set_model(self, Q):
+        """Replace the rate matrix between sweeps (B = I + Q/Omega is recomputed; the chain state is kept)."""
+        Qc = np.asfortranarray(np.asarray(Q, dtype=np.float64))
+        check(load().phm_engine_set_model(self.h, _p(Qc, C.c_double)))
 
     def sync(self):
         check(load().phm_engine_sync(self.h))

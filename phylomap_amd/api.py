@@ -66,6 +66,37 @@ def sumstatMCMCks_sweep(z, Q, pid, Omega, N, **opt):
     return _mcmc("phm_maketreelistMCMCks_sweep", z, Q, pid, Omega, N, **opt)
 
 
+def _qupdate(fn_name, z, Q, pid, Omega, N, prior, cols, **opt):
+    L = _lib.load()
+    Q = np.asfortranarray(np.asarray(Q, dtype=np.float64))
+    n = Q.shape[0]
+    nen, nodelist, root = _lib.tree_orders(z)
+    B = np.asfortranarray(np.eye(n) + Q / Omega)
+    pid = np.ascontiguousarray(pid, dtype=np.float64)
+    prior = np.ascontiguousarray(prior, dtype=np.float64)
+    ft = _lib.FlatTree(z)
+    o = _lib.make_options(**opt)
+    out = np.zeros((N, cols), order="F")
+    st = getattr(L, fn_name)(C.byref(ft.c), n, _lib._p(Q, C.c_double), _lib._p(pid, C.c_double), _lib._p(B, C.c_double),
+                             float(Omega), _lib._p(nen, C.c_int32), _lib._p(nodelist, C.c_int32), root, int(N),
+                             _lib._p(prior, C.c_double), int(prior.size), C.byref(o), _lib._p(out, C.c_double))
+    _lib.check(st)
+    return out
+
+
+def sumstatMCMCbf(z, Q, pid, Omega, N, prior, **opt):
+    """R/sumstatMCMCbf.R:19-35 -> phm_maketreelistMCMCbf: two-state model, rates re-drawn after every sweep.
+    Columns: time 0, time 1, n00, n01, n10, n11, l01, l10, root_state (R/sumstatMCMCbf.R:33).  ``Q`` is not modified."""
+    return _qupdate("phm_maketreelistMCMCbf", z, Q, pid, Omega, N, prior, 9, **opt)
+
+
+def sumstatMCMCks(z, Q, pid, Omega, N, prior, **opt):
+    """R/sumstatMCMCks.R:19-33 -> phm_maketreelistMCMCks: hidden-rates model with k regimes (n = 2k+2), all 2+3k rate
+    parameters updated after every sweep.  Layout man/sumstatMCMCks.Rd:19.  ``Q`` is not modified."""
+    n = np.asarray(Q).shape[0]
+    return _qupdate("phm_maketreelistMCMCks", z, Q, pid, Omega, N, prior, n + n * n + 2 + 3 * (n // 2 - 1) + 1, **opt)
+
+
 def eigen_decompose(Q):
     """R/sumstatEXP.R:26-29: lefts = eigen(Q)$vectors, rights = solve(lefts), d = diag(values) (real spectrum only)."""
     vals, vecs = np.linalg.eig(np.asarray(Q, dtype=np.float64))

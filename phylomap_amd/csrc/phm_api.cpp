@@ -18,6 +18,7 @@
 
 #include "phm_exp.h"
 #include "phm_mcmc.h"
+#include "phm_qupdate.h"
 #include "phm_sched.h"
 #include "phm_wide.h"
 
@@ -893,4 +894,73 @@ extern "C" int32_t phm_engine_set_model(phm_engine* e, const double* Q) {
   if (st) return st;
   e->hB2 = B2; e->hBc = Bc; e->hscale = scale; e->qparams = qp;
   return upload_model(e);
+}
+
+// ---- Q-updating drivers: sweep on the device, rate-matrix update on the host, every iteration ---------------------------
+// maketreelistMCMCbf src/phylomap.cpp:1258-1305 (R/sumstatMCMCbf.R) and maketreelistMCMCks :1802-1872 (R/sumstatMCMCks.R).
+// With opt->n_replicas = S > 1 the replicas are sites sharing one Q: the update sees the statistics summed over sites and
+// `out` holds those sums (S = 1 is the reference's semantics exactly).
+static int32_t run_qupdate(int variant, const phm_tree* x, int32_t n, const double* Q, const double* pid, const double* B,
+                           double Omega, const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
+                           const double* prior, int32_t n_prior, const phm_options* opt_in, double* out) {
+  if (!out || !prior || !Q) return fail(PHM_ERR_BAD_INPUT, "out/prior/Q is NULL");
+  if (N < 1) return fail(PHM_ERR_BAD_INPUT, "N must be >= 1");
+  const int need = (variant == PHM_MCMC_BF) ? 4 : 6;
+  if (n_prior < need) return fail(PHM_ERR_BAD_INPUT, variant == PHM_MCMC_BF ? "sumstatMCMCbf needs prior = c(a01, b01, a10, b10)" : "sumstatMCMCks needs prior = c(a_l, b_l, a_k, b_k, a_g, b_g)");
+  if (variant == PHM_MCMC_KS && (n < 4 || (n & 1))) return fail(PHM_ERR_BAD_INPUT, "sumstatMCMCks needs n = 2k+2 states with k >= 1 (src/phylomap.cpp:1820; updateksl01 reads rkappas(0))");
+  phm_options o;
+  std::memset(&o, 0, sizeof(o));
+  o.device = -1;
+  if (opt_in) o = *opt_in;
+  if (o.n_replicas <= 0) o.n_replicas = 1;
+  o.reduce = o.n_replicas > 1;     // one chain: its own statistics, accumulated in the reference's order (bit-exact vs the oracle)
+  o.iters_per_launch = 1;
+  (void)B;     // the reference aliases the caller's B and then overwrites it entry by entry; B = I + Q/Omega throughout
+  phm_model model;
+  model.n_states = n; model.Q = Q; model.pid = pid; model.B = nullptr; model.Omega = Omega; model.variant = variant;
+  phm_engine* e = nullptr;
+  int32_t st = phm_engine_create(x, &model, &o, N, &e);
+  if (st) return st;
+  std::string serr;
+  if (!phm::check_reference_orders(e->sched, x->edge, nen, nodelist, root, serr)) { phm_engine_destroy(e); return fail(PHM_ERR_BAD_INPUT, serr); }
+  std::vector<double> Qw(Q, Q + (size_t)n * n), row(e->cols);
+  for (int i = 0; i < N && !st; ++i) {
+    st = phm_engine_run(e, 1, nullptr);
+    if (!st) st = phm_engine_sync(e);
+    if (!st) st = phm_engine_read_stats(e, i, 1, row.data());
+    if (st) break;
+    if (variant == PHM_MCMC_BF) phm::bf_updates(Qw.data(), Omega, prior, row.data(), o.seed, (uint32_t)i);
+    else phm::ks_updates(Qw.data(), n, Omega, prior, row.data(), o.seed, (uint32_t)i);
+    if (i + 1 < N) st = phm_engine_set_model(e, Qw.data());
+  }
+  if (!st) st = phm_engine_read_stats(e, 0, N, out);
+  phm_engine_destroy(e);
+  return st;
+}
+
+extern "C" int32_t phm_maketreelistMCMCbf(const phm_tree* x, int32_t n, const double* Q, const double* pid, const double* B,
+                                          double Omega, const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
+                                          const double* prior, int32_t n_prior, const phm_options* opt, double* out) {
+  return run_qupdate(PHM_MCMC_BF, x, n, Q, pid, B, Omega, nen, nodelist, root, N, prior, n_prior, opt, out);
+}
+
+extern "C" int32_t phm_maketreelistMCMCks(const phm_tree* x, int32_t n, const double* Q, const double* pid, const double* B,
+                                          double Omega, const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
+                                          const double* prior, int32_t n_prior, const phm_options* opt, double* out) {
+  return run_qupdate(PHM_MCMC_KS, x, n, Q, pid, B, Omega, nen, nodelist, root, N, prior, n_prior, opt, out);
+}
+
+// Host-only: apply one iteration's rate-matrix updates to Q (column-major, edited in place) given a statistics row
+// (n dwell sums, n*n counts).  What phm_maketreelistMCMCbf / ks run between sweeps; exported for CPU-side tests.
+extern "C" int32_t phm_qupdate_apply(int32_t variant, int32_t n, double* Q, double Omega, const double* prior, int32_t n_prior,
+                                     const double* row, uint64_t seed, uint32_t iter) {
+  if (!Q || !prior || !row) return fail(PHM_ERR_BAD_INPUT, "phm_qupdate_apply: NULL argument");
+  if (variant == PHM_MCMC_BF) {
+    if (n != 2 || n_prior < 4) return fail(PHM_ERR_BAD_INPUT, "bf: n = 2, prior[4]");
+    phm::bf_updates(Q, Omega, prior, row, seed, iter);
+  } else if (variant == PHM_MCMC_KS) {
+    if (n < 4 || (n & 1) || n > 64 || n_prior < 6) return fail(PHM_ERR_BAD_INPUT, "ks: n = 2k+2 in 4..64, prior[6]");
+    phm::ks_updates(Q, n, Omega, prior, row, seed, iter);
+  } else return fail(PHM_ERR_BAD_INPUT, "variant must be PHM_MCMC_BF or PHM_MCMC_KS");
+  return PHM_OK;
 }

@@ -11,7 +11,7 @@ _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _SO = os.path.join(_ROOT, "oracle", "_build", "libphm_oracle.so")
 
 ERR_ZERO_PROB, ERR_UNIF_CAP, ERR_BAD_INPUT, ERR_TAPE, ERR_SAMPLEONCE = 1, 2, 4, 8, 16
-PLAIN, BIGTREE, SPARSE, KS = 0, 1, 2, 3
+PLAIN, BIGTREE, SPARSE, KS, BF = 0, 1, 2, 3, 4
 
 
 class Rng(C.Structure):
@@ -116,7 +116,7 @@ def philox(ctr, key):
 
 
 def maketreelistMCMC(z, Q, pid, B, Omega, nen, nodelist, root, N, variant=PLAIN, seed=1, replica=0,
-                     faithful_search=False, tape_u=None, tape_e=None, dump=False):
+                     faithful_search=False, tape_u=None, tape_e=None, dump=False, prior=None):
     Q = np.asarray(Q, dtype=np.float64)
     n = Q.shape[0]
     ft = FlatTree(z)
@@ -124,9 +124,21 @@ def maketreelistMCMC(z, Q, pid, B, Omega, nen, nodelist, root, N, variant=PLAIN,
     pid = np.ascontiguousarray(pid, dtype=np.float64)
     nen = np.ascontiguousarray(nen, dtype=np.int32)
     nodelist = np.ascontiguousarray(nodelist, dtype=np.int32)
-    cols = n + n * (n - 1) if variant != KS else n + n * n + 2 + 3 * (n // 2 - 1) + 1
+    cols = n + n * (n - 1)
+    if variant == KS:
+        cols = n + n * n + 2 + 3 * (n // 2 - 1) + 1
+    if variant == BF:
+        cols = 9
     out = np.zeros((N, cols), order="F")
     rng, keep = make_rng(seed, replica, tape_u, tape_e)
+    if prior is not None:
+        prior = np.ascontiguousarray(prior, dtype=np.float64)
+        rc = lib().orc_maketreelistMCMC_qupdate(C.byref(ft.c), n, _ptr(Qc, C.c_double), _ptr(pid, C.c_double),
+                                                _ptr(Bc, C.c_double), C.c_double(Omega), _ptr(nen, C.c_int32),
+                                                _ptr(nodelist, C.c_int32), int(root), int(N), int(variant),
+                                                _ptr(prior, C.c_double), int(faithful_search), C.byref(rng),
+                                                _ptr(out, C.c_double), None)
+        return out, rc
     db = DumpBuf(ft, n) if dump else None
     rc = lib().orc_maketreelistMCMC(C.byref(ft.c), n, _ptr(Qc, C.c_double), _ptr(pid, C.c_double),
                                     _ptr(Bc, C.c_double), C.c_double(Omega), _ptr(nen, C.c_int32),

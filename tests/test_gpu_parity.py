@@ -298,6 +298,42 @@ def test_ks_sweep_matches_oracle(n):
     np.testing.assert_array_equal(red[:, -1], got.sum(0)[:, -1])
 
 
+def test_sumstatMCMCbf_with_rate_updates_matches_oracle():
+    """R/sumstatMCMCbf.R: sweep on the GPU, Gibbs update of (l01, l10) on the host, every iteration."""
+    Q = np.array([[-.1, .1], [.1, -.1]])
+    Omega, pid, prior = 10.0, np.array([.5, .5]), [.55, 1, .56, 1.01]        # vignettes/phylomap_tutorial.Rnw:204-212
+    z = synth.make_tree(40, Q, 0.5, 15, pid)
+    nen, nodelist, root = _orders(z)
+    Q0 = Q.copy()
+    got = api.sumstatMCMCbf(z, Q, pid, Omega, 30, prior, seed=99)
+    assert np.array_equal(Q, Q0)                                             # inputs are never written (:1212-1217 does)
+    want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(2) + Q / Omega, Omega, nen, nodelist, root, 30, variant=O.BF, seed=99, prior=prior)
+    assert rc == 0 and got.shape == (30, 9)
+    np.testing.assert_array_equal(got, want)
+    assert len(np.unique(got[:, 6])) > 20 and np.all(got[:, 6] > 0)          # l01 really moves
+
+
+@pytest.mark.parametrize("n", [4, 6])
+def test_sumstatMCMCks_with_rate_updates_matches_oracle(n):
+    """R/sumstatMCMCks.R: hidden-rates model, 2+3k parameters updated after every sweep (n = 6 runs the wide kernel)."""
+    Q = synth.make2sQ(.1, .1, .2, .2, 10) if n == 4 else synth.make2sQ(.1, .3, [.2, .4], [.5, .6], [2, 3])
+    Omega, pid = 25.0, np.full(n, 1.0 / n)
+    prior = [1, 10, 2, 10, 20, 2]                                            # vignettes/phylomap_tutorial.Rnw:248-256
+    # n = 4: ~100 segments per branch (general path of the lane kernel); n = 6: the wide kernel holds <= 128 per branch
+    z = synth.make_tree(30, Q, 1.0 if n == 4 else Omega / 3, 16, pid)
+    z["states"] = ((z["states"] - 1) % 2 + 1).astype(np.int32)
+    nen, nodelist, root = _orders(z)
+    got = api.sumstatMCMCks(z, Q, pid, Omega, 25, prior, seed=7)
+    want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(n) + Q / Omega, Omega, nen, nodelist, root, 25, variant=O.KS, seed=7, prior=prior)
+    assert rc == 0
+    np.testing.assert_array_equal(got, want)
+    k = n // 2 - 1
+    assert len(np.unique(got[:, n + n * n])) > 10                            # l01 moves
+    # multi-site: S sites share Q; updates see the summed statistics
+    got2 = api.sumstatMCMCks(z, Q, pid, Omega, 10, prior, seed=7, n_replicas=3)
+    np.testing.assert_allclose(got2[:, :n].sum(1), 3 * z["edge.length"].sum(), rtol=1e-12)
+
+
 def test_replica_offset_shards_like_one_device():
     z, Q, pid, Omega = _problem(2, 18, 4)
     a = api.sumstatMCMC(z, Q, pid, Omega, 10, seed=3, n_replicas=4)
