@@ -1,5 +1,5 @@
 // phylomap_shim.cpp -- the ONLY file that includes R headers.  Replaces src/RcppExports.cpp for the hot-path
-// symbols: same `.Call` names, same argument order (src/RcppExports.cpp:11,34,57,80; R/RcppExports.R:4-22), so
+// symbols: same `.Call` names, same argument order (src/RcppExports.cpp:11,34,57,80,106,132; R/RcppExports.R:4-30), so
 // R/sumstat*.R and user code run unchanged.  Each export unpacks the SEXPs into the plain structs of
 // include/phylomap_hip.h, calls the C-ABI, and returns a fresh N x cols numeric matrix.
 //
@@ -106,6 +106,41 @@ RcppExport SEXP phylomap_SPARSEmaketreelistMCMC(SEXP x, SEXP Q, SEXP pid, SEXP B
                                                 SEXP nodelist, SEXP root, SEXP N) {
   BEGIN_RCPP
   return run_mcmc(phm_SPARSEmaketreelistMCMC, x, Q, pid, B, Omega, nen, nodelist, root, N);
+  END_RCPP
+}
+
+typedef int32_t (*qupd_fn)(const phm_tree*, int32_t, const double*, const double*, const double*, double, const int32_t*,
+                           const int32_t*, int32_t, int32_t, const double*, int32_t, const phm_options*, double*);
+
+// maketreelistMCMCbf / maketreelistMCMCks (src/RcppExports.cpp:106,132): the reference edits the caller's Q and B in place
+// (src/phylomap.cpp:1212-1217) -- vignettes re-create Q before every call for that reason; this binding leaves them alone.
+static SEXP run_qupdate(qupd_fn fn, int cols_extra_k, SEXP xSEXP, SEXP QSEXP, SEXP pidSEXP, SEXP BSEXP, SEXP OmegaSEXP,
+                        SEXP nenSEXP, SEXP nodelistSEXP, SEXP rootSEXP, SEXP NSEXP, SEXP priorSEXP) {
+  RNGScope scope;
+  FlatTree ft(as<List>(xSEXP));
+  NumericMatrix Q(QSEXP), B(BSEXP);
+  NumericVector pid(pidSEXP), prior(priorSEXP);
+  IntegerVector nen(nenSEXP), nodelist(nodelistSEXP);
+  const int n = Q.nrow(), N = as<int>(NSEXP);
+  const int k = cols_extra_k ? n / 2 - 1 : 0;
+  NumericMatrix out(N, n + n * n + 2 + 3 * k + 1);                  // :1293 (bf), :1857 (ks)
+  phm_options o = options_from_R();
+  check(fn(&ft.t, n, Q.begin(), pid.begin(), B.begin(), as<double>(OmegaSEXP), nen.begin(), nodelist.begin(),
+           as<int>(rootSEXP), N, prior.begin(), (int32_t)prior.size(), &o, out.begin()));
+  return out;
+}
+
+RcppExport SEXP phylomap_maketreelistMCMCbf(SEXP x, SEXP Q, SEXP pid, SEXP B, SEXP Omega, SEXP nen, SEXP nodelist, SEXP root,
+                                            SEXP N, SEXP prior) {
+  BEGIN_RCPP
+  return run_qupdate(phm_maketreelistMCMCbf, 0, x, Q, pid, B, Omega, nen, nodelist, root, N, prior);
+  END_RCPP
+}
+
+RcppExport SEXP phylomap_maketreelistMCMCks(SEXP x, SEXP Q, SEXP pid, SEXP B, SEXP Omega, SEXP nen, SEXP nodelist, SEXP root,
+                                            SEXP N, SEXP prior) {
+  BEGIN_RCPP
+  return run_qupdate(phm_maketreelistMCMCks, 1, x, Q, pid, B, Omega, nen, nodelist, root, N, prior);
   END_RCPP
 }
 
