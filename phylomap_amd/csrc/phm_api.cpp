@@ -79,7 +79,7 @@ struct phm_engine {
   bool tips_per_replica = false;
   int64_t rows = 0;
   DevBuf d_mask;
-  DevBuf d_up, d_down, d_col, d_row, d_tips, d_mcount, d_dw0, d_dw1, d_PL, d_nstate, d_stats, d_err, d_seg, d_red;
+  DevBuf d_up, d_down, d_col, d_row, d_tips, d_mcount, d_dw0, d_cursor, d_PL, d_nstate, d_stats, d_err, d_seg, d_red;
   phm::McmcParams<2> p2;
   phm::McmcParams<3> p3;
   phm::McmcParams<4> p4;
@@ -117,7 +117,7 @@ void fill_params(phm_engine* e, phm::McmcParams<NS>& p, const double* B2, const 
   p.up = e->d_up.as<phm::UpStep>(); p.down = e->d_down.as<phm::DownStep>();
   p.colpow = e->d_col.as<double>(); p.rowpow = e->d_row.as<double>();
   p.tips = e->d_tips.as<uint8_t>(); p.mcount = e->d_mcount.as<uint16_t>();
-  p.dwell0 = e->d_dw0.as<double>(); p.dwell1 = e->d_dw1.as<double>();
+  p.dwell0 = e->d_dw0.as<double>(); p.cursor = e->d_cursor.as<int32_t>();
   p.PL = e->d_PL.as<double>(); p.nstate = e->d_nstate.as<uint8_t>(); p.stats = e->d_stats.as<double>();
   p.err = e->d_err.as<uint32_t>(); p.segcnt = e->d_seg.as<unsigned long long>();
 }
@@ -323,6 +323,8 @@ int32_t phm_engine_create(const phm_tree* x, const phm_model* model, const phm_o
   // (t_b = sum(x$maps[[b]])) and occupies max-over-64-lanes rows; provision the per-branch quantile at
   // `cap_tail` (default 1e-3, i.e. beyond the expected maximum of 64 draws) and check at run time.
   int64_t rows = 0;
+  int64_t max_q = 0;
+  double sum_lambda = 0.0;
   std::vector<int32_t> init_row(E);
   int64_t init_rows = 0;
   for (int k = 0; k < E; ++k) {
@@ -336,8 +338,14 @@ int32_t phm_engine_create(const phm_tree* x, const phm_model* model, const phm_o
     // caller-supplied path longer than the stationary quantile (e.g. 100 equal pieces) needs m0 + that quantile
     int q = phm::poisson_capacity(model->Omega * tb, o.cap_tail > 0.0 ? o.cap_tail : 1e-3);
     rows += std::max(q, m0 + q - 1);
+    max_q = std::max<int64_t>(max_q, std::max(q, m0 + q - 1));
+    sum_lambda += model->Omega * tb;
   }
-  rows = std::max(rows, init_rows) + 64;
+  // Ring capacity: the stream being read, plus head-room for the stream being written behind it.  While branch k is
+  // processed its input rows are still occupied and its output rows are already being written (one full branch of
+  // slack), and rows written so far minus rows freed so far performs a random walk whose standard deviation is about
+  // 0.7 sqrt(sum lambda) (wave-maximum of 64 Poisson counts per branch); 6 sigma of that on top.
+  rows = std::max(rows, init_rows) + max_q + (int64_t)(6.0 * 0.7 * std::sqrt(sum_lambda)) + 64;
   if (rows * 64 > 0x7fffff00ll) return fail(PHM_ERR_UNSUPPORTED, "tree too large: dwell rows per replica tile exceed 32-bit indexing");
   e->rows = rows;
 
@@ -361,7 +369,7 @@ int32_t phm_engine_create(const phm_tree* x, const phm_model* model, const phm_o
   const size_t stats_bytes = e->reduce ? sizeof(double) * (size_t)max_iters * e->tiles * e->dcols
                                                      : sizeof(double) * (size_t)max_iters * e->dcols * e->S_pad;
   const size_t dw_bytes = sizeof(double) * (size_t)e->tiles * rows * 64;
-  size_t need = 2 * dw_bytes + stats_bytes + sizeof(double) * (size_t)e->tiles * s.n_node * n * 64 +
+  size_t need = dw_bytes + stats_bytes + sizeof(double) * (size_t)e->tiles * s.n_node * n * 64 +
                 (size_t)e->tiles * (s.n_node + 2 * (size_t)E) * 64 + e->tips_host.size();
   size_t free_b = 0, total_b = 0;
   HIPCHK(hipMemGetInfo(&free_b, &total_b));
@@ -379,7 +387,7 @@ int32_t phm_engine_create(const phm_tree* x, const phm_model* model, const phm_o
   HIPCHK(e->d_tips.alloc(e->tips_host.size()));
   HIPCHK(e->d_mcount.alloc(sizeof(uint16_t) * (size_t)e->tiles * E * 64));
   HIPCHK(e->d_dw0.alloc(dw_bytes));
-  HIPCHK(e->d_dw1.alloc(dw_bytes));
+  HIPCHK(e->d_cursor.alloc(sizeof(int32_t) * 2 * e->tiles));
   HIPCHK(e->d_PL.alloc(sizeof(double) * (size_t)e->tiles * s.n_node * n * 64));
   HIPCHK(e->d_nstate.alloc((size_t)e->tiles * s.n_node * 64));
   HIPCHK(e->d_stats.alloc(stats_bytes));
@@ -387,7 +395,7 @@ int32_t phm_engine_create(const phm_tree* x, const phm_model* model, const phm_o
   HIPCHK(e->d_seg.alloc(sizeof(unsigned long long)));
   if (e->reduce) HIPCHK(e->d_red.alloc(sizeof(double) * (size_t)max_iters * e->dcols));
   e->bytes = (int64_t)(e->d_up.bytes + e->d_down.bytes + e->d_col.bytes + e->d_row.bytes + e->d_tips.bytes + e->d_mcount.bytes +
-                       e->d_dw0.bytes + e->d_dw1.bytes + e->d_PL.bytes + e->d_nstate.bytes + e->d_stats.bytes + e->d_red.bytes);
+                       e->d_dw0.bytes + e->d_cursor.bytes + e->d_PL.bytes + e->d_nstate.bytes + e->d_stats.bytes + e->d_red.bytes);
 
   HIPCHK(hipMemcpy(e->d_up.p, s.up.data(), e->d_up.bytes, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(e->d_down.p, s.down.data(), e->d_down.bytes, hipMemcpyHostToDevice));
@@ -408,6 +416,9 @@ int32_t phm_engine_create(const phm_tree* x, const phm_model* model, const phm_o
     HIPCHK(phm::launch_mcmc_init(E, e->tiles, rows, e->d_down.as<phm::DownStep>(), d_irow.as<int32_t>(), d_off.as<int32_t>(), d_maps.as<double>(),
                                  e->d_dw0.as<double>(), e->d_mcount.as<uint16_t>(), nullptr));
     HIPCHK(hipDeviceSynchronize());
+    std::vector<int32_t> cur(2 * (size_t)e->tiles);
+    for (int t = 0; t < e->tiles; ++t) { cur[2 * t] = 0; cur[2 * t + 1] = (int32_t)(init_rows % rows); }
+    HIPCHK(hipMemcpy(e->d_cursor.p, cur.data(), e->d_cursor.bytes, hipMemcpyHostToDevice));
   }
 
   if (e->wide) {
@@ -429,7 +440,7 @@ int32_t phm_engine_create(const phm_tree* x, const phm_model* model, const phm_o
     p.up = e->d_up.as<phm::UpStep>(); p.down = e->d_down.as<phm::DownStep>();
     p.colpow = e->d_col.as<double>(); p.rowpow = e->d_row.as<double>();
     p.tips = e->d_tips.as<uint8_t>(); p.mcount = e->d_mcount.as<uint16_t>();
-    p.dwell0 = e->d_dw0.as<double>(); p.dwell1 = e->d_dw1.as<double>();
+    p.dwell0 = e->d_dw0.as<double>(); p.cursor = e->d_cursor.as<int32_t>();
     p.PL = e->d_PL.as<double>(); p.nstate = e->d_nstate.as<uint8_t>(); p.stats = e->d_stats.as<double>();
     p.err = e->d_err.as<uint32_t>(); p.segcnt = e->d_seg.as<unsigned long long>();
   }
@@ -538,13 +549,15 @@ int32_t phm_engine_dump(phm_engine* e, int32_t replica, int32_t* seg_count, doub
   if (seg_count) for (int b = 0; b < E; ++b) seg_count[b] = mc[(size_t)b * 64 + lane];
   if (seg_dwell) {
     std::vector<double> dw((size_t)e->rows * 64);
-    const double* src = ((e->iters_done & 1) ? e->d_dw1.as<double>() : e->d_dw0.as<double>()) + (size_t)tile * e->rows * 64;
+    const double* src = e->d_dw0.as<double>() + (size_t)tile * e->rows * 64;
     HIPCHK(hipMemcpy(dw.data(), src, sizeof(double) * dw.size(), hipMemcpyDeviceToHost));
-    size_t row = 0;     // replay the stream layout: branch down[k] occupies max-over-lanes(m) rows
+    int32_t cur[2];
+    HIPCHK(hipMemcpy(cur, e->d_cursor.as<int32_t>() + 2 * tile, sizeof cur, hipMemcpyDeviceToHost));
+    size_t row = (size_t)cur[0];     // replay the stream layout from the ring cursor: branch down[k] occupies max-over-lanes(m) rows
     for (int k = 0; k < E; ++k) {
       const phm::DownStep& d = s.down[k];
       int m = std::min<int>(mc[(size_t)d.edge * 64 + lane], seg_cap);
-      for (int i = 0; i < m; ++i) seg_dwell[(size_t)d.edge * seg_cap + i] = dw[(row + i) * 64 + lane];
+      for (int i = 0; i < m; ++i) seg_dwell[(size_t)d.edge * seg_cap + i] = dw[((row + i) % (size_t)e->rows) * 64 + lane];
       int mx = 0;
       for (int l = 0; l < 64; ++l) mx = std::max<int>(mx, mc[(size_t)d.edge * 64 + l]);
       row += mx;

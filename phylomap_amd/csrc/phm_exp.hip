@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256) void expm_pade_mfma_kernel(int n, const double
     const int s = sq[b];
     const double inv_sc = ldexp(1.0, -s);
     d4_t X[4], Em[4], Dm[4], T[4];
-    if (w < rb) {
+    {   // every wave fills its column block (blocks beyond n carry the identity), so the LDS images have no holes
       double Af[4][16];                                          // A = Q t / 2^s, A-operand fragments
 #pragma unroll
       for (int sI = 0; sI < 16; ++sI) {
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256) void expm_pade_mfma_kernel(int n, const double
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           d4_t acc = {0.0, 0.0, 0.0, 0.0};
-          if (i < rb) {
+          if (i < rb && w < rb) {
 #pragma unroll
             for (int sI = 0; sI < 16; ++sI) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Af[i][sI], X[sI >> 2][sI & 3], acc, 0, 0, 0);
           }
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(256) void expm_pade_mfma_kernel(int n, const double
 
     // ---- s squarings: Y <- Y Y, operands re-read from LDS in A- and B-slice layouts ----
     for (int it = 0; it < s; ++it) {
-      if (w < rb) {
+      {
         d4_t Yb[4];
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb)
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(256) void expm_pade_mfma_kernel(int n, const double
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           d4_t acc = {0.0, 0.0, 0.0, 0.0};
-          if (i < rb) {
+          if (i < rb && w < rb) {
 #pragma unroll
             for (int sI = 0; sI < 16; ++sI)
               acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sE[(16 * i + lr) * PADE_LDP + 4 * sI + lk], Yb[sI >> 2][sI & 3], acc, 0, 0, 0);
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(256) void expm_pade_mfma_kernel(int n, const double
         }
       }
       __syncthreads();
-      if (w < rb) {
+      {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll

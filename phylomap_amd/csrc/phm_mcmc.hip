@@ -106,9 +106,16 @@ __global__ __launch_bounds__(MCMC_BLOCK, 5) void mcmc_sweep_kernel(McmcParams<NS
   uint16_t* __restrict__ mct = p.mcount + (size_t)tile * p.n_edge * 64;
   const uint8_t* __restrict__ tips_t = p.tips_per_replica ? p.tips + (size_t)tile * p.n_tips * 64 : p.tips;
 
+  double* ring = p.dwell0 + (size_t)tile * p.rows * 64;
+  const int C = (int)p.rows;
+  int cur_r = p.cursor[tile * 2], cur_w = p.cursor[tile * 2 + 1];      // wave-uniform: start of the current stream, end of it
   for (int it = iter0; it < iter0 + n_iters; ++it) {
-    double* dw_in = ((it & 1) ? p.dwell1 : p.dwell0) + (size_t)tile * p.rows * 64;   // consumed AND reused as scratch
-    double* dw_out = ((it & 1) ? p.dwell0 : p.dwell1) + (size_t)tile * p.rows * 64;
+    // One ring of C rows per tile holds the stream being consumed and, behind it, the stream being produced: the
+    // producer starts where the consumer's data end and may wrap into rows the consumer has already freed.
+    const int rbase = cur_r, wbase = cur_w;
+    const int r_in = (wbase >= rbase) ? wbase - rbase : wbase - rbase + C;      // rows of the input stream
+    auto IN = [&](int k) -> double& { int idx = rbase + k; idx = idx >= C ? idx - C : idx; return ring[idx * 64 + lane]; };
+    auto OUT = [&](int k) -> double& { int idx = wbase + k; idx = idx >= C ? idx - C : idx; return ring[idx * 64 + lane]; };
 #pragma unroll
     for (int c = 0; c < NS; ++c) s_dw[c * 64 + lane] = 0.0;
 #pragma unroll
@@ -205,7 +212,7 @@ __global__ __launch_bounds__(MCMC_BLOCK, 5) void mcmc_sweep_kernel(McmcParams<NS
       se.open(ENT_BEXP | (uint32_t)b, (uint32_t)it, rep, p.seed_lo, p.seed_hi);
       const int roff = in_row;
       const int woff = out_row;
-      const int cap = (int)p.rows - out_row;     // rows left in the output stream
+      const int cap = C - (r_in - in_row) - out_row;   // free rows: the ring minus unread input minus output so far
       const int mmax = wave_max(m);
       int mnew = 0;                              // pieces emitted = new segment count
 
@@ -231,17 +238,17 @@ __global__ __launch_bounds__(MCMC_BLOCK, 5) void mcmc_sweep_kernel(McmcParams<NS
         uint64_t pk0 = 0, pk1 = 0;
         int w = 0;
         int cur_s = (m == 1) ? cs : ps;            // updatenodestates :469-472 (m==1: child wins)
-        double cur_len = dw_in[roff * 64 + lane];
-        double dnext = (m > 1) ? dw_in[(roff + 1) * 64 + lane] : 0.0;
+        double cur_len = IN(roff);
+        double dnext = (m > 1) ? IN(roff + 1) : 0.0;
         for (int i = 1; i < mmax; ++i) {
           if (i < m) {
             int si = (i == m - 1) ? cs : draw_state(i, cur_s);
             double di = dnext;
-            if (i + 1 < m) dnext = dw_in[(roff + i + 1) * 64 + lane];
+            if (i + 1 < m) dnext = IN(roff + i + 1);
             if (KS) s_cnt[(cur_s * NS + si) * 64 + lane] += 1u;               // shortenerbf :1010-1014
             if (si == cur_s) cur_len = cur_len + di;                           // shortener :54
             else {
-              dw_in[(roff + w) * 64 + lane] = cur_len;
+              IN(roff + w) = cur_len;
               if (w < 32) pk0 |= (uint64_t)cur_s << (2 * w); else pk1 |= (uint64_t)cur_s << (2 * (w - 32));
               if (!KS) {
                 int col = cur_s * (NS - 1) + (si > cur_s ? si - 1 : si);       // shortener :65-66
@@ -253,14 +260,14 @@ __global__ __launch_bounds__(MCMC_BLOCK, 5) void mcmc_sweep_kernel(McmcParams<NS
         }
         if (w < 32) pk0 |= (uint64_t)cur_s << (2 * w); else pk1 |= (uint64_t)cur_s << (2 * (w - 32));
         const int nmerged = w + 1;
-        const double len0 = (w == 0) ? cur_len : dw_in[roff * 64 + lane];
-        if (w > 0) dw_in[(roff + w) * 64 + lane] = cur_len;
+        const double len0 = (w == 0) ? cur_len : IN(roff);
+        if (w > 0) IN(roff + w) = cur_len;
 
         // Pass B: one new piece per step for every lane (virtual jumps :391-410, dwell sums :745-757).
         int j = 0;
         int s = (int)(pk0 & 3u);
         double len = len0;
-        double lnext = (nmerged > 1) ? ((w == 1) ? cur_len : dw_in[(roff + 1) * 64 + lane]) : 0.0;
+        double lnext = (nmerged > 1) ? ((w == 1) ? cur_len : IN(roff + 1)) : 0.0;
         double tot = 0.0, scale = s_scale[s], acc = s_dw[s * 64 + lane];
         uint32_t edraw = 0;
         bool stuck = false, done = false;
@@ -273,7 +280,7 @@ __global__ __launch_bounds__(MCMC_BLOCK, 5) void mcmc_sweep_kernel(McmcParams<NS
             if ((tot + rl) < len) { piece = rl; tot += rl; adv = false; }
             else { piece = len - tot; adv = true; }
           }
-          if (mnew < cap) dw_out[(woff + mnew) * 64 + lane] = piece; else err |= DERR_CAPACITY;
+          if (mnew < cap) OUT(woff + mnew) = piece; else err |= DERR_CAPACITY;
           acc += piece;                                                        // updatedwelltimes :752
           ++mnew;
           if (adv) {
@@ -282,7 +289,7 @@ __global__ __launch_bounds__(MCMC_BLOCK, 5) void mcmc_sweep_kernel(McmcParams<NS
             if (j >= nmerged) done = true;
             else {
               len = lnext;
-              if (j + 1 < nmerged) lnext = dw_in[(roff + j + 1) * 64 + lane];
+              if (j + 1 < nmerged) lnext = IN(roff + j + 1);
               s = (int)(((j < 32) ? (pk0 >> (2 * j)) : (pk1 >> (2 * (j - 32)))) & 3u);
               scale = s_scale[s]; tot = 0.0; acc = s_dw[s * 64 + lane];
             }
@@ -295,7 +302,7 @@ __global__ __launch_bounds__(MCMC_BLOCK, 5) void mcmc_sweep_kernel(McmcParams<NS
         auto finalize = [&](int s, double len) {
           if (stuck || !(0.0 < len)) {
             stuck = true;
-            if (mnew < cap) dw_out[(woff + mnew) * 64 + lane] = len; else err |= DERR_CAPACITY;
+            if (mnew < cap) OUT(woff + mnew) = len; else err |= DERR_CAPACITY;
             s_dw[s * 64 + lane] += len;
             ++mnew;
             return;
@@ -308,20 +315,20 @@ __global__ __launch_bounds__(MCMC_BLOCK, 5) void mcmc_sweep_kernel(McmcParams<NS
             double piece;
             if ((tot + rl) < len) { piece = rl; tot += rl; }
             else { piece = len - tot; tot = len; }
-            if (mnew < cap) dw_out[(woff + mnew) * 64 + lane] = piece; else err |= DERR_CAPACITY;
+            if (mnew < cap) OUT(woff + mnew) = piece; else err |= DERR_CAPACITY;
             acc += piece;
             ++mnew;
           }
           s_dw[s * 64 + lane] = acc;
         };
         int cur_s = (m == 1) ? cs : ps;
-        double cur_len = dw_in[roff * 64 + lane];
+        double cur_len = IN(roff);
         for (int i = 1; i <= m; ++i) {              // i == m: sentinel that flushes the last merged segment
           int si = -1;
           double di = 0.0;
           if (i < m) {
             si = (i == m - 1) ? cs : draw_state(i, cur_s);
-            di = dw_in[(roff + i) * 64 + lane];
+            di = IN(roff + i);
           }
           if (KS && si >= 0) s_cnt[(cur_s * NS + si) * 64 + lane] += 1u;
           if (si == cur_s) cur_len = cur_len + di;
@@ -340,10 +347,13 @@ __global__ __launch_bounds__(MCMC_BLOCK, 5) void mcmc_sweep_kernel(McmcParams<NS
       seg_rw += (uint32_t)(m + mnew);
       in_row += mmax;
       out_row += wave_max(mnew);
-      if (out_row > (int)p.rows) out_row = (int)p.rows;
+      if (out_row > C) out_row = C;
     }
 
     // ------------------------------ statistics row of this iteration ------------------------------
+    cur_r = wbase;                                          // the stream just written is the next sweep's input
+    cur_w = wbase + out_row; if (cur_w >= C) cur_w -= C;
+
     // columns: n dwell sums, NCNT transition counters, then (ks) the root state, 0-based (:1350-1352)
     constexpr int DCOLS = NS + NCNT + (KS ? 1 : 0);
     if (p.reduce) {
@@ -370,6 +380,7 @@ __global__ __launch_bounds__(MCMC_BLOCK, 5) void mcmc_sweep_kernel(McmcParams<NS
       if (lane == 0) atomicAdd(p.segcnt, (unsigned long long)v);
     }
   }
+  if (lane == 0) { p.cursor[tile * 2] = cur_r; p.cursor[tile * 2 + 1] = cur_w; }
   if (err) atomicOr(p.err, err);
 }
 

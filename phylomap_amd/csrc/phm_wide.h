@@ -37,8 +37,8 @@ struct WideParams {
   const double* maskpow;                     // [ktab][2][n] (ks)
   const uint8_t* tips;
   uint16_t* mcount;                          // [tile][n_edge][64]
-  double* dwell0;                            // [tile][rows][64]
-  double* dwell1;
+  double* dwell0;                            // [tile][rows][64] ring (consumed stream + produced stream)
+  int32_t* cursor;                           // [tile][2]
   double* PL;                                // [tile][n_node][64][n]  (a replica's vector is contiguous)
   uint8_t* nstate;                           // [tile][n_node][64]
   double* stats;                             // reduce: [iter][tile][cols] (atomics); else [iter][cols][n_rep_pad]; zeroed at create

@@ -113,9 +113,14 @@ __global__ __launch_bounds__(WIDE_BLOCK) void mcmc_wide_kernel(WideParams p, int
     return v;
   };
 
+  double* ring = p.dwell0 + (size_t)tile * p.rows * 64;
+  const int C = (int)p.rows;
+  int cur_r = p.cursor[tile * 2], cur_w = p.cursor[tile * 2 + 1];
   for (int it = iter0; it < iter0 + n_iters; ++it) {
-    double* dw_in = ((it & 1) ? p.dwell1 : p.dwell0) + (size_t)tile * p.rows * 64;
-    double* dw_out = ((it & 1) ? p.dwell0 : p.dwell1) + (size_t)tile * p.rows * 64;
+    const int rbase = cur_r, wbase = cur_w;              // one ring per tile, as in phm_mcmc.hip
+    const int r_in = (wbase >= rbase) ? wbase - rbase : wbase - rbase + C;
+    auto IN = [&](int k) -> double& { int idx = rbase + k; idx = idx >= C ? idx - C : idx; return ring[idx * 64 + lane]; };
+    auto OUT = [&](int k) -> double& { int idx = wbase + k; idx = idx >= C ? idx - C : idx; return ring[idx * 64 + lane]; };
     // statistics: reduce = 0 -> [iter][col][replica], plain read-modify-write by the owning lane;
     //             reduce = 1 -> [iter][tile][col] shared by the 64 lanes of the wave, f64 atomics (counts are exact
     //             in any order; dwell sums agree to rounding) -- n(n-1) columns per replica would not fit for n = 61
@@ -228,23 +233,23 @@ __global__ __launch_bounds__(WIDE_BLOCK) void mcmc_wide_kernel(WideParams p, int
       Stream se;
       se.open(ENT_BEXP | (uint32_t)b, (uint32_t)it, rep, p.seed_lo, p.seed_hi);
       const int roff = in_row, woff = out_row;
-      const int cap = (int)p.rows - out_row;
+      const int cap = C - (r_in - in_row) - out_row;
       int mnew = 0;
       {
         // pass A: merged segments written back in place (lengths into the consumed input rows, states into s_st)
         int w = 0;
         int cur_s = (m == 1) ? cs : ps;                              // updatenodestates :469-472
-        double cur_len = dw_in[roff * 64 + lane];
-        double dnext = (m > 1) ? dw_in[(roff + 1) * 64 + lane] : 0.0;
+        double cur_len = IN(roff);
+        double dnext = (m > 1) ? IN(roff + 1) : 0.0;
         for (int i = 1; i < mmax; ++i) {
           if (i < m) {
             int si = (i == m - 1) ? cs : (int)s_st[(i - 1) * 64 + lane];
             double di = dnext;
-            if (i + 1 < m) dnext = dw_in[(roff + i + 1) * 64 + lane];
+            if (i + 1 < m) dnext = IN(roff + i + 1);
             if (p.count_self) stat_add(n + cur_s * n + si, 1.0);                            // shortenerbf :1010-1014
             if (si == cur_s) cur_len = cur_len + di;                 // shortener :54
             else {
-              dw_in[(roff + w) * 64 + lane] = cur_len;
+              IN(roff + w) = cur_len;
               s_st[w * 64 + lane] = (uint8_t)cur_s;                  // w <= i-1: slot already consumed
               if (!p.count_self) {
                 int col = cur_s * (n - 1) + (si > cur_s ? si - 1 : si);                        // shortener :65-66
@@ -255,14 +260,14 @@ __global__ __launch_bounds__(WIDE_BLOCK) void mcmc_wide_kernel(WideParams p, int
           }
         }
         const int nmerged = w + 1;
-        const double len0 = (w == 0) ? cur_len : dw_in[roff * 64 + lane];
+        const double len0 = (w == 0) ? cur_len : IN(roff);
         const int s0 = (w == 0) ? cur_s : (int)s_st[lane];
-        if (w > 0) { dw_in[(roff + w) * 64 + lane] = cur_len; s_st[w * 64 + lane] = (uint8_t)cur_s; }
+        if (w > 0) { IN(roff + w) = cur_len; s_st[w * 64 + lane] = (uint8_t)cur_s; }
 
         // pass B: one new piece per step per lane (virtual jumps :391-410, updatedwelltimes :745-757)
         int j = 0, s = s0;
         double len = len0;
-        double lnext = (nmerged > 1) ? ((w == 1) ? cur_len : dw_in[(roff + 1) * 64 + lane]) : 0.0;
+        double lnext = (nmerged > 1) ? ((w == 1) ? cur_len : IN(roff + 1)) : 0.0;
         double tot = 0.0, scale = s_scale[s];
         // running dwell sum of state s: continued piece by piece from the stored total (the reference's order,
         // :752) when statistics are per replica; a fresh partial handed to one atomic when they are summed
@@ -278,7 +283,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) void mcmc_wide_kernel(WideParams p, int
             if ((tot + rl) < len) { piece = rl; tot += rl; adv = false; }
             else { piece = len - tot; adv = true; }
           }
-          if (mnew < cap) dw_out[(woff + mnew) * 64 + lane] = piece; else err |= DERR_CAPACITY;
+          if (mnew < cap) OUT(woff + mnew) = piece; else err |= DERR_CAPACITY;
           acc += piece;
           ++mnew;
           if (adv) {
@@ -287,7 +292,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) void mcmc_wide_kernel(WideParams p, int
             if (j >= nmerged) done = true;
             else {
               len = lnext;
-              if (j + 1 < nmerged) lnext = dw_in[(roff + j + 1) * 64 + lane];
+              if (j + 1 < nmerged) lnext = IN(roff + j + 1);
               s = (int)s_st[j * 64 + lane];
               scale = s_scale[s]; tot = 0.0;
               acc = red ? 0.0 : srow[(size_t)s * cstride];
@@ -300,8 +305,10 @@ __global__ __launch_bounds__(WIDE_BLOCK) void mcmc_wide_kernel(WideParams p, int
       seg_rw += (uint32_t)(m + mnew);
       in_row += mmax;
       out_row += wave_max_w(mnew);
-      if (out_row > (int)p.rows) out_row = (int)p.rows;
+      if (out_row > C) out_row = C;
     }
+    cur_r = wbase;
+    cur_w = wbase + out_row; if (cur_w >= C) cur_w -= C;
     {
       uint32_t v = valid ? seg_rw : 0u;
 #pragma unroll
@@ -309,6 +316,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) void mcmc_wide_kernel(WideParams p, int
       if (lane == 0) atomicAdd(p.segcnt, (unsigned long long)v);
     }
   }
+  if (lane == 0) { p.cursor[tile * 2] = cur_r; p.cursor[tile * 2 + 1] = cur_w; }
   if (err) atomicOr(p.err, err);
 }
 
