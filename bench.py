@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--replicas", type=int, default=0, help="replicas per GPU (0: sized from free HBM, max 327680 = 5 waves per SIMD)")
     ap.add_argument("--config", type=int, default=2)
     ap.add_argument("--ipl", type=int, default=8, help="sweeps fused per kernel launch")
+    ap.add_argument("--storage", type=int, default=2, help="dwell streams: 2 = two buffers (fastest), 1 = one ring (half the HBM)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--force-collective", action="store_true", help="exercise the statistics hand-over to torch at N=1")
     args = ap.parse_args()
@@ -88,7 +89,7 @@ def main():
     if S <= 0:
         free_b, _ = torch.cuda.mem_get_info()
         probe = _lib.Engine(z, Q, pid, Omega, 1, variant=_lib.PHM_MCMC_BIGTREE, seed=1, n_replicas=64, reduce=True,
-                            device=local_rank)
+                            device=local_rank, storage=args.storage)
         per_tile = probe.info().device_bytes
         probe.close()
         S = int(min(327680, (0.80 * free_b) // per_tile * 64))
@@ -96,7 +97,7 @@ def main():
 
     eng = _lib.Engine(z, Q, pid, Omega, K + W, variant=_lib.PHM_MCMC_BIGTREE, seed=0x5EED0000 + args.config,
                       n_replicas=S, replica_offset=parallel.weak_shard(S, rank)[0], reduce=True, device=local_rank,
-                      iters_per_launch=args.ipl)
+                      iters_per_launch=args.ipl, storage=args.storage)
     stream = torch.cuda.current_stream().cuda_stream
 
     def barrier():
@@ -169,6 +170,7 @@ def main():
                                    f"{z['states'].size}-tip synthetic tree, Omega*mean(t_b)=4",
                        "n_states": n, "n_tips": int(z["states"].size), "branches": E,
                        "replicas_per_gpu": S, "sweeps_per_launch": args.ipl,
+                       "dwell_storage": "two buffers" if args.storage == 2 else "ring",
                        "parallelism": f"replica-sharded x{world}, one RCCL all-reduce of the statistics"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -91,7 +91,8 @@ typedef struct phm_options {
   int32_t iters_per_launch;    /* MCMC iterations fused into one kernel launch; 0 -> default */
   double  cap_tail;            /* dwell-stream capacity of a 64-replica tile = sum over branches of the
                                   1+Poisson(Omega*t_b) quantile at this tail; 0 -> 1e-3 */
-  int32_t reserved[6];
+  int32_t reserved[6];         /* [0]: dwell-stream storage, 0 = automatic, 1 = one ring per tile (half the HBM),
+                                  2 = two buffers (5 % faster sweep for n <= 4) */
 } phm_options;
 
 typedef struct phm_info {

@@ -162,10 +162,11 @@ def tree_orders(z):
 
 
 def make_options(seed=0, n_replicas=1, replica_offset=0, reduce=False, tips_per_replica=False, device=-1,
-                 iters_per_launch=0, cap_tail=0.0):
+                 iters_per_launch=0, cap_tail=0.0, storage=0):
     o = Options()
     o.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
     o.n_replicas, o.replica_offset, o.reduce = int(n_replicas), int(replica_offset), int(bool(reduce))
+    o.reserved[0] = int(storage)          # 0 automatic, 1 ring, 2 two buffers
     o.tips_per_replica, o.device, o.iters_per_launch, o.cap_tail = int(bool(tips_per_replica)), int(device), int(iters_per_launch), float(cap_tail)
     return o
 

@@ -79,11 +79,12 @@ struct phm_engine {
   bool tips_per_replica = false;
   int64_t rows = 0;
   DevBuf d_mask;
-  DevBuf d_up, d_down, d_col, d_row, d_tips, d_mcount, d_dw0, d_cursor, d_PL, d_nstate, d_stats, d_err, d_seg, d_red;
+  DevBuf d_up, d_down, d_col, d_row, d_tips, d_mcount, d_dw0, d_dw1, d_cursor, d_PL, d_nstate, d_stats, d_err, d_seg, d_red;
   phm::McmcParams<2> p2;
   phm::McmcParams<3> p3;
   phm::McmcParams<4> p4;
   bool wide = false;                   // 5..64 states: phm_wide.hip
+  bool ring = true;                    // one ring per tile for both dwell streams (else two buffers)
   phm::WideParams pw;
   DevBuf d_B2, d_Bc, d_scale, d_pid;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -117,7 +118,7 @@ void fill_params(phm_engine* e, phm::McmcParams<NS>& p, const double* B2, const 
   p.up = e->d_up.as<phm::UpStep>(); p.down = e->d_down.as<phm::DownStep>();
   p.colpow = e->d_col.as<double>(); p.rowpow = e->d_row.as<double>();
   p.tips = e->d_tips.as<uint8_t>(); p.mcount = e->d_mcount.as<uint16_t>();
-  p.dwell0 = e->d_dw0.as<double>(); p.cursor = e->d_cursor.as<int32_t>();
+  p.dwell0 = e->d_dw0.as<double>(); p.dwell1 = e->ring ? nullptr : e->d_dw1.as<double>(); p.cursor = e->d_cursor.as<int32_t>();
   p.PL = e->d_PL.as<double>(); p.nstate = e->d_nstate.as<uint8_t>(); p.stats = e->d_stats.as<double>();
   p.err = e->d_err.as<uint32_t>(); p.segcnt = e->d_seg.as<unsigned long long>();
 }
@@ -369,10 +370,13 @@ int32_t phm_engine_create(const phm_tree* x, const phm_model* model, const phm_o
   const size_t stats_bytes = e->reduce ? sizeof(double) * (size_t)max_iters * e->tiles * e->dcols
                                                      : sizeof(double) * (size_t)max_iters * e->dcols * e->S_pad;
   const size_t dw_bytes = sizeof(double) * (size_t)e->tiles * rows * 64;
-  size_t need = dw_bytes + stats_bytes + sizeof(double) * (size_t)e->tiles * s.n_node * n * 64 +
-                (size_t)e->tiles * (s.n_node + 2 * (size_t)E) * 64 + e->tips_host.size();
+  // Two buffers save two VALU operations per dwell access (about 5 % of the n <= 4 sweep) and cost twice the HBM:
+  // used when they take less than a third of the free memory, unless the caller asks (reserved[0]: 1 ring, 2 two buffers).
   size_t free_b = 0, total_b = 0;
   HIPCHK(hipMemGetInfo(&free_b, &total_b));
+  e->ring = e->wide || o.reserved[0] == 1 || (o.reserved[0] != 2 && 2 * dw_bytes > free_b / 3);
+  size_t need = (e->ring ? 1 : 2) * dw_bytes + stats_bytes + sizeof(double) * (size_t)e->tiles * s.n_node * n * 64 +
+                (size_t)e->tiles * (s.n_node + 2 * (size_t)E) * 64 + e->tips_host.size();
   if (need + (64u << 20) > free_b) {
     char buf[256];
     std::snprintf(buf, sizeof buf, "engine needs %.2f GiB of HBM, %.2f GiB free (reduce n_replicas or max_iters)", need / 1073741824.0, free_b / 1073741824.0);
@@ -388,6 +392,7 @@ int32_t phm_engine_create(const phm_tree* x, const phm_model* model, const phm_o
   HIPCHK(e->d_mcount.alloc(sizeof(uint16_t) * (size_t)e->tiles * E * 64));
   HIPCHK(e->d_dw0.alloc(dw_bytes));
   HIPCHK(e->d_cursor.alloc(sizeof(int32_t) * 2 * e->tiles));
+  if (!e->ring) HIPCHK(e->d_dw1.alloc(dw_bytes));
   HIPCHK(e->d_PL.alloc(sizeof(double) * (size_t)e->tiles * s.n_node * n * 64));
   HIPCHK(e->d_nstate.alloc((size_t)e->tiles * s.n_node * 64));
   HIPCHK(e->d_stats.alloc(stats_bytes));
@@ -395,7 +400,7 @@ int32_t phm_engine_create(const phm_tree* x, const phm_model* model, const phm_o
   HIPCHK(e->d_seg.alloc(sizeof(unsigned long long)));
   if (e->reduce) HIPCHK(e->d_red.alloc(sizeof(double) * (size_t)max_iters * e->dcols));
   e->bytes = (int64_t)(e->d_up.bytes + e->d_down.bytes + e->d_col.bytes + e->d_row.bytes + e->d_tips.bytes + e->d_mcount.bytes +
-                       e->d_dw0.bytes + e->d_cursor.bytes + e->d_PL.bytes + e->d_nstate.bytes + e->d_stats.bytes + e->d_red.bytes);
+                       e->d_dw0.bytes + e->d_dw1.bytes + e->d_cursor.bytes + e->d_PL.bytes + e->d_nstate.bytes + e->d_stats.bytes + e->d_red.bytes);
 
   HIPCHK(hipMemcpy(e->d_up.p, s.up.data(), e->d_up.bytes, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(e->d_down.p, s.down.data(), e->d_down.bytes, hipMemcpyHostToDevice));
@@ -417,7 +422,7 @@ int32_t phm_engine_create(const phm_tree* x, const phm_model* model, const phm_o
                                  e->d_dw0.as<double>(), e->d_mcount.as<uint16_t>(), nullptr));
     HIPCHK(hipDeviceSynchronize());
     std::vector<int32_t> cur(2 * (size_t)e->tiles);
-    for (int t = 0; t < e->tiles; ++t) { cur[2 * t] = 0; cur[2 * t + 1] = (int32_t)(init_rows % rows); }
+    for (int t = 0; t < e->tiles; ++t) { cur[2 * t] = 0; cur[2 * t + 1] = e->ring ? (int32_t)(init_rows % rows) : 0; }
     HIPCHK(hipMemcpy(e->d_cursor.p, cur.data(), e->d_cursor.bytes, hipMemcpyHostToDevice));
   }
 
@@ -549,11 +554,11 @@ int32_t phm_engine_dump(phm_engine* e, int32_t replica, int32_t* seg_count, doub
   if (seg_count) for (int b = 0; b < E; ++b) seg_count[b] = mc[(size_t)b * 64 + lane];
   if (seg_dwell) {
     std::vector<double> dw((size_t)e->rows * 64);
-    const double* src = e->d_dw0.as<double>() + (size_t)tile * e->rows * 64;
-    HIPCHK(hipMemcpy(dw.data(), src, sizeof(double) * dw.size(), hipMemcpyDeviceToHost));
     int32_t cur[2];
     HIPCHK(hipMemcpy(cur, e->d_cursor.as<int32_t>() + 2 * tile, sizeof cur, hipMemcpyDeviceToHost));
-    size_t row = (size_t)cur[0];     // replay the stream layout from the ring cursor: branch down[k] occupies max-over-lanes(m) rows
+    const double* src = ((!e->ring && cur[0]) ? e->d_dw1.as<double>() : e->d_dw0.as<double>()) + (size_t)tile * e->rows * 64;
+    HIPCHK(hipMemcpy(dw.data(), src, sizeof(double) * dw.size(), hipMemcpyDeviceToHost));
+    size_t row = e->ring ? (size_t)cur[0] : 0;     // replay the stream layout from the ring cursor: branch down[k] occupies max-over-lanes(m) rows
     for (int k = 0; k < E; ++k) {
       const phm::DownStep& d = s.down[k];
       int m = std::min<int>(mc[(size_t)d.edge * 64 + lane], seg_cap);

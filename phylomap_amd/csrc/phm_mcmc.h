@@ -36,7 +36,9 @@ struct McmcParams {
   const uint8_t* tips;                       // 0-based tip states: [n_tips] or [tile][n_tips][64]
   uint16_t* mcount;                          // [tile][n_edge][64] segments per branch
   double* dwell0;                            // [tile][rows][64] ring holding the consumed and the produced dwell stream
-  int32_t* cursor;                           // [tile][2]: first row of the current stream, first free row after it
+  double* dwell1;                            // NULL: ring mode; else the second buffer of the two-buffer mode
+  int32_t* cursor;                           // [tile][2]: ring: first row of the current stream, first free row after it;
+                                             //            two buffers: {sweep parity, unused}
   double* PL;                                // [tile][n_node][NS][64] internal nodes only
   uint8_t* nstate;                           // [tile][n_node][64] sampled internal-node states
   double* stats;                             // reduce: [iter][tile][cols]; else [iter][cols][n_rep_pad]

@@ -71,7 +71,9 @@ __device__ __forceinline__ void child_vector(const McmcParams<NS>& p, const doub
 // KS = the tree sweep of sumstatMCMCks (treesampleks, src/phylomap.cpp:1422-1432) with Q held fixed: parity tip masks,
 // hidden tip states re-sampled every sweep (:1384-1397), every consecutive state pair counted, self pairs included,
 // into n x n counters (shortenerbf :1010-1014), root state recorded (:1350-1352).
-template <int NS, bool KS>
+// RING = one ring of C rows per tile holds both dwell streams (half the HBM, two extra VALU ops per access);
+// !RING = two buffers of C rows, swapped every sweep (chosen by the host when HBM is plentiful).
+template <int NS, bool KS, bool RING>
 __global__ __launch_bounds__(MCMC_BLOCK, 5) void mcmc_sweep_kernel(McmcParams<NS> p, int iter0, int n_iters) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x & 63;
@@ -107,6 +109,7 @@ __global__ __launch_bounds__(MCMC_BLOCK, 5) void mcmc_sweep_kernel(McmcParams<NS
   const uint8_t* __restrict__ tips_t = p.tips_per_replica ? p.tips + (size_t)tile * p.n_tips * 64 : p.tips;
 
   double* ring = p.dwell0 + (size_t)tile * p.rows * 64;
+  double* ring2 = RING ? ring : p.dwell1 + (size_t)tile * p.rows * 64;
   const int C = (int)p.rows;
   int cur_r = p.cursor[tile * 2], cur_w = p.cursor[tile * 2 + 1];      // wave-uniform: start of the current stream, end of it
   for (int it = iter0; it < iter0 + n_iters; ++it) {
@@ -114,8 +117,18 @@ __global__ __launch_bounds__(MCMC_BLOCK, 5) void mcmc_sweep_kernel(McmcParams<NS
     // producer starts where the consumer's data end and may wrap into rows the consumer has already freed.
     const int rbase = cur_r, wbase = cur_w;
     const int r_in = (wbase >= rbase) ? wbase - rbase : wbase - rbase + C;      // rows of the input stream
-    auto IN = [&](int k) -> double& { int idx = rbase + k; idx = idx >= C ? idx - C : idx; return ring[idx * 64 + lane]; };
-    auto OUT = [&](int k) -> double& { int idx = wbase + k; idx = idx >= C ? idx - C : idx; return ring[idx * 64 + lane]; };
+    double* buf_in = RING ? ring : (cur_r ? ring2 : ring);                      // !RING: cur_r is the sweep parity
+    double* buf_out = RING ? ring : (cur_r ? ring : ring2);
+    auto IN = [&](int k) -> double& {
+      int idx = k;
+      if (RING) { idx = rbase + k; idx = idx >= C ? idx - C : idx; }
+      return buf_in[idx * 64 + lane];
+    };
+    auto OUT = [&](int k) -> double& {
+      int idx = k;
+      if (RING) { idx = wbase + k; idx = idx >= C ? idx - C : idx; }
+      return buf_out[idx * 64 + lane];
+    };
 #pragma unroll
     for (int c = 0; c < NS; ++c) s_dw[c * 64 + lane] = 0.0;
 #pragma unroll
@@ -212,7 +225,8 @@ __global__ __launch_bounds__(MCMC_BLOCK, 5) void mcmc_sweep_kernel(McmcParams<NS
       se.open(ENT_BEXP | (uint32_t)b, (uint32_t)it, rep, p.seed_lo, p.seed_hi);
       const int roff = in_row;
       const int woff = out_row;
-      const int cap = C - (r_in - in_row) - out_row;   // free rows: the ring minus unread input minus output so far
+      const int cap = RING ? C - (r_in - in_row) - out_row    // free rows: the ring minus unread input minus output so far
+                           : C - out_row;
       const int mmax = wave_max(m);
       int mnew = 0;                              // pieces emitted = new segment count
 
@@ -351,8 +365,10 @@ __global__ __launch_bounds__(MCMC_BLOCK, 5) void mcmc_sweep_kernel(McmcParams<NS
     }
 
     // ------------------------------ statistics row of this iteration ------------------------------
-    cur_r = wbase;                                          // the stream just written is the next sweep's input
-    cur_w = wbase + out_row; if (cur_w >= C) cur_w -= C;
+    if (RING) {
+      cur_r = wbase;                                        // the stream just written is the next sweep's input
+      cur_w = wbase + out_row; if (cur_w >= C) cur_w -= C;
+    } else cur_r ^= 1;
 
     // columns: n dwell sums, NCNT transition counters, then (ks) the root state, 0-based (:1350-1352)
     constexpr int DCOLS = NS + NCNT + (KS ? 1 : 0);
@@ -427,8 +443,11 @@ hipError_t launch_mcmc(const McmcParams<NS>& p, int iter0, int n_iters, hipStrea
   const int waves_per_block = MCMC_BLOCK / 64;
   dim3 grid((p.n_tiles + waves_per_block - 1) / waves_per_block);
   size_t lds = mcmc_lds_bytes<NS>(p.ktab, p.ks != 0);
-  if (p.ks) hipLaunchKernelGGL((mcmc_sweep_kernel<NS, true>), grid, dim3(MCMC_BLOCK), lds, stream, p, iter0, n_iters);
-  else hipLaunchKernelGGL((mcmc_sweep_kernel<NS, false>), grid, dim3(MCMC_BLOCK), lds, stream, p, iter0, n_iters);
+  const bool ring = p.dwell1 == nullptr;
+  if (p.ks && ring) hipLaunchKernelGGL((mcmc_sweep_kernel<NS, true, true>), grid, dim3(MCMC_BLOCK), lds, stream, p, iter0, n_iters);
+  else if (p.ks) hipLaunchKernelGGL((mcmc_sweep_kernel<NS, true, false>), grid, dim3(MCMC_BLOCK), lds, stream, p, iter0, n_iters);
+  else if (ring) hipLaunchKernelGGL((mcmc_sweep_kernel<NS, false, true>), grid, dim3(MCMC_BLOCK), lds, stream, p, iter0, n_iters);
+  else hipLaunchKernelGGL((mcmc_sweep_kernel<NS, false, false>), grid, dim3(MCMC_BLOCK), lds, stream, p, iter0, n_iters);
   return hipGetLastError();
 }
 

@@ -52,11 +52,12 @@ def test_mcmc_single_chain_is_drop_in_shape():
     np.testing.assert_array_equal(got, want)
 
 
-def test_mcmc_chain_state_matches_oracle():
+@pytest.mark.parametrize("storage", [1, 2])      # 1: one ring per tile for both dwell streams; 2: two buffers
+def test_mcmc_chain_state_matches_oracle(storage):
     z, Q, pid, Omega = _problem(4, 40, 99)
     nen, nodelist, root = _orders(z)
     N, seed = 15, 42
-    eng = _lib.Engine(z, Q, pid, Omega, N, variant=_lib.PHM_MCMC_BIGTREE, seed=seed, n_replicas=70)
+    eng = _lib.Engine(z, Q, pid, Omega, N, variant=_lib.PHM_MCMC_BIGTREE, seed=seed, n_replicas=70, storage=storage)
     eng.run(7); eng.run(N - 7); eng.sync()
     for r in (0, 63, 69):
         want, rc, dump = O.maketreelistMCMC(z, Q, pid, np.eye(4) + Q / Omega, Omega, nen, nodelist, root, N,
@@ -73,7 +74,8 @@ def test_mcmc_chain_state_matches_oracle():
     eng.close()
 
 
-def test_mcmc_long_initial_paths_take_the_general_branch_path():
+@pytest.mark.parametrize("storage", [1, 2])
+def test_mcmc_long_initial_paths_take_the_general_branch_path(storage):
     """100 equal segments per branch (R/Squamate_tree_setup.R:57): exercises the > 64-segment code path and the
     hand-over to the packed two-pass path once the chain has shrunk the paths."""
     Q = synth.config_Q(2)
@@ -81,7 +83,7 @@ def test_mcmc_long_initial_paths_take_the_general_branch_path():
     pid = np.full(4, 0.25)
     z = synth.make_tree(14, Q, Omega, 21, pid, init_segments=100)
     nen, nodelist, root = _orders(z)
-    got = api.sumstatMCMC(z, Q, pid, Omega, 12, seed=13, n_replicas=2)
+    got = api.sumstatMCMC(z, Q, pid, Omega, 12, seed=13, n_replicas=2, storage=storage)
     for r in range(2):
         want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(4) + Q / Omega, Omega, nen, nodelist, root, 12, seed=13, replica=r)
         assert rc == 0
@@ -173,7 +175,7 @@ def test_mcmc_config2_shape_matches_oracle():
     z, Q, pid, Omega = synth.config_problem(2)
     nen, nodelist, root = _orders(z)
     N, seed = 12, 2024
-    eng = _lib.Engine(z, Q, pid, Omega, N, variant=_lib.PHM_MCMC_BIGTREE, seed=seed, n_replicas=128)
+    eng = _lib.Engine(z, Q, pid, Omega, N, variant=_lib.PHM_MCMC_BIGTREE, seed=seed, n_replicas=128, storage=1)
     eng.run(N); eng.sync()
     st = eng.stats(0, N)
     for r in (0, 63, 127):
@@ -298,14 +300,15 @@ def test_ks_sweep_matches_oracle(n):
     np.testing.assert_array_equal(red[:, -1], got.sum(0)[:, -1])
 
 
-def test_sumstatMCMCbf_with_rate_updates_matches_oracle():
+@pytest.mark.parametrize("storage", [1, 2])
+def test_sumstatMCMCbf_with_rate_updates_matches_oracle(storage):
     """R/sumstatMCMCbf.R: sweep on the GPU, Gibbs update of (l01, l10) on the host, every iteration."""
     Q = np.array([[-.1, .1], [.1, -.1]])
     Omega, pid, prior = 10.0, np.array([.5, .5]), [.55, 1, .56, 1.01]        # vignettes/phylomap_tutorial.Rnw:204-212
     z = synth.make_tree(40, Q, 0.5, 15, pid)
     nen, nodelist, root = _orders(z)
     Q0 = Q.copy()
-    got = api.sumstatMCMCbf(z, Q, pid, Omega, 30, prior, seed=99)
+    got = api.sumstatMCMCbf(z, Q, pid, Omega, 30, prior, seed=99, storage=storage)
     assert np.array_equal(Q, Q0)                                             # inputs are never written (:1212-1217 does)
     want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(2) + Q / Omega, Omega, nen, nodelist, root, 30, variant=O.BF, seed=99, prior=prior)
     assert rc == 0 and got.shape == (30, 9)
