@@ -74,7 +74,7 @@ __device__ __forceinline__ void child_vector(const McmcParams<NS>& p, const doub
 // RING = one ring of C rows per tile holds both dwell streams (half the HBM, two extra VALU ops per access);
 // !RING = two buffers of C rows, swapped every sweep (chosen by the host when HBM is plentiful).
 template <int NS, bool KS, bool RING>
-__global__ __launch_bounds__(MCMC_BLOCK, 5) void mcmc_sweep_kernel(McmcParams<NS> p, int iter0, int n_iters) {
+__device__ __forceinline__ void sweep_body(const McmcParams<NS>& p, int iter0, int n_iters) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -400,6 +400,17 @@ __global__ __launch_bounds__(MCMC_BLOCK, 5) void mcmc_sweep_kernel(McmcParams<NS
   if (err) atomicOr(p.err, err);
 }
 
+template <int NS, bool KS, bool RING>
+__global__ __launch_bounds__(MCMC_BLOCK, 5) void mcmc_sweep_kernel(McmcParams<NS> p, int iter0, int n_iters) {
+  sweep_body<NS, KS, RING>(p, iter0, n_iters);
+}
+
+// The pruning (up) sweep alone, under its own name so that profiles separate it from the full sweep (p.prune_only = 1).
+template <int NS, bool KS, bool RING>
+__global__ __launch_bounds__(MCMC_BLOCK, 5) void mcmc_pruning_kernel(McmcParams<NS> p, int iter0, int n_iters) {
+  sweep_body<NS, KS, RING>(p, iter0, n_iters);
+}
+
 // Load the caller's initial paths (x$maps, makeabranch src/phylomap.cpp:24-34) into every replica:
 // one sequential stream per tile in sweep order, init_row[k] = first row of branch down[k].
 __global__ void mcmc_init_kernel(int n_edge, int n_tiles, int64_t rows, const DownStep* __restrict__ down,
@@ -444,6 +455,13 @@ hipError_t launch_mcmc(const McmcParams<NS>& p, int iter0, int n_iters, hipStrea
   dim3 grid((p.n_tiles + waves_per_block - 1) / waves_per_block);
   size_t lds = mcmc_lds_bytes<NS>(p.ktab, p.ks != 0);
   const bool ring = p.dwell1 == nullptr;
+  if (p.prune_only) {
+    if (p.ks && ring) hipLaunchKernelGGL((mcmc_pruning_kernel<NS, true, true>), grid, dim3(MCMC_BLOCK), lds, stream, p, iter0, n_iters);
+    else if (p.ks) hipLaunchKernelGGL((mcmc_pruning_kernel<NS, true, false>), grid, dim3(MCMC_BLOCK), lds, stream, p, iter0, n_iters);
+    else if (ring) hipLaunchKernelGGL((mcmc_pruning_kernel<NS, false, true>), grid, dim3(MCMC_BLOCK), lds, stream, p, iter0, n_iters);
+    else hipLaunchKernelGGL((mcmc_pruning_kernel<NS, false, false>), grid, dim3(MCMC_BLOCK), lds, stream, p, iter0, n_iters);
+    return hipGetLastError();
+  }
   if (p.ks && ring) hipLaunchKernelGGL((mcmc_sweep_kernel<NS, true, true>), grid, dim3(MCMC_BLOCK), lds, stream, p, iter0, n_iters);
   else if (p.ks) hipLaunchKernelGGL((mcmc_sweep_kernel<NS, true, false>), grid, dim3(MCMC_BLOCK), lds, stream, p, iter0, n_iters);
   else if (ring) hipLaunchKernelGGL((mcmc_sweep_kernel<NS, false, true>), grid, dim3(MCMC_BLOCK), lds, stream, p, iter0, n_iters);
