@@ -120,6 +120,85 @@ double orc_exp(double x) {
   return ldexp(y, k);
 }
 
+
+/* ------------------------------------------------------------------------------------------ */
+/* "R-stream" mode (rng.mode = 2): R's default generator consumed sequentially in the reference's draw order, so that a
+ * machine WITH R + phylomap can be compared sample for sample (tools/r_parity/).  Restated from the published R sources
+ * (RNG.c: Mersenne-Twister with set.seed's LCG scrambling; sexp.c: Ahrens-Dieter exp_rand) -- third-party code that is
+ * not under /root/reference and could NOT be checked here (no R in the build image): UNVERIFIED.  Covers what the
+ * fixed-Q MCMC variants draw: unif_rand (via runif / RcppArmadillo::sample) and exp_rand (via Rcpp::rexp).            */
+/* ------------------------------------------------------------------------------------------ */
+static uint32_t r_mt[624];
+static int r_mti = 625;
+static void r_set_seed(uint32_t seed) {
+  for (int j = 0; j < 50; ++j) seed = 69069u * seed + 1u;             /* RNG_Init: initial scrambling */
+  uint32_t dummy0 = 0;
+  for (int j = 0; j < 625; ++j) {
+    seed = 69069u * seed + 1u;
+    if (j == 0) dummy0 = seed; else r_mt[j - 1] = seed;
+  }
+  (void)dummy0;
+  r_mti = 624;                                                        /* FixupSeeds: dummy[0] = 624 */
+}
+static double r_unif_rand(void) {
+  static const uint32_t mag01[2] = { 0x0u, 0x9908b0dfu };
+  if (r_mti >= 624) {
+    int kk;
+    for (kk = 0; kk < 624 - 397; kk++) { uint32_t y = (r_mt[kk] & 0x80000000u) | (r_mt[kk + 1] & 0x7fffffffu); r_mt[kk] = r_mt[kk + 397] ^ (y >> 1) ^ mag01[y & 1u]; }
+    for (; kk < 623; kk++) { uint32_t y = (r_mt[kk] & 0x80000000u) | (r_mt[kk + 1] & 0x7fffffffu); r_mt[kk] = r_mt[kk + (397 - 624)] ^ (y >> 1) ^ mag01[y & 1u]; }
+    uint32_t y = (r_mt[623] & 0x80000000u) | (r_mt[0] & 0x7fffffffu);
+    r_mt[623] = r_mt[396] ^ (y >> 1) ^ mag01[y & 1u];
+    r_mti = 0;
+  }
+  uint32_t y = r_mt[r_mti++];
+  y ^= (y >> 11); y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= (y >> 18);
+  double x = (double)y * 2.3283064365386963e-10;                      /* [0,1) */
+  if (x <= 0.0) return 0.5 * 2.328306437080797e-10;                   /* fixup(): never 0 or 1 */
+  if ((1.0 - x) <= 0.0) return 1.0 - 0.5 * 2.328306437080797e-10;
+  return x;
+}
+static double r_exp_rand(void) {                                      /* sexp.c, Ahrens & Dieter (1972) */
+  static const double q[] = { 0.6931471805599453, 0.9333736875190459, 0.9888777961838675, 0.9984589039328339,
+    0.9998292811061389, 0.9999833164100727, 0.9999985691438767, 0.9999998906925558, 0.9999999924734159,
+    0.9999999995283275, 0.9999999999728814, 0.9999999999985598, 0.9999999999999289, 0.9999999999999968,
+    0.9999999999999999, 1.0000000000000000 };
+  double a = 0.;
+  double u = r_unif_rand();
+  while (u <= 0. || u >= 1.) u = r_unif_rand();
+  for (;;) { u += u; if (u > 1.) break; a += q[0]; }
+  u -= 1.;
+  if (u <= q[0]) return a + u;
+  int i = 0;
+  double ustar = r_unif_rand(), umin = ustar;
+  do { ustar = r_unif_rand(); if (umin > ustar) umin = ustar; i++; } while (u > q[i]);
+  return a + umin * q[0];
+}
+/* RcppArmadillo::sample(sts,1,TRUE,p): FixProb (sequential sum of the positive entries, p/sum), sort DESCENDING
+ * (std::sort on <= 16 elements is an insertion sort, hence stable for ties; larger n is implementation-defined),
+ * cumulative sum, first jj < n-1 with u <= cum[jj], else the last; returns the original index. */
+static int sample_cat_R(const double* p, int n, double u, int* err) {
+  double sum = 0.0; int npos = 0;
+  for (int i = 0; i < n; ++i) { if (!isfinite(p[i]) || p[i] < 0.0) { *err |= ORC_ERR_ZERO_PROB; return 0; } if (p[i] > 0.0) { sum += p[i]; npos++; } }
+  if (npos == 0) { *err |= ORC_ERR_ZERO_PROB; return 0; }
+  double pr[64]; int perm[64];
+  if (n > 64) { *err |= ORC_ERR_BAD_INPUT; return 0; }
+  for (int i = 0; i < n; ++i) { pr[i] = p[i] / sum; perm[i] = i; }
+  for (int i = 1; i < n; ++i) {                                       /* stable insertion sort, descending */
+    double v = pr[i]; int id = perm[i]; int j = i - 1;
+    while (j >= 0 && pr[j] < v) { pr[j + 1] = pr[j]; perm[j + 1] = perm[j]; --j; }
+    pr[j + 1] = v; perm[j + 1] = id;
+  }
+  double cum = 0.0; int jj;
+  for (jj = 0; jj < n - 1; ++jj) { cum += pr[jj]; if (u <= cum) break; }
+  return perm[jj];
+}
+int orc_rstream_selftest(uint32_t seed, int n_unif, int n_exp, double* unif_out, double* exp_out) {   /* set.seed; runif(n_unif); rexp(n_exp) */
+  r_set_seed(seed);
+  for (int i = 0; i < n_unif; ++i) unif_out[i] = r_unif_rand();
+  for (int i = 0; i < n_exp; ++i) exp_out[i] = r_exp_rand();
+  return 0;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* RNG front end                                                                               */
 /* ------------------------------------------------------------------------------------------ */
@@ -131,6 +210,7 @@ static double draw_u(rngctx* c, uint32_t iter, uint32_t entity, uint32_t draw) {
     if (r->pos_u >= r->n_u) { c->err |= ORC_ERR_TAPE; return 0.5; }
     return r->tape_u[r->pos_u++];
   }
+  if (r->mode == 2) return r_unif_rand();
   return orc_stream_u(r->seed_lo, r->seed_hi, r->replica, iter, entity, draw);
 }
 /* standard exponential: -log(u) (R's exp_rand is Ahrens-Dieter; not restated in Philox mode) */
@@ -140,6 +220,7 @@ static double draw_e(rngctx* c, uint32_t iter, uint32_t entity, uint32_t draw) {
     if (r->pos_e >= r->n_e) { c->err |= ORC_ERR_TAPE; return 1.0; }
     return r->tape_e[r->pos_e++];
   }
+  if (r->mode == 2) return r_exp_rand();
   return -orc_log(orc_stream_u(r->seed_lo, r->seed_hi, r->replica, iter, entity, draw));
 }
 
@@ -179,7 +260,9 @@ static void chainT(const double* M, double* v, int k, int n, double* tmp) {
  * uses index order, keeps the `<=`, and compares u*sum(p) with the running sum instead of dividing
  * every p_j.  All-zero / non-finite p (RcppArmadillo throws) raises ORC_ERR_ZERO_PROB.
  */
+static int g_rstream = 0;     /* set by the drivers when rng.mode == 2 */
 static int sample_cat(const double* p, int n, double u, int* err) {
+  if (g_rstream) return sample_cat_R(p, n, u, err);
   double total = p[0];
   for (int j = 1; j < n; ++j) total += p[j];
   if (!(total > 0.0) || isinf(total)) { *err |= ORC_ERR_ZERO_PROB; return 0; }
@@ -659,6 +742,8 @@ static int mcmc_driver(const orc_tree* x, int n, const double* Q_cm, const doubl
   double* Q = (double*)malloc(sizeof(double) * n * n);        /* row-major working copy; the updates edit it */
   for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) QQ(i, j) = Q_cm[i + (size_t)j * n];
   rngctx rc = { rng, 0 };
+  g_rstream = (rng->mode == 2);
+  if (g_rstream) { if (prior) return ORC_ERR_BAD_INPUT; r_set_seed(rng->seed_lo); }   /* rgamma is not restated */
 
   double* B2 = (double*)malloc(sizeof(double) * n * n);       /* row-major copies */
   double* Bc = (double*)malloc(sizeof(double) * n * n);
@@ -981,6 +1066,8 @@ int orc_maketreelistEXP(const orc_tree* x, int n, const double* Q_cm, const doub
   int cols = n + n * (n - 1);
   size_t nn = (size_t)n * n;
   rngctx rc = { rng, 0 };
+  if (rng->mode == 2) return ORC_ERR_BAD_INPUT;       /* R-stream mode: Rf_dpois (saddle-point) is not restated */
+  g_rstream = 0;
 
   double* L = (double*)malloc(sizeof(double) * nn * 3);
   double *R = L + nn, *B2 = L + 2 * nn;

@@ -44,7 +44,9 @@ extern "C" {
                                  shortenerbf counts, columns l01 l10 root); out: N x 9 */
 
 /* RNG: mode 0 = counter-based Philox4x32-10 streams (the mode the GPU matches bit for bit);
- *      mode 1 = scripted tapes consumed in the reference's draw order (for hand KATs). */
+ *      mode 1 = scripted tapes consumed in the reference's draw order (for hand KATs);
+ *      mode 2 = "R stream": set.seed(seed_lo) + unif_rand / exp_rand / sorted RcppArmadillo::sample consumed sequentially
+ *               in the reference's order (fixed-Q MCMC variants only).  UNVERIFIED: no R here; see tools/r_parity/. */
 typedef struct orc_rng {
   int32_t  mode;
   uint32_t seed_lo, seed_hi;   /* Philox key */
@@ -83,6 +85,8 @@ double orc_log(double x);
 double orc_exp(double x);
 double orc_stream_u(uint32_t seed_lo, uint32_t seed_hi, uint32_t replica, uint32_t iter,
                     uint32_t entity, uint32_t draw);
+
+int orc_rstream_selftest(uint32_t seed, int n_unif, int n_exp, double* unif_out, double* exp_out);   /* set.seed(seed); runif(n_unif); rexp(n_exp) */
 
 /* ---- per-function entry points for known-answer tests ---- */
 /* shortener  src/phylomap.cpp:44-73; returns new segment count; stats row gets += counts */

@@ -79,9 +79,13 @@ class FlatTree:
                       _ptr(self.maps, C.c_double), _ptr(self.mapnames, C.c_int32))
 
 
-def make_rng(seed=1, replica=0, tape_u=None, tape_e=None):
+def make_rng(seed=1, replica=0, tape_u=None, tape_e=None, rstream=False):
     r = Rng()
     keep = []
+    if rstream:
+        r.mode = 2
+        r.seed_lo, r.seed_hi, r.replica = seed & 0xFFFFFFFF, 0, 0
+        return r, keep
     if tape_u is not None or tape_e is not None:
         r.mode = 1
         tu = np.ascontiguousarray(tape_u if tape_u is not None else [], dtype=np.float64)
@@ -116,7 +120,7 @@ def philox(ctr, key):
 
 
 def maketreelistMCMC(z, Q, pid, B, Omega, nen, nodelist, root, N, variant=PLAIN, seed=1, replica=0,
-                     faithful_search=False, tape_u=None, tape_e=None, dump=False, prior=None):
+                     faithful_search=False, tape_u=None, tape_e=None, dump=False, prior=None, rstream=False):
     Q = np.asarray(Q, dtype=np.float64)
     n = Q.shape[0]
     ft = FlatTree(z)
@@ -130,7 +134,7 @@ def maketreelistMCMC(z, Q, pid, B, Omega, nen, nodelist, root, N, variant=PLAIN,
     if variant == BF:
         cols = 9
     out = np.zeros((N, cols), order="F")
-    rng, keep = make_rng(seed, replica, tape_u, tape_e)
+    rng, keep = make_rng(seed, replica, tape_u, tape_e, rstream)
     if prior is not None:
         prior = np.ascontiguousarray(prior, dtype=np.float64)
         rc = lib().orc_maketreelistMCMC_qupdate(C.byref(ft.c), n, _ptr(Qc, C.c_double), _ptr(pid, C.c_double),

@@ -63,6 +63,44 @@ def test_log_exp_accuracy_and_python_twin():
         assert L.orc_exp(float(v)) == pyref.pexp(float(v))
 
 
+def test_r_stream_primitives():
+    """R-stream mode (tools/r_parity): set.seed scrambling + Mersenne-Twister + unif_rand + Ahrens-Dieter exp_rand
+    reproduce R's well-known outputs."""
+    import ctypes as C
+    L = O.lib()
+    def draws(seed, nu, ne):
+        u, e = np.zeros(max(nu, 1)), np.zeros(max(ne, 1))
+        L.orc_rstream_selftest(C.c_uint32(seed), nu, ne, u.ctypes.data_as(C.POINTER(C.c_double)), e.ctypes.data_as(C.POINTER(C.c_double)))
+        return u[:nu], e[:ne]
+    np.testing.assert_allclose(draws(42, 5, 0)[0], [0.9148060, 0.9370754, 0.2861395, 0.8304476, 0.6417455], atol=5e-8)
+    np.testing.assert_allclose(draws(1, 3, 0)[0], [0.2655087, 0.3721239, 0.5728534], atol=5e-8)
+    np.testing.assert_allclose(draws(123, 3, 0)[0], [0.2875775, 0.7883051, 0.4089769], atol=5e-8)
+    np.testing.assert_allclose(draws(42, 0, 5)[1], [0.1983368, 0.6608953, 0.2834910, 0.0381919, 0.4731766], atol=5e-8)
+    np.testing.assert_allclose(draws(1, 0, 3)[1], [0.7551818, 1.1816428, 0.1457067], atol=5e-8)
+    # the Ahrens-Dieter table is q[k-1] = sum_{j<=k} ln2^j / j!
+    import math
+    acc, q = 0.0, []
+    for j in range(1, 17):
+        acc += math.log(2.0) ** j / math.factorial(j)
+        q.append(acc)
+    assert abs(q[0] - 0.6931471805599453) < 1e-16 and abs(q[1] - 0.9333736875190459) < 1e-15 and abs(q[15] - 1.0) < 1e-15
+
+
+def test_r_stream_mode_runs_the_same_sampler():
+    """Sequential R stream instead of Philox: a different realisation of the same chain (invariants hold, statistics agree)."""
+    z, Q, pid, Omega = synth.config_problem(2, n_tips=25)
+    nen, nodelist, root = _orders(z)
+    B = np.eye(4) + Q / Omega
+    a, rc = O.maketreelistMCMC(z, Q, pid, B, Omega, nen, nodelist, root, 400, variant=O.BIGTREE, seed=7, rstream=True)
+    assert rc == 0
+    np.testing.assert_allclose(a[:, :4].sum(1), z["edge.length"].sum(), rtol=1e-12)
+    b, rc = O.maketreelistMCMC(z, Q, pid, B, Omega, nen, nodelist, root, 400, variant=O.BIGTREE, seed=7)
+    ja, jb = a[100:, 4:].sum(1), b[100:, 4:].sum(1)
+    assert abs(ja.mean() - jb.mean()) < 6 * 4 * np.hypot(ja.std(), jb.std()) / np.sqrt(300)
+    a2, _ = O.maketreelistMCMC(z, Q, pid, B, Omega, nen, nodelist, root, 400, variant=O.BIGTREE, seed=7, rstream=True)
+    np.testing.assert_array_equal(a, a2)
+
+
 # ---- per-function known answers (hand-derived) ---------------------------------------------------------
 def test_shortener_merges_and_counts():
     # states 0,0,2,2,1,0 with n=3: merged 0(1.5) 2(3.0) 1(4.0) 0(8.0); transitions 0->2, 2->1, 1->0

@@ -1,0 +1,38 @@
+"""Compare the R package's output (run_reference.R) with the oracle in R-stream mode (see README.md)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib as O  # noqa: E402
+
+d = sys.argv[1]
+edge = np.loadtxt(os.path.join(d, "edge.csv"), delimiter=",", dtype=np.int32)
+el = np.loadtxt(os.path.join(d, "edge_length.csv"))
+states = np.loadtxt(os.path.join(d, "states.csv"), dtype=np.int32)
+Q = np.loadtxt(os.path.join(d, "Q.csv"), delimiter=",")
+pid = np.loadtxt(os.path.join(d, "pid.csv"))
+par = np.genfromtxt(os.path.join(d, "params.csv"), delimiter=",", names=True)
+maps, names = [], []
+for line in open(os.path.join(d, "maps.csv")):
+    a, b = line.strip().split(";")
+    maps.append(np.array([float(v) for v in a.split()]))
+    names.append(np.array([int(v) for v in b.split()], dtype=np.int32))
+z = {"edge": edge, "Nnode": states.size - 1, "edge.length": el, "states": states, "maps": maps, "mapnames": names}
+nen = np.loadtxt(os.path.join(d, "nen.csv"), dtype=np.int32)
+nodelist = np.atleast_1d(np.loadtxt(os.path.join(d, "nodelist.csv"), dtype=np.int32))
+root = int(np.loadtxt(os.path.join(d, "root.csv")))
+Omega, N, seed = float(par["Omega"]), int(par["N"]), int(par["seed"])
+n = Q.shape[0]
+ok = True
+for name, var in (("sumstatMCMC", O.PLAIN), ("sumstatMCMC_bigtree", O.BIGTREE), ("SPARSEsumstatMCMC", O.SPARSE)):
+    want = np.loadtxt(os.path.join(d, name + ".csv"), delimiter=",")
+    got, rc = O.maketreelistMCMC(z, Q, pid, np.eye(n) + Q / Omega, Omega, nen, nodelist, root, N, variant=var, seed=seed, rstream=True)
+    counts = np.array_equal(got[:, n:], want[:, n:])
+    dwell = np.allclose(got[:, :n], want[:, :n], rtol=1e-10, atol=0)
+    print(f"{name}: rc={rc} counts {'EXACT' if counts else 'DIFFER'}, dwell {'within 1e-10' if dwell else 'DIFFER'}")
+    ok = ok and counts and dwell and rc == 0
+sys.exit(0 if ok else 1)

@@ -1,0 +1,33 @@
+# Runs the genuine phylomap package on the case written by export_case.py (see README.md).
+# Usage: Rscript run_reference.R case_dir
+library(ape); library(phylomap)
+d <- commandArgs(trailingOnly = TRUE)[1]
+edge <- as.matrix(read.csv(file.path(d, "edge.csv"), header = FALSE)); storage.mode(edge) <- "integer"; dimnames(edge) <- NULL
+el <- scan(file.path(d, "edge_length.csv"), quiet = TRUE)
+states <- scan(file.path(d, "states.csv"), quiet = TRUE)
+Q <- as.matrix(read.csv(file.path(d, "Q.csv"), header = FALSE)); dimnames(Q) <- NULL
+pid <- scan(file.path(d, "pid.csv"), quiet = TRUE)
+par <- read.csv(file.path(d, "params.csv"))
+ntip <- length(states)
+z <- list(edge = edge, Nnode = ntip - 1L, tip.label = paste0("t", 1:ntip), edge.length = el)
+class(z) <- "phylo"; attr(z, "order") <- "cladewise"
+lines <- readLines(file.path(d, "maps.csv"))
+z$maps <- list(); z$mapnames <- list()
+for (i in seq_along(lines)) {
+  p <- strsplit(lines[i], ";")[[1]]
+  dw <- as.numeric(strsplit(p[1], " ")[[1]]); st <- as.integer(strsplit(p[2], " ")[[1]])
+  names(dw) <- st; z$maps[[i]] <- dw; z$mapnames[[i]] <- st
+}
+z$states <- states
+z$node.states <- matrix(1L, nrow = nrow(edge), ncol = 2)
+# the helper preamble every wrapper carries (R/sumstatMCMC.R:1-18)
+nen <- pruningwiseedgeorder(z); nodelist <- makenodelist(z); root <- myreorder(z)
+write.table(nen, file.path(d, "nen.csv"), row.names = FALSE, col.names = FALSE)
+write.table(nodelist, file.path(d, "nodelist.csv"), row.names = FALSE, col.names = FALSE)
+write.table(root, file.path(d, "root.csv"), row.names = FALSE, col.names = FALSE)
+for (v in c("sumstatMCMC", "sumstatMCMC_bigtree", "SPARSEsumstatMCMC")) {
+  set.seed(par$seed)
+  ss <- do.call(v, list(z, Q, pid, par$Omega, par$N))
+  write.table(format(ss, digits = 17), file.path(d, paste0(v, ".csv")), sep = ",", row.names = FALSE, col.names = FALSE, quote = FALSE)
+}
+cat("done\n")
