@@ -76,8 +76,13 @@ def main():
     rank, world, local_rank = parallel.env_rank()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
+    # Rehearsal switches (never set by the driver): several ranks on ONE card with a gloo process group, to exercise the
+    # sharding / barrier / reduction logic where only one GPU is available.  The real N > 1 path is RCCL ("nccl").
+    backend = os.environ.get("PHM_DIST_BACKEND", "nccl")
+    if os.environ.get("PHM_ALL_RANKS_ON_DEVICE0") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
-    parallel.init_process_group("nccl")
+    parallel.init_process_group(backend, device_index=local_rank)
 
     z, Q, pid, Omega = synth.config_problem(args.config)
     n = Q.shape[0]
@@ -122,6 +127,8 @@ def main():
         except Exception:                                # no zero-copy view: one 30 KB host round trip instead
             eng.sync()
             total = torch.from_numpy(np.ascontiguousarray(eng.stats(W, K))).to(torch.device("cuda", local_rank))
+        if backend != "nccl":
+            total = total.cpu()
         parallel.allreduce_stats(total)
         torch.cuda.synchronize()
     eng.sync()
