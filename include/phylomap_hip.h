@@ -37,7 +37,8 @@ typedef enum phm_status {
   PHM_ERR_NO_DEVICE = 3,      /* no HIP device, or a HIP call failed */
   PHM_ERR_OOM = 4,            /* device memory */
   PHM_ERR_ZERO_PROB = 5,      /* all-zero / non-finite probability vector (RcppArmadillo::sample throws) */
-  PHM_ERR_CAPACITY = 6,       /* a branch outgrew its slot capacity (std::list in the reference is unbounded) */
+  PHM_ERR_CAPACITY = 6,       /* a replica tile outgrew its dwell-stream capacity, or (n > 4) a branch exceeded 128 segments
+                                 (std::list in the reference is unbounded) */
   PHM_ERR_UNIF_CAP = 7,       /* newunifSample needed > 300 jumps (src/phylomap.cpp:120-125) */
   PHM_ERR_STATE = 8           /* API misuse (engine not created, iteration range, ...) */
 } phm_status;
@@ -98,8 +99,10 @@ typedef struct phm_options {
 typedef struct phm_info {
   int32_t n_states, n_edge, n_replicas, n_replicas_padded, n_cols, max_iters;
   int64_t device_bytes;        /* HBM held by the engine */
-  int64_t rows_per_replica;    /* sum of per-branch slot capacities */
-  int64_t seg_read, seg_written; /* sum over branches x replicas x iterations of m_b and m'_b */
+  int64_t rows_per_replica;    /* capacity (64-lane rows) of one tile's dwell storage */
+  int64_t seg_read;            /* sum over branches x valid replicas x iterations run so far of (m_b + m'_b): segments
+                                  read plus segments written; feeds the algorithmic-bytes figure of bench.py */
+  int64_t seg_written;         /* reserved (0) */
   double  last_run_ms;         /* HIP-event time of the last phm_engine_run (all its launches) */
   int32_t last_run_launches;
   int32_t iters_done;

@@ -48,7 +48,5 @@ struct WideParams {
 
 size_t wide_lds_bytes(int n, bool sparse);
 hipError_t launch_mcmc_wide(const WideParams& p, int iter0, int n_iters, hipStream_t stream);
-hipError_t launch_stats_reduce_replicas(const double* stats, int n_iters, int n_cols, int n_rep, int n_rep_pad,
-                                        double* out, hipStream_t stream);
 
 }  // namespace phm

@@ -320,17 +320,6 @@ __global__ __launch_bounds__(WIDE_BLOCK) void mcmc_wide_kernel(WideParams p, int
   if (err) atomicOr(p.err, err);
 }
 
-// sum the per-replica statistics over the valid replicas, replica order: out[it][col]
-__global__ void stats_reduce_replicas_kernel(const double* __restrict__ stats, int n_iters, int n_cols, int n_rep,
-                                             int n_rep_pad, double* __restrict__ out) {
-  int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= n_iters * n_cols) return;
-  const double* src = stats + (size_t)idx * n_rep_pad;
-  double acc = 0.0;
-  for (int r = 0; r < n_rep; ++r) acc += src[r];
-  out[idx] = acc;
-}
-
 size_t wide_lds_bytes(int n, bool sparse) {
   return sizeof(double) * ((size_t)(sparse ? 2 : 1) * n * (n | 1) + n) + (size_t)(WIDE_BLOCK / 64) * wide_maxseg(n) * 64;
 }
@@ -344,14 +333,6 @@ hipError_t launch_mcmc_wide(const WideParams& p, int iter0, int n_iters, hipStre
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL(mcmc_wide_kernel, dim3((p.n_tiles + wpb - 1) / wpb), dim3(WIDE_BLOCK), lds, stream, p, iter0, n_iters);
-  return hipGetLastError();
-}
-
-hipError_t launch_stats_reduce_replicas(const double* stats, int n_iters, int n_cols, int n_rep, int n_rep_pad, double* out,
-                                        hipStream_t stream) {
-  int total = n_iters * n_cols;
-  hipLaunchKernelGGL(stats_reduce_replicas_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, stats, n_iters, n_cols,
-                     n_rep, n_rep_pad, out);
   return hipGetLastError();
 }
 
