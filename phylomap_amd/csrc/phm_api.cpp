@@ -766,7 +766,7 @@ int32_t phm_maketreelistEXP(const phm_tree* x, int32_t n, const double* Q, const
   if (!x || !Q || !pid || !lefts || !rights || !d || !out) return fail(PHM_ERR_BAD_INPUT, "phm_maketreelistEXP: NULL argument");
   if (N < 1) return fail(PHM_ERR_BAD_INPUT, "N must be >= 1");
   if (n < 2) return fail(PHM_ERR_BAD_INPUT, "n_states must be >= 2");
-  if (n > 4) return fail(PHM_ERR_UNSUPPORTED, "this build has EXP kernels for n_states in {2,3,4} only");
+  if (n > 64) return fail(PHM_ERR_UNSUPPORTED, "this build has EXP kernels for n_states <= 64 only");
   if (!x->edge_length) return fail(PHM_ERR_BAD_INPUT, "x$edge.length is required (src/phylomap.cpp:3034)");
   phm_options o;
   std::memset(&o, 0, sizeof(o));
@@ -842,6 +842,22 @@ int32_t phm_maketreelistEXP(const phm_tree* x, int32_t n, const double* Q, const
   if (n == 2) { phm::ExpParams<2> p; fill(p); le = phm::launch_exp_sample<2>(p, nullptr); }
   if (n == 3) { phm::ExpParams<3> p; fill(p); le = phm::launch_exp_sample<3>(p, nullptr); }
   if (n == 4) { phm::ExpParams<4> p; fill(p); le = phm::launch_exp_sample<4>(p, nullptr); }
+  if (n > 4) {
+    DevBuf dpid;
+    HIPCHK(dpid.alloc(sizeof(double) * n));
+    HIPCHK(hipMemcpy(dpid.p, pid, sizeof(double) * n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(dout.p, 0, dout.bytes));
+    phm::ExpWideParams p;
+    p.n_states = n; p.n_tips = T; p.n_node = s.n_node; p.n_edge = E; p.root = s.root; p.N = N; p.n_tiles = tiles;
+    p.seed_lo = (uint32_t)(o.seed & 0xFFFFFFFFull); p.seed_hi = (uint32_t)(o.seed >> 32); p.replica = (uint32_t)o.replica_offset;
+    p.poisson_rate = rate; p.pid = dpid.as<double>();
+    p.down = ddown.as<phm::DownStep>(); p.P = dP.as<double>(); p.PL = dPL.as<double>(); p.edge_length = dt.as<double>();
+    p.colpow = dcol.as<double>(); p.B2 = dB2.as<double>(); p.tips = dtips.as<uint8_t>(); p.nstate = dnst.as<uint8_t>();
+    p.times = dtimes.as<double>(); p.out = dout.as<double>(); p.err = derr.as<uint32_t>();
+    le = phm::launch_exp_wide(p, nullptr);
+    HIPCHK(le);
+    HIPCHK(hipDeviceSynchronize());
+  }
   HIPCHK(le);
   HIPCHK(hipMemcpy(out, dout.p, dout.bytes, hipMemcpyDeviceToHost));
   uint32_t derrh = 0;

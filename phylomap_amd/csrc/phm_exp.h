@@ -57,4 +57,25 @@ struct ExpParams {
 
 template <int NS> hipError_t launch_exp_sample(const ExpParams<NS>& p, hipStream_t stream);
 
+struct ExpWideParams {                         // 5 <= n <= 64: runtime state count, model vectors in global memory
+  int32_t n_states;
+  int32_t n_tips, n_node, n_edge, root;
+  int32_t N, n_tiles;
+  uint32_t seed_lo, seed_hi, replica;
+  double poisson_rate;
+  const double* pid;                           // [n]
+  const DownStep* down;
+  const double* P;                             // [n_edge][n][n]
+  const double* PL;                            // [2T-1][n]
+  const double* edge_length;
+  const double* colpow;                        // [UNIF_CAP+1][n][n]
+  const double* B2;                            // [n][n]
+  const uint8_t* tips;
+  uint8_t* nstate;                             // [tile][n_node][64]
+  double* times;                               // [tile][UNIF_CAP][64]
+  double* out;                                 // N x cols column-major, zeroed by the host, accumulated in place
+  uint32_t* err;
+};
+hipError_t launch_exp_wide(const ExpWideParams& p, hipStream_t stream);
+
 }  // namespace phm

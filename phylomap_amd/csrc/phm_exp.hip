@@ -343,6 +343,148 @@ template hipError_t launch_exp_sample<3>(const ExpParams<3>&, hipStream_t);
 template hipError_t launch_exp_sample<4>(const ExpParams<4>&, hipStream_t);
 
 // ------------------------------------------------------------------------------------------------
+// K5 for 5 <= n <= 64 states (the tutorial's 20-state tridiagonal Q, C4's 61 states): same algorithm and draw order as
+// exp_sample_kernel, one LANE per i.i.d. sample, with the n-vectors streamed instead of held in registers: every
+// categorical draw makes two passes over its weights (total, then running sum), the weights being recomputed from
+// P_b[ps,:] (.) PL[child,:] or B[prev,:] (.) B^(k-i) e_end on the fly.  Statistics go straight to the result matrix
+// (column-major N x cols, zeroed by the host): lanes are consecutive samples, so a column access is coalesced.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(EXP_BLOCK) void exp_wide_kernel(ExpWideParams p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int n = p.n_states;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int tile = blockIdx.x * (EXP_BLOCK / 64) + wave;
+  double* s_B2 = reinterpret_cast<double*>(smem);                            // [n][n]
+  for (int i = threadIdx.x; i < n * n; i += EXP_BLOCK) s_B2[i] = p.B2[i];
+  __syncthreads();
+  if (tile >= p.n_tiles) return;
+
+  const int it = tile * 64 + lane;
+  const bool valid = it < p.N;
+  const int itc = valid ? it : p.N - 1;          // padded lanes compute on a valid column and never store
+  uint32_t err = 0;
+  uint8_t* __restrict__ nst = p.nstate + (size_t)tile * p.n_node * 64;
+  double* __restrict__ tms = p.times + (size_t)tile * UNIF_CAP * 64;
+  double* __restrict__ orow = p.out + itc;                                    // + col * N
+  auto stat_add = [&](int col, double v) { if (valid) orow[(size_t)col * p.N] += v; };
+
+  // first j with u*sum(w) <= w_0+..+w_j, w_c = a[c]*b[c]   (sample_cat, index order)
+  auto draw_node = [&](const double* a, const double* b, double u) -> int {
+    double total = a[0] * b[0];
+    for (int c = 1; c < n; ++c) total += a[c] * b[c];
+    if (!(total > 0.0) || isinf(total)) err |= DERR_ZERO_PROB;
+    const double thr = u * total;
+    double cum = a[0] * b[0];
+    int idx = (thr <= cum) ? 0 : 1;
+    for (int c = 1; c < n; ++c) { cum += a[c] * b[c]; idx += (thr <= cum) ? 0 : 1; }
+    return idx < n ? idx : n - 1;
+  };
+
+  {
+    const double* plr = p.PL + (size_t)(p.root + p.n_tips) * n;
+    double u = stream_u(p.seed_lo, p.seed_hi, p.replica, (uint32_t)it, ENT_NODE | (uint32_t)(p.root + p.n_tips), 0);
+    nst[p.root * 64 + lane] = (uint8_t)draw_node(p.pid, plr, u);                // :2926-2934
+  }
+
+  for (int k = 0; k < p.n_edge; ++k) {
+    const DownStep ds = p.down[k];
+    const int b = ds.edge;
+    const int a = nst[ds.parent * 64 + lane];
+    const double* Pb = p.P + (size_t)b * n * n;
+    int e;
+    if (ds.child >= 0) {
+      double u = stream_u(p.seed_lo, p.seed_hi, p.replica, (uint32_t)it, ENT_NODE | (uint32_t)(ds.child + p.n_tips), 0);
+      e = draw_node(Pb + (size_t)a * n, p.PL + (size_t)(ds.child + p.n_tips) * n, u);   // :2953-2956
+      nst[ds.child * 64 + lane] = (uint8_t)e;
+    } else {
+      e = p.tips[~ds.child];
+    }
+
+    // ---- newunifSample(a, e, t_b, P_b[a,e]) :93-208 ----
+    const double tb = p.edge_length[b];
+    const double transProb = Pb[(size_t)a * n + e];
+    Stream sr;
+    sr.open(ENT_BUNIF | (uint32_t)b, (uint32_t)it, p.replica, p.seed_lo, p.seed_hi);
+    uint32_t dr = 0;
+    const double rU = sr.draw(dr++);
+    const double lam = p.poisson_rate * tb;
+    double pk = phm_exp(-lam);
+    double cum = 0.0;
+    if (a == e) cum = pk / transProb;
+    bool notExceed = !(cum > rU);
+    int nj = 0;
+    bool capped = false;
+    while (notExceed) {
+      nj++;
+      if (nj > UNIF_CAP) { capped = true; break; }
+      pk = pk * lam / (double)nj;
+      double nextProb = pk * p.colpow[((size_t)nj * n + e) * n + a] / transProb;
+      cum += nextProb;
+      if (cum > rU) notExceed = false;
+    }
+    if (capped) { err |= DERR_UNIF_CAP; continue; }
+    auto count = [&](int from, int to) { stat_add(n + from * (n - 1) + (to > from ? to - 1 : to), 1.0); };
+    if (nj == 0 || (nj == 1 && a == e)) {
+      stat_add(a, tb - 0.0);
+    } else if (nj == 1) {
+      double tj = tb * sr.draw(dr++);
+      stat_add(a, tj - 0.0);
+      stat_add(e, tb - tj);
+      count(a, e);
+    } else {
+      for (int i = 0; i < nj; ++i) {
+        double v = tb * sr.draw(dr++);
+        int j = i - 1;
+        while (j >= 0) {
+          double tj = tms[j * 64 + lane];
+          if (!(tj > v)) break;
+          tms[(j + 1) * 64 + lane] = tj;
+          --j;
+        }
+        tms[(j + 1) * 64 + lane] = v;
+      }
+      int prev = a, sprev = a;
+      double tprev = 0.0;
+      for (int i = 1; i <= nj; ++i) {
+        int di = e;
+        if (i < nj) {                                                         // sampleOnce :81-90, :158-160
+          const double* beta = p.colpow + ((size_t)(nj - i) * n + e) * n;
+          const double* row = s_B2 + prev * n;
+          double total = row[0] * beta[0];
+          for (int c = 1; c < n; ++c) total += row[c] * beta[c];
+          const double u = sr.draw(dr++);
+          double cw = 0.0;
+          int pick = n;
+          for (int c = 0; c < n; ++c) {
+            cw += (row[c] * beta[c]) / total;
+            if (pick == n && u < cw) pick = c;
+          }
+          if (pick == n) { err |= DERR_SAMPLEONCE; pick = n - 1; }
+          di = pick;
+        }
+        if (prev != di) {
+          double ti = tms[(i - 1) * 64 + lane];
+          stat_add(sprev, ti - tprev);
+          count(sprev, di);
+          tprev = ti; sprev = di;
+        }
+        prev = di;
+      }
+      stat_add(sprev, tb - tprev);
+    }
+  }
+  if (valid && err) atomicOr(p.err, err);
+}
+
+hipError_t launch_exp_wide(const ExpWideParams& p, hipStream_t stream) {
+  constexpr int W = EXP_BLOCK / 64;
+  size_t lds = sizeof(double) * (size_t)p.n_states * p.n_states;
+  hipLaunchKernelGGL(exp_wide_kernel, dim3((p.n_tiles + W - 1) / W), dim3(EXP_BLOCK), lds, stream, p);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // K1 on the matrix cores: P_b = |(L diag(exp(d t_b))) R| as a batched small GEMM with MFMA f64 16x16x4.
 // For 16 < n <= 64 (C4's 61-state Q pads to 64).  R and L are the same for every branch, so each wave keeps its
 // MFMA fragments of both in registers for the whole batch (R: its 16-column block; L: all four row blocks) and a

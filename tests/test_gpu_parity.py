@@ -358,6 +358,50 @@ def test_exp_matches_oracle(n):
     np.testing.assert_array_equal(got, want)
 
 
+@pytest.mark.parametrize("n", [5, 20, 61])
+def test_exp_wide_matches_oracle(n):
+    """sumstatEXP for 5..64 states (the tutorial's 20-state tridiagonal Q, vignettes/phylomap_tutorial.Rnw:72-134)."""
+    if n == 20:
+        Q = synth.tridiagonal_Q(20, 0.03)
+    else:
+        Q = synth.dense_Q(n, 0.005, 0.03, seed=n)
+        Q = (Q + Q.T) / 2
+        np.fill_diagonal(Q, 0.0)
+        np.fill_diagonal(Q, -Q.sum(1))
+    pid = np.full(n, 1.0 / n)
+    z = synth.make_tree(12 if n == 61 else 30, Q, 1.25 * float(np.max(np.abs(np.diag(Q)))), 70 + n, pid)
+    nen, nodelist, root = _orders(z)
+    lefts, rights, d = api.eigen_decompose(Q)
+    N = 150
+    got = api.sumstatEXP(z, Q, pid, N, seed=23)
+    want, rc = O.maketreelistEXP(z, Q, pid, nen, nodelist, root, N, lefts, rights, d, seed=23)
+    assert rc == 0
+    np.testing.assert_array_equal(got[:, n:], want[:, n:])
+    np.testing.assert_array_equal(got[:, :n], want[:, :n])
+    np.testing.assert_allclose(got[:, :n].sum(1), z["edge.length"].sum(), rtol=1e-12)
+
+
+def test_tutorial_three_way_agreement_on_gpu():
+    """The reference's own validation (vignettes/phylomap_tutorial.Rnw:72-134): 20-state tridiagonal Q (rate .003), 50 tips,
+    Omega = 0.2; total jump counts from sumstatEXP, sumstatMCMC and SPARSEsumstatMCMC must agree in distribution."""
+    Q = synth.tridiagonal_Q(20, 0.003)
+    Omega = 0.2
+    pid = np.full(20, 1 / 20)
+    z = synth.make_tree(50, Q, 4.0 / 30.0, 321, pid, init_segments=20)      # mean branch length 30: a few jumps per tree
+    ex = api.sumstatEXP(z, Q, pid, 20000, seed=1)
+    je = ex[:, 20:].sum(1)
+    means = {"EXP": je.mean()}
+    for name, fn in (("MCMC", api.sumstatMCMC), ("SPARSE", api.SPARSEsumstatMCMC)):
+        out = fn(z, Q, pid, Omega, 360, seed=2, n_replicas=64)                # 64 chains, first 120 sweeps dropped
+        jm = out[:, 120:, 20:].sum(2)
+        means[name] = jm.mean()
+        chain_means = jm.mean(1)
+        se = np.hypot(chain_means.std() / np.sqrt(64), je.std() / np.sqrt(je.size))
+        assert abs(means[name] - means["EXP"]) < 6 * se, means
+        np.testing.assert_allclose(out[:, 120:, :20].mean((0, 1)), ex[:, :20].mean(0), rtol=0.15, atol=1.0)
+    assert means["EXP"] > 1.0
+
+
 @pytest.mark.parametrize("n", [2, 4, 20, 61])
 def test_expm_routes(n):
     from scipy.linalg import expm
