@@ -153,6 +153,17 @@ int32_t phm_maketreelistMCMCks(       /* src/phylomap.cpp:1802, src/RcppExports.
     const phm_tree* x, int32_t n_states, const double* Q, const double* pid, const double* B, double Omega,
     const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N, const double* prior, int32_t n_prior,
     const phm_options* opt, double* out);
+/* The DIC drivers: the bf / ks drivers plus log p(y|Q) by matrix exponentiation every iteration (expmat(Q t_b) for every
+ * branch -- Pade scaling-and-squaring on the device -- then pruning with scale factors in nen order), appended as the last
+ * column: out is N x 10 (2sDICt) or N x (n+n*n+2+3k+2) (ksDICt).  One chain (n_replicas = 1); needs x->edge_length. */
+int32_t phm_maketreelistMCMC2sDICt(   /* src/phylomap.cpp:3183, src/RcppExports.cpp:211 */
+    const phm_tree* x, int32_t n_states, const double* Q, const double* pid, const double* B, double Omega,
+    const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N, const double* prior, int32_t n_prior,
+    const phm_options* opt, double* out);
+int32_t phm_maketreelistMCMCksDICt(   /* src/phylomap.cpp:3300, src/RcppExports.cpp:237 */
+    const phm_tree* x, int32_t n_states, const double* Q, const double* pid, const double* B, double Omega,
+    const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N, const double* prior, int32_t n_prior,
+    const phm_options* opt, double* out);
 int32_t phm_maketreelistEXP(          /* src/phylomap.cpp:3001, src/RcppExports.cpp:80 */
     const phm_tree* x, int32_t n_states, const double* Q, const double* pid,
     const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,

@@ -728,8 +728,9 @@ static void updategammas(double* Q, int n, double Omega, const double* prior, co
 static int mcmc_driver(const orc_tree* x, int n, const double* Q_cm, const double* pid,
                          const double* B_cm, double Omega, const int32_t* nen,
                          const int32_t* nodelist, int32_t root, int32_t N, int variant,
-                         int faithful_search, orc_rng* rng, double* out, orc_dump* dump, const double* prior) {
+                         int faithful_search, orc_rng* rng, double* out, orc_dump* dump, const double* prior, int dic) {
   int e = check_tree(x); if (e) return e;
+  if (dic && (!prior || !x->edge_length)) return ORC_ERR_BAD_INPUT;
   if (n < 2 || N < 0) return ORC_ERR_BAD_INPUT;
   int E = x->n_edge, T = x->n_tips, Nnode = x->n_node;
   const int32_t* edge1 = x->edge; const int32_t* edge2 = x->edge + E;
@@ -738,7 +739,7 @@ static int mcmc_driver(const orc_tree* x, int n, const double* Q_cm, const doubl
   if (ks == 2 && n != 2) return ORC_ERR_BAD_INPUT;            /* recordQ / updatel01 hard-wire two states (:1181-1185) */
   if (prior && (!ks || (ks == 1 && n < 4) || n > 64)) return ORC_ERR_BAD_INPUT;
   const int kk = (ks == 1) ? n / 2 - 1 : 0;
-  int cols = ks ? n + n * n + 2 + 3 * kk + 1 : n + n * (n - 1);
+  int cols = ks ? n + n * n + 2 + 3 * kk + 1 + (dic ? 1 : 0) : n + n * (n - 1);
   double* Q = (double*)malloc(sizeof(double) * n * n);        /* row-major working copy; the updates edit it */
   for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) QQ(i, j) = Q_cm[i + (size_t)j * n];
   rngctx rc = { rng, 0 };
@@ -787,11 +788,43 @@ static int mcmc_driver(const orc_tree* x, int n, const double* Q_cm, const doubl
     }
     sampleinternalnodesMCMC(brs, E, PL, pid, Bc, root, nodelist, Nnode - 1, nen, edge1, edge2, Nnode,
                             x->states, T, normalise, n, faithful_search, eoc, &rc, (uint32_t)it, rm, bl, w, ks, &rootst);
-    if (ks) out[(int64_t)(n + n * n + 2 + 3 * kk) * N + it] = rootst;
+    if (ks) out[(int64_t)(n + n * n + 2 + 3 * kk) * N + it] = rootst;      /* root column; the DIC drivers add log p(y|Q) after it */
     updatenodestates(brs, edge1, edge2, E, rm);                                              /* :779 / :1426 */
     for (int i = 0; i < E; ++i)                                                              /* :781 / :1428 */
       sampleabranch(&brs[i], Bc, B2, Omega, Qd, ks ? -n : n, out, N, it, &rc, (uint32_t)i, &scratch, &scratch_len, &tmp);
     for (int i = 0; i < E; ++i) updatedwelltimes(it, &brs[i], out, N);                       /* :782 */
+    if (dic) {
+      /* log p(y|Q) by matrix exponentiation, maketreelistMCMC2sDICt :3239-3251 / ksDICt :3379-3391:
+         P_b = expmat(Q t_b); PPmakePLD / PPmakePLksD (:3158-3178, :3268-3297) prune with row normalisation and sum the
+         log scale factors in nen order; log(sum_j PL[root,j] pid_j) + S goes into the last column */
+      size_t nn2 = (size_t)n * n;
+      double* Pm = (double*)malloc(sizeof(double) * nn2 * (E + 1));
+      double* A = Pm + nn2 * E;
+      for (int b = 0; b < E; ++b) {
+        for (size_t q = 0; q < nn2; ++q) A[q] = Q[q] * x->edge_length[b];
+        if (orc_expmat_pade(A, n, Pm + nn2 * b)) rc.err |= ORC_ERR_BAD_INPUT;
+      }
+      double* PL2 = (double*)calloc(pl_len, sizeof(double));
+      if (ks != 1) for (int i = 0; i < T; ++i) PL2[(size_t)i * n + (x->states[i] - 1)] = 1.0;
+      else for (int i = 0; i < T; ++i) for (int j = (x->states[i] % 2 == 0) ? 1 : 0; j < n; j += 2) PL2[(size_t)i * n + j] = 1.0;
+      double S = 0;
+      double* va = w; double* vb = w + n;
+      for (int i = 0; i < Nnode; ++i) {
+        int ea = nen[2 * i] - 1, eb = nen[2 * i + 1] - 1;
+        matvec(Pm + nn2 * ea, PL2 + (size_t)(edge2[ea] - 1) * n, va, n);
+        matvec(Pm + nn2 * eb, PL2 + (size_t)(edge2[eb] - 1) * n, vb, n);
+        double* row = PL2 + (size_t)(edge1[ea] - 1) * n;
+        for (int c = 0; c < n; ++c) row[c] = va[c] * vb[c];
+        double sm = row[0];
+        for (int c = 1; c < n; ++c) sm += row[c];
+        S = S + orc_log(sm);
+        for (int c = 0; c < n; ++c) row[c] = row[c] / sm;
+      }
+      double X = 0;
+      for (int j = 0; j < n; ++j) X = X + PL2[(size_t)(root - 1) * n + j] * pid[j];
+      out[(int64_t)(cols - 1) * N + it] = orc_log(X) + S;
+      free(PL2); free(Pm);
+    }
     if (prior) {                                              /* maketreelistMCMCbf :1299-1300 / maketreelistMCMCks :1862-1866 */
       hstream h = { &rc, (uint32_t)it, 0, 0 };
 #define HS(id) (h.ent = 0xFFFFFF00u | (uint32_t)(id), h.d = 0, &h)
@@ -826,7 +859,7 @@ static int mcmc_driver(const orc_tree* x, int n, const double* Q_cm, const doubl
 int orc_maketreelistMCMC(const orc_tree* x, int n, const double* Q_cm, const double* pid, const double* B_cm, double Omega,
                          const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N, int variant,
                          int faithful_search, orc_rng* rng, double* out, orc_dump* dump) {
-  return mcmc_driver(x, n, Q_cm, pid, B_cm, Omega, nen, nodelist, root, N, variant, faithful_search, rng, out, dump, NULL);
+  return mcmc_driver(x, n, Q_cm, pid, B_cm, Omega, nen, nodelist, root, N, variant, faithful_search, rng, out, dump, NULL, 0);
 }
 
 /* maketreelistMCMCbf :1258-1305 (variant ORC_MCMC_BF, prior = 4 numbers) and maketreelistMCMCks :1802-1872
@@ -836,7 +869,9 @@ int orc_maketreelistMCMC_qupdate(const orc_tree* x, int n, const double* Q_cm, c
                                  int variant, const double* prior, int faithful_search, orc_rng* rng, double* out,
                                  orc_dump* dump) {
   if (!prior) return ORC_ERR_BAD_INPUT;
-  return mcmc_driver(x, n, Q_cm, pid, B_cm, Omega, nen, nodelist, root, N, variant, faithful_search, rng, out, dump, prior);
+  /* variant | 16: the DIC drivers maketreelistMCMC2sDICt :3183-3264 / maketreelistMCMCksDICt :3300-3403 (one more column) */
+  return mcmc_driver(x, n, Q_cm, pid, B_cm, Omega, nen, nodelist, root, N, variant & 15, faithful_search, rng, out, dump, prior,
+                     (variant & 16) != 0);
 }
 
 /* one iteration's updates applied to a row-major Q given a statistics row (test entry point) */

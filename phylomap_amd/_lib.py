@@ -18,7 +18,7 @@ PHM_MCMC, PHM_MCMC_BIGTREE, PHM_MCMC_SPARSE, PHM_MCMC_KS, PHM_MCMC_BF = 0, 1, 2,
 EXPORTS = [
     "phm_version", "phm_device_count", "phm_last_error", "phm_status_string",
     "phm_maketreelistMCMC", "phm_maketreelistMCMC_bigtree", "phm_SPARSEmaketreelistMCMC", "phm_maketreelistEXP",
-    "phm_maketreelistMCMCks_sweep", "phm_maketreelistMCMCbf", "phm_maketreelistMCMCks", "phm_engine_set_model", "phm_qupdate_apply",
+    "phm_maketreelistMCMCks_sweep", "phm_maketreelistMCMCbf", "phm_maketreelistMCMCks", "phm_maketreelistMCMC2sDICt", "phm_maketreelistMCMCksDICt", "phm_engine_set_model", "phm_qupdate_apply",
     "phm_expm_eigen", "phm_expm_eigen_mfma", "phm_expm_pade", "phm_expm_pade_mfma",
     "phm_engine_create", "phm_engine_run", "phm_engine_sync", "phm_engine_read_stats", "phm_engine_dump",
     "phm_engine_info", "phm_engine_destroy", "phm_engine_reduced_stats_device",
@@ -101,6 +101,8 @@ def load():
         mcq = mc[:10] + [C.POINTER(C.c_double), C.c_int32] + mc[10:]
         L.phm_maketreelistMCMCbf.argtypes = mcq
         L.phm_maketreelistMCMCks.argtypes = mcq
+        L.phm_maketreelistMCMC2sDICt.argtypes = mcq
+        L.phm_maketreelistMCMCksDICt.argtypes = mcq
         L.phm_engine_set_model.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         L.phm_qupdate_apply.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_double),
                                         C.c_int32, C.POINTER(C.c_double), C.c_uint64, C.c_uint32]

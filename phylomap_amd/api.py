@@ -97,6 +97,18 @@ def sumstatMCMCks(z, Q, pid, Omega, N, prior, **opt):
     return _qupdate("phm_maketreelistMCMCks", z, Q, pid, Omega, N, prior, n + n * n + 2 + 3 * (n // 2 - 1) + 1, **opt)
 
 
+def sumstatMCMC2sDICt(z, Q, pid, Omega, N, prior, **opt):
+    """R/sumstatMCMC2sDICt.R -> phm_maketreelistMCMC2sDICt: ``sumstatMCMCbf`` plus log p(y|Q) (matrix exponentiation) per
+    iteration; columns time 0, time 1, n00, n01, n10, n11, l01, l10, root_state, log(p(y|Q))."""
+    return _qupdate("phm_maketreelistMCMC2sDICt", z, Q, pid, Omega, N, prior, 10, **opt)
+
+
+def sumstatMCMCksDICt(z, Q, pid, Omega, N, prior, **opt):
+    """R/sumstatMCMCksDICt.R -> phm_maketreelistMCMCksDICt: ``sumstatMCMCks`` plus log p(y|Q) per iteration (last column)."""
+    n = np.asarray(Q).shape[0]
+    return _qupdate("phm_maketreelistMCMCksDICt", z, Q, pid, Omega, N, prior, n + n * n + 2 + 3 * (n // 2 - 1) + 2, **opt)
+
+
 def eigen_decompose(Q):
     """R/sumstatEXP.R:26-29: lefts = eigen(Q)$vectors, rights = solve(lefts), d = diag(values) (real spectrum only)."""
     vals, vecs = np.linalg.eig(np.asarray(Q, dtype=np.float64))

@@ -934,19 +934,21 @@ extern "C" int32_t phm_engine_set_model(phm_engine* e, const double* Q) {
 // maketreelistMCMCbf src/phylomap.cpp:1258-1305 (R/sumstatMCMCbf.R) and maketreelistMCMCks :1802-1872 (R/sumstatMCMCks.R).
 // With opt->n_replicas = S > 1 the replicas are sites sharing one Q: the update sees the statistics summed over sites and
 // `out` holds those sums (S = 1 is the reference's semantics exactly).
-static int32_t run_qupdate(int variant, const phm_tree* x, int32_t n, const double* Q, const double* pid, const double* B,
-                           double Omega, const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
+static int32_t run_qupdate(int variant, bool dic, const phm_tree* x, int32_t n, const double* Q, const double* pid,
+                           const double* B, double Omega, const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
                            const double* prior, int32_t n_prior, const phm_options* opt_in, double* out) {
   if (!out || !prior || !Q) return fail(PHM_ERR_BAD_INPUT, "out/prior/Q is NULL");
   if (N < 1) return fail(PHM_ERR_BAD_INPUT, "N must be >= 1");
   const int need = (variant == PHM_MCMC_BF) ? 4 : 6;
-  if (n_prior < need) return fail(PHM_ERR_BAD_INPUT, variant == PHM_MCMC_BF ? "sumstatMCMCbf needs prior = c(a01, b01, a10, b10)" : "sumstatMCMCks needs prior = c(a_l, b_l, a_k, b_k, a_g, b_g)");
+  if (n_prior < need) return fail(PHM_ERR_BAD_INPUT, variant == PHM_MCMC_BF ? "the two-state drivers need prior = c(a01, b01, a10, b10)" : "the hidden-rates drivers need prior = c(a_l, b_l, a_k, b_k, a_g, b_g)");
   if (variant == PHM_MCMC_KS && (n < 4 || (n & 1))) return fail(PHM_ERR_BAD_INPUT, "sumstatMCMCks needs n = 2k+2 states with k >= 1 (src/phylomap.cpp:1820; updateksl01 reads rkappas(0))");
+  if (dic && (!x || !x->edge_length || !nen)) return fail(PHM_ERR_BAD_INPUT, "the DIC drivers need x$edge.length and nen (src/phylomap.cpp:3223, :3158)");
   phm_options o;
   std::memset(&o, 0, sizeof(o));
   o.device = -1;
   if (opt_in) o = *opt_in;
   if (o.n_replicas <= 0) o.n_replicas = 1;
+  if (dic && o.n_replicas != 1) return fail(PHM_ERR_UNSUPPORTED, "the DIC drivers run one chain (log p(y|Q) is per data set)");
   o.reduce = o.n_replicas > 1;     // one chain: its own statistics, accumulated in the reference's order (bit-exact vs the oracle)
   o.iters_per_launch = 1;
   (void)B;     // the reference aliases the caller's B and then overwrites it entry by entry; B = I + Q/Omega throughout
@@ -955,33 +957,84 @@ static int32_t run_qupdate(int variant, const phm_tree* x, int32_t n, const doub
   phm_engine* e = nullptr;
   int32_t st = phm_engine_create(x, &model, &o, N, &e);
   if (st) return st;
+  std::unique_ptr<phm_engine, void (*)(phm_engine*)> guard(e, phm_engine_destroy);
   std::string serr;
-  if (!phm::check_reference_orders(e->sched, x->edge, nen, nodelist, root, serr)) { phm_engine_destroy(e); return fail(PHM_ERR_BAD_INPUT, serr); }
-  std::vector<double> Qw(Q, Q + (size_t)n * n), row(e->cols);
+  if (!phm::check_reference_orders(e->sched, x->edge, nen, nodelist, root, serr)) return fail(PHM_ERR_BAD_INPUT, serr);
+  const int ecols = e->cols, E = e->sched.n_edge, T = e->sched.n_tips, Nn = e->sched.n_node;
+  const size_t nn = (size_t)n * n;
+
+  // DIC: device state of the per-iteration log-likelihood (expmat(Q t_b) for every branch, then pruning in nen order)
+  DevBuf dQ, dt, ds, dwork, dP, dPL0, dPL, dpid, dup, dll, derr;
+  std::vector<double> loglik;
+  std::vector<int32_t> sq(E);
+  if (dic) {
+    std::vector<phm::UpStep> upn(Nn);
+    const int32_t* e1 = x->edge; const int32_t* e2 = x->edge + E;
+    auto code = [&](int32_t node) { return node > T ? node - T - 1 : ~(node - 1); };
+    for (int i = 0; i < Nn; ++i) {
+      const int ea = nen[2 * i] - 1, eb = nen[2 * i + 1] - 1;
+      upn[i].parent = e1[ea] - T - 1;
+      upn[i].child[0] = code(e2[ea]); upn[i].child[1] = code(e2[eb]);
+      upn[i].edge[0] = ea; upn[i].edge[1] = eb;
+    }
+    std::vector<double> PLh((size_t)(2 * T - 1) * n, 0.0);
+    for (int t = 0; t < T; ++t) {
+      if (variant == PHM_MCMC_BF) PLh[(size_t)t * n + (x->states[t] - 1)] = 1.0;                         // :3165
+      else for (int j = (x->states[t] % 2 == 0) ? 1 : 0; j < n; j += 2) PLh[(size_t)t * n + j] = 1.0;   // :3275-3282
+    }
+    HIPCHK(dQ.alloc(sizeof(double) * nn)); HIPCHK(dt.alloc(sizeof(double) * E)); HIPCHK(ds.alloc(sizeof(int32_t) * E));
+    HIPCHK(dwork.alloc(sizeof(double) * nn * 5 * E)); HIPCHK(dP.alloc(sizeof(double) * nn * E));
+    HIPCHK(dPL0.alloc(sizeof(double) * PLh.size())); HIPCHK(dPL.alloc(sizeof(double) * PLh.size()));
+    HIPCHK(dpid.alloc(sizeof(double) * n)); HIPCHK(dup.alloc(sizeof(phm::UpStep) * Nn)); HIPCHK(dll.alloc(sizeof(double)));
+    HIPCHK(derr.alloc(sizeof(uint32_t)));
+    HIPCHK(hipMemcpy(dt.p, x->edge_length, dt.bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dPL0.p, PLh.data(), dPL0.bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dpid.p, pid, dpid.bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dup.p, upn.data(), dup.bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(derr.p, 0, sizeof(uint32_t)));
+    loglik.resize(N);
+  }
+
+  std::vector<double> Qw(Q, Q + nn), Qr, row(ecols);
   for (int i = 0; i < N && !st; ++i) {
     st = phm_engine_run(e, 1, nullptr);
     if (!st) st = phm_engine_sync(e);
     if (!st) st = phm_engine_read_stats(e, i, 1, row.data());
     if (st) break;
+    if (dic) {                                        // :3239-3251 / :3379-3391, with the Q that drove this sweep
+      cm_to_rm(Qw.data(), n, Qr);
+      for (int b = 0; b < E; ++b) sq[b] = pade_squarings(Qr.data(), n, x->edge_length[b]);
+      HIPCHK(hipMemcpy(dQ.p, Qr.data(), dQ.bytes, hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(ds.p, sq.data(), ds.bytes, hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpyAsync(dPL.p, dPL0.p, dPL.bytes, hipMemcpyDeviceToDevice, nullptr));
+      HIPCHK(phm::launch_expm_pade(n, dQ.as<double>(), dt.as<double>(), ds.as<int32_t>(), E, dwork.as<double>(), dP.as<double>(), derr.as<uint32_t>(), nullptr));
+      HIPCHK(phm::launch_exp_pl_loglik(n, Nn, T, dup.as<phm::UpStep>(), dP.as<double>(), dPL.as<double>(), dpid.as<double>(), root - 1, dll.as<double>(), nullptr));
+      HIPCHK(hipMemcpy(&loglik[i], dll.p, sizeof(double), hipMemcpyDeviceToHost));
+    }
     if (variant == PHM_MCMC_BF) phm::bf_updates(Qw.data(), Omega, prior, row.data(), o.seed, (uint32_t)i);
     else phm::ks_updates(Qw.data(), n, Omega, prior, row.data(), o.seed, (uint32_t)i);
     if (i + 1 < N) st = phm_engine_set_model(e, Qw.data());
   }
-  if (!st) st = phm_engine_read_stats(e, 0, N, out);
-  phm_engine_destroy(e);
-  return st;
+  if (st) return st;
+  if (!dic) return phm_engine_read_stats(e, 0, N, out);
+  std::vector<double> tmp((size_t)N * ecols);
+  st = phm_engine_read_stats(e, 0, N, tmp.data());
+  if (st) return st;
+  std::memcpy(out, tmp.data(), sizeof(double) * tmp.size());           // column-major: the first ecols columns are unchanged
+  for (int i = 0; i < N; ++i) out[(size_t)ecols * N + i] = loglik[i];     // log p(y|Q) after the root-state column
+  return PHM_OK;
 }
 
 extern "C" int32_t phm_maketreelistMCMCbf(const phm_tree* x, int32_t n, const double* Q, const double* pid, const double* B,
                                           double Omega, const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
                                           const double* prior, int32_t n_prior, const phm_options* opt, double* out) {
-  return run_qupdate(PHM_MCMC_BF, x, n, Q, pid, B, Omega, nen, nodelist, root, N, prior, n_prior, opt, out);
+  return run_qupdate(PHM_MCMC_BF, false, x, n, Q, pid, B, Omega, nen, nodelist, root, N, prior, n_prior, opt, out);
 }
 
 extern "C" int32_t phm_maketreelistMCMCks(const phm_tree* x, int32_t n, const double* Q, const double* pid, const double* B,
                                           double Omega, const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
                                           const double* prior, int32_t n_prior, const phm_options* opt, double* out) {
-  return run_qupdate(PHM_MCMC_KS, x, n, Q, pid, B, Omega, nen, nodelist, root, N, prior, n_prior, opt, out);
+  return run_qupdate(PHM_MCMC_KS, false, x, n, Q, pid, B, Omega, nen, nodelist, root, N, prior, n_prior, opt, out);
 }
 
 // Host-only: apply one iteration's rate-matrix updates to Q (column-major, edited in place) given a statistics row
@@ -997,4 +1050,18 @@ extern "C" int32_t phm_qupdate_apply(int32_t variant, int32_t n, double* Q, doub
     phm::ks_updates(Q, n, Omega, prior, row, seed, iter);
   } else return fail(PHM_ERR_BAD_INPUT, "variant must be PHM_MCMC_BF or PHM_MCMC_KS");
   return PHM_OK;
+}
+
+// maketreelistMCMC2sDICt src/phylomap.cpp:3183-3264 and maketreelistMCMCksDICt :3300-3403: the bf / ks drivers plus, every
+// iteration, log p(y|Q) by matrix exponentiation (expmat(Q t_b) for every branch, pruning with scale factors) in one more column.
+extern "C" int32_t phm_maketreelistMCMC2sDICt(const phm_tree* x, int32_t n, const double* Q, const double* pid, const double* B,
+                                              double Omega, const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
+                                              const double* prior, int32_t n_prior, const phm_options* opt, double* out) {
+  return run_qupdate(PHM_MCMC_BF, true, x, n, Q, pid, B, Omega, nen, nodelist, root, N, prior, n_prior, opt, out);
+}
+
+extern "C" int32_t phm_maketreelistMCMCksDICt(const phm_tree* x, int32_t n, const double* Q, const double* pid, const double* B,
+                                              double Omega, const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
+                                              const double* prior, int32_t n_prior, const phm_options* opt, double* out) {
+  return run_qupdate(PHM_MCMC_KS, true, x, n, Q, pid, B, Omega, nen, nodelist, root, N, prior, n_prior, opt, out);
 }

@@ -34,6 +34,10 @@ hipError_t launch_expm_pade_mfma(int n, const double* Q, const double* t, const 
 hipError_t launch_exp_pl(int n, int n_node, int n_tips, const UpStep* up, const double* P, double* PL,
                          hipStream_t stream);
 
+// log p(y|Q): pruning with P(t_b), rows normalised, log scale factors summed in the order of `up` (DIC drivers)
+hipError_t launch_exp_pl_loglik(int n, int n_node, int n_tips, const UpStep* up, const double* P, double* PL,
+                                const double* pid, int root_node, double* out_ll, hipStream_t stream);
+
 template <int NS>
 struct ExpParams {
   int32_t n_tips, n_node, n_edge, root;      // root: internal index

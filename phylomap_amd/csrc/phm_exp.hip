@@ -180,6 +180,50 @@ hipError_t launch_exp_pl(int n, int n_node, int n_tips, const UpStep* up, const 
 }
 
 // ------------------------------------------------------------------------------------------------
+// log p(y|Q) by matrix exponentiation (the DIC drivers: PPmakePLD :3158-3178, PPmakePLksD :3268-3297): pruning with
+// P(t_b), every internal row divided by its sum, the log scale factors accumulated in the caller's pruningwise order
+// (`up` is built from nen), then log(sum_j PL[root,j] pid_j) + S.  One thread: the tree is walked once per MCMC
+// iteration and the result is a single number.
+// ------------------------------------------------------------------------------------------------
+__global__ void exp_pl_loglik_kernel(int n, int n_node, int n_tips, const UpStep* __restrict__ up,
+                                     const double* __restrict__ P, double* __restrict__ PL, const double* __restrict__ pid,
+                                     int root_node, double* __restrict__ out_ll) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  double S = 0;
+  for (int k = 0; k < n_node; ++k) {
+    const UpStep st = up[k];
+    const int ca = st.child[0] >= 0 ? st.child[0] + n_tips : ~st.child[0];
+    const int cb = st.child[1] >= 0 ? st.child[1] + n_tips : ~st.child[1];
+    const double* Pa = P + (size_t)st.edge[0] * n * n;
+    const double* Pb = P + (size_t)st.edge[1] * n * n;
+    const double* va = PL + (size_t)ca * n;
+    const double* vb = PL + (size_t)cb * n;
+    double* dst = PL + (size_t)(st.parent + n_tips) * n;
+    double sm = 0.0;
+    for (int i = 0; i < n; ++i) {
+      double a = Pa[i * n] * va[0];
+      for (int j = 1; j < n; ++j) a += Pa[i * n + j] * va[j];
+      double b = Pb[i * n] * vb[0];
+      for (int j = 1; j < n; ++j) b += Pb[i * n + j] * vb[j];
+      const double r = a * b;
+      dst[i] = r;
+      sm = (i == 0) ? r : sm + r;
+    }
+    S = S + phm_log(sm);
+    for (int i = 0; i < n; ++i) dst[i] = dst[i] / sm;
+  }
+  double X = 0;
+  for (int j = 0; j < n; ++j) X = X + PL[(size_t)root_node * n + j] * pid[j];
+  *out_ll = phm_log(X) + S;
+}
+
+hipError_t launch_exp_pl_loglik(int n, int n_node, int n_tips, const UpStep* up, const double* P, double* PL,
+                                const double* pid, int root_node, double* out_ll, hipStream_t stream) {
+  hipLaunchKernelGGL(exp_pl_loglik_kernel, dim3(1), dim3(64), 0, stream, n, n_node, n_tips, up, P, PL, pid, root_node, out_ll);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // K5: one lane per i.i.d. sample (treesampleEXP :2977-2996)
 // ------------------------------------------------------------------------------------------------
 // sampleOnce, src/phylomap.cpp:81-90: no sort, per-element division, strict '<'

@@ -114,7 +114,7 @@ typedef int32_t (*qupd_fn)(const phm_tree*, int32_t, const double*, const double
 
 // maketreelistMCMCbf / maketreelistMCMCks (src/RcppExports.cpp:106,132): the reference edits the caller's Q and B in place
 // (src/phylomap.cpp:1212-1217) -- vignettes re-create Q before every call for that reason; this binding leaves them alone.
-static SEXP run_qupdate(qupd_fn fn, int cols_extra_k, SEXP xSEXP, SEXP QSEXP, SEXP pidSEXP, SEXP BSEXP, SEXP OmegaSEXP,
+static SEXP run_qupdate(qupd_fn fn, int cols_extra_k, int dic, SEXP xSEXP, SEXP QSEXP, SEXP pidSEXP, SEXP BSEXP, SEXP OmegaSEXP,
                         SEXP nenSEXP, SEXP nodelistSEXP, SEXP rootSEXP, SEXP NSEXP, SEXP priorSEXP) {
   RNGScope scope;
   FlatTree ft(as<List>(xSEXP));
@@ -123,7 +123,7 @@ static SEXP run_qupdate(qupd_fn fn, int cols_extra_k, SEXP xSEXP, SEXP QSEXP, SE
   IntegerVector nen(nenSEXP), nodelist(nodelistSEXP);
   const int n = Q.nrow(), N = as<int>(NSEXP);
   const int k = cols_extra_k ? n / 2 - 1 : 0;
-  NumericMatrix out(N, n + n * n + 2 + 3 * k + 1);                  // :1293 (bf), :1857 (ks)
+  NumericMatrix out(N, n + n * n + 2 + 3 * k + 1 + dic);            // :1293 (bf), :1857 (ks), :3230 / :3372 (DIC)
   phm_options o = options_from_R();
   check(fn(&ft.t, n, Q.begin(), pid.begin(), B.begin(), as<double>(OmegaSEXP), nen.begin(), nodelist.begin(),
            as<int>(rootSEXP), N, prior.begin(), (int32_t)prior.size(), &o, out.begin()));
@@ -133,14 +133,28 @@ static SEXP run_qupdate(qupd_fn fn, int cols_extra_k, SEXP xSEXP, SEXP QSEXP, SE
 RcppExport SEXP phylomap_maketreelistMCMCbf(SEXP x, SEXP Q, SEXP pid, SEXP B, SEXP Omega, SEXP nen, SEXP nodelist, SEXP root,
                                             SEXP N, SEXP prior) {
   BEGIN_RCPP
-  return run_qupdate(phm_maketreelistMCMCbf, 0, x, Q, pid, B, Omega, nen, nodelist, root, N, prior);
+  return run_qupdate(phm_maketreelistMCMCbf, 0, 0, x, Q, pid, B, Omega, nen, nodelist, root, N, prior);
   END_RCPP
 }
 
 RcppExport SEXP phylomap_maketreelistMCMCks(SEXP x, SEXP Q, SEXP pid, SEXP B, SEXP Omega, SEXP nen, SEXP nodelist, SEXP root,
                                             SEXP N, SEXP prior) {
   BEGIN_RCPP
-  return run_qupdate(phm_maketreelistMCMCks, 1, x, Q, pid, B, Omega, nen, nodelist, root, N, prior);
+  return run_qupdate(phm_maketreelistMCMCks, 1, 0, x, Q, pid, B, Omega, nen, nodelist, root, N, prior);
+  END_RCPP
+}
+
+RcppExport SEXP phylomap_maketreelistMCMC2sDICt(SEXP x, SEXP Q, SEXP pid, SEXP B, SEXP Omega, SEXP nen, SEXP nodelist,
+                                                SEXP root, SEXP N, SEXP prior) {      // src/RcppExports.cpp:211
+  BEGIN_RCPP
+  return run_qupdate(phm_maketreelistMCMC2sDICt, 0, 1, x, Q, pid, B, Omega, nen, nodelist, root, N, prior);
+  END_RCPP
+}
+
+RcppExport SEXP phylomap_maketreelistMCMCksDICt(SEXP x, SEXP Q, SEXP pid, SEXP B, SEXP Omega, SEXP nen, SEXP nodelist,
+                                                SEXP root, SEXP N, SEXP prior) {      // src/RcppExports.cpp:237
+  BEGIN_RCPP
+  return run_qupdate(phm_maketreelistMCMCksDICt, 1, 1, x, Q, pid, B, Omega, nen, nodelist, root, N, prior);
   END_RCPP
 }
 

@@ -120,7 +120,7 @@ def philox(ctr, key):
 
 
 def maketreelistMCMC(z, Q, pid, B, Omega, nen, nodelist, root, N, variant=PLAIN, seed=1, replica=0,
-                     faithful_search=False, tape_u=None, tape_e=None, dump=False, prior=None, rstream=False):
+                     faithful_search=False, tape_u=None, tape_e=None, dump=False, prior=None, rstream=False, dic=False):
     Q = np.asarray(Q, dtype=np.float64)
     n = Q.shape[0]
     ft = FlatTree(z)
@@ -133,13 +133,15 @@ def maketreelistMCMC(z, Q, pid, B, Omega, nen, nodelist, root, N, variant=PLAIN,
         cols = n + n * n + 2 + 3 * (n // 2 - 1) + 1
     if variant == BF:
         cols = 9
+    if dic:
+        cols += 1
     out = np.zeros((N, cols), order="F")
     rng, keep = make_rng(seed, replica, tape_u, tape_e, rstream)
     if prior is not None:
         prior = np.ascontiguousarray(prior, dtype=np.float64)
         rc = lib().orc_maketreelistMCMC_qupdate(C.byref(ft.c), n, _ptr(Qc, C.c_double), _ptr(pid, C.c_double),
                                                 _ptr(Bc, C.c_double), C.c_double(Omega), _ptr(nen, C.c_int32),
-                                                _ptr(nodelist, C.c_int32), int(root), int(N), int(variant),
+                                                _ptr(nodelist, C.c_int32), int(root), int(N), int(variant) | (16 if dic else 0),
                                                 _ptr(prior, C.c_double), int(faithful_search), C.byref(rng),
                                                 _ptr(out, C.c_double), None)
         return out, rc

@@ -337,6 +337,38 @@ def test_sumstatMCMCks_with_rate_updates_matches_oracle(n):
     np.testing.assert_allclose(got2[:, :n].sum(1), 3 * z["edge.length"].sum(), rtol=1e-12)
 
 
+@pytest.mark.parametrize("which", ["2s", "ks"])
+def test_dic_drivers_match_oracle(which):
+    """sumstatMCMC2sDICt / sumstatMCMCksDICt: the bf / ks drivers plus log p(y|Q) by matrix exponentiation every iteration
+    (Pade expm of every branch on the device, pruning with scale factors)."""
+    from scipy.linalg import expm
+    if which == "2s":
+        Q, prior, var, fn = np.array([[-.1, .1], [.1, -.1]]), [.55, 1, .56, 1.01], O.BF, api.sumstatMCMC2sDICt
+    else:
+        Q, prior, var, fn = synth.make2sQ(.1, .1, .2, .2, 10), [1, 10, 2, 10, 20, 2], O.KS, api.sumstatMCMCksDICt
+    n = Q.shape[0]
+    Omega, pid = 25.0, np.full(n, 1.0 / n)
+    z = synth.make_tree(25, Q, Omega / 3, 44, pid)
+    z["states"] = ((z["states"] - 1) % 2 + 1).astype(np.int32)
+    nen, nodelist, root = _orders(z)
+    got = fn(z, Q, pid, Omega, 20, prior, seed=5)
+    want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(n) + Q / Omega, Omega, nen, nodelist, root, 20, variant=var, seed=5, prior=prior, dic=True)
+    assert rc == 0 and got.shape == want.shape
+    np.testing.assert_array_equal(got, want)
+    # the first log-likelihood against an independent Felsenstein pass with scipy's expm
+    T, E = 25, z["edge"]
+    PL = np.zeros((2 * T - 1, n))
+    for i, s_ in enumerate(z["states"]):
+        if which == "2s":
+            PL[i, s_ - 1] = 1
+        else:
+            PL[i, (0 if s_ % 2 == 1 else 1)::2] = 1
+    for i in range(T - 1):
+        ea, eb = nen[2 * i] - 1, nen[2 * i + 1] - 1
+        PL[E[ea, 0] - 1] = (expm(Q * z["edge.length"][ea]) @ PL[E[ea, 1] - 1]) * (expm(Q * z["edge.length"][eb]) @ PL[E[eb, 1] - 1])
+    np.testing.assert_allclose(got[0, -1], np.log(PL[root - 1] @ pid), rtol=1e-11)
+
+
 def test_replica_offset_shards_like_one_device():
     z, Q, pid, Omega = _problem(2, 18, 4)
     a = api.sumstatMCMC(z, Q, pid, Omega, 10, seed=3, n_replicas=4)

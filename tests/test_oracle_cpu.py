@@ -237,6 +237,27 @@ def test_ks_sweep_oracle_equals_python_restatement(n):
         assert rc == 0
 
 
+def test_dic_loglikelihood_against_scipy():
+    """The log p(y|Q) column of the DIC drivers (src/phylomap.cpp:3239-3251): Pade expm + scaled pruning vs scipy."""
+    from scipy.linalg import expm
+    Q = np.array([[-.1, .1], [.1, -.1]])
+    Omega, pid, prior = 10.0, np.array([.3, .7]), [.55, 1, .56, 1.01]
+    z = synth.make_tree(40, Q, 2.0, 61, pid)
+    nen, nodelist, root = _orders(z)
+    out, rc = O.maketreelistMCMC(z, Q, pid, np.eye(2) + Q / Omega, Omega, nen, nodelist, root, 6, variant=O.BF, seed=3,
+                                 prior=prior, dic=True)
+    assert rc == 0 and out.shape == (6, 10)
+    E, T = z["edge"], 40
+    for it in range(6):
+        Qi = np.array([[-out[it, 6], out[it, 6]], [out[it, 7], -out[it, 7]]])      # the Q recorded for this sweep
+        PL = np.zeros((2 * T - 1, 2))
+        PL[np.arange(T), z["states"] - 1] = 1
+        for i in range(T - 1):
+            ea, eb = nen[2 * i] - 1, nen[2 * i + 1] - 1
+            PL[E[ea, 0] - 1] = (expm(Qi * z["edge.length"][ea]) @ PL[E[ea, 1] - 1]) * (expm(Qi * z["edge.length"][eb]) @ PL[E[eb, 1] - 1])
+        np.testing.assert_allclose(out[it, 9], np.log(PL[root - 1] @ pid), rtol=1e-11)
+
+
 @pytest.mark.parametrize("n", [2, 4])
 def test_exp_oracle_equals_python_restatement(n):
     Q = {2: synth.config_Q(1), 4: synth.config_Q(2)}[n]
