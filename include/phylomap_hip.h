@@ -57,6 +57,11 @@ typedef enum phm_variant {
   ,
   PHM_MCMC_BF = 4             /* tree sweep of maketreelistMCMCbf (treesamplebf :1169-1179): two states, tips observed, n x n counts
                                  incl. self pairs, layout time0,time1,n00,n01,n10,n11,l01,l10,root_state (R/sumstatMCMCbf.R:33) */
+  ,
+  PHM_MCMC_MT = 5             /* tree sweep of maketreelistMCMCmt (treesamplemtNS :2157-2165): the bf sweep with the UN-normalised
+                                 pruning makePLrcppmt :1938-1950; two states */
+  ,
+  PHM_MCMC_KSMT = 6           /* tree sweep of maketreelistMCMCksmt (:2722-2844): the ks sweep with the un-normalised pruning */
 } phm_variant;
 
 /* The phylomap tree object `x` (fields read at src/phylomap.cpp:896-910 and :3034). */
@@ -164,6 +169,21 @@ int32_t phm_maketreelistMCMCksDICt(   /* src/phylomap.cpp:3300, src/RcppExports.
     const phm_tree* x, int32_t n_states, const double* Q, const double* pid, const double* B, double Omega,
     const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N, const double* prior, int32_t n_prior,
     const phm_options* opt, double* out);
+/* The multi-tree drivers: `trees` is the R list x of `n_trees` phylomap trees with equal tip and edge counts
+ * (R/sumstatMCMCmt.R:33-35).  Every iteration sweeps every tree with the current Q -- one launch, tree j on replica tile j --
+ * draws one tree uniformly, writes that tree's row plus its 0-based index (the last column; R/sumstatMCMCmt.R:41
+ * "tree_number") and updates Q from it with the mt twins of the updates (updatel01mtNS :2192, updateksl01mt :2371, ...).
+ * nen_m: n_trees x 2*Nnode, nodelist_m: n_trees x (Nnode-1), both COLUMN-major as R passes its matrices; either may be
+ * NULL (orders are derived from edge; when given they are checked against it).  out: N x (n+n*n+2+3k+1) column-major.
+ * prior: 4 numbers (mt), 8 (ksmt: l01, l10, kappas, gammas shape/rate pairs as the mt updates index them). */
+int32_t phm_maketreelistMCMCmt(       /* src/phylomap.cpp:2267, src/RcppExports.cpp:158 */
+    const phm_tree* trees, int32_t n_trees, int32_t n_states, const double* Q, const double* pid, const double* B,
+    double Omega, const int32_t* nen_m, const int32_t* nodelist_m, const int32_t* roots, int32_t N, const double* prior,
+    int32_t n_prior, const phm_options* opt, double* out);
+int32_t phm_maketreelistMCMCksmt(     /* src/phylomap.cpp:2722, src/RcppExports.cpp:184 */
+    const phm_tree* trees, int32_t n_trees, int32_t n_states, const double* Q, const double* pid, const double* B,
+    double Omega, const int32_t* nen_m, const int32_t* nodelist_m, const int32_t* roots, int32_t N, const double* prior,
+    int32_t n_prior, const phm_options* opt, double* out);
 int32_t phm_maketreelistEXP(          /* src/phylomap.cpp:3001, src/RcppExports.cpp:80 */
     const phm_tree* x, int32_t n_states, const double* Q, const double* pid,
     const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
@@ -203,6 +223,11 @@ int32_t phm_expm_pade_mfma(int32_t n_states, const double* Q, const double* t, i
 /* ---- resident engine (inputs stay in HBM between calls; what bench.py times) ---- */
 int32_t phm_engine_create(const phm_tree* x, const phm_model* model, const phm_options* opt,
                           int32_t max_iters, phm_engine** out);
+/* the same over a list of `n_trees` trees (equal tip and edge counts) sharing one model: opt->n_replicas chains PER TREE,
+ * tree j's chains on their own 64-lane tiles (replica index j * n_replicas + c in every per-replica call; Philox replica
+ * word replica_offset + 64 * tiles_per_tree * j + c).  reduce and tips_per_replica are not available here. */
+int32_t phm_engine_create_multi(const phm_tree* trees, int32_t n_trees, const phm_model* model, const phm_options* opt,
+                                int32_t max_iters, phm_engine** out);
 /* enqueue iterations [iters_done, iters_done + n_iters) on `hip_stream` (a hipStream_t, NULL = default
  * stream); asynchronous */
 int32_t phm_engine_run(phm_engine* e, int32_t n_iters, void* hip_stream);

@@ -202,7 +202,7 @@ int orc_rstream_selftest(uint32_t seed, int n_unif, int n_exp, double* unif_out,
 /* ------------------------------------------------------------------------------------------ */
 /* RNG front end                                                                               */
 /* ------------------------------------------------------------------------------------------ */
-typedef struct { orc_rng* r; int err; } rngctx;
+typedef struct { orc_rng* r; int err; uint32_t iter_base; } rngctx;   /* iter_base: added to the Philox iteration word */
 
 static double draw_u(rngctx* c, uint32_t iter, uint32_t entity, uint32_t draw) {
   orc_rng* r = c->r;
@@ -211,7 +211,7 @@ static double draw_u(rngctx* c, uint32_t iter, uint32_t entity, uint32_t draw) {
     return r->tape_u[r->pos_u++];
   }
   if (r->mode == 2) return r_unif_rand();
-  return orc_stream_u(r->seed_lo, r->seed_hi, r->replica, iter, entity, draw);
+  return orc_stream_u(r->seed_lo, r->seed_hi, r->replica, iter + c->iter_base, entity, draw);
 }
 /* standard exponential: -log(u) (R's exp_rand is Ahrens-Dieter; not restated in Philox mode) */
 static double draw_e(rngctx* c, uint32_t iter, uint32_t entity, uint32_t draw) {
@@ -221,7 +221,7 @@ static double draw_e(rngctx* c, uint32_t iter, uint32_t entity, uint32_t draw) {
     return r->tape_e[r->pos_e++];
   }
   if (r->mode == 2) return r_exp_rand();
-  return -orc_log(orc_stream_u(r->seed_lo, r->seed_hi, r->replica, iter, entity, draw));
+  return -orc_log(orc_stream_u(r->seed_lo, r->seed_hi, r->replica, iter + c->iter_base, entity, draw));
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -604,6 +604,23 @@ static void updatel10(double* Q, int n, double Omega, const double* prior, const
   QQ(1, 0) = newl10; QQ(1, 1) = -newl10;                                  /* :1244-1245 */
 }
 
+/* updatel01mtNS :2192-2226 / updatel10mtNS :2228-2262 (side = 0 / 1): unlike the single-tree twins these DO test the
+ * acceptance ratio -- accept = ((Omega-new)/(Omega-old))^n_ss * exp(t_s (new-old)), capped at 1, against one runif that is
+ * drawn only when the proposal is not above Omega; `acceptcompare` (metropolis*hastings, :2176-2190) is never used. */
+static void updatelmtNS(int side, double* Q, int n, double Omega, const double* prior, const double* stats, int64_t stride, int it, hstream* h) {
+  int nss = (int)stats[(int64_t)(side == 0 ? 2 : 5) * stride + it];         /* n00 / n11 */
+  int nsd = (int)stats[(int64_t)(side == 0 ? 3 : 4) * stride + it];         /* n01 / n10 */
+  double ts = stats[(int64_t)side * stride + it];
+  double old = side == 0 ? QQ(0, 1) : QQ(1, 0);
+  double nw = hs_rgamma(h, prior[2 * side] + nsd, 1 / (prior[2 * side + 1] + ts));
+  if (nw > Omega) return;
+  double accept = pow((Omega - nw) / (Omega - old), nss) * exp(ts * (nw - old));
+  if (accept > 1) accept = 1;
+  double compare = hs_u(h);
+  if (accept < compare) return;
+  if (side == 0) { QQ(0, 0) = -nw; QQ(0, 1) = nw; } else { QQ(1, 0) = nw; QQ(1, 1) = -nw; }
+}
+
 /* parameters as every ks update re-reads them from Q (e.g. :1441-1450) */
 static void ks_params(const double* Q, int n, int k, double* lambdas, double* rk, double* lk, double* gm) {
   lambdas[0] = QQ(0, 1); lambdas[1] = QQ(1, 0);
@@ -614,13 +631,15 @@ static void ks_params(const double* Q, int n, int k, double* lambdas, double* rk
 }
 
 /* updateksl01 :1435-1505 (side = 0) and updateksl10 :1509-1578 (side = 1) */
-static void updateksl(int side, double* Q, int n, double Omega, const double* prior, const double* stats, int64_t stride, int it, hstream* h) {
+/* mt != 0: the multi-tree twins updateksl01mt :2371-2439 / updateksl10mt :2443-2510 -- side 1 reads prior(2), prior(3) yet
+ * still subtracts prior(1) for gammatimes (:2471), and the `< 1e-300` guard is absent */
+static void updateksl(int side, double* Q, int n, double Omega, const double* prior, const double* stats, int64_t stride, int it, hstream* h, int mt) {
   int k = n / 2 - 1, i;
   double lambdas[2], rk[32], lk[32], gm[33];
   ks_params(Q, n, k, lambdas, rk, lk, gm);
-  double alphaprime = prior[0];
+  double alphaprime = prior[(mt && side) ? 2 : 0];
   for (i = 0; i <= k; ++i) alphaprime = alphaprime + (side == 0 ? TC(2 * i * n + 2 * i + 1) : TC((2 * i + 1) * n + 2 * i));
-  double betaprime = prior[1];
+  double betaprime = prior[(mt && side) ? 3 : 1];
   for (i = 0; i <= k; ++i) betaprime = betaprime + gm[i] * SJ(2 * i + side);
   double newl = hs_rgamma(h, alphaprime, 1 / betaprime);
   double old = lambdas[side];
@@ -636,7 +655,7 @@ static void updateksl(int side, double* Q, int n, double Omega, const double* pr
   if (newl + rk[0] > Omega) return;
   for (i = 1; i < k; ++i) if (gm[i] * newl + rk[i] + lk[i - 1] > Omega) return;
   if (gm[k] * newl + lk[k - 1] > Omega) return;
-  if (newl < 1e-300) return;
+  if (!mt && newl < 1e-300) return;
   if (logaccept < log(compare)) return;
   int a = side, b = 1 - side;                                              /* row a, column b of each 2x2 block */
   QQ(a, a) = -rk[0] - gm[0] * newl; QQ(a, b) = gm[0] * newl;
@@ -645,7 +664,9 @@ static void updateksl(int side, double* Q, int n, double Omega, const double* pr
 }
 
 /* updaterkappas :1582-1644 */
-static void updaterkappas(double* Q, int n, double Omega, const double* prior, const double* stats, int64_t stride, int it, hstream* h, int j) {
+/* mt != 0: updaterkappasmt :2514-2576 (prior indices two further on, no `< 1e-300` guard) */
+static void updaterkappas(double* Q, int n, double Omega, const double* prior, const double* stats, int64_t stride, int it, hstream* h, int j, int mt) {
+  if (mt) prior += 2;
   int k = n / 2 - 1;
   double lambdas[2], rk[32], lk[32], gm[33];
   ks_params(Q, n, k, lambdas, rk, lk, gm);
@@ -664,7 +685,7 @@ static void updaterkappas(double* Q, int n, double Omega, const double* prior, c
   double compare = hs_u(h);
   if (j == 0) { if (nw + gm[j] * lambdas[0] > Omega) return; if (nw + gm[j] * lambdas[1] > Omega) return; }
   else { if (nw + gm[j] * lambdas[0] + lk[j - 1] > Omega) return; if (nw + gm[j] * lambdas[1] + lk[j - 1] > Omega) return; }
-  if (nw < 1e-300) return;
+  if (!mt && nw < 1e-300) return;
   if (logaccept < log(compare)) return;
   QQ(2 * j, 2 * j + 2) = nw; QQ(2 * j + 1, 2 * j + 3) = nw;
   if (j == 0) { QQ(0, 0) = -nw - gm[j] * lambdas[0]; QQ(1, 1) = -nw - gm[j] * lambdas[1]; }
@@ -672,7 +693,9 @@ static void updaterkappas(double* Q, int n, double Omega, const double* prior, c
 }
 
 /* updatelkappas :1648-1710 */
-static void updatelkappas(double* Q, int n, double Omega, const double* prior, const double* stats, int64_t stride, int it, hstream* h, int j) {
+/* mt != 0: updatelkappasmt :2580-2639 (prior indices two further on, no `< 1e-300` guard) */
+static void updatelkappas(double* Q, int n, double Omega, const double* prior, const double* stats, int64_t stride, int it, hstream* h, int j, int mt) {
+  if (mt) prior += 2;
   int k = n / 2 - 1;
   double lambdas[2], rk[32], lk[32], gm[33];
   ks_params(Q, n, k, lambdas, rk, lk, gm);
@@ -690,7 +713,7 @@ static void updatelkappas(double* Q, int n, double Omega, const double* prior, c
   double compare = hs_u(h);
   if (j == k) { if (nw + gm[j] * lambdas[0] > Omega) return; if (nw + gm[j] * lambdas[1] > Omega) return; }
   else { if (nw + gm[j] * lambdas[0] + rk[j] > Omega) return; if (nw + gm[j] * lambdas[1] + rk[j] > Omega) return; }
-  if (nw < 1e-300) return;
+  if (!mt && nw < 1e-300) return;
   if (logaccept < log(compare)) return;
   QQ(2 * j, 2 * j - 2) = nw; QQ(2 * j + 1, 2 * j - 1) = nw;
   if (j == k) { QQ(2 * j, 2 * j) = -nw - gm[j] * lambdas[0]; QQ(2 * j + 1, 2 * j + 1) = -nw - gm[j] * lambdas[1]; }
@@ -698,7 +721,9 @@ static void updatelkappas(double* Q, int n, double Omega, const double* prior, c
 }
 
 /* updategammas :1714-1785 */
-static void updategammas(double* Q, int n, double Omega, const double* prior, const double* stats, int64_t stride, int it, hstream* h, int j) {
+/* mt != 0: updategammasmt :2643-2705 (prior indices two further on, no `< 1e-300` guard) */
+static void updategammas(double* Q, int n, double Omega, const double* prior, const double* stats, int64_t stride, int it, hstream* h, int j, int mt) {
+  if (mt) prior += 2;
   int k = n / 2 - 1;
   double lambdas[2], rk[32], lk[32], gm[33];
   ks_params(Q, n, k, lambdas, rk, lk, gm);
@@ -716,7 +741,7 @@ static void updategammas(double* Q, int n, double Omega, const double* prior, co
   double compare = hs_u(h);
   if (j == k) { if (lk[j - 1] + nw * lambdas[0] > Omega) return; if (lk[j - 1] + nw * lambdas[1] > Omega) return; }
   else { if (lk[j - 1] + nw * lambdas[0] + rk[j] > Omega) return; if (lk[j - 1] + nw * lambdas[1] + rk[j] > Omega) return; }
-  if (nw < 1e-300) return;
+  if (!mt && nw < 1e-300) return;
   if (logaccept < log(compare)) return;
   QQ(2 * j, 2 * j + 1) = nw * lambdas[0]; QQ(2 * j + 1, 2 * j) = nw * lambdas[1];
   if (j == k) { QQ(2 * j, 2 * j) = -lk[j - 1] - nw * lambdas[0]; QQ(2 * j + 1, 2 * j + 1) = -lk[j - 1] - nw * lambdas[1]; }
@@ -724,6 +749,81 @@ static void updategammas(double* Q, int n, double Omega, const double* prior, co
 }
 #undef TC
 #undef SJ
+
+/* One tree with its chain state: what maketreelistMCMC* unpacks from the R list x (:895-915) and carries across sweeps */
+typedef struct {
+  const orc_tree* x; int E, T, Nnode; const int32_t *edge1, *edge2;
+  Branch* brs; double* PL; size_t pl_len; int32_t *rm, *bl, *eoc; double* w;
+  double* scratch; size_t scratch_len; Branch tmp;
+} treechain;
+
+static void tips_into_PL(const orc_tree* x, int n, int masks, double* PL) {
+  if (!masks) for (int i = 0; i < x->n_tips; ++i) PL[(size_t)i * n + (x->states[i] - 1)] = 1.0;   /* :914 */
+  else for (int i = 0; i < x->n_tips; ++i)                    /* only the binary trait is observed :1838-1845 */
+    for (int j = (x->states[i] % 2 == 0) ? 1 : 0; j < n; j += 2) PL[(size_t)i * n + j] = 1.0;
+}
+
+static int chain_init(treechain* c, const orc_tree* x, int n, int masks) {
+  memset(c, 0, sizeof *c);
+  int e = check_tree(x); if (e) return e;
+  c->x = x; c->E = x->n_edge; c->T = x->n_tips; c->Nnode = x->n_node;
+  c->edge1 = x->edge; c->edge2 = x->edge + c->E;
+  c->brs = (Branch*)calloc(c->E, sizeof(Branch));
+  for (int i = 0; i < c->E; ++i) {
+    int o = x->map_off[i], m = x->map_off[i + 1] - o;
+    if (m < 1) { e = ORC_ERR_BAD_INPUT; m = 0; }
+    makeabranch(&c->brs[i], x->maps + o, x->mapnames + o, m);    /* :901 */
+  }
+  c->pl_len = (size_t)(2 * c->Nnode + 1) * n;
+  c->PL = (double*)calloc(c->pl_len, sizeof(double));
+  tips_into_PL(x, n, masks, c->PL);
+  c->rm = (int32_t*)calloc(2 * c->T - 1, sizeof(int32_t));
+  c->bl = (int32_t*)calloc(c->E, sizeof(int32_t));
+  c->eoc = (int32_t*)calloc(2 * c->T - 1, sizeof(int32_t));
+  for (int i = 0; i < c->E; ++i) c->eoc[c->edge2[i] - 1] = i;
+  c->w = (double*)malloc(sizeof(double) * 3 * n);
+  return e;
+}
+
+static void chain_free(treechain* c) {
+  if (c->brs) for (int i = 0; i < c->E; ++i) { free(c->brs[i].d); free(c->brs[i].s); }
+  free(c->tmp.d); free(c->tmp.s); free(c->scratch); free(c->w); free(c->eoc); free(c->bl); free(c->rm); free(c->PL); free(c->brs);
+  memset(c, 0, sizeof *c);
+}
+
+/* treesample :766-785 / treesampleks :1422-1432 / treesamplemtNS :2157-2165: nodes, then every branch, then dwell times.
+ * stats(it, .) is column-major with `stride` rows; returns the root state in *rootst (ks / bf sweeps record it). */
+static void chain_sweep(treechain* c, int n, const double* pid, const double* Bc, const double* B2, double Omega, const double* Qd,
+                        const int32_t* nen, const int32_t* nodelist, int32_t root, int normalise, int ks, int faithful_search,
+                        rngctx* rc, double* stats, int64_t stride, int it, double* rootst) {
+  sampleinternalnodesMCMC(c->brs, c->E, c->PL, pid, Bc, root, nodelist, c->Nnode - 1, nen, c->edge1, c->edge2, c->Nnode,
+                          c->x->states, c->T, normalise, n, faithful_search, c->eoc, rc, (uint32_t)it, c->rm, c->bl, c->w, ks, rootst);
+  updatenodestates(c->brs, c->edge1, c->edge2, c->E, c->rm);                                /* :779 / :1426 */
+  for (int i = 0; i < c->E; ++i)                                                            /* :781 / :1428 */
+    sampleabranch(&c->brs[i], Bc, B2, Omega, Qd, ks ? -n : n, stats, stride, it, rc, (uint32_t)i, &c->scratch, &c->scratch_len, &c->tmp);
+  for (int i = 0; i < c->E; ++i) updatedwelltimes(it, &c->brs[i], stats, stride);           /* :782 */
+}
+
+/* recordQ :1181-1185 / recordQks :1789-1798 / recordQmtNS :2169-2173 / recordQksmt :2709-2718 */
+static void record_Q(const double* Q, int n, int kk, double* stats, int64_t stride, int it) {
+  int base = n + n * n;
+  stats[(int64_t)base * stride + it] = QQ(0, 1);
+  stats[(int64_t)(base + 1) * stride + it] = QQ(1, 0);
+  for (int i = 0; i < kk; ++i) {
+    stats[(int64_t)(base + 2 + i) * stride + it] = QQ(2 * i, 2 * i + 2);
+    stats[(int64_t)(base + 2 + kk + i) * stride + it] = QQ(2 * i + 2, 2 * i);
+    stats[(int64_t)(base + 2 + 2 * kk + i) * stride + it] = QQ(2 * (i + 1), 2 * (i + 1) + 1) / QQ(0, 1);
+  }
+}
+
+/* B2 = I + Q/Omega entry by entry, as the updates write it (e.g. :1214-1217) */
+static void model_from_Q(const double* Q, int n, double Omega, double* B2, double* Bc, double* Qd) {
+  for (int i = 0; i < n; ++i) {
+    Qd[i] = QQ(i, i);
+    for (int j = 0; j < n; ++j) B2[i * n + j] = (i == j) ? 1 + QQ(i, j) / Omega : QQ(i, j) / Omega;
+  }
+  memcpy(Bc, B2, sizeof(double) * n * n);
+}
 
 static int mcmc_driver(const orc_tree* x, int n, const double* Q_cm, const double* pid,
                          const double* B_cm, double Omega, const int32_t* nen,
@@ -733,7 +833,7 @@ static int mcmc_driver(const orc_tree* x, int n, const double* Q_cm, const doubl
   if (dic && (!prior || !x->edge_length)) return ORC_ERR_BAD_INPUT;
   if (n < 2 || N < 0) return ORC_ERR_BAD_INPUT;
   int E = x->n_edge, T = x->n_tips, Nnode = x->n_node;
-  const int32_t* edge1 = x->edge; const int32_t* edge2 = x->edge + E;
+  const int32_t* edge2 = x->edge + E; const int32_t* edge1 = x->edge;
   const int ks = (variant == ORC_MCMC_KS) ? 1 : (variant == ORC_MCMC_BF) ? 2 : 0;   /* 1: ks sweep, 2: bf sweep */
   if (ks == 1 && (n & 1)) return ORC_ERR_BAD_INPUT;           /* hidden-rates structure: n = 2k+2 (:1820) */
   if (ks == 2 && n != 2) return ORC_ERR_BAD_INPUT;            /* recordQ / updatel01 hard-wire two states (:1181-1185) */
@@ -742,9 +842,9 @@ static int mcmc_driver(const orc_tree* x, int n, const double* Q_cm, const doubl
   int cols = ks ? n + n * n + 2 + 3 * kk + 1 + (dic ? 1 : 0) : n + n * (n - 1);
   double* Q = (double*)malloc(sizeof(double) * n * n);        /* row-major working copy; the updates edit it */
   for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) QQ(i, j) = Q_cm[i + (size_t)j * n];
-  rngctx rc = { rng, 0 };
+  rngctx rc = { rng, 0, 0 };
   g_rstream = (rng->mode == 2);
-  if (g_rstream) { if (prior) return ORC_ERR_BAD_INPUT; r_set_seed(rng->seed_lo); }   /* rgamma is not restated */
+  if (g_rstream) { if (prior) { free(Q); return ORC_ERR_BAD_INPUT; } r_set_seed(rng->seed_lo); }   /* rgamma is not restated */
 
   double* B2 = (double*)malloc(sizeof(double) * n * n);       /* row-major copies */
   double* Bc = (double*)malloc(sizeof(double) * n * n);
@@ -754,45 +854,17 @@ static int mcmc_driver(const orc_tree* x, int n, const double* Q_cm, const doubl
   else memcpy(Bc, B2, sizeof(double) * n * n);
   int normalise = (variant == ORC_MCMC_BIGTREE) || ks;        /* makePLnormalized :1085 */
 
-  Branch* brs = (Branch*)calloc(E, sizeof(Branch));
-  for (int i = 0; i < E; ++i) {
-    int o = x->map_off[i], m = x->map_off[i + 1] - o;
-    if (m < 1) { e = ORC_ERR_BAD_INPUT; m = 0; }
-    makeabranch(&brs[i], x->maps + o, x->mapnames + o, m);    /* :901 */
-  }
-  size_t pl_len = (size_t)(2 * Nnode + 1) * n;
-  double* PL = (double*)calloc(pl_len, sizeof(double));
-  if (ks != 1) for (int i = 0; i < T; ++i) PL[(size_t)i * n + (x->states[i] - 1)] = 1.0;   /* :914 */
-  else for (int i = 0; i < T; ++i)                            /* only the binary trait is observed :1838-1845 */
-    for (int j = (x->states[i] % 2 == 0) ? 1 : 0; j < n; j += 2) PL[(size_t)i * n + j] = 1.0;
-  int32_t* rm = (int32_t*)calloc(2 * T - 1, sizeof(int32_t));
-  int32_t* bl = (int32_t*)calloc(E, sizeof(int32_t));
-  int32_t* eoc = (int32_t*)calloc(2 * T - 1, sizeof(int32_t));
-  for (int i = 0; i < E; ++i) eoc[edge2[i] - 1] = i;
-  double* w = (double*)malloc(sizeof(double) * 3 * n);
-  double* scratch = NULL; size_t scratch_len = 0;
-  Branch tmp = { NULL, NULL, 0, 0 };
+  treechain ch;
+  e = chain_init(&ch, x, n, ks == 1);
+  const size_t pl_len = ch.pl_len;
+  double* w = ch.w;
   memset(out, 0, sizeof(double) * (size_t)N * cols);          /* :926 */
 
   if (!e) for (int it = 0; it < N; ++it) {
     double rootst = 0.0;
-    if (ks) {                                                 /* recordQks :1789-1798 / recordQ :1181-1185 */
-      int base = n + n * n;
-      out[(int64_t)base * N + it] = QQ(0, 1);
-      out[(int64_t)(base + 1) * N + it] = QQ(1, 0);
-      for (int i = 0; i < kk; ++i) {
-        out[(int64_t)(base + 2 + i) * N + it] = QQ(2 * i, 2 * i + 2);
-        out[(int64_t)(base + 2 + kk + i) * N + it] = QQ(2 * i + 2, 2 * i);
-        out[(int64_t)(base + 2 + 2 * kk + i) * N + it] = QQ(2 * (i + 1), 2 * (i + 1) + 1) / QQ(0, 1);
-      }
-    }
-    sampleinternalnodesMCMC(brs, E, PL, pid, Bc, root, nodelist, Nnode - 1, nen, edge1, edge2, Nnode,
-                            x->states, T, normalise, n, faithful_search, eoc, &rc, (uint32_t)it, rm, bl, w, ks, &rootst);
+    if (ks) record_Q(Q, n, kk, out, N, it);
+    chain_sweep(&ch, n, pid, Bc, B2, Omega, Qd, nen, nodelist, root, normalise, ks, faithful_search, &rc, out, N, it, &rootst);
     if (ks) out[(int64_t)(n + n * n + 2 + 3 * kk) * N + it] = rootst;      /* root column; the DIC drivers add log p(y|Q) after it */
-    updatenodestates(brs, edge1, edge2, E, rm);                                              /* :779 / :1426 */
-    for (int i = 0; i < E; ++i)                                                              /* :781 / :1428 */
-      sampleabranch(&brs[i], Bc, B2, Omega, Qd, ks ? -n : n, out, N, it, &rc, (uint32_t)i, &scratch, &scratch_len, &tmp);
-    for (int i = 0; i < E; ++i) updatedwelltimes(it, &brs[i], out, N);                       /* :782 */
     if (dic) {
       /* log p(y|Q) by matrix exponentiation, maketreelistMCMC2sDICt :3239-3251 / ksDICt :3379-3391:
          P_b = expmat(Q t_b); PPmakePLD / PPmakePLksD (:3158-3178, :3268-3297) prune with row normalisation and sum the
@@ -805,8 +877,7 @@ static int mcmc_driver(const orc_tree* x, int n, const double* Q_cm, const doubl
         if (orc_expmat_pade(A, n, Pm + nn2 * b)) rc.err |= ORC_ERR_BAD_INPUT;
       }
       double* PL2 = (double*)calloc(pl_len, sizeof(double));
-      if (ks != 1) for (int i = 0; i < T; ++i) PL2[(size_t)i * n + (x->states[i] - 1)] = 1.0;
-      else for (int i = 0; i < T; ++i) for (int j = (x->states[i] % 2 == 0) ? 1 : 0; j < n; j += 2) PL2[(size_t)i * n + j] = 1.0;
+      tips_into_PL(x, n, ks == 1, PL2);
       double S = 0;
       double* va = w; double* vb = w + n;
       for (int i = 0; i < Nnode; ++i) {
@@ -832,26 +903,102 @@ static int mcmc_driver(const orc_tree* x, int n, const double* Q_cm, const doubl
         updatel01(Q, n, Omega, prior, out, N, it, HS(0));
         updatel10(Q, n, Omega, prior, out, N, it, HS(1));
       } else {
-        updateksl(0, Q, n, Omega, prior, out, N, it, HS(0));
-        updateksl(1, Q, n, Omega, prior, out, N, it, HS(1));
-        for (int j = 0; j < kk; ++j) updaterkappas(Q, n, Omega, prior, out, N, it, HS(2 + j), j);
-        for (int j = 1; j <= kk; ++j) updatelkappas(Q, n, Omega, prior, out, N, it, HS(2 + kk + j), j);
-        for (int j = 1; j <= kk; ++j) updategammas(Q, n, Omega, prior, out, N, it, HS(2 + 2 * kk + j), j);
+        updateksl(0, Q, n, Omega, prior, out, N, it, HS(0), 0);
+        updateksl(1, Q, n, Omega, prior, out, N, it, HS(1), 0);
+        for (int j = 0; j < kk; ++j) updaterkappas(Q, n, Omega, prior, out, N, it, HS(2 + j), j, 0);
+        for (int j = 1; j <= kk; ++j) updatelkappas(Q, n, Omega, prior, out, N, it, HS(2 + kk + j), j, 0);
+        for (int j = 1; j <= kk; ++j) updategammas(Q, n, Omega, prior, out, N, it, HS(2 + 2 * kk + j), j, 0);
       }
 #undef HS
-      for (int i = 0; i < n; ++i) {                           /* B2 = I + Q/Omega entry by entry, as the updates write it */
-        Qd[i] = QQ(i, i);
-        for (int j = 0; j < n; ++j) B2[i * n + j] = (i == j) ? 1 + QQ(i, j) / Omega : QQ(i, j) / Omega;
-      }
-      memcpy(Bc, B2, sizeof(double) * n * n);
+      model_from_Q(Q, n, Omega, B2, Bc, Qd);
     }
   }
   free(Q);
-  fill_dump(dump, brs, E, rm, 2 * T - 1, PL, pl_len);
-  for (int i = 0; i < E; ++i) { free(brs[i].d); free(brs[i].s); }
-  free(tmp.d); free(tmp.s); free(scratch); free(w); free(eoc); free(bl); free(rm); free(PL); free(brs);
+  if (!e) fill_dump(dump, ch.brs, E, ch.rm, 2 * T - 1, ch.PL, pl_len);
+  chain_free(&ch);
   free(Qd); free(Bc); free(B2);
   return e | rc.err;
+}
+
+/* maketreelistMCMCmt :2267-2365 (variant ORC_MCMC_MT, two states, prior = 4 numbers) and maketreelistMCMCksmt :2722-2844
+ * (variant ORC_MCMC_KSMT, n = 2k+2 states, prior = 8 numbers).  Every iteration sweeps EVERY tree of the list with the current
+ * Q (treesamplemtNS :2157-2165: the ks-style sweep -- B4 chain for the nodes, tips re-drawn under their PL rows, virtual
+ * jumps counted -- but with the UN-normalised pruning makePLrcppmt :1938-1950 and no root column), then draws one tree
+ * uniformly (sampleOnce over unit weights, :2347-2348), copies that tree's row and its 0-based index into the output
+ * (:2349-2350) and updates Q from that row with the mt twins of the updates.
+ * nen_m: treecount x 2*Nnode, nodelist_m: treecount x (Nnode-1), row-major (one row per tree).
+ * Random numbers: tree j sweeps on Philox replica word rng->replica + 64 j (one 64-lane tile per tree in the device layout);
+ * the tree choice is host stream 0xFD of the iteration; the updates use the same stream ids as the single-tree drivers. */
+int orc_maketreelistMCMCmt(const orc_tree* const* xs, int treecount, int n, const double* Q_cm, const double* pid,
+                           const double* B_cm, double Omega, const int32_t* nen_m, const int32_t* nodelist_m,
+                           const int32_t* roots, int32_t N, int variant, const double* prior, int faithful_search,
+                           orc_rng* rng, double* out) {
+  if (treecount < 1 || !xs || !prior || n < 2 || N < 0 || rng->mode != 0) return ORC_ERR_BAD_INPUT;
+  if (variant != ORC_MCMC_MT && variant != ORC_MCMC_KSMT) return ORC_ERR_BAD_INPUT;
+  const int mtks = (variant == ORC_MCMC_KSMT);
+  if (mtks ? ((n & 1) || n < 4 || n > 64) : (n != 2)) return ORC_ERR_BAD_INPUT;   /* recordQmtNS hard-wires columns 6, 7 */
+  const int kk = mtks ? n / 2 - 1 : 0;
+  const int rowlen = n + n * n + 2 + 3 * kk, cols = rowlen + 1;
+  const int Nnode = xs[0]->n_node;
+  for (int j = 0; j < treecount; ++j)
+    if (xs[j]->n_node != Nnode || xs[j]->n_edge != xs[0]->n_edge || xs[j]->n_tips != xs[0]->n_tips) return ORC_ERR_BAD_INPUT;
+  g_rstream = 0;
+  int e = 0;
+  double* Q = (double*)malloc(sizeof(double) * n * n);
+  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) QQ(i, j) = Q_cm[i + (size_t)j * n];
+  double* B2 = (double*)malloc(sizeof(double) * n * n);
+  double* Bc = (double*)malloc(sizeof(double) * n * n);
+  double* Qd = (double*)malloc(sizeof(double) * n);
+  for (int i = 0; i < n; ++i) { Qd[i] = Q_cm[i + (size_t)i * n]; for (int j = 0; j < n; ++j) B2[i * n + j] = B_cm[i + (size_t)j * n]; }
+  memcpy(Bc, B2, sizeof(double) * n * n);
+  treechain* ch = (treechain*)calloc(treecount, sizeof(treechain));
+  orc_rng* rngs = (orc_rng*)calloc(treecount, sizeof(orc_rng));
+  rngctx* rcs = (rngctx*)calloc(treecount, sizeof(rngctx));
+  double* rows = (double*)calloc((size_t)treecount * rowlen + 1, sizeof(double));   /* DwellTimes[j] :2335-2336 (+1: unused root slot) */
+  double* weights = (double*)malloc(sizeof(double) * treecount);
+  for (int j = 0; j < treecount; ++j) {
+    e |= chain_init(&ch[j], xs[j], n, mtks);
+    rngs[j] = *rng; rngs[j].replica = rng->replica + 64u * (uint32_t)j;
+    rcs[j].r = &rngs[j]; rcs[j].err = 0; rcs[j].iter_base = 0;
+    weights[j] = 1.0;
+  }
+  rngctx rc0 = { rng, 0, 0 };
+  memset(out, 0, sizeof(double) * (size_t)N * cols);
+  if (!e) for (int it = 0; it < N; ++it) {
+    for (int j = 0; j < treecount; ++j) {
+      double* row = rows + (size_t)j * rowlen;
+      double rootst = 0.0;
+      memset(row, 0, sizeof(double) * rowlen);                                               /* :2342 */
+      record_Q(Q, n, kk, row, 1, 0);                                                           /* :2343 */
+      rcs[j].iter_base = (uint32_t)it;                     /* the row is "iteration 0" of a one-row matrix; Philox sees `it` */
+      chain_sweep(&ch[j], n, pid, Bc, B2, Omega, Qd, nen_m + (size_t)j * 2 * Nnode, nodelist_m + (size_t)j * (Nnode - 1),
+                  roots[j], 0, mtks ? 1 : 2, faithful_search, &rcs[j], row, 1, 0, &rootst);
+    }
+    hstream h = { &rc0, (uint32_t)it, 0, 0 };
+#define HS(id) (h.ent = 0xFFFFFF00u | (uint32_t)(id), h.d = 0, &h)
+    double wt = hs_u(HS(0xFD));                                                                /* :2347 */
+    int pick = sampleOnce(weights, treecount, wt, &rc0.err);                                   /* :2348 */
+    if (pick >= treecount) { e |= ORC_ERR_SAMPLEONCE; break; }
+    const double* row = rows + (size_t)pick * rowlen;
+    for (int c = 0; c < rowlen; ++c) out[(int64_t)c * N + it] = row[c];                        /* :2349 */
+    out[(int64_t)rowlen * N + it] = pick;                                                      /* :2350 */
+    if (!mtks) {
+      updatelmtNS(0, Q, n, Omega, prior, row, 1, 0, HS(0));                                    /* :2351-2352 */
+      updatelmtNS(1, Q, n, Omega, prior, row, 1, 0, HS(1));
+    } else {                                                                                   /* :2828-2832 */
+      updateksl(0, Q, n, Omega, prior, row, 1, 0, HS(0), 1);
+      updateksl(1, Q, n, Omega, prior, row, 1, 0, HS(1), 1);
+      for (int j = 0; j < kk; ++j) updaterkappas(Q, n, Omega, prior, row, 1, 0, HS(2 + j), j, 1);
+      for (int j = 1; j <= kk; ++j) updatelkappas(Q, n, Omega, prior, row, 1, 0, HS(2 + kk + j), j, 1);
+      for (int j = 1; j <= kk; ++j) updategammas(Q, n, Omega, prior, row, 1, 0, HS(2 + 2 * kk + j), j, 1);
+    }
+#undef HS
+    model_from_Q(Q, n, Omega, B2, Bc, Qd);
+  }
+  for (int j = 0; j < treecount; ++j) { e |= rcs[j].err; chain_free(&ch[j]); }
+  e |= rc0.err;
+  free(weights); free(rows); free(rcs); free(rngs); free(ch); free(Qd); free(Bc); free(B2); free(Q);
+  return e;
 }
 
 #undef QQ
@@ -878,21 +1025,27 @@ int orc_maketreelistMCMC_qupdate(const orc_tree* x, int n, const double* Q_cm, c
 int orc_qupdate_apply(int variant, int n, double* Q_rm, double Omega, const double* prior, const double* row,
                       uint32_t seed_lo, uint32_t seed_hi, uint32_t iter) {
   orc_rng r; memset(&r, 0, sizeof r); r.mode = 0; r.seed_lo = seed_lo; r.seed_hi = seed_hi;
-  rngctx rc = { &r, 0 };
+  rngctx rc = { &r, 0, 0 };
   hstream h = { &rc, iter, 0, 0 };
   const int kk = n / 2 - 1;
 #define HS(id) (h.ent = 0xFFFFFF00u | (uint32_t)(id), h.d = 0, &h)
-  if (variant == ORC_MCMC_BF) {
+  if (variant == ORC_MCMC_BF || variant == ORC_MCMC_MT) {
     if (n != 2) return ORC_ERR_BAD_INPUT;
-    updatel01(Q_rm, n, Omega, prior, row, 1, 0, HS(0));
-    updatel10(Q_rm, n, Omega, prior, row, 1, 0, HS(1));
-  } else if (variant == ORC_MCMC_KS) {
+    if (variant == ORC_MCMC_MT) {
+      updatelmtNS(0, Q_rm, n, Omega, prior, row, 1, 0, HS(0));
+      updatelmtNS(1, Q_rm, n, Omega, prior, row, 1, 0, HS(1));
+    } else {
+      updatel01(Q_rm, n, Omega, prior, row, 1, 0, HS(0));
+      updatel10(Q_rm, n, Omega, prior, row, 1, 0, HS(1));
+    }
+  } else if (variant == ORC_MCMC_KS || variant == ORC_MCMC_KSMT) {
+    const int mt = (variant == ORC_MCMC_KSMT);
     if (n < 4 || (n & 1) || n > 64) return ORC_ERR_BAD_INPUT;
-    updateksl(0, Q_rm, n, Omega, prior, row, 1, 0, HS(0));
-    updateksl(1, Q_rm, n, Omega, prior, row, 1, 0, HS(1));
-    for (int j = 0; j < kk; ++j) updaterkappas(Q_rm, n, Omega, prior, row, 1, 0, HS(2 + j), j);
-    for (int j = 1; j <= kk; ++j) updatelkappas(Q_rm, n, Omega, prior, row, 1, 0, HS(2 + kk + j), j);
-    for (int j = 1; j <= kk; ++j) updategammas(Q_rm, n, Omega, prior, row, 1, 0, HS(2 + 2 * kk + j), j);
+    updateksl(0, Q_rm, n, Omega, prior, row, 1, 0, HS(0), mt);
+    updateksl(1, Q_rm, n, Omega, prior, row, 1, 0, HS(1), mt);
+    for (int j = 0; j < kk; ++j) updaterkappas(Q_rm, n, Omega, prior, row, 1, 0, HS(2 + j), j, mt);
+    for (int j = 1; j <= kk; ++j) updatelkappas(Q_rm, n, Omega, prior, row, 1, 0, HS(2 + kk + j), j, mt);
+    for (int j = 1; j <= kk; ++j) updategammas(Q_rm, n, Omega, prior, row, 1, 0, HS(2 + 2 * kk + j), j, mt);
   } else return ORC_ERR_BAD_INPUT;
 #undef HS
   return 0;
@@ -1100,7 +1253,7 @@ int orc_maketreelistEXP(const orc_tree* x, int n, const double* Q_cm, const doub
   const int32_t* edge1 = x->edge; const int32_t* edge2 = x->edge + E;
   int cols = n + n * (n - 1);
   size_t nn = (size_t)n * n;
-  rngctx rc = { rng, 0 };
+  rngctx rc = { rng, 0, 0 };
   if (rng->mode == 2) return ORC_ERR_BAD_INPUT;       /* R-stream mode: Rf_dpois (saddle-point) is not restated */
   g_rstream = 0;
 

@@ -42,6 +42,8 @@ extern "C" {
 
 #define ORC_MCMC_BF       4   /* tree sweep of maketreelistMCMCbf src/phylomap.cpp:1258-1305 (two states, tips observed,
                                  shortenerbf counts, columns l01 l10 root); out: N x 9 */
+#define ORC_MCMC_MT       5   /* maketreelistMCMCmt   src/phylomap.cpp:2267-2365: list of trees, two states, Q updated */
+#define ORC_MCMC_KSMT     6   /* maketreelistMCMCksmt src/phylomap.cpp:2722-2844: list of trees, hidden rates */
 
 /* RNG: mode 0 = counter-based Philox4x32-10 streams (the mode the GPU matches bit for bit);
  *      mode 1 = scripted tapes consumed in the reference's draw order (for hand KATs);
@@ -120,6 +122,14 @@ int orc_maketreelistMCMC_qupdate(const orc_tree* x, int n, const double* Q_cm, c
 
 int orc_qupdate_apply(int variant, int n, double* Q_rm, double Omega, const double* prior, const double* row,
                       uint32_t seed_lo, uint32_t seed_hi, uint32_t iter);
+
+/* Multi-tree drivers (variant ORC_MCMC_MT / ORC_MCMC_KSMT): xs = `treecount` trees with equal tip / edge counts,
+ * nen_m treecount x 2*Nnode, nodelist_m treecount x (Nnode-1) row-major, roots[treecount].  out: N x (n+n*n+2+3k+1)
+ * column-major, the last column the 0-based index of the tree drawn that iteration (R/sumstatMCMCmt.R:41). */
+int orc_maketreelistMCMCmt(const orc_tree* const* xs, int treecount, int n, const double* Q_cm, const double* pid,
+                           const double* B_cm, double Omega, const int32_t* nen_m, const int32_t* nodelist_m,
+                           const int32_t* roots, int32_t N, int variant, const double* prior, int faithful_search,
+                           orc_rng* rng, double* out);
 
 /* maketreelistEXP src/phylomap.cpp:3001-3051. lefts/rights column-major, d = n x n col-major (diag used). */
 int orc_maketreelistEXP(const orc_tree* x, int n, const double* Q_cm, const double* pid,

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("PHM_LIB", os.path.join(_HERE, "libphylomap_hip.so")) 
 PHM_OK = 0
 STATUS = {0: "PHM_OK", 1: "PHM_ERR_BAD_INPUT", 2: "PHM_ERR_UNSUPPORTED", 3: "PHM_ERR_NO_DEVICE", 4: "PHM_ERR_OOM",
           5: "PHM_ERR_ZERO_PROB", 6: "PHM_ERR_CAPACITY", 7: "PHM_ERR_UNIF_CAP", 8: "PHM_ERR_STATE"}
-PHM_MCMC, PHM_MCMC_BIGTREE, PHM_MCMC_SPARSE, PHM_MCMC_KS, PHM_MCMC_BF = 0, 1, 2, 3, 4
+PHM_MCMC, PHM_MCMC_BIGTREE, PHM_MCMC_SPARSE, PHM_MCMC_KS, PHM_MCMC_BF, PHM_MCMC_MT, PHM_MCMC_KSMT = 0, 1, 2, 3, 4, 5, 6
 
 EXPORTS = [
     "phm_version", "phm_device_count", "phm_last_error", "phm_status_string",
@@ -23,6 +23,7 @@ EXPORTS = [
     "phm_engine_create", "phm_engine_run", "phm_engine_sync", "phm_engine_read_stats", "phm_engine_dump",
     "phm_engine_info", "phm_engine_destroy", "phm_engine_reduced_stats_device",
     "phm_engine_time_pruning", "phm_tree_orders",
+    "phm_engine_create_multi", "phm_maketreelistMCMCmt", "phm_maketreelistMCMCksmt",
 ]
 
 
@@ -78,6 +79,8 @@ def load():
         L.phm_status_string.argtypes = [C.c_int32]
         L.phm_engine_create.argtypes = [C.POINTER(Tree), C.POINTER(Model), C.POINTER(Options), C.c_int32,
                                         C.POINTER(C.c_void_p)]
+        L.phm_engine_create_multi.argtypes = [C.POINTER(Tree), C.c_int32, C.POINTER(Model), C.POINTER(Options), C.c_int32,
+                                              C.POINTER(C.c_void_p)]
         L.phm_engine_run.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         L.phm_engine_sync.argtypes = [C.c_void_p]
         L.phm_engine_read_stats.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
@@ -103,6 +106,11 @@ def load():
         L.phm_maketreelistMCMCks.argtypes = mcq
         L.phm_maketreelistMCMC2sDICt.argtypes = mcq
         L.phm_maketreelistMCMCksDICt.argtypes = mcq
+        mt = [C.POINTER(Tree), C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+              C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32,
+              C.POINTER(C.c_double), C.c_int32, C.POINTER(Options), C.POINTER(C.c_double)]
+        L.phm_maketreelistMCMCmt.argtypes = mt
+        L.phm_maketreelistMCMCksmt.argtypes = mt
         L.phm_engine_set_model.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         L.phm_qupdate_apply.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_double),
                                         C.c_int32, C.POINTER(C.c_double), C.c_uint64, C.c_uint32]
@@ -150,6 +158,18 @@ class FlatTree:
                       _p(self.mapnames, C.c_int32))
 
 
+class FlatTreeList:
+    """A list of phylomap trees (R/sumstatMCMCmt.R:33) as one contiguous array of ``phm_tree``."""
+
+    def __init__(self, treelist):
+        if len(treelist) < 1:
+            raise ValueError("treelist is empty")
+        self.trees = [FlatTree(z) for z in treelist]
+        self.n = len(self.trees)
+        self.c = (Tree * self.n)(*[t.c for t in self.trees])
+        self.E, self.T = self.trees[0].E, self.trees[0].T
+
+
 def tree_orders(z):
     """(nen, nodelist, root) computed natively in O(E): phm_tree_orders, the replacement of R/sumstatMCMC.R:1-18."""
     edge = np.asarray(z["edge"], dtype=np.int32)
@@ -182,19 +202,28 @@ class Engine:
         self.n = self.Q.shape[0]
         self.pid = np.ascontiguousarray(pid, dtype=np.float64)
         self.B = None if B is None else np.asfortranarray(np.asarray(B, dtype=np.float64))
-        self.ft = FlatTree(z, states)
         self.opt = make_options(**opt)
         self.model = Model(self.n, _p(self.Q, C.c_double), _p(self.pid, C.c_double), _p(self.B, C.c_double),
                            float(Omega), int(variant))
         self.h = C.c_void_p()
-        check(L.phm_engine_create(C.byref(self.ft.c), C.byref(self.model), C.byref(self.opt), int(max_iters),
-                                  C.byref(self.h)))
+        n_trees = 1
+        if isinstance(z, (list, tuple)):      # a list of trees sharing the model: n_replicas chains per tree
+            if states is not None:
+                raise ValueError("a list of trees carries its own tip states")
+            self.ft = FlatTreeList(z)
+            n_trees = self.ft.n
+            check(L.phm_engine_create_multi(self.ft.c, n_trees, C.byref(self.model), C.byref(self.opt), int(max_iters),
+                                            C.byref(self.h)))
+        else:
+            self.ft = FlatTree(z, states)
+            check(L.phm_engine_create(C.byref(self.ft.c), C.byref(self.model), C.byref(self.opt), int(max_iters),
+                                      C.byref(self.h)))
         self.cols = self.n + self.n * (self.n - 1)
-        if int(variant) == PHM_MCMC_KS:
+        if int(variant) in (PHM_MCMC_KS, PHM_MCMC_KSMT):
             self.cols = self.n + self.n * self.n + 2 + 3 * (self.n // 2 - 1) + 1
-        if int(variant) == PHM_MCMC_BF:
+        if int(variant) in (PHM_MCMC_BF, PHM_MCMC_MT):
             self.cols = 9
-        self.S = max(1, int(self.opt.n_replicas))
+        self.S = max(1, int(self.opt.n_replicas)) * n_trees      # tree-major: replica j * n_replicas + c
         self.reduce = bool(self.opt.reduce)
 
     def run(self, n_iters, stream=None):

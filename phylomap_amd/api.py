@@ -109,6 +109,42 @@ def sumstatMCMCksDICt(z, Q, pid, Omega, N, prior, **opt):
     return _qupdate("phm_maketreelistMCMCksDICt", z, Q, pid, Omega, N, prior, n + n * n + 2 + 3 * (n // 2 - 1) + 2, **opt)
 
 
+def _qupdate_mt(fn_name, treelist, Q, pid, Omega, N, prior, cols, **opt):
+    L = _lib.load()
+    Q = np.asfortranarray(np.asarray(Q, dtype=np.float64))
+    n = Q.shape[0]
+    orders = [_lib.tree_orders(z) for z in treelist]                 # R/sumstatMCMCmt.R:37-46, one row per tree
+    nen_m = np.asfortranarray(np.stack([o[0] for o in orders]), dtype=np.int32)
+    nodelist_m = np.asfortranarray(np.stack([o[1] for o in orders]), dtype=np.int32)
+    roots = np.ascontiguousarray([o[2] for o in orders], dtype=np.int32)
+    B = np.asfortranarray(np.eye(n) + Q / Omega)
+    pid = np.ascontiguousarray(pid, dtype=np.float64)
+    prior = np.ascontiguousarray(prior, dtype=np.float64)
+    ftl = _lib.FlatTreeList(treelist)
+    o = _lib.make_options(**opt)
+    out = np.zeros((N, cols), order="F")
+    st = getattr(L, fn_name)(ftl.c, ftl.n, n, _lib._p(Q, C.c_double), _lib._p(pid, C.c_double), _lib._p(B, C.c_double),
+                             float(Omega), _lib._p(nen_m, C.c_int32), _lib._p(nodelist_m, C.c_int32),
+                             _lib._p(roots, C.c_int32), int(N), _lib._p(prior, C.c_double), int(prior.size), C.byref(o),
+                             _lib._p(out, C.c_double))
+    _lib.check(st)
+    return out
+
+
+def sumstatMCMCmt(treelist, Q, pid, Omega, N, prior, **opt):
+    """R/sumstatMCMCmt.R:29-52 -> phm_maketreelistMCMCmt: two-state model over a list of trees (same tips, different
+    topologies / branch lengths); every iteration sweeps every tree, keeps one drawn uniformly and updates the rates from
+    it.  Columns: time_0, time_1, n00, n01, n10, n11, l01, l10, tree_number (0-based, as the reference stores it)."""
+    return _qupdate_mt("phm_maketreelistMCMCmt", treelist, Q, pid, Omega, N, prior, 9, **opt)
+
+
+def sumstatMCMCksmt(treelist, Q, pid, Omega, N, prior, **opt):
+    """R/sumstatMCMCksmt.R -> phm_maketreelistMCMCksmt: hidden-rates model (n = 2k+2) over a list of trees; ``prior`` has
+    8 entries (l01, l10, kappa, gamma shape/rate pairs).  Columns as ``sumstatMCMCks`` with tree_number last."""
+    n = np.asarray(Q).shape[0]
+    return _qupdate_mt("phm_maketreelistMCMCksmt", treelist, Q, pid, Omega, N, prior, n + n * n + 2 + 3 * (n // 2 - 1) + 1, **opt)
+
+
 def eigen_decompose(Q):
     """R/sumstatEXP.R:26-29: lefts = eigen(Q)$vectors, rights = solve(lefts), d = diag(values) (real spectrum only)."""
     vals, vecs = np.linalg.eig(np.asarray(Q, dtype=np.float64))

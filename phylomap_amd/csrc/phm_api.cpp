@@ -74,8 +74,13 @@ struct phm_engine {
   std::vector<double> hB2, hBc, hscale, hpid;      // current model, row-major
   int S = 0, S_pad = 0, tiles = 0, max_iters = 0, iters_done = 0, ipl = 0;
   int reduce = 0, device = 0;
-  phm::Schedule sched;
-  std::vector<uint8_t> tips_host;      // 0-based, [n_tips] or [S][n_tips]
+  phm::Schedule sched;                 // tree 0 (every tree of a list has the same tip / edge counts)
+  std::vector<phm::Schedule> scheds;   // one per tree
+  int n_trees = 1, S_tree = 0, tpt = 0;   // list of trees: S_tree chains per tree on tpt tiles each; S = n_trees * S_tree
+  DevBuf d_roots;
+  // logical replica r (tree-major) -> lane index in the padded device layout
+  int pad_index(int r) const { return n_trees > 1 ? (r / S_tree) * tpt * 64 + r % S_tree : r; }
+  std::vector<uint8_t> tips_host;      // 0-based, [n_tips] or [tile][n_tips][64]
   bool tips_per_replica = false;
   int64_t rows = 0;
   DevBuf d_mask;
@@ -102,14 +107,19 @@ struct phm_engine {
 
 namespace {
 
+bool ks_layout(int v) { return v == PHM_MCMC_KS || v == PHM_MCMC_BF || v == PHM_MCMC_MT || v == PHM_MCMC_KSMT; }   // n x n counts, root column
+bool hidden_rates(int v) { return v == PHM_MCMC_KS || v == PHM_MCMC_KSMT; }                                         // parity tip masks
+bool normalised(int v) { return v == PHM_MCMC_BIGTREE || v == PHM_MCMC_KS || v == PHM_MCMC_BF; }                   // makePLnormalized :1085
+
 template <int NS>
 void fill_params(phm_engine* e, phm::McmcParams<NS>& p, const double* B2, const double* Bc, const double* scale,
                  const double* pid, const phm_options& o) {
   p.n_tips = e->sched.n_tips; p.n_node = e->sched.n_node; p.n_edge = e->sched.n_edge; p.root = e->sched.root;
-  p.n_tiles = e->tiles; p.n_rep = e->S; p.n_rep_pad = e->S_pad; p.replica_offset = o.replica_offset;
-  p.normalise = (e->variant == PHM_MCMC_BIGTREE || e->variant == PHM_MCMC_KS || e->variant == PHM_MCMC_BF); p.tips_per_replica = e->tips_per_replica ? 1 : 0;
+  p.n_tiles = e->tiles; p.n_rep = e->n_trees > 1 ? e->S_tree : e->S; p.n_rep_pad = e->S_pad; p.replica_offset = o.replica_offset;
+  p.tiles_per_tree = e->n_trees > 1 ? e->tpt : 0; p.roots = e->d_roots.as<int32_t>();
+  p.normalise = normalised(e->variant); p.tips_per_replica = e->tips_per_replica ? 1 : 0;
   p.reduce = e->reduce; p.n_cols = e->dcols; p.ktab = phm::MCMC_KTAB; p.prune_only = 0;
-  p.ks = (e->variant == PHM_MCMC_KS || e->variant == PHM_MCMC_BF); p.tip_masks = (e->variant == PHM_MCMC_KS);
+  p.ks = ks_layout(e->variant); p.tip_masks = hidden_rates(e->variant);
   p.maskpow = e->d_mask.as<double>();
   p.seed_lo = (uint32_t)(o.seed & 0xFFFFFFFFull); p.seed_hi = (uint32_t)(o.seed >> 32);
   p.rows = e->rows;
@@ -183,8 +193,8 @@ int32_t compute_model(int variant, int n, const double* Q, const double* B, doub
     }
   }
   qparams.clear();
-  if (variant == PHM_MCMC_KS || variant == PHM_MCMC_BF) {
-    const int k = (variant == PHM_MCMC_KS) ? n / 2 - 1 : 0;
+  if (ks_layout(variant)) {
+    const int k = hidden_rates(variant) ? n / 2 - 1 : 0;
     auto Qe = [&](int i, int j) { return Q[i + (size_t)j * n]; };
     qparams.push_back(Qe(0, 1));
     qparams.push_back(Qe(1, 0));
@@ -264,9 +274,16 @@ const char* phm_status_string(int32_t s) {
 
 int32_t phm_engine_create(const phm_tree* x, const phm_model* model, const phm_options* opt_in, int32_t max_iters,
                           phm_engine** out) {
+  return phm_engine_create_multi(x, 1, model, opt_in, max_iters, out);
+}
+
+int32_t phm_engine_create_multi(const phm_tree* trees, int32_t n_trees, const phm_model* model, const phm_options* opt_in,
+                                int32_t max_iters, phm_engine** out) {
   if (!out) return fail(PHM_ERR_BAD_INPUT, "out is NULL");
   *out = nullptr;
-  if (!x || !model) return fail(PHM_ERR_BAD_INPUT, "tree/model is NULL");
+  if (!trees || !model) return fail(PHM_ERR_BAD_INPUT, "tree/model is NULL");
+  if (n_trees < 1) return fail(PHM_ERR_BAD_INPUT, "n_trees must be >= 1");
+  const phm_tree* x = trees;
   phm_options o;
   std::memset(&o, 0, sizeof(o));
   o.device = -1;
@@ -276,13 +293,19 @@ int32_t phm_engine_create(const phm_tree* x, const phm_model* model, const phm_o
   if (n < 2) return fail(PHM_ERR_BAD_INPUT, "n_states must be >= 2");
   if (n > 64) return fail(PHM_ERR_UNSUPPORTED, "this build has MCMC kernels for n_states <= 64 only");
   if (!model->Q || !model->pid) return fail(PHM_ERR_BAD_INPUT, "model: Q/pid missing");
-  if (model->variant < PHM_MCMC || model->variant > PHM_MCMC_BF) return fail(PHM_ERR_BAD_INPUT, "unknown variant");
-  if (model->variant == PHM_MCMC_KS && (n & 1)) return fail(PHM_ERR_BAD_INPUT, "sumstatMCMCks needs a hidden-rates Q of even size n = 2k+2 (src/phylomap.cpp:1820)");
-  if (model->variant == PHM_MCMC_BF && n != 2) return fail(PHM_ERR_BAD_INPUT, "sumstatMCMCbf is the two-state model (hard-wired columns, src/phylomap.cpp:1181-1185)");
+  if (model->variant < PHM_MCMC || model->variant > PHM_MCMC_KSMT) return fail(PHM_ERR_BAD_INPUT, "unknown variant");
+  if (hidden_rates(model->variant) && (n & 1)) return fail(PHM_ERR_BAD_INPUT, "sumstatMCMCks needs a hidden-rates Q of even size n = 2k+2 (src/phylomap.cpp:1820)");
+  if ((model->variant == PHM_MCMC_BF || model->variant == PHM_MCMC_MT) && n != 2) return fail(PHM_ERR_BAD_INPUT, "sumstatMCMCbf / sumstatMCMCmt are two-state models (hard-wired columns, src/phylomap.cpp:1181-1185, :2169-2173)");
+  if (n_trees > 1 && (o.reduce || o.tips_per_replica)) return fail(PHM_ERR_UNSUPPORTED, "a list of trees takes neither reduce nor tips_per_replica");
   if (max_iters < 1) return fail(PHM_ERR_BAD_INPUT, "max_iters must be >= 1");
   if (!(model->Omega > 0.0) || !std::isfinite(model->Omega)) return fail(PHM_ERR_BAD_INPUT, "Omega must be positive");
-  int32_t st = validate_tree_paths(x, n, o.tips_per_replica ? o.n_replicas : 1);
-  if (st) return st;
+  int32_t st = PHM_OK;
+  for (int j = 0; j < n_trees; ++j) {
+    if (trees[j].n_tips != x->n_tips || trees[j].n_edge != x->n_edge || trees[j].n_node != x->n_node)
+      return fail(PHM_ERR_BAD_INPUT, "every tree of the list must have the same number of tips and edges (src/phylomap.cpp:2275-2287)");
+    st = validate_tree_paths(&trees[j], n, o.tips_per_replica ? o.n_replicas : 1);
+    if (st) return st;
+  }
 
   // model matrices, row-major copies (inputs are R's column-major)
   std::vector<double> B2v, Bcv, scalev, pidv(n), qp;
@@ -299,21 +322,25 @@ int32_t phm_engine_create(const phm_tree* x, const phm_model* model, const phm_o
   e->n = n; e->cols = n + n * (n - 1); e->variant = model->variant;
   e->dcols = e->cols;
   e->wide = n > 4;
-  if (e->variant == PHM_MCMC_KS || e->variant == PHM_MCMC_BF) {
-    const int k = (e->variant == PHM_MCMC_KS) ? n / 2 - 1 : 0;
+  if (ks_layout(e->variant)) {
+    const int k = hidden_rates(e->variant) ? n / 2 - 1 : 0;
     e->cols = n + n * n + 2 + 3 * k + 1;        // man/sumstatMCMCks.Rd:19; bf: src/phylomap.cpp:1293
     e->dcols = n + n * n + 1;
   }
   e->qparams = qp;
   e->Omega = model->Omega;
   e->hB2 = B2v; e->hBc = Bcv; e->hscale = scalev; e->hpid = pidv;
-  e->S = o.n_replicas; e->tiles = (e->S + 63) / 64; e->S_pad = e->tiles * 64;
+  e->n_trees = n_trees; e->S_tree = o.n_replicas; e->tpt = (o.n_replicas + 63) / 64;
+  e->S = n_trees * o.n_replicas; e->tiles = n_trees * e->tpt; e->S_pad = e->tiles * 64;
   e->max_iters = max_iters; e->reduce = o.reduce ? 1 : 0;
   e->ipl = o.iters_per_launch > 0 ? o.iters_per_launch : 8;
-  e->tips_per_replica = o.tips_per_replica != 0;
+  e->tips_per_replica = o.tips_per_replica != 0 || n_trees > 1;      // a list of trees: tip data per tile
 
   std::string serr;
-  if (!phm::build_schedule(x->n_tips, x->n_node, x->n_edge, x->edge, e->sched, serr)) return fail(PHM_ERR_BAD_INPUT, "tree: " + serr);
+  e->scheds.resize(n_trees);
+  for (int j = 0; j < n_trees; ++j)
+    if (!phm::build_schedule(x->n_tips, x->n_node, x->n_edge, trees[j].edge, e->scheds[j], serr)) return fail(PHM_ERR_BAD_INPUT, "tree: " + serr);
+  e->sched = e->scheds[0];
   phm::Schedule& s = e->sched;
   st = select_device(o.device);          // every input check above runs without a device
   if (st) return st;
@@ -324,34 +351,43 @@ int32_t phm_engine_create(const phm_tree* x, const phm_model* model, const phm_o
   // (t_b = sum(x$maps[[b]])) and occupies max-over-64-lanes rows; provision the per-branch quantile at
   // `cap_tail` (default 1e-3, i.e. beyond the expected maximum of 64 draws) and check at run time.
   int64_t rows = 0;
-  int64_t max_q = 0;
-  double sum_lambda = 0.0;
-  std::vector<int32_t> init_row(E);
-  int64_t init_rows = 0;
-  for (int k = 0; k < E; ++k) {
-    const phm::DownStep& d = s.down[k];
-    double tb = 0.0;
-    for (int i = x->map_off[d.edge]; i < x->map_off[d.edge + 1]; ++i) tb += x->maps[i];
-    int m0 = x->map_off[d.edge + 1] - x->map_off[d.edge];
-    init_row[k] = (int32_t)init_rows;
-    init_rows += m0;
-    // a sweep keeps at most the m merged segments it was given and adds Poisson(<= Omega t_b) virtual jumps, so a
-    // caller-supplied path longer than the stationary quantile (e.g. 100 equal pieces) needs m0 + that quantile
-    int q = phm::poisson_capacity(model->Omega * tb, o.cap_tail > 0.0 ? o.cap_tail : 1e-3);
-    rows += std::max(q, m0 + q - 1);
-    max_q = std::max<int64_t>(max_q, std::max(q, m0 + q - 1));
-    sum_lambda += model->Omega * tb;
+  std::vector<std::vector<int32_t>> init_row(n_trees, std::vector<int32_t>(E));
+  std::vector<int64_t> init_rows(n_trees, 0);
+  for (int j = 0; j < n_trees; ++j) {
+    const phm_tree* xt = &trees[j];
+    int64_t rows_j = 0, max_q = 0;
+    double sum_lambda = 0.0;
+    for (int k = 0; k < E; ++k) {
+      const phm::DownStep& d = e->scheds[j].down[k];
+      double tb = 0.0;
+      for (int i = xt->map_off[d.edge]; i < xt->map_off[d.edge + 1]; ++i) tb += xt->maps[i];
+      int m0 = xt->map_off[d.edge + 1] - xt->map_off[d.edge];
+      init_row[j][k] = (int32_t)init_rows[j];
+      init_rows[j] += m0;
+      // a sweep keeps at most the m merged segments it was given and adds Poisson(<= Omega t_b) virtual jumps, so a
+      // caller-supplied path longer than the stationary quantile (e.g. 100 equal pieces) needs m0 + that quantile
+      int q = phm::poisson_capacity(model->Omega * tb, o.cap_tail > 0.0 ? o.cap_tail : 1e-3);
+      rows_j += std::max(q, m0 + q - 1);
+      max_q = std::max<int64_t>(max_q, std::max(q, m0 + q - 1));
+      sum_lambda += model->Omega * tb;
+    }
+    // Ring capacity: the stream being read, plus head-room for the stream being written behind it.  While branch k is
+    // processed its input rows are still occupied and its output rows are already being written (one full branch of
+    // slack), and rows written so far minus rows freed so far performs a random walk whose standard deviation is about
+    // 0.7 sqrt(sum lambda) (wave-maximum of 64 Poisson counts per branch); 6 sigma of that on top.
+    rows_j = std::max(rows_j, init_rows[j]) + max_q + (int64_t)(6.0 * 0.7 * std::sqrt(sum_lambda)) + 64;
+    rows = std::max(rows, rows_j);
   }
-  // Ring capacity: the stream being read, plus head-room for the stream being written behind it.  While branch k is
-  // processed its input rows are still occupied and its output rows are already being written (one full branch of
-  // slack), and rows written so far minus rows freed so far performs a random walk whose standard deviation is about
-  // 0.7 sqrt(sum lambda) (wave-maximum of 64 Poisson counts per branch); 6 sigma of that on top.
-  rows = std::max(rows, init_rows) + max_q + (int64_t)(6.0 * 0.7 * std::sqrt(sum_lambda)) + 64;
   if (rows * 64 > 0x7fffff00ll) return fail(PHM_ERR_UNSUPPORTED, "tree too large: dwell rows per replica tile exceed 32-bit indexing");
   e->rows = rows;
 
   // tips (0-based u8)
-  if (e->tips_per_replica) {
+  if (n_trees > 1) {
+    e->tips_host.assign((size_t)e->tiles * T * 64, 0);
+    for (int tl = 0; tl < e->tiles; ++tl)
+      for (int t = 0; t < T; ++t)
+        std::memset(&e->tips_host[((size_t)tl * T + t) * 64], trees[tl / e->tpt].states[t] - 1, 64);
+  } else if (e->tips_per_replica) {
     e->tips_host.assign((size_t)e->tiles * T * 64, 0);
     for (int r = 0; r < e->S_pad; ++r) {
       int src = r < e->S ? r : e->S - 1;
@@ -382,8 +418,9 @@ int32_t phm_engine_create(const phm_tree* x, const phm_model* model, const phm_o
     std::snprintf(buf, sizeof buf, "engine needs %.2f GiB of HBM, %.2f GiB free (reduce n_replicas or max_iters)", need / 1073741824.0, free_b / 1073741824.0);
     return fail(PHM_ERR_OOM, buf);
   }
-  HIPCHK(e->d_up.alloc(sizeof(phm::UpStep) * s.up.size()));
-  HIPCHK(e->d_down.alloc(sizeof(phm::DownStep) * s.down.size()));
+  HIPCHK(e->d_up.alloc(sizeof(phm::UpStep) * s.up.size() * n_trees));
+  HIPCHK(e->d_down.alloc(sizeof(phm::DownStep) * s.down.size() * n_trees));
+  HIPCHK(e->d_roots.alloc(sizeof(int32_t) * n_trees));
   HIPCHK(e->d_col.alloc(sizeof(double) * col.size()));
   HIPCHK(e->d_row.alloc(sizeof(double) * row.size()));
   HIPCHK(e->d_mask.alloc(sizeof(double) * maskpow.size()));
@@ -402,27 +439,35 @@ int32_t phm_engine_create(const phm_tree* x, const phm_model* model, const phm_o
   e->bytes = (int64_t)(e->d_up.bytes + e->d_down.bytes + e->d_col.bytes + e->d_row.bytes + e->d_tips.bytes + e->d_mcount.bytes +
                        e->d_dw0.bytes + e->d_dw1.bytes + e->d_cursor.bytes + e->d_PL.bytes + e->d_nstate.bytes + e->d_stats.bytes + e->d_red.bytes);
 
-  HIPCHK(hipMemcpy(e->d_up.p, s.up.data(), e->d_up.bytes, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(e->d_down.p, s.down.data(), e->d_down.bytes, hipMemcpyHostToDevice));
+  for (int j = 0; j < n_trees; ++j) {
+    const phm::Schedule& sj = e->scheds[j];
+    HIPCHK(hipMemcpy(e->d_up.as<phm::UpStep>() + (size_t)j * sj.up.size(), sj.up.data(), sizeof(phm::UpStep) * sj.up.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_down.as<phm::DownStep>() + (size_t)j * sj.down.size(), sj.down.data(), sizeof(phm::DownStep) * sj.down.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_roots.as<int32_t>() + j, &sj.root, sizeof(int32_t), hipMemcpyHostToDevice));
+  }
   HIPCHK(hipMemcpy(e->d_tips.p, e->tips_host.data(), e->tips_host.size(), hipMemcpyHostToDevice));
   HIPCHK(hipMemset(e->d_err.p, 0, sizeof(uint32_t)));
   HIPCHK(hipMemset(e->d_seg.p, 0, sizeof(unsigned long long)));
   HIPCHK(hipMemset(e->d_stats.p, 0, stats_bytes));
   HIPCHK(hipMemset(e->d_nstate.p, 0, e->d_nstate.bytes));
 
-  {   // initial paths -> every replica (makeabranch, src/phylomap.cpp:24-34, :901)
-    DevBuf d_off, d_maps, d_irow;
-    HIPCHK(d_irow.alloc(sizeof(int32_t) * E));
-    HIPCHK(hipMemcpy(d_irow.p, init_row.data(), d_irow.bytes, hipMemcpyHostToDevice));
-    HIPCHK(d_off.alloc(sizeof(int32_t) * (E + 1)));
-    HIPCHK(d_maps.alloc(sizeof(double) * (size_t)x->map_off[E]));
-    HIPCHK(hipMemcpy(d_off.p, x->map_off, d_off.bytes, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_maps.p, x->maps, d_maps.bytes, hipMemcpyHostToDevice));
-    HIPCHK(phm::launch_mcmc_init(E, e->tiles, rows, e->d_down.as<phm::DownStep>(), d_irow.as<int32_t>(), d_off.as<int32_t>(), d_maps.as<double>(),
-                                 e->d_dw0.as<double>(), e->d_mcount.as<uint16_t>(), nullptr));
-    HIPCHK(hipDeviceSynchronize());
+  {   // initial paths -> every replica (makeabranch, src/phylomap.cpp:24-34, :901), tree by tree
     std::vector<int32_t> cur(2 * (size_t)e->tiles);
-    for (int t = 0; t < e->tiles; ++t) { cur[2 * t] = 0; cur[2 * t + 1] = e->ring ? (int32_t)(init_rows % rows) : 0; }
+    for (int j = 0; j < n_trees; ++j) {
+      const phm_tree* xt = &trees[j];
+      DevBuf d_off, d_maps, d_irow;
+      HIPCHK(d_irow.alloc(sizeof(int32_t) * E));
+      HIPCHK(hipMemcpy(d_irow.p, init_row[j].data(), d_irow.bytes, hipMemcpyHostToDevice));
+      HIPCHK(d_off.alloc(sizeof(int32_t) * (E + 1)));
+      HIPCHK(d_maps.alloc(sizeof(double) * (size_t)xt->map_off[E]));
+      HIPCHK(hipMemcpy(d_off.p, xt->map_off, d_off.bytes, hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(d_maps.p, xt->maps, d_maps.bytes, hipMemcpyHostToDevice));
+      const size_t tile0 = (size_t)j * e->tpt;
+      HIPCHK(phm::launch_mcmc_init(E, e->tpt, rows, e->d_down.as<phm::DownStep>() + (size_t)j * E, d_irow.as<int32_t>(), d_off.as<int32_t>(),
+                                   d_maps.as<double>(), e->d_dw0.as<double>() + tile0 * rows * 64, e->d_mcount.as<uint16_t>() + tile0 * E * 64, nullptr));
+      HIPCHK(hipDeviceSynchronize());
+      for (int t = 0; t < e->tpt; ++t) { cur[2 * (tile0 + t)] = 0; cur[2 * (tile0 + t) + 1] = e->ring ? (int32_t)(init_rows[j] % rows) : 0; }
+    }
     HIPCHK(hipMemcpy(e->d_cursor.p, cur.data(), e->d_cursor.bytes, hipMemcpyHostToDevice));
   }
 
@@ -435,9 +480,10 @@ int32_t phm_engine_create(const phm_tree* x, const phm_model* model, const phm_o
     HIPCHK(hipMemcpy(e->d_pid.p, pid, e->d_pid.bytes, hipMemcpyHostToDevice));
     phm::WideParams& p = e->pw;
     p.n_states = n; p.n_tips = s.n_tips; p.n_node = s.n_node; p.n_edge = s.n_edge; p.root = s.root;
-    p.n_tiles = e->tiles; p.n_rep = e->S; p.n_rep_pad = e->S_pad; p.replica_offset = o.replica_offset;
-    p.normalise = (e->variant == PHM_MCMC_BIGTREE || e->variant == PHM_MCMC_KS || e->variant == PHM_MCMC_BF); p.tips_per_replica = e->tips_per_replica ? 1 : 0;
-    p.reduce = e->reduce; p.n_cols = e->dcols; p.ktab = phm::WIDE_KTAB; p.sparse = (e->variant == PHM_MCMC_SPARSE); p.ks = (e->variant == PHM_MCMC_KS || e->variant == PHM_MCMC_BF); p.count_self = p.ks; p.tip_masks = (e->variant == PHM_MCMC_KS);
+    p.n_tiles = e->tiles; p.n_rep = n_trees > 1 ? e->S_tree : e->S; p.n_rep_pad = e->S_pad; p.replica_offset = o.replica_offset;
+    p.tiles_per_tree = n_trees > 1 ? e->tpt : 0; p.roots = e->d_roots.as<int32_t>();
+    p.normalise = normalised(e->variant); p.tips_per_replica = e->tips_per_replica ? 1 : 0;
+    p.reduce = e->reduce; p.n_cols = e->dcols; p.ktab = phm::WIDE_KTAB; p.sparse = (e->variant == PHM_MCMC_SPARSE); p.ks = ks_layout(e->variant); p.count_self = p.ks; p.tip_masks = hidden_rates(e->variant);
     p.maskpow = e->d_mask.as<double>();
     p.seed_lo = (uint32_t)(o.seed & 0xFFFFFFFFull); p.seed_hi = (uint32_t)(o.seed >> 32);
     p.rows = e->rows;
@@ -534,7 +580,7 @@ int32_t phm_engine_read_stats(phm_engine* e, int32_t iter0, int32_t n, double* o
     HIPCHK(hipMemcpy(h.data(), e->d_stats.as<double>() + (size_t)iter0 * dcols * e->S_pad, sizeof(double) * h.size(), hipMemcpyDeviceToHost));
     for (int r = 0; r < e->S; ++r) {
       for (int c = 0; c < dcols; ++c)
-        for (int i = 0; i < n; ++i) out[((size_t)r * cols + out_col(c)) * n + i] = h[((size_t)i * dcols + c) * e->S_pad + r];
+        for (int i = 0; i < n; ++i) out[((size_t)r * cols + out_col(c)) * n + i] = h[((size_t)i * dcols + c) * e->S_pad + e->pad_index(r)];
       fill_params(out + (size_t)r * cols * n);
     }
   }
@@ -547,8 +593,9 @@ int32_t phm_engine_dump(phm_engine* e, int32_t replica, int32_t* seg_count, doub
   if (replica < 0 || replica >= e->S) return fail(PHM_ERR_BAD_INPUT, "replica out of range");
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipStreamSynchronize(e->last_stream));
-  const phm::Schedule& s = e->sched;
-  const int E = s.n_edge, T = s.n_tips, n = e->n, tile = replica / 64, lane = replica % 64;
+  const int padded = e->pad_index(replica), tile = padded / 64, lane = padded % 64;
+  const phm::Schedule& s = e->scheds[e->n_trees > 1 ? tile / e->tpt : 0];
+  const int E = s.n_edge, T = s.n_tips, n = e->n;
   std::vector<uint16_t> mc((size_t)E * 64);
   HIPCHK(hipMemcpy(mc.data(), e->d_mcount.as<uint16_t>() + (size_t)tile * E * 64, sizeof(uint16_t) * mc.size(), hipMemcpyDeviceToHost));
   if (seg_count) for (int b = 0; b < E; ++b) seg_count[b] = mc[(size_t)b * 64 + lane];
@@ -1042,13 +1089,15 @@ extern "C" int32_t phm_maketreelistMCMCks(const phm_tree* x, int32_t n, const do
 extern "C" int32_t phm_qupdate_apply(int32_t variant, int32_t n, double* Q, double Omega, const double* prior, int32_t n_prior,
                                      const double* row, uint64_t seed, uint32_t iter) {
   if (!Q || !prior || !row) return fail(PHM_ERR_BAD_INPUT, "phm_qupdate_apply: NULL argument");
-  if (variant == PHM_MCMC_BF) {
-    if (n != 2 || n_prior < 4) return fail(PHM_ERR_BAD_INPUT, "bf: n = 2, prior[4]");
-    phm::bf_updates(Q, Omega, prior, row, seed, iter);
-  } else if (variant == PHM_MCMC_KS) {
-    if (n < 4 || (n & 1) || n > 64 || n_prior < 6) return fail(PHM_ERR_BAD_INPUT, "ks: n = 2k+2 in 4..64, prior[6]");
-    phm::ks_updates(Q, n, Omega, prior, row, seed, iter);
-  } else return fail(PHM_ERR_BAD_INPUT, "variant must be PHM_MCMC_BF or PHM_MCMC_KS");
+  if (variant == PHM_MCMC_BF || variant == PHM_MCMC_MT) {
+    if (n != 2 || n_prior < 4) return fail(PHM_ERR_BAD_INPUT, "bf / mt: n = 2, prior[4]");
+    if (variant == PHM_MCMC_MT) phm::mt_updates(Q, Omega, prior, row, seed, iter);
+    else phm::bf_updates(Q, Omega, prior, row, seed, iter);
+  } else if (variant == PHM_MCMC_KS || variant == PHM_MCMC_KSMT) {
+    const bool mt = variant == PHM_MCMC_KSMT;
+    if (n < 4 || (n & 1) || n > 64 || n_prior < (mt ? 8 : 6)) return fail(PHM_ERR_BAD_INPUT, "ks: n = 2k+2 in 4..64, prior[6] (ksmt: prior[8])");
+    phm::ks_updates(Q, n, Omega, prior, row, seed, iter, mt);
+  } else return fail(PHM_ERR_BAD_INPUT, "variant must be PHM_MCMC_BF, PHM_MCMC_KS, PHM_MCMC_MT or PHM_MCMC_KSMT");
   return PHM_OK;
 }
 
@@ -1064,4 +1113,77 @@ extern "C" int32_t phm_maketreelistMCMCksDICt(const phm_tree* x, int32_t n, cons
                                               double Omega, const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
                                               const double* prior, int32_t n_prior, const phm_options* opt, double* out) {
   return run_qupdate(PHM_MCMC_KS, true, x, n, Q, pid, B, Omega, nen, nodelist, root, N, prior, n_prior, opt, out);
+}
+
+// ---- multi-tree drivers -----------------------------------------------------------------------------------------------
+// maketreelistMCMCmt src/phylomap.cpp:2267-2365 (R/sumstatMCMCmt.R) and maketreelistMCMCksmt :2722-2844 (R/sumstatMCMCksmt.R).
+// One engine over the whole list: tree j's chain lives on replica tile j, so one launch per iteration sweeps every tree with
+// the current Q (:2341-2345); the host then draws the tree whose row is kept (:2347-2350), updates Q from that row and
+// uploads the new model once for all trees.
+static int32_t run_qupdate_mt(int variant, const phm_tree* trees, int32_t n_trees, int32_t n, const double* Q, const double* pid,
+                              double Omega, const int32_t* nen_m, const int32_t* nodelist_m, const int32_t* roots, int32_t N,
+                              const double* prior, int32_t n_prior, const phm_options* opt_in, double* out) {
+  if (!out || !prior || !Q || !trees) return fail(PHM_ERR_BAD_INPUT, "out/prior/Q/trees is NULL");
+  if (N < 1 || n_trees < 1) return fail(PHM_ERR_BAD_INPUT, "N and n_trees must be >= 1");
+  const bool ksmt = variant == PHM_MCMC_KSMT;
+  if (n_prior < (ksmt ? 8 : 4)) return fail(PHM_ERR_BAD_INPUT, ksmt ? "sumstatMCMCksmt needs prior = c(a_l01, b_l01, a_l10, b_l10, a_k, b_k, a_g, b_g) (src/phylomap.cpp:2391-2663)" : "sumstatMCMCmt needs prior = c(a01, b01, a10, b10)");
+  if (ksmt && (n < 4 || (n & 1))) return fail(PHM_ERR_BAD_INPUT, "sumstatMCMCksmt needs n = 2k+2 states with k >= 1 (src/phylomap.cpp:2729)");
+  phm_options o;
+  std::memset(&o, 0, sizeof(o));
+  o.device = -1;
+  if (opt_in) o = *opt_in;
+  if (o.n_replicas > 1) return fail(PHM_ERR_UNSUPPORTED, "the multi-tree drivers run one chain per tree");
+  o.n_replicas = 1; o.reduce = 0; o.tips_per_replica = 0; o.iters_per_launch = 1;
+  phm_model model;
+  model.n_states = n; model.Q = Q; model.pid = pid; model.B = nullptr; model.Omega = Omega; model.variant = variant;
+  phm_engine* e = nullptr;
+  int32_t st = phm_engine_create_multi(trees, n_trees, &model, &o, N, &e);
+  if (st) return st;
+  std::unique_ptr<phm_engine, void (*)(phm_engine*)> guard(e, phm_engine_destroy);
+  const int Nn = e->sched.n_node;
+  if (nen_m || nodelist_m || roots) {      // R's matrices are column-major: row j = elements j, j + n_trees, ...
+    std::vector<int32_t> nen(2 * (size_t)Nn), nodelist(Nn > 1 ? Nn - 1 : 0);
+    std::string serr;
+    for (int j = 0; j < n_trees; ++j) {
+      if (nen_m) for (int i = 0; i < 2 * Nn; ++i) nen[i] = nen_m[j + (size_t)i * n_trees];
+      if (nodelist_m) for (int i = 0; i < Nn - 1; ++i) nodelist[i] = nodelist_m[j + (size_t)i * n_trees];
+      if (!phm::check_reference_orders(e->scheds[j], trees[j].edge, nen_m ? nen.data() : nullptr, nodelist_m ? nodelist.data() : nullptr,
+                                       roots ? roots[j] : e->scheds[j].root + e->sched.n_tips + 1, serr))
+        return fail(PHM_ERR_BAD_INPUT, "tree " + std::to_string(j) + ": " + serr);
+    }
+  }
+  const int ecols = e->cols;                 // n + n*n + 2 + 3k + 1: the engine's root-state column becomes tree_number
+  const size_t nn = (size_t)n * n;
+  std::vector<double> Qw(Q, Q + nn), rows((size_t)n_trees * ecols);
+  for (int i = 0; i < N; ++i) {
+    st = phm_engine_run(e, 1, nullptr);
+    if (!st) st = phm_engine_sync(e);
+    if (!st) st = phm_engine_read_stats(e, i, 1, rows.data());       // one 1 x ecols row per tree
+    if (st) return st;
+    const uint32_t pick = phm::pick_tree(n_trees, o.seed, (uint32_t)i);
+    if (pick >= (uint32_t)n_trees) return fail(PHM_ERR_ZERO_PROB, "sampleOnce ran past the last tree (src/phylomap.cpp:85-89)");
+    const double* row = rows.data() + (size_t)pick * ecols;
+    for (int c = 0; c + 1 < ecols; ++c) out[(size_t)c * N + i] = row[c];
+    out[(size_t)(ecols - 1) * N + i] = (double)pick;                   // :2350, 0-based as the reference stores it
+    if (ksmt) phm::ks_updates(Qw.data(), n, Omega, prior, row, o.seed, (uint32_t)i, true);
+    else phm::mt_updates(Qw.data(), Omega, prior, row, o.seed, (uint32_t)i);
+    if (i + 1 < N) { st = phm_engine_set_model(e, Qw.data()); if (st) return st; }
+  }
+  return PHM_OK;
+}
+
+extern "C" int32_t phm_maketreelistMCMCmt(const phm_tree* trees, int32_t n_trees, int32_t n, const double* Q, const double* pid,
+                                          const double* B, double Omega, const int32_t* nen_m, const int32_t* nodelist_m,
+                                          const int32_t* roots, int32_t N, const double* prior, int32_t n_prior,
+                                          const phm_options* opt, double* out) {
+  (void)B;
+  return run_qupdate_mt(PHM_MCMC_MT, trees, n_trees, n, Q, pid, Omega, nen_m, nodelist_m, roots, N, prior, n_prior, opt, out);
+}
+
+extern "C" int32_t phm_maketreelistMCMCksmt(const phm_tree* trees, int32_t n_trees, int32_t n, const double* Q, const double* pid,
+                                            const double* B, double Omega, const int32_t* nen_m, const int32_t* nodelist_m,
+                                            const int32_t* roots, int32_t N, const double* prior, int32_t n_prior,
+                                            const phm_options* opt, double* out) {
+  (void)B;
+  return run_qupdate_mt(PHM_MCMC_KSMT, trees, n_trees, n, Q, pid, Omega, nen_m, nodelist_m, roots, N, prior, n_prior, opt, out);
 }

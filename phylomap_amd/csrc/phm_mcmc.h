@@ -22,6 +22,8 @@ struct McmcParams {
   int32_t ks;                                // 1: bf/ks layout: n x n counts incl. self pairs (shortenerbf), root-state column
   int32_t tip_masks;                         // 1 (ks): tips observed up to parity and re-sampled; 0 (bf): tips observed
   int32_t prune_only;                        // measurement aid: run only the pruning (up) sweep of each iteration
+  int32_t tiles_per_tree;                    // 0: one tree; else tile t walks tree t / tiles_per_tree (up, down hold one
+  const int32_t* roots;                      //    schedule per tree back to back, roots[tree] the internal root index)
   uint32_t seed_lo, seed_hi;
   int64_t rows;                              // capacity (64-lane rows) of one tile's dwell stream
   double B2[NS * NS];                        // dense B = I + Q/Omega, row-major

@@ -100,7 +100,12 @@ __device__ __forceinline__ void sweep_body(const McmcParams<NS>& p, int iter0, i
 
   const int rep_local = tile * 64 + lane;
   const uint32_t rep = (uint32_t)(p.replica_offset + rep_local);
-  const bool valid = rep_local < p.n_rep;
+  // list of trees (maketreelistMCMCmt :2267): consecutive groups of tiles walk different topologies with one model
+  const int tree = p.tiles_per_tree ? tile / p.tiles_per_tree : 0;
+  const bool valid = (rep_local - tree * p.tiles_per_tree * 64) < p.n_rep;
+  const UpStep* __restrict__ up = p.up + (size_t)tree * p.n_node;
+  const DownStep* __restrict__ down = p.down + (size_t)tree * p.n_edge;
+  const int root = p.tiles_per_tree ? p.roots[tree] : p.root;
   uint32_t err = 0;
 
   double* __restrict__ PLt = p.PL + (size_t)tile * p.n_node * NS * 64;
@@ -138,7 +143,7 @@ __device__ __forceinline__ void sweep_body(const McmcParams<NS>& p, int iter0, i
 
     // ------------------------------ up sweep: partial likelihoods ------------------------------
     for (int k = 0; k < p.n_node; ++k) {
-      const UpStep st = p.up[k];
+      const UpStep st = up[k];
       double x[NS], y[NS];
       int ma = mct[st.edge[0] * 64 + lane];
       int mb = mct[st.edge[1] * 64 + lane];
@@ -164,15 +169,15 @@ __device__ __forceinline__ void sweep_body(const McmcParams<NS>& p, int iter0, i
     {
       double pr[NS];
 #pragma unroll
-      for (int c = 0; c < NS; ++c) pr[c] = p.pid[c] * PLt[(p.root * NS + c) * 64 + lane];   // :618
-      double u = stream_u(p.seed_lo, p.seed_hi, rep, (uint32_t)it, ENT_NODE | (uint32_t)(p.root + p.n_tips), 0);
+      for (int c = 0; c < NS; ++c) pr[c] = p.pid[c] * PLt[(root * NS + c) * 64 + lane];   // :618
+      double u = stream_u(p.seed_lo, p.seed_hi, rep, (uint32_t)it, ENT_NODE | (uint32_t)(root + p.n_tips), 0);
       my_root = sample_cat<NS>(pr, u, err);                                                 // :627
-      nst[p.root * 64 + lane] = (uint8_t)my_root;
+      nst[root * 64 + lane] = (uint8_t)my_root;
     }
 
     // ------------------------------ down sweep: node states + branch paths ------------------------------
     for (int k = 0; k < p.n_edge; ++k) {
-      const DownStep ds = p.down[k];
+      const DownStep ds = down[k];
       const int b = ds.edge;
       const int m = mct[b * 64 + lane];
       const int ps = nst[ds.parent * 64 + lane];

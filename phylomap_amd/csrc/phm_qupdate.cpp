@@ -1,7 +1,8 @@
 // phm_qupdate.cpp -- host glue of the Q-updating drivers: the Gibbs / Metropolis-Hastings updates the reference runs
 // on the rate matrix after every tree sweep (maketreelistMCMCbf src/phylomap.cpp:1299-1300 with updatel01/updatel10
 // :1189-1253; maketreelistMCMCks :1862-1866 with updateksl01/l10 :1435-1578, updaterkappas :1582-1644,
-// updatelkappas :1648-1710, updategammas :1714-1785).  O(k) scalar work per iteration on statistics the device has
+// updatelkappas :1648-1710, updategammas :1714-1785; the multi-tree twins maketreelistMCMCmt :2351-2352 with updatel01mtNS /
+// updatel10mtNS :2192-2262 and maketreelistMCMCksmt :2828-2832 with update*mt :2371-2705).  O(k) scalar work per iteration on statistics the device has
 // already reduced; the sweeps themselves stay on the GPU (phm_api.cpp drives both).
 //
 // Random numbers: the reference draws Rf_rgamma and runif from R's global stream.  Here every update owns a Philox
@@ -91,8 +92,41 @@ void bf_updates(double* Q, double Omega, const double* prior, const double* row,
   }
 }
 
-void ks_updates(double* Q, int n, double Omega, const double* prior, const double* row, uint64_t seed, uint32_t iter) {
+void mt_updates(double* Q, double Omega, const double* prior, const double* row, uint64_t seed, uint32_t iter) {
+  const Ctx c{Q, 2, Omega, prior, row};
+  // updatel01mtNS :2192-2226 (side 0), updatel10mtNS :2228-2262 (side 1): unlike the single-tree twins the acceptance
+  // ratio IS tested; the runif is drawn only for proposals not above Omega; `acceptcompare` is dead code there
+  for (int side = 0; side < 2; ++side) {
+    UpdateStream rs{seed, iter, (uint32_t)side};
+    const int other = 1 - side;
+    const int stay = (int)c.count(side, side), leave = (int)c.count(side, other);
+    const double cur = c.q(side, other);
+    const double fresh = rs.gamma(prior[2 * side] + leave, 1 / (prior[2 * side + 1] + c.time(side)));
+    if (fresh > Omega) continue;
+    double accept = std::pow((Omega - fresh) / (Omega - cur), stay) * std::exp(c.time(side) * (fresh - cur));
+    if (accept > 1) accept = 1;
+    const double cmp = rs.uniform();
+    if (accept < cmp) continue;
+    c.q(side, side) = -fresh; c.q(side, other) = fresh;
+  }
+}
+
+uint32_t pick_tree(int n_trees, uint64_t seed, uint32_t iter) {
+  UpdateStream rs{seed, iter, 0xFDu};
+  const double u = rs.uniform();
+  double total = 1.0;                                   // sampleOnce :81-90 over unit weights (:2332-2333, :2348)
+  for (int j = 1; j < n_trees; ++j) total += 1.0;
+  double cum = 0.0;
+  for (int i = 0; i < n_trees; ++i) { cum += 1.0 / total; if (u < cum) return (uint32_t)i; }
+  return (uint32_t)n_trees;                             // ran off the end: the reference would index out of range
+}
+
+void ks_updates(double* Q, int n, double Omega, const double* prior, const double* row, uint64_t seed, uint32_t iter, bool mt) {
   const Ctx c{Q, n, Omega, prior, row};
+  // the mt twins read their hyper-parameters two places further on (l10: prior(2), prior(3); kappas: 4, 5; gammas: 6, 7),
+  // keep `betaprime - prior(1)` for side 1 (:2471) and drop the `< 1e-300` guards
+  const double* prior_k = prior + (mt ? 2 : 0);
+  const double tiny = mt ? -1.0 : 1e-300;
   const int k = n / 2 - 1;
 
   // ---- the two base rates: updateksl01 :1435-1505 (side 0), updateksl10 :1509-1578 (side 1) ----
@@ -100,9 +134,9 @@ void ks_updates(double* Q, int n, double Omega, const double* prior, const doubl
     UpdateStream rs{seed, iter, (uint32_t)side};
     const HiddenRates h(c);
     const int other = 1 - side;
-    double shape = prior[0];
+    double shape = prior[(mt && side) ? 2 : 0];
     for (int i = 0; i <= k; ++i) shape = shape + c.count(2 * i + side, 2 * i + other);
-    double rate = prior[1];
+    double rate = prior[(mt && side) ? 3 : 1];
     for (int i = 0; i <= k; ++i) rate = rate + h.gm[i] * c.time(2 * i + side);
     const double fresh = rs.gamma(shape, 1 / rate);
     const double cur = h.lam[side];
@@ -117,7 +151,7 @@ void ks_updates(double* Q, int n, double Omega, const double* prior, const doubl
     const double cmp = rs.uniform();
     bool ok = !(fresh + h.rk[0] > Omega);
     for (int i = 1; i < k && ok; ++i) ok = !(h.gm[i] * fresh + h.rk[i] + h.lk[i - 1] > Omega);
-    ok = ok && !(h.gm[k] * fresh + h.lk[k - 1] > Omega) && !(fresh < 1e-300) && !(logacc < std::log(cmp));
+    ok = ok && !(h.gm[k] * fresh + h.lk[k - 1] > Omega) && !(fresh < tiny) && !(logacc < std::log(cmp));
     if (!ok) continue;
     c.q(side, side) = -h.rk[0] - h.gm[0] * fresh;
     c.q(side, other) = h.gm[0] * fresh;
@@ -133,8 +167,8 @@ void ks_updates(double* Q, int n, double Omega, const double* prior, const doubl
   for (int j = 0; j < k; ++j) {
     UpdateStream rs{seed, iter, (uint32_t)(2 + j)};
     const HiddenRates h(c);
-    const double shape = prior[2] + c.count(2 * j, 2 * j + 2) + c.count(2 * j + 1, 2 * j + 3);
-    const double rate = prior[3] + c.time(2 * j) + c.time(2 * j + 1);
+    const double shape = prior_k[2] + c.count(2 * j, 2 * j + 2) + c.count(2 * j + 1, 2 * j + 3);
+    const double rate = prior_k[3] + c.time(2 * j) + c.time(2 * j + 1);
     const double fresh = rs.gamma(shape, 1 / rate);
     double logacc = (fresh - h.rk[j]) * (c.time(2 * j) + c.time(2 * j + 1));
     bool ok = true;
@@ -149,7 +183,7 @@ void ks_updates(double* Q, int n, double Omega, const double* prior, const doubl
       if (j == 0) ok = ok && !(fresh + gl > Omega);
       else ok = ok && !(fresh + gl + h.lk[j - 1] > Omega);
     }
-    ok = ok && !(fresh < 1e-300) && !(logacc < std::log(cmp));
+    ok = ok && !(fresh < tiny) && !(logacc < std::log(cmp));
     if (!ok) continue;
     c.q(2 * j, 2 * j + 2) = fresh;
     c.q(2 * j + 1, 2 * j + 3) = fresh;
@@ -163,8 +197,8 @@ void ks_updates(double* Q, int n, double Omega, const double* prior, const doubl
   for (int j = 1; j <= k; ++j) {
     UpdateStream rs{seed, iter, (uint32_t)(2 + k + j)};
     const HiddenRates h(c);
-    const double shape = prior[2] + c.count(2 * j, 2 * j - 2) + c.count(2 * j + 1, 2 * j - 1);
-    const double rate = prior[3] + c.time(2 * j) + c.time(2 * j + 1);
+    const double shape = prior_k[2] + c.count(2 * j, 2 * j - 2) + c.count(2 * j + 1, 2 * j - 1);
+    const double rate = prior_k[3] + c.time(2 * j) + c.time(2 * j + 1);
     const double fresh = rs.gamma(shape, 1 / rate);
     double logacc = (fresh - h.lk[j - 1]) * (c.time(2 * j) + c.time(2 * j + 1));
     for (int side = 0; side < 2; ++side) {
@@ -179,7 +213,7 @@ void ks_updates(double* Q, int n, double Omega, const double* prior, const doubl
       if (j == k) ok = ok && !(fresh + gl > Omega);
       else ok = ok && !(fresh + gl + h.rk[j] > Omega);
     }
-    ok = ok && !(fresh < 1e-300) && !(logacc < std::log(cmp));
+    ok = ok && !(fresh < tiny) && !(logacc < std::log(cmp));
     if (!ok) continue;
     c.q(2 * j, 2 * j - 2) = fresh;
     c.q(2 * j + 1, 2 * j - 1) = fresh;
@@ -193,9 +227,9 @@ void ks_updates(double* Q, int n, double Omega, const double* prior, const doubl
   for (int j = 1; j <= k; ++j) {
     UpdateStream rs{seed, iter, (uint32_t)(2 + 2 * k + j)};
     const HiddenRates h(c);
-    const double shape = prior[4] + c.count(2 * j, 2 * j + 1) + c.count(2 * j + 1, 2 * j);
+    const double shape = prior_k[4] + c.count(2 * j, 2 * j + 1) + c.count(2 * j + 1, 2 * j);
     const double exposure = c.time(2 * j) * h.lam[0] + c.time(2 * j + 1) * h.lam[1];
-    const double rate = prior[5] + c.time(2 * j) * h.lam[0] + c.time(2 * j + 1) * h.lam[1];
+    const double rate = prior_k[5] + c.time(2 * j) * h.lam[0] + c.time(2 * j + 1) * h.lam[1];
     const double fresh = rs.gamma(shape, 1 / rate);
     double logacc = (fresh - h.gm[j]) * exposure;
     for (int side = 0; side < 2; ++side) {
@@ -210,7 +244,7 @@ void ks_updates(double* Q, int n, double Omega, const double* prior, const doubl
       if (j == k) ok = ok && !(h.lk[j - 1] + fresh * h.lam[side] > Omega);
       else ok = ok && !(h.lk[j - 1] + fresh * h.lam[side] + h.rk[j] > Omega);
     }
-    ok = ok && !(fresh < 1e-300) && !(logacc < std::log(cmp));
+    ok = ok && !(fresh < tiny) && !(logacc < std::log(cmp));
     if (!ok) continue;
     c.q(2 * j, 2 * j + 1) = fresh * h.lam[0];
     c.q(2 * j + 1, 2 * j) = fresh * h.lam[1];

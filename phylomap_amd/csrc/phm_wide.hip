@@ -88,7 +88,12 @@ __global__ __launch_bounds__(WIDE_BLOCK) void mcmc_wide_kernel(WideParams p, int
   const int rep_local = tile * 64 + lane;
   const uint32_t rep0 = (uint32_t)(p.replica_offset + tile * 64);
   const uint32_t rep = rep0 + (uint32_t)lane;
-  const bool valid = rep_local < p.n_rep;
+  // list of trees (maketreelistMCMCmt :2267): consecutive groups of tiles walk different topologies with one model
+  const int tree = p.tiles_per_tree ? tile / p.tiles_per_tree : 0;
+  const bool valid = (rep_local - tree * p.tiles_per_tree * 64) < p.n_rep;
+  const UpStep* __restrict__ up = p.up + (size_t)tree * p.n_node;
+  const DownStep* __restrict__ down = p.down + (size_t)tree * p.n_edge;
+  const int root = p.tiles_per_tree ? p.roots[tree] : p.root;
   uint32_t err = 0;
   const double pid_c = p.pid[c];
 
@@ -137,7 +142,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) void mcmc_wide_kernel(WideParams p, int
 
     // ------------------------------ up sweep ------------------------------
     for (int k = 0; k < p.n_node; ++k) {
-      const UpStep st = p.up[k];
+      const UpStep st = up[k];
       const int ma = mct[st.edge[0] * 64 + lane];
       const int mb = mct[st.edge[1] * 64 + lane];
       int ta = 0, tb = 0;
@@ -158,18 +163,18 @@ __global__ __launch_bounds__(WIDE_BLOCK) void mcmc_wide_kernel(WideParams p, int
     {
       int mine = 0;
       for (int r = 0; r < 64; ++r) {
-        double pr = (lane < n) ? pid_c * PLt[((size_t)p.root * 64 + r) * n + c] : 0.0;     // :618
-        double u = uni_draw(p, rep0 + r, (uint32_t)it, ENT_NODE | (uint32_t)(p.root + p.n_tips), 0);
+        double pr = (lane < n) ? pid_c * PLt[((size_t)root * 64 + r) * n + c] : 0.0;     // :618
+        double u = uni_draw(p, rep0 + r, (uint32_t)it, ENT_NODE | (uint32_t)(root + p.n_tips), 0);
         int rs = coop_sample(pr, u, n, lane, err);                                         // :627
         if (lane == r) mine = rs;
       }
-      nst[p.root * 64 + lane] = (uint8_t)mine;
+      nst[root * 64 + lane] = (uint8_t)mine;
       if (p.ks) stat_add(n + n * n, (double)mine);                                           // :1350-1352
     }
 
     // ------------------------------ down sweep ------------------------------
     for (int k = 0; k < p.n_edge; ++k) {
-      const DownStep ds = p.down[k];
+      const DownStep ds = down[k];
       const int b = ds.edge;
       int m = mct[b * 64 + lane];
       const int ps = nst[ds.parent * 64 + lane];

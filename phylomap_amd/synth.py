@@ -227,6 +227,15 @@ def make_tree(n_tips: int, Q, Omega: float, seed: int, pid=None, states=None, in
             "maps": maps, "mapnames": mapnames, "node.states": node_states}
 
 
+def make_treelist(n_trees: int, n_tips: int, Q, Omega: float, seed: int, pid=None, init_segments: int = 2):
+    """A list of trees as sumstatMCMCmt takes it (R/sumstatMCMCmt.R:29): the same taxa with the same observed tip
+    states on ``n_trees`` different random topologies / branch lengths (a posterior sample of trees)."""
+    first = make_tree(n_tips, Q, Omega, seed, pid=pid, init_segments=init_segments)
+    rest = [make_tree(n_tips, Q, Omega, seed + 7919 * j, pid=pid, states=first["states"], init_segments=init_segments)
+            for j in range(1, n_trees)]
+    return [first] + rest
+
+
 def config_problem(config: int, n_tips: int | None = None):
     """(z, Q, pid, Omega) for BASELINE.json config C1..C5; seed = 0x5EED0000 + config."""
     tips = {1: 100, 2: 1000, 3: 10000, 4: 500, 5: 5000}[config] if n_tips is None else n_tips

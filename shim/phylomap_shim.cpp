@@ -158,6 +158,52 @@ RcppExport SEXP phylomap_maketreelistMCMCksDICt(SEXP x, SEXP Q, SEXP pid, SEXP B
   END_RCPP
 }
 
+typedef int32_t (*mt_fn)(const phm_tree*, int32_t, int32_t, const double*, const double*, const double*, double, const int32_t*,
+                         const int32_t*, const int32_t*, int32_t, const double*, int32_t, const phm_options*, double*);
+
+// maketreelistMCMCmt / maketreelistMCMCksmt (src/RcppExports.cpp:158,184): x is the R list of trees; nen_m / nodelist_m are
+// R integer matrices with one ROW per tree (R/sumstatMCMCmt.R:37-43), handed over column-major as R stores them.
+static SEXP run_qupdate_mt(mt_fn fn, int hidden, SEXP xSEXP, SEXP QSEXP, SEXP pidSEXP, SEXP BSEXP, SEXP OmegaSEXP, SEXP nenSEXP,
+                           SEXP nodelistSEXP, SEXP rootsSEXP, SEXP NSEXP, SEXP priorSEXP) {
+  RNGScope scope;
+  List xs(xSEXP);
+  std::vector<FlatTree> fts;
+  fts.reserve(xs.size());                                           // FlatTree::t points into its own vectors: no reallocation
+  for (int j = 0; j < xs.size(); ++j) fts.emplace_back(as<List>(xs[j]));
+  std::vector<phm_tree> trees;
+  for (size_t j = 0; j < fts.size(); ++j) {                          // re-point after the moves into the vector
+    FlatTree& f = fts[j];
+    f.t.edge = f.edge.data(); f.t.edge_length = f.edge_length.empty() ? nullptr : f.edge_length.data();
+    f.t.states = f.states.data(); f.t.map_off = f.map_off.data(); f.t.maps = f.maps.data(); f.t.mapnames = f.mapnames.data();
+    trees.push_back(f.t);
+  }
+  NumericMatrix Q(QSEXP), B(BSEXP);
+  NumericVector pid(pidSEXP), prior(priorSEXP);
+  IntegerMatrix nen_m(nenSEXP), nodelist_m(nodelistSEXP);
+  IntegerVector roots(rootsSEXP);
+  const int n = Q.nrow(), N = as<int>(NSEXP);
+  const int k = hidden ? n / 2 - 1 : 0;
+  NumericMatrix out(N, n + n * n + 2 + 3 * k + 1);                  // :2338 (mt), :2815 (ksmt); last column tree_number
+  phm_options o = options_from_R();
+  check(fn(trees.data(), (int32_t)trees.size(), n, Q.begin(), pid.begin(), B.begin(), as<double>(OmegaSEXP), nen_m.begin(),
+           nodelist_m.begin(), roots.begin(), N, prior.begin(), (int32_t)prior.size(), &o, out.begin()));
+  return out;
+}
+
+RcppExport SEXP phylomap_maketreelistMCMCmt(SEXP x, SEXP Q, SEXP pid, SEXP B, SEXP Omega, SEXP nen_m, SEXP nodelist_m, SEXP roots,
+                                            SEXP N, SEXP prior) {          // src/RcppExports.cpp:159
+  BEGIN_RCPP
+  return run_qupdate_mt(phm_maketreelistMCMCmt, 0, x, Q, pid, B, Omega, nen_m, nodelist_m, roots, N, prior);
+  END_RCPP
+}
+
+RcppExport SEXP phylomap_maketreelistMCMCksmt(SEXP x, SEXP Q, SEXP pid, SEXP B, SEXP Omega, SEXP nen_m, SEXP nodelist_m,
+                                              SEXP roots, SEXP N, SEXP prior) {      // src/RcppExports.cpp:185
+  BEGIN_RCPP
+  return run_qupdate_mt(phm_maketreelistMCMCksmt, 1, x, Q, pid, B, Omega, nen_m, nodelist_m, roots, N, prior);
+  END_RCPP
+}
+
 RcppExport SEXP phylomap_maketreelistEXP(SEXP xSEXP, SEXP QSEXP, SEXP pidSEXP, SEXP nenSEXP, SEXP nodelistSEXP,
                                          SEXP rootSEXP, SEXP NSEXP, SEXP leftsSEXP, SEXP rightsSEXP, SEXP dSEXP) {
   BEGIN_RCPP

@@ -11,7 +11,7 @@ _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _SO = os.path.join(_ROOT, "oracle", "_build", "libphm_oracle.so")
 
 ERR_ZERO_PROB, ERR_UNIF_CAP, ERR_BAD_INPUT, ERR_TAPE, ERR_SAMPLEONCE = 1, 2, 4, 8, 16
-PLAIN, BIGTREE, SPARSE, KS, BF = 0, 1, 2, 3, 4
+PLAIN, BIGTREE, SPARSE, KS, BF, MT, KSMT = 0, 1, 2, 3, 4, 5, 6
 
 
 class Rng(C.Structure):
@@ -153,6 +153,30 @@ def maketreelistMCMC(z, Q, pid, B, Omega, nen, nodelist, root, N, variant=PLAIN,
                                     C.byref(db.c) if db else None)
     del keep
     return (out, rc, db) if dump else (out, rc)
+
+
+def maketreelistMCMCmt(treelist, Q, pid, B, Omega, nen_m, nodelist_m, roots, N, prior, variant=MT, seed=1, replica=0,
+                       faithful_search=False):
+    """orc_maketreelistMCMCmt: nen_m / nodelist_m one row per tree (row-major), roots one entry per tree."""
+    Q = np.asarray(Q, dtype=np.float64)
+    n = Q.shape[0]
+    fts = [FlatTree(z) for z in treelist]
+    arr = (C.POINTER(Tree) * len(fts))(*[C.pointer(ft.c) for ft in fts])
+    Qc, Bc = np.asfortranarray(Q), np.asfortranarray(np.asarray(B, dtype=np.float64))
+    pid = np.ascontiguousarray(pid, dtype=np.float64)
+    nen_m = np.ascontiguousarray(nen_m, dtype=np.int32)
+    nodelist_m = np.ascontiguousarray(nodelist_m, dtype=np.int32)
+    roots = np.ascontiguousarray(roots, dtype=np.int32)
+    prior = np.ascontiguousarray(prior, dtype=np.float64)
+    cols = n + n * n + 2 + (3 * (n // 2 - 1) if variant == KSMT else 0) + 1
+    out = np.zeros((N, cols), order="F")
+    rng, keep = make_rng(seed, replica)
+    rc = lib().orc_maketreelistMCMCmt(arr, len(fts), n, _ptr(Qc, C.c_double), _ptr(pid, C.c_double), _ptr(Bc, C.c_double),
+                                      C.c_double(Omega), _ptr(nen_m, C.c_int32), _ptr(nodelist_m, C.c_int32),
+                                      _ptr(roots, C.c_int32), int(N), int(variant), _ptr(prior, C.c_double),
+                                      int(faithful_search), C.byref(rng), _ptr(out, C.c_double))
+    del keep
+    return out, rc
 
 
 def maketreelistEXP(z, Q, pid, nen, nodelist, root, N, lefts, rights, d, seed=1, replica=0,

@@ -369,6 +369,79 @@ def test_dic_drivers_match_oracle(which):
     np.testing.assert_allclose(got[0, -1], np.log(PL[root - 1] @ pid), rtol=1e-11)
 
 
+def _list_orders(treelist):
+    orders = [_orders(z) for z in treelist]
+    return np.stack([o[0] for o in orders]), np.stack([o[1] for o in orders]), [o[2] for o in orders]
+
+
+def test_sumstatMCMCmt_list_of_trees_matches_oracle():
+    """R/sumstatMCMCmt.R: every iteration sweeps EVERY tree of the list (one launch, tree j on replica tile j), keeps a
+    uniformly drawn one, and updates (l01, l10) from it with the acceptance-testing mt updates."""
+    Q = np.array([[-.1, .1], [.1, -.1]])
+    Omega, pid, prior = 2.0, np.array([.5, .5]), [.55, 1, .56, 1.01]
+    trees = synth.make_treelist(7, 16, Q, 0.5, 314, pid)
+    nen_m, nodelist_m, roots = _list_orders(trees)
+    N = 40
+    got = api.sumstatMCMCmt(trees, Q, pid, Omega, N, prior, seed=2718)
+    want, rc = O.maketreelistMCMCmt(trees, Q, pid, np.eye(2) + Q / Omega, Omega, nen_m, nodelist_m, roots, N, prior, variant=O.MT, seed=2718)
+    assert rc == 0 and got.shape == (N, 9)
+    np.testing.assert_array_equal(got, want)
+    assert len(np.unique(got[:, 8])) >= 5 and got[:, 8].max() <= 6          # tree_number, 0-based (:2350)
+    assert len(np.unique(got[:, 6])) > 10                                     # l01 moves (and some proposals are rejected)
+    assert np.any(got[1:, 6] == got[:-1, 6])
+    # one tree in the list: the single-tree sweep without normalisation; total time = that tree's length
+    one = api.sumstatMCMCmt(trees[:1], Q, pid, Omega, 5, prior, seed=3)
+    np.testing.assert_allclose(one[:, :2].sum(1), trees[0]["edge.length"].sum(), rtol=1e-12)
+    assert np.all(one[:, 8] == 0)
+
+
+@pytest.mark.parametrize("n", [4, 6])
+def test_sumstatMCMCksmt_list_of_trees_matches_oracle(n):
+    """R/sumstatMCMCksmt.R: hidden-rates model over a list of trees (n = 6 runs the wide kernel); 8 prior entries."""
+    Q = synth.make2sQ(.1, .1, .2, .2, 10) if n == 4 else synth.make2sQ(.1, .3, [.2, .4], [.5, .6], [2, 3])
+    Omega, pid = 25.0, np.full(n, 1.0 / n)
+    prior = [1, 10, 1.5, 11, 2, 10, 20, 2]
+    trees = synth.make_treelist(5, 14, Q, Omega / 3, 2024, pid)
+    for z in trees:
+        z["states"] = ((z["states"] - 1) % 2 + 1).astype(np.int32)
+    nen_m, nodelist_m, roots = _list_orders(trees)
+    N = 20
+    got = api.sumstatMCMCksmt(trees, Q, pid, Omega, N, prior, seed=11)
+    want, rc = O.maketreelistMCMCmt(trees, Q, pid, np.eye(n) + Q / Omega, Omega, nen_m, nodelist_m, roots, N, prior, variant=O.KSMT, seed=11)
+    k = n // 2 - 1
+    assert rc == 0 and got.shape == (N, n + n * n + 2 + 3 * k + 1)
+    np.testing.assert_array_equal(got, want)
+    assert len(np.unique(got[:, -1])) >= 3
+
+
+def test_engine_over_a_list_of_trees_runs_each_tree_like_its_own_engine():
+    """phm_engine_create_multi: chains of tree j on their own tiles, Philox replica word 64*tiles_per_tree*j + c; every
+    (tree, chain) pair reproduces the oracle's single-tree run, and the chain state dump follows the right topology."""
+    z0, Q, pid, Omega = _problem(3, 20, 99)
+    trees = synth.make_treelist(4, 20, Q, Omega, 99, pid)
+    B = np.eye(3) + Q / Omega
+    N, S = 12, 3
+    eng = _lib.Engine(trees, Q, pid, Omega, N, variant=_lib.PHM_MCMC_BIGTREE, seed=5, n_replicas=S)
+    eng.run(N)
+    eng.sync()
+    got = eng.stats(0, N)
+    assert got.shape == (4 * S, N, 9)
+    for j, z in enumerate(trees):
+        nen, nodelist, root = _orders(z)
+        for c in range(S):
+            want, rc, dump = O.maketreelistMCMC(z, Q, pid, B, Omega, nen, nodelist, root, N, variant=O.BIGTREE, seed=5,
+                                                replica=64 * j + c, dump=True)
+            assert rc == 0
+            np.testing.assert_array_equal(got[j * S + c][:, 3:], want[:, 3:])
+            np.testing.assert_allclose(got[j * S + c][:, :3], want[:, :3], rtol=1e-10)
+            d = eng.dump(j * S + c)
+            np.testing.assert_array_equal(d["seg_count"], dump.seg_count)
+            np.testing.assert_array_equal(d["node_states"], dump.node_states)
+    eng.close()
+    with pytest.raises(_lib.PhmError):                                        # lists of unequal trees are refused
+        _lib.Engine([trees[0], synth.make_tree(21, Q, Omega, 1, pid)], Q, pid, Omega, 2)
+
+
 def test_replica_offset_shards_like_one_device():
     z, Q, pid, Omega = _problem(2, 18, 4)
     a = api.sumstatMCMC(z, Q, pid, Omega, 10, seed=3, n_replicas=4)

@@ -112,18 +112,21 @@ def test_synthetic_configs_are_deterministic():
     assert all(len(m) == 2 for m in z1["maps"])
 
 
-@pytest.mark.parametrize("n", [2, 4, 6, 8])
-def test_rate_matrix_updates_product_equals_oracle(n):
+@pytest.mark.parametrize("n,mt", [(2, 0), (4, 0), (6, 0), (8, 0), (2, 1), (4, 1), (8, 1)])
+def test_rate_matrix_updates_product_equals_oracle(n, mt):
     """The host glue of sumstatMCMCbf / sumstatMCMCks (phm_qupdate.cpp) against the oracle's transcription of
-    updatel01/l10 (src/phylomap.cpp:1189-1253) and the five ks updates (:1435-1785): same Philox stream, same
-    Marsaglia-Tsang gamma, same libm -> bit-identical Q after every update."""
+    updatel01/l10 (src/phylomap.cpp:1189-1253) and the five ks updates (:1435-1785), and of their multi-tree twins
+    (updatel01mtNS :2192-2262, update*mt :2371-2705): same Philox stream, same Marsaglia-Tsang gamma, same libm ->
+    bit-identical Q after every update."""
     import ctypes as C
     import oracle_lib as O
-    rs = np.random.default_rng(n)
-    variant = _lib.PHM_MCMC_BF if n == 2 else _lib.PHM_MCMC_KS
+    rs = np.random.default_rng(n + 100 * mt)
+    variant = (_lib.PHM_MCMC_MT if mt else _lib.PHM_MCMC_BF) if n == 2 else (_lib.PHM_MCMC_KSMT if mt else _lib.PHM_MCMC_KS)
     k = n // 2 - 1
     Q = synth.config_Q(1) if n == 2 else synth.make2sQ(.1, .3, rs.uniform(.1, .4, k), rs.uniform(.1, .4, k), rs.uniform(1, 5, k))
     prior = np.array([.55, 1, .56, 1.01]) if n == 2 else np.array([1., 10, 2, 10, 20, 2])
+    if mt and n > 2:
+        prior = np.array([1., 10, 1.5, 11, 2, 10, 20, 2])
     Omega = 12.0
     changed = 0
     for it in range(40):

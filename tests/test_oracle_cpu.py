@@ -342,3 +342,57 @@ def test_exp_mcmc_sparse_agree_in_distribution():
         sm = 4 * jm.std() / np.sqrt(jm.size)
         assert abs(jm.mean() - je.mean()) < 6 * np.hypot(se, sm), (name, jm.mean(), je.mean())
         np.testing.assert_allclose(out[:, :6].mean(0), ex[:, :6].mean(0), rtol=0.1, atol=0.5)
+
+
+def test_multitree_oracle_structure():
+    """orc_maketreelistMCMCmt (maketreelistMCMCmt src/phylomap.cpp:2267-2365): with one tree in the list the first sweep is
+    the plain single-tree sweep (un-normalised pruning, replica word 0) with self pairs counted as well; with several
+    trees the kept row belongs to the tree named in the last column, and the recorded rates are the ones the previous
+    iteration's update left behind (recordQmtNS :2169-2173 runs before the sweep)."""
+    Q = synth.config_Q(1)
+    Omega, pid, prior = 0.5, [.5, .5], [.55, 1, .56, 1.01]
+    trees = synth.make_treelist(5, 12, Q, Omega, 77)
+    orders = [_orders(z) for z in trees]
+    nen_m, nl_m, roots = np.stack([o[0] for o in orders]), np.stack([o[1] for o in orders]), [o[2] for o in orders]
+    B = np.eye(2) + Q / Omega
+    one, rc = O.maketreelistMCMCmt(trees[:1], Q, pid, B, Omega, nen_m[:1], nl_m[:1], roots[:1], 1, prior, seed=5)
+    plain, rc2 = O.maketreelistMCMC(trees[0], Q, pid, B, Omega, nen_m[0], nl_m[0], roots[0], 1, variant=O.PLAIN, seed=5)
+    assert rc == 0 and rc2 == 0
+    np.testing.assert_array_equal(one[0, [0, 1, 3, 4]], plain[0])
+    assert one[0, 6] == Q[0, 1] and one[0, 7] == Q[1, 0] and one[0, 8] == 0
+
+    N = 60
+    out, rc = O.maketreelistMCMCmt(trees, Q, pid, B, Omega, nen_m, nl_m, roots, N, prior, seed=5)
+    assert rc == 0 and out.shape == (N, 9)
+    picks = out[:, 8].astype(int)
+    assert set(picks) == set(range(5))                                    # sampleOnce over unit weights reaches every tree
+    lengths = np.array([z["edge.length"].sum() for z in trees])
+    np.testing.assert_allclose(out[:, 0] + out[:, 1], lengths[picks], rtol=1e-12)
+    # the rates recorded at iteration i+1 are what phm_qupdate_apply-style updates make of row i
+    import ctypes as C
+    for i in range(N - 1):
+        Qi = np.array([[-out[i, 6], out[i, 6]], [out[i, 7], -out[i, 7]]])
+        rc = O.lib().orc_qupdate_apply(O.MT, 2, Qi.ctypes.data_as(C.POINTER(C.c_double)), C.c_double(Omega),
+                                       np.asarray(prior, dtype=float).ctypes.data_as(C.POINTER(C.c_double)),
+                                       np.ascontiguousarray(out[i, :6]).ctypes.data_as(C.POINTER(C.c_double)),
+                                       C.c_uint32(5), C.c_uint32(0), C.c_uint32(i))
+        assert rc == 0
+        assert Qi[0, 1] == out[i + 1, 6] and Qi[1, 0] == out[i + 1, 7]
+    assert 3 < len(np.unique(out[:, 6])) < N                              # some proposals accepted, some rejected (:2207)
+
+    # hidden rates over a list (maketreelistMCMCksmt :2722-2844): shapes, tree column, conserved tree length
+    Qk = synth.make2sQ(.1, .1, .2, .2, 10)
+    tk = synth.make_treelist(3, 10, Qk, 8.0, 9)
+    for z in tk:
+        z["states"] = ((z["states"] - 1) % 2 + 1).astype(np.int32)
+    ok = [_orders(z) for z in tk]
+    outk, rc = O.maketreelistMCMCmt(tk, Qk, np.full(4, .25), np.eye(4) + Qk / 25.0, 25.0, np.stack([o[0] for o in ok]),
+                                    np.stack([o[1] for o in ok]), [o[2] for o in ok], 15, [1, 10, 1.5, 11, 2, 10, 20, 2],
+                                    variant=O.KSMT, seed=3)
+    assert rc == 0 and outk.shape == (15, 4 + 16 + 2 + 3 + 1)
+    lk = np.array([z["edge.length"].sum() for z in tk])
+    np.testing.assert_allclose(outk[:, :4].sum(1), lk[outk[:, -1].astype(int)], rtol=1e-12)
+    # n must be 2k+2 (:2729)
+    _, rc = O.maketreelistMCMCmt(tk, Qk[:3, :3], [1 / 3] * 3, np.eye(3), 25.0, np.stack([o[0] for o in ok]),
+                                 np.stack([o[1] for o in ok]), [o[2] for o in ok], 2, [1] * 8, variant=O.KSMT)
+    assert rc & O.ERR_BAD_INPUT
