@@ -183,12 +183,18 @@ def tree_orders(z):
     return nen, nodelist[: int(z["Nnode"]) - 1], int(root.value)
 
 
+MAPPING = {"auto": 0, "replicas": 1, "branches": 2}
+
+
 def make_options(seed=0, n_replicas=1, replica_offset=0, reduce=False, tips_per_replica=False, device=-1,
-                 iters_per_launch=0, cap_tail=0.0, storage=0):
+                 iters_per_launch=0, cap_tail=0.0, storage=0, mapping="auto"):
+    """``mapping``: how a sweep is laid over the lanes -- "replicas" (one lane per chain: the throughput layout for many
+    replicas), "branches" (one lane per branch: few chains on a large tree, n <= 4) or "auto" (branches up to 16 chains)."""
     o = Options()
     o.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
     o.n_replicas, o.replica_offset, o.reduce = int(n_replicas), int(replica_offset), int(bool(reduce))
     o.reserved[0] = int(storage)          # 0 automatic, 1 ring, 2 two buffers
+    o.reserved[1] = MAPPING[mapping] if isinstance(mapping, str) else int(mapping)
     o.tips_per_replica, o.device, o.iters_per_launch, o.cap_tail = int(bool(tips_per_replica)), int(device), int(iters_per_launch), float(cap_tail)
     return o
 

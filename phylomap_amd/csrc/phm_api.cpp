@@ -20,6 +20,7 @@
 #include "phm_mcmc.h"
 #include "phm_qupdate.h"
 #include "phm_sched.h"
+#include "phm_narrow.h"
 #include "phm_wide.h"
 
 namespace {
@@ -92,6 +93,17 @@ struct phm_engine {
   bool ring = true;                    // one ring per tile for both dwell streams (else two buffers)
   phm::WideParams pw;
   DevBuf d_B2, d_Bc, d_scale, d_pid;
+  // branch-parallel mapping for few chains on a large tree (phm_narrow.hip)
+  bool narrow = false;
+  std::vector<int32_t> nw_up_off, nw_down_off;     // level boundaries into up_order / down_order
+  std::vector<int64_t> nw_off;                     // CSR offsets of the branch slots
+  int nw_klong = 0;
+  int64_t nw_total_cap = 0;
+  DevBuf d_nw_up_order, d_nw_down_order, d_nw_border, d_nw_off, d_nw_colL, d_nw_rowL, d_nw_maskL, d_nw_mcount, d_nw_dwA, d_nw_dwB,
+      d_nw_mstate, d_nw_estate, d_nw_part, d_nw_rowbuf;
+  phm::NarrowParams<2> n2;
+  phm::NarrowParams<3> n3;
+  phm::NarrowParams<4> n4;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipStream_t last_stream = nullptr;
   bool timing_pending = false;
@@ -106,6 +118,8 @@ struct phm_engine {
 };
 
 namespace {
+
+constexpr int NARROW_AUTO_MAX_REPLICAS = 16;     // automatic choice of the branch-parallel mapping: at most this many chains
 
 bool ks_layout(int v) { return v == PHM_MCMC_KS || v == PHM_MCMC_BF || v == PHM_MCMC_MT || v == PHM_MCMC_KSMT; }   // n x n counts, root column
 bool hidden_rates(int v) { return v == PHM_MCMC_KS || v == PHM_MCMC_KSMT; }                                         // parity tip masks
@@ -208,7 +222,7 @@ int32_t compute_model(int variant, int n, const double* Q, const double* B, doub
 // chain tables for the current model -> device; refresh the by-value kernel parameter blocks
 int32_t upload_model(phm_engine* e) {
   const int n = e->n;
-  const int ktab = e->wide ? phm::WIDE_KTAB : phm::MCMC_KTAB;
+  const int ktab = e->narrow ? e->nw_klong : e->wide ? phm::WIDE_KTAB : phm::MCMC_KTAB;
   const double* Bc = e->hBc.data();
   std::vector<double> col, row;
   build_chain_tables(Bc, n, ktab, col, row);
@@ -225,6 +239,19 @@ int32_t upload_model(phm_engine* e) {
       }
     }
   }
+  if (e->narrow) {      // tables long enough for every possible segment count, read from global memory / L2
+    HIPCHK(hipMemcpy(e->d_nw_colL.p, col.data(), sizeof(double) * col.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_nw_rowL.p, row.data(), sizeof(double) * row.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_nw_maskL.p, maskpow.data(), sizeof(double) * maskpow.size(), hipMemcpyHostToDevice));
+    auto refresh_n = [&](auto& p) {
+      for (int i = 0; i < n * n; ++i) { p.B2[i] = e->hB2[i]; p.Bc[i] = e->hBc[i]; }
+      for (int i = 0; i < n; ++i) p.scale[i] = e->hscale[i];
+    };
+    if (n == 2) refresh_n(e->n2);
+    if (n == 3) refresh_n(e->n3);
+    if (n == 4) refresh_n(e->n4);
+    return PHM_OK;
+  }
   HIPCHK(hipMemcpy(e->d_col.p, col.data(), sizeof(double) * col.size(), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(e->d_row.p, row.data(), sizeof(double) * row.size(), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(e->d_mask.p, maskpow.data(), sizeof(double) * maskpow.size(), hipMemcpyHostToDevice));
@@ -240,6 +267,152 @@ int32_t upload_model(phm_engine* e) {
   if (n == 2) refresh(e->p2);
   if (n == 3) refresh(e->p3);
   if (n == 4) refresh(e->p4);
+  return PHM_OK;
+}
+
+// Branch-parallel engine state (phm_narrow.hip): level schedules, CSR branch slots, long chain tables, per-replica buffers.
+template <int NS>
+void fill_narrow_params(phm_engine* e, phm::NarrowParams<NS>& p, const phm_options& o) {
+  const phm::Schedule& s = e->sched;
+  p.n_tips = s.n_tips; p.n_node = s.n_node; p.n_edge = s.n_edge; p.root = s.root;
+  p.n_rep = e->S; p.n_rep_pad = e->S_pad; p.replica_offset = o.replica_offset; p.n_tiles = e->tiles;
+  p.normalise = normalised(e->variant); p.tips_per_replica = e->tips_per_replica ? 1 : 0;
+  p.ks = ks_layout(e->variant); p.tip_masks = hidden_rates(e->variant); p.reduce = e->reduce; p.n_cols = e->dcols;
+  p.klong = e->nw_klong;
+  p.seed_lo = (uint32_t)(o.seed & 0xFFFFFFFFull); p.seed_hi = (uint32_t)(o.seed >> 32);
+  p.total_cap = e->nw_total_cap;
+  for (int i = 0; i < NS * NS; ++i) { p.B2[i] = e->hB2[i]; p.Bc[i] = e->hBc[i]; }
+  for (int i = 0; i < NS; ++i) { p.scale[i] = e->hscale[i]; p.pid[i] = e->hpid[i]; }
+  p.up = e->d_up.as<phm::UpStep>(); p.down = e->d_down.as<phm::DownStep>();
+  p.up_order = e->d_nw_up_order.as<int32_t>(); p.down_order = e->d_nw_down_order.as<int32_t>();
+  p.branch_order = e->d_nw_border.as<int32_t>(); p.off = e->d_nw_off.as<int64_t>();
+  p.colL = e->d_nw_colL.as<double>(); p.rowL = e->d_nw_rowL.as<double>(); p.maskL = e->d_nw_maskL.as<double>();
+  p.tips = e->d_tips.as<uint8_t>();
+  p.mcount = e->d_nw_mcount.as<int32_t>(); p.dw[0] = e->d_nw_dwA.as<double>(); p.dw[1] = e->d_nw_dwB.as<double>();
+  p.mstate = e->d_nw_mstate.as<uint8_t>(); p.estate = e->d_nw_estate.as<uint8_t>();
+  p.PL = e->d_PL.as<double>(); p.nstate = e->d_nstate.as<uint8_t>(); p.part = e->d_nw_part.as<double>();
+  p.rowbuf = e->d_nw_rowbuf.as<double>(); p.stats = e->d_stats.as<double>();
+  p.err = e->d_err.as<uint32_t>(); p.segcnt = e->d_seg.as<unsigned long long>();
+}
+
+int32_t narrow_setup(phm_engine* e, const phm_tree* x, const phm_model* model, const phm_options& o, int32_t max_iters) {
+  const phm::Schedule& s = e->sched;
+  const int E = s.n_edge, T = s.n_tips, Nn = s.n_node, n = e->n, S = e->S;
+  // height levels of the pruning sweep (children strictly below their parent), depth levels of the sampling sweep
+  std::vector<int32_t> height(Nn, 0), depth(Nn, 0);
+  int max_h = 0, max_d = 0;
+  for (int k = 0; k < Nn; ++k) {
+    const phm::UpStep& u = s.up[k];
+    int h = 0;
+    for (int c = 0; c < 2; ++c) if (u.child[c] >= 0) h = std::max(h, height[u.child[c]] + 1);
+    height[u.parent] = h; max_h = std::max(max_h, h);
+  }
+  std::vector<int32_t> edepth(E, 0);
+  for (int k = 0; k < E; ++k) {
+    const phm::DownStep& d = s.down[k];
+    edepth[k] = depth[d.parent];
+    if (d.child >= 0) depth[d.child] = depth[d.parent] + 1;
+    max_d = std::max(max_d, edepth[k]);
+  }
+  std::vector<int32_t> up_order(Nn), down_order(E);
+  e->nw_up_off.assign(max_h + 2, 0); e->nw_down_off.assign(max_d + 2, 0);
+  for (int k = 0; k < Nn; ++k) e->nw_up_off[height[s.up[k].parent] + 1]++;
+  for (int k = 0; k < E; ++k) e->nw_down_off[edepth[k] + 1]++;
+  for (size_t l = 1; l < e->nw_up_off.size(); ++l) e->nw_up_off[l] += e->nw_up_off[l - 1];
+  for (size_t l = 1; l < e->nw_down_off.size(); ++l) e->nw_down_off[l] += e->nw_down_off[l - 1];
+  {
+    std::vector<int32_t> pu(e->nw_up_off.begin(), e->nw_up_off.end() - 1), pd(e->nw_down_off.begin(), e->nw_down_off.end() - 1);
+    for (int k = 0; k < Nn; ++k) up_order[pu[height[s.up[k].parent]]++] = k;
+    for (int k = 0; k < E; ++k) down_order[pd[edepth[k]]++] = k;
+  }
+  // One slot per branch: 1 + Poisson(Omega t_b) segments in stationarity, provisioned far into the tail because a slot
+  // has no neighbour to borrow from (default 1e-12 per branch and sweep); longer caller-supplied paths get m0 on top.
+  const double tail = o.cap_tail > 0.0 ? o.cap_tail : 1e-12;
+  e->nw_off.assign(E + 1, 0);
+  std::vector<int32_t> cap(E);
+  int max_cap = 0;
+  for (int b = 0; b < E; ++b) {
+    double tb = 0.0;
+    for (int i = x->map_off[b]; i < x->map_off[b + 1]; ++i) tb += x->maps[i];
+    const int m0 = x->map_off[b + 1] - x->map_off[b];
+    const int q = phm::poisson_capacity(model->Omega * tb, tail);
+    cap[b] = std::max(q, m0 + q - 1) + 2;
+    max_cap = std::max(max_cap, cap[b]);
+    e->nw_off[b + 1] = e->nw_off[b] + cap[b];
+  }
+  e->nw_total_cap = e->nw_off[E];
+  e->nw_klong = max_cap + 1;
+  e->rows = e->nw_total_cap;
+  std::vector<int32_t> border(E);
+  for (int b = 0; b < E; ++b) border[b] = b;
+  std::stable_sort(border.begin(), border.end(), [&](int a, int b) { return cap[a] > cap[b]; });
+
+  // tips: [T] shared, or [replica][T]
+  if (e->tips_per_replica) {
+    e->tips_host.resize((size_t)S * T);
+    for (int r = 0; r < S; ++r) for (int t = 0; t < T; ++t) e->tips_host[(size_t)r * T + t] = (uint8_t)(x->states[(size_t)r * T + t] - 1);
+  } else {
+    e->tips_host.resize(T);
+    for (int t = 0; t < T; ++t) e->tips_host[t] = (uint8_t)(x->states[t] - 1);
+  }
+
+  const size_t stats_bytes = e->reduce ? sizeof(double) * (size_t)max_iters * e->tiles * e->dcols
+                                       : sizeof(double) * (size_t)max_iters * e->dcols * e->S_pad;
+  const size_t dw_bytes = sizeof(double) * (size_t)S * e->nw_total_cap;
+  const size_t tab = (size_t)e->nw_klong * n * n;
+  size_t free_b = 0, total_b = 0;
+  HIPCHK(hipMemGetInfo(&free_b, &total_b));
+  const size_t need = 2 * dw_bytes + (size_t)S * e->nw_total_cap + stats_bytes + sizeof(double) * (3 * tab + (size_t)S * E * (n + n * n));
+  if (need + (64u << 20) > free_b) {
+    char buf[256];
+    std::snprintf(buf, sizeof buf, "engine needs %.2f GiB of HBM, %.2f GiB free (reduce n_replicas or max_iters)", need / 1073741824.0, free_b / 1073741824.0);
+    return fail(PHM_ERR_OOM, buf);
+  }
+  HIPCHK(e->d_up.alloc(sizeof(phm::UpStep) * Nn)); HIPCHK(e->d_down.alloc(sizeof(phm::DownStep) * E));
+  HIPCHK(e->d_nw_up_order.alloc(sizeof(int32_t) * Nn)); HIPCHK(e->d_nw_down_order.alloc(sizeof(int32_t) * E));
+  HIPCHK(e->d_nw_border.alloc(sizeof(int32_t) * E)); HIPCHK(e->d_nw_off.alloc(sizeof(int64_t) * (E + 1)));
+  HIPCHK(e->d_nw_colL.alloc(sizeof(double) * tab)); HIPCHK(e->d_nw_rowL.alloc(sizeof(double) * tab));
+  HIPCHK(e->d_nw_maskL.alloc(sizeof(double) * (size_t)e->nw_klong * 2 * n));
+  HIPCHK(e->d_tips.alloc(e->tips_host.size()));
+  HIPCHK(e->d_nw_mcount.alloc(sizeof(int32_t) * (size_t)S * E));
+  HIPCHK(e->d_nw_dwA.alloc(dw_bytes)); HIPCHK(e->d_nw_dwB.alloc(dw_bytes));
+  HIPCHK(e->d_nw_mstate.alloc((size_t)S * e->nw_total_cap));
+  HIPCHK(e->d_nw_estate.alloc((size_t)S * E * 2));
+  HIPCHK(e->d_PL.alloc(sizeof(double) * (size_t)S * Nn * n));
+  HIPCHK(e->d_nstate.alloc((size_t)S * Nn));
+  HIPCHK(e->d_nw_part.alloc(sizeof(double) * (size_t)S * E * (n + n * n)));
+  HIPCHK(e->d_nw_rowbuf.alloc(sizeof(double) * (size_t)S * e->dcols));
+  HIPCHK(e->d_stats.alloc(stats_bytes));
+  HIPCHK(e->d_err.alloc(sizeof(uint32_t))); HIPCHK(e->d_seg.alloc(sizeof(unsigned long long)));
+  if (e->reduce) HIPCHK(e->d_red.alloc(sizeof(double) * (size_t)max_iters * e->dcols));
+  e->bytes = (int64_t)(2 * dw_bytes + e->d_nw_mstate.bytes + e->d_nw_part.bytes + e->d_PL.bytes + e->d_stats.bytes + e->d_red.bytes +
+                       sizeof(double) * 3 * tab + e->d_nw_mcount.bytes);
+  HIPCHK(hipMemcpy(e->d_up.p, s.up.data(), e->d_up.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(e->d_down.p, s.down.data(), e->d_down.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(e->d_nw_up_order.p, up_order.data(), e->d_nw_up_order.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(e->d_nw_down_order.p, down_order.data(), e->d_nw_down_order.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(e->d_nw_border.p, border.data(), e->d_nw_border.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(e->d_nw_off.p, e->nw_off.data(), e->d_nw_off.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(e->d_tips.p, e->tips_host.data(), e->tips_host.size(), hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(e->d_err.p, 0, sizeof(uint32_t)));
+  HIPCHK(hipMemset(e->d_seg.p, 0, sizeof(unsigned long long)));
+  HIPCHK(hipMemset(e->d_stats.p, 0, stats_bytes));
+  HIPCHK(hipMemset(e->d_nstate.p, 0, e->d_nstate.bytes));
+  {   // initial paths (makeabranch, src/phylomap.cpp:24-34, :901) into every chain's first buffer
+    std::vector<double> init((size_t)e->nw_total_cap, 0.0);
+    std::vector<int32_t> m0(E);
+    for (int b = 0; b < E; ++b) {
+      m0[b] = x->map_off[b + 1] - x->map_off[b];
+      std::memcpy(&init[(size_t)e->nw_off[b]], x->maps + x->map_off[b], sizeof(double) * m0[b]);
+    }
+    for (int r = 0; r < S; ++r) {
+      HIPCHK(hipMemcpy(e->d_nw_dwA.as<double>() + (size_t)r * e->nw_total_cap, init.data(), sizeof(double) * init.size(), hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(e->d_nw_mcount.as<int32_t>() + (size_t)r * E, m0.data(), sizeof(int32_t) * E, hipMemcpyHostToDevice));
+    }
+  }
+  if (n == 2) fill_narrow_params<2>(e, e->n2, o);
+  if (n == 3) fill_narrow_params<3>(e, e->n3, o);
+  if (n == 4) fill_narrow_params<4>(e, e->n4, o);
   return PHM_OK;
 }
 
@@ -346,6 +519,21 @@ int32_t phm_engine_create_multi(const phm_tree* trees, int32_t n_trees, const ph
   if (st) return st;
   HIPCHK(hipGetDevice(&e->device));
   const int E = s.n_edge, T = s.n_tips;
+
+  // Mapping of the sweep onto lanes (reserved[1]: 0 automatic, 1 one lane per replica, 2 one lane per branch): with few
+  // chains the replica mapping would leave all but a handful of lanes idle and walk the tree sequentially.
+  e->narrow = !e->wide && n_trees == 1 && (o.reserved[1] == 2 || (o.reserved[1] == 0 && e->S <= NARROW_AUTO_MAX_REPLICAS));
+  if (o.reserved[1] == 2 && !e->narrow) return fail(PHM_ERR_UNSUPPORTED, "the branch-parallel mapping covers n_states <= 4 and a single tree");
+  if (e->narrow) {
+    st = narrow_setup(e, x, model, o, max_iters);
+    if (st) return st;
+    st = upload_model(e);
+    if (st) return st;
+    HIPCHK(hipEventCreate(&e->ev0));
+    HIPCHK(hipEventCreate(&e->ev1));
+    *out = guard.release();
+    return PHM_OK;
+  }
 
   // Capacity of a tile's dwell stream.  Branch b holds 1 + Poisson(Omega t_b) segments in stationarity
   // (t_b = sum(x$maps[[b]])) and occupies max-over-64-lanes rows; provision the per-branch quantile at
@@ -513,7 +701,18 @@ int32_t phm_engine_run(phm_engine* e, int32_t n_iters, void* hip_stream) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
   HIPCHK(hipEventRecord(e->ev0, stream));
   int launches = 0;
-  for (int done = 0; done < n_iters;) {
+  if (e->narrow) {
+    hipError_t le = hipSuccess;
+    for (int i = 0; i < n_iters && le == hipSuccess; ++i) {
+      const int it = e->iters_done + i;
+      if (e->n == 2) le = phm::launch_narrow_sweep<2>(e->n2, e->nw_up_off, e->nw_down_off, it, stream);
+      if (e->n == 3) le = phm::launch_narrow_sweep<3>(e->n3, e->nw_up_off, e->nw_down_off, it, stream);
+      if (e->n == 4) le = phm::launch_narrow_sweep<4>(e->n4, e->nw_up_off, e->nw_down_off, it, stream);
+      launches += (int)(e->nw_up_off.size() + e->nw_down_off.size()) + 2;
+    }
+    HIPCHK(le);
+  }
+  for (int done = 0; done < n_iters && !e->narrow;) {
     int chunk = std::min(e->ipl, n_iters - done);
     hipError_t le = hipSuccess;
     if (e->n == 2) le = phm::launch_mcmc<2>(e->p2, e->iters_done + done, chunk, stream);
@@ -593,6 +792,36 @@ int32_t phm_engine_dump(phm_engine* e, int32_t replica, int32_t* seg_count, doub
   if (replica < 0 || replica >= e->S) return fail(PHM_ERR_BAD_INPUT, "replica out of range");
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipStreamSynchronize(e->last_stream));
+  if (e->narrow) {      // branch-parallel layout: CSR slots of the buffer the next sweep will read
+    const phm::Schedule& s = e->sched;
+    const int E = s.n_edge, T = s.n_tips, n = e->n;
+    std::vector<int32_t> mc(E);
+    HIPCHK(hipMemcpy(mc.data(), e->d_nw_mcount.as<int32_t>() + (size_t)replica * E, sizeof(int32_t) * E, hipMemcpyDeviceToHost));
+    if (seg_count) for (int b = 0; b < E; ++b) seg_count[b] = mc[b];
+    if (seg_dwell) {
+      std::vector<double> dw((size_t)e->nw_total_cap);
+      const double* src = ((e->iters_done & 1) ? e->d_nw_dwB.as<double>() : e->d_nw_dwA.as<double>()) + (size_t)replica * e->nw_total_cap;
+      HIPCHK(hipMemcpy(dw.data(), src, sizeof(double) * dw.size(), hipMemcpyDeviceToHost));
+      for (int b = 0; b < E; ++b)
+        for (int i = 0; i < std::min<int>(mc[b], seg_cap); ++i) seg_dwell[(size_t)b * seg_cap + i] = dw[(size_t)e->nw_off[b] + i];
+    }
+    auto tip_state = [&](int t) -> int { return e->tips_per_replica ? e->tips_host[(size_t)replica * T + t] : e->tips_host[t]; };
+    if (node_states) {
+      std::vector<uint8_t> ns(s.n_node);
+      HIPCHK(hipMemcpy(ns.data(), e->d_nstate.as<uint8_t>() + (size_t)replica * s.n_node, ns.size(), hipMemcpyDeviceToHost));
+      for (int t = 0; t < T; ++t) node_states[t] = tip_state(t) + 1;
+      for (int v = 0; v < s.n_node; ++v) node_states[T + v] = ns[v] + 1;
+    }
+    if (PL) {
+      std::vector<double> pl((size_t)s.n_node * n);
+      HIPCHK(hipMemcpy(pl.data(), e->d_PL.as<double>() + (size_t)replica * s.n_node * n, sizeof(double) * pl.size(), hipMemcpyDeviceToHost));
+      for (int t = 0; t < T; ++t)
+        for (int c = 0; c < n; ++c) PL[(size_t)t * n + c] = (c == tip_state(t)) ? 1.0 : 0.0;
+      for (int v = 0; v < s.n_node; ++v)
+        for (int c = 0; c < n; ++c) PL[(size_t)(T + v) * n + c] = pl[(size_t)v * n + c];
+    }
+    return PHM_OK;
+  }
   const int padded = e->pad_index(replica), tile = padded / 64, lane = padded % 64;
   const phm::Schedule& s = e->scheds[e->n_trees > 1 ? tile / e->tpt : 0];
   const int E = s.n_edge, T = s.n_tips, n = e->n;
@@ -934,7 +1163,7 @@ extern "C" int32_t phm_engine_reduced_stats_device(phm_engine* e, int32_t iter0,
 // Returns the HIP-event time in milliseconds.  n <= 4 kernels only.
 extern "C" int32_t phm_engine_time_pruning(phm_engine* e, int32_t n_iters, void* hip_stream, double* ms_out) {
   if (!e || !ms_out) return fail(PHM_ERR_STATE, "engine/ms_out is NULL");
-  if (e->wide) return fail(PHM_ERR_UNSUPPORTED, "pruning-only timing is implemented for n_states <= 4");
+  if (e->wide || e->narrow) return fail(PHM_ERR_UNSUPPORTED, "pruning-only timing is implemented for the replica mapping with n_states <= 4");
   if (n_iters < 1) return fail(PHM_ERR_BAD_INPUT, "n_iters must be >= 1");
   HIPCHK(hipSetDevice(e->device));
   hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);

@@ -141,4 +141,19 @@ __device__ __forceinline__ int sample_cat(const double (&p)[NS], double u, uint3
   return idx < NS ? idx : NS - 1;
 }
 
+template <int NS>
+__device__ __forceinline__ void matvec_u(const double* __restrict__ M, double (&v)[NS]) {
+  // v <- M v, left-to-right, unfused; M is wave-uniform (kernel argument -> SGPRs)
+  double y[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    double acc = M[i * NS] * v[0];
+#pragma unroll
+    for (int j = 1; j < NS; ++j) acc += M[i * NS + j] * v[j];
+    y[i] = acc;
+  }
+#pragma unroll
+  for (int i = 0; i < NS; ++i) v[i] = y[i];
+}
+
 }  // namespace phm

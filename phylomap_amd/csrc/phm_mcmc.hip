@@ -23,21 +23,6 @@
 
 namespace phm {
 
-template <int NS>
-__device__ __forceinline__ void matvec_u(const double* __restrict__ M, double (&v)[NS]) {
-  // v <- M v, left-to-right, unfused; M is wave-uniform (kernel argument -> SGPRs)
-  double y[NS];
-#pragma unroll
-  for (int i = 0; i < NS; ++i) {
-    double acc = M[i * NS] * v[0];
-#pragma unroll
-    for (int j = 1; j < NS; ++j) acc += M[i * NS + j] * v[j];
-    y[i] = acc;
-  }
-#pragma unroll
-  for (int i = 0; i < NS; ++i) v[i] = y[i];
-}
-
 // wave-uniform maximum of a per-lane count (all 64 lanes active at the call sites)
 __device__ __forceinline__ int wave_max(int v) {
 #pragma unroll

@@ -1,0 +1,68 @@
+// phm_narrow.h -- the MCMC sweep for FEW chains on a LARGE tree (n <= 4): one lane per BRANCH instead of one lane per
+// replica.  The reference's own workflows run a single chain (every driver's default; e.g. the 3 951-tip squamate analysis,
+// vignettes/Squamate_DIC_model_selection.Rnw:76-120, 10 000 sweeps of ~880 000 segments each); with one lane per replica
+// such a call would walk the whole tree in ONE lane.  Given the node states the branches of a sweep are conditionally
+// independent (sampleabranch src/phylomap.cpp:370-413 touches one branch), and the random numbers are addressed by
+// (replica, iteration, branch), so the branches can be resampled concurrently with the same results:
+//   up    : one launch per HEIGHT level of the tree, a lane per internal node             makePLrcpp* :503-529
+//   root  : a lane per chain                                                              :618-627
+//   down  : one launch per DEPTH level, a lane per edge: child state + the edge's end states   :640-657, :460-475
+//   branch: a lane per branch (longest first): resample, merge, count, re-insert virtual jumps    :264-413
+//   stats : fixed-order reduction of the per-branch partial sums                          :745-757
+// Dwell paths live in CSR form (one slot of `cap_b` doubles per branch, two buffers swapped every sweep); the chain powers
+// B^k e_j are read from tables that cover every possible segment count (built on the host with the kernels' arithmetic),
+// so each state draw costs O(1) instead of the O(m) continuation the LDS tables of phm_mcmc.hip need beyond k = 32.
+// Transition counts are bit-identical to the oracle; dwell sums are added per branch and then reduced, so they agree to
+// rounding (<= 1e-10 relative, the stated bar) rather than bit for bit.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "phm_device.h"
+#include "phm_sched.h"
+
+namespace phm {
+
+constexpr int NARROW_BLOCK = 64;      // one wavefront per workgroup: latency-bound work spread over as many CUs as possible
+
+template <int NS>
+struct NarrowParams {
+  int32_t n_tips, n_node, n_edge, root;      // root: internal index
+  int32_t n_rep, n_rep_pad, replica_offset, n_tiles;
+  int32_t normalise, tips_per_replica, ks, tip_masks, reduce, n_cols;
+  int32_t klong;                             // rows of the long chain tables (> every branch capacity)
+  uint32_t seed_lo, seed_hi;
+  int64_t total_cap;                         // doubles per replica in one dwell buffer
+  double B2[NS * NS], Bc[NS * NS], scale[NS], pid[NS];
+  const UpStep* up;                          // [n_node]
+  const DownStep* down;                      // [n_edge]
+  const int32_t* up_order;                   // positions into up[], grouped by height level
+  const int32_t* down_order;                 // positions into down[], grouped by depth level
+  const int32_t* branch_order;               // edge rows, largest capacity first
+  const int64_t* off;                        // [n_edge + 1] CSR offsets of the branch slots
+  const double* colL;                        // [klong][NS][NS]  (Bc^k e_j)[r]
+  const double* rowL;                        // [klong][NS][NS]  ((Bc^T)^k e_j)[c]
+  const double* maskL;                       // [klong][2][NS]   Bc^k applied to the even / odd state mask (ks)
+  const uint8_t* tips;                       // [n_tips] or [replica][n_tips], 0-based
+  int32_t* mcount;                           // [replica][n_edge]
+  double* dw[2];                             // [replica][total_cap] each; sweep `it` reads dw[it & 1], writes the other
+  uint8_t* mstate;                           // [replica][total_cap] states of the merged segments (scratch of one sweep)
+  uint8_t* estate;                           // [replica][n_edge][2] end states (parent side, child side) of every edge
+  double* PL;                                // [replica][n_node][NS]
+  uint8_t* nstate;                           // [replica][n_node]
+  double* part;                              // [replica][n_edge][NS + NS*NS] per-branch dwell sums and counts
+  double* rowbuf;                            // [replica][n_cols] statistics row of the sweep
+  double* stats;                             // engine layout: reduce ? [iter][tile][cols] : [iter][cols][n_rep_pad]
+  uint32_t* err;
+  unsigned long long* segcnt;
+};
+
+// one full sweep (iteration index `it`) enqueued on `stream`; level boundaries are host arrays (L+1 entries each)
+template <int NS>
+hipError_t launch_narrow_sweep(const NarrowParams<NS>& p, const std::vector<int32_t>& up_off,
+                               const std::vector<int32_t>& down_off, int it, hipStream_t stream);
+
+}  // namespace phm

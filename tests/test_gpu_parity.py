@@ -23,23 +23,41 @@ def _problem(n, tips, seed, omega_factor=1.25):
     return z, Q, pid, Omega
 
 
+MAPPINGS = ["replicas", "branches"]     # one lane per chain (throughput layout) / one lane per branch (few chains)
+
+
+def _same(got, want, n, mapping, ks=False):
+    """The bar of BASELINE.json: counts bit-exact, dwell times within 1e-10 relative.  The replica mapping adds the dwell
+    times in the reference's order (bit-identical on cladewise trees); the branch mapping adds them per branch and then
+    reduces, and whatever is derived from those sums (updated rates, log-likelihoods) inherits the rounding."""
+    got, want = np.asarray(got), np.asarray(want)
+    assert got.shape == want.shape
+    if mapping == "replicas":
+        np.testing.assert_array_equal(got, want)
+        return
+    ncnt = n * n if ks else n * (n - 1)
+    np.testing.assert_array_equal(got[..., n:n + ncnt], want[..., n:n + ncnt])
+    np.testing.assert_allclose(got[..., :n], want[..., :n], rtol=1e-10, atol=0)
+    np.testing.assert_allclose(got[..., n + ncnt:], want[..., n + ncnt:], rtol=1e-9, atol=0)
+
+
 VARIANTS = [("sumstatMCMC", O.PLAIN), ("sumstatMCMC_bigtree", O.BIGTREE), ("SPARSEsumstatMCMC", O.SPARSE)]
 
 
+@pytest.mark.parametrize("mapping", MAPPINGS)
 @pytest.mark.parametrize("n", [2, 3, 4])
 @pytest.mark.parametrize("fn,variant", VARIANTS)
-def test_mcmc_matches_oracle_small(n, fn, variant):
+def test_mcmc_matches_oracle_small(n, fn, variant, mapping):
     z, Q, pid, Omega = _problem(n, 24, 1234 + n)
     nen, nodelist, root = _orders(z)
     B = np.eye(n) + Q / Omega
     N, S, seed = 40, 3, 0xC0FFEE
-    got = getattr(api, fn)(z, Q, pid, Omega, N, seed=seed, n_replicas=S)
+    got = getattr(api, fn)(z, Q, pid, Omega, N, seed=seed, n_replicas=S, mapping=mapping)
     assert got.shape == (S, N, n + n * (n - 1))
     for r in range(S):
         want, rc = O.maketreelistMCMC(z, Q, pid, B, Omega, nen, nodelist, root, N, variant=variant, seed=seed, replica=r)
         assert rc == 0
-        np.testing.assert_array_equal(got[r][:, n:], want[:, n:])          # counts: bit-exact
-        np.testing.assert_array_equal(got[r][:, :n], want[:, :n])          # dwell: same summation order here
+        _same(got[r], want, n, mapping)      # counts bit-exact; dwell bit-exact (replicas: same summation order) / 1e-10
         np.testing.assert_allclose(got[r][:, :n].sum(1), z["edge.length"].sum(), rtol=1e-12)
 
 
@@ -49,15 +67,17 @@ def test_mcmc_single_chain_is_drop_in_shape():
     got = api.sumstatMCMC(z, Q, pid, Omega, 25, seed=5)
     want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(4) + Q / Omega, Omega, nen, nodelist, root, 25, seed=5)
     assert rc == 0 and got.shape == (25, 16)
-    np.testing.assert_array_equal(got, want)
+    _same(got, want, 4, "branches")                    # one chain: the automatic choice is the branch mapping
+    np.testing.assert_array_equal(api.sumstatMCMC(z, Q, pid, Omega, 25, seed=5, mapping="replicas"), want)
 
 
-@pytest.mark.parametrize("storage", [1, 2])      # 1: one ring per tile for both dwell streams; 2: two buffers
+@pytest.mark.parametrize("storage", [1, 2, 0])   # 1: one ring per tile for both dwell streams; 2: two buffers; 0: branch mapping
 def test_mcmc_chain_state_matches_oracle(storage):
     z, Q, pid, Omega = _problem(4, 40, 99)
     nen, nodelist, root = _orders(z)
     N, seed = 15, 42
-    eng = _lib.Engine(z, Q, pid, Omega, N, variant=_lib.PHM_MCMC_BIGTREE, seed=seed, n_replicas=70, storage=storage)
+    mapping = "replicas" if storage else "branches"
+    eng = _lib.Engine(z, Q, pid, Omega, N, variant=_lib.PHM_MCMC_BIGTREE, seed=seed, n_replicas=70, storage=storage, mapping=mapping)
     eng.run(7); eng.run(N - 7); eng.sync()
     for r in (0, 63, 69):
         want, rc, dump = O.maketreelistMCMC(z, Q, pid, np.eye(4) + Q / Omega, Omega, nen, nodelist, root, N,
@@ -70,11 +90,11 @@ def test_mcmc_chain_state_matches_oracle(storage):
             m = dump.seg_count[b]
             np.testing.assert_array_equal(got["seg_dwell"][b, :m], dump.seg_dwell[b, :m])
         np.testing.assert_array_equal(got["PL"], dump.PL)
-        np.testing.assert_array_equal(eng.stats(0, N)[r], want)
+        _same(eng.stats(0, N)[r], want, 4, mapping)
     eng.close()
 
 
-@pytest.mark.parametrize("storage", [1, 2])
+@pytest.mark.parametrize("storage", [1, 2, 0])        # 0: the branch mapping (CSR slots; no ring / buffer choice)
 def test_mcmc_long_initial_paths_take_the_general_branch_path(storage):
     """100 equal segments per branch (R/Squamate_tree_setup.R:57): exercises the > 64-segment code path and the
     hand-over to the packed two-pass path once the chain has shrunk the paths."""
@@ -83,11 +103,12 @@ def test_mcmc_long_initial_paths_take_the_general_branch_path(storage):
     pid = np.full(4, 0.25)
     z = synth.make_tree(14, Q, Omega, 21, pid, init_segments=100)
     nen, nodelist, root = _orders(z)
-    got = api.sumstatMCMC(z, Q, pid, Omega, 12, seed=13, n_replicas=2, storage=storage)
+    mapping = "replicas" if storage else "branches"
+    got = api.sumstatMCMC(z, Q, pid, Omega, 12, seed=13, n_replicas=2, storage=storage, mapping=mapping)
     for r in range(2):
         want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(4) + Q / Omega, Omega, nen, nodelist, root, 12, seed=13, replica=r)
         assert rc == 0
-        np.testing.assert_array_equal(got[r], want)
+        _same(got[r], want, 4, mapping)
 
 
 def _two_tip_tree(states, lens=(1.5, 0.7), segs=(1, 1)):
@@ -109,11 +130,12 @@ def test_edge_case_smallest_tree_and_single_segment_branches(segs):
     nen, nodelist, root = _orders(z)
     assert len(nodelist) == 0 and root == 3
     for fn, var in VARIANTS:
-        got = getattr(api, fn)(z, Q, pid, Omega, 30, seed=8, n_replicas=2)
-        for r in range(2):
-            want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(4) + Q / Omega, Omega, nen, nodelist, root, 30, variant=var, seed=8, replica=r)
-            assert rc == 0
-            np.testing.assert_array_equal(got[r], want)
+        for mapping in MAPPINGS:
+            got = getattr(api, fn)(z, Q, pid, Omega, 30, seed=8, n_replicas=2, mapping=mapping)
+            for r in range(2):
+                want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(4) + Q / Omega, Omega, nen, nodelist, root, 30, variant=var, seed=8, replica=r)
+                assert rc == 0
+                _same(got[r], want, 4, mapping)
     lefts, rights, d = api.eigen_decompose(Q)
     got = api.sumstatEXP(z, Q, pid, 100, seed=8)
     want, rc = O.maketreelistEXP(z, Q, pid, nen, nodelist, root, 100, lefts, rights, d, seed=8)
@@ -131,11 +153,12 @@ def test_edge_case_zero_length_segments_and_omega_on_the_boundary():
     z["maps"] = [np.array([m[0], 0.0, m[1]]) if i % 3 == 0 else m for i, m in enumerate(z["maps"])]
     z["mapnames"] = [np.array([n_[0], n_[0], n_[1]], dtype=np.int32) if i % 3 == 0 else n_ for i, n_ in enumerate(z["mapnames"])]
     nen, nodelist, root = _orders(z)
-    got = api.sumstatMCMC(z, Q, pid, Omega, 25, seed=21, n_replicas=3)
-    for r in range(3):
-        want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(2) + Q / Omega, Omega, nen, nodelist, root, 25, seed=21, replica=r)
-        assert rc == 0
-        np.testing.assert_array_equal(got[r], want)
+    for mapping in MAPPINGS:
+        got = api.sumstatMCMC(z, Q, pid, Omega, 25, seed=21, n_replicas=3, mapping=mapping)
+        for r in range(3):
+            want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(2) + Q / Omega, Omega, nen, nodelist, root, 25, seed=21, replica=r)
+            assert rc == 0
+            _same(got[r], want, 2, mapping)
 
 
 def test_edge_case_impossible_data_raises_like_the_sampler():
@@ -147,9 +170,10 @@ def test_edge_case_impossible_data_raises_like_the_sampler():
     nen, nodelist, root = _orders(z)
     _, rc = O.maketreelistMCMC(z, Q, np.array([.5, .5]), np.eye(2) + Q / Omega, Omega, nen, nodelist, root, 3, seed=1)
     assert rc & O.ERR_ZERO_PROB
-    with pytest.raises(_lib.PhmError) as e:
-        api.sumstatMCMC(z, Q, np.array([.5, .5]), Omega, 3, seed=1)
-    assert e.value.status == 5
+    for mapping in MAPPINGS:
+        with pytest.raises(_lib.PhmError) as e:
+            api.sumstatMCMC(z, Q, np.array([.5, .5]), Omega, 3, seed=1, mapping=mapping)
+        assert e.value.status == 5
 
 
 def test_mcmc_non_cladewise_edge_order():
@@ -163,11 +187,12 @@ def test_mcmc_non_cladewise_edge_order():
     z2["mapnames"] = [z["mapnames"][i] for i in perm]
     z2["node.states"] = z["node.states"][perm]
     nen, nodelist, root = _orders(z2)
-    got = api.sumstatMCMC(z2, Q, pid, Omega, 30, seed=9)
     want, rc = O.maketreelistMCMC(z2, Q, pid, np.eye(4) + Q / Omega, Omega, nen, nodelist, root, 30, seed=9)
     assert rc == 0
-    np.testing.assert_array_equal(got[:, 4:], want[:, 4:])
-    np.testing.assert_allclose(got[:, :4], want[:, :4], rtol=1e-10)
+    for mapping in MAPPINGS:
+        got = api.sumstatMCMC(z2, Q, pid, Omega, 30, seed=9, mapping=mapping)
+        np.testing.assert_array_equal(got[:, 4:], want[:, 4:])
+        np.testing.assert_allclose(got[:, :4], want[:, :4], rtol=1e-10)
 
 
 def test_mcmc_config2_shape_matches_oracle():
@@ -193,18 +218,20 @@ def test_plain_variant_underflows_like_the_reference():
     nen, nodelist, root = _orders(z)
     _, rc = O.maketreelistMCMC(z, Q, pid, np.eye(4) + Q / Omega, Omega, nen, nodelist, root, 2, seed=1)
     assert rc & O.ERR_ZERO_PROB
-    with pytest.raises(_lib.PhmError) as e:
-        api.sumstatMCMC(z, Q, pid, Omega, 2, seed=1)
-    assert e.value.status == 5
+    for mapping in MAPPINGS:
+        with pytest.raises(_lib.PhmError) as e:
+            api.sumstatMCMC(z, Q, pid, Omega, 2, seed=1, mapping=mapping)
+        assert e.value.status == 5
 
 
-def test_mcmc_per_site_tips_and_reduce():
+@pytest.mark.parametrize("mapping", MAPPINGS)
+def test_mcmc_per_site_tips_and_reduce(mapping):
     z, Q, pid, Omega = _problem(4, 20, 8)
     nen, nodelist, root = _orders(z)
     S, N, seed = 5, 20, 11
     rs = np.random.default_rng(0)
     sites = rs.integers(1, 5, size=(S, 20)).astype(np.int32)
-    eng = _lib.Engine(z, Q, pid, Omega, N, seed=seed, n_replicas=S, tips_per_replica=True, states=sites)
+    eng = _lib.Engine(z, Q, pid, Omega, N, seed=seed, n_replicas=S, tips_per_replica=True, states=sites, mapping=mapping)
     eng.run(N); eng.sync()
     per = eng.stats(0, N)
     eng.close()
@@ -213,9 +240,9 @@ def test_mcmc_per_site_tips_and_reduce():
         zr = dict(z); zr["states"] = sites[r]
         want, rc = O.maketreelistMCMC(zr, Q, pid, np.eye(4) + Q / Omega, Omega, nen, nodelist, root, N, seed=seed, replica=r)
         assert rc == 0
-        np.testing.assert_array_equal(per[r], want)
+        _same(per[r], want, 4, mapping)
         total += want
-    eng = _lib.Engine(z, Q, pid, Omega, N, seed=seed, n_replicas=S, tips_per_replica=True, states=sites, reduce=True)
+    eng = _lib.Engine(z, Q, pid, Omega, N, seed=seed, n_replicas=S, tips_per_replica=True, states=sites, reduce=True, mapping=mapping)
     eng.run(N); eng.sync()
     red = eng.stats(0, N)
     eng.close()
@@ -272,8 +299,8 @@ def test_wide_kernel_chain_state_and_golden():
     np.testing.assert_array_equal(d["PL"], dump.PL)
 
 
-@pytest.mark.parametrize("n", [2, 4, 6])
-def test_ks_sweep_matches_oracle(n):
+@pytest.mark.parametrize("n,mapping", [(2, "replicas"), (4, "replicas"), (2, "branches"), (4, "branches"), (6, "replicas")])
+def test_ks_sweep_matches_oracle(n, mapping):
     """Tree sweep of sumstatMCMCks with Q fixed (hidden-rates Q = make2sQ, binary trait observed): n<=4 kernel and,
     for k=2 (n=6), the wide kernel."""
     Q = {2: synth.config_Q(1), 4: synth.make2sQ(.1, .1, .2, .2, 10), 6: synth.make2sQ(.1, .3, [.2, .4], [.5, .6], [2, 3])}[n]
@@ -286,21 +313,21 @@ def test_ks_sweep_matches_oracle(n):
             z["mapnames"][b][-1] = z["states"][c_ - 1]
     nen, nodelist, root = _orders(z)
     N, S, seed = 15, 3, 77
-    got = api.sumstatMCMCks_sweep(z, Q, pid, Omega, N, seed=seed, n_replicas=S)
+    got = api.sumstatMCMCks_sweep(z, Q, pid, Omega, N, seed=seed, n_replicas=S, mapping=mapping)
     k = n // 2 - 1
     assert got.shape == (S, N, n + n * n + 2 + 3 * k + 1)
     for r in range(S):
         want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(n) + Q / Omega, Omega, nen, nodelist, root, N, variant=O.KS,
                                       seed=seed, replica=r)
         assert rc == 0
-        np.testing.assert_array_equal(got[r], want)
-    red = api.sumstatMCMCks_sweep(z, Q, pid, Omega, N, seed=seed, n_replicas=S, reduce=True)
+        _same(got[r], want, n, mapping, ks=True)
+    red = api.sumstatMCMCks_sweep(z, Q, pid, Omega, N, seed=seed, n_replicas=S, reduce=True, mapping=mapping)
     np.testing.assert_array_equal(red[:, n:n + n * n], got.sum(0)[:, n:n + n * n])
     np.testing.assert_array_equal(red[:, n + n * n:-1], got[0][:, n + n * n:-1])     # parameter columns: plain values
     np.testing.assert_array_equal(red[:, -1], got.sum(0)[:, -1])
 
 
-@pytest.mark.parametrize("storage", [1, 2])
+@pytest.mark.parametrize("storage", [1, 2, 0])        # 0: the branch mapping (what a default single-chain call gets)
 def test_sumstatMCMCbf_with_rate_updates_matches_oracle(storage):
     """R/sumstatMCMCbf.R: sweep on the GPU, Gibbs update of (l01, l10) on the host, every iteration."""
     Q = np.array([[-.1, .1], [.1, -.1]])
@@ -308,11 +335,12 @@ def test_sumstatMCMCbf_with_rate_updates_matches_oracle(storage):
     z = synth.make_tree(40, Q, 0.5, 15, pid)
     nen, nodelist, root = _orders(z)
     Q0 = Q.copy()
-    got = api.sumstatMCMCbf(z, Q, pid, Omega, 30, prior, seed=99, storage=storage)
+    mapping = "replicas" if storage else "branches"
+    got = api.sumstatMCMCbf(z, Q, pid, Omega, 30, prior, seed=99, storage=storage, mapping=mapping)
     assert np.array_equal(Q, Q0)                                             # inputs are never written (:1212-1217 does)
     want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(2) + Q / Omega, Omega, nen, nodelist, root, 30, variant=O.BF, seed=99, prior=prior)
     assert rc == 0 and got.shape == (30, 9)
-    np.testing.assert_array_equal(got, want)
+    _same(got, want, 2, mapping, ks=True)
     assert len(np.unique(got[:, 6])) > 20 and np.all(got[:, 6] > 0)          # l01 really moves
 
 
@@ -326,10 +354,11 @@ def test_sumstatMCMCks_with_rate_updates_matches_oracle(n):
     z = synth.make_tree(30, Q, 1.0 if n == 4 else Omega / 3, 16, pid)
     z["states"] = ((z["states"] - 1) % 2 + 1).astype(np.int32)
     nen, nodelist, root = _orders(z)
-    got = api.sumstatMCMCks(z, Q, pid, Omega, 25, prior, seed=7)
     want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(n) + Q / Omega, Omega, nen, nodelist, root, 25, variant=O.KS, seed=7, prior=prior)
     assert rc == 0
-    np.testing.assert_array_equal(got, want)
+    for mapping in (MAPPINGS if n == 4 else ["replicas"]):                   # n = 4, one chain: "branches" is the default
+        got = api.sumstatMCMCks(z, Q, pid, Omega, 25, prior, seed=7, mapping=mapping)
+        _same(got, want, n, mapping, ks=True)
     k = n // 2 - 1
     assert len(np.unique(got[:, n + n * n])) > 10                            # l01 moves
     # multi-site: S sites share Q; updates see the summed statistics
@@ -351,10 +380,11 @@ def test_dic_drivers_match_oracle(which):
     z = synth.make_tree(25, Q, Omega / 3, 44, pid)
     z["states"] = ((z["states"] - 1) % 2 + 1).astype(np.int32)
     nen, nodelist, root = _orders(z)
-    got = fn(z, Q, pid, Omega, 20, prior, seed=5)
     want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(n) + Q / Omega, Omega, nen, nodelist, root, 20, variant=var, seed=5, prior=prior, dic=True)
-    assert rc == 0 and got.shape == want.shape
-    np.testing.assert_array_equal(got, want)
+    assert rc == 0
+    for mapping in MAPPINGS:
+        got = fn(z, Q, pid, Omega, 20, prior, seed=5, mapping=mapping)
+        _same(got, want, n, mapping, ks=True)
     # the first log-likelihood against an independent Felsenstein pass with scipy's expm
     T, E = 25, z["edge"]
     PL = np.zeros((2 * T - 1, n))

@@ -396,3 +396,56 @@ def test_multitree_oracle_structure():
     _, rc = O.maketreelistMCMCmt(tk, Qk[:3, :3], [1 / 3] * 3, np.eye(3), 25.0, np.stack([o[0] for o in ok]),
                                  np.stack([o[1] for o in ok]), [o[2] for o in ok], 2, [1] * 8, variant=O.KSMT)
     assert rc & O.ERR_BAD_INPUT
+
+
+SQUAMATE_RDS = "/root/reference/inst/extdata/Squamate/phylomap_compatible_squamate_tree.RData"
+
+
+@pytest.mark.skipif(not os.path.exists(SQUAMATE_RDS), reason="the reference's data file is only present in the build container")
+def test_known_answer_squamate_seed_101_tip_simulation():
+    """The reference's own known answer for its data pipeline: R/simulate_2_state_tree.R:11 notes "n01 is 21" for
+    set.seed(101) on the shipped 3 951-tip squamate tree.  Reproducing it takes the RDS reader, the R random stream of the
+    oracle (set.seed scrambling, Mersenne-Twister, unif_rand, Ahrens-Dieter exp_rand) and ape's postorder -- all restated
+    here without R.  The committed fixture (tree + these tips) is what tools/squamate_dic/run_dic.py feeds the DIC drivers."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "squamate_dic"))
+    import simulate_tips as st
+    from phylomap_amd import rds
+    z = rds.read_phylomap_tree(SQUAMATE_RDS)
+    assert z["edge"].shape == (7900, 2) and z["Nnode"] == 3950 and all(len(m) == 100 for m in z["maps"][:50])
+    Q2 = np.array([[-0.001, 0.001], [0.006, -0.006]])
+    tips, n01, n10, t0, t1, used = st.sample2statehistory(z, Q2, [.5, .5], 101, root_tie_first=2)
+    assert n01 == 21
+    np.testing.assert_allclose(t0 + t1, z["edge.length"].sum(), rtol=1e-12)
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "squamate", "seed101_tips.npz"))
+    np.testing.assert_array_equal(fx["states"], tips)
+    np.testing.assert_array_equal(fx["edge"], z["edge"])
+    np.testing.assert_array_equal(fx["edge_length"], z["edge.length"])
+
+
+def test_rds_reader_round_trip_of_hand_built_stream(tmp_path):
+    """phylomap_amd/rds.py on a stream assembled by hand from the published format (list with names, integer matrix with
+    dim, named real vector, character vector)."""
+    import gzip
+    import struct
+    from phylomap_amd import rds
+
+    def i32(v): return struct.pack(">i", v)
+    def chars(s_): return i32(9 | (1 << 18)) + i32(len(s_)) + s_.encode()            # CHARSXP, UTF-8 flag in gp
+    def sym(s_): return i32(1) + chars(s_)
+    def strvec(v): return i32(16) + i32(len(v)) + b"".join(chars(x) for x in v)
+    def attrs(pairs):                                                                 # pairlist with tags
+        out = b""
+        for k, v in pairs:
+            out += i32(2 | 0x400) + sym(k) + v
+        return out + i32(254)
+    edge = i32(13 | 0x200) + i32(4) + b"".join(i32(v) for v in (3, 3, 1, 2)) + attrs([("dim", i32(13) + i32(2) + i32(2) + i32(2))])
+    maps1 = i32(14 | 0x200) + i32(2) + struct.pack(">dd", 0.25, 0.5) + attrs([("names", strvec(["1", "2"]))])
+    lst = i32(19 | 0x200) + i32(3) + edge + (i32(19) + i32(1) + maps1) + strvec(["a", "b"]) + \
+        attrs([("names", strvec(["edge", "maps", "tip.label"]))])
+    path = tmp_path / "x.rds"
+    path.write_bytes(gzip.compress(b"X\n" + i32(2) + i32(0x030102) + i32(0x020300) + lst))
+    x = rds.read_rds(str(path))
+    np.testing.assert_array_equal(x["edge"], [[3, 1], [3, 2]])
+    np.testing.assert_array_equal(x["maps"][0], [0.25, 0.5])
+    assert x["maps"][0].names == ["1", "2"] and x["tip.label"] == ["a", "b"]
