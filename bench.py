@@ -94,7 +94,7 @@ def main():
     if S <= 0:
         free_b, _ = torch.cuda.mem_get_info()
         probe = _lib.Engine(z, Q, pid, Omega, 1, variant=_lib.PHM_MCMC_BIGTREE, seed=1, n_replicas=64, reduce=True,
-                            device=local_rank, storage=args.storage)
+                            device=local_rank, storage=args.storage, mapping="replicas")
         per_tile = probe.info().device_bytes
         probe.close()
         S = int(min(327680, (0.80 * free_b) // per_tile * 64))
@@ -102,7 +102,7 @@ def main():
 
     eng = _lib.Engine(z, Q, pid, Omega, K + W, variant=_lib.PHM_MCMC_BIGTREE, seed=0x5EED0000 + args.config,
                       n_replicas=S, replica_offset=parallel.weak_shard(S, rank)[0], reduce=True, device=local_rank,
-                      iters_per_launch=args.ipl, storage=args.storage)
+                      iters_per_launch=args.ipl, storage=args.storage, mapping="replicas")   # one lane per replica
     stream = torch.cuda.current_stream().cuda_stream
 
     def barrier():

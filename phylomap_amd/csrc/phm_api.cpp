@@ -100,7 +100,7 @@ struct phm_engine {
   int nw_klong = 0;
   int64_t nw_total_cap = 0;
   DevBuf d_nw_up_order, d_nw_down_order, d_nw_border, d_nw_off, d_nw_colL, d_nw_rowL, d_nw_maskL, d_nw_mcount, d_nw_dwA, d_nw_dwB,
-      d_nw_mstate, d_nw_estate, d_nw_part, d_nw_rowbuf;
+      d_nw_mstate, d_nw_mlen, d_nw_estate, d_nw_part, d_nw_rowbuf;
   phm::NarrowParams<2> n2;
   phm::NarrowParams<3> n3;
   phm::NarrowParams<4> n4;
@@ -119,7 +119,10 @@ struct phm_engine {
 
 namespace {
 
-constexpr int NARROW_AUTO_MAX_REPLICAS = 16;     // automatic choice of the branch-parallel mapping: at most this many chains
+// Automatic choice of the branch-parallel mapping: up to this many chains.  Measured on C2 (profiles/r01_probe_mapping.log):
+// one lane per branch takes 0.29 ms per sweep for one chain (one lane per replica: 22 ms) and is still 3x ahead at 4096
+// chains; the replica mapping only pays off once tens of thousands of replicas fill its 64-lane tiles.
+constexpr int NARROW_AUTO_MAX_REPLICAS = 8192;
 
 bool ks_layout(int v) { return v == PHM_MCMC_KS || v == PHM_MCMC_BF || v == PHM_MCMC_MT || v == PHM_MCMC_KSMT; }   // n x n counts, root column
 bool hidden_rates(int v) { return v == PHM_MCMC_KS || v == PHM_MCMC_KSMT; }                                         // parity tip masks
@@ -289,7 +292,7 @@ void fill_narrow_params(phm_engine* e, phm::NarrowParams<NS>& p, const phm_optio
   p.colL = e->d_nw_colL.as<double>(); p.rowL = e->d_nw_rowL.as<double>(); p.maskL = e->d_nw_maskL.as<double>();
   p.tips = e->d_tips.as<uint8_t>();
   p.mcount = e->d_nw_mcount.as<int32_t>(); p.dw[0] = e->d_nw_dwA.as<double>(); p.dw[1] = e->d_nw_dwB.as<double>();
-  p.mstate = e->d_nw_mstate.as<uint8_t>(); p.estate = e->d_nw_estate.as<uint8_t>();
+  p.mstate = e->d_nw_mstate.as<uint8_t>(); p.mlen = e->d_nw_mlen.as<double>(); p.estate = e->d_nw_estate.as<uint8_t>();
   p.PL = e->d_PL.as<double>(); p.nstate = e->d_nstate.as<uint8_t>(); p.part = e->d_nw_part.as<double>();
   p.rowbuf = e->d_nw_rowbuf.as<double>(); p.stats = e->d_stats.as<double>();
   p.err = e->d_err.as<uint32_t>(); p.segcnt = e->d_seg.as<unsigned long long>();
@@ -362,7 +365,7 @@ int32_t narrow_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
   const size_t tab = (size_t)e->nw_klong * n * n;
   size_t free_b = 0, total_b = 0;
   HIPCHK(hipMemGetInfo(&free_b, &total_b));
-  const size_t need = 2 * dw_bytes + (size_t)S * e->nw_total_cap + stats_bytes + sizeof(double) * (3 * tab + (size_t)S * E * (n + n * n));
+  const size_t need = 3 * dw_bytes + (size_t)S * e->nw_total_cap + stats_bytes + sizeof(double) * (3 * tab + (size_t)S * E * (n + n * n));
   if (need + (64u << 20) > free_b) {
     char buf[256];
     std::snprintf(buf, sizeof buf, "engine needs %.2f GiB of HBM, %.2f GiB free (reduce n_replicas or max_iters)", need / 1073741824.0, free_b / 1073741824.0);
@@ -377,6 +380,7 @@ int32_t narrow_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
   HIPCHK(e->d_nw_mcount.alloc(sizeof(int32_t) * (size_t)S * E));
   HIPCHK(e->d_nw_dwA.alloc(dw_bytes)); HIPCHK(e->d_nw_dwB.alloc(dw_bytes));
   HIPCHK(e->d_nw_mstate.alloc((size_t)S * e->nw_total_cap));
+  HIPCHK(e->d_nw_mlen.alloc(dw_bytes));
   HIPCHK(e->d_nw_estate.alloc((size_t)S * E * 2));
   HIPCHK(e->d_PL.alloc(sizeof(double) * (size_t)S * Nn * n));
   HIPCHK(e->d_nstate.alloc((size_t)S * Nn));
@@ -385,7 +389,7 @@ int32_t narrow_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
   HIPCHK(e->d_stats.alloc(stats_bytes));
   HIPCHK(e->d_err.alloc(sizeof(uint32_t))); HIPCHK(e->d_seg.alloc(sizeof(unsigned long long)));
   if (e->reduce) HIPCHK(e->d_red.alloc(sizeof(double) * (size_t)max_iters * e->dcols));
-  e->bytes = (int64_t)(2 * dw_bytes + e->d_nw_mstate.bytes + e->d_nw_part.bytes + e->d_PL.bytes + e->d_stats.bytes + e->d_red.bytes +
+  e->bytes = (int64_t)(3 * dw_bytes + e->d_nw_mstate.bytes + e->d_nw_part.bytes + e->d_PL.bytes + e->d_stats.bytes + e->d_red.bytes +
                        sizeof(double) * 3 * tab + e->d_nw_mcount.bytes);
   HIPCHK(hipMemcpy(e->d_up.p, s.up.data(), e->d_up.bytes, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(e->d_down.p, s.down.data(), e->d_down.bytes, hipMemcpyHostToDevice));
@@ -523,9 +527,13 @@ int32_t phm_engine_create_multi(const phm_tree* trees, int32_t n_trees, const ph
   // Mapping of the sweep onto lanes (reserved[1]: 0 automatic, 1 one lane per replica, 2 one lane per branch): with few
   // chains the replica mapping would leave all but a handful of lanes idle and walk the tree sequentially.
   e->narrow = !e->wide && n_trees == 1 && (o.reserved[1] == 2 || (o.reserved[1] == 0 && e->S <= NARROW_AUTO_MAX_REPLICAS));
+  if (e->narrow && o.reserved[1] == 0 && o.reserved[0] != 0) e->narrow = false;     // a ring / two-buffer request names the replica layout
   if (o.reserved[1] == 2 && !e->narrow) return fail(PHM_ERR_UNSUPPORTED, "the branch-parallel mapping covers n_states <= 4 and a single tree");
   if (e->narrow) {
     st = narrow_setup(e, x, model, o, max_iters);
+    if (st == PHM_ERR_OOM && o.reserved[1] == 0) { e->narrow = false; st = PHM_OK; }     // automatic choice: try the replica layout
+  }
+  if (e->narrow) {
     if (st) return st;
     st = upload_model(e);
     if (st) return st;
@@ -1240,19 +1248,32 @@ static int32_t run_qupdate(int variant, bool dic, const phm_tree* x, int32_t n, 
   const size_t nn = (size_t)n * n;
 
   // DIC: device state of the per-iteration log-likelihood (expmat(Q t_b) for every branch, then pruning in nen order)
-  DevBuf dQ, dt, ds, dwork, dP, dPL0, dPL, dpid, dup, dll, derr;
+  DevBuf dQ, dt, ds, dwork, dP, dPL0, dPL, dpid, dup, dll, derr, dorder, dlogs;
   std::vector<double> loglik;
+  std::vector<int32_t> ll_level_off;
   std::vector<int32_t> sq(E);
   if (dic) {
     std::vector<phm::UpStep> upn(Nn);
     const int32_t* e1 = x->edge; const int32_t* e2 = x->edge + E;
     auto code = [&](int32_t node) { return node > T ? node - T - 1 : ~(node - 1); };
+    std::vector<int32_t> height(Nn, 0);
+    int max_h = 0;
     for (int i = 0; i < Nn; ++i) {
       const int ea = nen[2 * i] - 1, eb = nen[2 * i + 1] - 1;
       upn[i].parent = e1[ea] - T - 1;
       upn[i].child[0] = code(e2[ea]); upn[i].child[1] = code(e2[eb]);
       upn[i].edge[0] = ea; upn[i].edge[1] = eb;
+      int h = 0;                                        // nen lists children before parents (checked above)
+      for (int c = 0; c < 2; ++c) if (upn[i].child[c] >= 0) h = std::max(h, height[upn[i].child[c]] + 1);
+      height[upn[i].parent] = h; max_h = std::max(max_h, h);
     }
+    ll_level_off.assign(max_h + 2, 0);
+    for (int i = 0; i < Nn; ++i) ll_level_off[height[upn[i].parent] + 1]++;
+    for (size_t l = 1; l < ll_level_off.size(); ++l) ll_level_off[l] += ll_level_off[l - 1];
+    std::vector<int32_t> ll_order(Nn), pos(ll_level_off.begin(), ll_level_off.end() - 1);
+    for (int i = 0; i < Nn; ++i) ll_order[pos[height[upn[i].parent]]++] = i;
+    HIPCHK(dorder.alloc(sizeof(int32_t) * Nn)); HIPCHK(dlogs.alloc(sizeof(double) * Nn));
+    HIPCHK(hipMemcpy(dorder.p, ll_order.data(), dorder.bytes, hipMemcpyHostToDevice));
     std::vector<double> PLh((size_t)(2 * T - 1) * n, 0.0);
     for (int t = 0; t < T; ++t) {
       if (variant == PHM_MCMC_BF) PLh[(size_t)t * n + (x->states[t] - 1)] = 1.0;                         // :3165
@@ -1284,7 +1305,8 @@ static int32_t run_qupdate(int variant, bool dic, const phm_tree* x, int32_t n, 
       HIPCHK(hipMemcpy(ds.p, sq.data(), ds.bytes, hipMemcpyHostToDevice));
       HIPCHK(hipMemcpyAsync(dPL.p, dPL0.p, dPL.bytes, hipMemcpyDeviceToDevice, nullptr));
       HIPCHK(phm::launch_expm_pade(n, dQ.as<double>(), dt.as<double>(), ds.as<int32_t>(), E, dwork.as<double>(), dP.as<double>(), derr.as<uint32_t>(), nullptr));
-      HIPCHK(phm::launch_exp_pl_loglik(n, Nn, T, dup.as<phm::UpStep>(), dP.as<double>(), dPL.as<double>(), dpid.as<double>(), root - 1, dll.as<double>(), nullptr));
+      HIPCHK(phm::launch_exp_pl_loglik(n, Nn, T, dup.as<phm::UpStep>(), dorder.as<int32_t>(), ll_level_off, dP.as<double>(), dPL.as<double>(),
+                                       dlogs.as<double>(), dpid.as<double>(), root - 1, dll.as<double>(), nullptr));
       HIPCHK(hipMemcpy(&loglik[i], dll.p, sizeof(double), hipMemcpyDeviceToHost));
     }
     if (variant == PHM_MCMC_BF) phm::bf_updates(Qw.data(), Omega, prior, row.data(), o.seed, (uint32_t)i);

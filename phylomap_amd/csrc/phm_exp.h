@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "phm_device.h"
 #include "phm_sched.h"
 
@@ -34,8 +36,10 @@ hipError_t launch_expm_pade_mfma(int n, const double* Q, const double* t, const 
 hipError_t launch_exp_pl(int n, int n_node, int n_tips, const UpStep* up, const double* P, double* PL,
                          hipStream_t stream);
 
-// log p(y|Q): pruning with P(t_b), rows normalised, log scale factors summed in the order of `up` (DIC drivers)
-hipError_t launch_exp_pl_loglik(int n, int n_node, int n_tips, const UpStep* up, const double* P, double* PL,
+// log p(y|Q): pruning with P(t_b), rows normalised, log scale factors summed in the order of `up` (DIC drivers).
+// `order` (device): positions of `up` grouped by height level, `level_off` (host) the level boundaries; `logs`: n_node doubles.
+hipError_t launch_exp_pl_loglik(int n, int n_node, int n_tips, const UpStep* up, const int32_t* order,
+                                const std::vector<int32_t>& level_off, const double* P, double* PL, double* logs,
                                 const double* pid, int root_node, double* out_ll, hipStream_t stream);
 
 template <int NS>

@@ -182,44 +182,69 @@ hipError_t launch_exp_pl(int n, int n_node, int n_tips, const UpStep* up, const 
 // ------------------------------------------------------------------------------------------------
 // log p(y|Q) by matrix exponentiation (the DIC drivers: PPmakePLD :3158-3178, PPmakePLksD :3268-3297): pruning with
 // P(t_b), every internal row divided by its sum, the log scale factors accumulated in the caller's pruningwise order
-// (`up` is built from nen), then log(sum_j PL[root,j] pid_j) + S.  One thread: the tree is walked once per MCMC
-// iteration and the result is a single number.
+// (`up` is built from nen), then log(sum_j PL[root,j] pid_j) + S.
+// The tree is walked level by level (a lane per node of one height level; `order` lists positions of `up` grouped by
+// level), each node leaving log(scale factor) in logs[position]; one thread then adds the logs in nen order, so the sum
+// is the reference's left-to-right sum whatever the launch geometry.
 // ------------------------------------------------------------------------------------------------
-__global__ void exp_pl_loglik_kernel(int n, int n_node, int n_tips, const UpStep* __restrict__ up,
-                                     const double* __restrict__ P, double* __restrict__ PL, const double* __restrict__ pid,
-                                     int root_node, double* __restrict__ out_ll) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
-  double S = 0;
-  for (int k = 0; k < n_node; ++k) {
-    const UpStep st = up[k];
-    const int ca = st.child[0] >= 0 ? st.child[0] + n_tips : ~st.child[0];
-    const int cb = st.child[1] >= 0 ? st.child[1] + n_tips : ~st.child[1];
-    const double* Pa = P + (size_t)st.edge[0] * n * n;
-    const double* Pb = P + (size_t)st.edge[1] * n * n;
-    const double* va = PL + (size_t)ca * n;
-    const double* vb = PL + (size_t)cb * n;
-    double* dst = PL + (size_t)(st.parent + n_tips) * n;
-    double sm = 0.0;
-    for (int i = 0; i < n; ++i) {
-      double a = Pa[i * n] * va[0];
-      for (int j = 1; j < n; ++j) a += Pa[i * n + j] * va[j];
-      double b = Pb[i * n] * vb[0];
-      for (int j = 1; j < n; ++j) b += Pb[i * n + j] * vb[j];
-      const double r = a * b;
-      dst[i] = r;
-      sm = (i == 0) ? r : sm + r;
-    }
-    S = S + phm_log(sm);
-    for (int i = 0; i < n; ++i) dst[i] = dst[i] / sm;
+__global__ void exp_pl_level_kernel(int n, int n_tips, const UpStep* __restrict__ up, const int32_t* __restrict__ order,
+                                    int begin, int end, const double* __restrict__ P, double* __restrict__ PL,
+                                    double* __restrict__ logs) {
+  const int idx = begin + blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= end) return;
+  const int k = order[idx];
+  const UpStep st = up[k];
+  const int ca = st.child[0] >= 0 ? st.child[0] + n_tips : ~st.child[0];
+  const int cb = st.child[1] >= 0 ? st.child[1] + n_tips : ~st.child[1];
+  const double* Pa = P + (size_t)st.edge[0] * n * n;
+  const double* Pb = P + (size_t)st.edge[1] * n * n;
+  const double* va = PL + (size_t)ca * n;
+  const double* vb = PL + (size_t)cb * n;
+  double* dst = PL + (size_t)(st.parent + n_tips) * n;
+  double sm = 0.0;
+  for (int i = 0; i < n; ++i) {
+    double a = Pa[i * n] * va[0];
+    for (int j = 1; j < n; ++j) a += Pa[i * n + j] * va[j];
+    double b = Pb[i * n] * vb[0];
+    for (int j = 1; j < n; ++j) b += Pb[i * n + j] * vb[j];
+    const double r = a * b;
+    dst[i] = r;
+    sm = (i == 0) ? r : sm + r;
   }
-  double X = 0;
-  for (int j = 0; j < n; ++j) X = X + PL[(size_t)root_node * n + j] * pid[j];
-  *out_ll = phm_log(X) + S;
+  logs[k] = phm_log(sm);
+  for (int i = 0; i < n; ++i) dst[i] = dst[i] / sm;
 }
 
-hipError_t launch_exp_pl_loglik(int n, int n_node, int n_tips, const UpStep* up, const double* P, double* PL,
+__global__ __launch_bounds__(256) void exp_pl_logsum_kernel(int n, int n_node, const double* __restrict__ logs,
+                                                            const double* __restrict__ PL, const double* __restrict__ pid,
+                                                            int root_node, double* __restrict__ out_ll) {
+  __shared__ double chunk[4096];
+  double S = 0;
+  for (int base = 0; base < n_node; base += 4096) {
+    const int len = min(4096, n_node - base);
+    for (int i = threadIdx.x; i < len; i += 256) chunk[i] = logs[base + i];
+    __syncthreads();
+    if (threadIdx.x == 0)
+      for (int i = 0; i < len; ++i) S = S + chunk[i];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    double X = 0;
+    for (int j = 0; j < n; ++j) X = X + PL[(size_t)root_node * n + j] * pid[j];
+    *out_ll = phm_log(X) + S;
+  }
+}
+
+hipError_t launch_exp_pl_loglik(int n, int n_node, int n_tips, const UpStep* up, const int32_t* order,
+                                const std::vector<int32_t>& level_off, const double* P, double* PL, double* logs,
                                 const double* pid, int root_node, double* out_ll, hipStream_t stream) {
-  hipLaunchKernelGGL(exp_pl_loglik_kernel, dim3(1), dim3(64), 0, stream, n, n_node, n_tips, up, P, PL, pid, root_node, out_ll);
+  for (size_t l = 0; l + 1 < level_off.size(); ++l) {
+    const int cnt = level_off[l + 1] - level_off[l];
+    if (cnt <= 0) continue;
+    hipLaunchKernelGGL(exp_pl_level_kernel, dim3((cnt + 63) / 64), dim3(64), 0, stream, n, n_tips, up, order, level_off[l],
+                       level_off[l + 1], P, PL, logs);
+  }
+  hipLaunchKernelGGL(exp_pl_logsum_kernel, dim3(1), dim3(256), 0, stream, n, n_node, logs, PL, pid, root_node, out_ll);
   return hipGetLastError();
 }
 

@@ -130,8 +130,9 @@ __global__ __launch_bounds__(NARROW_BLOCK) void narrow_branch_kernel(NarrowParam
   const int ps = es[0], cs = es[1];
   const int64_t o = p.off[b];
   const int cap = (int)(p.off[b + 1] - o);
-  double* __restrict__ in = p.dw[it & 1] + (size_t)r * p.total_cap + o;
+  const double* __restrict__ in = p.dw[it & 1] + (size_t)r * p.total_cap + o;
   double* __restrict__ out = p.dw[(it & 1) ^ 1] + (size_t)r * p.total_cap + o;
+  double* __restrict__ ml = p.mlen + (size_t)r * p.total_cap + o;
   uint8_t* __restrict__ ms = p.mstate + (size_t)r * p.total_cap + o;
   uint32_t err = 0;
 #pragma unroll
@@ -143,32 +144,48 @@ __global__ __launch_bounds__(NARROW_BLOCK) void narrow_branch_kernel(NarrowParam
   se.open(ENT_BEXP | (uint32_t)b, (uint32_t)it, rep, p.seed_lo, p.seed_hi);
 
   // pass A: states of the interior change points, s_i ~ B[s_{i-1},:] (.) B^(m-i-1) e_end (:290, :301-304); equal
-  // neighbours merged (:54) and written back in place over the consumed slots, their states beside them
+  // neighbours merged (:54), merged lengths and states written to the scratch slots.  The input lengths and the table
+  // rows do not depend on the states drawn so far, so they are fetched eight steps at a time ahead of the dependent chain.
+  constexpr int CH = 8;
   int w = 0;
   int cur_s = (m == 1) ? cs : ps;                    // updatenodestates :469-472 (m == 1: the child end wins)
   double cur_len = in[0];
-  for (int i = 1; i < m; ++i) {
-    int si;
-    if (i == m - 1) si = cs;
-    else {
+  for (int i0 = 1; i0 < m; i0 += CH) {
+    double dbuf[CH], bbuf[CH][NS];
+#pragma unroll
+    for (int q = 0; q < CH; ++q) {
+      const int i = i0 + q;
+      dbuf[q] = (i < m) ? in[i] : 0.0;
       int kk = m - i - 1;
       if (kk >= p.klong) { err |= DERR_CAPACITY; kk = p.klong - 1; }
-      const double* beta = p.colL + ((size_t)kk * NS + cs) * NS;
-      double pr[NS];
+      const double* beta = p.colL + ((size_t)(kk > 0 ? kk : 0) * NS + cs) * NS;
 #pragma unroll
-      for (int c = 0; c < NS; ++c) pr[c] = p.B2[cur_s * NS + c] * beta[c];
-      si = sample_cat<NS>(pr, su.draw((uint32_t)(i - 1)), err);
+      for (int c = 0; c < NS; ++c) bbuf[q][c] = (i < m - 1) ? beta[c] : 0.0;
     }
-    const double di = in[i];
-    if (KS) s_cnt[(cur_s * NS + si) * NARROW_BLOCK + lane] += 1u;              // shortenerbf :1010-1014
-    if (si == cur_s) cur_len = cur_len + di;
-    else {
-      in[w] = cur_len; ms[w] = (uint8_t)cur_s;
-      if (!KS) s_cnt[(cur_s * (NS - 1) + (si > cur_s ? si - 1 : si)) * NARROW_BLOCK + lane] += 1u;   // shortener :65-66
-      ++w; cur_s = si; cur_len = di;
+#pragma unroll
+    for (int q = 0; q < CH; ++q) {
+      const int i = i0 + q;
+      if (i < m) {
+        int si;
+        if (i == m - 1) si = cs;
+        else {
+          double pr[NS];
+#pragma unroll
+          for (int c = 0; c < NS; ++c) pr[c] = p.B2[cur_s * NS + c] * bbuf[q][c];
+          si = sample_cat<NS>(pr, su.draw((uint32_t)(i - 1)), err);
+        }
+        const double di = dbuf[q];
+        if (KS) s_cnt[(cur_s * NS + si) * NARROW_BLOCK + lane] += 1u;            // shortenerbf :1010-1014
+        if (si == cur_s) cur_len = cur_len + di;
+        else {
+          ml[w] = cur_len; ms[w] = (uint8_t)cur_s;
+          if (!KS) s_cnt[(cur_s * (NS - 1) + (si > cur_s ? si - 1 : si)) * NARROW_BLOCK + lane] += 1u;   // shortener :65-66
+          ++w; cur_s = si; cur_len = di;
+        }
+      }
     }
   }
-  in[w] = cur_len; ms[w] = (uint8_t)cur_s;
+  ml[w] = cur_len; ms[w] = (uint8_t)cur_s;
   const int nmerged = w + 1;
 
   // pass B: virtual jumps, gaps ~ Exp(Omega + q_ss) until each merged segment is used up (:391-410); a segment that is not
@@ -178,7 +195,7 @@ __global__ __launch_bounds__(NARROW_BLOCK) void narrow_branch_kernel(NarrowParam
   bool stuck = false;
   for (int j = 0; j < nmerged; ++j) {
     const int s = ms[j];
-    const double len = in[j];
+    const double len = ml[j];
     double acc = s_dw[s * NARROW_BLOCK + lane];
     if (stuck || !(0.0 < len)) {
       stuck = true;

@@ -200,7 +200,7 @@ def test_mcmc_config2_shape_matches_oracle():
     z, Q, pid, Omega = synth.config_problem(2)
     nen, nodelist, root = _orders(z)
     N, seed = 12, 2024
-    eng = _lib.Engine(z, Q, pid, Omega, N, variant=_lib.PHM_MCMC_BIGTREE, seed=seed, n_replicas=128, storage=1)
+    eng = _lib.Engine(z, Q, pid, Omega, N, variant=_lib.PHM_MCMC_BIGTREE, seed=seed, n_replicas=128, storage=1, mapping="replicas")
     eng.run(N); eng.sync()
     st = eng.stats(0, N)
     for r in (0, 63, 127):
@@ -593,14 +593,15 @@ def test_expm_pade_on_matrix_cores(n):
         np.testing.assert_allclose(P_mfma[b].sum(1), 1.0, atol=1e-12)
 
 
-def test_full_size_invariants():
+@pytest.mark.parametrize("mapping", MAPPINGS)
+def test_full_size_invariants(mapping):
     """BASELINE sizes, size-independent properties: dwell row sums = tree length; counts are integers;
-    a second engine with the same seed reproduces the first bit for bit."""
+    a second engine with the same seed reproduces the first bit for bit (both mappings reduce in a fixed order)."""
     z, Q, pid, Omega = synth.config_problem(2)
     N = 30
     outs = []
     for _ in range(2):
-        eng = _lib.Engine(z, Q, pid, Omega, N, variant=_lib.PHM_MCMC_BIGTREE, seed=7, n_replicas=1024, reduce=True)
+        eng = _lib.Engine(z, Q, pid, Omega, N, variant=_lib.PHM_MCMC_BIGTREE, seed=7, n_replicas=1024, reduce=True, mapping=mapping)
         eng.run(N); eng.sync()
         outs.append(eng.stats(0, N))
         info = eng.info()
@@ -609,6 +610,13 @@ def test_full_size_invariants():
     np.testing.assert_allclose(outs[0][:, :4].sum(1), 1024 * z["edge.length"].sum(), rtol=1e-11)
     assert np.all(outs[0][:, 4:] == np.round(outs[0][:, 4:]))
     assert info.seg_read > 0
+    if mapping == "branches":          # the two mappings sample the same histories: counts equal, dwell sums to rounding
+        eng = _lib.Engine(z, Q, pid, Omega, N, variant=_lib.PHM_MCMC_BIGTREE, seed=7, n_replicas=1024, reduce=True, mapping="replicas")
+        eng.run(N); eng.sync()
+        lanes = eng.stats(0, N)
+        eng.close()
+        np.testing.assert_array_equal(outs[0][:, 4:], lanes[:, 4:])
+        np.testing.assert_allclose(outs[0][:, :4], lanes[:, :4], rtol=1e-10)
 
 
 def test_errors_are_loud():
