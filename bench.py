@@ -193,6 +193,15 @@ def main():
         }
     eng.close()
 
+    if rank == 0 and n <= 4:
+        # the reference's own calling pattern -- ONE chain -- on the same tree: the branch-parallel mapping (phm_narrow.hip)
+        one = _lib.Engine(z, Q, pid, Omega, 104, variant=_lib.PHM_MCMC_BIGTREE, seed=1, n_replicas=1, device=local_rank,
+                          mapping="branches")
+        one.run(4); one.sync()
+        t1 = time.perf_counter(); one.run(100); one.sync(); d1 = time.perf_counter() - t1
+        one.close()
+        out["single_chain"] = {"mapping": "one lane per branch", "ms_per_sweep": d1 / 100 * 1e3, "realisations_per_s": E * 100 / d1}
+
     if rank == 0:
         # secondary metric of BASELINE.json: expm(Q t)/s (batched 4x4 transition matrices, kernel time)
         t = np.random.default_rng(0).exponential(4.0 / Omega, 1 << 20)

@@ -606,7 +606,7 @@ int32_t phm_engine_create_multi(const phm_tree* trees, int32_t n_trees, const ph
   // used when they take less than a third of the free memory, unless the caller asks (reserved[0]: 1 ring, 2 two buffers).
   size_t free_b = 0, total_b = 0;
   HIPCHK(hipMemGetInfo(&free_b, &total_b));
-  e->ring = e->wide || o.reserved[0] == 1 || (o.reserved[0] != 2 && 2 * dw_bytes > free_b / 3);
+  e->ring = e->wide || n_trees > 1 || o.reserved[0] == 1 || (o.reserved[0] != 2 && 2 * dw_bytes > free_b / 3);
   size_t need = (e->ring ? 1 : 2) * dw_bytes + stats_bytes + sizeof(double) * (size_t)e->tiles * s.n_node * n * 64 +
                 (size_t)e->tiles * (s.n_node + 2 * (size_t)E) * 64 + e->tips_host.size();
   if (need + (64u << 20) > free_b) {
@@ -1171,7 +1171,7 @@ extern "C" int32_t phm_engine_reduced_stats_device(phm_engine* e, int32_t iter0,
 // Returns the HIP-event time in milliseconds.  n <= 4 kernels only.
 extern "C" int32_t phm_engine_time_pruning(phm_engine* e, int32_t n_iters, void* hip_stream, double* ms_out) {
   if (!e || !ms_out) return fail(PHM_ERR_STATE, "engine/ms_out is NULL");
-  if (e->wide || e->narrow) return fail(PHM_ERR_UNSUPPORTED, "pruning-only timing is implemented for the replica mapping with n_states <= 4");
+  if (e->wide || e->narrow || e->n_trees > 1) return fail(PHM_ERR_UNSUPPORTED, "pruning-only timing is implemented for the replica mapping with n_states <= 4 and one tree");
   if (n_iters < 1) return fail(PHM_ERR_BAD_INPUT, "n_iters must be >= 1");
   HIPCHK(hipSetDevice(e->device));
   hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);

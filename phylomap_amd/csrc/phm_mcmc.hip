@@ -58,7 +58,9 @@ __device__ __forceinline__ void child_vector(const McmcParams<NS>& p, const doub
 // into n x n counters (shortenerbf :1010-1014), root state recorded (:1350-1352).
 // RING = one ring of C rows per tile holds both dwell streams (half the HBM, two extra VALU ops per access);
 // !RING = two buffers of C rows, swapped every sweep (chosen by the host when HBM is plentiful).
-template <int NS, bool KS, bool RING>
+// MT = a list of trees (phm_engine_create_multi): the tile picks its topology; kept out of the single-tree kernels, whose
+// scalar registers are fully used.
+template <int NS, bool KS, bool RING, bool MT = false>
 __device__ __forceinline__ void sweep_body(const McmcParams<NS>& p, int iter0, int n_iters) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x & 63;
@@ -86,11 +88,11 @@ __device__ __forceinline__ void sweep_body(const McmcParams<NS>& p, int iter0, i
   const int rep_local = tile * 64 + lane;
   const uint32_t rep = (uint32_t)(p.replica_offset + rep_local);
   // list of trees (maketreelistMCMCmt :2267): consecutive groups of tiles walk different topologies with one model
-  const int tree = p.tiles_per_tree ? tile / p.tiles_per_tree : 0;
-  const bool valid = (rep_local - tree * p.tiles_per_tree * 64) < p.n_rep;
-  const UpStep* __restrict__ up = p.up + (size_t)tree * p.n_node;
-  const DownStep* __restrict__ down = p.down + (size_t)tree * p.n_edge;
-  const int root = p.tiles_per_tree ? p.roots[tree] : p.root;
+  const int tree = MT ? tile / p.tiles_per_tree : 0;
+  const bool valid = MT ? (rep_local - tree * p.tiles_per_tree * 64) < p.n_rep : rep_local < p.n_rep;
+  const UpStep* __restrict__ up = MT ? p.up + (size_t)tree * p.n_node : p.up;
+  const DownStep* __restrict__ down = MT ? p.down + (size_t)tree * p.n_edge : p.down;
+  const int root = MT ? p.roots[tree] : p.root;
   uint32_t err = 0;
 
   double* __restrict__ PLt = p.PL + (size_t)tile * p.n_node * NS * 64;
@@ -395,6 +397,12 @@ __global__ __launch_bounds__(MCMC_BLOCK, 5) void mcmc_sweep_kernel(McmcParams<NS
   sweep_body<NS, KS, RING>(p, iter0, n_iters);
 }
 
+// the same sweep over a list of trees (ring storage only)
+template <int NS, bool KS>
+__global__ __launch_bounds__(MCMC_BLOCK, 5) void mcmc_sweep_trees_kernel(McmcParams<NS> p, int iter0, int n_iters) {
+  sweep_body<NS, KS, true, true>(p, iter0, n_iters);
+}
+
 // The pruning (up) sweep alone, under its own name so that profiles separate it from the full sweep (p.prune_only = 1).
 template <int NS, bool KS, bool RING>
 __global__ __launch_bounds__(MCMC_BLOCK, 5) void mcmc_pruning_kernel(McmcParams<NS> p, int iter0, int n_iters) {
@@ -445,6 +453,12 @@ hipError_t launch_mcmc(const McmcParams<NS>& p, int iter0, int n_iters, hipStrea
   dim3 grid((p.n_tiles + waves_per_block - 1) / waves_per_block);
   size_t lds = mcmc_lds_bytes<NS>(p.ktab, p.ks != 0);
   const bool ring = p.dwell1 == nullptr;
+  if (p.tiles_per_tree) {
+    if (!ring || p.prune_only) return hipErrorInvalidValue;
+    if (p.ks) hipLaunchKernelGGL((mcmc_sweep_trees_kernel<NS, true>), grid, dim3(MCMC_BLOCK), lds, stream, p, iter0, n_iters);
+    else hipLaunchKernelGGL((mcmc_sweep_trees_kernel<NS, false>), grid, dim3(MCMC_BLOCK), lds, stream, p, iter0, n_iters);
+    return hipGetLastError();
+  }
   if (p.prune_only) {
     if (p.ks && ring) hipLaunchKernelGGL((mcmc_pruning_kernel<NS, true, true>), grid, dim3(MCMC_BLOCK), lds, stream, p, iter0, n_iters);
     else if (p.ks) hipLaunchKernelGGL((mcmc_pruning_kernel<NS, true, false>), grid, dim3(MCMC_BLOCK), lds, stream, p, iter0, n_iters);
