@@ -183,13 +183,14 @@ def tree_orders(z):
     return nen, nodelist[: int(z["Nnode"]) - 1], int(root.value)
 
 
-MAPPING = {"auto": 0, "replicas": 1, "branches": 2}
+MAPPING = {"auto": 0, "replicas": 1, "branches": 2, "tiles": 3}
 
 
 def make_options(seed=0, n_replicas=1, replica_offset=0, reduce=False, tips_per_replica=False, device=-1,
                  iters_per_launch=0, cap_tail=0.0, storage=0, mapping="auto"):
     """``mapping``: how a sweep is laid over the lanes -- "replicas" (one lane per chain: the throughput layout for many
-    replicas), "branches" (one lane per branch: few chains on a large tree, n <= 4) or "auto" (branches up to 16 chains)."""
+    replicas), "branches" (one lane per branch: few chains on a large tree, n <= 4), "tiles" (one wave per tile of 64 replicas and
+    branch: 10^2 .. 10^5 replicas, n <= 4) or "auto"."""
     o = Options()
     o.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
     o.n_replicas, o.replica_offset, o.reduce = int(n_replicas), int(replica_offset), int(bool(reduce))

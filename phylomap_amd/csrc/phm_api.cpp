@@ -21,6 +21,7 @@
 #include "phm_qupdate.h"
 #include "phm_sched.h"
 #include "phm_narrow.h"
+#include "phm_tiles.h"
 #include "phm_wide.h"
 
 namespace {
@@ -104,6 +105,13 @@ struct phm_engine {
   phm::NarrowParams<2> n2;
   phm::NarrowParams<3> n3;
   phm::NarrowParams<4> n4;
+  // wave per (tile, branch) mapping for 10^2 .. 10^5 replicas (phm_tiles.hip); shares the level schedules and long tables
+  bool tiled = false;
+  std::vector<int32_t> tl_slot;                    // first row of every branch slot
+  DevBuf d_tl_slot, d_tl_pdw, d_tl_pchunk, d_tl_cnt, d_tl_estate;
+  phm::TileParams<2> t2;
+  phm::TileParams<3> t3;
+  phm::TileParams<4> t4;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipStream_t last_stream = nullptr;
   bool timing_pending = false;
@@ -119,10 +127,15 @@ struct phm_engine {
 
 namespace {
 
-// Automatic choice of the branch-parallel mapping: up to this many chains.  Measured on C2 (profiles/r01_probe_mapping.log):
-// one lane per branch takes 0.29 ms per sweep for one chain (one lane per replica: 22 ms) and is still 3x ahead at 4096
-// chains; the replica mapping only pays off once tens of thousands of replicas fill its 64-lane tiles.
-constexpr int NARROW_AUTO_MAX_REPLICAS = 8192;
+// Automatic choice of the mapping (measured on C2, profiles/r01_probe_mapping.log; ms per sweep):
+//   chains          1     64    256    1024   4096   16384   65536   327680
+//   lane=branch   0.29   0.41   0.87    2.5    9.4
+//   wave=tile x branch   0.31   0.40    0.75   2.1     7.4    28.7
+//   lane=replica  23.0          24.3   28.4   30.0    29.6    30.8     58.5
+// one lane per branch for a handful of chains, one wave per (tile, branch) up to ~5e4 replicas, beyond that the replica
+// mapping (its single wave per tile needs tens of thousands of replicas to fill the chip but then streams at 2.5x the rate).
+constexpr int NARROW_AUTO_MAX_REPLICAS = 47;
+constexpr int TILES_AUTO_MAX_REPLICAS = 49152;
 
 bool ks_layout(int v) { return v == PHM_MCMC_KS || v == PHM_MCMC_BF || v == PHM_MCMC_MT || v == PHM_MCMC_KSMT; }   // n x n counts, root column
 bool hidden_rates(int v) { return v == PHM_MCMC_KS || v == PHM_MCMC_KSMT; }                                         // parity tip masks
@@ -225,7 +238,7 @@ int32_t compute_model(int variant, int n, const double* Q, const double* B, doub
 // chain tables for the current model -> device; refresh the by-value kernel parameter blocks
 int32_t upload_model(phm_engine* e) {
   const int n = e->n;
-  const int ktab = e->narrow ? e->nw_klong : e->wide ? phm::WIDE_KTAB : phm::MCMC_KTAB;
+  const int ktab = (e->narrow || e->tiled) ? e->nw_klong : e->wide ? phm::WIDE_KTAB : phm::MCMC_KTAB;
   const double* Bc = e->hBc.data();
   std::vector<double> col, row;
   build_chain_tables(Bc, n, ktab, col, row);
@@ -242,7 +255,7 @@ int32_t upload_model(phm_engine* e) {
       }
     }
   }
-  if (e->narrow) {      // tables long enough for every possible segment count, read from global memory / L2
+  if (e->narrow || e->tiled) {      // tables long enough for every possible segment count, read from global memory / L2
     HIPCHK(hipMemcpy(e->d_nw_colL.p, col.data(), sizeof(double) * col.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(e->d_nw_rowL.p, row.data(), sizeof(double) * row.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(e->d_nw_maskL.p, maskpow.data(), sizeof(double) * maskpow.size(), hipMemcpyHostToDevice));
@@ -250,9 +263,8 @@ int32_t upload_model(phm_engine* e) {
       for (int i = 0; i < n * n; ++i) { p.B2[i] = e->hB2[i]; p.Bc[i] = e->hBc[i]; }
       for (int i = 0; i < n; ++i) p.scale[i] = e->hscale[i];
     };
-    if (n == 2) refresh_n(e->n2);
-    if (n == 3) refresh_n(e->n3);
-    if (n == 4) refresh_n(e->n4);
+    if (e->narrow) { if (n == 2) refresh_n(e->n2); if (n == 3) refresh_n(e->n3); if (n == 4) refresh_n(e->n4); }
+    else { if (n == 2) refresh_n(e->t2); if (n == 3) refresh_n(e->t3); if (n == 4) refresh_n(e->t4); }
     return PHM_OK;
   }
   HIPCHK(hipMemcpy(e->d_col.p, col.data(), sizeof(double) * col.size(), hipMemcpyHostToDevice));
@@ -298,10 +310,11 @@ void fill_narrow_params(phm_engine* e, phm::NarrowParams<NS>& p, const phm_optio
   p.err = e->d_err.as<uint32_t>(); p.segcnt = e->d_seg.as<unsigned long long>();
 }
 
-int32_t narrow_setup(phm_engine* e, const phm_tree* x, const phm_model* model, const phm_options& o, int32_t max_iters) {
+// Level schedules shared by the branch-parallel mappings: positions of up[] grouped by HEIGHT (children strictly below their
+// parent) and of down[] grouped by DEPTH; uploads the two order arrays, leaves the level boundaries in the engine.
+int32_t build_level_orders(phm_engine* e) {
   const phm::Schedule& s = e->sched;
-  const int E = s.n_edge, T = s.n_tips, Nn = s.n_node, n = e->n, S = e->S;
-  // height levels of the pruning sweep (children strictly below their parent), depth levels of the sampling sweep
+  const int E = s.n_edge, Nn = s.n_node;
   std::vector<int32_t> height(Nn, 0), depth(Nn, 0);
   int max_h = 0, max_d = 0;
   for (int k = 0; k < Nn; ++k) {
@@ -328,6 +341,15 @@ int32_t narrow_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
     for (int k = 0; k < Nn; ++k) up_order[pu[height[s.up[k].parent]]++] = k;
     for (int k = 0; k < E; ++k) down_order[pd[edepth[k]]++] = k;
   }
+  HIPCHK(e->d_nw_up_order.alloc(sizeof(int32_t) * Nn)); HIPCHK(e->d_nw_down_order.alloc(sizeof(int32_t) * E));
+  HIPCHK(hipMemcpy(e->d_nw_up_order.p, up_order.data(), e->d_nw_up_order.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(e->d_nw_down_order.p, down_order.data(), e->d_nw_down_order.bytes, hipMemcpyHostToDevice));
+  return PHM_OK;
+}
+
+int32_t narrow_setup(phm_engine* e, const phm_tree* x, const phm_model* model, const phm_options& o, int32_t max_iters) {
+  const phm::Schedule& s = e->sched;
+  const int E = s.n_edge, T = s.n_tips, Nn = s.n_node, n = e->n, S = e->S;
   // One slot per branch: 1 + Poisson(Omega t_b) segments in stationarity, provisioned far into the tail because a slot
   // has no neighbour to borrow from (default 1e-12 per branch and sweep); longer caller-supplied paths get m0 on top.
   const double tail = o.cap_tail > 0.0 ? o.cap_tail : 1e-12;
@@ -372,7 +394,7 @@ int32_t narrow_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
     return fail(PHM_ERR_OOM, buf);
   }
   HIPCHK(e->d_up.alloc(sizeof(phm::UpStep) * Nn)); HIPCHK(e->d_down.alloc(sizeof(phm::DownStep) * E));
-  HIPCHK(e->d_nw_up_order.alloc(sizeof(int32_t) * Nn)); HIPCHK(e->d_nw_down_order.alloc(sizeof(int32_t) * E));
+  { int32_t lst = build_level_orders(e); if (lst) return lst; }
   HIPCHK(e->d_nw_border.alloc(sizeof(int32_t) * E)); HIPCHK(e->d_nw_off.alloc(sizeof(int64_t) * (E + 1)));
   HIPCHK(e->d_nw_colL.alloc(sizeof(double) * tab)); HIPCHK(e->d_nw_rowL.alloc(sizeof(double) * tab));
   HIPCHK(e->d_nw_maskL.alloc(sizeof(double) * (size_t)e->nw_klong * 2 * n));
@@ -393,8 +415,6 @@ int32_t narrow_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
                        sizeof(double) * 3 * tab + e->d_nw_mcount.bytes);
   HIPCHK(hipMemcpy(e->d_up.p, s.up.data(), e->d_up.bytes, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(e->d_down.p, s.down.data(), e->d_down.bytes, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(e->d_nw_up_order.p, up_order.data(), e->d_nw_up_order.bytes, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(e->d_nw_down_order.p, down_order.data(), e->d_nw_down_order.bytes, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(e->d_nw_border.p, border.data(), e->d_nw_border.bytes, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(e->d_nw_off.p, e->nw_off.data(), e->d_nw_off.bytes, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(e->d_tips.p, e->tips_host.data(), e->tips_host.size(), hipMemcpyHostToDevice));
@@ -417,6 +437,129 @@ int32_t narrow_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
   if (n == 2) fill_narrow_params<2>(e, e->n2, o);
   if (n == 3) fill_narrow_params<3>(e, e->n3, o);
   if (n == 4) fill_narrow_params<4>(e, e->n4, o);
+  return PHM_OK;
+}
+
+// Engine state of the wave-per-(tile, branch) mapping (phm_tiles.hip).
+template <int NS>
+void fill_tile_params(phm_engine* e, phm::TileParams<NS>& p, const phm_options& o) {
+  const phm::Schedule& s = e->sched;
+  p.n_tips = s.n_tips; p.n_node = s.n_node; p.n_edge = s.n_edge; p.root = s.root;
+  p.n_tiles = e->tiles; p.n_rep = e->S; p.n_rep_pad = e->S_pad; p.replica_offset = o.replica_offset;
+  p.normalise = normalised(e->variant); p.tips_per_replica = e->tips_per_replica ? 1 : 0;
+  p.ks = ks_layout(e->variant); p.tip_masks = hidden_rates(e->variant); p.reduce = e->reduce; p.n_cols = e->dcols;
+  p.klong = e->nw_klong; p.n_chunks = (s.n_edge + phm::TILES_CHUNK - 1) / phm::TILES_CHUNK;
+  p.seed_lo = (uint32_t)(o.seed & 0xFFFFFFFFull); p.seed_hi = (uint32_t)(o.seed >> 32);
+  p.rows = e->nw_total_cap;
+  for (int i = 0; i < NS * NS; ++i) { p.B2[i] = e->hB2[i]; p.Bc[i] = e->hBc[i]; }
+  for (int i = 0; i < NS; ++i) { p.scale[i] = e->hscale[i]; p.pid[i] = e->hpid[i]; }
+  p.up = e->d_up.as<phm::UpStep>(); p.down = e->d_down.as<phm::DownStep>();
+  p.up_order = e->d_nw_up_order.as<int32_t>(); p.down_order = e->d_nw_down_order.as<int32_t>();
+  p.branch_order = e->d_nw_border.as<int32_t>(); p.slot = e->d_tl_slot.as<int32_t>();
+  p.colL = e->d_nw_colL.as<double>(); p.rowL = e->d_nw_rowL.as<double>(); p.maskL = e->d_nw_maskL.as<double>();
+  p.tips = e->d_tips.as<uint8_t>(); p.mcount = e->d_mcount.as<uint16_t>();
+  p.dw[0] = e->d_dw0.as<double>(); p.dw[1] = e->d_dw1.as<double>();
+  p.estate = e->d_tl_estate.as<uint8_t>(); p.PL = e->d_PL.as<double>(); p.nstate = e->d_nstate.as<uint8_t>();
+  p.pdw = e->d_tl_pdw.as<double>(); p.pchunk = e->d_tl_pchunk.as<double>(); p.cnt = e->d_tl_cnt.as<uint32_t>();
+  p.stats = e->d_stats.as<double>(); p.err = e->d_err.as<uint32_t>(); p.segcnt = e->d_seg.as<unsigned long long>();
+}
+
+int32_t tiles_setup(phm_engine* e, const phm_tree* x, const phm_model* model, const phm_options& o, int32_t max_iters) {
+  const phm::Schedule& s = e->sched;
+  const int E = s.n_edge, T = s.n_tips, Nn = s.n_node, n = e->n, tiles = e->tiles;
+  // One slot of rows per branch; a row holds the 64 replicas of the tile, so the slot must take the LARGEST of 64 segment
+  // counts: provisioned at 1e-12 per replica, branch and sweep (1 + Poisson(Omega t_b), plus the caller's initial length).
+  const double tail = o.cap_tail > 0.0 ? o.cap_tail : 1e-12;
+  e->tl_slot.assign(E + 1, 0);
+  std::vector<int32_t> cap(E);
+  int max_cap = 0;
+  int64_t rows = 0;
+  for (int b = 0; b < E; ++b) {
+    double tb = 0.0;
+    for (int i = x->map_off[b]; i < x->map_off[b + 1]; ++i) tb += x->maps[i];
+    const int m0 = x->map_off[b + 1] - x->map_off[b];
+    const int q = phm::poisson_capacity(model->Omega * tb, tail);
+    cap[b] = std::max(q, m0 + q - 1) + 2;
+    max_cap = std::max(max_cap, cap[b]);
+    rows += cap[b];
+    if (rows > 0x7fffff00ll / 64) return fail(PHM_ERR_UNSUPPORTED, "tree too large: dwell rows per replica tile exceed 32-bit indexing");
+    e->tl_slot[b + 1] = (int32_t)rows;
+  }
+  e->nw_total_cap = rows;
+  e->nw_klong = max_cap + 1;
+  e->rows = rows;
+  std::vector<int32_t> border(E);
+  for (int b = 0; b < E; ++b) border[b] = b;
+  std::stable_sort(border.begin(), border.end(), [&](int a, int b) { return cap[a] > cap[b]; });
+
+  if (e->tips_per_replica) {
+    e->tips_host.assign((size_t)tiles * T * 64, 0);
+    for (int r = 0; r < e->S_pad; ++r) {
+      const int src = r < e->S ? r : e->S - 1;
+      for (int t = 0; t < T; ++t) e->tips_host[((size_t)(r / 64) * T + t) * 64 + (r % 64)] = (uint8_t)(x->states[(size_t)src * T + t] - 1);
+    }
+  } else {
+    e->tips_host.resize(T);
+    for (int t = 0; t < T; ++t) e->tips_host[t] = (uint8_t)(x->states[t] - 1);
+  }
+
+  const int n_chunks = (E + phm::TILES_CHUNK - 1) / phm::TILES_CHUNK;
+  const size_t stats_bytes = e->reduce ? sizeof(double) * (size_t)max_iters * tiles * e->dcols
+                                       : sizeof(double) * (size_t)max_iters * e->dcols * e->S_pad;
+  const size_t dw_bytes = sizeof(double) * (size_t)tiles * rows * 64;
+  const size_t tab = (size_t)e->nw_klong * n * n;
+  const size_t pdw_bytes = sizeof(double) * (size_t)tiles * E * n * 64;
+  const size_t pl_bytes = sizeof(double) * (size_t)tiles * Nn * n * 64;
+  size_t free_b = 0, total_b = 0;
+  HIPCHK(hipMemGetInfo(&free_b, &total_b));
+  const size_t need = 2 * dw_bytes + pdw_bytes + pl_bytes + stats_bytes + sizeof(double) * 3 * tab + (size_t)tiles * (4 * (size_t)E + Nn) * 64;
+  if (need + (64u << 20) > free_b) {
+    char buf[256];
+    std::snprintf(buf, sizeof buf, "engine needs %.2f GiB of HBM, %.2f GiB free (reduce n_replicas or max_iters)", need / 1073741824.0, free_b / 1073741824.0);
+    return fail(PHM_ERR_OOM, buf);
+  }
+  HIPCHK(e->d_up.alloc(sizeof(phm::UpStep) * Nn)); HIPCHK(e->d_down.alloc(sizeof(phm::DownStep) * E));
+  { int32_t lst = build_level_orders(e); if (lst) return lst; }
+  HIPCHK(e->d_nw_border.alloc(sizeof(int32_t) * E)); HIPCHK(e->d_tl_slot.alloc(sizeof(int32_t) * (E + 1)));
+  HIPCHK(e->d_nw_colL.alloc(sizeof(double) * tab)); HIPCHK(e->d_nw_rowL.alloc(sizeof(double) * tab));
+  HIPCHK(e->d_nw_maskL.alloc(sizeof(double) * (size_t)e->nw_klong * 2 * n));
+  HIPCHK(e->d_tips.alloc(e->tips_host.size()));
+  HIPCHK(e->d_mcount.alloc(sizeof(uint16_t) * (size_t)tiles * E * 64));
+  HIPCHK(e->d_dw0.alloc(dw_bytes)); HIPCHK(e->d_dw1.alloc(dw_bytes));
+  HIPCHK(e->d_tl_estate.alloc((size_t)tiles * E * 64));
+  HIPCHK(e->d_PL.alloc(pl_bytes));
+  HIPCHK(e->d_nstate.alloc((size_t)tiles * Nn * 64));
+  HIPCHK(e->d_tl_pdw.alloc(pdw_bytes));
+  HIPCHK(e->d_tl_pchunk.alloc(sizeof(double) * (size_t)tiles * n_chunks * n * 64));
+  HIPCHK(e->d_tl_cnt.alloc(sizeof(uint32_t) * (size_t)tiles * n * n * 64));
+  HIPCHK(e->d_stats.alloc(stats_bytes));
+  HIPCHK(e->d_err.alloc(sizeof(uint32_t))); HIPCHK(e->d_seg.alloc(sizeof(unsigned long long)));
+  if (e->reduce) HIPCHK(e->d_red.alloc(sizeof(double) * (size_t)max_iters * e->dcols));
+  e->bytes = (int64_t)(2 * dw_bytes + pdw_bytes + pl_bytes + e->d_stats.bytes + e->d_red.bytes + e->d_mcount.bytes + e->d_tl_pchunk.bytes +
+                       sizeof(double) * 3 * tab);
+  HIPCHK(hipMemcpy(e->d_up.p, s.up.data(), e->d_up.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(e->d_down.p, s.down.data(), e->d_down.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(e->d_nw_border.p, border.data(), e->d_nw_border.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(e->d_tl_slot.p, e->tl_slot.data(), e->d_tl_slot.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(e->d_tips.p, e->tips_host.data(), e->tips_host.size(), hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(e->d_err.p, 0, sizeof(uint32_t)));
+  HIPCHK(hipMemset(e->d_seg.p, 0, sizeof(unsigned long long)));
+  HIPCHK(hipMemset(e->d_stats.p, 0, stats_bytes));
+  HIPCHK(hipMemset(e->d_nstate.p, 0, e->d_nstate.bytes));
+  HIPCHK(hipMemset(e->d_tl_cnt.p, 0, e->d_tl_cnt.bytes));
+  {   // initial paths -> every replica (makeabranch, src/phylomap.cpp:24-34, :901)
+    DevBuf d_off, d_maps;
+    HIPCHK(d_off.alloc(sizeof(int32_t) * (E + 1)));
+    HIPCHK(d_maps.alloc(sizeof(double) * (size_t)x->map_off[E]));
+    HIPCHK(hipMemcpy(d_off.p, x->map_off, d_off.bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_maps.p, x->maps, d_maps.bytes, hipMemcpyHostToDevice));
+    HIPCHK(phm::launch_tiles_init(E, tiles, rows, e->d_tl_slot.as<int32_t>(), d_off.as<int32_t>(), d_maps.as<double>(),
+                                  e->d_dw0.as<double>(), e->d_mcount.as<uint16_t>(), nullptr));
+    HIPCHK(hipDeviceSynchronize());
+  }
+  if (n == 2) fill_tile_params<2>(e, e->t2, o);
+  if (n == 3) fill_tile_params<3>(e, e->t3, o);
+  if (n == 4) fill_tile_params<4>(e, e->t4, o);
   return PHM_OK;
 }
 
@@ -526,14 +669,20 @@ int32_t phm_engine_create_multi(const phm_tree* trees, int32_t n_trees, const ph
 
   // Mapping of the sweep onto lanes (reserved[1]: 0 automatic, 1 one lane per replica, 2 one lane per branch): with few
   // chains the replica mapping would leave all but a handful of lanes idle and walk the tree sequentially.
-  e->narrow = !e->wide && n_trees == 1 && (o.reserved[1] == 2 || (o.reserved[1] == 0 && e->S <= NARROW_AUTO_MAX_REPLICAS));
-  if (e->narrow && o.reserved[1] == 0 && o.reserved[0] != 0) e->narrow = false;     // a ring / two-buffer request names the replica layout
-  if (o.reserved[1] == 2 && !e->narrow) return fail(PHM_ERR_UNSUPPORTED, "the branch-parallel mapping covers n_states <= 4 and a single tree");
+  const bool small_n = !e->wide && n_trees == 1;
+  const bool auto_map = o.reserved[1] == 0 && o.reserved[0] == 0;      // a ring / two-buffer request names the replica layout
+  if ((o.reserved[1] == 2 || o.reserved[1] == 3) && !small_n) return fail(PHM_ERR_UNSUPPORTED, "the branch-parallel mappings cover n_states <= 4 and a single tree");
+  e->narrow = small_n && (o.reserved[1] == 2 || (auto_map && e->S <= NARROW_AUTO_MAX_REPLICAS));
+  e->tiled = small_n && !e->narrow && (o.reserved[1] == 3 || (auto_map && e->S <= TILES_AUTO_MAX_REPLICAS));
   if (e->narrow) {
     st = narrow_setup(e, x, model, o, max_iters);
-    if (st == PHM_ERR_OOM && o.reserved[1] == 0) { e->narrow = false; st = PHM_OK; }     // automatic choice: try the replica layout
+    if (st == PHM_ERR_OOM && auto_map) { e->narrow = false; e->tiled = true; st = PHM_OK; }
   }
-  if (e->narrow) {
+  if (e->tiled) {
+    st = tiles_setup(e, x, model, o, max_iters);
+    if (st == PHM_ERR_OOM && auto_map) { e->tiled = false; st = PHM_OK; }     // automatic choice: fall back to the replica layout
+  }
+  if (e->narrow || e->tiled) {
     if (st) return st;
     st = upload_model(e);
     if (st) return st;
@@ -720,7 +869,18 @@ int32_t phm_engine_run(phm_engine* e, int32_t n_iters, void* hip_stream) {
     }
     HIPCHK(le);
   }
-  for (int done = 0; done < n_iters && !e->narrow;) {
+  if (e->tiled) {
+    hipError_t le = hipSuccess;
+    for (int i = 0; i < n_iters && le == hipSuccess; ++i) {
+      const int it = e->iters_done + i;
+      if (e->n == 2) le = phm::launch_tiles_sweep<2>(e->t2, e->nw_up_off, e->nw_down_off, it, stream);
+      if (e->n == 3) le = phm::launch_tiles_sweep<3>(e->t3, e->nw_up_off, e->nw_down_off, it, stream);
+      if (e->n == 4) le = phm::launch_tiles_sweep<4>(e->t4, e->nw_up_off, e->nw_down_off, it, stream);
+      launches += (int)(e->nw_up_off.size() + e->nw_down_off.size()) + 2;
+    }
+    HIPCHK(le);
+  }
+  for (int done = 0; done < n_iters && !e->narrow && !e->tiled;) {
     int chunk = std::min(e->ipl, n_iters - done);
     hipError_t le = hipSuccess;
     if (e->n == 2) le = phm::launch_mcmc<2>(e->p2, e->iters_done + done, chunk, stream);
@@ -836,7 +996,14 @@ int32_t phm_engine_dump(phm_engine* e, int32_t replica, int32_t* seg_count, doub
   std::vector<uint16_t> mc((size_t)E * 64);
   HIPCHK(hipMemcpy(mc.data(), e->d_mcount.as<uint16_t>() + (size_t)tile * E * 64, sizeof(uint16_t) * mc.size(), hipMemcpyDeviceToHost));
   if (seg_count) for (int b = 0; b < E; ++b) seg_count[b] = mc[(size_t)b * 64 + lane];
-  if (seg_dwell) {
+  if (seg_dwell && e->tiled) {      // slots of the buffer the next sweep will read
+    std::vector<double> dw((size_t)e->rows * 64);
+    const double* src = ((e->iters_done & 1) ? e->d_dw1.as<double>() : e->d_dw0.as<double>()) + (size_t)tile * e->rows * 64;
+    HIPCHK(hipMemcpy(dw.data(), src, sizeof(double) * dw.size(), hipMemcpyDeviceToHost));
+    for (int b = 0; b < E; ++b)
+      for (int i = 0; i < std::min<int>(mc[(size_t)b * 64 + lane], seg_cap); ++i)
+        seg_dwell[(size_t)b * seg_cap + i] = dw[((size_t)e->tl_slot[b] + i) * 64 + lane];
+  } else if (seg_dwell) {
     std::vector<double> dw((size_t)e->rows * 64);
     int32_t cur[2];
     HIPCHK(hipMemcpy(cur, e->d_cursor.as<int32_t>() + 2 * tile, sizeof cur, hipMemcpyDeviceToHost));
@@ -1171,7 +1338,7 @@ extern "C" int32_t phm_engine_reduced_stats_device(phm_engine* e, int32_t iter0,
 // Returns the HIP-event time in milliseconds.  n <= 4 kernels only.
 extern "C" int32_t phm_engine_time_pruning(phm_engine* e, int32_t n_iters, void* hip_stream, double* ms_out) {
   if (!e || !ms_out) return fail(PHM_ERR_STATE, "engine/ms_out is NULL");
-  if (e->wide || e->narrow || e->n_trees > 1) return fail(PHM_ERR_UNSUPPORTED, "pruning-only timing is implemented for the replica mapping with n_states <= 4 and one tree");
+  if (e->wide || e->narrow || e->tiled || e->n_trees > 1) return fail(PHM_ERR_UNSUPPORTED, "pruning-only timing is implemented for the replica mapping with n_states <= 4 and one tree");
   if (n_iters < 1) return fail(PHM_ERR_BAD_INPUT, "n_iters must be >= 1");
   HIPCHK(hipSetDevice(e->device));
   hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);

@@ -1,0 +1,74 @@
+// phm_tiles.h -- the MCMC sweep for a MODERATE number of replicas (n <= 4): one wavefront per (tile of 64 replicas, branch).
+//
+// The replica mapping of phm_mcmc.hip gives every tile of 64 replicas ONE wave that walks the whole tree, so it needs
+// tens of thousands of replicas to fill the 1 024 SIMDs of an MI355X; an alignment of 10^3 - 10^4 sites leaves it mostly
+// idle (measured on C2 at 4 096 replicas: 30 ms per sweep, 0.27 G realisations/s).  Here the lanes are still replicas --
+// every access stays a contiguous 512-byte row, the 64 lanes of a wave still run the same control flow on the same branch
+// -- but the branches of a tile are spread over different waves: given the node states they are conditionally independent
+// and the random numbers are addressed by (replica, iteration, node | branch), so the results do not depend on the order.
+//   up     : one launch per HEIGHT level, a wave per (tile, internal node)          makePLrcpp* :503-529
+//   root   : a wave per tile                                                       :618-627
+//   down   : one launch per DEPTH level, a wave per (tile, edge)                   :640-657, :460-475
+//   branch : a wave per (tile, branch)                                             :264-413, :44-73, :745-757
+//   stats  : fixed-order reduction of the per-branch dwell sums (two stages), integer counters
+// Layout per tile: every branch owns a slot of cap_b rows (64 lanes each) in each of two dwell buffers swapped per sweep;
+// chain powers come from the long tables (see phm_narrow.h).  Counts are bit-identical to the oracle, dwell sums are added
+// per branch and then reduced in a fixed order (<= 1e-10 relative, identical from run to run).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "phm_device.h"
+#include "phm_sched.h"
+
+namespace phm {
+
+constexpr int TILES_BLOCK = 256;          // four waves = four (tile, item) pairs per workgroup
+constexpr int TILES_CHUNK = 64;           // branches per first-stage partial sum of the dwell reduction
+constexpr int TILES_KTAB = 32;            // chain-table rows staged in LDS by the branch kernel
+
+template <int NS>
+struct TileParams {
+  int32_t n_tips, n_node, n_edge, root;      // root: internal index
+  int32_t n_tiles, n_rep, n_rep_pad, replica_offset;
+  int32_t normalise, tips_per_replica, ks, tip_masks, reduce, n_cols;
+  int32_t klong;                             // rows of the long chain tables
+  int32_t n_chunks;                          // ceil(n_edge / TILES_CHUNK)
+  uint32_t seed_lo, seed_hi;
+  int64_t rows;                              // rows of one tile in one dwell buffer (sum of the slot sizes)
+  double B2[NS * NS], Bc[NS * NS], scale[NS], pid[NS];
+  const UpStep* up;
+  const DownStep* down;
+  const int32_t* up_order;                   // positions into up[], grouped by height level
+  const int32_t* down_order;                 // positions into down[], grouped by depth level
+  const int32_t* branch_order;               // edge rows, largest slot first
+  const int32_t* slot;                       // [n_edge + 1] first row of every branch slot
+  const double* colL;                        // [klong][NS][NS]
+  const double* rowL;                        // [klong][NS][NS]
+  const double* maskL;                       // [klong][2][NS]
+  const uint8_t* tips;                       // [n_tips] or [tile][n_tips][64]
+  uint16_t* mcount;                          // [tile][n_edge][64]
+  double* dw[2];                             // [tile][rows][64]; sweep `it` reads dw[it & 1], writes the other
+  uint8_t* estate;                           // [tile][n_edge][64]: parent-side state | child-side state << 4
+  double* PL;                                // [tile][n_node][NS][64]
+  uint8_t* nstate;                           // [tile][n_node][64]
+  double* pdw;                               // [tile][n_edge][NS][64] dwell sums of every branch
+  double* pchunk;                            // [tile][n_chunks][NS][64] first-stage sums
+  uint32_t* cnt;                             // [tile][NS*NS][64] transition counters of the sweep (integer atomics)
+  double* stats;                             // engine layout: reduce ? [iter][tile][cols] : [iter][cols][n_rep_pad]
+  uint32_t* err;
+  unsigned long long* segcnt;
+};
+
+// initial paths -> slot rows of buffer 0 and the segment counts, every lane of every tile
+hipError_t launch_tiles_init(int n_edge, int n_tiles, int64_t rows, const int32_t* slot, const int32_t* map_off,
+                             const double* maps, double* dw0, uint16_t* mcount, hipStream_t stream);
+
+template <int NS>
+hipError_t launch_tiles_sweep(const TileParams<NS>& p, const std::vector<int32_t>& up_off,
+                              const std::vector<int32_t>& down_off, int it, hipStream_t stream);
+
+}  // namespace phm

@@ -1,0 +1,421 @@
+// phm_tiles.hip -- one wavefront per (tile of 64 replicas, branch): the sweep for 10^2 .. 10^5 replicas (see phm_tiles.h).
+// The per-branch code is the two-flat-pass scheme of phm_mcmc.hip (same arithmetic, same draws), with the branch's rows
+// taken from its own slot instead of the tile's sequential stream and the chain powers read from the long tables.
+#include "phm_tiles.h"
+
+namespace phm {
+
+namespace {
+
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { int o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
+  return __builtin_amdgcn_readfirstlane(v);
+}
+
+// B^k applied to a child's partial-likelihood vector (mmmmvFORpl, src/phylomap.cpp:446-450)
+template <int NS>
+__device__ __forceinline__ void child_vec(const TileParams<NS>& p, const double* __restrict__ PLt,
+                                          const uint8_t* __restrict__ tips_t, int child, int k, int lane, double (&v)[NS],
+                                          uint32_t& err) {
+  if (child < 0) {
+    const int tip = ~child;
+    const int st = p.tips_per_replica ? tips_t[tip * 64 + lane] : p.tips[tip];
+    if (k >= p.klong) { err |= DERR_CAPACITY; k = p.klong - 1; }
+    const double* src = (p.ks && p.tip_masks) ? p.maskL + ((size_t)k * 2 + (st & 1)) * NS : p.colL + ((size_t)k * NS + st) * NS;
+#pragma unroll
+    for (int c = 0; c < NS; ++c) v[c] = src[c];
+  } else {
+#pragma unroll
+    for (int c = 0; c < NS; ++c) v[c] = PLt[(child * NS + c) * 64 + lane];
+    for (int i = 0; i < k; ++i) matvec_u<NS>(p.Bc, v);
+  }
+}
+
+template <int NS>
+__global__ __launch_bounds__(TILES_BLOCK) void tiles_up_kernel(TileParams<NS> p, int begin, int end) {
+  const int lane = threadIdx.x & 63;
+  const int item = blockIdx.x * (TILES_BLOCK / 64) + (threadIdx.x >> 6);
+  const int n_lvl = end - begin;
+  if (item >= n_lvl * p.n_tiles) return;
+  const int tile = item / n_lvl;
+  const UpStep st = p.up[p.up_order[begin + item % n_lvl]];
+  double* __restrict__ PLt = p.PL + (size_t)tile * p.n_node * NS * 64;
+  const uint16_t* __restrict__ mct = p.mcount + (size_t)tile * p.n_edge * 64;
+  const uint8_t* __restrict__ tips_t = p.tips_per_replica ? p.tips + (size_t)tile * p.n_tips * 64 : p.tips;
+  uint32_t err = 0;
+  double x[NS], y[NS];
+  child_vec<NS>(p, PLt, tips_t, st.child[1], (int)mct[st.edge[1] * 64 + lane] - 1, lane, x, err);   // "first"  (:508)
+  child_vec<NS>(p, PLt, tips_t, st.child[0], (int)mct[st.edge[0] * 64 + lane] - 1, lane, y, err);   // "second" (:509)
+#pragma unroll
+  for (int c = 0; c < NS; ++c) x[c] = x[c] * y[c];                             // :510
+  if (p.normalise) {                                                           // :525
+    double s = x[0];
+#pragma unroll
+    for (int c = 1; c < NS; ++c) s += x[c];
+#pragma unroll
+    for (int c = 0; c < NS; ++c) x[c] = x[c] / s;
+  }
+#pragma unroll
+  for (int c = 0; c < NS; ++c) PLt[(st.parent * NS + c) * 64 + lane] = x[c];
+  if (err) atomicOr(p.err, err);
+}
+
+template <int NS>
+__global__ __launch_bounds__(TILES_BLOCK) void tiles_root_kernel(TileParams<NS> p, int it) {
+  const int lane = threadIdx.x & 63;
+  const int tile = blockIdx.x * (TILES_BLOCK / 64) + (threadIdx.x >> 6);
+  if (tile >= p.n_tiles) return;
+  const double* __restrict__ PLt = p.PL + (size_t)tile * p.n_node * NS * 64;
+  const uint32_t rep = (uint32_t)(p.replica_offset + tile * 64 + lane);
+  uint32_t err = 0;
+  double pr[NS];
+#pragma unroll
+  for (int c = 0; c < NS; ++c) pr[c] = p.pid[c] * PLt[(p.root * NS + c) * 64 + lane];   // :618
+  const double u = stream_u(p.seed_lo, p.seed_hi, rep, (uint32_t)it, ENT_NODE | (uint32_t)(p.root + p.n_tips), 0);
+  p.nstate[((size_t)tile * p.n_node + p.root) * 64 + lane] = (uint8_t)sample_cat<NS>(pr, u, err);   // :627
+  if (err) atomicOr(p.err, err);
+}
+
+// child ~ e_ps^T B^(m-1) (.) PL[child]   (Tvmmp :431-436, :651); ks: tips too, against their parity mask (:1384-1397)
+template <int NS>
+__global__ __launch_bounds__(TILES_BLOCK) void tiles_down_kernel(TileParams<NS> p, int it, int begin, int end) {
+  const int lane = threadIdx.x & 63;
+  const int item = blockIdx.x * (TILES_BLOCK / 64) + (threadIdx.x >> 6);
+  const int n_lvl = end - begin;
+  if (item >= n_lvl * p.n_tiles) return;
+  const int tile = item / n_lvl;
+  const DownStep ds = p.down[p.down_order[begin + item % n_lvl]];
+  const int b = ds.edge;
+  const double* __restrict__ PLt = p.PL + (size_t)tile * p.n_node * NS * 64;
+  uint8_t* __restrict__ nst = p.nstate + (size_t)tile * p.n_node * 64;
+  const uint8_t* __restrict__ tips_t = p.tips_per_replica ? p.tips + (size_t)tile * p.n_tips * 64 : p.tips;
+  const uint32_t rep = (uint32_t)(p.replica_offset + tile * 64 + lane);
+  const int m = p.mcount[((size_t)tile * p.n_edge + b) * 64 + lane];
+  const int ps = nst[ds.parent * 64 + lane];
+  uint32_t err = 0;
+  int cs;
+  if (ds.child >= 0 || (p.ks && p.tip_masks)) {
+    int kk = m - 1;
+    if (kk >= p.klong) { err |= DERR_CAPACITY; kk = p.klong - 1; }
+    const double* src = p.rowL + ((size_t)kk * NS + ps) * NS;
+    double w[NS];
+    uint32_t node_id;
+    if (ds.child >= 0) {
+#pragma unroll
+      for (int c = 0; c < NS; ++c) w[c] = src[c] * PLt[(ds.child * NS + c) * 64 + lane];
+      node_id = (uint32_t)(ds.child + p.n_tips);
+    } else {
+      const int tip = ~ds.child;
+      const int par = (p.tips_per_replica ? tips_t[tip * 64 + lane] : p.tips[tip]) & 1;
+#pragma unroll
+      for (int c = 0; c < NS; ++c) w[c] = src[c] * (((c & 1) == par) ? 1.0 : 0.0);
+      node_id = (uint32_t)tip;
+    }
+    const double u = stream_u(p.seed_lo, p.seed_hi, rep, (uint32_t)it, ENT_NODE | node_id, 0);
+    cs = sample_cat<NS>(w, u, err);                                            // :655
+    if (ds.child >= 0) nst[ds.child * 64 + lane] = (uint8_t)cs;
+  } else {
+    const int tip = ~ds.child;
+    cs = p.tips_per_replica ? tips_t[tip * 64 + lane] : p.tips[tip];          // :612
+  }
+  p.estate[((size_t)tile * p.n_edge + b) * 64 + lane] = (uint8_t)(ps | (cs << 4));   // updatenodestates :460-475
+  if (err) atomicOr(p.err, err);
+}
+
+// One branch for the 64 replicas of a tile: resamplebranchstates :264-308, shortener :44-73 (shortenerbf :997-1030),
+// virtual jumps sampleabranch :391-410, dwell sums updatedwelltimes :745-757.
+template <int NS, bool KS>
+__global__ __launch_bounds__(TILES_BLOCK) void tiles_branch_kernel(TileParams<NS> p, int it) {
+  constexpr int NCNT = KS ? NS * NS : NS * (NS - 1);
+  __shared__ double s_dw_all[(TILES_BLOCK / 64) * NS * 64];
+  __shared__ uint32_t s_cnt_all[(TILES_BLOCK / 64) * NCNT * 64];
+  __shared__ double s_B2[NS * NS], s_scale[NS];      // indexed by a per-lane state: LDS, not the kernarg segment
+  __shared__ double s_col[TILES_KTAB * NS * NS];     // B^k e_j for the short chains (most draws); longer ones go to L2
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int item = blockIdx.x * (TILES_BLOCK / 64) + wave;
+  const int ktab = min(TILES_KTAB, p.klong);
+  for (int i = threadIdx.x; i < ktab * NS * NS; i += TILES_BLOCK) s_col[i] = p.colL[i];
+  if (threadIdx.x < NS * NS) s_B2[threadIdx.x] = p.B2[threadIdx.x];
+  if (threadIdx.x < NS) s_scale[threadIdx.x] = p.scale[threadIdx.x];
+  __syncthreads();
+  if (item >= p.n_edge * p.n_tiles) return;          // whole waves only; no barrier below this line
+  // neighbouring waves take the same branch of different tiles: similar run times inside a workgroup, longest branches first
+  const int tile = item % p.n_tiles;
+  const int b = p.branch_order[item / p.n_tiles];
+  double* s_dw = s_dw_all + wave * NS * 64;
+  uint32_t* s_cnt = s_cnt_all + wave * NCNT * 64;
+  const uint32_t rep = (uint32_t)(p.replica_offset + tile * 64 + lane);
+  uint16_t* __restrict__ mct = p.mcount + (size_t)tile * p.n_edge * 64;
+  const int m = mct[b * 64 + lane];
+  const int es = p.estate[((size_t)tile * p.n_edge + b) * 64 + lane];
+  const int ps = es & 15, cs = es >> 4;
+  const int roff = p.slot[b];
+  const int cap = p.slot[b + 1] - roff;
+  double* __restrict__ in = p.dw[it & 1] + ((size_t)tile * p.rows + roff) * 64 + lane;
+  double* __restrict__ out = p.dw[(it & 1) ^ 1] + ((size_t)tile * p.rows + roff) * 64 + lane;
+  auto IN = [&](int k) -> double& { return in[(size_t)k * 64]; };
+  uint32_t err = 0;
+#pragma unroll
+  for (int c = 0; c < NS; ++c) s_dw[c * 64 + lane] = 0.0;
+#pragma unroll
+  for (int c = 0; c < NCNT; ++c) s_cnt[c * 64 + lane] = 0u;
+
+  Stream su, se;
+  su.open(ENT_BSTATE | (uint32_t)b, (uint32_t)it, rep, p.seed_lo, p.seed_hi);
+  se.open(ENT_BEXP | (uint32_t)b, (uint32_t)it, rep, p.seed_lo, p.seed_hi);
+  const int mmax = wave_max_i(m);
+  int mnew = 0;
+
+  // s_i ~ B[s_{i-1},:] (.) B^(m-i-1) e_end          (resamplebranchstates :290, :301-304)
+  auto draw_state = [&](int i, int sprev) -> int {
+    int kk = m - i - 1;
+    if (kk >= p.klong) { err |= DERR_CAPACITY; kk = p.klong - 1; }
+    double pr[NS];
+    if (kk < ktab) {
+      const double* beta = s_col + (kk * NS + cs) * NS;
+#pragma unroll
+      for (int c = 0; c < NS; ++c) pr[c] = beta[c];
+    } else {
+      const double* beta = p.colL + ((size_t)kk * NS + cs) * NS;
+#pragma unroll
+      for (int c = 0; c < NS; ++c) pr[c] = beta[c];
+    }
+#pragma unroll
+    for (int c = 0; c < NS; ++c) pr[c] = s_B2[sprev * NS + c] * pr[c];
+    return sample_cat<NS>(pr, su.draw((uint32_t)(i - 1)), err);
+  };
+
+  if (mmax <= 64) {
+    // Pass A: one old segment per step for every lane; merged segments written back in place over the consumed rows of the
+    // slot, their states packed 2 bits apiece into two registers.
+    uint64_t pk0 = 0, pk1 = 0;
+    int w = 0;
+    int cur_s = (m == 1) ? cs : ps;            // updatenodestates :469-472 (m==1: child wins)
+    double cur_len = IN(0);
+    double dnext = (m > 1) ? IN(1) : 0.0;
+    for (int i = 1; i < mmax; ++i) {
+      if (i < m) {
+        int si = (i == m - 1) ? cs : draw_state(i, cur_s);
+        double di = dnext;
+        if (i + 1 < m) dnext = IN(i + 1);
+        if (KS) s_cnt[(cur_s * NS + si) * 64 + lane] += 1u;               // shortenerbf :1010-1014
+        if (si == cur_s) cur_len = cur_len + di;                           // shortener :54
+        else {
+          IN(w) = cur_len;
+          if (w < 32) pk0 |= (uint64_t)cur_s << (2 * w); else pk1 |= (uint64_t)cur_s << (2 * (w - 32));
+          if (!KS) s_cnt[(cur_s * (NS - 1) + (si > cur_s ? si - 1 : si)) * 64 + lane] += 1u;   // shortener :65-66
+          ++w; cur_s = si; cur_len = di;
+        }
+      }
+    }
+    if (w < 32) pk0 |= (uint64_t)cur_s << (2 * w); else pk1 |= (uint64_t)cur_s << (2 * (w - 32));
+    const int nmerged = w + 1;
+    const double len0 = (w == 0) ? cur_len : IN(0);
+    if (w > 0) IN(w) = cur_len;
+
+    // Pass B: one new piece per step for every lane (virtual jumps :391-410, dwell sums :745-757).
+    int j = 0;
+    int s = (int)(pk0 & 3u);
+    double len = len0;
+    double lnext = (nmerged > 1) ? ((w == 1) ? cur_len : IN(1)) : 0.0;
+    double tot = 0.0, scale = s_scale[s], acc = s_dw[s * 64 + lane];
+    uint32_t edraw = 0;
+    bool stuck = false, done = false;
+    while (!done) {
+      double piece;
+      bool adv;
+      if (stuck || !(0.0 < len)) { stuck = true; piece = len; adv = true; }
+      else {
+        double rl = scale * (-phm_log(se.draw(edraw++)));                  // :398
+        if ((tot + rl) < len) { piece = rl; tot += rl; adv = false; }
+        else { piece = len - tot; adv = true; }
+      }
+      if (mnew < cap) out[(size_t)mnew * 64] = piece; else err |= DERR_CAPACITY;
+      acc += piece;                                                        // updatedwelltimes :752
+      ++mnew;
+      if (adv) {
+        s_dw[s * 64 + lane] = acc;
+        ++j;
+        if (j >= nmerged) done = true;
+        else {
+          len = lnext;
+          if (j + 1 < nmerged) lnext = IN(j + 1);
+          s = (int)(((j < 32) ? (pk0 >> (2 * j)) : (pk1 >> (2 * (j - 32)))) & 3u);
+          scale = s_scale[s]; tot = 0.0; acc = s_dw[s * 64 + lane];
+        }
+      }
+    }
+  } else {
+    // General path (a lane with more than 64 segments on this branch): the reference's loop nest as written.
+    uint32_t edraw = 0;
+    bool stuck = false;
+    auto finalize = [&](int s, double len) {
+      if (stuck || !(0.0 < len)) {
+        stuck = true;
+        if (mnew < cap) out[(size_t)mnew * 64] = len; else err |= DERR_CAPACITY;
+        s_dw[s * 64 + lane] += len;
+        ++mnew;
+        return;
+      }
+      const double scale = s_scale[s];
+      double tot = 0.0;
+      double acc = s_dw[s * 64 + lane];
+      while (tot < len) {
+        double rl = scale * (-phm_log(se.draw(edraw++)));
+        double piece;
+        if ((tot + rl) < len) { piece = rl; tot += rl; }
+        else { piece = len - tot; tot = len; }
+        if (mnew < cap) out[(size_t)mnew * 64] = piece; else err |= DERR_CAPACITY;
+        acc += piece;
+        ++mnew;
+      }
+      s_dw[s * 64 + lane] = acc;
+    };
+    int cur_s = (m == 1) ? cs : ps;
+    double cur_len = IN(0);
+    for (int i = 1; i <= m; ++i) {              // i == m: sentinel that flushes the last merged segment
+      int si = -1;
+      double di = 0.0;
+      if (i < m) {
+        si = (i == m - 1) ? cs : draw_state(i, cur_s);
+        di = IN(i);
+      }
+      if (KS && si >= 0) s_cnt[(cur_s * NS + si) * 64 + lane] += 1u;
+      if (si == cur_s) cur_len = cur_len + di;
+      else {
+        finalize(cur_s, cur_len);
+        if (!KS && si >= 0) s_cnt[(cur_s * (NS - 1) + (si > cur_s ? si - 1 : si)) * 64 + lane] += 1u;
+        cur_s = si; cur_len = di;
+      }
+    }
+  }
+  if (mnew > cap) mnew = cap;
+  if (mnew > 65535) { err |= DERR_CAPACITY; mnew = 65535; }
+  mct[b * 64 + lane] = (uint16_t)mnew;
+
+  double* pd = p.pdw + (((size_t)tile * p.n_edge + b) * NS) * 64 + lane;
+#pragma unroll
+  for (int c = 0; c < NS; ++c) pd[c * 64] = s_dw[c * 64 + lane];
+  uint32_t* gc = p.cnt + ((size_t)tile * NS * NS) * 64 + lane;
+#pragma unroll
+  for (int c = 0; c < NCNT; ++c) { const uint32_t v = s_cnt[c * 64 + lane]; if (v) atomicAdd(gc + c * 64, v); }
+  {
+    uint32_t v = (uint32_t)(m + mnew);
+    const bool valid = tile * 64 + lane < p.n_rep;
+    if (!valid) v = 0;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0) atomicAdd(p.segcnt, (unsigned long long)v);
+  }
+  if (err) atomicOr(p.err, err);
+}
+
+// Dwell sums, first stage: a wave per (tile, chunk of TILES_CHUNK branches), branches added in edge order.
+template <int NS>
+__global__ __launch_bounds__(TILES_BLOCK) void tiles_chunk_kernel(TileParams<NS> p) {
+  const int lane = threadIdx.x & 63;
+  const int item = blockIdx.x * (TILES_BLOCK / 64) + (threadIdx.x >> 6);
+  if (item >= p.n_chunks * p.n_tiles) return;
+  const int tile = item / p.n_chunks, chunk = item % p.n_chunks;
+  const int b0 = chunk * TILES_CHUNK, b1 = min(b0 + TILES_CHUNK, p.n_edge);
+  double s[NS];
+#pragma unroll
+  for (int c = 0; c < NS; ++c) s[c] = 0.0;
+  const double* src = p.pdw + ((size_t)tile * p.n_edge * NS) * 64 + lane;
+  for (int b = b0; b < b1; ++b)
+#pragma unroll
+    for (int c = 0; c < NS; ++c) s[c] += src[((size_t)b * NS + c) * 64];
+  double* dst = p.pchunk + (((size_t)tile * p.n_chunks + chunk) * NS) * 64 + lane;
+#pragma unroll
+  for (int c = 0; c < NS; ++c) dst[c * 64] = s[c];
+}
+
+// Second stage and the statistics row: a wave per tile.  Columns: n dwell sums, the counters, (ks) the root state.
+template <int NS, bool KS>
+__global__ __launch_bounds__(TILES_BLOCK) void tiles_stats_kernel(TileParams<NS> p, int it) {
+  constexpr int NCNT = KS ? NS * NS : NS * (NS - 1);
+  constexpr int DCOLS = NS + NCNT + (KS ? 1 : 0);
+  const int lane = threadIdx.x & 63;
+  const int tile = blockIdx.x * (TILES_BLOCK / 64) + (threadIdx.x >> 6);
+  if (tile >= p.n_tiles) return;
+  const int rep_local = tile * 64 + lane;
+  const bool valid = rep_local < p.n_rep;
+  double col[DCOLS];
+#pragma unroll
+  for (int c = 0; c < NS; ++c) col[c] = 0.0;
+  const double* src = p.pchunk + ((size_t)tile * p.n_chunks * NS) * 64 + lane;
+  for (int ch = 0; ch < p.n_chunks; ++ch)
+#pragma unroll
+    for (int c = 0; c < NS; ++c) col[c] += src[((size_t)ch * NS + c) * 64];
+  uint32_t* gc = p.cnt + ((size_t)tile * NS * NS) * 64 + lane;
+#pragma unroll
+  for (int c = 0; c < NCNT; ++c) { col[NS + c] = (double)gc[c * 64]; gc[c * 64] = 0u; }
+  if (KS) col[NS + NCNT] = (double)p.nstate[((size_t)tile * p.n_node + p.root) * 64 + lane];   // :1350-1352
+  if (p.reduce) {
+    double* dst = p.stats + ((size_t)it * p.n_tiles + tile) * p.n_cols;
+#pragma unroll
+    for (int c = 0; c < DCOLS; ++c) {
+      double v = valid ? col[c] : 0.0;
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane == c) dst[c] = v;
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < DCOLS; ++c) p.stats[((size_t)it * p.n_cols + c) * p.n_rep_pad + rep_local] = col[c];
+  }
+}
+
+// Load the caller's initial paths (x$maps, makeabranch src/phylomap.cpp:24-34) into every replica of every tile.
+__global__ void tiles_init_kernel(int n_edge, int n_tiles, int64_t rows, const int32_t* __restrict__ slot,
+                                  const int32_t* __restrict__ map_off, const double* __restrict__ maps,
+                                  double* __restrict__ dw0, uint16_t* __restrict__ mcount) {
+  const int lane = threadIdx.x & 63;
+  const int item = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+  if (item >= n_edge * n_tiles) return;
+  const int tile = item / n_edge, b = item % n_edge;
+  const int o = map_off[b], m = map_off[b + 1] - o;
+  double* dst = dw0 + ((size_t)tile * rows + slot[b]) * 64 + lane;
+  for (int i = 0; i < m; ++i) dst[(size_t)i * 64] = maps[o + i];
+  mcount[((size_t)tile * n_edge + b) * 64 + lane] = (uint16_t)m;
+}
+
+}  // namespace
+
+hipError_t launch_tiles_init(int n_edge, int n_tiles, int64_t rows, const int32_t* slot, const int32_t* map_off,
+                             const double* maps, double* dw0, uint16_t* mcount, hipStream_t stream) {
+  const int64_t items = (int64_t)n_edge * n_tiles;
+  hipLaunchKernelGGL(tiles_init_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, n_edge, n_tiles, rows, slot, map_off,
+                     maps, dw0, mcount);
+  return hipGetLastError();
+}
+
+template <int NS>
+hipError_t launch_tiles_sweep(const TileParams<NS>& p, const std::vector<int32_t>& up_off,
+                              const std::vector<int32_t>& down_off, int it, hipStream_t stream) {
+  constexpr int WPB = TILES_BLOCK / 64;
+  auto blocks = [&](int64_t items) { return dim3((unsigned)((items + WPB - 1) / WPB)); };
+  for (size_t l = 0; l + 1 < up_off.size(); ++l) {
+    const int n = up_off[l + 1] - up_off[l];
+    if (n > 0) hipLaunchKernelGGL(tiles_up_kernel<NS>, blocks((int64_t)n * p.n_tiles), dim3(TILES_BLOCK), 0, stream, p, up_off[l], up_off[l + 1]);
+  }
+  hipLaunchKernelGGL(tiles_root_kernel<NS>, blocks(p.n_tiles), dim3(TILES_BLOCK), 0, stream, p, it);
+  for (size_t l = 0; l + 1 < down_off.size(); ++l) {
+    const int n = down_off[l + 1] - down_off[l];
+    if (n > 0) hipLaunchKernelGGL(tiles_down_kernel<NS>, blocks((int64_t)n * p.n_tiles), dim3(TILES_BLOCK), 0, stream, p, it, down_off[l], down_off[l + 1]);
+  }
+  if (p.ks) hipLaunchKernelGGL((tiles_branch_kernel<NS, true>), blocks((int64_t)p.n_edge * p.n_tiles), dim3(TILES_BLOCK), 0, stream, p, it);
+  else hipLaunchKernelGGL((tiles_branch_kernel<NS, false>), blocks((int64_t)p.n_edge * p.n_tiles), dim3(TILES_BLOCK), 0, stream, p, it);
+  hipLaunchKernelGGL(tiles_chunk_kernel<NS>, blocks((int64_t)p.n_chunks * p.n_tiles), dim3(TILES_BLOCK), 0, stream, p);
+  if (p.ks) hipLaunchKernelGGL((tiles_stats_kernel<NS, true>), blocks(p.n_tiles), dim3(TILES_BLOCK), 0, stream, p, it);
+  else hipLaunchKernelGGL((tiles_stats_kernel<NS, false>), blocks(p.n_tiles), dim3(TILES_BLOCK), 0, stream, p, it);
+  return hipGetLastError();
+}
+
+template hipError_t launch_tiles_sweep<2>(const TileParams<2>&, const std::vector<int32_t>&, const std::vector<int32_t>&, int, hipStream_t);
+template hipError_t launch_tiles_sweep<3>(const TileParams<3>&, const std::vector<int32_t>&, const std::vector<int32_t>&, int, hipStream_t);
+template hipError_t launch_tiles_sweep<4>(const TileParams<4>&, const std::vector<int32_t>&, const std::vector<int32_t>&, int, hipStream_t);
+
+}  // namespace phm

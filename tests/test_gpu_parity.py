@@ -23,7 +23,7 @@ def _problem(n, tips, seed, omega_factor=1.25):
     return z, Q, pid, Omega
 
 
-MAPPINGS = ["replicas", "branches"]     # one lane per chain (throughput layout) / one lane per branch (few chains)
+MAPPINGS = ["replicas", "branches", "tiles"]     # lane per chain in one wave per tile / lane per branch / wave per (tile, branch)
 
 
 def _same(got, want, n, mapping, ks=False):
@@ -71,12 +71,13 @@ def test_mcmc_single_chain_is_drop_in_shape():
     np.testing.assert_array_equal(api.sumstatMCMC(z, Q, pid, Omega, 25, seed=5, mapping="replicas"), want)
 
 
-@pytest.mark.parametrize("storage", [1, 2, 0])   # 1: one ring per tile for both dwell streams; 2: two buffers; 0: branch mapping
+@pytest.mark.parametrize("storage", [1, 2, 0, -1])   # 1: one ring per tile; 2: two buffers; 0: branch mapping; -1: tiles mapping
 def test_mcmc_chain_state_matches_oracle(storage):
     z, Q, pid, Omega = _problem(4, 40, 99)
     nen, nodelist, root = _orders(z)
     N, seed = 15, 42
-    mapping = "replicas" if storage else "branches"
+    mapping = "replicas" if storage > 0 else ("branches" if storage == 0 else "tiles")
+    storage = max(storage, 0)
     eng = _lib.Engine(z, Q, pid, Omega, N, variant=_lib.PHM_MCMC_BIGTREE, seed=seed, n_replicas=70, storage=storage, mapping=mapping)
     eng.run(7); eng.run(N - 7); eng.sync()
     for r in (0, 63, 69):
@@ -94,7 +95,7 @@ def test_mcmc_chain_state_matches_oracle(storage):
     eng.close()
 
 
-@pytest.mark.parametrize("storage", [1, 2, 0])        # 0: the branch mapping (CSR slots; no ring / buffer choice)
+@pytest.mark.parametrize("storage", [1, 2, 0, -1])    # 0: the branch mapping (CSR slots; no ring / buffer choice); -1: tiles
 def test_mcmc_long_initial_paths_take_the_general_branch_path(storage):
     """100 equal segments per branch (R/Squamate_tree_setup.R:57): exercises the > 64-segment code path and the
     hand-over to the packed two-pass path once the chain has shrunk the paths."""
@@ -103,8 +104,8 @@ def test_mcmc_long_initial_paths_take_the_general_branch_path(storage):
     pid = np.full(4, 0.25)
     z = synth.make_tree(14, Q, Omega, 21, pid, init_segments=100)
     nen, nodelist, root = _orders(z)
-    mapping = "replicas" if storage else "branches"
-    got = api.sumstatMCMC(z, Q, pid, Omega, 12, seed=13, n_replicas=2, storage=storage, mapping=mapping)
+    mapping = "replicas" if storage > 0 else ("branches" if storage == 0 else "tiles")
+    got = api.sumstatMCMC(z, Q, pid, Omega, 12, seed=13, n_replicas=2, storage=max(storage, 0), mapping=mapping)
     for r in range(2):
         want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(4) + Q / Omega, Omega, nen, nodelist, root, 12, seed=13, replica=r)
         assert rc == 0
@@ -299,7 +300,7 @@ def test_wide_kernel_chain_state_and_golden():
     np.testing.assert_array_equal(d["PL"], dump.PL)
 
 
-@pytest.mark.parametrize("n,mapping", [(2, "replicas"), (4, "replicas"), (2, "branches"), (4, "branches"), (6, "replicas")])
+@pytest.mark.parametrize("n,mapping", [(2, "replicas"), (4, "replicas"), (2, "branches"), (4, "branches"), (2, "tiles"), (4, "tiles"), (6, "replicas")])
 def test_ks_sweep_matches_oracle(n, mapping):
     """Tree sweep of sumstatMCMCks with Q fixed (hidden-rates Q = make2sQ, binary trait observed): n<=4 kernel and,
     for k=2 (n=6), the wide kernel."""

@@ -2,7 +2,7 @@ import sys, time, numpy as np
 sys.path.insert(0,'/root/repo')
 from phylomap_amd import _lib, synth
 z,Q,pid,Om=synth.config_problem(2)
-for mapping,S in (("branches",1),("replicas",1),("branches",16),("branches",64),("branches",256),("replicas",256),("branches",1024),("replicas",1024),("branches",4096),("replicas",4096)):
+for mapping,S in (("branches",1),("replicas",1),("branches",16),("branches",64),("tiles",64),("branches",256),("tiles",256),("replicas",256),("branches",1024),("tiles",1024),("replicas",1024),("branches",4096),("tiles",4096),("replicas",4096),("tiles",16384),("replicas",16384),("tiles",65536),("replicas",65536),("tiles",131072)):
     N=40 if mapping=="branches" or S>1 else 10
     try:
         eng=_lib.Engine(z,Q,pid,Om,N+2,variant=_lib.PHM_MCMC_BIGTREE,seed=1,n_replicas=S,mapping=mapping,reduce=True)
