@@ -202,6 +202,16 @@ def main():
         one.close()
         out["single_chain"] = {"mapping": "one lane per branch", "ms_per_sweep": d1 / 100 * 1e3, "realisations_per_s": E * 100 / d1}
 
+    if rank == 0 and n <= 4:
+        # an alignment-sized job (4 096 sites) on the same tree: one wave per (tile of 64 replicas, branch) (phm_tiles.hip)
+        mid = _lib.Engine(z, Q, pid, Omega, 44, variant=_lib.PHM_MCMC_BIGTREE, seed=1, n_replicas=4096, reduce=True,
+                          device=local_rank, mapping="tiles")
+        mid.run(4); mid.sync()
+        t1 = time.perf_counter(); mid.run(40); mid.sync(); d1 = time.perf_counter() - t1
+        mid.close()
+        out["replicas_4096"] = {"mapping": "one wave per (tile, branch)", "ms_per_sweep": d1 / 40 * 1e3,
+                                "realisations_per_s": E * 4096 * 40 / d1}
+
     if rank == 0:
         # secondary metric of BASELINE.json: expm(Q t)/s (batched 4x4 transition matrices, kernel time)
         t = np.random.default_rng(0).exponential(4.0 / Omega, 1 << 20)

@@ -108,7 +108,7 @@ struct phm_engine {
   // wave per (tile, branch) mapping for 10^2 .. 10^5 replicas (phm_tiles.hip); shares the level schedules and long tables
   bool tiled = false;
   std::vector<int32_t> tl_slot;                    // first row of every branch slot
-  DevBuf d_tl_slot, d_tl_pdw, d_tl_pchunk, d_tl_cnt, d_tl_estate;
+  DevBuf d_tl_slot, d_tl_pdw, d_tl_pchunk, d_tl_cnt, d_tl_estate, d_tl_pseg, d_tl_segprev;
   phm::TileParams<2> t2;
   phm::TileParams<3> t3;
   phm::TileParams<4> t4;
@@ -128,14 +128,14 @@ struct phm_engine {
 namespace {
 
 // Automatic choice of the mapping (measured on C2, profiles/r01_probe_mapping.log; ms per sweep):
-//   chains          1     64    256    1024   4096   16384   65536   327680
-//   lane=branch   0.29   0.41   0.87    2.5    9.4
-//   wave=tile x branch   0.31   0.40    0.75   2.1     7.4    28.7
-//   lane=replica  23.0          24.3   28.4   30.0    29.6    30.8     58.5
-// one lane per branch for a handful of chains, one wave per (tile, branch) up to ~5e4 replicas, beyond that the replica
-// mapping (its single wave per tile needs tens of thousands of replicas to fill the chip but then streams at 2.5x the rate).
+//   chains                  1     64    256   1024   4096   16384   65536   131072   196608   327680
+//   lane = branch         0.29   0.41   0.87   2.5    9.4
+//   wave = tile x branch         0.33   0.36   0.50   1.1     3.8    13.7     27.3     39.8   (does not fit)
+//   lane = replica        23.0          24.3   28.4   30.0    29.6    30.8     37.9     44.4     58.5
+// One lane per branch for a handful of chains; one wave per (tile, branch) as long as its slots fit in HBM; the replica
+// mapping (a single wave per tile, compact sequential streams) for the largest replica counts.
 constexpr int NARROW_AUTO_MAX_REPLICAS = 47;
-constexpr int TILES_AUTO_MAX_REPLICAS = 49152;
+constexpr int TILES_AUTO_MAX_REPLICAS = 262144;
 
 bool ks_layout(int v) { return v == PHM_MCMC_KS || v == PHM_MCMC_BF || v == PHM_MCMC_MT || v == PHM_MCMC_KSMT; }   // n x n counts, root column
 bool hidden_rates(int v) { return v == PHM_MCMC_KS || v == PHM_MCMC_KSMT; }                                         // parity tip masks
@@ -387,7 +387,7 @@ int32_t narrow_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
   const size_t tab = (size_t)e->nw_klong * n * n;
   size_t free_b = 0, total_b = 0;
   HIPCHK(hipMemGetInfo(&free_b, &total_b));
-  const size_t need = 3 * dw_bytes + (size_t)S * e->nw_total_cap + stats_bytes + sizeof(double) * (3 * tab + (size_t)S * E * (n + n * n));
+  const size_t need = 3 * dw_bytes + (size_t)S * e->nw_total_cap + stats_bytes + sizeof(double) * (3 * tab + (size_t)S * E * (n + n * n + 1));
   if (need + (64u << 20) > free_b) {
     char buf[256];
     std::snprintf(buf, sizeof buf, "engine needs %.2f GiB of HBM, %.2f GiB free (reduce n_replicas or max_iters)", need / 1073741824.0, free_b / 1073741824.0);
@@ -406,7 +406,7 @@ int32_t narrow_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
   HIPCHK(e->d_nw_estate.alloc((size_t)S * E * 2));
   HIPCHK(e->d_PL.alloc(sizeof(double) * (size_t)S * Nn * n));
   HIPCHK(e->d_nstate.alloc((size_t)S * Nn));
-  HIPCHK(e->d_nw_part.alloc(sizeof(double) * (size_t)S * E * (n + n * n)));
+  HIPCHK(e->d_nw_part.alloc(sizeof(double) * (size_t)S * E * (n + n * n + 1)));
   HIPCHK(e->d_nw_rowbuf.alloc(sizeof(double) * (size_t)S * e->dcols));
   HIPCHK(e->d_stats.alloc(stats_bytes));
   HIPCHK(e->d_err.alloc(sizeof(uint32_t))); HIPCHK(e->d_seg.alloc(sizeof(unsigned long long)));
@@ -461,6 +461,7 @@ void fill_tile_params(phm_engine* e, phm::TileParams<NS>& p, const phm_options& 
   p.dw[0] = e->d_dw0.as<double>(); p.dw[1] = e->d_dw1.as<double>();
   p.estate = e->d_tl_estate.as<uint8_t>(); p.PL = e->d_PL.as<double>(); p.nstate = e->d_nstate.as<uint8_t>();
   p.pdw = e->d_tl_pdw.as<double>(); p.pchunk = e->d_tl_pchunk.as<double>(); p.cnt = e->d_tl_cnt.as<uint32_t>();
+  p.pseg = e->d_tl_pseg.as<uint32_t>(); p.segprev = e->d_tl_segprev.as<uint32_t>();
   p.stats = e->d_stats.as<double>(); p.err = e->d_err.as<uint32_t>(); p.segcnt = e->d_seg.as<unsigned long long>();
 }
 
@@ -532,6 +533,7 @@ int32_t tiles_setup(phm_engine* e, const phm_tree* x, const phm_model* model, co
   HIPCHK(e->d_tl_pdw.alloc(pdw_bytes));
   HIPCHK(e->d_tl_pchunk.alloc(sizeof(double) * (size_t)tiles * n_chunks * n * 64));
   HIPCHK(e->d_tl_cnt.alloc(sizeof(uint32_t) * (size_t)tiles * n * n * 64));
+  HIPCHK(e->d_tl_pseg.alloc(sizeof(uint32_t) * (size_t)tiles * n_chunks * 64)); HIPCHK(e->d_tl_segprev.alloc(sizeof(uint32_t) * tiles));
   HIPCHK(e->d_stats.alloc(stats_bytes));
   HIPCHK(e->d_err.alloc(sizeof(uint32_t))); HIPCHK(e->d_seg.alloc(sizeof(unsigned long long)));
   if (e->reduce) HIPCHK(e->d_red.alloc(sizeof(double) * (size_t)max_iters * e->dcols));
@@ -556,6 +558,9 @@ int32_t tiles_setup(phm_engine* e, const phm_tree* x, const phm_model* model, co
     HIPCHK(phm::launch_tiles_init(E, tiles, rows, e->d_tl_slot.as<int32_t>(), d_off.as<int32_t>(), d_maps.as<double>(),
                                   e->d_dw0.as<double>(), e->d_mcount.as<uint16_t>(), nullptr));
     HIPCHK(hipDeviceSynchronize());
+    std::vector<uint32_t> segprev(tiles);
+    for (int t = 0; t < tiles; ++t) segprev[t] = (uint32_t)((int64_t)x->map_off[E] * std::min(64, e->S - t * 64));
+    HIPCHK(hipMemcpy(e->d_tl_segprev.p, segprev.data(), e->d_tl_segprev.bytes, hipMemcpyHostToDevice));
   }
   if (n == 2) fill_tile_params<2>(e, e->t2, o);
   if (n == 3) fill_tile_params<3>(e, e->t3, o);

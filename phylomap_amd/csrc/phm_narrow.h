@@ -54,7 +54,7 @@ struct NarrowParams {
   uint8_t* estate;                           // [replica][n_edge][2] end states (parent side, child side) of every edge
   double* PL;                                // [replica][n_node][NS]
   uint8_t* nstate;                           // [replica][n_node]
-  double* part;                              // [replica][n_edge][NS + NS*NS] per-branch dwell sums and counts
+  double* part;                              // [replica][n_edge][NS + NS*NS + 1] per-branch dwell sums, counts, segments touched
   double* rowbuf;                            // [replica][n_cols] statistics row of the sweep
   double* stats;                             // engine layout: reduce ? [iter][tile][cols] : [iter][cols][n_rep_pad]
   uint32_t* err;

@@ -220,11 +220,11 @@ __global__ __launch_bounds__(NARROW_BLOCK) void narrow_branch_kernel(NarrowParam
   if (mnew > cap) mnew = cap;
   mc[b] = mnew;
 
-  double* part = p.part + ((size_t)r * p.n_edge + b) * (NS + NS * NS);
+  double* part = p.part + ((size_t)r * p.n_edge + b) * (NS + NS * NS + 1);
 #pragma unroll
   for (int c = 0; c < NS; ++c) part[c] = s_dw[c * NARROW_BLOCK + lane];
   for (int c = 0; c < ncnt; ++c) part[NS + c] = (double)s_cnt[c * NARROW_BLOCK + lane];
-  atomicAdd(p.segcnt, (unsigned long long)(m + mnew));
+  part[NS + NS * NS] = (double)(m + mnew);           // segments read + written (one global counter would serialise every lane)
   if (err) atomicOr(p.err, err);
 }
 
@@ -235,18 +235,22 @@ __global__ __launch_bounds__(256) void narrow_stats_kernel(NarrowParams<NS> p) {
   __shared__ double red[256];
   const int r = blockIdx.x;
   const int ncnt = p.ks ? NS * NS : NS * (NS - 1);
-  const int pc = NS + NS * NS;
+  const int pc = NS + NS * NS + 1;
   const double* part = p.part + (size_t)r * p.n_edge * pc;
-  for (int c = 0; c < NS + ncnt; ++c) {
+  for (int c = 0; c <= NS + ncnt; ++c) {             // the last round adds the segment counts (column pc - 1)
+    const int src_c = (c == NS + ncnt) ? pc - 1 : c;
     double s = 0.0;
-    for (int e = threadIdx.x; e < p.n_edge; e += 256) s += part[(size_t)e * pc + c];
+    for (int e = threadIdx.x; e < p.n_edge; e += 256) s += part[(size_t)e * pc + src_c];
     red[threadIdx.x] = s;
     __syncthreads();
     for (int half = 128; half >= 1; half >>= 1) {
       if ((int)threadIdx.x < half) red[threadIdx.x] = red[threadIdx.x] + red[threadIdx.x + half];
       __syncthreads();
     }
-    if (threadIdx.x == 0) p.rowbuf[(size_t)r * p.n_cols + c] = red[0];
+    if (threadIdx.x == 0) {
+      if (c < NS + ncnt) p.rowbuf[(size_t)r * p.n_cols + c] = red[0];
+      else atomicAdd(p.segcnt, (unsigned long long)red[0]);
+    }
     __syncthreads();
   }
   if (p.ks && threadIdx.x == 0)                                                // root state, 0-based (:1350-1352)

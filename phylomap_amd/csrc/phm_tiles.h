@@ -58,6 +58,8 @@ struct TileParams {
   double* pdw;                               // [tile][n_edge][NS][64] dwell sums of every branch
   double* pchunk;                            // [tile][n_chunks][NS][64] first-stage sums
   uint32_t* cnt;                             // [tile][NS*NS][64] transition counters of the sweep (integer atomics)
+  uint32_t* pseg;                            // [tile][n_chunks][64] segments held by each chunk of branches after the sweep
+  uint32_t* segprev;                         // [tile] segments held by the tile's valid replicas before the sweep
   double* stats;                             // engine layout: reduce ? [iter][tile][cols] : [iter][cols][n_rep_pad]
   uint32_t* err;
   unsigned long long* segcnt;

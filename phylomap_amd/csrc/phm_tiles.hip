@@ -301,14 +301,6 @@ __global__ __launch_bounds__(TILES_BLOCK) void tiles_branch_kernel(TileParams<NS
   uint32_t* gc = p.cnt + ((size_t)tile * NS * NS) * 64 + lane;
 #pragma unroll
   for (int c = 0; c < NCNT; ++c) { const uint32_t v = s_cnt[c * 64 + lane]; if (v) atomicAdd(gc + c * 64, v); }
-  {
-    uint32_t v = (uint32_t)(m + mnew);
-    const bool valid = tile * 64 + lane < p.n_rep;
-    if (!valid) v = 0;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    if (lane == 0) atomicAdd(p.segcnt, (unsigned long long)v);
-  }
   if (err) atomicOr(p.err, err);
 }
 
@@ -330,6 +322,11 @@ __global__ __launch_bounds__(TILES_BLOCK) void tiles_chunk_kernel(TileParams<NS>
   double* dst = p.pchunk + (((size_t)tile * p.n_chunks + chunk) * NS) * 64 + lane;
 #pragma unroll
   for (int c = 0; c < NS; ++c) dst[c * 64] = s[c];
+  // segments now held by these branches (for the read + written counter; one global atomic per wave would serialise)
+  uint32_t segs = 0;
+  const uint16_t* mc = p.mcount + ((size_t)tile * p.n_edge) * 64 + lane;
+  for (int b = b0; b < b1; ++b) segs += mc[(size_t)b * 64];
+  p.pseg[((size_t)tile * p.n_chunks + chunk) * 64 + lane] = segs;
 }
 
 // Second stage and the statistics row: a wave per tile.  Columns: n dwell sums, the counters, (ks) the root state.
@@ -352,6 +349,14 @@ __global__ __launch_bounds__(TILES_BLOCK) void tiles_stats_kernel(TileParams<NS>
   uint32_t* gc = p.cnt + ((size_t)tile * NS * NS) * 64 + lane;
 #pragma unroll
   for (int c = 0; c < NCNT; ++c) { col[NS + c] = (double)gc[c * 64]; gc[c * 64] = 0u; }
+  {   // segments read (the previous sweep's total) + written (this sweep's), valid replicas only
+    uint32_t segs = 0;
+    for (int ch = 0; ch < p.n_chunks; ++ch) segs += p.pseg[((size_t)tile * p.n_chunks + ch) * 64 + lane];
+    if (!valid) segs = 0;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) segs += __shfl_xor(segs, off, 64);
+    if (lane == 0) { atomicAdd(p.segcnt, (unsigned long long)p.segprev[tile] + segs); p.segprev[tile] = segs; }
+  }
   if (KS) col[NS + NCNT] = (double)p.nstate[((size_t)tile * p.n_node + p.root) * 64 + lane];   // :1350-1352
   if (p.reduce) {
     double* dst = p.stats + ((size_t)it * p.n_tiles + tile) * p.n_cols;
