@@ -97,8 +97,14 @@ typedef struct phm_options {
   int32_t iters_per_launch;    /* MCMC iterations fused into one kernel launch; 0 -> default */
   double  cap_tail;            /* dwell-stream capacity of a 64-replica tile = sum over branches of the
                                   1+Poisson(Omega*t_b) quantile at this tail; 0 -> 1e-3 */
-  int32_t reserved[6];         /* [0]: dwell-stream storage, 0 = automatic, 1 = one ring per tile (half the HBM),
-                                  2 = two buffers (5 % faster sweep for n <= 4) */
+  int32_t reserved[6];         /* [0]: dwell-stream storage of the replica mapping, 0 = automatic, 1 = one ring per tile (half the
+                                       HBM), 2 = two buffers (5 % faster sweep for n <= 4)
+                                  [1]: mapping of a sweep onto the lanes (n <= 4, one tree), 0 = automatic by replica count,
+                                       1 = one lane per replica, one wave per 64-replica tile walks the tree (largest replica counts),
+                                       2 = one lane per branch of one chain (a handful of chains, large trees),
+                                       3 = one wave per (64-replica tile, branch) (10^2 .. 10^5 replicas).
+                                       Same draws and counts in every mapping; dwell sums differ in the last bits between
+                                       1 and 2/3 (summation order).  cap_tail defaults to 1e-12 for 2 and 3 (fixed slots). */
 } phm_options;
 
 typedef struct phm_info {
