@@ -11,7 +11,7 @@
 
 namespace phm {
 
-// device error bits -> phm_status (phm_api.cpp)
+// device error bits -> phm_status (phm_internal.h)
 constexpr uint32_t DERR_ZERO_PROB = 1u;   // all-zero / non-finite probability vector
 constexpr uint32_t DERR_CAPACITY  = 2u;   // branch outgrew its slot capacity
 constexpr uint32_t DERR_UNIF_CAP  = 4u;   // newunifSample > 300 jumps (src/phylomap.cpp:120)

@@ -1,0 +1,282 @@
+// phm_drivers.cpp -- the reference-shaped entry points (one per exported driver of src/phylomap.cpp) on top of the engine:
+// fixed-Q drivers, the Q-updating drivers (bf / ks / DIC) and the multi-tree drivers (mt / ksmt); host-side glue only.
+#include "phm_internal.h"
+
+extern "C" {
+
+// ---- reference-shaped one-shot drivers -------------------------------------------------------------
+static int32_t run_mcmc_oneshot(int variant, const phm_tree* x, int32_t n, const double* Q, const double* pid,
+                                const double* B, double Omega, const int32_t* nen, const int32_t* nodelist, int32_t root,
+                                int32_t N, const phm_options* opt, double* out) {
+  if (!out) return fail(PHM_ERR_BAD_INPUT, "out is NULL");
+  if (N < 1) return fail(PHM_ERR_BAD_INPUT, "N must be >= 1");
+  phm_model model;
+  model.n_states = n; model.Q = Q; model.pid = pid; model.B = B; model.Omega = Omega; model.variant = variant;
+  phm_engine* e = nullptr;
+  int32_t st = phm_engine_create(x, &model, opt, N, &e);
+  if (st) return st;
+  std::string serr;
+  if (!phm::check_reference_orders(e->sched, x->edge, nen, nodelist, root, serr)) { phm_engine_destroy(e); return fail(PHM_ERR_BAD_INPUT, serr); }
+  st = phm_engine_run(e, N, nullptr);
+  if (!st) st = phm_engine_sync(e);
+  if (!st) st = phm_engine_read_stats(e, 0, N, out);
+  phm_engine_destroy(e);
+  return st;
+}
+
+int32_t phm_maketreelistMCMC(const phm_tree* x, int32_t n, const double* Q, const double* pid, const double* B, double Omega,
+                             const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N, const phm_options* opt,
+                             double* out) {
+  return run_mcmc_oneshot(PHM_MCMC, x, n, Q, pid, B, Omega, nen, nodelist, root, N, opt, out);
+}
+int32_t phm_maketreelistMCMC_bigtree(const phm_tree* x, int32_t n, const double* Q, const double* pid, const double* B,
+                                     double Omega, const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
+                                     const phm_options* opt, double* out) {
+  return run_mcmc_oneshot(PHM_MCMC_BIGTREE, x, n, Q, pid, B, Omega, nen, nodelist, root, N, opt, out);
+}
+int32_t phm_maketreelistMCMCks_sweep(const phm_tree* x, int32_t n, const double* Q, const double* pid, const double* B,
+                                     double Omega, const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
+                                     const phm_options* opt, double* out) {
+  return run_mcmc_oneshot(PHM_MCMC_KS, x, n, Q, pid, B, Omega, nen, nodelist, root, N, opt, out);
+}
+int32_t phm_SPARSEmaketreelistMCMC(const phm_tree* x, int32_t n, const double* Q, const double* pid, const double* B,
+                                   double Omega, const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
+                                   const phm_options* opt, double* out) {
+  return run_mcmc_oneshot(PHM_MCMC_SPARSE, x, n, Q, pid, B, Omega, nen, nodelist, root, N, opt, out);
+}
+
+}  // extern "C"
+
+// Native O(E) replacement of pruningwiseedgeorder / makenodelist / myreorder (R/sumstatMCMC.R:1-18); pure host code.
+extern "C" int32_t phm_tree_orders(int32_t n_tips, int32_t n_edge, const int32_t* edge, int32_t* nen, int32_t* nodelist,
+                                   int32_t* root) {
+  if (!edge || !nen || !nodelist || !root) return fail(PHM_ERR_BAD_INPUT, "phm_tree_orders: NULL argument");
+  std::string serr;
+  if (!phm::pruningwise_orders(n_tips, n_edge, edge, nen, nodelist, root, serr)) return fail(PHM_ERR_BAD_INPUT, serr);
+  return PHM_OK;
+}
+
+// ---- Q-updating drivers: sweep on the device, rate-matrix update on the host, every iteration ---------------------------
+// maketreelistMCMCbf src/phylomap.cpp:1258-1305 (R/sumstatMCMCbf.R) and maketreelistMCMCks :1802-1872 (R/sumstatMCMCks.R).
+// With opt->n_replicas = S > 1 the replicas are sites sharing one Q: the update sees the statistics summed over sites and
+// `out` holds those sums (S = 1 is the reference's semantics exactly).
+static int32_t run_qupdate(int variant, bool dic, const phm_tree* x, int32_t n, const double* Q, const double* pid,
+                           const double* B, double Omega, const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
+                           const double* prior, int32_t n_prior, const phm_options* opt_in, double* out) {
+  if (!out || !prior || !Q) return fail(PHM_ERR_BAD_INPUT, "out/prior/Q is NULL");
+  if (N < 1) return fail(PHM_ERR_BAD_INPUT, "N must be >= 1");
+  const int need = (variant == PHM_MCMC_BF) ? 4 : 6;
+  if (n_prior < need) return fail(PHM_ERR_BAD_INPUT, variant == PHM_MCMC_BF ? "the two-state drivers need prior = c(a01, b01, a10, b10)" : "the hidden-rates drivers need prior = c(a_l, b_l, a_k, b_k, a_g, b_g)");
+  if (variant == PHM_MCMC_KS && (n < 4 || (n & 1))) return fail(PHM_ERR_BAD_INPUT, "sumstatMCMCks needs n = 2k+2 states with k >= 1 (src/phylomap.cpp:1820; updateksl01 reads rkappas(0))");
+  if (dic && (!x || !x->edge_length || !nen)) return fail(PHM_ERR_BAD_INPUT, "the DIC drivers need x$edge.length and nen (src/phylomap.cpp:3223, :3158)");
+  phm_options o;
+  std::memset(&o, 0, sizeof(o));
+  o.device = -1;
+  if (opt_in) o = *opt_in;
+  if (o.n_replicas <= 0) o.n_replicas = 1;
+  if (dic && o.n_replicas != 1) return fail(PHM_ERR_UNSUPPORTED, "the DIC drivers run one chain (log p(y|Q) is per data set)");
+  o.reduce = o.n_replicas > 1;     // one chain: its own statistics, accumulated in the reference's order (bit-exact vs the oracle)
+  o.iters_per_launch = 1;
+  (void)B;     // the reference aliases the caller's B and then overwrites it entry by entry; B = I + Q/Omega throughout
+  phm_model model;
+  model.n_states = n; model.Q = Q; model.pid = pid; model.B = nullptr; model.Omega = Omega; model.variant = variant;
+  phm_engine* e = nullptr;
+  int32_t st = phm_engine_create(x, &model, &o, N, &e);
+  if (st) return st;
+  std::unique_ptr<phm_engine, void (*)(phm_engine*)> guard(e, phm_engine_destroy);
+  std::string serr;
+  if (!phm::check_reference_orders(e->sched, x->edge, nen, nodelist, root, serr)) return fail(PHM_ERR_BAD_INPUT, serr);
+  const int ecols = e->cols, E = e->sched.n_edge, T = e->sched.n_tips, Nn = e->sched.n_node;
+  const size_t nn = (size_t)n * n;
+
+  // DIC: device state of the per-iteration log-likelihood (expmat(Q t_b) for every branch, then pruning in nen order)
+  DevBuf dQ, dt, ds, dwork, dP, dPL0, dPL, dpid, dup, dll, derr, dorder, dlogs;
+  std::vector<double> loglik;
+  std::vector<int32_t> ll_level_off;
+  std::vector<int32_t> sq(E);
+  if (dic) {
+    std::vector<phm::UpStep> upn(Nn);
+    const int32_t* e1 = x->edge; const int32_t* e2 = x->edge + E;
+    auto code = [&](int32_t node) { return node > T ? node - T - 1 : ~(node - 1); };
+    std::vector<int32_t> height(Nn, 0);
+    int max_h = 0;
+    for (int i = 0; i < Nn; ++i) {
+      const int ea = nen[2 * i] - 1, eb = nen[2 * i + 1] - 1;
+      upn[i].parent = e1[ea] - T - 1;
+      upn[i].child[0] = code(e2[ea]); upn[i].child[1] = code(e2[eb]);
+      upn[i].edge[0] = ea; upn[i].edge[1] = eb;
+      int h = 0;                                        // nen lists children before parents (checked above)
+      for (int c = 0; c < 2; ++c) if (upn[i].child[c] >= 0) h = std::max(h, height[upn[i].child[c]] + 1);
+      height[upn[i].parent] = h; max_h = std::max(max_h, h);
+    }
+    ll_level_off.assign(max_h + 2, 0);
+    for (int i = 0; i < Nn; ++i) ll_level_off[height[upn[i].parent] + 1]++;
+    for (size_t l = 1; l < ll_level_off.size(); ++l) ll_level_off[l] += ll_level_off[l - 1];
+    std::vector<int32_t> ll_order(Nn), pos(ll_level_off.begin(), ll_level_off.end() - 1);
+    for (int i = 0; i < Nn; ++i) ll_order[pos[height[upn[i].parent]]++] = i;
+    HIPCHK(dorder.alloc(sizeof(int32_t) * Nn)); HIPCHK(dlogs.alloc(sizeof(double) * Nn));
+    HIPCHK(hipMemcpy(dorder.p, ll_order.data(), dorder.bytes, hipMemcpyHostToDevice));
+    std::vector<double> PLh((size_t)(2 * T - 1) * n, 0.0);
+    for (int t = 0; t < T; ++t) {
+      if (variant == PHM_MCMC_BF) PLh[(size_t)t * n + (x->states[t] - 1)] = 1.0;                         // :3165
+      else for (int j = (x->states[t] % 2 == 0) ? 1 : 0; j < n; j += 2) PLh[(size_t)t * n + j] = 1.0;   // :3275-3282
+    }
+    HIPCHK(dQ.alloc(sizeof(double) * nn)); HIPCHK(dt.alloc(sizeof(double) * E)); HIPCHK(ds.alloc(sizeof(int32_t) * E));
+    HIPCHK(dwork.alloc(sizeof(double) * nn * 5 * E)); HIPCHK(dP.alloc(sizeof(double) * nn * E));
+    HIPCHK(dPL0.alloc(sizeof(double) * PLh.size())); HIPCHK(dPL.alloc(sizeof(double) * PLh.size()));
+    HIPCHK(dpid.alloc(sizeof(double) * n)); HIPCHK(dup.alloc(sizeof(phm::UpStep) * Nn)); HIPCHK(dll.alloc(sizeof(double)));
+    HIPCHK(derr.alloc(sizeof(uint32_t)));
+    HIPCHK(hipMemcpy(dt.p, x->edge_length, dt.bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dPL0.p, PLh.data(), dPL0.bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dpid.p, pid, dpid.bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dup.p, upn.data(), dup.bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(derr.p, 0, sizeof(uint32_t)));
+    loglik.resize(N);
+  }
+
+  std::vector<double> Qw(Q, Q + nn), Qr, row(ecols);
+  for (int i = 0; i < N && !st; ++i) {
+    st = phm_engine_run(e, 1, nullptr);
+    if (!st) st = phm_engine_sync(e);
+    if (!st) st = phm_engine_read_stats(e, i, 1, row.data());
+    if (st) break;
+    if (dic) {                                        // :3239-3251 / :3379-3391, with the Q that drove this sweep
+      cm_to_rm(Qw.data(), n, Qr);
+      for (int b = 0; b < E; ++b) sq[b] = pade_squarings(Qr.data(), n, x->edge_length[b]);
+      HIPCHK(hipMemcpy(dQ.p, Qr.data(), dQ.bytes, hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(ds.p, sq.data(), ds.bytes, hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpyAsync(dPL.p, dPL0.p, dPL.bytes, hipMemcpyDeviceToDevice, nullptr));
+      HIPCHK(phm::launch_expm_pade(n, dQ.as<double>(), dt.as<double>(), ds.as<int32_t>(), E, dwork.as<double>(), dP.as<double>(), derr.as<uint32_t>(), nullptr));
+      HIPCHK(phm::launch_exp_pl_loglik(n, Nn, T, dup.as<phm::UpStep>(), dorder.as<int32_t>(), ll_level_off, dP.as<double>(), dPL.as<double>(),
+                                       dlogs.as<double>(), dpid.as<double>(), root - 1, dll.as<double>(), nullptr));
+      HIPCHK(hipMemcpy(&loglik[i], dll.p, sizeof(double), hipMemcpyDeviceToHost));
+    }
+    if (variant == PHM_MCMC_BF) phm::bf_updates(Qw.data(), Omega, prior, row.data(), o.seed, (uint32_t)i);
+    else phm::ks_updates(Qw.data(), n, Omega, prior, row.data(), o.seed, (uint32_t)i);
+    if (i + 1 < N) st = phm_engine_set_model(e, Qw.data());
+  }
+  if (st) return st;
+  if (!dic) return phm_engine_read_stats(e, 0, N, out);
+  std::vector<double> tmp((size_t)N * ecols);
+  st = phm_engine_read_stats(e, 0, N, tmp.data());
+  if (st) return st;
+  std::memcpy(out, tmp.data(), sizeof(double) * tmp.size());           // column-major: the first ecols columns are unchanged
+  for (int i = 0; i < N; ++i) out[(size_t)ecols * N + i] = loglik[i];     // log p(y|Q) after the root-state column
+  return PHM_OK;
+}
+
+extern "C" int32_t phm_maketreelistMCMCbf(const phm_tree* x, int32_t n, const double* Q, const double* pid, const double* B,
+                                          double Omega, const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
+                                          const double* prior, int32_t n_prior, const phm_options* opt, double* out) {
+  return run_qupdate(PHM_MCMC_BF, false, x, n, Q, pid, B, Omega, nen, nodelist, root, N, prior, n_prior, opt, out);
+}
+
+extern "C" int32_t phm_maketreelistMCMCks(const phm_tree* x, int32_t n, const double* Q, const double* pid, const double* B,
+                                          double Omega, const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
+                                          const double* prior, int32_t n_prior, const phm_options* opt, double* out) {
+  return run_qupdate(PHM_MCMC_KS, false, x, n, Q, pid, B, Omega, nen, nodelist, root, N, prior, n_prior, opt, out);
+}
+
+// Host-only: apply one iteration's rate-matrix updates to Q (column-major, edited in place) given a statistics row
+// (n dwell sums, n*n counts).  What phm_maketreelistMCMCbf / ks run between sweeps; exported for CPU-side tests.
+extern "C" int32_t phm_qupdate_apply(int32_t variant, int32_t n, double* Q, double Omega, const double* prior, int32_t n_prior,
+                                     const double* row, uint64_t seed, uint32_t iter) {
+  if (!Q || !prior || !row) return fail(PHM_ERR_BAD_INPUT, "phm_qupdate_apply: NULL argument");
+  if (variant == PHM_MCMC_BF || variant == PHM_MCMC_MT) {
+    if (n != 2 || n_prior < 4) return fail(PHM_ERR_BAD_INPUT, "bf / mt: n = 2, prior[4]");
+    if (variant == PHM_MCMC_MT) phm::mt_updates(Q, Omega, prior, row, seed, iter);
+    else phm::bf_updates(Q, Omega, prior, row, seed, iter);
+  } else if (variant == PHM_MCMC_KS || variant == PHM_MCMC_KSMT) {
+    const bool mt = variant == PHM_MCMC_KSMT;
+    if (n < 4 || (n & 1) || n > 64 || n_prior < (mt ? 8 : 6)) return fail(PHM_ERR_BAD_INPUT, "ks: n = 2k+2 in 4..64, prior[6] (ksmt: prior[8])");
+    phm::ks_updates(Q, n, Omega, prior, row, seed, iter, mt);
+  } else return fail(PHM_ERR_BAD_INPUT, "variant must be PHM_MCMC_BF, PHM_MCMC_KS, PHM_MCMC_MT or PHM_MCMC_KSMT");
+  return PHM_OK;
+}
+
+// maketreelistMCMC2sDICt src/phylomap.cpp:3183-3264 and maketreelistMCMCksDICt :3300-3403: the bf / ks drivers plus, every
+// iteration, log p(y|Q) by matrix exponentiation (expmat(Q t_b) for every branch, pruning with scale factors) in one more column.
+extern "C" int32_t phm_maketreelistMCMC2sDICt(const phm_tree* x, int32_t n, const double* Q, const double* pid, const double* B,
+                                              double Omega, const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
+                                              const double* prior, int32_t n_prior, const phm_options* opt, double* out) {
+  return run_qupdate(PHM_MCMC_BF, true, x, n, Q, pid, B, Omega, nen, nodelist, root, N, prior, n_prior, opt, out);
+}
+
+extern "C" int32_t phm_maketreelistMCMCksDICt(const phm_tree* x, int32_t n, const double* Q, const double* pid, const double* B,
+                                              double Omega, const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
+                                              const double* prior, int32_t n_prior, const phm_options* opt, double* out) {
+  return run_qupdate(PHM_MCMC_KS, true, x, n, Q, pid, B, Omega, nen, nodelist, root, N, prior, n_prior, opt, out);
+}
+
+// ---- multi-tree drivers -----------------------------------------------------------------------------------------------
+// maketreelistMCMCmt src/phylomap.cpp:2267-2365 (R/sumstatMCMCmt.R) and maketreelistMCMCksmt :2722-2844 (R/sumstatMCMCksmt.R).
+// One engine over the whole list: tree j's chain lives on replica tile j, so one launch per iteration sweeps every tree with
+// the current Q (:2341-2345); the host then draws the tree whose row is kept (:2347-2350), updates Q from that row and
+// uploads the new model once for all trees.
+static int32_t run_qupdate_mt(int variant, const phm_tree* trees, int32_t n_trees, int32_t n, const double* Q, const double* pid,
+                              double Omega, const int32_t* nen_m, const int32_t* nodelist_m, const int32_t* roots, int32_t N,
+                              const double* prior, int32_t n_prior, const phm_options* opt_in, double* out) {
+  if (!out || !prior || !Q || !trees) return fail(PHM_ERR_BAD_INPUT, "out/prior/Q/trees is NULL");
+  if (N < 1 || n_trees < 1) return fail(PHM_ERR_BAD_INPUT, "N and n_trees must be >= 1");
+  const bool ksmt = variant == PHM_MCMC_KSMT;
+  if (n_prior < (ksmt ? 8 : 4)) return fail(PHM_ERR_BAD_INPUT, ksmt ? "sumstatMCMCksmt needs prior = c(a_l01, b_l01, a_l10, b_l10, a_k, b_k, a_g, b_g) (src/phylomap.cpp:2391-2663)" : "sumstatMCMCmt needs prior = c(a01, b01, a10, b10)");
+  if (ksmt && (n < 4 || (n & 1))) return fail(PHM_ERR_BAD_INPUT, "sumstatMCMCksmt needs n = 2k+2 states with k >= 1 (src/phylomap.cpp:2729)");
+  phm_options o;
+  std::memset(&o, 0, sizeof(o));
+  o.device = -1;
+  if (opt_in) o = *opt_in;
+  if (o.n_replicas > 1) return fail(PHM_ERR_UNSUPPORTED, "the multi-tree drivers run one chain per tree");
+  o.n_replicas = 1; o.reduce = 0; o.tips_per_replica = 0; o.iters_per_launch = 1;
+  phm_model model;
+  model.n_states = n; model.Q = Q; model.pid = pid; model.B = nullptr; model.Omega = Omega; model.variant = variant;
+  phm_engine* e = nullptr;
+  int32_t st = phm_engine_create_multi(trees, n_trees, &model, &o, N, &e);
+  if (st) return st;
+  std::unique_ptr<phm_engine, void (*)(phm_engine*)> guard(e, phm_engine_destroy);
+  const int Nn = e->sched.n_node;
+  if (nen_m || nodelist_m || roots) {      // R's matrices are column-major: row j = elements j, j + n_trees, ...
+    std::vector<int32_t> nen(2 * (size_t)Nn), nodelist(Nn > 1 ? Nn - 1 : 0);
+    std::string serr;
+    for (int j = 0; j < n_trees; ++j) {
+      if (nen_m) for (int i = 0; i < 2 * Nn; ++i) nen[i] = nen_m[j + (size_t)i * n_trees];
+      if (nodelist_m) for (int i = 0; i < Nn - 1; ++i) nodelist[i] = nodelist_m[j + (size_t)i * n_trees];
+      if (!phm::check_reference_orders(e->scheds[j], trees[j].edge, nen_m ? nen.data() : nullptr, nodelist_m ? nodelist.data() : nullptr,
+                                       roots ? roots[j] : e->scheds[j].root + e->sched.n_tips + 1, serr))
+        return fail(PHM_ERR_BAD_INPUT, "tree " + std::to_string(j) + ": " + serr);
+    }
+  }
+  const int ecols = e->cols;                 // n + n*n + 2 + 3k + 1: the engine's root-state column becomes tree_number
+  const size_t nn = (size_t)n * n;
+  std::vector<double> Qw(Q, Q + nn), rows((size_t)n_trees * ecols);
+  for (int i = 0; i < N; ++i) {
+    st = phm_engine_run(e, 1, nullptr);
+    if (!st) st = phm_engine_sync(e);
+    if (!st) st = phm_engine_read_stats(e, i, 1, rows.data());       // one 1 x ecols row per tree
+    if (st) return st;
+    const uint32_t pick = phm::pick_tree(n_trees, o.seed, (uint32_t)i);
+    if (pick >= (uint32_t)n_trees) return fail(PHM_ERR_ZERO_PROB, "sampleOnce ran past the last tree (src/phylomap.cpp:85-89)");
+    const double* row = rows.data() + (size_t)pick * ecols;
+    for (int c = 0; c + 1 < ecols; ++c) out[(size_t)c * N + i] = row[c];
+    out[(size_t)(ecols - 1) * N + i] = (double)pick;                   // :2350, 0-based as the reference stores it
+    if (ksmt) phm::ks_updates(Qw.data(), n, Omega, prior, row, o.seed, (uint32_t)i, true);
+    else phm::mt_updates(Qw.data(), Omega, prior, row, o.seed, (uint32_t)i);
+    if (i + 1 < N) { st = phm_engine_set_model(e, Qw.data()); if (st) return st; }
+  }
+  return PHM_OK;
+}
+
+extern "C" int32_t phm_maketreelistMCMCmt(const phm_tree* trees, int32_t n_trees, int32_t n, const double* Q, const double* pid,
+                                          const double* B, double Omega, const int32_t* nen_m, const int32_t* nodelist_m,
+                                          const int32_t* roots, int32_t N, const double* prior, int32_t n_prior,
+                                          const phm_options* opt, double* out) {
+  (void)B;
+  return run_qupdate_mt(PHM_MCMC_MT, trees, n_trees, n, Q, pid, Omega, nen_m, nodelist_m, roots, N, prior, n_prior, opt, out);
+}
+
+extern "C" int32_t phm_maketreelistMCMCksmt(const phm_tree* trees, int32_t n_trees, int32_t n, const double* Q, const double* pid,
+                                            const double* B, double Omega, const int32_t* nen_m, const int32_t* nodelist_m,
+                                            const int32_t* roots, int32_t N, const double* prior, int32_t n_prior,
+                                            const phm_options* opt, double* out) {
+  (void)B;
+  return run_qupdate_mt(PHM_MCMC_KSMT, trees, n_trees, n, Q, pid, Omega, nen_m, nodelist_m, roots, N, prior, n_prior, opt, out);
+}

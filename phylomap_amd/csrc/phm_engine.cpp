@@ -1,129 +1,10 @@
-// phm_api.cpp -- C-ABI of the engine (include/phylomap_hip.h): input validation, HBM layout, launches.
+// phm_engine.cpp -- the resident engine behind the C-ABI (include/phylomap_hip.h): input validation, HBM layout of the
+// three mappings of the sweep (phm_mcmc.hip / phm_tiles.hip / phm_narrow.hip, phm_wide.hip for n > 4), launches, statistics.
 //
-// Host-side counterpart of the exported drivers maketreelistMCMC / _bigtree / SPARSE
-// (src/phylomap.cpp:891-986, 822-870): unpack `x`, set up B, allocate the statistics matrix, run N sweeps.
-// Built with -ffp-contract=off: the B^k chain tables computed here must carry exactly the bits the
-// kernels (and the oracle) would produce by running the chains themselves.
-#include "../../include/phylomap_hip.h"
-
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <cmath>
-#include <cstdio>
-#include <cstring>
-#include <memory>
-#include <string>
-#include <vector>
-
-#include "phm_exp.h"
-#include "phm_mcmc.h"
-#include "phm_qupdate.h"
-#include "phm_sched.h"
-#include "phm_narrow.h"
-#include "phm_tiles.h"
-#include "phm_wide.h"
-
-namespace {
-
-thread_local std::string g_err;
-
-int32_t fail(int32_t st, const std::string& msg) { g_err = msg; return st; }
-
-#define HIPCHK(call)                                                                              \
-  do {                                                                                            \
-    hipError_t _e = (call);                                                                       \
-    if (_e != hipSuccess) {                                                                       \
-      int32_t _st = (_e == hipErrorOutOfMemory) ? PHM_ERR_OOM : PHM_ERR_NO_DEVICE;                \
-      return fail(_st, std::string(#call) + ": " + hipGetErrorString(_e));                        \
-    }                                                                                             \
-  } while (0)
-
-struct DevBuf {
-  void* p = nullptr;
-  size_t bytes = 0;
-  ~DevBuf() { if (p) (void)hipFree(p); }
-  hipError_t alloc(size_t n) { bytes = n; return hipMalloc(&p, n ? n : 16); }
-  template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
-};
-
-int32_t select_device(int32_t device) {
-  int n = 0;
-  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(PHM_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
-  if (device >= 0) {
-    if (device >= n) return fail(PHM_ERR_NO_DEVICE, "device ordinal out of range");
-    HIPCHK(hipSetDevice(device));
-  }
-  return PHM_OK;
-}
-
-int32_t device_status(uint32_t derr) {
-  if (derr & phm::DERR_ZERO_PROB) return fail(PHM_ERR_ZERO_PROB, "all-zero or non-finite probability vector while sampling a state (RcppArmadillo::sample would throw)");
-  if (derr & phm::DERR_CAPACITY) return fail(PHM_ERR_CAPACITY, "a replica tile outgrew its dwell-stream capacity; lower phm_options.cap_tail");
-  if (derr & phm::DERR_UNIF_CAP) return fail(PHM_ERR_UNIF_CAP, "newunifSample needed more than 300 jumps on a branch (src/phylomap.cpp:120)");
-  if (derr & phm::DERR_SAMPLEONCE) return fail(PHM_ERR_ZERO_PROB, "sampleOnce ran past the last state (src/phylomap.cpp:85-89)");
-  return PHM_OK;
-}
-
-}  // namespace
-
-// -------------------------------------------------------------------------------------------------
-struct phm_engine {
-  int n = 0, cols = 0, dcols = 0, variant = 0;   // cols: result columns; dcols: columns kept on the device
-  std::vector<double> qparams;                     // bf/ks: l01, l10, rkappas, lkappas, gammas of the CURRENT Q (recordQks :1789-1798)
-  std::vector<std::vector<double>> qhist;          // ... as recorded at the start of every iteration that has run
-  double Omega = 0.0;
-  std::vector<double> hB2, hBc, hscale, hpid;      // current model, row-major
-  int S = 0, S_pad = 0, tiles = 0, max_iters = 0, iters_done = 0, ipl = 0;
-  int reduce = 0, device = 0;
-  phm::Schedule sched;                 // tree 0 (every tree of a list has the same tip / edge counts)
-  std::vector<phm::Schedule> scheds;   // one per tree
-  int n_trees = 1, S_tree = 0, tpt = 0;   // list of trees: S_tree chains per tree on tpt tiles each; S = n_trees * S_tree
-  DevBuf d_roots;
-  // logical replica r (tree-major) -> lane index in the padded device layout
-  int pad_index(int r) const { return n_trees > 1 ? (r / S_tree) * tpt * 64 + r % S_tree : r; }
-  std::vector<uint8_t> tips_host;      // 0-based, [n_tips] or [tile][n_tips][64]
-  bool tips_per_replica = false;
-  int64_t rows = 0;
-  DevBuf d_mask;
-  DevBuf d_up, d_down, d_col, d_row, d_tips, d_mcount, d_dw0, d_dw1, d_cursor, d_PL, d_nstate, d_stats, d_err, d_seg, d_red;
-  phm::McmcParams<2> p2;
-  phm::McmcParams<3> p3;
-  phm::McmcParams<4> p4;
-  bool wide = false;                   // 5..64 states: phm_wide.hip
-  bool ring = true;                    // one ring per tile for both dwell streams (else two buffers)
-  phm::WideParams pw;
-  DevBuf d_B2, d_Bc, d_scale, d_pid;
-  // branch-parallel mapping for few chains on a large tree (phm_narrow.hip)
-  bool narrow = false;
-  std::vector<int32_t> nw_up_off, nw_down_off;     // level boundaries into up_order / down_order
-  std::vector<int64_t> nw_off;                     // CSR offsets of the branch slots
-  int nw_klong = 0;
-  int64_t nw_total_cap = 0;
-  DevBuf d_nw_up_order, d_nw_down_order, d_nw_border, d_nw_off, d_nw_colL, d_nw_rowL, d_nw_maskL, d_nw_mcount, d_nw_dwA, d_nw_dwB,
-      d_nw_mstate, d_nw_mlen, d_nw_estate, d_nw_part, d_nw_rowbuf;
-  phm::NarrowParams<2> n2;
-  phm::NarrowParams<3> n3;
-  phm::NarrowParams<4> n4;
-  // wave per (tile, branch) mapping for 10^2 .. 10^5 replicas (phm_tiles.hip); shares the level schedules and long tables
-  bool tiled = false;
-  std::vector<int32_t> tl_slot;                    // first row of every branch slot
-  DevBuf d_tl_slot, d_tl_pdw, d_tl_pchunk, d_tl_cnt, d_tl_estate, d_tl_pseg, d_tl_segprev;
-  phm::TileParams<2> t2;
-  phm::TileParams<3> t3;
-  phm::TileParams<4> t4;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  hipStream_t last_stream = nullptr;
-  bool timing_pending = false;
-  double last_ms = 0.0;
-  int last_launches = 0;
-  int64_t bytes = 0;
-  unsigned long long seg_total = 0;
-  ~phm_engine() {
-    if (ev0) (void)hipEventDestroy(ev0);
-    if (ev1) (void)hipEventDestroy(ev1);
-  }
-};
+// Host-side counterpart of what the exported drivers do before and after their N-loop (src/phylomap.cpp:891-986, 822-870):
+// unpack `x`, set up B, allocate the statistics matrix.  Built with -ffp-contract=off: the B^k chain tables computed here
+// must carry exactly the bits the kernels (and the oracle) would produce by running the chains themselves.
+#include "phm_internal.h"
 
 namespace {
 
@@ -162,49 +43,6 @@ void fill_params(phm_engine* e, phm::McmcParams<NS>& p, const double* B2, const 
   p.PL = e->d_PL.as<double>(); p.nstate = e->d_nstate.as<uint8_t>(); p.stats = e->d_stats.as<double>();
   p.err = e->d_err.as<uint32_t>(); p.segcnt = e->d_seg.as<unsigned long long>();
 }
-
-// chain tables: col[k][j][:] = Bc^k e_j  (v <- Bc v), row[k][j][:] = (Bc^T)^k e_j (w <- Bc^T w);
-// same left-to-right unfused sums as the kernels' matvec_u, so entries are bit-identical to running the chain.
-void build_chain_tables(const double* Bc, int n, int ktab, std::vector<double>& col, std::vector<double>& row) {
-  col.assign((size_t)ktab * n * n, 0.0);
-  row.assign((size_t)ktab * n * n, 0.0);
-  for (int j = 0; j < n; ++j) { col[(size_t)j * n + j] = 1.0; row[(size_t)j * n + j] = 1.0; }
-  for (int k = 1; k < ktab; ++k)
-    for (int j = 0; j < n; ++j) {
-      const double* v = &col[((size_t)(k - 1) * n + j) * n];
-      double* y = &col[((size_t)k * n + j) * n];
-      for (int i = 0; i < n; ++i) {
-        double acc = Bc[i * n] * v[0];
-        for (int c = 1; c < n; ++c) acc += Bc[i * n + c] * v[c];
-        y[i] = acc;
-      }
-      const double* w = &row[((size_t)(k - 1) * n + j) * n];
-      double* z = &row[((size_t)k * n + j) * n];
-      for (int c = 0; c < n; ++c) {
-        double acc = Bc[c] * w[0];
-        for (int r = 1; r < n; ++r) acc += Bc[r * n + c] * w[r];
-        z[c] = acc;
-      }
-    }
-}
-
-int32_t validate_tree_paths(const phm_tree* x, int n, int n_tip_vectors) {
-  if (!x || !x->edge || !x->states || !x->map_off || !x->maps || !x->mapnames) return fail(PHM_ERR_BAD_INPUT, "tree: missing field");
-  for (int64_t i = 0; i < (int64_t)n_tip_vectors * x->n_tips; ++i)
-    if (x->states[i] < 1 || x->states[i] > n) return fail(PHM_ERR_BAD_INPUT, "x$states must be in 1..n");
-  if (x->map_off[0] != 0) return fail(PHM_ERR_BAD_INPUT, "map_off[0] must be 0");
-  for (int b = 0; b < x->n_edge; ++b) {
-    int m = x->map_off[b + 1] - x->map_off[b];
-    if (m < 1) return fail(PHM_ERR_BAD_INPUT, "every branch needs at least one segment in x$maps");
-    if (m > 50000) return fail(PHM_ERR_BAD_INPUT, "more than 50000 segments on one branch");
-    for (int i = x->map_off[b]; i < x->map_off[b + 1]; ++i) {
-      if (x->mapnames[i] < 1 || x->mapnames[i] > n) return fail(PHM_ERR_BAD_INPUT, "x$mapnames must be in 1..n");
-      if (!std::isfinite(x->maps[i]) || x->maps[i] < 0.0) return fail(PHM_ERR_BAD_INPUT, "x$maps must be finite and non-negative");
-    }
-  }
-  return PHM_OK;
-}
-
 
 // Model matrices from R's column-major Q / B: dense B2, chain matrix Bc (thresholded for SPARSE), rexp scales, and the
 // parameter columns recordQ / recordQks write (src/phylomap.cpp:1181-1185, :1789-1798).
@@ -580,7 +418,7 @@ int32_t phm_device_count(void) {
   return n;
 }
 
-const char* phm_last_error(void) { return g_err.c_str(); }
+const char* phm_last_error(void) { return g_phm_err.c_str(); }
 
 const char* phm_status_string(int32_t s) {
   switch (s) {
@@ -1058,270 +896,8 @@ int32_t phm_engine_info(phm_engine* e, phm_info* info) {
 
 void phm_engine_destroy(phm_engine* e) { delete e; }
 
-// ---- reference-shaped one-shot drivers -------------------------------------------------------------
-static int32_t run_mcmc_oneshot(int variant, const phm_tree* x, int32_t n, const double* Q, const double* pid,
-                                const double* B, double Omega, const int32_t* nen, const int32_t* nodelist, int32_t root,
-                                int32_t N, const phm_options* opt, double* out) {
-  if (!out) return fail(PHM_ERR_BAD_INPUT, "out is NULL");
-  if (N < 1) return fail(PHM_ERR_BAD_INPUT, "N must be >= 1");
-  phm_model model;
-  model.n_states = n; model.Q = Q; model.pid = pid; model.B = B; model.Omega = Omega; model.variant = variant;
-  phm_engine* e = nullptr;
-  int32_t st = phm_engine_create(x, &model, opt, N, &e);
-  if (st) return st;
-  std::string serr;
-  if (!phm::check_reference_orders(e->sched, x->edge, nen, nodelist, root, serr)) { phm_engine_destroy(e); return fail(PHM_ERR_BAD_INPUT, serr); }
-  st = phm_engine_run(e, N, nullptr);
-  if (!st) st = phm_engine_sync(e);
-  if (!st) st = phm_engine_read_stats(e, 0, N, out);
-  phm_engine_destroy(e);
-  return st;
-}
-
-int32_t phm_maketreelistMCMC(const phm_tree* x, int32_t n, const double* Q, const double* pid, const double* B, double Omega,
-                             const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N, const phm_options* opt,
-                             double* out) {
-  return run_mcmc_oneshot(PHM_MCMC, x, n, Q, pid, B, Omega, nen, nodelist, root, N, opt, out);
-}
-int32_t phm_maketreelistMCMC_bigtree(const phm_tree* x, int32_t n, const double* Q, const double* pid, const double* B,
-                                     double Omega, const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
-                                     const phm_options* opt, double* out) {
-  return run_mcmc_oneshot(PHM_MCMC_BIGTREE, x, n, Q, pid, B, Omega, nen, nodelist, root, N, opt, out);
-}
-int32_t phm_maketreelistMCMCks_sweep(const phm_tree* x, int32_t n, const double* Q, const double* pid, const double* B,
-                                     double Omega, const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
-                                     const phm_options* opt, double* out) {
-  return run_mcmc_oneshot(PHM_MCMC_KS, x, n, Q, pid, B, Omega, nen, nodelist, root, N, opt, out);
-}
-int32_t phm_SPARSEmaketreelistMCMC(const phm_tree* x, int32_t n, const double* Q, const double* pid, const double* B,
-                                   double Omega, const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
-                                   const phm_options* opt, double* out) {
-  return run_mcmc_oneshot(PHM_MCMC_SPARSE, x, n, Q, pid, B, Omega, nen, nodelist, root, N, opt, out);
-}
-
 }  // extern "C"
 
-// ---- batched transition matrices -------------------------------------------------------------------
-namespace {
-
-void cm_to_rm(const double* cm, int n, std::vector<double>& rm) {
-  rm.resize((size_t)n * n);
-  for (int i = 0; i < n; ++i)
-    for (int j = 0; j < n; ++j) rm[(size_t)i * n + j] = cm[i + (size_t)j * n];
-}
-
-struct Timer {
-  hipEvent_t a = nullptr, b = nullptr;
-  ~Timer() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
-};
-
-// squaring count of arma::expmat: s = max(0, exponent(frexp(log2 ||A||_inf)) + 1)
-int pade_squarings(const double* Q_rm, int n, double t) {
-  double norm = 0.0;
-  for (int i = 0; i < n; ++i) {
-    double r = 0.0;
-    for (int j = 0; j < n; ++j) r += std::fabs(Q_rm[(size_t)i * n + j] * t);
-    if (r > norm) norm = r;
-  }
-  double l2 = (norm > 0.0) ? std::log2(norm) : 0.0;
-  int ex = 0;
-  (void)std::frexp(l2, &ex);
-  return std::max(0, ex + 1);
-}
-
-}  // namespace
-
-extern "C" {
-
-static int32_t expm_eigen_impl(bool mfma, int32_t n, const double* lefts, const double* rights, const double* d, const double* t,
-                               int32_t n_t, int32_t device, double* out, double* kernel_ms) {
-  if (n < 1 || n > 256 || !lefts || !rights || !d || !t || !out || n_t < 0) return fail(PHM_ERR_BAD_INPUT, "phm_expm_eigen: bad arguments");
-  int32_t st = select_device(device);
-  if (st) return st;
-  if (n_t == 0) return PHM_OK;
-  std::vector<double> L, R, dv(n);
-  cm_to_rm(lefts, n, L); cm_to_rm(rights, n, R);
-  for (int i = 0; i < n; ++i) dv[i] = d[i + (size_t)i * n];
-  const size_t nn = (size_t)n * n;
-  DevBuf dL, dR, dd, dt, dout;
-  HIPCHK(dL.alloc(sizeof(double) * nn)); HIPCHK(dR.alloc(sizeof(double) * nn)); HIPCHK(dd.alloc(sizeof(double) * n));
-  HIPCHK(dt.alloc(sizeof(double) * n_t)); HIPCHK(dout.alloc(sizeof(double) * nn * n_t));
-  HIPCHK(hipMemcpy(dL.p, L.data(), dL.bytes, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(dR.p, R.data(), dR.bytes, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(dd.p, dv.data(), dd.bytes, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(dt.p, t, dt.bytes, hipMemcpyHostToDevice));
-  Timer tm;
-  HIPCHK(hipEventCreate(&tm.a)); HIPCHK(hipEventCreate(&tm.b));
-  HIPCHK(hipEventRecord(tm.a, nullptr));
-  if (mfma) HIPCHK(phm::launch_expm_eigen_mfma(n, dL.as<double>(), dR.as<double>(), dd.as<double>(), dt.as<double>(), n_t, dout.as<double>(), nullptr));
-  else HIPCHK(phm::launch_expm_eigen(n, dL.as<double>(), dR.as<double>(), dd.as<double>(), dt.as<double>(), n_t, dout.as<double>(), nullptr));
-  HIPCHK(hipEventRecord(tm.b, nullptr));
-  HIPCHK(hipMemcpy(out, dout.p, dout.bytes, hipMemcpyDeviceToHost));
-  if (kernel_ms) { float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, tm.a, tm.b)); *kernel_ms = ms; }
-  return PHM_OK;
-}
-
-int32_t phm_expm_eigen(int32_t n, const double* lefts, const double* rights, const double* d, const double* t,
-                       int32_t n_t, int32_t device, double* out, double* kernel_ms) {
-  return expm_eigen_impl(false, n, lefts, rights, d, t, n_t, device, out, kernel_ms);
-}
-
-int32_t phm_expm_eigen_mfma(int32_t n, const double* lefts, const double* rights, const double* d, const double* t,
-                            int32_t n_t, int32_t device, double* out, double* kernel_ms) {
-  if (n <= 16 || n > 64) return fail(PHM_ERR_UNSUPPORTED, "phm_expm_eigen_mfma: 16 < n_states <= 64 (smaller matrices do not fill an MFMA tile)");
-  return expm_eigen_impl(true, n, lefts, rights, d, t, n_t, device, out, kernel_ms);
-}
-
-static int32_t expm_pade_impl(bool mfma, int32_t n, const double* Q, const double* t, int32_t n_t, int32_t device, double* out,
-                              double* kernel_ms) {
-  if (n < 1 || n > 128 || !Q || !t || !out || n_t < 0) return fail(PHM_ERR_BAD_INPUT, "phm_expm_pade: bad arguments (n <= 128)");
-  int32_t st = select_device(device);
-  if (st) return st;
-  if (n_t == 0) return PHM_OK;
-  std::vector<double> Qr;
-  cm_to_rm(Q, n, Qr);
-  std::vector<int32_t> sq(n_t);
-  for (int b = 0; b < n_t; ++b) sq[b] = pade_squarings(Qr.data(), n, t[b]);
-  const size_t nn = (size_t)n * n;
-  DevBuf dQ, dt, ds, dwork, dout, derr;
-  HIPCHK(dQ.alloc(sizeof(double) * nn)); HIPCHK(dt.alloc(sizeof(double) * n_t)); HIPCHK(ds.alloc(sizeof(int32_t) * n_t));
-  HIPCHK(dwork.alloc(mfma ? 16 : sizeof(double) * nn * 5 * n_t)); HIPCHK(dout.alloc(sizeof(double) * nn * n_t)); HIPCHK(derr.alloc(sizeof(uint32_t)));
-  HIPCHK(hipMemcpy(dQ.p, Qr.data(), dQ.bytes, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(dt.p, t, dt.bytes, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(ds.p, sq.data(), ds.bytes, hipMemcpyHostToDevice));
-  HIPCHK(hipMemset(derr.p, 0, sizeof(uint32_t)));
-  Timer tm;
-  HIPCHK(hipEventCreate(&tm.a)); HIPCHK(hipEventCreate(&tm.b));
-  HIPCHK(hipEventRecord(tm.a, nullptr));
-  if (mfma) HIPCHK(phm::launch_expm_pade_mfma(n, dQ.as<double>(), dt.as<double>(), ds.as<int32_t>(), n_t, dout.as<double>(), derr.as<uint32_t>(), nullptr));
-  else HIPCHK(phm::launch_expm_pade(n, dQ.as<double>(), dt.as<double>(), ds.as<int32_t>(), n_t, dwork.as<double>(), dout.as<double>(), derr.as<uint32_t>(), nullptr));
-  HIPCHK(hipEventRecord(tm.b, nullptr));
-  HIPCHK(hipMemcpy(out, dout.p, dout.bytes, hipMemcpyDeviceToHost));
-  uint32_t derrh = 0;
-  HIPCHK(hipMemcpy(&derrh, derr.p, sizeof derrh, hipMemcpyDeviceToHost));
-  if (kernel_ms) { float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, tm.a, tm.b)); *kernel_ms = ms; }
-  if (derrh) return fail(PHM_ERR_BAD_INPUT, "phm_expm_pade: singular Pade denominator");
-  return PHM_OK;
-}
-
-int32_t phm_expm_pade(int32_t n, const double* Q, const double* t, int32_t n_t, int32_t device, double* out, double* kernel_ms) {
-  return expm_pade_impl(false, n, Q, t, n_t, device, out, kernel_ms);
-}
-
-int32_t phm_expm_pade_mfma(int32_t n, const double* Q, const double* t, int32_t n_t, int32_t device, double* out,
-                           double* kernel_ms) {
-  if (n <= 16 || n > 64) return fail(PHM_ERR_UNSUPPORTED, "phm_expm_pade_mfma: 16 < n_states <= 64 (smaller matrices do not fill an MFMA tile)");
-  return expm_pade_impl(true, n, Q, t, n_t, device, out, kernel_ms);
-}
-
-// maketreelistEXP, src/phylomap.cpp:3001-3051.  P(t_b) and the pruning pass are computed ONCE (the reference
-// recomputes both every iteration although Q never changes, :2980-2981).
-int32_t phm_maketreelistEXP(const phm_tree* x, int32_t n, const double* Q, const double* pid, const int32_t* nen,
-                            const int32_t* nodelist, int32_t root, int32_t N, const double* lefts, const double* rights,
-                            const double* d, const phm_options* opt_in, double* out) {
-  if (!x || !Q || !pid || !lefts || !rights || !d || !out) return fail(PHM_ERR_BAD_INPUT, "phm_maketreelistEXP: NULL argument");
-  if (N < 1) return fail(PHM_ERR_BAD_INPUT, "N must be >= 1");
-  if (n < 2) return fail(PHM_ERR_BAD_INPUT, "n_states must be >= 2");
-  if (n > 64) return fail(PHM_ERR_UNSUPPORTED, "this build has EXP kernels for n_states <= 64 only");
-  if (!x->edge_length) return fail(PHM_ERR_BAD_INPUT, "x$edge.length is required (src/phylomap.cpp:3034)");
-  phm_options o;
-  std::memset(&o, 0, sizeof(o));
-  o.device = -1;
-  if (opt_in) o = *opt_in;
-  int32_t st = validate_tree_paths(x, n, 1);
-  if (st) return st;
-  phm::Schedule s;
-  std::string serr;
-  if (!phm::build_schedule(x->n_tips, x->n_node, x->n_edge, x->edge, s, serr)) return fail(PHM_ERR_BAD_INPUT, "tree: " + serr);
-  if (!phm::check_reference_orders(s, x->edge, nen, nodelist, root, serr)) return fail(PHM_ERR_BAD_INPUT, serr);
-  const int E = s.n_edge, T = s.n_tips;
-  for (int b = 0; b < E; ++b)
-    if (!std::isfinite(x->edge_length[b]) || x->edge_length[b] < 0.0) return fail(PHM_ERR_BAD_INPUT, "edge.length must be finite and non-negative");
-
-  std::vector<double> L, R, dv(n), B2((size_t)n * n);
-  cm_to_rm(lefts, n, L); cm_to_rm(rights, n, R);
-  double minq = Q[0];
-  for (int i = 0; i < n; ++i) { dv[i] = d[i + (size_t)i * n]; minq = std::min(minq, Q[i + (size_t)i * n]); }
-  const double rate = -1.0 * minq;                                             // :3008
-  if (!(rate > 0.0)) return fail(PHM_ERR_BAD_INPUT, "Q must have a negative diagonal entry");
-  for (int i = 0; i < n; ++i)
-    for (int j = 0; j < n; ++j) {
-      double b = ((i == j) ? 1.0 : 0.0) + Q[i + (size_t)j * n] / rate;          // :3011
-      if (!(b >= 0.0)) return fail(PHM_ERR_BAD_INPUT, "I + Q/poissonRate must be non-negative");
-      B2[(size_t)i * n + j] = b;
-    }
-  std::vector<double> col, rowtab;
-  build_chain_tables(B2.data(), n, phm::UNIF_CAP + 1, col, rowtab);
-
-  st = select_device(o.device);
-  if (st) return st;
-  const size_t nn = (size_t)n * n;
-  const int tiles = (N + 63) / 64;
-  const int cols = n + n * (n - 1);
-  DevBuf dL, dR, dd, dt, dP, dPL, dup, ddown, dcol, dB2, dtips, dnst, dtimes, dout, derr;
-  HIPCHK(dL.alloc(sizeof(double) * nn)); HIPCHK(dR.alloc(sizeof(double) * nn)); HIPCHK(dd.alloc(sizeof(double) * n));
-  HIPCHK(dt.alloc(sizeof(double) * E)); HIPCHK(dP.alloc(sizeof(double) * nn * E));
-  HIPCHK(dPL.alloc(sizeof(double) * (size_t)(2 * T - 1) * n));
-  HIPCHK(dup.alloc(sizeof(phm::UpStep) * s.up.size())); HIPCHK(ddown.alloc(sizeof(phm::DownStep) * s.down.size()));
-  HIPCHK(dcol.alloc(sizeof(double) * col.size())); HIPCHK(dB2.alloc(sizeof(double) * nn)); HIPCHK(dtips.alloc(T));
-  HIPCHK(dnst.alloc((size_t)tiles * s.n_node * 64)); HIPCHK(dtimes.alloc(sizeof(double) * (size_t)tiles * phm::UNIF_CAP * 64));
-  HIPCHK(dout.alloc(sizeof(double) * (size_t)N * cols)); HIPCHK(derr.alloc(sizeof(uint32_t)));
-  std::vector<double> PLh((size_t)(2 * T - 1) * n, 0.0);
-  std::vector<uint8_t> tips(T);
-  for (int t = 0; t < T; ++t) { tips[t] = (uint8_t)(x->states[t] - 1); PLh[(size_t)t * n + tips[t]] = 1.0; }   // :2883
-  HIPCHK(hipMemcpy(dL.p, L.data(), dL.bytes, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(dR.p, R.data(), dR.bytes, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(dd.p, dv.data(), dd.bytes, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(dt.p, x->edge_length, dt.bytes, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(dPL.p, PLh.data(), dPL.bytes, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(dup.p, s.up.data(), dup.bytes, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(ddown.p, s.down.data(), ddown.bytes, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(dcol.p, col.data(), dcol.bytes, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(dB2.p, B2.data(), dB2.bytes, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(dtips.p, tips.data(), T, hipMemcpyHostToDevice));
-  HIPCHK(hipMemset(derr.p, 0, sizeof(uint32_t)));
-  HIPCHK(hipMemset(dnst.p, 0, dnst.bytes));
-
-  HIPCHK(phm::launch_expm_eigen(n, dL.as<double>(), dR.as<double>(), dd.as<double>(), dt.as<double>(), E, dP.as<double>(), nullptr));   // :3042
-  HIPCHK(phm::launch_exp_pl(n, s.n_node, T, dup.as<phm::UpStep>(), dP.as<double>(), dPL.as<double>(), nullptr));                       // :3043
-
-  auto fill = [&](auto& p) {
-    p.n_tips = T; p.n_node = s.n_node; p.n_edge = E; p.root = s.root; p.N = N; p.n_tiles = tiles;
-    p.seed_lo = (uint32_t)(o.seed & 0xFFFFFFFFull); p.seed_hi = (uint32_t)(o.seed >> 32); p.replica = (uint32_t)o.replica_offset;
-    p.poisson_rate = rate;
-    for (int i = 0; i < n; ++i) p.pid[i] = pid[i];
-    p.down = ddown.as<phm::DownStep>(); p.P = dP.as<double>(); p.PL = dPL.as<double>(); p.edge_length = dt.as<double>();
-    p.colpow = dcol.as<double>(); p.B2 = dB2.as<double>(); p.tips = dtips.as<uint8_t>(); p.nstate = dnst.as<uint8_t>();
-    p.times = dtimes.as<double>(); p.out = dout.as<double>(); p.err = derr.as<uint32_t>();
-  };
-  hipError_t le = hipSuccess;
-  if (n == 2) { phm::ExpParams<2> p; fill(p); le = phm::launch_exp_sample<2>(p, nullptr); }
-  if (n == 3) { phm::ExpParams<3> p; fill(p); le = phm::launch_exp_sample<3>(p, nullptr); }
-  if (n == 4) { phm::ExpParams<4> p; fill(p); le = phm::launch_exp_sample<4>(p, nullptr); }
-  if (n > 4) {
-    DevBuf dpid;
-    HIPCHK(dpid.alloc(sizeof(double) * n));
-    HIPCHK(hipMemcpy(dpid.p, pid, sizeof(double) * n, hipMemcpyHostToDevice));
-    HIPCHK(hipMemset(dout.p, 0, dout.bytes));
-    phm::ExpWideParams p;
-    p.n_states = n; p.n_tips = T; p.n_node = s.n_node; p.n_edge = E; p.root = s.root; p.N = N; p.n_tiles = tiles;
-    p.seed_lo = (uint32_t)(o.seed & 0xFFFFFFFFull); p.seed_hi = (uint32_t)(o.seed >> 32); p.replica = (uint32_t)o.replica_offset;
-    p.poisson_rate = rate; p.pid = dpid.as<double>();
-    p.down = ddown.as<phm::DownStep>(); p.P = dP.as<double>(); p.PL = dPL.as<double>(); p.edge_length = dt.as<double>();
-    p.colpow = dcol.as<double>(); p.B2 = dB2.as<double>(); p.tips = dtips.as<uint8_t>(); p.nstate = dnst.as<uint8_t>();
-    p.times = dtimes.as<double>(); p.out = dout.as<double>(); p.err = derr.as<uint32_t>();
-    le = phm::launch_exp_wide(p, nullptr);
-    HIPCHK(le);
-    HIPCHK(hipDeviceSynchronize());
-  }
-  HIPCHK(le);
-  HIPCHK(hipMemcpy(out, dout.p, dout.bytes, hipMemcpyDeviceToHost));
-  uint32_t derrh = 0;
-  HIPCHK(hipMemcpy(&derrh, derr.p, sizeof derrh, hipMemcpyDeviceToHost));
-  return device_status(derrh);
-}
-
-}  // extern "C"
 
 // Device-resident reduced statistics (reduce mode): runs the fixed-order tile reduction on `hip_stream` and
 // returns a DEVICE pointer to n x cols doubles, row-major [iteration][column].  For multi-GPU callers that
@@ -1364,15 +940,6 @@ extern "C" int32_t phm_engine_time_pruning(phm_engine* e, int32_t n_iters, void*
   return PHM_OK;
 }
 
-// Native O(E) replacement of pruningwiseedgeorder / makenodelist / myreorder (R/sumstatMCMC.R:1-18); pure host code.
-extern "C" int32_t phm_tree_orders(int32_t n_tips, int32_t n_edge, const int32_t* edge, int32_t* nen, int32_t* nodelist,
-                                   int32_t* root) {
-  if (!edge || !nen || !nodelist || !root) return fail(PHM_ERR_BAD_INPUT, "phm_tree_orders: NULL argument");
-  std::string serr;
-  if (!phm::pruningwise_orders(n_tips, n_edge, edge, nen, nodelist, root, serr)) return fail(PHM_ERR_BAD_INPUT, serr);
-  return PHM_OK;
-}
-
 // Replace the rate matrix between sweeps (the Q-updating variants edit Q and B after every iteration,
 // src/phylomap.cpp:1212-1217, :1862-1866).  Q column-major; B = I + Q/Omega is recomputed.  The chain state is kept.
 extern "C" int32_t phm_engine_set_model(phm_engine* e, const double* Q) {
@@ -1384,229 +951,4 @@ extern "C" int32_t phm_engine_set_model(phm_engine* e, const double* Q) {
   if (st) return st;
   e->hB2 = B2; e->hBc = Bc; e->hscale = scale; e->qparams = qp;
   return upload_model(e);
-}
-
-// ---- Q-updating drivers: sweep on the device, rate-matrix update on the host, every iteration ---------------------------
-// maketreelistMCMCbf src/phylomap.cpp:1258-1305 (R/sumstatMCMCbf.R) and maketreelistMCMCks :1802-1872 (R/sumstatMCMCks.R).
-// With opt->n_replicas = S > 1 the replicas are sites sharing one Q: the update sees the statistics summed over sites and
-// `out` holds those sums (S = 1 is the reference's semantics exactly).
-static int32_t run_qupdate(int variant, bool dic, const phm_tree* x, int32_t n, const double* Q, const double* pid,
-                           const double* B, double Omega, const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
-                           const double* prior, int32_t n_prior, const phm_options* opt_in, double* out) {
-  if (!out || !prior || !Q) return fail(PHM_ERR_BAD_INPUT, "out/prior/Q is NULL");
-  if (N < 1) return fail(PHM_ERR_BAD_INPUT, "N must be >= 1");
-  const int need = (variant == PHM_MCMC_BF) ? 4 : 6;
-  if (n_prior < need) return fail(PHM_ERR_BAD_INPUT, variant == PHM_MCMC_BF ? "the two-state drivers need prior = c(a01, b01, a10, b10)" : "the hidden-rates drivers need prior = c(a_l, b_l, a_k, b_k, a_g, b_g)");
-  if (variant == PHM_MCMC_KS && (n < 4 || (n & 1))) return fail(PHM_ERR_BAD_INPUT, "sumstatMCMCks needs n = 2k+2 states with k >= 1 (src/phylomap.cpp:1820; updateksl01 reads rkappas(0))");
-  if (dic && (!x || !x->edge_length || !nen)) return fail(PHM_ERR_BAD_INPUT, "the DIC drivers need x$edge.length and nen (src/phylomap.cpp:3223, :3158)");
-  phm_options o;
-  std::memset(&o, 0, sizeof(o));
-  o.device = -1;
-  if (opt_in) o = *opt_in;
-  if (o.n_replicas <= 0) o.n_replicas = 1;
-  if (dic && o.n_replicas != 1) return fail(PHM_ERR_UNSUPPORTED, "the DIC drivers run one chain (log p(y|Q) is per data set)");
-  o.reduce = o.n_replicas > 1;     // one chain: its own statistics, accumulated in the reference's order (bit-exact vs the oracle)
-  o.iters_per_launch = 1;
-  (void)B;     // the reference aliases the caller's B and then overwrites it entry by entry; B = I + Q/Omega throughout
-  phm_model model;
-  model.n_states = n; model.Q = Q; model.pid = pid; model.B = nullptr; model.Omega = Omega; model.variant = variant;
-  phm_engine* e = nullptr;
-  int32_t st = phm_engine_create(x, &model, &o, N, &e);
-  if (st) return st;
-  std::unique_ptr<phm_engine, void (*)(phm_engine*)> guard(e, phm_engine_destroy);
-  std::string serr;
-  if (!phm::check_reference_orders(e->sched, x->edge, nen, nodelist, root, serr)) return fail(PHM_ERR_BAD_INPUT, serr);
-  const int ecols = e->cols, E = e->sched.n_edge, T = e->sched.n_tips, Nn = e->sched.n_node;
-  const size_t nn = (size_t)n * n;
-
-  // DIC: device state of the per-iteration log-likelihood (expmat(Q t_b) for every branch, then pruning in nen order)
-  DevBuf dQ, dt, ds, dwork, dP, dPL0, dPL, dpid, dup, dll, derr, dorder, dlogs;
-  std::vector<double> loglik;
-  std::vector<int32_t> ll_level_off;
-  std::vector<int32_t> sq(E);
-  if (dic) {
-    std::vector<phm::UpStep> upn(Nn);
-    const int32_t* e1 = x->edge; const int32_t* e2 = x->edge + E;
-    auto code = [&](int32_t node) { return node > T ? node - T - 1 : ~(node - 1); };
-    std::vector<int32_t> height(Nn, 0);
-    int max_h = 0;
-    for (int i = 0; i < Nn; ++i) {
-      const int ea = nen[2 * i] - 1, eb = nen[2 * i + 1] - 1;
-      upn[i].parent = e1[ea] - T - 1;
-      upn[i].child[0] = code(e2[ea]); upn[i].child[1] = code(e2[eb]);
-      upn[i].edge[0] = ea; upn[i].edge[1] = eb;
-      int h = 0;                                        // nen lists children before parents (checked above)
-      for (int c = 0; c < 2; ++c) if (upn[i].child[c] >= 0) h = std::max(h, height[upn[i].child[c]] + 1);
-      height[upn[i].parent] = h; max_h = std::max(max_h, h);
-    }
-    ll_level_off.assign(max_h + 2, 0);
-    for (int i = 0; i < Nn; ++i) ll_level_off[height[upn[i].parent] + 1]++;
-    for (size_t l = 1; l < ll_level_off.size(); ++l) ll_level_off[l] += ll_level_off[l - 1];
-    std::vector<int32_t> ll_order(Nn), pos(ll_level_off.begin(), ll_level_off.end() - 1);
-    for (int i = 0; i < Nn; ++i) ll_order[pos[height[upn[i].parent]]++] = i;
-    HIPCHK(dorder.alloc(sizeof(int32_t) * Nn)); HIPCHK(dlogs.alloc(sizeof(double) * Nn));
-    HIPCHK(hipMemcpy(dorder.p, ll_order.data(), dorder.bytes, hipMemcpyHostToDevice));
-    std::vector<double> PLh((size_t)(2 * T - 1) * n, 0.0);
-    for (int t = 0; t < T; ++t) {
-      if (variant == PHM_MCMC_BF) PLh[(size_t)t * n + (x->states[t] - 1)] = 1.0;                         // :3165
-      else for (int j = (x->states[t] % 2 == 0) ? 1 : 0; j < n; j += 2) PLh[(size_t)t * n + j] = 1.0;   // :3275-3282
-    }
-    HIPCHK(dQ.alloc(sizeof(double) * nn)); HIPCHK(dt.alloc(sizeof(double) * E)); HIPCHK(ds.alloc(sizeof(int32_t) * E));
-    HIPCHK(dwork.alloc(sizeof(double) * nn * 5 * E)); HIPCHK(dP.alloc(sizeof(double) * nn * E));
-    HIPCHK(dPL0.alloc(sizeof(double) * PLh.size())); HIPCHK(dPL.alloc(sizeof(double) * PLh.size()));
-    HIPCHK(dpid.alloc(sizeof(double) * n)); HIPCHK(dup.alloc(sizeof(phm::UpStep) * Nn)); HIPCHK(dll.alloc(sizeof(double)));
-    HIPCHK(derr.alloc(sizeof(uint32_t)));
-    HIPCHK(hipMemcpy(dt.p, x->edge_length, dt.bytes, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(dPL0.p, PLh.data(), dPL0.bytes, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(dpid.p, pid, dpid.bytes, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(dup.p, upn.data(), dup.bytes, hipMemcpyHostToDevice));
-    HIPCHK(hipMemset(derr.p, 0, sizeof(uint32_t)));
-    loglik.resize(N);
-  }
-
-  std::vector<double> Qw(Q, Q + nn), Qr, row(ecols);
-  for (int i = 0; i < N && !st; ++i) {
-    st = phm_engine_run(e, 1, nullptr);
-    if (!st) st = phm_engine_sync(e);
-    if (!st) st = phm_engine_read_stats(e, i, 1, row.data());
-    if (st) break;
-    if (dic) {                                        // :3239-3251 / :3379-3391, with the Q that drove this sweep
-      cm_to_rm(Qw.data(), n, Qr);
-      for (int b = 0; b < E; ++b) sq[b] = pade_squarings(Qr.data(), n, x->edge_length[b]);
-      HIPCHK(hipMemcpy(dQ.p, Qr.data(), dQ.bytes, hipMemcpyHostToDevice));
-      HIPCHK(hipMemcpy(ds.p, sq.data(), ds.bytes, hipMemcpyHostToDevice));
-      HIPCHK(hipMemcpyAsync(dPL.p, dPL0.p, dPL.bytes, hipMemcpyDeviceToDevice, nullptr));
-      HIPCHK(phm::launch_expm_pade(n, dQ.as<double>(), dt.as<double>(), ds.as<int32_t>(), E, dwork.as<double>(), dP.as<double>(), derr.as<uint32_t>(), nullptr));
-      HIPCHK(phm::launch_exp_pl_loglik(n, Nn, T, dup.as<phm::UpStep>(), dorder.as<int32_t>(), ll_level_off, dP.as<double>(), dPL.as<double>(),
-                                       dlogs.as<double>(), dpid.as<double>(), root - 1, dll.as<double>(), nullptr));
-      HIPCHK(hipMemcpy(&loglik[i], dll.p, sizeof(double), hipMemcpyDeviceToHost));
-    }
-    if (variant == PHM_MCMC_BF) phm::bf_updates(Qw.data(), Omega, prior, row.data(), o.seed, (uint32_t)i);
-    else phm::ks_updates(Qw.data(), n, Omega, prior, row.data(), o.seed, (uint32_t)i);
-    if (i + 1 < N) st = phm_engine_set_model(e, Qw.data());
-  }
-  if (st) return st;
-  if (!dic) return phm_engine_read_stats(e, 0, N, out);
-  std::vector<double> tmp((size_t)N * ecols);
-  st = phm_engine_read_stats(e, 0, N, tmp.data());
-  if (st) return st;
-  std::memcpy(out, tmp.data(), sizeof(double) * tmp.size());           // column-major: the first ecols columns are unchanged
-  for (int i = 0; i < N; ++i) out[(size_t)ecols * N + i] = loglik[i];     // log p(y|Q) after the root-state column
-  return PHM_OK;
-}
-
-extern "C" int32_t phm_maketreelistMCMCbf(const phm_tree* x, int32_t n, const double* Q, const double* pid, const double* B,
-                                          double Omega, const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
-                                          const double* prior, int32_t n_prior, const phm_options* opt, double* out) {
-  return run_qupdate(PHM_MCMC_BF, false, x, n, Q, pid, B, Omega, nen, nodelist, root, N, prior, n_prior, opt, out);
-}
-
-extern "C" int32_t phm_maketreelistMCMCks(const phm_tree* x, int32_t n, const double* Q, const double* pid, const double* B,
-                                          double Omega, const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
-                                          const double* prior, int32_t n_prior, const phm_options* opt, double* out) {
-  return run_qupdate(PHM_MCMC_KS, false, x, n, Q, pid, B, Omega, nen, nodelist, root, N, prior, n_prior, opt, out);
-}
-
-// Host-only: apply one iteration's rate-matrix updates to Q (column-major, edited in place) given a statistics row
-// (n dwell sums, n*n counts).  What phm_maketreelistMCMCbf / ks run between sweeps; exported for CPU-side tests.
-extern "C" int32_t phm_qupdate_apply(int32_t variant, int32_t n, double* Q, double Omega, const double* prior, int32_t n_prior,
-                                     const double* row, uint64_t seed, uint32_t iter) {
-  if (!Q || !prior || !row) return fail(PHM_ERR_BAD_INPUT, "phm_qupdate_apply: NULL argument");
-  if (variant == PHM_MCMC_BF || variant == PHM_MCMC_MT) {
-    if (n != 2 || n_prior < 4) return fail(PHM_ERR_BAD_INPUT, "bf / mt: n = 2, prior[4]");
-    if (variant == PHM_MCMC_MT) phm::mt_updates(Q, Omega, prior, row, seed, iter);
-    else phm::bf_updates(Q, Omega, prior, row, seed, iter);
-  } else if (variant == PHM_MCMC_KS || variant == PHM_MCMC_KSMT) {
-    const bool mt = variant == PHM_MCMC_KSMT;
-    if (n < 4 || (n & 1) || n > 64 || n_prior < (mt ? 8 : 6)) return fail(PHM_ERR_BAD_INPUT, "ks: n = 2k+2 in 4..64, prior[6] (ksmt: prior[8])");
-    phm::ks_updates(Q, n, Omega, prior, row, seed, iter, mt);
-  } else return fail(PHM_ERR_BAD_INPUT, "variant must be PHM_MCMC_BF, PHM_MCMC_KS, PHM_MCMC_MT or PHM_MCMC_KSMT");
-  return PHM_OK;
-}
-
-// maketreelistMCMC2sDICt src/phylomap.cpp:3183-3264 and maketreelistMCMCksDICt :3300-3403: the bf / ks drivers plus, every
-// iteration, log p(y|Q) by matrix exponentiation (expmat(Q t_b) for every branch, pruning with scale factors) in one more column.
-extern "C" int32_t phm_maketreelistMCMC2sDICt(const phm_tree* x, int32_t n, const double* Q, const double* pid, const double* B,
-                                              double Omega, const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
-                                              const double* prior, int32_t n_prior, const phm_options* opt, double* out) {
-  return run_qupdate(PHM_MCMC_BF, true, x, n, Q, pid, B, Omega, nen, nodelist, root, N, prior, n_prior, opt, out);
-}
-
-extern "C" int32_t phm_maketreelistMCMCksDICt(const phm_tree* x, int32_t n, const double* Q, const double* pid, const double* B,
-                                              double Omega, const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
-                                              const double* prior, int32_t n_prior, const phm_options* opt, double* out) {
-  return run_qupdate(PHM_MCMC_KS, true, x, n, Q, pid, B, Omega, nen, nodelist, root, N, prior, n_prior, opt, out);
-}
-
-// ---- multi-tree drivers -----------------------------------------------------------------------------------------------
-// maketreelistMCMCmt src/phylomap.cpp:2267-2365 (R/sumstatMCMCmt.R) and maketreelistMCMCksmt :2722-2844 (R/sumstatMCMCksmt.R).
-// One engine over the whole list: tree j's chain lives on replica tile j, so one launch per iteration sweeps every tree with
-// the current Q (:2341-2345); the host then draws the tree whose row is kept (:2347-2350), updates Q from that row and
-// uploads the new model once for all trees.
-static int32_t run_qupdate_mt(int variant, const phm_tree* trees, int32_t n_trees, int32_t n, const double* Q, const double* pid,
-                              double Omega, const int32_t* nen_m, const int32_t* nodelist_m, const int32_t* roots, int32_t N,
-                              const double* prior, int32_t n_prior, const phm_options* opt_in, double* out) {
-  if (!out || !prior || !Q || !trees) return fail(PHM_ERR_BAD_INPUT, "out/prior/Q/trees is NULL");
-  if (N < 1 || n_trees < 1) return fail(PHM_ERR_BAD_INPUT, "N and n_trees must be >= 1");
-  const bool ksmt = variant == PHM_MCMC_KSMT;
-  if (n_prior < (ksmt ? 8 : 4)) return fail(PHM_ERR_BAD_INPUT, ksmt ? "sumstatMCMCksmt needs prior = c(a_l01, b_l01, a_l10, b_l10, a_k, b_k, a_g, b_g) (src/phylomap.cpp:2391-2663)" : "sumstatMCMCmt needs prior = c(a01, b01, a10, b10)");
-  if (ksmt && (n < 4 || (n & 1))) return fail(PHM_ERR_BAD_INPUT, "sumstatMCMCksmt needs n = 2k+2 states with k >= 1 (src/phylomap.cpp:2729)");
-  phm_options o;
-  std::memset(&o, 0, sizeof(o));
-  o.device = -1;
-  if (opt_in) o = *opt_in;
-  if (o.n_replicas > 1) return fail(PHM_ERR_UNSUPPORTED, "the multi-tree drivers run one chain per tree");
-  o.n_replicas = 1; o.reduce = 0; o.tips_per_replica = 0; o.iters_per_launch = 1;
-  phm_model model;
-  model.n_states = n; model.Q = Q; model.pid = pid; model.B = nullptr; model.Omega = Omega; model.variant = variant;
-  phm_engine* e = nullptr;
-  int32_t st = phm_engine_create_multi(trees, n_trees, &model, &o, N, &e);
-  if (st) return st;
-  std::unique_ptr<phm_engine, void (*)(phm_engine*)> guard(e, phm_engine_destroy);
-  const int Nn = e->sched.n_node;
-  if (nen_m || nodelist_m || roots) {      // R's matrices are column-major: row j = elements j, j + n_trees, ...
-    std::vector<int32_t> nen(2 * (size_t)Nn), nodelist(Nn > 1 ? Nn - 1 : 0);
-    std::string serr;
-    for (int j = 0; j < n_trees; ++j) {
-      if (nen_m) for (int i = 0; i < 2 * Nn; ++i) nen[i] = nen_m[j + (size_t)i * n_trees];
-      if (nodelist_m) for (int i = 0; i < Nn - 1; ++i) nodelist[i] = nodelist_m[j + (size_t)i * n_trees];
-      if (!phm::check_reference_orders(e->scheds[j], trees[j].edge, nen_m ? nen.data() : nullptr, nodelist_m ? nodelist.data() : nullptr,
-                                       roots ? roots[j] : e->scheds[j].root + e->sched.n_tips + 1, serr))
-        return fail(PHM_ERR_BAD_INPUT, "tree " + std::to_string(j) + ": " + serr);
-    }
-  }
-  const int ecols = e->cols;                 // n + n*n + 2 + 3k + 1: the engine's root-state column becomes tree_number
-  const size_t nn = (size_t)n * n;
-  std::vector<double> Qw(Q, Q + nn), rows((size_t)n_trees * ecols);
-  for (int i = 0; i < N; ++i) {
-    st = phm_engine_run(e, 1, nullptr);
-    if (!st) st = phm_engine_sync(e);
-    if (!st) st = phm_engine_read_stats(e, i, 1, rows.data());       // one 1 x ecols row per tree
-    if (st) return st;
-    const uint32_t pick = phm::pick_tree(n_trees, o.seed, (uint32_t)i);
-    if (pick >= (uint32_t)n_trees) return fail(PHM_ERR_ZERO_PROB, "sampleOnce ran past the last tree (src/phylomap.cpp:85-89)");
-    const double* row = rows.data() + (size_t)pick * ecols;
-    for (int c = 0; c + 1 < ecols; ++c) out[(size_t)c * N + i] = row[c];
-    out[(size_t)(ecols - 1) * N + i] = (double)pick;                   // :2350, 0-based as the reference stores it
-    if (ksmt) phm::ks_updates(Qw.data(), n, Omega, prior, row, o.seed, (uint32_t)i, true);
-    else phm::mt_updates(Qw.data(), Omega, prior, row, o.seed, (uint32_t)i);
-    if (i + 1 < N) { st = phm_engine_set_model(e, Qw.data()); if (st) return st; }
-  }
-  return PHM_OK;
-}
-
-extern "C" int32_t phm_maketreelistMCMCmt(const phm_tree* trees, int32_t n_trees, int32_t n, const double* Q, const double* pid,
-                                          const double* B, double Omega, const int32_t* nen_m, const int32_t* nodelist_m,
-                                          const int32_t* roots, int32_t N, const double* prior, int32_t n_prior,
-                                          const phm_options* opt, double* out) {
-  (void)B;
-  return run_qupdate_mt(PHM_MCMC_MT, trees, n_trees, n, Q, pid, Omega, nen_m, nodelist_m, roots, N, prior, n_prior, opt, out);
-}
-
-extern "C" int32_t phm_maketreelistMCMCksmt(const phm_tree* trees, int32_t n_trees, int32_t n, const double* Q, const double* pid,
-                                            const double* B, double Omega, const int32_t* nen_m, const int32_t* nodelist_m,
-                                            const int32_t* roots, int32_t N, const double* prior, int32_t n_prior,
-                                            const phm_options* opt, double* out) {
-  (void)B;
-  return run_qupdate_mt(PHM_MCMC_KSMT, trees, n_trees, n, Q, pid, Omega, nen_m, nodelist_m, roots, N, prior, n_prior, opt, out);
 }

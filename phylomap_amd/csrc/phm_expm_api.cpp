@@ -1,0 +1,204 @@
+// phm_expm_api.cpp -- C-ABI of the matrix-exponentiation path: batched transition matrices (eigen route, Pade route, their
+// MFMA f64 variants) and the sumstatEXP driver (maketreelistEXP, src/phylomap.cpp:3001-3051).
+#include "phm_internal.h"
+
+namespace {
+
+struct Timer {
+  hipEvent_t a = nullptr, b = nullptr;
+  ~Timer() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+};
+
+}  // namespace
+
+extern "C" {
+
+static int32_t expm_eigen_impl(bool mfma, int32_t n, const double* lefts, const double* rights, const double* d, const double* t,
+                               int32_t n_t, int32_t device, double* out, double* kernel_ms) {
+  if (n < 1 || n > 256 || !lefts || !rights || !d || !t || !out || n_t < 0) return fail(PHM_ERR_BAD_INPUT, "phm_expm_eigen: bad arguments");
+  int32_t st = select_device(device);
+  if (st) return st;
+  if (n_t == 0) return PHM_OK;
+  std::vector<double> L, R, dv(n);
+  cm_to_rm(lefts, n, L); cm_to_rm(rights, n, R);
+  for (int i = 0; i < n; ++i) dv[i] = d[i + (size_t)i * n];
+  const size_t nn = (size_t)n * n;
+  DevBuf dL, dR, dd, dt, dout;
+  HIPCHK(dL.alloc(sizeof(double) * nn)); HIPCHK(dR.alloc(sizeof(double) * nn)); HIPCHK(dd.alloc(sizeof(double) * n));
+  HIPCHK(dt.alloc(sizeof(double) * n_t)); HIPCHK(dout.alloc(sizeof(double) * nn * n_t));
+  HIPCHK(hipMemcpy(dL.p, L.data(), dL.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dR.p, R.data(), dR.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dd.p, dv.data(), dd.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dt.p, t, dt.bytes, hipMemcpyHostToDevice));
+  Timer tm;
+  HIPCHK(hipEventCreate(&tm.a)); HIPCHK(hipEventCreate(&tm.b));
+  HIPCHK(hipEventRecord(tm.a, nullptr));
+  if (mfma) HIPCHK(phm::launch_expm_eigen_mfma(n, dL.as<double>(), dR.as<double>(), dd.as<double>(), dt.as<double>(), n_t, dout.as<double>(), nullptr));
+  else HIPCHK(phm::launch_expm_eigen(n, dL.as<double>(), dR.as<double>(), dd.as<double>(), dt.as<double>(), n_t, dout.as<double>(), nullptr));
+  HIPCHK(hipEventRecord(tm.b, nullptr));
+  HIPCHK(hipMemcpy(out, dout.p, dout.bytes, hipMemcpyDeviceToHost));
+  if (kernel_ms) { float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, tm.a, tm.b)); *kernel_ms = ms; }
+  return PHM_OK;
+}
+
+int32_t phm_expm_eigen(int32_t n, const double* lefts, const double* rights, const double* d, const double* t,
+                       int32_t n_t, int32_t device, double* out, double* kernel_ms) {
+  return expm_eigen_impl(false, n, lefts, rights, d, t, n_t, device, out, kernel_ms);
+}
+
+int32_t phm_expm_eigen_mfma(int32_t n, const double* lefts, const double* rights, const double* d, const double* t,
+                            int32_t n_t, int32_t device, double* out, double* kernel_ms) {
+  if (n <= 16 || n > 64) return fail(PHM_ERR_UNSUPPORTED, "phm_expm_eigen_mfma: 16 < n_states <= 64 (smaller matrices do not fill an MFMA tile)");
+  return expm_eigen_impl(true, n, lefts, rights, d, t, n_t, device, out, kernel_ms);
+}
+
+static int32_t expm_pade_impl(bool mfma, int32_t n, const double* Q, const double* t, int32_t n_t, int32_t device, double* out,
+                              double* kernel_ms) {
+  if (n < 1 || n > 128 || !Q || !t || !out || n_t < 0) return fail(PHM_ERR_BAD_INPUT, "phm_expm_pade: bad arguments (n <= 128)");
+  int32_t st = select_device(device);
+  if (st) return st;
+  if (n_t == 0) return PHM_OK;
+  std::vector<double> Qr;
+  cm_to_rm(Q, n, Qr);
+  std::vector<int32_t> sq(n_t);
+  for (int b = 0; b < n_t; ++b) sq[b] = pade_squarings(Qr.data(), n, t[b]);
+  const size_t nn = (size_t)n * n;
+  DevBuf dQ, dt, ds, dwork, dout, derr;
+  HIPCHK(dQ.alloc(sizeof(double) * nn)); HIPCHK(dt.alloc(sizeof(double) * n_t)); HIPCHK(ds.alloc(sizeof(int32_t) * n_t));
+  HIPCHK(dwork.alloc(mfma ? 16 : sizeof(double) * nn * 5 * n_t)); HIPCHK(dout.alloc(sizeof(double) * nn * n_t)); HIPCHK(derr.alloc(sizeof(uint32_t)));
+  HIPCHK(hipMemcpy(dQ.p, Qr.data(), dQ.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dt.p, t, dt.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(ds.p, sq.data(), ds.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(derr.p, 0, sizeof(uint32_t)));
+  Timer tm;
+  HIPCHK(hipEventCreate(&tm.a)); HIPCHK(hipEventCreate(&tm.b));
+  HIPCHK(hipEventRecord(tm.a, nullptr));
+  if (mfma) HIPCHK(phm::launch_expm_pade_mfma(n, dQ.as<double>(), dt.as<double>(), ds.as<int32_t>(), n_t, dout.as<double>(), derr.as<uint32_t>(), nullptr));
+  else HIPCHK(phm::launch_expm_pade(n, dQ.as<double>(), dt.as<double>(), ds.as<int32_t>(), n_t, dwork.as<double>(), dout.as<double>(), derr.as<uint32_t>(), nullptr));
+  HIPCHK(hipEventRecord(tm.b, nullptr));
+  HIPCHK(hipMemcpy(out, dout.p, dout.bytes, hipMemcpyDeviceToHost));
+  uint32_t derrh = 0;
+  HIPCHK(hipMemcpy(&derrh, derr.p, sizeof derrh, hipMemcpyDeviceToHost));
+  if (kernel_ms) { float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, tm.a, tm.b)); *kernel_ms = ms; }
+  if (derrh) return fail(PHM_ERR_BAD_INPUT, "phm_expm_pade: singular Pade denominator");
+  return PHM_OK;
+}
+
+int32_t phm_expm_pade(int32_t n, const double* Q, const double* t, int32_t n_t, int32_t device, double* out, double* kernel_ms) {
+  return expm_pade_impl(false, n, Q, t, n_t, device, out, kernel_ms);
+}
+
+int32_t phm_expm_pade_mfma(int32_t n, const double* Q, const double* t, int32_t n_t, int32_t device, double* out,
+                           double* kernel_ms) {
+  if (n <= 16 || n > 64) return fail(PHM_ERR_UNSUPPORTED, "phm_expm_pade_mfma: 16 < n_states <= 64 (smaller matrices do not fill an MFMA tile)");
+  return expm_pade_impl(true, n, Q, t, n_t, device, out, kernel_ms);
+}
+
+// maketreelistEXP, src/phylomap.cpp:3001-3051.  P(t_b) and the pruning pass are computed ONCE (the reference
+// recomputes both every iteration although Q never changes, :2980-2981).
+int32_t phm_maketreelistEXP(const phm_tree* x, int32_t n, const double* Q, const double* pid, const int32_t* nen,
+                            const int32_t* nodelist, int32_t root, int32_t N, const double* lefts, const double* rights,
+                            const double* d, const phm_options* opt_in, double* out) {
+  if (!x || !Q || !pid || !lefts || !rights || !d || !out) return fail(PHM_ERR_BAD_INPUT, "phm_maketreelistEXP: NULL argument");
+  if (N < 1) return fail(PHM_ERR_BAD_INPUT, "N must be >= 1");
+  if (n < 2) return fail(PHM_ERR_BAD_INPUT, "n_states must be >= 2");
+  if (n > 64) return fail(PHM_ERR_UNSUPPORTED, "this build has EXP kernels for n_states <= 64 only");
+  if (!x->edge_length) return fail(PHM_ERR_BAD_INPUT, "x$edge.length is required (src/phylomap.cpp:3034)");
+  phm_options o;
+  std::memset(&o, 0, sizeof(o));
+  o.device = -1;
+  if (opt_in) o = *opt_in;
+  int32_t st = validate_tree_paths(x, n, 1);
+  if (st) return st;
+  phm::Schedule s;
+  std::string serr;
+  if (!phm::build_schedule(x->n_tips, x->n_node, x->n_edge, x->edge, s, serr)) return fail(PHM_ERR_BAD_INPUT, "tree: " + serr);
+  if (!phm::check_reference_orders(s, x->edge, nen, nodelist, root, serr)) return fail(PHM_ERR_BAD_INPUT, serr);
+  const int E = s.n_edge, T = s.n_tips;
+  for (int b = 0; b < E; ++b)
+    if (!std::isfinite(x->edge_length[b]) || x->edge_length[b] < 0.0) return fail(PHM_ERR_BAD_INPUT, "edge.length must be finite and non-negative");
+
+  std::vector<double> L, R, dv(n), B2((size_t)n * n);
+  cm_to_rm(lefts, n, L); cm_to_rm(rights, n, R);
+  double minq = Q[0];
+  for (int i = 0; i < n; ++i) { dv[i] = d[i + (size_t)i * n]; minq = std::min(minq, Q[i + (size_t)i * n]); }
+  const double rate = -1.0 * minq;                                             // :3008
+  if (!(rate > 0.0)) return fail(PHM_ERR_BAD_INPUT, "Q must have a negative diagonal entry");
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) {
+      double b = ((i == j) ? 1.0 : 0.0) + Q[i + (size_t)j * n] / rate;          // :3011
+      if (!(b >= 0.0)) return fail(PHM_ERR_BAD_INPUT, "I + Q/poissonRate must be non-negative");
+      B2[(size_t)i * n + j] = b;
+    }
+  std::vector<double> col, rowtab;
+  build_chain_tables(B2.data(), n, phm::UNIF_CAP + 1, col, rowtab);
+
+  st = select_device(o.device);
+  if (st) return st;
+  const size_t nn = (size_t)n * n;
+  const int tiles = (N + 63) / 64;
+  const int cols = n + n * (n - 1);
+  DevBuf dL, dR, dd, dt, dP, dPL, dup, ddown, dcol, dB2, dtips, dnst, dtimes, dout, derr;
+  HIPCHK(dL.alloc(sizeof(double) * nn)); HIPCHK(dR.alloc(sizeof(double) * nn)); HIPCHK(dd.alloc(sizeof(double) * n));
+  HIPCHK(dt.alloc(sizeof(double) * E)); HIPCHK(dP.alloc(sizeof(double) * nn * E));
+  HIPCHK(dPL.alloc(sizeof(double) * (size_t)(2 * T - 1) * n));
+  HIPCHK(dup.alloc(sizeof(phm::UpStep) * s.up.size())); HIPCHK(ddown.alloc(sizeof(phm::DownStep) * s.down.size()));
+  HIPCHK(dcol.alloc(sizeof(double) * col.size())); HIPCHK(dB2.alloc(sizeof(double) * nn)); HIPCHK(dtips.alloc(T));
+  HIPCHK(dnst.alloc((size_t)tiles * s.n_node * 64)); HIPCHK(dtimes.alloc(sizeof(double) * (size_t)tiles * phm::UNIF_CAP * 64));
+  HIPCHK(dout.alloc(sizeof(double) * (size_t)N * cols)); HIPCHK(derr.alloc(sizeof(uint32_t)));
+  std::vector<double> PLh((size_t)(2 * T - 1) * n, 0.0);
+  std::vector<uint8_t> tips(T);
+  for (int t = 0; t < T; ++t) { tips[t] = (uint8_t)(x->states[t] - 1); PLh[(size_t)t * n + tips[t]] = 1.0; }   // :2883
+  HIPCHK(hipMemcpy(dL.p, L.data(), dL.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dR.p, R.data(), dR.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dd.p, dv.data(), dd.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dt.p, x->edge_length, dt.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dPL.p, PLh.data(), dPL.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dup.p, s.up.data(), dup.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(ddown.p, s.down.data(), ddown.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dcol.p, col.data(), dcol.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dB2.p, B2.data(), dB2.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dtips.p, tips.data(), T, hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(derr.p, 0, sizeof(uint32_t)));
+  HIPCHK(hipMemset(dnst.p, 0, dnst.bytes));
+
+  HIPCHK(phm::launch_expm_eigen(n, dL.as<double>(), dR.as<double>(), dd.as<double>(), dt.as<double>(), E, dP.as<double>(), nullptr));   // :3042
+  HIPCHK(phm::launch_exp_pl(n, s.n_node, T, dup.as<phm::UpStep>(), dP.as<double>(), dPL.as<double>(), nullptr));                       // :3043
+
+  auto fill = [&](auto& p) {
+    p.n_tips = T; p.n_node = s.n_node; p.n_edge = E; p.root = s.root; p.N = N; p.n_tiles = tiles;
+    p.seed_lo = (uint32_t)(o.seed & 0xFFFFFFFFull); p.seed_hi = (uint32_t)(o.seed >> 32); p.replica = (uint32_t)o.replica_offset;
+    p.poisson_rate = rate;
+    for (int i = 0; i < n; ++i) p.pid[i] = pid[i];
+    p.down = ddown.as<phm::DownStep>(); p.P = dP.as<double>(); p.PL = dPL.as<double>(); p.edge_length = dt.as<double>();
+    p.colpow = dcol.as<double>(); p.B2 = dB2.as<double>(); p.tips = dtips.as<uint8_t>(); p.nstate = dnst.as<uint8_t>();
+    p.times = dtimes.as<double>(); p.out = dout.as<double>(); p.err = derr.as<uint32_t>();
+  };
+  hipError_t le = hipSuccess;
+  if (n == 2) { phm::ExpParams<2> p; fill(p); le = phm::launch_exp_sample<2>(p, nullptr); }
+  if (n == 3) { phm::ExpParams<3> p; fill(p); le = phm::launch_exp_sample<3>(p, nullptr); }
+  if (n == 4) { phm::ExpParams<4> p; fill(p); le = phm::launch_exp_sample<4>(p, nullptr); }
+  if (n > 4) {
+    DevBuf dpid;
+    HIPCHK(dpid.alloc(sizeof(double) * n));
+    HIPCHK(hipMemcpy(dpid.p, pid, sizeof(double) * n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(dout.p, 0, dout.bytes));
+    phm::ExpWideParams p;
+    p.n_states = n; p.n_tips = T; p.n_node = s.n_node; p.n_edge = E; p.root = s.root; p.N = N; p.n_tiles = tiles;
+    p.seed_lo = (uint32_t)(o.seed & 0xFFFFFFFFull); p.seed_hi = (uint32_t)(o.seed >> 32); p.replica = (uint32_t)o.replica_offset;
+    p.poisson_rate = rate; p.pid = dpid.as<double>();
+    p.down = ddown.as<phm::DownStep>(); p.P = dP.as<double>(); p.PL = dPL.as<double>(); p.edge_length = dt.as<double>();
+    p.colpow = dcol.as<double>(); p.B2 = dB2.as<double>(); p.tips = dtips.as<uint8_t>(); p.nstate = dnst.as<uint8_t>();
+    p.times = dtimes.as<double>(); p.out = dout.as<double>(); p.err = derr.as<uint32_t>();
+    le = phm::launch_exp_wide(p, nullptr);
+    HIPCHK(le);
+    HIPCHK(hipDeviceSynchronize());
+  }
+  HIPCHK(le);
+  HIPCHK(hipMemcpy(out, dout.p, dout.bytes, hipMemcpyDeviceToHost));
+  uint32_t derrh = 0;
+  HIPCHK(hipMemcpy(&derrh, derr.p, sizeof derrh, hipMemcpyDeviceToHost));
+  return device_status(derrh);
+}
+
+}  // extern "C"

@@ -1,0 +1,183 @@
+// phm_internal.h -- shared by the translation units behind the C-ABI (phm_engine.cpp, phm_drivers.cpp, phm_expm_api.cpp):
+// error reporting, device buffers, the engine object.  Not installed; include/phylomap_hip.h is the public interface.
+#pragma once
+
+#include "../../include/phylomap_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "phm_exp.h"
+#include "phm_mcmc.h"
+#include "phm_narrow.h"
+#include "phm_qupdate.h"
+#include "phm_sched.h"
+#include "phm_tiles.h"
+#include "phm_wide.h"
+
+inline thread_local std::string g_phm_err;      // phm_last_error()
+
+inline int32_t fail(int32_t st, const std::string& msg) { g_phm_err = msg; return st; }
+
+#define HIPCHK(call)                                                                              \
+  do {                                                                                            \
+    hipError_t _e = (call);                                                                       \
+    if (_e != hipSuccess) {                                                                       \
+      int32_t _st = (_e == hipErrorOutOfMemory) ? PHM_ERR_OOM : PHM_ERR_NO_DEVICE;                \
+      return fail(_st, std::string(#call) + ": " + hipGetErrorString(_e));                        \
+    }                                                                                             \
+  } while (0)
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t n) { bytes = n; return hipMalloc(&p, n ? n : 16); }
+  template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+inline int32_t select_device(int32_t device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(PHM_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+  if (device >= 0) {
+    if (device >= n) return fail(PHM_ERR_NO_DEVICE, "device ordinal out of range");
+    HIPCHK(hipSetDevice(device));
+  }
+  return PHM_OK;
+}
+
+inline int32_t device_status(uint32_t derr) {
+  if (derr & phm::DERR_ZERO_PROB) return fail(PHM_ERR_ZERO_PROB, "all-zero or non-finite probability vector while sampling a state (RcppArmadillo::sample would throw)");
+  if (derr & phm::DERR_CAPACITY) return fail(PHM_ERR_CAPACITY, "a branch outgrew its dwell capacity; lower phm_options.cap_tail");
+  if (derr & phm::DERR_UNIF_CAP) return fail(PHM_ERR_UNIF_CAP, "newunifSample needed more than 300 jumps on a branch (src/phylomap.cpp:120)");
+  if (derr & phm::DERR_SAMPLEONCE) return fail(PHM_ERR_ZERO_PROB, "sampleOnce ran past the last state (src/phylomap.cpp:85-89)");
+  return PHM_OK;
+}
+
+// R's column-major matrix -> row-major
+inline void cm_to_rm(const double* cm, int n, std::vector<double>& rm) {
+  rm.resize((size_t)n * n);
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) rm[(size_t)i * n + j] = cm[i + (size_t)j * n];
+}
+
+// squaring count of arma::expmat: s = max(0, exponent(frexp(log2 ||A||_inf)) + 1)
+inline int pade_squarings(const double* Q_rm, int n, double t) {
+  double norm = 0.0;
+  for (int i = 0; i < n; ++i) {
+    double r = 0.0;
+    for (int j = 0; j < n; ++j) r += std::fabs(Q_rm[(size_t)i * n + j] * t);
+    if (r > norm) norm = r;
+  }
+  double l2 = (norm > 0.0) ? std::log2(norm) : 0.0;
+  int ex = 0;
+  (void)std::frexp(l2, &ex);
+  return std::max(0, ex + 1);
+}
+
+// chain tables: col[k][j][:] = Bc^k e_j  (v <- Bc v), row[k][j][:] = (Bc^T)^k e_j (w <- Bc^T w);
+// same left-to-right unfused sums as the kernels' matvec_u, so entries are bit-identical to running the chain.
+inline void build_chain_tables(const double* Bc, int n, int ktab, std::vector<double>& col, std::vector<double>& row) {
+  col.assign((size_t)ktab * n * n, 0.0);
+  row.assign((size_t)ktab * n * n, 0.0);
+  for (int j = 0; j < n; ++j) { col[(size_t)j * n + j] = 1.0; row[(size_t)j * n + j] = 1.0; }
+  for (int k = 1; k < ktab; ++k)
+    for (int j = 0; j < n; ++j) {
+      const double* v = &col[((size_t)(k - 1) * n + j) * n];
+      double* y = &col[((size_t)k * n + j) * n];
+      for (int i = 0; i < n; ++i) {
+        double acc = Bc[i * n] * v[0];
+        for (int c = 1; c < n; ++c) acc += Bc[i * n + c] * v[c];
+        y[i] = acc;
+      }
+      const double* w = &row[((size_t)(k - 1) * n + j) * n];
+      double* z = &row[((size_t)k * n + j) * n];
+      for (int c = 0; c < n; ++c) {
+        double acc = Bc[c] * w[0];
+        for (int r = 1; r < n; ++r) acc += Bc[r * n + c] * w[r];
+        z[c] = acc;
+      }
+    }
+}
+
+inline int32_t validate_tree_paths(const phm_tree* x, int n, int n_tip_vectors) {
+  if (!x || !x->edge || !x->states || !x->map_off || !x->maps || !x->mapnames) return fail(PHM_ERR_BAD_INPUT, "tree: missing field");
+  for (int64_t i = 0; i < (int64_t)n_tip_vectors * x->n_tips; ++i)
+    if (x->states[i] < 1 || x->states[i] > n) return fail(PHM_ERR_BAD_INPUT, "x$states must be in 1..n");
+  if (x->map_off[0] != 0) return fail(PHM_ERR_BAD_INPUT, "map_off[0] must be 0");
+  for (int b = 0; b < x->n_edge; ++b) {
+    int m = x->map_off[b + 1] - x->map_off[b];
+    if (m < 1) return fail(PHM_ERR_BAD_INPUT, "every branch needs at least one segment in x$maps");
+    if (m > 50000) return fail(PHM_ERR_BAD_INPUT, "more than 50000 segments on one branch");
+    for (int i = x->map_off[b]; i < x->map_off[b + 1]; ++i) {
+      if (x->mapnames[i] < 1 || x->mapnames[i] > n) return fail(PHM_ERR_BAD_INPUT, "x$mapnames must be in 1..n");
+      if (!std::isfinite(x->maps[i]) || x->maps[i] < 0.0) return fail(PHM_ERR_BAD_INPUT, "x$maps must be finite and non-negative");
+    }
+  }
+  return PHM_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+struct phm_engine {
+  int n = 0, cols = 0, dcols = 0, variant = 0;   // cols: result columns; dcols: columns kept on the device
+  std::vector<double> qparams;                     // bf/ks: l01, l10, rkappas, lkappas, gammas of the CURRENT Q (recordQks :1789-1798)
+  std::vector<std::vector<double>> qhist;          // ... as recorded at the start of every iteration that has run
+  double Omega = 0.0;
+  std::vector<double> hB2, hBc, hscale, hpid;      // current model, row-major
+  int S = 0, S_pad = 0, tiles = 0, max_iters = 0, iters_done = 0, ipl = 0;
+  int reduce = 0, device = 0;
+  phm::Schedule sched;                 // tree 0 (every tree of a list has the same tip / edge counts)
+  std::vector<phm::Schedule> scheds;   // one per tree
+  int n_trees = 1, S_tree = 0, tpt = 0;   // list of trees: S_tree chains per tree on tpt tiles each; S = n_trees * S_tree
+  DevBuf d_roots;
+  // logical replica r (tree-major) -> lane index in the padded device layout
+  int pad_index(int r) const { return n_trees > 1 ? (r / S_tree) * tpt * 64 + r % S_tree : r; }
+  std::vector<uint8_t> tips_host;      // 0-based, [n_tips] or [tile][n_tips][64]
+  bool tips_per_replica = false;
+  int64_t rows = 0;
+  DevBuf d_mask;
+  DevBuf d_up, d_down, d_col, d_row, d_tips, d_mcount, d_dw0, d_dw1, d_cursor, d_PL, d_nstate, d_stats, d_err, d_seg, d_red;
+  phm::McmcParams<2> p2;
+  phm::McmcParams<3> p3;
+  phm::McmcParams<4> p4;
+  bool wide = false;                   // 5..64 states: phm_wide.hip
+  bool ring = true;                    // one ring per tile for both dwell streams (else two buffers)
+  phm::WideParams pw;
+  DevBuf d_B2, d_Bc, d_scale, d_pid;
+  // branch-parallel mapping for few chains on a large tree (phm_narrow.hip)
+  bool narrow = false;
+  std::vector<int32_t> nw_up_off, nw_down_off;     // level boundaries into up_order / down_order
+  std::vector<int64_t> nw_off;                     // CSR offsets of the branch slots
+  int nw_klong = 0;
+  int64_t nw_total_cap = 0;
+  DevBuf d_nw_up_order, d_nw_down_order, d_nw_border, d_nw_off, d_nw_colL, d_nw_rowL, d_nw_maskL, d_nw_mcount, d_nw_dwA, d_nw_dwB,
+      d_nw_mstate, d_nw_mlen, d_nw_estate, d_nw_part, d_nw_rowbuf;
+  phm::NarrowParams<2> n2;
+  phm::NarrowParams<3> n3;
+  phm::NarrowParams<4> n4;
+  // wave per (tile, branch) mapping for 10^2 .. 10^5 replicas (phm_tiles.hip); shares the level schedules and long tables
+  bool tiled = false;
+  std::vector<int32_t> tl_slot;                    // first row of every branch slot
+  DevBuf d_tl_slot, d_tl_pdw, d_tl_pchunk, d_tl_cnt, d_tl_estate, d_tl_pseg, d_tl_segprev;
+  phm::TileParams<2> t2;
+  phm::TileParams<3> t3;
+  phm::TileParams<4> t4;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipStream_t last_stream = nullptr;
+  bool timing_pending = false;
+  double last_ms = 0.0;
+  int last_launches = 0;
+  int64_t bytes = 0;
+  unsigned long long seg_total = 0;
+  ~phm_engine() {
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+  }
+};

@@ -3,7 +3,7 @@
 // :1189-1253; maketreelistMCMCks :1862-1866 with updateksl01/l10 :1435-1578, updaterkappas :1582-1644,
 // updatelkappas :1648-1710, updategammas :1714-1785; the multi-tree twins maketreelistMCMCmt :2351-2352 with updatel01mtNS /
 // updatel10mtNS :2192-2262 and maketreelistMCMCksmt :2828-2832 with update*mt :2371-2705).  O(k) scalar work per iteration on statistics the device has
-// already reduced; the sweeps themselves stay on the GPU (phm_api.cpp drives both).
+// already reduced; the sweeps themselves stay on the GPU (phm_drivers.cpp drives both).
 //
 // Random numbers: the reference draws Rf_rgamma and runif from R's global stream.  Here every update owns a Philox
 // stream (replica word 0xFFFFFFFF, entity 0xFFFFFF00 | update id, iteration word = sweep index); the gamma variate is
