@@ -569,6 +569,24 @@ int32_t phm_engine_create_multi(const phm_tree* trees, int32_t n_trees, const ph
   if (rows * 64 > 0x7fffff00ll) return fail(PHM_ERR_UNSUPPORTED, "tree too large: dwell rows per replica tile exceed 32-bit indexing");
   e->rows = rows;
 
+  if (e->wide && n_trees == 1) {
+    // n > 4: a wave takes the replicas of its tile in turn for the n-vector work (phm_wide.hip), so a tile that holds
+    // 64 replicas is 64 sequential passes in ONE wave.  With few replicas, place fewer of them on a tile (the unused lanes
+    // are skipped) until about 2 048 waves exist or the padded layout would take more than a quarter of the free HBM.
+    size_t free_now = 0, total_now = 0;
+    HIPCHK(hipMemGetInfo(&free_now, &total_now));
+    int rpt = 64;
+    while (rpt > 1 && (e->S + rpt / 2 - 1) / (rpt / 2) <= 2048) rpt /= 2;
+    auto tile_bytes = [&](int r) {
+      const size_t tl = (size_t)(e->S + r - 1) / r;
+      return tl * (sizeof(double) * ((size_t)rows * 64 + (size_t)s.n_node * n * 64) + 3 * (size_t)E * 64) +
+             sizeof(double) * (size_t)max_iters * e->dcols * (e->reduce ? tl : tl * 64);
+    };
+    while (rpt < 64 && tile_bytes(rpt) > free_now / 4) rpt *= 2;
+    e->rpt = rpt;
+    e->tiles = (e->S + rpt - 1) / rpt; e->S_pad = e->tiles * 64; e->tpt = e->tiles;
+  }
+
   // tips (0-based u8)
   if (n_trees > 1) {
     e->tips_host.assign((size_t)e->tiles * T * 64, 0);
@@ -576,11 +594,14 @@ int32_t phm_engine_create_multi(const phm_tree* trees, int32_t n_trees, const ph
       for (int t = 0; t < T; ++t)
         std::memset(&e->tips_host[((size_t)tl * T + t) * 64], trees[tl / e->tpt].states[t] - 1, 64);
   } else if (e->tips_per_replica) {
-    e->tips_host.assign((size_t)e->tiles * T * 64, 0);
-    for (int r = 0; r < e->S_pad; ++r) {
-      int src = r < e->S ? r : e->S - 1;
-      for (int t = 0; t < T; ++t) e->tips_host[((size_t)(r / 64) * T + t) * 64 + (r % 64)] = (uint8_t)(x->states[(size_t)src * T + t] - 1);
+    e->tips_host.assign((size_t)e->tiles * T * 64, (uint8_t)(x->states[0] - 1));      // padding lanes: any valid state
+    for (int r = 0; r < e->S; ++r) {
+      const int pr = e->pad_index(r);
+      for (int t = 0; t < T; ++t) e->tips_host[((size_t)(pr / 64) * T + t) * 64 + (pr % 64)] = (uint8_t)(x->states[(size_t)r * T + t] - 1);
     }
+    if (e->rpt == 64)      // dense tiles of the n <= 4 kernels: padding lanes are run like replicas, give them the last site
+      for (int r = e->S; r < e->S_pad; ++r)
+        for (int t = 0; t < T; ++t) e->tips_host[((size_t)(r / 64) * T + t) * 64 + (r % 64)] = (uint8_t)(x->states[(size_t)(e->S - 1) * T + t] - 1);
   } else {
     e->tips_host.resize(T);
     for (int t = 0; t < T; ++t) e->tips_host[t] = (uint8_t)(x->states[t] - 1);
@@ -669,7 +690,7 @@ int32_t phm_engine_create_multi(const phm_tree* trees, int32_t n_trees, const ph
     phm::WideParams& p = e->pw;
     p.n_states = n; p.n_tips = s.n_tips; p.n_node = s.n_node; p.n_edge = s.n_edge; p.root = s.root;
     p.n_tiles = e->tiles; p.n_rep = n_trees > 1 ? e->S_tree : e->S; p.n_rep_pad = e->S_pad; p.replica_offset = o.replica_offset;
-    p.tiles_per_tree = n_trees > 1 ? e->tpt : 0; p.roots = e->d_roots.as<int32_t>();
+    p.tiles_per_tree = n_trees > 1 ? e->tpt : 0; p.roots = e->d_roots.as<int32_t>(); p.rep_stride = e->rpt;
     p.normalise = normalised(e->variant); p.tips_per_replica = e->tips_per_replica ? 1 : 0;
     p.reduce = e->reduce; p.n_cols = e->dcols; p.ktab = phm::WIDE_KTAB; p.sparse = (e->variant == PHM_MCMC_SPARSE); p.ks = ks_layout(e->variant); p.count_self = p.ks; p.tip_masks = hidden_rates(e->variant);
     p.maskpow = e->d_mask.as<double>();

@@ -138,7 +138,8 @@ struct phm_engine {
   int n_trees = 1, S_tree = 0, tpt = 0;   // list of trees: S_tree chains per tree on tpt tiles each; S = n_trees * S_tree
   DevBuf d_roots;
   // logical replica r (tree-major) -> lane index in the padded device layout
-  int pad_index(int r) const { return n_trees > 1 ? (r / S_tree) * tpt * 64 + r % S_tree : r; }
+  int rpt = 64;                        // replicas placed on one tile (n > 4 spreads few replicas thinly, see phm_wide.hip)
+  int pad_index(int r) const { return n_trees > 1 ? (r / S_tree) * tpt * 64 + r % S_tree : (r / rpt) * 64 + r % rpt; }
   std::vector<uint8_t> tips_host;      // 0-based, [n_tips] or [tile][n_tips][64]
   bool tips_per_replica = false;
   int64_t rows = 0;

@@ -24,6 +24,7 @@ struct WideParams {
   int32_t ks;                                // 1: bf/ks layout (n x n counts incl. self pairs, root-state column)
   int32_t tip_masks;                         // 1 (ks): parity tip masks, tips re-sampled
   int32_t count_self;                        // 1: n x n transition counts incl. self pairs (shortenerbf :1010-1014)
+  int32_t rep_stride;                        // replicas placed on one tile (1..64; 64 = dense), single tree only
   int32_t tiles_per_tree;                    // 0: one tree; else tile t walks tree t / tiles_per_tree (up, down hold one
   const int32_t* roots;                      //    schedule per tree back to back, roots[tree] the internal root index)
   uint32_t seed_lo, seed_hi;

@@ -85,12 +85,17 @@ __global__ __launch_bounds__(WIDE_BLOCK) void mcmc_wide_kernel(WideParams p, int
   __syncthreads();
   if (tile >= p.n_tiles) return;
 
-  const int rep_local = tile * 64 + lane;
-  const uint32_t rep0 = (uint32_t)(p.replica_offset + tile * 64);
-  const uint32_t rep = rep0 + (uint32_t)lane;
+  const int rep_local = tile * 64 + lane;                 // position in the padded statistics layout
   // list of trees (maketreelistMCMCmt :2267): consecutive groups of tiles walk different topologies with one model
   const int tree = p.tiles_per_tree ? tile / p.tiles_per_tree : 0;
-  const bool valid = (rep_local - tree * p.tiles_per_tree * 64) < p.n_rep;
+  // Replicas of this tile that exist.  The n-vector work below takes the replicas of a tile in turn and skips the padding
+  // lanes; with few replicas the host therefore spreads them thinly (rep_stride < 64 replicas per tile) so that many waves
+  // share the work.  Padding lanes carry a one-segment dummy path through the scalar part.
+  const int stride = p.tiles_per_tree ? 64 : p.rep_stride;
+  const int nr = min(stride, p.n_rep - (tile - tree * p.tiles_per_tree) * stride);
+  const bool valid = lane < nr;
+  const uint32_t rep0 = (uint32_t)(p.replica_offset + tile * stride);       // Philox replica word = logical replica id
+  const uint32_t rep = rep0 + (uint32_t)lane;
   const UpStep* __restrict__ up = p.up + (size_t)tree * p.n_node;
   const DownStep* __restrict__ down = p.down + (size_t)tree * p.n_edge;
   const int root = p.tiles_per_tree ? p.roots[tree] : p.root;
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) void mcmc_wide_kernel(WideParams p, int
       int ta = 0, tb = 0;
       if (st.child[0] < 0) ta = p.tips_per_replica ? tips_t[(~st.child[0]) * 64 + lane] : p.tips[~st.child[0]];
       if (st.child[1] < 0) tb = p.tips_per_replica ? tips_t[(~st.child[1]) * 64 + lane] : p.tips[~st.child[1]];
-      for (int r = 0; r < 64; ++r) {
+      for (int r = 0; r < nr; ++r) {
         const int mar = __builtin_amdgcn_readlane(ma, r), mbr = __builtin_amdgcn_readlane(mb, r);
         const int tar = __builtin_amdgcn_readlane(ta, r), tbr = __builtin_amdgcn_readlane(tb, r);
         double x = child_vec(st.child[1], mbr - 1, r, tbr);        // "first"  (:508)
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) void mcmc_wide_kernel(WideParams p, int
     // ------------------------------ root ------------------------------
     {
       int mine = 0;
-      for (int r = 0; r < 64; ++r) {
+      for (int r = 0; r < nr; ++r) {
         double pr = (lane < n) ? pid_c * PLt[((size_t)root * 64 + r) * n + c] : 0.0;     // :618
         double u = uni_draw(p, rep0 + r, (uint32_t)it, ENT_NODE | (uint32_t)(root + p.n_tips), 0);
         int rs = coop_sample(pr, u, n, lane, err);                                         // :627
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) void mcmc_wide_kernel(WideParams p, int
     for (int k = 0; k < p.n_edge; ++k) {
       const DownStep ds = down[k];
       const int b = ds.edge;
-      int m = mct[b * 64 + lane];
+      int m = valid ? (int)mct[b * 64 + lane] : 1;
       const int ps = nst[ds.parent * 64 + lane];
       int mmax = wave_max_w(m);
       int cs = 0;
@@ -189,7 +194,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) void mcmc_wide_kernel(WideParams p, int
       }
 
       // ---- n-vector work, replicas in turn: child state, then the interior states of the branch ----
-      for (int r = 0; r < 64; ++r) {
+      for (int r = 0; r < nr; ++r) {
         const int mr = __builtin_amdgcn_readlane(m, r);
         const int psr = __builtin_amdgcn_readlane(ps, r);
         int csr;
@@ -278,7 +283,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) void mcmc_wide_kernel(WideParams p, int
         // :752) when statistics are per replica; a fresh partial handed to one atomic when they are summed
         double acc = red ? 0.0 : srow[(size_t)s * cstride];
         uint32_t edraw = 0;
-        bool stuck = false, done = false;
+        bool stuck = !valid, done = false;             // padding lanes: one piece, no draws
         while (!done) {
           double piece;
           bool adv;

@@ -251,6 +251,39 @@ def test_mcmc_per_site_tips_and_reduce(mapping):
     np.testing.assert_allclose(red[:, :4], total[:, :4], rtol=1e-12)
 
 
+def test_wide_kernel_per_site_tips_on_thinly_filled_tiles():
+    """n > 4 with few replicas: the engine places fewer than 64 replicas on a tile (the wave takes them in turn) -- per-site
+    tip vectors, per-replica statistics and the reduced sum must still belong to the right replica."""
+    n = 6
+    Q = synth.dense_Q(n, 0.02, 0.08, seed=60)
+    Omega = 1.25 * float(np.max(np.abs(np.diag(Q))))
+    pid = np.full(n, 1.0 / n)
+    z = synth.make_tree(14, Q, Omega, 61, pid, init_segments=n)
+    nen, nodelist, root = _orders(z)
+    S, N, seed = 5, 12, 19
+    sites = np.random.default_rng(1).integers(1, n + 1, size=(S, 14)).astype(np.int32)
+    eng = _lib.Engine(z, Q, pid, Omega, N, variant=_lib.PHM_MCMC_BIGTREE, seed=seed, n_replicas=S, tips_per_replica=True, states=sites)
+    assert eng.info().n_replicas_padded == 64 * S                         # one replica per tile
+    eng.run(N); eng.sync()
+    per = eng.stats(0, N)
+    total = np.zeros_like(per[0])
+    for r in range(S):
+        zr = dict(z); zr["states"] = sites[r]
+        want, rc, dump = O.maketreelistMCMC(zr, Q, pid, np.eye(n) + Q / Omega, Omega, nen, nodelist, root, N, variant=O.BIGTREE,
+                                            seed=seed, replica=r, dump=True)
+        assert rc == 0
+        np.testing.assert_array_equal(per[r], want)
+        np.testing.assert_array_equal(eng.dump(r)["node_states"], dump.node_states)
+        total += want
+    eng.close()
+    eng = _lib.Engine(z, Q, pid, Omega, N, variant=_lib.PHM_MCMC_BIGTREE, seed=seed, n_replicas=S, tips_per_replica=True, states=sites, reduce=True)
+    eng.run(N); eng.sync()
+    red = eng.stats(0, N)
+    eng.close()
+    np.testing.assert_array_equal(red[:, n:], total[:, n:])
+    np.testing.assert_allclose(red[:, :n], total[:, :n], rtol=1e-12)
+
+
 @pytest.mark.parametrize("n,fn,variant", [(20, "sumstatMCMC", O.PLAIN), (20, "SPARSEsumstatMCMC", O.SPARSE),
                                           (20, "sumstatMCMC_bigtree", O.BIGTREE), (5, "sumstatMCMC", O.PLAIN),
                                           (61, "sumstatMCMC_bigtree", O.BIGTREE), (64, "sumstatMCMC", O.PLAIN)])
