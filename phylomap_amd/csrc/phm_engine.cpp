@@ -29,7 +29,7 @@ void fill_params(phm_engine* e, phm::McmcParams<NS>& p, const double* B2, const 
   p.n_tiles = e->tiles; p.n_rep = e->n_trees > 1 ? e->S_tree : e->S; p.n_rep_pad = e->S_pad; p.replica_offset = o.replica_offset;
   p.tiles_per_tree = e->n_trees > 1 ? e->tpt : 0; p.roots = e->d_roots.as<int32_t>();
   p.normalise = normalised(e->variant); p.tips_per_replica = e->tips_per_replica ? 1 : 0;
-  p.reduce = e->reduce; p.n_cols = e->dcols; p.ktab = phm::MCMC_KTAB; p.prune_only = 0;
+  p.reduce = e->reduce; p.n_cols = e->dcols; p.ktab = phm::MCMC_KTAB; p.klong = std::max(e->nw_klong, phm::MCMC_KTAB); p.prune_only = 0;
   p.ks = ks_layout(e->variant); p.tip_masks = hidden_rates(e->variant);
   p.maskpow = e->d_mask.as<double>();
   p.seed_lo = (uint32_t)(o.seed & 0xFFFFFFFFull); p.seed_hi = (uint32_t)(o.seed >> 32);
@@ -76,7 +76,9 @@ int32_t compute_model(int variant, int n, const double* Q, const double* B, doub
 // chain tables for the current model -> device; refresh the by-value kernel parameter blocks
 int32_t upload_model(phm_engine* e) {
   const int n = e->n;
-  const int ktab = (e->narrow || e->tiled) ? e->nw_klong : e->wide ? phm::WIDE_KTAB : phm::MCMC_KTAB;
+  // rows of the chain tables: every mapping keeps full-length tables in global memory (nw_klong > every possible segment
+  // count); the replica kernels additionally stage the first MCMC_KTAB rows in LDS
+  const int ktab = (e->narrow || e->tiled) ? e->nw_klong : std::max(e->nw_klong, e->wide ? phm::WIDE_KTAB : phm::MCMC_KTAB);
   const double* Bc = e->hBc.data();
   std::vector<double> col, row;
   build_chain_tables(Bc, n, ktab, col, row);
@@ -608,7 +610,10 @@ int32_t phm_engine_create_multi(const phm_tree* trees, int32_t n_trees, const ph
   }
 
   std::vector<double> col, row;
-  const int ktab = e->wide ? phm::WIDE_KTAB : phm::MCMC_KTAB;
+  // Full-length chain tables in global memory: the LDS copies of the replica kernels hold MCMC_KTAB rows, a longer chain
+  // reads row k of these instead of being continued step by step (which made a draw on an m-segment branch cost O(m)).
+  e->nw_klong = e->wide ? phm::wide_maxseg(n) + 1 : (int)std::min<int64_t>(65536, rows + 1);
+  const int ktab = std::max(e->nw_klong, e->wide ? phm::WIDE_KTAB : phm::MCMC_KTAB);
   col.assign((size_t)ktab * n * n, 0.0); row.assign((size_t)ktab * n * n, 0.0);     // sizes only; filled by upload_model
   std::vector<double> maskpow((size_t)ktab * 2 * n, 0.0);
 
@@ -692,7 +697,7 @@ int32_t phm_engine_create_multi(const phm_tree* trees, int32_t n_trees, const ph
     p.n_tiles = e->tiles; p.n_rep = n_trees > 1 ? e->S_tree : e->S; p.n_rep_pad = e->S_pad; p.replica_offset = o.replica_offset;
     p.tiles_per_tree = n_trees > 1 ? e->tpt : 0; p.roots = e->d_roots.as<int32_t>(); p.rep_stride = e->rpt;
     p.normalise = normalised(e->variant); p.tips_per_replica = e->tips_per_replica ? 1 : 0;
-    p.reduce = e->reduce; p.n_cols = e->dcols; p.ktab = phm::WIDE_KTAB; p.sparse = (e->variant == PHM_MCMC_SPARSE); p.ks = ks_layout(e->variant); p.count_self = p.ks; p.tip_masks = hidden_rates(e->variant);
+    p.reduce = e->reduce; p.n_cols = e->dcols; p.ktab = std::max(e->nw_klong, phm::WIDE_KTAB); p.sparse = (e->variant == PHM_MCMC_SPARSE); p.ks = ks_layout(e->variant); p.count_self = p.ks; p.tip_masks = hidden_rates(e->variant);
     p.maskpow = e->d_mask.as<double>();
     p.seed_lo = (uint32_t)(o.seed & 0xFFFFFFFFull); p.seed_hi = (uint32_t)(o.seed >> 32);
     p.rows = e->rows;

@@ -18,7 +18,8 @@ struct McmcParams {
   int32_t n_tips, n_node, n_edge, root;      // root: internal index
   int32_t n_tiles, n_rep, n_rep_pad, replica_offset;
   int32_t normalise, tips_per_replica, reduce, n_cols;
-  int32_t ktab;
+  int32_t ktab;                              // rows of the chain tables staged in LDS
+  int32_t klong;                             // rows of the tables in global memory (>= ktab; covers every possible segment count)
   int32_t ks;                                // 1: bf/ks layout: n x n counts incl. self pairs (shortenerbf), root-state column
   int32_t tip_masks;                         // 1 (ks): tips observed up to parity and re-sampled; 0 (bf): tips observed
   int32_t prune_only;                        // measurement aid: run only the pruning (up) sweep of each iteration

@@ -41,10 +41,18 @@ __device__ __forceinline__ void child_vector(const McmcParams<NS>& p, const doub
     // one-hot row -> column `state` of B^k; ks: parity mask row (:1838-1845) -> B^k applied to that mask
     int tip = ~child;
     int st = p.tips_per_replica ? tips_t[tip * 64 + lane] : p.tips[tip];
-    int kt = k < p.ktab ? k : p.ktab - 1;
-    const double* src = (KS && p.tip_masks) ? s_mask + (kt * 2 + (st & 1)) * NS : s_col + (kt * NS + st) * NS;
+    // chains of up to ktab - 1 steps from the LDS copy; longer ones from the full-length table in global memory (L2), whose
+    // rows are the same chain run on the host; only beyond that table (never, by construction of klong) is the chain continued
+    int kt = k < p.klong ? k : p.klong - 1;
+    if (kt < p.ktab) {                       // separate branches: an LDS read and a global read, never a generic pointer
+      const double* src = (KS && p.tip_masks) ? s_mask + (kt * 2 + (st & 1)) * NS : s_col + (kt * NS + st) * NS;
 #pragma unroll
-    for (int c = 0; c < NS; ++c) v[c] = src[c];
+      for (int c = 0; c < NS; ++c) v[c] = src[c];
+    } else {
+      const double* __restrict__ src = (KS && p.tip_masks) ? p.maskpow + ((size_t)kt * 2 + (st & 1)) * NS : p.colpow + ((size_t)kt * NS + st) * NS;
+#pragma unroll
+      for (int c = 0; c < NS; ++c) v[c] = src[c];
+    }
     for (int i = kt; i < k; ++i) matvec_u<NS>(p.Bc, v);
   } else {
 #pragma unroll
@@ -173,10 +181,16 @@ __device__ __forceinline__ void sweep_body(const McmcParams<NS>& p, int iter0, i
         // child ~ e_ps^T B^(m-1) (.) PL[child]   (Tvmmp :431-436, :651); ks: tips too, against their mask (:1384-1397)
         double w[NS];
         int kk = m - 1;
-        int kt = kk < p.ktab ? kk : p.ktab - 1;
-        const double* src = s_row + (kt * NS + ps) * NS;
+        int kt = kk < p.klong ? kk : p.klong - 1;
+        if (kt < p.ktab) {
+          const double* src = s_row + (kt * NS + ps) * NS;
 #pragma unroll
-        for (int c = 0; c < NS; ++c) w[c] = src[c];
+          for (int c = 0; c < NS; ++c) w[c] = src[c];
+        } else {
+          const double* __restrict__ src = p.rowpow + ((size_t)kt * NS + ps) * NS;
+#pragma unroll
+          for (int c = 0; c < NS; ++c) w[c] = src[c];
+        }
         for (int i = kt; i < kk; ++i) {           // beyond the table: continue the same chain, w <- B^T w
           double yv[NS];
 #pragma unroll
@@ -226,10 +240,16 @@ __device__ __forceinline__ void sweep_body(const McmcParams<NS>& p, int iter0, i
       auto draw_state = [&](int i, int sprev) -> int {
         int kk = m - i - 1;
         double pr[NS];
-        int kt = kk < p.ktab ? kk : p.ktab - 1;
-        const double* beta = s_col + (kt * NS + cs) * NS;
+        int kt = kk < p.klong ? kk : p.klong - 1;
+        if (kt < p.ktab) {
+          const double* beta = s_col + (kt * NS + cs) * NS;
 #pragma unroll
-        for (int c = 0; c < NS; ++c) pr[c] = beta[c];
+          for (int c = 0; c < NS; ++c) pr[c] = beta[c];
+        } else {
+          const double* __restrict__ beta = p.colpow + ((size_t)kt * NS + cs) * NS;
+#pragma unroll
+          for (int c = 0; c < NS; ++c) pr[c] = beta[c];
+        }
         for (int q = kt; q < kk; ++q) matvec_u<NS>(p.Bc, pr);
         const double* row = s_B2 + sprev * NS;
 #pragma unroll
