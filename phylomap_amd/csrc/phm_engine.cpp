@@ -140,6 +140,7 @@ void fill_narrow_params(phm_engine* e, phm::NarrowParams<NS>& p, const phm_optio
   for (int i = 0; i < NS; ++i) { p.scale[i] = e->hscale[i]; p.pid[i] = e->hpid[i]; }
   p.up = e->d_up.as<phm::UpStep>(); p.down = e->d_down.as<phm::DownStep>();
   p.up_order = e->d_nw_up_order.as<int32_t>(); p.down_order = e->d_nw_down_order.as<int32_t>();
+  p.up_off = e->d_nw_up_off.as<int32_t>(); p.down_off = e->d_nw_down_off.as<int32_t>();
   p.branch_order = e->d_nw_border.as<int32_t>(); p.off = e->d_nw_off.as<int64_t>();
   p.colL = e->d_nw_colL.as<double>(); p.rowL = e->d_nw_rowL.as<double>(); p.maskL = e->d_nw_maskL.as<double>();
   p.tips = e->d_tips.as<uint8_t>();
@@ -184,6 +185,9 @@ int32_t build_level_orders(phm_engine* e) {
   HIPCHK(e->d_nw_up_order.alloc(sizeof(int32_t) * Nn)); HIPCHK(e->d_nw_down_order.alloc(sizeof(int32_t) * E));
   HIPCHK(hipMemcpy(e->d_nw_up_order.p, up_order.data(), e->d_nw_up_order.bytes, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(e->d_nw_down_order.p, down_order.data(), e->d_nw_down_order.bytes, hipMemcpyHostToDevice));
+  HIPCHK(e->d_nw_up_off.alloc(sizeof(int32_t) * e->nw_up_off.size())); HIPCHK(e->d_nw_down_off.alloc(sizeof(int32_t) * e->nw_down_off.size()));
+  HIPCHK(hipMemcpy(e->d_nw_up_off.p, e->nw_up_off.data(), e->d_nw_up_off.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(e->d_nw_down_off.p, e->nw_down_off.data(), e->d_nw_down_off.bytes, hipMemcpyHostToDevice));
   return PHM_OK;
 }
 

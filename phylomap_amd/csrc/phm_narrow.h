@@ -41,6 +41,8 @@ struct NarrowParams {
   const DownStep* down;                      // [n_edge]
   const int32_t* up_order;                   // positions into up[], grouped by height level
   const int32_t* down_order;                 // positions into down[], grouped by depth level
+  const int32_t* up_off;                     // level boundaries into up_order (device copy of the host array)
+  const int32_t* down_off;                   // level boundaries into down_order
   const int32_t* branch_order;               // edge rows, largest capacity first
   const int64_t* off;                        // [n_edge + 1] CSR offsets of the branch slots
   const double* colL;                        // [klong][NS][NS]  (Bc^k e_j)[r]

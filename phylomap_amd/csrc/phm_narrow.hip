@@ -25,16 +25,13 @@ __device__ __forceinline__ void child_vec(const NarrowParams<NS>& p, const doubl
   }
 }
 
+// one internal node of one chain: PL[parent] = (B^(ma-1) PL[a]) (.) (B^(mb-1) PL[b])
 template <int NS>
-__global__ __launch_bounds__(NARROW_BLOCK) void narrow_up_kernel(NarrowParams<NS> p, int begin, int end) {
-  const int idx = begin + blockIdx.x * NARROW_BLOCK + threadIdx.x;
-  const int r = blockIdx.y;
-  if (idx >= end) return;
+__device__ __forceinline__ void up_node(const NarrowParams<NS>& p, int r, int idx, uint32_t& err) {
   const UpStep st = p.up[p.up_order[idx]];
   const int32_t* __restrict__ mc = p.mcount + (size_t)r * p.n_edge;
-  double* __restrict__ PLr = p.PL + (size_t)r * p.n_node * NS;
+  double* PLr = p.PL + (size_t)r * p.n_node * NS;
   const uint8_t* __restrict__ tips = p.tips_per_replica ? p.tips + (size_t)r * p.n_tips : p.tips;
-  uint32_t err = 0;
   double x[NS], y[NS];
   child_vec<NS>(p, PLr, tips, st.child[1], mc[st.edge[1]] - 1, x, err);        // "first"  (:508)
   child_vec<NS>(p, PLr, tips, st.child[0], mc[st.edge[0]] - 1, y, err);        // "second" (:509)
@@ -49,37 +46,37 @@ __global__ __launch_bounds__(NARROW_BLOCK) void narrow_up_kernel(NarrowParams<NS
   }
 #pragma unroll
   for (int c = 0; c < NS; ++c) PLr[st.parent * NS + c] = x[c];
+}
+
+template <int NS>
+__global__ __launch_bounds__(NARROW_BLOCK) void narrow_up_kernel(NarrowParams<NS> p, int begin, int end) {
+  const int idx = begin + blockIdx.x * NARROW_BLOCK + threadIdx.x;
+  if (idx >= end) return;
+  uint32_t err = 0;
+  up_node<NS>(p, blockIdx.y, idx, err);
   if (err) atomicOr(p.err, err);
 }
 
 template <int NS>
-__global__ __launch_bounds__(NARROW_BLOCK) void narrow_root_kernel(NarrowParams<NS> p, int it) {
-  const int r = blockIdx.x * NARROW_BLOCK + threadIdx.x;
-  if (r >= p.n_rep) return;
-  const double* __restrict__ PLr = p.PL + (size_t)r * p.n_node * NS;
-  uint32_t err = 0;
+__device__ __forceinline__ void root_node(const NarrowParams<NS>& p, int r, int it, uint32_t& err) {
+  const double* PLr = p.PL + (size_t)r * p.n_node * NS;
   double pr[NS];
 #pragma unroll
   for (int c = 0; c < NS; ++c) pr[c] = p.pid[c] * PLr[p.root * NS + c];        // :618
   const double u = stream_u(p.seed_lo, p.seed_hi, (uint32_t)(p.replica_offset + r), (uint32_t)it,
                             ENT_NODE | (uint32_t)(p.root + p.n_tips), 0);
   p.nstate[(size_t)r * p.n_node + p.root] = (uint8_t)sample_cat<NS>(pr, u, err);   // :627
-  if (err) atomicOr(p.err, err);
 }
 
 // child ~ e_ps^T B^(m-1) (.) PL[child]   (Tvmmp :431-436, :651); ks: tips too, against their parity mask (:1384-1397)
 template <int NS>
-__global__ __launch_bounds__(NARROW_BLOCK) void narrow_down_kernel(NarrowParams<NS> p, int it, int begin, int end) {
-  const int idx = begin + blockIdx.x * NARROW_BLOCK + threadIdx.x;
-  const int r = blockIdx.y;
-  if (idx >= end) return;
+__device__ __forceinline__ void down_edge(const NarrowParams<NS>& p, int r, int it, int idx, uint32_t& err) {
   const DownStep ds = p.down[p.down_order[idx]];
   const int b = ds.edge;
   const int m = p.mcount[(size_t)r * p.n_edge + b];
   uint8_t* __restrict__ nst = p.nstate + (size_t)r * p.n_node;
   const uint8_t* __restrict__ tips = p.tips_per_replica ? p.tips + (size_t)r * p.n_tips : p.tips;
   const int ps = nst[ds.parent];
-  uint32_t err = 0;
   int cs;
   if (ds.child >= 0 || (p.ks && p.tip_masks)) {
     int kk = m - 1;
@@ -107,6 +104,39 @@ __global__ __launch_bounds__(NARROW_BLOCK) void narrow_down_kernel(NarrowParams<
   }
   uint8_t* es = p.estate + ((size_t)r * p.n_edge + b) * 2;
   es[0] = (uint8_t)ps; es[1] = (uint8_t)cs;                                    // updatenodestates :460-475
+}
+
+template <int NS>
+__global__ __launch_bounds__(NARROW_BLOCK) void narrow_down_kernel(NarrowParams<NS> p, int it, int begin, int end) {
+  const int idx = begin + blockIdx.x * NARROW_BLOCK + threadIdx.x;
+  if (idx >= end) return;
+  uint32_t err = 0;
+  down_edge<NS>(p, blockIdx.y, it, idx, err);
+  if (err) atomicOr(p.err, err);
+}
+
+// The levels near the root hold a handful of nodes each; one workgroup per chain walks them in a single launch -- the top
+// of the pruning sweep, the root draw, the first levels of the sampling sweep -- with a device-scope fence and a barrier
+// between levels (the next level reads what this one wrote through L2).
+constexpr int NARROW_MID_BLOCK = 256;
+template <int NS>
+__global__ __launch_bounds__(NARROW_MID_BLOCK) void narrow_mid_kernel(NarrowParams<NS> p, int it, int up_first, int up_levels,
+                                                                      int down_levels) {
+  const int r = blockIdx.x;
+  uint32_t err = 0;
+  for (int l = up_first; l < up_levels; ++l) {
+    for (int idx = p.up_off[l] + threadIdx.x; idx < p.up_off[l + 1]; idx += NARROW_MID_BLOCK) up_node<NS>(p, r, idx, err);
+    __threadfence();
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) root_node<NS>(p, r, it, err);
+  __threadfence();
+  __syncthreads();
+  for (int l = 0; l < down_levels; ++l) {
+    for (int idx = p.down_off[l] + threadIdx.x; idx < p.down_off[l + 1]; idx += NARROW_MID_BLOCK) down_edge<NS>(p, r, it, idx, err);
+    __threadfence();
+    __syncthreads();
+  }
   if (err) atomicOr(p.err, err);
 }
 
@@ -280,14 +310,19 @@ template <int NS>
 hipError_t launch_narrow_sweep(const NarrowParams<NS>& p, const std::vector<int32_t>& up_off,
                                const std::vector<int32_t>& down_off, int it, hipStream_t stream) {
   const unsigned S = (unsigned)p.n_rep;
-  for (size_t l = 0; l + 1 < up_off.size(); ++l) {
+  // big levels: one launch each; the small levels around the root: one launch for all of them
+  const int UL = (int)up_off.size() - 1, DL = (int)down_off.size() - 1;
+  int up_first = UL, down_levels = 0;
+  while (up_first > 0 && up_off[up_first] - up_off[up_first - 1] <= NARROW_MID_BLOCK) --up_first;
+  while (down_levels < DL && down_off[down_levels + 1] - down_off[down_levels] <= NARROW_MID_BLOCK) ++down_levels;
+  for (int l = 0; l < up_first; ++l) {
     const int n = up_off[l + 1] - up_off[l];
     if (n <= 0) continue;
     hipLaunchKernelGGL(narrow_up_kernel<NS>, dim3((n + NARROW_BLOCK - 1) / NARROW_BLOCK, S), dim3(NARROW_BLOCK), 0, stream, p,
                        up_off[l], up_off[l + 1]);
   }
-  hipLaunchKernelGGL(narrow_root_kernel<NS>, dim3((S + NARROW_BLOCK - 1) / NARROW_BLOCK), dim3(NARROW_BLOCK), 0, stream, p, it);
-  for (size_t l = 0; l + 1 < down_off.size(); ++l) {
+  hipLaunchKernelGGL(narrow_mid_kernel<NS>, dim3(S), dim3(NARROW_MID_BLOCK), 0, stream, p, it, up_first, UL, down_levels);
+  for (int l = down_levels; l < DL; ++l) {
     const int n = down_off[l + 1] - down_off[l];
     if (n <= 0) continue;
     hipLaunchKernelGGL(narrow_down_kernel<NS>, dim3((n + NARROW_BLOCK - 1) / NARROW_BLOCK, S), dim3(NARROW_BLOCK), 0, stream, p,
