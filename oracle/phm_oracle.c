@@ -11,7 +11,8 @@
  *   - categorical draw: first j with u*sum(p) <= p_0+..+p_j (index order, no sort; see
  *     sample_cat below for why RcppArmadillo's descending sort is not restated);
  *   - Exp(rate r) gap = (1/r) * (-phm_log(u))   (Rcpp::rexp(n,rate) multiplies by scale=1/rate);
- *   - uniforms from Philox4x32-10 keyed (seed) with counter (block, entity, iteration, replica).
+ *   - uniforms from Philox4x32-10 keyed (seed) with counter (block, entity, iteration, replica); draw d of a stream is
+ *     word d%4 of block d/4, mapped to (0,1) as (x + 0.5) 2^-32.
  */
 #include "phm_oracle.h"
 
@@ -38,21 +39,19 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-/* 64 random bits -> double in the OPEN interval (0,1): ((x>>12)+0.5)*2^-52, exact. */
-double orc_u01(uint32_t lo, uint32_t hi) {
-  uint64_t x = ((uint64_t)hi << 32) | lo;
-  uint64_t k = ((x >> 12) << 1) | 1u;               /* odd, < 2^53: exact in a double */
-  return (double)k * 1.1102230246251565404e-16;     /* 2^-53 */
+/* 32 random bits -> double in the OPEN interval (0,1): (x + 0.5) * 2^-32, exact (the resolution of R's unif_rand). */
+double orc_u01(uint32_t x) {
+  return ((double)x + 0.5) * 2.3283064365386962890625e-10;   /* 2^-32 */
 }
 
-/* draw number `draw` of stream (replica, iter, entity): Philox block draw/2, words (0,1) or (2,3) */
+/* draw number `draw` of stream (replica, iter, entity): Philox block draw/4, word draw%4 */
 double orc_stream_u(uint32_t seed_lo, uint32_t seed_hi, uint32_t replica, uint32_t iter,
                     uint32_t entity, uint32_t draw) {
-  uint32_t ctr[4] = { draw >> 1, entity, iter, replica };
+  uint32_t ctr[4] = { draw >> 2, entity, iter, replica };
   uint32_t key[2] = { seed_lo, seed_hi };
   uint32_t o[4];
   orc_philox4x32_10(ctr, key, o);
-  return (draw & 1u) ? orc_u01(o[2], o[3]) : orc_u01(o[0], o[1]);
+  return orc_u01(o[draw & 3u]);
 }
 
 /* entity tags (top two bits of the entity word) */

@@ -82,7 +82,7 @@ typedef struct orc_dump {
 
 /* ---- deterministic scalar maths (spec shared, by restatement, with the HIP kernels) ---- */
 void   orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
-double orc_u01(uint32_t lo, uint32_t hi);   /* ((x>>12)+0.5)*2^-52, x = hi:lo */
+double orc_u01(uint32_t x);   /* (x + 0.5) * 2^-32 */
 double orc_log(double x);
 double orc_exp(double x);
 double orc_stream_u(uint32_t seed_lo, uint32_t seed_hi, uint32_t replica, uint32_t iter,

@@ -1,7 +1,7 @@
 // phm_device.h -- device-side scalar building blocks shared by every kernel.
 //
 // These restate, independently of oracle/phm_oracle.c, the arithmetic spec of DESIGN.md:
-// Philox4x32-10 counter streams, the (0,1) map of 64 random bits, and the deterministic
+// Philox4x32-10 counter streams, the (0,1) map of 32 random bits, and the deterministic
 // log/exp (basic IEEE-754 binary64 operations only, no FMA contraction: the library is built
 // with -ffp-contract=off) so that the CPU oracle and the GPU agree bit for bit.
 #pragma once
@@ -39,32 +39,31 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
   o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
 }
 
-// 64 random bits -> double in the open interval (0,1): ((x>>12)+0.5)*2^-52, exact
-__device__ __forceinline__ double u01(uint32_t lo, uint32_t hi) {
-  uint64_t x = ((uint64_t)hi << 32) | lo;
-  uint64_t k = ((x >> 12) << 1) | 1ull;
-  return (double)k * 1.1102230246251565404e-16;
+// 32 random bits -> double in the open interval (0,1): (x + 0.5) * 2^-32, exact.  R's own unif_rand (which the reference
+// draws from through runif / rexp / sample) has the same 32-bit resolution; four uniforms come out of one Philox block.
+__device__ __forceinline__ double u01(uint32_t x) {
+  return ((double)x + 0.5) * 2.3283064365386962890625e-10;
 }
 
-// Sequential draws of one stream (replica, iteration, entity): draw d lives in Philox block d>>1.
+// Sequential draws of one stream (replica, iteration, entity): draw d is word d & 3 of Philox block d >> 2.
 struct Stream {
   uint32_t ent, iter, rep, k0, k1;
   uint32_t blk;
-  double u0, u1;
+  uint32_t w0, w1, w2, w3;
   __device__ __forceinline__ void open(uint32_t entity, uint32_t iteration, uint32_t replica, uint32_t seed_lo,
                                        uint32_t seed_hi) {
-    ent = entity; iter = iteration; rep = replica; k0 = seed_lo; k1 = seed_hi; blk = 0xFFFFFFFFu; u0 = 0.5; u1 = 0.5;
+    ent = entity; iter = iteration; rep = replica; k0 = seed_lo; k1 = seed_hi; blk = 0xFFFFFFFFu; w0 = w1 = w2 = w3 = 0u;
   }
   __device__ __forceinline__ double draw(uint32_t d) {
-    uint32_t b = d >> 1;
+    uint32_t b = d >> 2;
     if (b != blk) {
       uint32_t o[4];
       philox4x32_10(b, ent, iter, rep, k0, k1, o);
-      u0 = u01(o[0], o[1]);
-      u1 = u01(o[2], o[3]);
+      w0 = o[0]; w1 = o[1]; w2 = o[2]; w3 = o[3];
       blk = b;
     }
-    return (d & 1u) ? u1 : u0;
+    const uint32_t lo = (d & 1u) ? w1 : w0, hi = (d & 1u) ? w3 : w2;
+    return u01((d & 2u) ? hi : lo);
   }
 };
 
@@ -72,8 +71,9 @@ struct Stream {
 __device__ __forceinline__ double stream_u(uint32_t seed_lo, uint32_t seed_hi, uint32_t rep, uint32_t iter,
                                            uint32_t ent, uint32_t d) {
   uint32_t o[4];
-  philox4x32_10(d >> 1, ent, iter, rep, seed_lo, seed_hi, o);
-  return (d & 1u) ? u01(o[2], o[3]) : u01(o[0], o[1]);
+  philox4x32_10(d >> 2, ent, iter, rep, seed_lo, seed_hi, o);
+  const uint32_t lo = (d & 1u) ? o[1] : o[0], hi = (d & 1u) ? o[3] : o[2];
+  return u01((d & 2u) ? hi : lo);
 }
 
 // natural log for normal positive finite x (all callers pass u in (0,1) or validated positives)

@@ -33,9 +33,8 @@ struct UpdateStream {
   double uniform() {
     uint32_t o[4];
     const uint32_t d = next++;
-    philox_host(d >> 1, 0xFFFFFF00u | id, iter, 0xFFFFFFFFu, (uint32_t)(seed & 0xFFFFFFFFull), (uint32_t)(seed >> 32), o);
-    const uint64_t x = (d & 1u) ? (((uint64_t)o[3] << 32) | o[2]) : (((uint64_t)o[1] << 32) | o[0]);
-    return (double)(((x >> 12) << 1) | 1ull) * 1.1102230246251565404e-16;
+    philox_host(d >> 2, 0xFFFFFF00u | id, iter, 0xFFFFFFFFu, (uint32_t)(seed & 0xFFFFFFFFull), (uint32_t)(seed >> 32), o);
+    return ((double)o[d & 3u] + 0.5) * 2.3283064365386962890625e-10;      // draw d = word d & 3 of block d >> 2, (x + 0.5) 2^-32
   }
   double gamma(double shape, double scale) {
     double boost = 1.0;

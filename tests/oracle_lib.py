@@ -47,7 +47,7 @@ def lib():
             subprocess.check_call(["make", "-C", os.path.join(_ROOT, "oracle")], stdout=subprocess.DEVNULL)
         L = C.CDLL(_SO)
         L.orc_u01.restype = C.c_double
-        L.orc_u01.argtypes = [C.c_uint32, C.c_uint32]
+        L.orc_u01.argtypes = [C.c_uint32]
         L.orc_log.restype = C.c_double
         L.orc_log.argtypes = [C.c_double]
         L.orc_exp.restype = C.c_double

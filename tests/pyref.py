@@ -23,9 +23,8 @@ def philox(ctr, key):
     return c0, c1, c2, c3
 
 
-def u01(lo, hi):
-    x = (hi << 32) | lo
-    return float(((x >> 12) << 1) | 1) * 2.0 ** -53
+def u01(x):
+    return (float(x) + 0.5) * 2.0 ** -32
 
 
 def d2u(x):
@@ -87,8 +86,8 @@ class Rng:
         self.rep = replica
 
     def u(self, it, ent, d):
-        o = philox((d >> 1, ent, it, self.rep), self.key)
-        return u01(o[2], o[3]) if d & 1 else u01(o[0], o[1])
+        o = philox((d >> 2, ent, it, self.rep), self.key)
+        return u01(o[d & 3])
 
 
 def matvec(M, v):

@@ -33,13 +33,13 @@ def test_philox_random123_known_answers():
 
 def test_u01_is_open_interval_and_exact():
     L = O.lib()
-    assert L.orc_u01(0, 0) == 2.0 ** -53
-    assert L.orc_u01(0xffffffff, 0xffffffff) == 1.0 - 2.0 ** -53
-    assert L.orc_u01(0x12345678, 0x9abcdef0) == pyref.u01(0x12345678, 0x9abcdef0)
-    # stream layout: draw d -> block d>>1, words (0,1) or (2,3)
+    assert L.orc_u01(0) == 2.0 ** -33                          # (x + 0.5) 2^-32: never 0, never 1, exact in a double
+    assert L.orc_u01(0xffffffff) == 1.0 - 2.0 ** -33
+    assert L.orc_u01(0x12345678) == pyref.u01(0x12345678) == (0x12345678 + 0.5) / 2.0 ** 32
+    # stream layout: draw d -> word d & 3 of Philox block d >> 2
     o = O.philox([3, 7, 9, 2], [5, 6])
-    assert L.orc_stream_u(5, 6, 2, 9, 7, 6) == L.orc_u01(o[0], o[1])
-    assert L.orc_stream_u(5, 6, 2, 9, 7, 7) == L.orc_u01(o[2], o[3])
+    for w in range(4):
+        assert L.orc_stream_u(5, 6, 2, 9, 7, 12 + w) == L.orc_u01(o[w])
 
 
 def test_log_exp_accuracy_and_python_twin():
