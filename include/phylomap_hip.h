@@ -13,8 +13,8 @@
  *  - matrices follow R's layout (COLUMN-major): Q, B, lefts, rights, d, edge, and the result;
  *  - every call returns a phm_status; phm_last_error() gives a thread-local message
  *    (the reference throws through BEGIN_RCPP/END_RCPP, src/RcppExports.cpp:35,53);
- * *  - randomness: Philox4x32-10 keyed by phm_options.seed, counter (block, entity, iteration,
- *    replica); the Rcpp shim draws the seed from R's stream inside its RNGScope
+ *  - randomness: Philox4x32-10 keyed by phm_options.seed, counter (block, entity, iteration,
+ *    replica), draw d = word d & 3 of block d >> 2 mapped to (x + 0.5) 2^-32; the Rcpp shim draws the seed from R's stream inside its RNGScope
  *    (src/RcppExports.cpp:38) so set.seed() still controls results;
  *  - there is NO CPU fallback: without a usable HIP device every compute call returns
  *    PHM_ERR_NO_DEVICE.
