@@ -15,6 +15,7 @@
  *     word d%4 of block d/4, mapped to (0,1) as (x + 0.5) 2^-32.
  */
 #include "phm_oracle.h"
+#include "../phylomap_amd/csrc/phm_logtab.h"     /* generated data shared with the kernels: tools/gen_log_table.py */
 
 #include <math.h>
 #include <stdlib.h>
@@ -52,6 +53,43 @@ double orc_stream_u(uint32_t seed_lo, uint32_t seed_hi, uint32_t replica, uint32
   uint32_t o[4];
   orc_philox4x32_10(ctr, key, o);
   return orc_u01(o[draw & 3u]);
+}
+
+/* the 32 random bits behind draw number `draw` of a stream */
+uint32_t orc_stream_word(uint32_t seed_lo, uint32_t seed_hi, uint32_t replica, uint32_t iter,
+                         uint32_t entity, uint32_t draw) {
+  uint32_t ctr[4] = { draw >> 2, entity, iter, replica };
+  uint32_t key[2] = { seed_lo, seed_hi };
+  uint32_t o[4];
+  orc_philox4x32_10(ctr, key, o);
+  return o[draw & 3u];
+}
+
+/* Standard exponential variate from 32 random bits: -log(U), U = (k + 0.5) 2^-32 -- what Rcpp::rexp's exp_rand delivers
+ * in distribution (src/phylomap.cpp:398).  y = 2k + 1 = 2^e f, f in [0.5, 1); table point c_j = 0.5 + (j + 0.5)/256 below f;
+ * -log U = -((e - 33) ln 2 + log c_j + log1p(r)), r = (f - c_j)/c_j with f - c_j exact, log1p by its series to r^7; within
+ * 2^-8 of U = 1 the series runs on r = f - 1 directly.  Same expression, same table (phm_logtab.h) as the kernels. */
+double orc_neglog_u32(uint32_t k) {
+  const double y = (double)k * 2.0 + 1.0;
+  int e;
+  const double f = frexp(y, &e);
+  const int top = (e == 33) && (f >= 0.99609375);
+  const int j = (int)((f - 0.5) * 256.0);
+  const double c = 0.501953125 + (double)j * 0.00390625;
+  double inv, lc;
+  memcpy(&inv, &PHM_LOGTAB_INV_BITS[j], sizeof inv);
+  memcpy(&lc, &PHM_LOGTAB_LOG_BITS[j], sizeof lc);
+  const double r = top ? f - 1.0 : (f - c) * inv;
+  const double c0 = top ? 0.0 : lc;
+  const double ee = top ? 0.0 : (double)(e - 33);
+  double p = 1.0 / 7.0;
+  p = p * r - 1.0 / 6.0;
+  p = p * r + 0.2;
+  p = p * r - 0.25;
+  p = p * r + 1.0 / 3.0;
+  p = p * r - 0.5;
+  p = p * r * r + r;
+  return -(ee * 6.93147180369123816490e-01 + (c0 + (p + ee * 1.90821492927058770002e-10)));
 }
 
 /* entity tags (top two bits of the entity word) */
@@ -212,7 +250,7 @@ static double draw_u(rngctx* c, uint32_t iter, uint32_t entity, uint32_t draw) {
   if (r->mode == 2) return r_unif_rand();
   return orc_stream_u(r->seed_lo, r->seed_hi, r->replica, iter + c->iter_base, entity, draw);
 }
-/* standard exponential: -log(u) (R's exp_rand is Ahrens-Dieter; not restated in Philox mode) */
+/* standard exponential: orc_neglog_u32 of the draw's 32 bits (R's exp_rand is Ahrens-Dieter; restated in R-stream mode only) */
 static double draw_e(rngctx* c, uint32_t iter, uint32_t entity, uint32_t draw) {
   orc_rng* r = c->r;
   if (r->mode == 1) {
@@ -220,7 +258,7 @@ static double draw_e(rngctx* c, uint32_t iter, uint32_t entity, uint32_t draw) {
     return r->tape_e[r->pos_e++];
   }
   if (r->mode == 2) return r_exp_rand();
-  return -orc_log(orc_stream_u(r->seed_lo, r->seed_hi, r->replica, iter + c->iter_base, entity, draw));
+  return orc_neglog_u32(orc_stream_word(r->seed_lo, r->seed_hi, r->replica, iter + c->iter_base, entity, draw));
 }
 
 /* ------------------------------------------------------------------------------------------ */

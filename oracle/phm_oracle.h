@@ -85,6 +85,8 @@ void   orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t 
 double orc_u01(uint32_t x);   /* (x + 0.5) * 2^-32 */
 double orc_log(double x);
 double orc_exp(double x);
+uint32_t orc_stream_word(uint32_t seed_lo, uint32_t seed_hi, uint32_t replica, uint32_t iter, uint32_t entity, uint32_t draw);
+double orc_neglog_u32(uint32_t k);   /* -log((k + 0.5) 2^-32), table-based, ~1 ulp */
 double orc_stream_u(uint32_t seed_lo, uint32_t seed_hi, uint32_t replica, uint32_t iter,
                     uint32_t entity, uint32_t draw);
 

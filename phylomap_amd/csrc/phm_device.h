@@ -9,6 +9,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#define PHM_LOGTAB_QUAL __device__
+#include "phm_logtab.h"
+
 namespace phm {
 
 // device error bits -> phm_status (phm_internal.h)
@@ -54,7 +57,7 @@ struct Stream {
                                        uint32_t seed_hi) {
     ent = entity; iter = iteration; rep = replica; k0 = seed_lo; k1 = seed_hi; blk = 0xFFFFFFFFu; w0 = w1 = w2 = w3 = 0u;
   }
-  __device__ __forceinline__ double draw(uint32_t d) {
+  __device__ __forceinline__ uint32_t draw_word(uint32_t d) {      // the 32 random bits of draw d
     uint32_t b = d >> 2;
     if (b != blk) {
       uint32_t o[4];
@@ -63,8 +66,9 @@ struct Stream {
       blk = b;
     }
     const uint32_t lo = (d & 1u) ? w1 : w0, hi = (d & 1u) ? w3 : w2;
-    return u01((d & 2u) ? hi : lo);
+    return (d & 2u) ? hi : lo;
   }
+  __device__ __forceinline__ double draw(uint32_t d) { return u01(draw_word(d)); }
 };
 
 // one-off draw (node states)
@@ -74,6 +78,37 @@ __device__ __forceinline__ double stream_u(uint32_t seed_lo, uint32_t seed_hi, u
   philox4x32_10(d >> 2, ent, iter, rep, seed_lo, seed_hi, o);
   const uint32_t lo = (d & 1u) ? o[1] : o[0], hi = (d & 1u) ? o[3] : o[2];
   return u01((d & 2u) ? hi : lo);
+}
+
+// Standard exponential variate from 32 random bits: -log(U), U = (k + 0.5) 2^-32 (what Rcpp::rexp's exp_rand delivers in
+// distribution).  With y = 2k + 1 = 2^e f, f in [0.5, 1):  -log(U) = -((e - 33) ln 2 + log(c_j) + log1p(r)),
+// c_j = 0.5 + (j + 0.5)/256 the table point below f, r = (f - c_j) / c_j (|r| < 2^-8; f - c_j is exact), log1p by its
+// series to r^7; for U within 2^-8 of 1 the series is applied to r = f - 1 directly (no cancellation).  About one ulp
+// (tools/gen_log_table.py, tests/test_oracle_cpu.py); 40 operations instead of the 65 of a general log.  `tab` holds the
+// PHM_LOGTAB_N pairs (1/c_j, log c_j); the oracle and the Python restatement evaluate the same expression on the same table.
+__device__ __forceinline__ double neglog_u32(uint32_t k, const double* __restrict__ tab) {
+  const double y = (double)k * 2.0 + 1.0;
+  int e;
+  const double f = frexp(y, &e);
+  const bool top = (e == 33) && (f >= 0.99609375);
+  const int j = (int)((f - 0.5) * 256.0);
+  const double c = 0.501953125 + (double)j * 0.00390625;
+  const double r = top ? f - 1.0 : (f - c) * tab[2 * j];
+  const double c0 = top ? 0.0 : tab[2 * j + 1];
+  const double ee = top ? 0.0 : (double)(e - 33);
+  double p = 1.0 / 7.0;
+  p = p * r - 1.0 / 6.0;
+  p = p * r + 0.2;
+  p = p * r - 0.25;
+  p = p * r + 1.0 / 3.0;
+  p = p * r - 0.5;
+  p = p * r * r + r;
+  return -(ee * 6.93147180369123816490e-01 + (c0 + (p + ee * 1.90821492927058770002e-10)));
+}
+
+// the table as doubles, interleaved (1/c_j, log c_j), for kernels that stage it in LDS or read it through L1
+__device__ __forceinline__ double logtab_entry(int i) {
+  return __longlong_as_double((long long)((i & 1) ? PHM_LOGTAB_LOG_BITS[i >> 1] : PHM_LOGTAB_INV_BITS[i >> 1]));
 }
 
 // natural log for normal positive finite x (all callers pass u in (0,1) or validated positives)

@@ -86,6 +86,8 @@ __device__ __forceinline__ void sweep_body(const McmcParams<NS>& p, int iter0, i
                     (size_t)wave * NCNT * 64;                 // [NCNT][64] transition counters of this wave
   double* s_mask = reinterpret_cast<double*>(reinterpret_cast<uint32_t*>(s_scale + NS + (size_t)(MCMC_BLOCK / 64) * NS * 64) +
                                              (size_t)(MCMC_BLOCK / 64) * NS * NS * 64);   // [ktab][2][NS] (ks only)
+  __shared__ double s_ltab[2 * PHM_LOGTAB_N];                 // (1/c_j, log c_j) of the exponential variates (neglog_u32)
+  for (int i = threadIdx.x; i < 2 * PHM_LOGTAB_N; i += MCMC_BLOCK) s_ltab[i] = logtab_entry(i);
   for (int i = threadIdx.x; i < p.ktab * NS * NS; i += MCMC_BLOCK) { s_col[i] = p.colpow[i]; s_row[i] = p.rowpow[i]; }
   if (KS && p.tip_masks) for (int i = threadIdx.x; i < p.ktab * 2 * NS; i += MCMC_BLOCK) s_mask[i] = p.maskpow[i];
   if (threadIdx.x < NS * NS) s_B2[threadIdx.x] = p.B2[threadIdx.x];
@@ -302,7 +304,7 @@ __device__ __forceinline__ void sweep_body(const McmcParams<NS>& p, int iter0, i
           bool adv;
           if (stuck || !(0.0 < len)) { stuck = true; piece = len; adv = true; }
           else {
-            double rl = scale * (-phm_log(se.draw(edraw++)));                  // :398
+            double rl = scale * neglog_u32(se.draw_word(edraw++), s_ltab);        // :398
             if ((tot + rl) < len) { piece = rl; tot += rl; adv = false; }
             else { piece = len - tot; adv = true; }
           }
@@ -337,7 +339,7 @@ __device__ __forceinline__ void sweep_body(const McmcParams<NS>& p, int iter0, i
           double tot = 0.0;
           double acc = s_dw[s * 64 + lane];
           while (tot < len) {
-            double rl = scale * (-phm_log(se.draw(edraw++)));
+            double rl = scale * neglog_u32(se.draw_word(edraw++), s_ltab);
             double piece;
             if ((tot + rl) < len) { piece = rl; tot += rl; }
             else { piece = len - tot; tot = len; }

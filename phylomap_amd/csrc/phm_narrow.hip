@@ -146,9 +146,12 @@ template <int NS>
 __global__ __launch_bounds__(NARROW_BLOCK) void narrow_branch_kernel(NarrowParams<NS> p, int it) {
   __shared__ double s_dw[NS * NARROW_BLOCK];
   __shared__ uint32_t s_cnt[NS * NS * NARROW_BLOCK];
+  __shared__ double s_ltab[2 * PHM_LOGTAB_N];        // (1/c_j, log c_j) of the exponential variates (neglog_u32)
   const int lane = threadIdx.x;
   const int idx = blockIdx.x * NARROW_BLOCK + lane;
   const int r = blockIdx.y;
+  for (int i = lane; i < 2 * PHM_LOGTAB_N; i += NARROW_BLOCK) s_ltab[i] = logtab_entry(i);
+  __syncthreads();
   if (idx >= p.n_edge) return;
   const int b = p.branch_order[idx];
   const uint32_t rep = (uint32_t)(p.replica_offset + r);
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(NARROW_BLOCK) void narrow_branch_kernel(NarrowParam
       const double scale = p.scale[s];
       double tot = 0.0;
       while (tot < len) {
-        const double rl = scale * (-phm_log(se.draw(edraw++)));                // :398
+        const double rl = scale * neglog_u32(se.draw_word(edraw++), s_ltab);      // :398
         double piece;
         if ((tot + rl) < len) { piece = rl; tot += rl; }
         else { piece = len - tot; tot = len; }

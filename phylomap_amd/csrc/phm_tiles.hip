@@ -132,11 +132,13 @@ __global__ __launch_bounds__(TILES_BLOCK) void tiles_branch_kernel(TileParams<NS
   __shared__ uint32_t s_cnt_all[(TILES_BLOCK / 64) * NCNT * 64];
   __shared__ double s_B2[NS * NS], s_scale[NS];      // indexed by a per-lane state: LDS, not the kernarg segment
   __shared__ double s_col[TILES_KTAB * NS * NS];     // B^k e_j for the short chains (most draws); longer ones go to L2
+  __shared__ double s_ltab[2 * PHM_LOGTAB_N];        // (1/c_j, log c_j) of the exponential variates (neglog_u32)
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int item = blockIdx.x * (TILES_BLOCK / 64) + wave;
   const int ktab = min(TILES_KTAB, p.klong);
   for (int i = threadIdx.x; i < ktab * NS * NS; i += TILES_BLOCK) s_col[i] = p.colL[i];
+  for (int i = threadIdx.x; i < 2 * PHM_LOGTAB_N; i += TILES_BLOCK) s_ltab[i] = logtab_entry(i);
   if (threadIdx.x < NS * NS) s_B2[threadIdx.x] = p.B2[threadIdx.x];
   if (threadIdx.x < NS) s_scale[threadIdx.x] = p.scale[threadIdx.x];
   __syncthreads();
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(TILES_BLOCK) void tiles_branch_kernel(TileParams<NS
       bool adv;
       if (stuck || !(0.0 < len)) { stuck = true; piece = len; adv = true; }
       else {
-        double rl = scale * (-phm_log(se.draw(edraw++)));                  // :398
+        double rl = scale * neglog_u32(se.draw_word(edraw++), s_ltab);        // :398
         if ((tot + rl) < len) { piece = rl; tot += rl; adv = false; }
         else { piece = len - tot; adv = true; }
       }
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(TILES_BLOCK) void tiles_branch_kernel(TileParams<NS
       double tot = 0.0;
       double acc = s_dw[s * 64 + lane];
       while (tot < len) {
-        double rl = scale * (-phm_log(se.draw(edraw++)));
+        double rl = scale * neglog_u32(se.draw_word(edraw++), s_ltab);
         double piece;
         if ((tot + rl) < len) { piece = rl; tot += rl; }
         else { piece = len - tot; tot = len; }

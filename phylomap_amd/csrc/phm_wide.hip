@@ -82,6 +82,8 @@ __global__ __launch_bounds__(WIDE_BLOCK) void mcmc_wide_kernel(WideParams p, int
     if (p.sparse) s_B2[r * ldn + cc] = p.B2[i];
   }
   if ((int)threadIdx.x < n) s_scale[threadIdx.x] = p.scale[threadIdx.x];
+  __shared__ double s_ltab[2 * PHM_LOGTAB_N];        // (1/c_j, log c_j) of the exponential variates (neglog_u32)
+  for (int i = threadIdx.x; i < 2 * PHM_LOGTAB_N; i += WIDE_BLOCK) s_ltab[i] = logtab_entry(i);
   __syncthreads();
   if (tile >= p.n_tiles) return;
 
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) void mcmc_wide_kernel(WideParams p, int
           bool adv;
           if (stuck || !(0.0 < len)) { stuck = true; piece = len; adv = true; }
           else {
-            double rl = scale * (-phm_log(se.draw(edraw++)));        // :398
+            double rl = scale * neglog_u32(se.draw_word(edraw++), s_ltab);   // :398
             if ((tot + rl) < len) { piece = rl; tot += rl; adv = false; }
             else { piece = len - tot; adv = true; }
           }

@@ -80,6 +80,39 @@ def pexp(x):
     return math.ldexp(y, k)
 
 
+def _logtab():
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "gen_log_table.py")
+    spec = importlib.util.spec_from_file_location("gen_log_table", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.table()
+
+
+_INV, _LOGC = _logtab()
+
+
+def neglog_u32(k):
+    """-log((k + 0.5) 2^-32): the engine's exponential variate (phm_device.h neglog_u32, oracle orc_neglog_u32)."""
+    y = float(k) * 2.0 + 1.0
+    f, e = math.frexp(y)
+    if e == 33 and f >= 0.99609375:
+        r, c0, ee = f - 1.0, 0.0, 0.0
+    else:
+        j = int((f - 0.5) * 256.0)
+        c = 0.501953125 + float(j) * 0.00390625
+        r, c0, ee = (f - c) * _INV[j], _LOGC[j], float(e - 33)
+    p = 1.0 / 7.0
+    p = p * r - 1.0 / 6.0
+    p = p * r + 0.2
+    p = p * r - 0.25
+    p = p * r + 1.0 / 3.0
+    p = p * r - 0.5
+    p = p * r * r + r
+    return -(ee * 6.93147180369123816490e-01 + (c0 + (p + ee * 1.90821492927058770002e-10)))
+
+
 class Rng:
     def __init__(self, seed, replica):
         self.key = (seed & M32, (seed >> 32) & M32)
@@ -88,6 +121,10 @@ class Rng:
     def u(self, it, ent, d):
         o = philox((d >> 2, ent, it, self.rep), self.key)
         return u01(o[d & 3])
+
+    def e(self, it, ent, d):
+        o = philox((d >> 2, ent, it, self.rep), self.key)
+        return neglog_u32(o[d & 3])
 
 
 def matvec(M, v):
@@ -228,7 +265,7 @@ def sumstatMCMC(z, Q, pid, Omega, N, nen, nodelist, root, seed, replica, variant
                 scale = 1.0 / (Omega + Q[s][s])
                 tot = 0.0
                 while tot < seglen:
-                    rl = scale * (-plog(rng.u(it, ENT_BEXP | b, ed)))
+                    rl = scale * rng.e(it, ENT_BEXP | b, ed)
                     ed += 1
                     if tot + rl < seglen:
                         fd.append(rl); fs.append(s); tot += rl

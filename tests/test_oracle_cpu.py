@@ -449,3 +449,28 @@ def test_rds_reader_round_trip_of_hand_built_stream(tmp_path):
     np.testing.assert_array_equal(x["edge"], [[3, 1], [3, 2]])
     np.testing.assert_array_equal(x["maps"][0], [0.25, 0.5])
     assert x["maps"][0].names == ["1", "2"] and x["tip.label"] == ["a", "b"]
+
+
+def test_exponential_variate_table_log_accuracy_and_agreement():
+    """orc_neglog_u32 / pyref.neglog_u32 / phm_device.h neglog_u32: -log((k + 0.5) 2^-32) through the 128-entry table of
+    tools/gen_log_table.py.  The C and the Python evaluation agree bit for bit; against 50-digit arithmetic the result is
+    within 1.5 ulp everywhere probed, including both ends (U near 0: 23.2; U within 2^-8 of 1: the direct series)."""
+    import ctypes as C
+    import decimal
+    import random
+    L = O.lib()
+    L.orc_neglog_u32.restype = C.c_double
+    L.orc_neglog_u32.argtypes = [C.c_uint32]
+    decimal.getcontext().prec = 50
+    random.seed(7)
+    ks = [0, 1, 2, 2 ** 31 - 1, 2 ** 31, 2 ** 31 + 1, 2 ** 32 - 2, 2 ** 32 - 1, 4278190079, 4278190080, 4278190081]
+    ks += [random.getrandbits(32) for _ in range(4000)] + [2 ** 32 - 1 - 4099 * i for i in range(1500)] + [8191 * i for i in range(500)]
+    worst = 0.0
+    for k in ks:
+        a = L.orc_neglog_u32(k)
+        assert a == pyref.neglog_u32(k)
+        exact = -((decimal.Decimal(k) + decimal.Decimal("0.5")) / decimal.Decimal(2 ** 32)).ln()
+        worst = max(worst, float(abs((decimal.Decimal(a) - exact) / exact)))
+    assert worst < 1.5 * 2.0 ** -52
+    assert L.orc_neglog_u32(0) == pyref.neglog_u32(0) and abs(L.orc_neglog_u32(0) - 33 * np.log(2.0)) < 1e-14
+    assert 0 < L.orc_neglog_u32(2 ** 32 - 1) < 1.2e-10
