@@ -506,10 +506,12 @@ def test_engine_over_a_list_of_trees_runs_each_tree_like_its_own_engine():
         _lib.Engine([trees[0], synth.make_tree(21, Q, Omega, 1, pid)], Q, pid, Omega, 2)
 
 
-def test_replica_offset_shards_like_one_device():
+@pytest.mark.parametrize("mapping", MAPPINGS)
+def test_replica_offset_shards_like_one_device(mapping):
+    """Multi-GPU sharding is by global replica id: ranks that take replicas [2, 4) reproduce those of a single device."""
     z, Q, pid, Omega = _problem(2, 18, 4)
-    a = api.sumstatMCMC(z, Q, pid, Omega, 10, seed=3, n_replicas=4)
-    b = api.sumstatMCMC(z, Q, pid, Omega, 10, seed=3, n_replicas=2, replica_offset=2)
+    a = api.sumstatMCMC(z, Q, pid, Omega, 10, seed=3, n_replicas=4, mapping=mapping)
+    b = api.sumstatMCMC(z, Q, pid, Omega, 10, seed=3, n_replicas=2, replica_offset=2, mapping=mapping)
     np.testing.assert_array_equal(a[2:], b)
 
 
