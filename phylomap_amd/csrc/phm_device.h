@@ -191,4 +191,22 @@ __device__ __forceinline__ void matvec_u(const double* __restrict__ M, double (&
   for (int i = 0; i < NS; ++i) v[i] = y[i];
 }
 
+// Maximum of a non-negative per-lane count over the 64 lanes of a wave (all lanes active at the call sites), as a wave-uniform
+// value: row-shift / row-broadcast DPP moves (4 within the 16-lane rows, 2 across rows) leave it in lane 63 -- a third of
+// the instructions of the shuffle butterfly, which goes through the LDS crossbar.  Lanes a move does not reach read 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_max_step(int v) {
+  const int o = __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
+  return o > v ? o : v;
+}
+__device__ __forceinline__ int wave_max_count(int v) {
+  v = dpp_max_step<0x111, 0xf>(v);      // row_shr:1
+  v = dpp_max_step<0x112, 0xf>(v);      // row_shr:2
+  v = dpp_max_step<0x114, 0xf>(v);      // row_shr:4
+  v = dpp_max_step<0x118, 0xf>(v);      // row_shr:8  -> lane 15 of every row holds its row's maximum
+  v = dpp_max_step<0x142, 0xa>(v);      // row_bcast:15 into rows 1 and 3
+  v = dpp_max_step<0x143, 0xc>(v);      // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's maximum
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
 }  // namespace phm

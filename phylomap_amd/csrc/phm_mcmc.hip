@@ -23,13 +23,6 @@
 
 namespace phm {
 
-// wave-uniform maximum of a per-lane count (all 64 lanes active at the call sites)
-__device__ __forceinline__ int wave_max(int v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) { int o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
-  return __builtin_amdgcn_readfirstlane(v);
-}
-
 // B^k applied to a child's partial-likelihood vector (mmmmvFORpl, src/phylomap.cpp:446-450)
 template <int NS, bool KS>
 __device__ __forceinline__ void child_vector(const McmcParams<NS>& p, const double* __restrict__ s_col,
@@ -227,7 +220,7 @@ __device__ __forceinline__ void sweep_body(const McmcParams<NS>& p, int iter0, i
 
       // ---- branch path: resample states, merge, count, re-insert virtual jumps ----
       // The dwell lists of a tile form one sequential stream of 64-lane rows in sweep order: branch k
-      // occupies wave_max(m) rows of the input stream and wave_max(m') rows of the output stream.
+      // occupies wave_max_count(m) rows of the input stream and wave_max_count(m') rows of the output stream.
       Stream su, se;
       su.open(ENT_BSTATE | (uint32_t)b, (uint32_t)it, rep, p.seed_lo, p.seed_hi);
       se.open(ENT_BEXP | (uint32_t)b, (uint32_t)it, rep, p.seed_lo, p.seed_hi);
@@ -235,7 +228,7 @@ __device__ __forceinline__ void sweep_body(const McmcParams<NS>& p, int iter0, i
       const int woff = out_row;
       const int cap = RING ? C - (r_in - in_row) - out_row    // free rows: the ring minus unread input minus output so far
                            : C - out_row;
-      const int mmax = wave_max(m);
+      const int mmax = wave_max_count(m);
       int mnew = 0;                              // pieces emitted = new segment count
 
       // s_i ~ B[s_{i-1},:] (.) B^(m-i-1) e_end          (resamplebranchstates :290, :301-304)
@@ -374,7 +367,7 @@ __device__ __forceinline__ void sweep_body(const McmcParams<NS>& p, int iter0, i
       mct[b * 64 + lane] = (uint16_t)mnew;
       seg_rw += (uint32_t)(m + mnew);
       in_row += mmax;
-      out_row += wave_max(mnew);
+      out_row += wave_max_count(mnew);
       if (out_row > C) out_row = C;
     }
 

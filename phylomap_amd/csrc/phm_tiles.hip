@@ -7,12 +7,6 @@ namespace phm {
 
 namespace {
 
-__device__ __forceinline__ int wave_max_i(int v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) { int o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
-  return __builtin_amdgcn_readfirstlane(v);
-}
-
 // B^k applied to a child's partial-likelihood vector (mmmmvFORpl, src/phylomap.cpp:446-450)
 template <int NS>
 __device__ __forceinline__ void child_vec(const TileParams<NS>& p, const double* __restrict__ PLt,
@@ -167,7 +161,7 @@ __global__ __launch_bounds__(TILES_BLOCK) void tiles_branch_kernel(TileParams<NS
   Stream su, se;
   su.open(ENT_BSTATE | (uint32_t)b, (uint32_t)it, rep, p.seed_lo, p.seed_hi);
   se.open(ENT_BEXP | (uint32_t)b, (uint32_t)it, rep, p.seed_lo, p.seed_hi);
-  const int mmax = wave_max_i(m);
+  const int mmax = wave_max_count(m);
   int mnew = 0;
 
   // s_i ~ B[s_{i-1},:] (.) B^(m-i-1) e_end          (resamplebranchstates :290, :301-304)
