@@ -4,7 +4,7 @@ HIPCC   ?= /opt/rocm/bin/hipcc
 ARCH    ?= gfx950
 CSRC    := phylomap_amd/csrc
 LIB     := phylomap_amd/libphylomap_hip.so
-SRCS    := $(CSRC)/phm_engine.cpp $(CSRC)/phm_drivers.cpp $(CSRC)/phm_expm_api.cpp $(CSRC)/phm_sched.cpp $(CSRC)/phm_qupdate.cpp $(CSRC)/phm_mcmc.hip $(CSRC)/phm_wide.hip $(CSRC)/phm_narrow.hip $(CSRC)/phm_tiles.hip $(CSRC)/phm_exp.hip
+SRCS    := $(CSRC)/phm_engine.cpp $(CSRC)/phm_drivers.cpp $(CSRC)/phm_expm_api.cpp $(CSRC)/phm_sched.cpp $(CSRC)/phm_qupdate.cpp $(CSRC)/phm_mcmc.hip $(CSRC)/phm_wide.hip $(CSRC)/phm_narrow.hip $(CSRC)/phm_tiles.hip $(CSRC)/phm_wbranch.hip $(CSRC)/phm_exp.hip
 HDRS    := $(wildcard $(CSRC)/*.h) include/phylomap_hip.h
 FLAGS   := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function
 

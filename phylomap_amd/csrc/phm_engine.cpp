@@ -78,7 +78,7 @@ int32_t upload_model(phm_engine* e) {
   const int n = e->n;
   // rows of the chain tables: every mapping keeps full-length tables in global memory (nw_klong > every possible segment
   // count); the replica kernels additionally stage the first MCMC_KTAB rows in LDS
-  const int ktab = (e->narrow || e->tiled) ? e->nw_klong : std::max(e->nw_klong, e->wide ? phm::WIDE_KTAB : phm::MCMC_KTAB);
+  const int ktab = (e->narrow || e->tiled) ? e->nw_klong : std::max(e->nw_klong, e->wide ? phm::WIDE_KTAB : phm::MCMC_KTAB);      // narrow covers both branch mappings (n <= 4 and 5..64)
   const double* Bc = e->hBc.data();
   std::vector<double> col, row;
   build_chain_tables(Bc, n, ktab, col, row);
@@ -99,6 +99,12 @@ int32_t upload_model(phm_engine* e) {
     HIPCHK(hipMemcpy(e->d_nw_colL.p, col.data(), sizeof(double) * col.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(e->d_nw_rowL.p, row.data(), sizeof(double) * row.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(e->d_nw_maskL.p, maskpow.data(), sizeof(double) * maskpow.size(), hipMemcpyHostToDevice));
+    if (e->wide) {      // 5..64 states: the model matrices live in global memory
+      HIPCHK(hipMemcpy(e->d_B2.p, e->hB2.data(), sizeof(double) * n * n, hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(e->d_Bc.p, e->hBc.data(), sizeof(double) * n * n, hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(e->d_scale.p, e->hscale.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+      return PHM_OK;
+    }
     auto refresh_n = [&](auto& p) {
       for (int i = 0; i < n * n; ++i) { p.B2[i] = e->hB2[i]; p.Bc[i] = e->hBc[i]; }
       for (int i = 0; i < n; ++i) p.scale[i] = e->hscale[i];
@@ -231,7 +237,8 @@ int32_t narrow_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
   const size_t tab = (size_t)e->nw_klong * n * n;
   size_t free_b = 0, total_b = 0;
   HIPCHK(hipMemGetInfo(&free_b, &total_b));
-  const size_t need = 3 * dw_bytes + (size_t)S * e->nw_total_cap + stats_bytes + sizeof(double) * (3 * tab + (size_t)S * E * (n + n * n + 1));
+  const size_t part_cols = e->wide ? (size_t)n + 1 : (size_t)n + n * n + 1;      // n > 4: counters go through atomics, not per branch
+  const size_t need = 3 * dw_bytes + (size_t)S * e->nw_total_cap + stats_bytes + sizeof(double) * (3 * tab + (size_t)S * E * part_cols + (e->wide ? 2 * (size_t)S * e->dcols : 0));
   if (need + (64u << 20) > free_b) {
     char buf[256];
     std::snprintf(buf, sizeof buf, "engine needs %.2f GiB of HBM, %.2f GiB free (reduce n_replicas or max_iters)", need / 1073741824.0, free_b / 1073741824.0);
@@ -250,7 +257,7 @@ int32_t narrow_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
   HIPCHK(e->d_nw_estate.alloc((size_t)S * E * 2));
   HIPCHK(e->d_PL.alloc(sizeof(double) * (size_t)S * Nn * n));
   HIPCHK(e->d_nstate.alloc((size_t)S * Nn));
-  HIPCHK(e->d_nw_part.alloc(sizeof(double) * (size_t)S * E * (n + n * n + 1)));
+  HIPCHK(e->d_nw_part.alloc(sizeof(double) * (size_t)S * E * part_cols));
   HIPCHK(e->d_nw_rowbuf.alloc(sizeof(double) * (size_t)S * e->dcols));
   HIPCHK(e->d_stats.alloc(stats_bytes));
   HIPCHK(e->d_err.alloc(sizeof(uint32_t))); HIPCHK(e->d_seg.alloc(sizeof(unsigned long long)));
@@ -281,6 +288,32 @@ int32_t narrow_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
   if (n == 2) fill_narrow_params<2>(e, e->n2, o);
   if (n == 3) fill_narrow_params<3>(e, e->n3, o);
   if (n == 4) fill_narrow_params<4>(e, e->n4, o);
+  if (e->wide) {      // 5..64 states: one wave per (replica, branch), lanes = states (phm_wbranch.hip)
+    HIPCHK(e->d_wb_cnt.alloc(sizeof(double) * (size_t)S * e->dcols));
+    HIPCHK(hipMemset(e->d_wb_cnt.p, 0, e->d_wb_cnt.bytes));
+    HIPCHK(e->d_B2.alloc(sizeof(double) * n * n)); HIPCHK(e->d_Bc.alloc(sizeof(double) * n * n));
+    HIPCHK(e->d_scale.alloc(sizeof(double) * n)); HIPCHK(e->d_pid.alloc(sizeof(double) * n));
+    HIPCHK(hipMemcpy(e->d_pid.p, e->hpid.data(), e->d_pid.bytes, hipMemcpyHostToDevice));
+    phm::WideBranchParams& p = e->pwb;
+    p.n_states = n; p.n_tips = s.n_tips; p.n_node = s.n_node; p.n_edge = s.n_edge; p.root = s.root;
+    p.n_rep = e->S; p.n_rep_pad = e->S_pad; p.replica_offset = o.replica_offset; p.n_tiles = e->tiles;
+    p.normalise = normalised(e->variant); p.tips_per_replica = e->tips_per_replica ? 1 : 0;
+    p.sparse = (e->variant == PHM_MCMC_SPARSE); p.ks = ks_layout(e->variant); p.tip_masks = hidden_rates(e->variant);
+    p.count_self = p.ks; p.reduce = e->reduce; p.n_cols = e->dcols; p.klong = e->nw_klong;
+    p.seed_lo = (uint32_t)(o.seed & 0xFFFFFFFFull); p.seed_hi = (uint32_t)(o.seed >> 32);
+    p.total_cap = e->nw_total_cap;
+    p.B2 = e->d_B2.as<double>(); p.Bc = e->d_Bc.as<double>(); p.scale = e->d_scale.as<double>(); p.pid = e->d_pid.as<double>();
+    p.up = e->d_up.as<phm::UpStep>(); p.down = e->d_down.as<phm::DownStep>();
+    p.up_order = e->d_nw_up_order.as<int32_t>(); p.down_order = e->d_nw_down_order.as<int32_t>();
+    p.branch_order = e->d_nw_border.as<int32_t>(); p.off = e->d_nw_off.as<int64_t>();
+    p.colL = e->d_nw_colL.as<double>(); p.rowL = e->d_nw_rowL.as<double>(); p.maskL = e->d_nw_maskL.as<double>();
+    p.tips = e->d_tips.as<uint8_t>(); p.mcount = e->d_nw_mcount.as<int32_t>();
+    p.dw[0] = e->d_nw_dwA.as<double>(); p.dw[1] = e->d_nw_dwB.as<double>(); p.mlen = e->d_nw_mlen.as<double>();
+    p.mstate = e->d_nw_mstate.as<uint8_t>(); p.estate = e->d_nw_estate.as<uint8_t>();
+    p.PL = e->d_PL.as<double>(); p.nstate = e->d_nstate.as<uint8_t>(); p.part = e->d_nw_part.as<double>();
+    p.cnt = e->d_wb_cnt.as<double>(); p.rowbuf = e->d_nw_rowbuf.as<double>(); p.stats = e->d_stats.as<double>();
+    p.err = e->d_err.as<uint32_t>(); p.segcnt = e->d_seg.as<unsigned long long>();
+  }
   return PHM_OK;
 }
 
@@ -520,12 +553,17 @@ int32_t phm_engine_create_multi(const phm_tree* trees, int32_t n_trees, const ph
   // chains the replica mapping would leave all but a handful of lanes idle and walk the tree sequentially.
   const bool small_n = !e->wide && n_trees == 1;
   const bool auto_map = o.reserved[1] == 0 && o.reserved[0] == 0;      // a ring / two-buffer request names the replica layout
-  if ((o.reserved[1] == 2 || o.reserved[1] == 3) && !small_n) return fail(PHM_ERR_UNSUPPORTED, "the branch-parallel mappings cover n_states <= 4 and a single tree");
-  e->narrow = small_n && (o.reserved[1] == 2 || (auto_map && e->S <= NARROW_AUTO_MAX_REPLICAS));
-  e->tiled = small_n && !e->narrow && (o.reserved[1] == 3 || (auto_map && e->S <= TILES_AUTO_MAX_REPLICAS));
+  if ((o.reserved[1] == 2 || o.reserved[1] == 3) && n_trees != 1) return fail(PHM_ERR_UNSUPPORTED, "the branch-parallel mappings take a single tree");
+  if (e->wide) {      // 5..64 states: one wave per (replica, branch) unless the replica kernel is asked for or memory is short
+    e->narrow = n_trees == 1 && (o.reserved[1] == 2 || o.reserved[1] == 3 || auto_map);
+    e->tiled = false;
+  } else {
+    e->narrow = small_n && (o.reserved[1] == 2 || (auto_map && e->S <= NARROW_AUTO_MAX_REPLICAS));
+    e->tiled = small_n && !e->narrow && (o.reserved[1] == 3 || (auto_map && e->S <= TILES_AUTO_MAX_REPLICAS));
+  }
   if (e->narrow) {
     st = narrow_setup(e, x, model, o, max_iters);
-    if (st == PHM_ERR_OOM && auto_map) { e->narrow = false; e->tiled = true; st = PHM_OK; }
+    if (st == PHM_ERR_OOM && auto_map) { e->narrow = false; e->tiled = !e->wide; st = PHM_OK; }
   }
   if (e->tiled) {
     st = tiles_setup(e, x, model, o, max_iters);
@@ -578,11 +616,11 @@ int32_t phm_engine_create_multi(const phm_tree* trees, int32_t n_trees, const ph
   if (e->wide && n_trees == 1) {
     // n > 4: a wave takes the replicas of its tile in turn for the n-vector work (phm_wide.hip), so a tile that holds
     // 64 replicas is 64 sequential passes in ONE wave.  With few replicas, place fewer of them on a tile (the unused lanes
-    // are skipped) until about 2 048 waves exist or the padded layout would take more than a quarter of the free HBM.
+    // are skipped) until about 8 192 waves exist or the padded layout would take more than a quarter of the free HBM.
     size_t free_now = 0, total_now = 0;
     HIPCHK(hipMemGetInfo(&free_now, &total_now));
     int rpt = 64;
-    while (rpt > 1 && (e->S + rpt / 2 - 1) / (rpt / 2) <= 2048) rpt /= 2;
+    while (rpt > 1 && (e->S + rpt / 2 - 1) / (rpt / 2) <= 8192) rpt /= 2;
     auto tile_bytes = [&](int r) {
       const size_t tl = (size_t)(e->S + r - 1) / r;
       return tl * (sizeof(double) * ((size_t)rows * 64 + (size_t)s.n_node * n * 64) + 3 * (size_t)E * 64) +
@@ -738,6 +776,7 @@ int32_t phm_engine_run(phm_engine* e, int32_t n_iters, void* hip_stream) {
       if (e->n == 2) le = phm::launch_narrow_sweep<2>(e->n2, e->nw_up_off, e->nw_down_off, it, stream);
       if (e->n == 3) le = phm::launch_narrow_sweep<3>(e->n3, e->nw_up_off, e->nw_down_off, it, stream);
       if (e->n == 4) le = phm::launch_narrow_sweep<4>(e->n4, e->nw_up_off, e->nw_down_off, it, stream);
+      if (e->wide) le = phm::launch_wbranch_sweep(e->pwb, e->nw_up_off, e->nw_down_off, it, stream);
       launches += (int)(e->nw_up_off.size() + e->nw_down_off.size()) + 2;
     }
     HIPCHK(le);
@@ -759,7 +798,7 @@ int32_t phm_engine_run(phm_engine* e, int32_t n_iters, void* hip_stream) {
     if (e->n == 2) le = phm::launch_mcmc<2>(e->p2, e->iters_done + done, chunk, stream);
     if (e->n == 3) le = phm::launch_mcmc<3>(e->p3, e->iters_done + done, chunk, stream);
     if (e->n == 4) le = phm::launch_mcmc<4>(e->p4, e->iters_done + done, chunk, stream);
-    if (e->wide) le = phm::launch_mcmc_wide(e->pw, e->iters_done + done, chunk, stream);
+    if (e->wide && !e->narrow) le = phm::launch_mcmc_wide(e->pw, e->iters_done + done, chunk, stream);
     HIPCHK(le);
     done += chunk;
     ++launches;

@@ -1,0 +1,292 @@
+// phm_wbranch.hip -- 5..64 states, one wavefront per (replica, branch); see phm_wbranch.h.
+// Lanes are states; everything else (segment counts, end states, merged paths, draws) is the same in all 64 lanes of the
+// wave, so the compiler keeps it in scalar registers and the loops never diverge.  Uniform values that go through memory
+// (merged segments, end states) are written by ALL lanes (identical stores) so that each lane's own program order
+// guarantees what it reads back.  Arithmetic, draws and stream addressing are those of phm_wide.hip / the oracle.
+#include "phm_wbranch.h"
+
+#include "phm_coop.h"
+
+namespace phm {
+
+namespace {
+
+struct Lds {
+  double* Bc;      // [n][ldn] chain matrix
+  double* B2;      // [n][ldn] dense rows for the forward step (= Bc unless SPARSE)
+  double* scale;   // [n]
+  int ldn;
+};
+
+// stage the model matrices (odd row stride: conflict-free row and column access); ends with a barrier
+__device__ __forceinline__ Lds stage_model(const WideBranchParams& p, unsigned char* smem) {
+  const int n = p.n_states;
+  Lds l;
+  l.ldn = n | 1;
+  l.Bc = reinterpret_cast<double*>(smem);
+  l.B2 = p.sparse ? l.Bc + n * l.ldn : l.Bc;
+  l.scale = l.Bc + (p.sparse ? 2 : 1) * n * l.ldn;
+  for (int i = threadIdx.x; i < n * n; i += WB_BLOCK) {
+    const int r = i / n, cc = i - r * n;
+    l.Bc[r * l.ldn + cc] = p.Bc[i];
+    if (p.sparse) l.B2[r * l.ldn + cc] = p.B2[i];
+  }
+  if ((int)threadIdx.x < n) l.scale[threadIdx.x] = p.scale[threadIdx.x];
+  __syncthreads();
+  return l;
+}
+
+__global__ __launch_bounds__(WB_BLOCK) void wb_up_kernel(WideBranchParams p, int begin, int end) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const Lds l = stage_model(p, smem);
+  const int n = p.n_states, lane = threadIdx.x & 63;
+  const int idx = begin + blockIdx.x * (WB_BLOCK / 64) + (threadIdx.x >> 6);
+  const int r = blockIdx.y;
+  if (idx >= end) return;                         // whole waves only; no barrier below this line
+  const int c = lane < n ? lane : n - 1;
+  const UpStep st = p.up[p.up_order[idx]];
+  const int32_t* __restrict__ mc = p.mcount + (size_t)r * p.n_edge;
+  double* PLr = p.PL + (size_t)r * p.n_node * n;
+  const uint8_t* __restrict__ tips = p.tips_per_replica ? p.tips + (size_t)r * p.n_tips : p.tips;
+  uint32_t err = 0;
+  // B^k applied to a child's partial-likelihood vector (mmmmvFORpl :446-450); tips: a row of the chain table
+  auto child_vec = [&](int child, int k) -> double {
+    if (child < 0) {
+      const int ts = tips[~child];
+      if (k >= p.klong) { err |= DERR_CAPACITY; k = p.klong - 1; }
+      return p.tip_masks ? p.maskL[((size_t)k * 2 + (ts & 1)) * n + c] : p.colL[((size_t)k * n + ts) * n + c];
+    }
+    double v = PLr[(size_t)child * n + c];
+    for (int i = 0; i < k; ++i) v = coop_matvec(l.Bc, v, n, l.ldn, c);
+    return v;
+  };
+  double x = child_vec(st.child[1], mc[st.edge[1]] - 1);        // "first"  (:508)
+  const double y = child_vec(st.child[0], mc[st.edge[0]] - 1);  // "second" (:509)
+  x = x * y;                                                    // :510
+  if (p.normalise) x = x / coop_sum(x, n);                      // :525
+  if (lane < n) PLr[(size_t)st.parent * n + lane] = x;
+  if (err) atomicOr(p.err, err);
+}
+
+__global__ __launch_bounds__(WB_BLOCK) void wb_root_kernel(WideBranchParams p, int it) {
+  const int n = p.n_states, lane = threadIdx.x & 63;
+  const int r = blockIdx.x * (WB_BLOCK / 64) + (threadIdx.x >> 6);
+  if (r >= p.n_rep) return;
+  const int c = lane < n ? lane : n - 1;
+  const double* PLr = p.PL + (size_t)r * p.n_node * n;
+  uint32_t err = 0;
+  const double pr = (lane < n) ? p.pid[c] * PLr[(size_t)p.root * n + c] : 0.0;     // :618
+  const double u = stream_u(p.seed_lo, p.seed_hi, (uint32_t)(p.replica_offset + r), (uint32_t)it,
+                            ENT_NODE | (uint32_t)(p.root + p.n_tips), 0);
+  p.nstate[(size_t)r * p.n_node + p.root] = (uint8_t)coop_sample(pr, u, n, lane, err);   // :627 (every lane stores the same value)
+  if (err) atomicOr(p.err, err);
+}
+
+// child ~ e_ps^T B^(m-1) (.) PL[child]   (Tvmmp :431-436, :651); ks: tips too, against their parity mask (:1384-1397)
+__global__ __launch_bounds__(WB_BLOCK) void wb_down_kernel(WideBranchParams p, int it, int begin, int end) {
+  const int n = p.n_states, lane = threadIdx.x & 63;
+  const int idx = begin + blockIdx.x * (WB_BLOCK / 64) + (threadIdx.x >> 6);
+  const int r = blockIdx.y;
+  if (idx >= end) return;
+  const int c = lane < n ? lane : n - 1;
+  const DownStep ds = p.down[p.down_order[idx]];
+  const int b = ds.edge;
+  const int m = p.mcount[(size_t)r * p.n_edge + b];
+  uint8_t* nst = p.nstate + (size_t)r * p.n_node;
+  const uint8_t* __restrict__ tips = p.tips_per_replica ? p.tips + (size_t)r * p.n_tips : p.tips;
+  const int ps = nst[ds.parent];
+  uint32_t err = 0;
+  int cs;
+  if (ds.child >= 0 || p.tip_masks) {
+    int kk = m - 1;
+    if (kk >= p.klong) { err |= DERR_CAPACITY; kk = p.klong - 1; }
+    double w = p.rowL[((size_t)kk * n + ps) * n + c];
+    uint32_t node_id;
+    if (ds.child >= 0) {
+      w = (lane < n) ? w * p.PL[((size_t)r * p.n_node + ds.child) * n + c] : 0.0;
+      node_id = (uint32_t)(ds.child + p.n_tips);
+    } else {
+      const int par = tips[~ds.child] & 1;
+      w = (lane < n) ? w * (((c & 1) == par) ? 1.0 : 0.0) : 0.0;
+      node_id = (uint32_t)(~ds.child);
+    }
+    const double u = stream_u(p.seed_lo, p.seed_hi, (uint32_t)(p.replica_offset + r), (uint32_t)it, ENT_NODE | node_id, 0);
+    cs = coop_sample(w, u, n, lane, err);                                      // :655
+    if (ds.child >= 0) nst[ds.child] = (uint8_t)cs;
+  } else {
+    cs = tips[~ds.child];                                                      // :612
+  }
+  uint8_t* es = p.estate + ((size_t)r * p.n_edge + b) * 2;
+  es[0] = (uint8_t)ps; es[1] = (uint8_t)cs;                                    // updatenodestates :460-475
+  if (err) atomicOr(p.err, err);
+}
+
+// One branch of one replica: resamplebranchstates :264-308, shortener :44-73 (shortenerbf :997-1030), virtual jumps
+// sampleabranch :391-410, dwell sums updatedwelltimes :745-757.
+__global__ __launch_bounds__(WB_BLOCK) void wb_branch_kernel(WideBranchParams p, int it) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ double s_ltab[2 * PHM_LOGTAB_N];        // (1/c_j, log c_j) of the exponential variates (neglog_u32)
+  for (int i = threadIdx.x; i < 2 * PHM_LOGTAB_N; i += WB_BLOCK) s_ltab[i] = logtab_entry(i);
+  const Lds l = stage_model(p, smem);
+  const int n = p.n_states, lane = threadIdx.x & 63;
+  const int idx = blockIdx.x * (WB_BLOCK / 64) + (threadIdx.x >> 6);
+  const int r = blockIdx.y;
+  if (idx >= p.n_edge) return;                    // whole waves only; no barrier below this line
+  const int c = lane < n ? lane : n - 1;
+  const int b = p.branch_order[idx];
+  const uint32_t rep = (uint32_t)(p.replica_offset + r);
+  int32_t* mc = p.mcount + (size_t)r * p.n_edge;
+  const int m = mc[b];
+  const uint8_t* es = p.estate + ((size_t)r * p.n_edge + b) * 2;
+  const int ps = es[0], cs = es[1];
+  const int64_t o = p.off[b];
+  const int cap = (int)(p.off[b + 1] - o);
+  const double* in = p.dw[it & 1] + (size_t)r * p.total_cap + o;
+  double* out = p.dw[(it & 1) ^ 1] + (size_t)r * p.total_cap + o;
+  double* ml = p.mlen + (size_t)r * p.total_cap + o;
+  uint8_t* ms = p.mstate + (size_t)r * p.total_cap + o;
+  double* cnt = p.cnt + (size_t)r * p.n_cols + n;           // transition counters start after the n dwell columns
+  uint32_t err = 0;
+
+  Stream su, se;
+  su.open(ENT_BSTATE | (uint32_t)b, (uint32_t)it, rep, p.seed_lo, p.seed_hi);
+  se.open(ENT_BEXP | (uint32_t)b, (uint32_t)it, rep, p.seed_lo, p.seed_hi);
+
+  // pass A: interior states s_i ~ B[s_{i-1},:] (.) B^(m-i-1) e_end (:290, :301-304), neighbours merged (:54)
+  int w = 0;
+  int cur_s = (m == 1) ? cs : ps;                    // updatenodestates :469-472 (m == 1: the child end wins)
+  double cur_len = in[0];
+  for (int i = 1; i < m; ++i) {
+    int si;
+    if (i == m - 1) si = cs;
+    else {
+      int kk = m - i - 1;
+      if (kk >= p.klong) { err |= DERR_CAPACITY; kk = p.klong - 1; }
+      const double beta = p.colL[((size_t)kk * n + cs) * n + c];
+      const double pr = (lane < n) ? l.B2[cur_s * l.ldn + c] * beta : 0.0;
+      si = coop_sample(pr, su.draw((uint32_t)(i - 1)), n, lane, err);
+    }
+    const double di = in[i];
+    if (p.count_self && lane == 0) atomicAdd(cnt + cur_s * n + si, 1.0);                    // shortenerbf :1010-1014
+    if (si == cur_s) cur_len = cur_len + di;                                                // shortener :54
+    else {
+      ml[w] = cur_len; ms[w] = (uint8_t)cur_s;
+      if (!p.count_self && lane == 0) atomicAdd(cnt + cur_s * (n - 1) + (si > cur_s ? si - 1 : si), 1.0);   // :65-66
+      ++w; cur_s = si; cur_len = di;
+    }
+  }
+  ml[w] = cur_len; ms[w] = (uint8_t)cur_s;
+  const int nmerged = w + 1;
+
+  // pass B: virtual jumps, gaps ~ Exp(Omega + q_ss) until each merged segment is used up (:391-410); a segment that is not
+  // positive leaves itself and everything after it untouched (:397, :405-406).  Lane s carries the dwell sum of state s.
+  double mine = 0.0;
+  int mnew = 0;
+  uint32_t edraw = 0;
+  bool stuck = false;
+  for (int j = 0; j < nmerged; ++j) {
+    const int s = ms[j];
+    const double len = ml[j];
+    if (stuck || !(0.0 < len)) {
+      stuck = true;
+      if (mnew < cap) out[mnew] = len; else err |= DERR_CAPACITY;
+      if (lane == s) mine += len;
+      ++mnew;
+    } else {
+      const double scale = l.scale[s];
+      double tot = 0.0;
+      while (tot < len) {
+        const double rl = scale * neglog_u32(se.draw_word(edraw++), s_ltab);   // :398
+        double piece;
+        if ((tot + rl) < len) { piece = rl; tot += rl; }
+        else { piece = len - tot; tot = len; }
+        if (mnew < cap) out[mnew] = piece; else err |= DERR_CAPACITY;
+        if (lane == s) mine += piece;                                          // updatedwelltimes :752
+        ++mnew;
+      }
+    }
+  }
+  if (mnew > cap) mnew = cap;
+  mc[b] = mnew;
+  double* part = p.part + ((size_t)r * p.n_edge + b) * (n + 1);
+  if (lane < n) part[lane] = mine;
+  if (lane == 0) part[n] = (double)(m + mnew);
+  if (err) atomicOr(p.err, err);
+}
+
+// Statistics row of one replica: dwell columns = fixed-order sums of the per-branch values (thread t takes branches t,
+// t+256, ... then a fixed tree), counters copied out of the atomic buffer (and cleared), (ks) the root state.
+__global__ __launch_bounds__(256) void wb_stats_kernel(WideBranchParams p) {
+  __shared__ double red[256];
+  const int r = blockIdx.x, n = p.n_states;
+  const int ncnt = p.count_self ? n * n : n * (n - 1);
+  const int pc = n + 1;
+  const double* part = p.part + (size_t)r * p.n_edge * pc;
+  for (int c = 0; c <= n; ++c) {                    // c == n: segments read + written
+    double s = 0.0;
+    for (int e = threadIdx.x; e < p.n_edge; e += 256) s += part[(size_t)e * pc + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int half = 128; half >= 1; half >>= 1) {
+      if ((int)threadIdx.x < half) red[threadIdx.x] = red[threadIdx.x] + red[threadIdx.x + half];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      if (c < n) p.rowbuf[(size_t)r * p.n_cols + c] = red[0];
+      else atomicAdd(p.segcnt, (unsigned long long)red[0]);
+    }
+    __syncthreads();
+  }
+  double* cnt = p.cnt + (size_t)r * p.n_cols + n;
+  for (int c = threadIdx.x; c < ncnt; c += 256) { p.rowbuf[(size_t)r * p.n_cols + n + c] = cnt[c]; cnt[c] = 0.0; }
+  if (p.ks && threadIdx.x == 0)                                                // root state, 0-based (:1350-1352)
+    p.rowbuf[(size_t)r * p.n_cols + n + ncnt] = (double)p.nstate[(size_t)r * p.n_node + p.root];
+}
+
+__global__ void wb_emit_kernel(WideBranchParams p, int it) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (!p.reduce) {
+    if (gid >= (int64_t)p.n_rep * p.n_cols) return;
+    const int r = (int)(gid / p.n_cols), c = (int)(gid % p.n_cols);
+    p.stats[((size_t)it * p.n_cols + c) * p.n_rep_pad + r] = p.rowbuf[(size_t)r * p.n_cols + c];
+  } else {
+    if (gid >= (int64_t)p.n_tiles * p.n_cols) return;
+    const int tile = (int)(gid / p.n_cols), c = (int)(gid % p.n_cols);
+    double s = 0.0;
+    for (int r = tile * 64; r < tile * 64 + 64 && r < p.n_rep; ++r) s += p.rowbuf[(size_t)r * p.n_cols + c];
+    p.stats[((size_t)it * p.n_tiles + tile) * p.n_cols + c] = s;
+  }
+}
+
+}  // namespace
+
+size_t wbranch_lds_bytes(int n, bool sparse) { return sizeof(double) * ((size_t)(sparse ? 2 : 1) * n * (n | 1) + n); }
+
+hipError_t launch_wbranch_sweep(const WideBranchParams& p, const std::vector<int32_t>& up_off,
+                                const std::vector<int32_t>& down_off, int it, hipStream_t stream) {
+  constexpr int WPB = WB_BLOCK / 64;
+  const unsigned S = (unsigned)p.n_rep;
+  const size_t lds = wbranch_lds_bytes(p.n_states, p.sparse != 0);
+  if (lds > 48 * 1024) {      // SPARSE with ~60 states: two copies of B
+    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(wb_up_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(wb_branch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e1 != hipSuccess) return e1;
+    if (e2 != hipSuccess) return e2;
+  }
+  for (size_t l = 0; l + 1 < up_off.size(); ++l) {
+    const int cnt = up_off[l + 1] - up_off[l];
+    if (cnt > 0) hipLaunchKernelGGL(wb_up_kernel, dim3((cnt + WPB - 1) / WPB, S), dim3(WB_BLOCK), lds, stream, p, up_off[l], up_off[l + 1]);
+  }
+  hipLaunchKernelGGL(wb_root_kernel, dim3((S + WPB - 1) / WPB), dim3(WB_BLOCK), 0, stream, p, it);
+  for (size_t l = 0; l + 1 < down_off.size(); ++l) {
+    const int cnt = down_off[l + 1] - down_off[l];
+    if (cnt > 0) hipLaunchKernelGGL(wb_down_kernel, dim3((cnt + WPB - 1) / WPB, S), dim3(WB_BLOCK), 0, stream, p, it, down_off[l], down_off[l + 1]);
+  }
+  hipLaunchKernelGGL(wb_branch_kernel, dim3((p.n_edge + WPB - 1) / WPB, S), dim3(WB_BLOCK), lds, stream, p, it);
+  hipLaunchKernelGGL(wb_stats_kernel, dim3(S), dim3(256), 0, stream, p);
+  const int64_t items = (int64_t)(p.reduce ? p.n_tiles : p.n_rep) * p.n_cols;
+  hipLaunchKernelGGL(wb_emit_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, p, it);
+  return hipGetLastError();
+}
+
+}  // namespace phm

@@ -262,7 +262,8 @@ def test_wide_kernel_per_site_tips_on_thinly_filled_tiles():
     nen, nodelist, root = _orders(z)
     S, N, seed = 5, 12, 19
     sites = np.random.default_rng(1).integers(1, n + 1, size=(S, 14)).astype(np.int32)
-    eng = _lib.Engine(z, Q, pid, Omega, N, variant=_lib.PHM_MCMC_BIGTREE, seed=seed, n_replicas=S, tips_per_replica=True, states=sites)
+    eng = _lib.Engine(z, Q, pid, Omega, N, variant=_lib.PHM_MCMC_BIGTREE, seed=seed, n_replicas=S, tips_per_replica=True, states=sites,
+                      mapping="replicas")
     assert eng.info().n_replicas_padded == 64 * S                         # one replica per tile
     eng.run(N); eng.sync()
     per = eng.stats(0, N)
@@ -276,18 +277,21 @@ def test_wide_kernel_per_site_tips_on_thinly_filled_tiles():
         np.testing.assert_array_equal(eng.dump(r)["node_states"], dump.node_states)
         total += want
     eng.close()
-    eng = _lib.Engine(z, Q, pid, Omega, N, variant=_lib.PHM_MCMC_BIGTREE, seed=seed, n_replicas=S, tips_per_replica=True, states=sites, reduce=True)
-    eng.run(N); eng.sync()
-    red = eng.stats(0, N)
-    eng.close()
-    np.testing.assert_array_equal(red[:, n:], total[:, n:])
-    np.testing.assert_allclose(red[:, :n], total[:, :n], rtol=1e-12)
+    for mapping in ("replicas", "branches"):      # branches: one wave per (replica, branch) with per-replica tip vectors
+        eng = _lib.Engine(z, Q, pid, Omega, N, variant=_lib.PHM_MCMC_BIGTREE, seed=seed, n_replicas=S, tips_per_replica=True, states=sites,
+                          reduce=True, mapping=mapping)
+        eng.run(N); eng.sync()
+        red = eng.stats(0, N)
+        eng.close()
+        np.testing.assert_array_equal(red[:, n:], total[:, n:])
+        np.testing.assert_allclose(red[:, :n], total[:, :n], rtol=1e-12)
 
 
+@pytest.mark.parametrize("mapping", ["replicas", "branches"])     # wave per 64-replica tile / wave per (replica, branch)
 @pytest.mark.parametrize("n,fn,variant", [(20, "sumstatMCMC", O.PLAIN), (20, "SPARSEsumstatMCMC", O.SPARSE),
                                           (20, "sumstatMCMC_bigtree", O.BIGTREE), (5, "sumstatMCMC", O.PLAIN),
                                           (61, "sumstatMCMC_bigtree", O.BIGTREE), (64, "sumstatMCMC", O.PLAIN)])
-def test_wide_kernel_matches_oracle(n, fn, variant):
+def test_wide_kernel_matches_oracle(n, fn, variant, mapping):
     """5..64 states (C4: dense 61-state Q; C5: sparse 20-state tridiagonal Q): states-over-lanes kernel."""
     if n == 20:
         Q = synth.config_Q(5)
@@ -301,14 +305,13 @@ def test_wide_kernel_matches_oracle(n, fn, variant):
     z = synth.make_tree(tips, Q, Omega, 400 + n, pid, init_segments=(n if n == 20 else 2))
     nen, nodelist, root = _orders(z)
     N, S, seed = 10, 3, 31
-    got = getattr(api, fn)(z, Q, pid, Omega, N, seed=seed, n_replicas=S)
+    got = getattr(api, fn)(z, Q, pid, Omega, N, seed=seed, n_replicas=S, mapping=mapping)
     for r in range(S):
         want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(n) + Q / Omega, Omega, nen, nodelist, root, N, variant=variant,
                                       seed=seed, replica=r)
         assert rc == 0
-        np.testing.assert_array_equal(got[r][:, n:], want[:, n:])
-        np.testing.assert_array_equal(got[r][:, :n], want[:, :n])
-    red = getattr(api, fn)(z, Q, pid, Omega, N, seed=seed, n_replicas=S, reduce=True)
+        _same(got[r], want, n, mapping)
+    red = getattr(api, fn)(z, Q, pid, Omega, N, seed=seed, n_replicas=S, reduce=True, mapping=mapping)
     np.testing.assert_array_equal(red[:, n:], got.sum(0)[:, n:])
     np.testing.assert_allclose(red[:, :n], got.sum(0)[:, :n], rtol=1e-12)
 
@@ -319,21 +322,27 @@ def test_wide_kernel_chain_state_and_golden():
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "n20_t12.npz"))
     z = unpack_tree(g)
     Q, pid, Omega, seed = g["Q"], g["pid"], float(g["Omega"]), int(g["seed"])
-    got = api.SPARSEsumstatMCMC(z, Q, pid, Omega, 24, seed=seed, n_replicas=6)
+    got = api.SPARSEsumstatMCMC(z, Q, pid, Omega, 24, seed=seed, n_replicas=6, mapping="replicas")
+    gotb = api.SPARSEsumstatMCMC(z, Q, pid, Omega, 24, seed=seed, n_replicas=6, mapping="branches")
+    _same(gotb[0], g["sparse_r0"], 20, "branches")
+    _same(gotb[5], g["sparse_r5"], 20, "branches")
     np.testing.assert_array_equal(got[0], g["sparse_r0"])
     np.testing.assert_array_equal(got[5], g["sparse_r5"])
-    eng = _lib.Engine(z, Q, pid, Omega, 9, variant=_lib.PHM_MCMC_BIGTREE, seed=seed, n_replicas=2)
-    eng.run(9); eng.sync()
     want, rc, dump = O.maketreelistMCMC(z, Q, pid, np.eye(20) + Q / Omega, Omega, g["nen"], g["nodelist"], int(g["root"]), 9,
                                         variant=O.BIGTREE, seed=seed, replica=1, dump=True)
-    d = eng.dump(1)
-    eng.close()
-    np.testing.assert_array_equal(d["seg_count"], dump.seg_count)
-    np.testing.assert_array_equal(d["node_states"], dump.node_states)
-    np.testing.assert_array_equal(d["PL"], dump.PL)
+    for mapping in ("replicas", "branches"):
+        eng = _lib.Engine(z, Q, pid, Omega, 9, variant=_lib.PHM_MCMC_BIGTREE, seed=seed, n_replicas=2, mapping=mapping)
+        eng.run(9); eng.sync()
+        d = eng.dump(1)
+        eng.close()
+        np.testing.assert_array_equal(d["seg_count"], dump.seg_count)
+        np.testing.assert_array_equal(d["node_states"], dump.node_states)
+        np.testing.assert_array_equal(d["PL"], dump.PL)
+        for b in range(len(dump.seg_count)):
+            np.testing.assert_array_equal(d["seg_dwell"][b, :dump.seg_count[b]], dump.seg_dwell[b, :dump.seg_count[b]])
 
 
-@pytest.mark.parametrize("n,mapping", [(2, "replicas"), (4, "replicas"), (2, "branches"), (4, "branches"), (2, "tiles"), (4, "tiles"), (6, "replicas")])
+@pytest.mark.parametrize("n,mapping", [(2, "replicas"), (4, "replicas"), (2, "branches"), (4, "branches"), (2, "tiles"), (4, "tiles"), (6, "replicas"), (6, "branches")])
 def test_ks_sweep_matches_oracle(n, mapping):
     """Tree sweep of sumstatMCMCks with Q fixed (hidden-rates Q = make2sQ, binary trait observed): n<=4 kernel and,
     for k=2 (n=6), the wide kernel."""
