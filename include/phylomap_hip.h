@@ -99,10 +99,12 @@ typedef struct phm_options {
                                   1+Poisson(Omega*t_b) quantile at this tail; 0 -> 1e-3 */
   int32_t reserved[6];         /* [0]: dwell-stream storage of the replica mapping, 0 = automatic, 1 = one ring per tile (half the
                                        HBM), 2 = two buffers (5 % faster sweep for n <= 4)
-                                  [1]: mapping of a sweep onto the lanes (n <= 4, one tree), 0 = automatic by replica count,
+                                  [1]: mapping of a sweep onto the lanes (one tree), 0 = automatic by replica count; for n <= 4:
                                        1 = one lane per replica, one wave per 64-replica tile walks the tree (largest replica counts),
                                        2 = one lane per branch of one chain (a handful of chains, large trees),
-                                       3 = one wave per (64-replica tile, branch) (10^2 .. 10^5 replicas).
+                                       3 = one wave per (64-replica tile, branch) (10^2 .. 10^5 replicas);
+                                       for 5..64 states (one state per lane): 1 = one wave per 64-replica tile, replicas in turn,
+                                       2 or 3 = one wave per (replica, branch) (the automatic choice while its memory fits).
                                        Same draws and counts in every mapping; dwell sums differ in the last bits between
                                        1 and 2/3 (summation order).  cap_tail defaults to 1e-12 for 2 and 3 (fixed slots). */
 } phm_options;
