@@ -5,12 +5,18 @@
  * (src/phylomap.cpp).  Only tests/, __graft_entry__.smoke() and bench.py's
  * cpu_baseline leg may load this library; the product (phylomap_amd/) never does.
  *
- * PARITY STATUS: "parity unpinned" -- the reference ships no tests / golden vectors
- * and cannot be built here (needs R, Rcpp, RcppArmadillo).
- * The oracle is pinned by (i) Random123 known-answer vectors for Philox4x32-10,
- * (ii) libm for phm_log/phm_exp, (iii) scipy.linalg.expm for the two expm routes,
- * (iv) hand-derived tiny cases and an independent pure-Python restatement
- * (tests/pyref.py), (v) the reference's own validation idea: EXP == MCMC == SPARSE
+ * PARITY STATUS: bit-level parity with the R package is "parity unpinned" -- the reference ships no tests / golden vectors
+ * and cannot be built here (needs R, Rcpp, RcppArmadillo).  What the reference does hold are two known
+ * answers, and the oracle reproduces both (tools/squamate_dic/):
+ *   - exactly: R/simulate_2_state_tree.R:11 notes "n01 is 21" for set.seed(101) on the shipped squamate tree; the R random
+ *     stream of this file (set.seed scrambling, Mersenne-Twister, unif_rand, Ahrens-Dieter exp_rand) driving the restated
+ *     tip simulation gives n01 = 21;
+ *   - statistically: the published DIC 2538.272 (2-state) / 2536.056 (4-state hidden rates) of
+ *     vignettes/Squamate_DIC_model_selection.Rnw:120 -- four seeds of the bf / ks DIC drivers give 2538.30 .. 2538.34
+ *     (Monte-Carlo s.e. 0.05) and 2528.9 .. 2537.3.
+ * Further pins: (i) Random123 known-answer vectors for Philox4x32-10, (ii) libm for phm_log/phm_exp and 50-digit arithmetic
+ * for the exponential variates, (iii) scipy.linalg.expm for the two expm routes, (iv) hand-derived tiny cases and an
+ * independent pure-Python restatement (tests/pyref.py), (v) the reference's own validation idea: EXP == MCMC == SPARSE
  * in distribution (vignettes/phylomap_tutorial.Rnw:113-134).
  *
  * Every function cites the reference file:line it follows.
