@@ -561,6 +561,10 @@ int32_t phm_engine_create_multi(const phm_tree* trees, int32_t n_trees, const ph
     e->narrow = small_n && (o.reserved[1] == 2 || (auto_map && e->S <= NARROW_AUTO_MAX_REPLICAS));
     e->tiled = small_n && !e->narrow && (o.reserved[1] == 3 || (auto_map && e->S <= TILES_AUTO_MAX_REPLICAS));
   }
+  if (e->narrow && e->S > 65535) {      // the replica index is the grid's y dimension in these kernels
+    if (!auto_map) return fail(PHM_ERR_UNSUPPORTED, "the one-lane-per-branch / wave-per-(replica, branch) mappings take at most 65 535 replicas");
+    e->narrow = false; e->tiled = !e->wide && e->S <= TILES_AUTO_MAX_REPLICAS;
+  }
   if (e->narrow) {
     st = narrow_setup(e, x, model, o, max_iters);
     if (st == PHM_ERR_OOM && auto_map) { e->narrow = false; e->tiled = !e->wide; st = PHM_OK; }
