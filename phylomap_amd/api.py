@@ -20,14 +20,20 @@ from . import _lib
 from .treeorder import makenodelist, myreorder, pruningwiseedgeorder  # noqa: F401  (Python twins of phm_tree_orders)
 
 
-def _mcmc(fn_name, z, Q, pid, Omega, N, **opt):
+def _mcmc(fn_name, z, Q, pid, Omega, N, sites=None, **opt):
+    """``sites``: optional S x n_tips matrix of 1-based tip states -- S sites of an alignment on the same tree, one chain each
+    (``n_replicas = S``, ``tips_per_replica``); the initial paths of ``z`` must be compatible with every site (e.g. internal
+    segments in a state from which every tip state is reachable)."""
     L = _lib.load()
+    if sites is not None:
+        sites = np.ascontiguousarray(np.asarray(sites).round(), dtype=np.int32)
+        opt = dict(opt, n_replicas=sites.shape[0], tips_per_replica=True)
     Q = np.asfortranarray(np.asarray(Q, dtype=np.float64))
     n = Q.shape[0]
     nen, nodelist, root = _lib.tree_orders(z)                                 # R/sumstatMCMC.R:22-24, native O(E)
     B = np.asfortranarray(np.eye(n) + Q / Omega)                              # :25
     pid = np.ascontiguousarray(pid, dtype=np.float64)
-    ft = _lib.FlatTree(z)
+    ft = _lib.FlatTree(z, sites)
     o = _lib.make_options(**opt)
     S = max(1, int(o.n_replicas))
     cols = n + n * (n - 1)
@@ -60,9 +66,8 @@ def SPARSEsumstatMCMC(z, Q, pid, Omega, N, **opt):
 def sumstatMCMCks_sweep(z, Q, pid, Omega, N, **opt):
     """The tree sweep of ``sumstatMCMCks`` (R/sumstatMCMCks.R, src/phylomap.cpp:1802-1872) with Q held FIXED:
     hidden-rates Q of even size (``synth.make2sQ``), tips observed only up to parity and re-sampled every sweep,
-    n x n transition counters including self pairs, result layout of man/sumstatMCMCks.Rd:19.  The per-iteration
-    Gibbs/MH updates of Q driven by ``prior`` (src/phylomap.cpp:1862-1866) are host glue that is not built yet, so
-    this is not yet a drop-in for ``sumstatMCMCks(z,Q,pid,Omega,N,prior)``."""
+    n x n transition counters including self pairs, result layout of man/sumstatMCMCks.Rd:19.  ``sumstatMCMCks`` below
+    adds the per-iteration Gibbs/MH updates of Q (src/phylomap.cpp:1862-1866) and is the drop-in for the R function."""
     return _mcmc("phm_maketreelistMCMCks_sweep", z, Q, pid, Omega, N, **opt)
 
 

@@ -677,3 +677,20 @@ def test_errors_are_loud():
     with pytest.raises(_lib.PhmError) as e:
         api.sumstatMCMC(z65, Q65, np.full(65, 1 / 65), 1.0, 2)
     assert e.value.status == 2
+
+
+def test_alignment_sites_through_the_r_level_api():
+    """api.sumstatMCMC_bigtree(..., sites=): S sites of an alignment on one tree, one chain per site, per-site statistics."""
+    z, Q, pid, Omega = _problem(4, 30, 17)
+    nen, nodelist, root = _orders(z)
+    sites = np.random.default_rng(5).integers(1, 5, size=(130, 30)).astype(np.int32)
+    got = api.sumstatMCMC_bigtree(z, Q, pid, Omega, 6, sites=sites, seed=9)          # 130 sites: wave per (tile, branch)
+    assert got.shape == (130, 6, 16)
+    for r in (0, 64, 129):
+        zr = dict(z); zr["states"] = sites[r]
+        want, rc = O.maketreelistMCMC(zr, Q, pid, np.eye(4) + Q / Omega, Omega, nen, nodelist, root, 6, variant=O.BIGTREE, seed=9, replica=r)
+        assert rc == 0
+        _same(got[r], want, 4, "tiles")
+    red = api.sumstatMCMC_bigtree(z, Q, pid, Omega, 6, sites=sites, seed=9, reduce=True)
+    np.testing.assert_array_equal(red[:, 4:], got.sum(0)[:, 4:])
+    np.testing.assert_allclose(red[:, :4], got.sum(0)[:, :4], rtol=1e-12)
