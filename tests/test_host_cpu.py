@@ -190,3 +190,41 @@ def test_input_validation_happens_before_the_device():
     zb["edge"][2, 0] = zb["edge"][0, 0]                     # three children on one node
     with pytest.raises((_lib.PhmError, ValueError)):
         api.sumstatMCMC(zb, Q, pid, Om, 3)
+
+
+def test_newick_parser_numbers_nodes_like_ape_and_prunes():
+    """phylomap_amd/newick.py: tips 1..T in order of appearance, internal nodes in pre-order, cladewise edge rows; dropping
+    tips suppresses single-child nodes and adds their branch lengths."""
+    from phylomap_amd import newick
+    t = newick.read_newick("((A:1,B:2)X:3,(C:4,(D:5,E:6)Y:7)Z:8)R;")
+    assert t["tip.label"] == ["A", "B", "C", "D", "E"] and t["Nnode"] == 4 and t["node.label"] == ["R", "X", "Z", "Y"]
+    np.testing.assert_array_equal(t["edge"], [[6, 7], [7, 1], [7, 2], [6, 8], [8, 3], [8, 9], [9, 4], [9, 5]])
+    np.testing.assert_array_equal(t["edge.length"], [3, 1, 2, 8, 4, 7, 5, 6])
+    p = newick.drop_tips("((A:1,B:2)X:3,(C:4,(D:5,E:6)Y:7)Z:8)R;", ["B", "E"])
+    assert p["tip.label"] == ["A", "C", "D"]
+    np.testing.assert_array_equal(p["edge"], [[4, 1], [4, 5], [5, 2], [5, 3]])
+    np.testing.assert_array_equal(p["edge.length"], [4, 8, 4, 12])            # A: 1 + 3, D: 5 + 7
+    q = newick.drop_tips(t, ["A", "B"])                                         # the root loses a child and disappears with its edge
+    assert q["tip.label"] == ["C", "D", "E"] and q["Nnode"] == 2
+    np.testing.assert_array_equal(q["edge.length"], [4, 7, 5, 6])
+    z = newick.as_phylomap(p, [1, 2, 1], segments=4)
+    assert [len(m) for m in z["maps"]] == [4] * 4 and z["mapnames"][2].tolist() == [1, 1, 1, 2] and z["mapnames"][1].tolist() == [1] * 4
+    eng_orders = _lib.tree_orders(z)                                            # the result is a tree the engine accepts
+    assert eng_orders[2] == 4
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/inst/extdata/Squamate/squamate.phy"), reason="reference data only in the build container")
+def test_newick_reader_reproduces_the_reference_prepared_squamate_tree():
+    """inst/extdata/Squamate/squamate.phy through phylomap_amd/newick.py equals the tree the reference prepared in R
+    (R/Squamate_tree_setup.R -> phylomap_compatible_squamate_tree.RData): same tip labels, the same ape node numbering and
+    edge order, the same branch lengths, the same 100-segment initial paths."""
+    from phylomap_amd import newick, rds
+    t = newick.read_newick(open("/root/reference/inst/extdata/Squamate/squamate.phy").read())
+    z = rds.read_rds("/root/reference/inst/extdata/Squamate/phylomap_compatible_squamate_tree.RData")
+    assert t["tip.label"] == list(z["tip.label"]) and t["Nnode"] == 3950
+    np.testing.assert_array_equal(t["edge"], np.asarray(z["edge"]).astype(np.int32))
+    np.testing.assert_allclose(t["edge.length"], np.asarray(z["edge.length"]), rtol=0, atol=1e-12)
+    mine = newick.as_phylomap(t, np.asarray(z["states"]), segments=100)
+    for b in (0, 1, 17, 7899):
+        np.testing.assert_allclose(mine["maps"][b], np.asarray(z["maps"][b]), rtol=1e-15)
+        np.testing.assert_array_equal(mine["mapnames"][b], np.asarray(z["mapnames"][b]).round().astype(np.int32))
