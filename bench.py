@@ -63,6 +63,8 @@ def main():
     ap.add_argument("--config", type=int, default=2)
     ap.add_argument("--ipl", type=int, default=8, help="sweeps fused per kernel launch")
     ap.add_argument("--storage", type=int, default=2, help="dwell streams: 2 = two buffers (fastest), 1 = one ring (half the HBM)")
+    ap.add_argument("--mapping", default="replicas", choices=["replicas", "tiles", "branches", "auto"],
+                    help="how a sweep is laid over the lanes (DESIGN.md 4b); the headline configuration streams with one lane per replica")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--force-collective", action="store_true", help="exercise the statistics hand-over to torch at N=1")
     args = ap.parse_args()
@@ -94,7 +96,7 @@ def main():
     if S <= 0:
         free_b, _ = torch.cuda.mem_get_info()
         probe = _lib.Engine(z, Q, pid, Omega, 1, variant=_lib.PHM_MCMC_BIGTREE, seed=1, n_replicas=64, reduce=True,
-                            device=local_rank, storage=args.storage, mapping="replicas")
+                            device=local_rank, storage=args.storage if args.mapping == "replicas" else 0, mapping=args.mapping)
         per_tile = probe.info().device_bytes
         probe.close()
         S = int(min(327680, (0.80 * free_b) // per_tile * 64))
@@ -102,7 +104,8 @@ def main():
 
     eng = _lib.Engine(z, Q, pid, Omega, K + W, variant=_lib.PHM_MCMC_BIGTREE, seed=0x5EED0000 + args.config,
                       n_replicas=S, replica_offset=parallel.weak_shard(S, rank)[0], reduce=True, device=local_rank,
-                      iters_per_launch=args.ipl, storage=args.storage, mapping="replicas")   # one lane per replica
+                      iters_per_launch=args.ipl, storage=args.storage if args.mapping == "replicas" else 0,
+                      mapping=args.mapping)   # default: one lane per replica, the streaming layout of the headline configuration
     stream = torch.cuda.current_stream().cuda_stream
 
     def barrier():
@@ -147,7 +150,8 @@ def main():
     kernel_s = info.last_run_ms / 1e3
     achieved = units_rank * b_alg / kernel_s / 1e9
 
-    prune_ms = eng.time_pruning(8, stream) / 8.0           # the pruning sweep alone (12n+12 B per branch)
+    # the pruning sweep alone (12n+12 B per branch); timed for the n <= 4 replica kernel only
+    prune_ms = eng.time_pruning(8, stream) / 8.0 if (n <= 4 and args.mapping == "replicas") else None
     stats = eng.stats(W, K)
     # sanity: dwell row sums = S x tree length; the tensor handed to RCCL is the same matrix (x world)
     assert np.allclose(stats[:, :n].sum(1), S * z["edge.length"].sum(), rtol=1e-9)
@@ -185,10 +189,10 @@ def main():
                          "avg_launch_ms": info.last_run_ms / max(1, info.last_run_launches),
                          "alg_bytes_per_unit": b_alg, "mean_segments_read_plus_written": seg,
                          "units_per_launch": E * S * args.ipl},
-            "pruning_sweep": {"kernel": "mcmc_sweep_kernel<4> (up sweep only)", "ms_per_sweep": prune_ms,
-                              "alg_bytes_per_unit": 12 * n + 12,
-                              "achieved": E * S * (12 * n + 12) / (prune_ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS,
-                              "unit": "GB/s", "frac": E * S * (12 * n + 12) / (prune_ms / 1e3) / 1e9 / HBM_PEAK_GBS},
+            "pruning_sweep": None if prune_ms is None else {
+                "kernel": "mcmc_sweep_kernel<4> (up sweep only)", "ms_per_sweep": prune_ms, "alg_bytes_per_unit": 12 * n + 12,
+                "achieved": E * S * (12 * n + 12) / (prune_ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": E * S * (12 * n + 12) / (prune_ms / 1e3) / 1e9 / HBM_PEAK_GBS},
             "hbm_bytes_resident": int(info.device_bytes),
         }
     eng.close()
@@ -215,12 +219,18 @@ def main():
     if rank == 0:
         # secondary metric of BASELINE.json: expm(Q t)/s (batched 4x4 transition matrices, kernel time)
         t = np.random.default_rng(0).exponential(4.0 / Omega, 1 << 20)
-        lefts, rights, d = api.eigen_decompose(Q)
-        _, ms_e = api.expm_eigen(lefts, rights, d, t, device=local_rank)
-        _, ms_e = api.expm_eigen(lefts, rights, d, t, device=local_rank)
-        _, ms_p = api.expm_pade(Q, t[: 1 << 18], device=local_rank)
-        _, ms_p = api.expm_pade(Q, t[: 1 << 18], device=local_rank)
-        out["expm_per_s"] = {"n_states": n, "eigen_route": t.size / (ms_e / 1e3), "pade_route": (1 << 18) / (ms_p / 1e3)}
+        npade = (1 << 18) if n <= 8 else (1 << 13)
+        _, ms_p = api.expm_pade(Q, t[:npade], device=local_rank)
+        _, ms_p = api.expm_pade(Q, t[:npade], device=local_rank)
+        out["expm_per_s"] = {"n_states": n, "pade_route": npade / (ms_p / 1e3)}
+        try:                                          # the eigen route (matexp, R/sumstatEXP.R:26-29) needs a real spectrum
+            lefts, rights, d = api.eigen_decompose(Q)
+            nt = t.size if n <= 8 else (1 << 15)
+            _, ms_e = api.expm_eigen(lefts, rights, d, t[:nt], device=local_rank)
+            _, ms_e = api.expm_eigen(lefts, rights, d, t[:nt], device=local_rank)
+            out["expm_per_s"]["eigen_route"] = nt / (ms_e / 1e3)
+        except ValueError:
+            out["expm_per_s"]["eigen_route"] = None
         # the same metric on the dense 61-state shape of C4, where the products fill MFMA f64 tiles
         Q61 = synth.config_Q(4)
         Q61 = (Q61 + Q61.T) / 2                      # matexp handles a real spectrum only (R/sumstatEXP.R:26-29)
