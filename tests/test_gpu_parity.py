@@ -694,3 +694,15 @@ def test_alignment_sites_through_the_r_level_api():
     red = api.sumstatMCMC_bigtree(z, Q, pid, Omega, 6, sites=sites, seed=9, reduce=True)
     np.testing.assert_array_equal(red[:, 4:], got.sum(0)[:, 4:])
     np.testing.assert_allclose(red[:, :4], got.sum(0)[:, :4], rtol=1e-12)
+
+
+def test_random_cases_every_mapping_against_the_oracle():
+    """tools/fuzz_mappings.py: random state counts (2..12), trees, edge orders, initial paths, replica counts and variants,
+    every mapping of the sweep against the oracle (counts bit-exact, dwell <= 1e-10)."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_mappings.py")
+    spec = importlib.util.spec_from_file_location("fuzz_mappings", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(20261003, 120) == 0
