@@ -706,3 +706,18 @@ def test_random_cases_every_mapping_against_the_oracle():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.run(20261003, 120) == 0
+
+
+@pytest.mark.parametrize("mapping", MAPPINGS)
+def test_capacity_overflow_is_reported_not_written_out_of_bounds(mapping):
+    """A dwell store that would leave its slot / stream is dropped and reported (PHM_ERR_CAPACITY) -- the reference's
+    std::list is unbounded, a fixed HBM layout is not.  cap_tail = 0.9 provisions far too little on purpose."""
+    z, Q, pid, Omega = _problem(4, 40, 3)
+    with pytest.raises(_lib.PhmError) as e:
+        eng = _lib.Engine(z, Q, pid, 6.0 * Omega, 30, variant=_lib.PHM_MCMC_BIGTREE, seed=1, n_replicas=70, mapping=mapping, cap_tail=0.9,
+                          storage=1 if mapping == "replicas" else 0)
+        eng.run(30)
+        eng.sync()
+    assert e.value.status == 6
+    ok = api.sumstatMCMC_bigtree(z, Q, pid, 6.0 * Omega, 5, seed=1, n_replicas=70, mapping=mapping)      # default capacity: fine
+    np.testing.assert_allclose(ok[:, :, :4].sum(2), z["edge.length"].sum(), rtol=1e-12)
