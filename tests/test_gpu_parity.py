@@ -721,3 +721,17 @@ def test_capacity_overflow_is_reported_not_written_out_of_bounds(mapping):
     assert e.value.status == 6
     ok = api.sumstatMCMC_bigtree(z, Q, pid, 6.0 * Omega, 5, seed=1, n_replicas=70, mapping=mapping)      # default capacity: fine
     np.testing.assert_allclose(ok[:, :, :4].sum(2), z["edge.length"].sum(), rtol=1e-12)
+
+
+@pytest.mark.parametrize("mapping", ["replicas", "branches"])
+def test_capacity_overflow_is_reported_for_wide_state_spaces(mapping):
+    n = 6
+    Q = synth.dense_Q(n, 0.02, 0.08, seed=66)
+    Omega = 1.25 * float(np.max(np.abs(np.diag(Q))))
+    pid = np.full(n, 1.0 / n)
+    z = synth.make_tree(20, Q, Omega, 67, pid)
+    with pytest.raises(_lib.PhmError) as e:
+        eng = _lib.Engine(z, Q, pid, 8.0 * Omega, 30, variant=_lib.PHM_MCMC_BIGTREE, seed=1, n_replicas=5, mapping=mapping, cap_tail=0.9)
+        eng.run(30)
+        eng.sync()
+    assert e.value.status == 6
