@@ -474,3 +474,21 @@ def test_exponential_variate_table_log_accuracy_and_agreement():
     assert worst < 1.5 * 2.0 ** -52
     assert L.orc_neglog_u32(0) == pyref.neglog_u32(0) and abs(L.orc_neglog_u32(0) - 33 * np.log(2.0)) < 1e-14
     assert 0 < L.orc_neglog_u32(2 ** 32 - 1) < 1.2e-10
+
+
+def test_exponential_variates_are_exponential():
+    """Kolmogorov-Smirnov check of -log((k + 0.5) 2^-32) over a Philox stream against Exp(1), and of the uniforms against U(0,1)."""
+    import ctypes as C
+    from scipy import stats
+    L = O.lib()
+    L.orc_neglog_u32.restype = C.c_double
+    L.orc_neglog_u32.argtypes = [C.c_uint32]
+    L.orc_stream_word.restype = C.c_uint32
+    L.orc_stream_word.argtypes = [C.c_uint32] * 6
+    words = [L.orc_stream_word(11, 22, 3, 4, 2 << 30 | 5, d) for d in range(40000)]
+    e = np.array([L.orc_neglog_u32(k) for k in words])
+    u = np.array([L.orc_stream_u(11, 22, 3, 4, 2 << 30 | 5, d) for d in range(40000)])
+    assert stats.kstest(e, "expon").pvalue > 1e-3
+    assert stats.kstest(u, "uniform").pvalue > 1e-3
+    np.testing.assert_allclose(e, -np.log(u), rtol=1e-13)                  # the variate IS -log of the same draw's uniform
+    assert abs(e.mean() - 1.0) < 0.02 and abs(e.var() - 1.0) < 0.05
