@@ -59,7 +59,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=240)
     ap.add_argument("--warmup", type=int, default=24)
-    ap.add_argument("--replicas", type=int, default=0, help="replicas per GPU (0: sized from free HBM, max 327680 = 5 waves per SIMD)")
+    ap.add_argument("--replicas", type=int, default=0, help="replicas per GPU (0: sized from free HBM, max 393216 = 6 waves per SIMD)")
     ap.add_argument("--config", type=int, default=2)
     ap.add_argument("--ipl", type=int, default=8, help="sweeps fused per kernel launch")
     ap.add_argument("--storage", type=int, default=2, help="dwell streams: 2 = two buffers (fastest), 1 = one ring (half the HBM)")
@@ -99,7 +99,7 @@ def main():
                             device=local_rank, storage=args.storage if args.mapping == "replicas" else 0, mapping=args.mapping)
         per_tile = probe.info().device_bytes
         probe.close()
-        S = int(min(327680, (0.80 * free_b) // per_tile * 64))
+        S = int(min(393216, (0.80 * free_b) // per_tile * 64))
         S = max(64, S // 16384 * 16384 if S >= 16384 else S // 64 * 64)
 
     eng = _lib.Engine(z, Q, pid, Omega, K + W, variant=_lib.PHM_MCMC_BIGTREE, seed=0x5EED0000 + args.config,

@@ -71,8 +71,7 @@ __device__ __forceinline__ void sweep_body(const McmcParams<NS>& p, int iter0, i
 
   // ---- LDS carve-up: tables shared by the workgroup, accumulators private to each lane ----
   double* s_col = reinterpret_cast<double*>(smem);            // [ktab][NS][NS]  B^k e_j      (column chains)
-  double* s_row = s_col + p.ktab * NS * NS;                   // [ktab][NS][NS]  (B^T)^k e_j  (row chains)
-  double* s_B2 = s_row + p.ktab * NS * NS;                    // [NS][NS] dense B, rows for the forward step
+  double* s_B2 = s_col + p.ktab * NS * NS;                    // [NS][NS] dense B, rows for the forward step
   double* s_scale = s_B2 + NS * NS;                           // [NS] 1/(Omega+q_ss)
   double* s_dw = s_scale + NS + (size_t)wave * NS * 64;       // [NS][64] dwell accumulators of this wave
   uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_scale + NS + (size_t)(MCMC_BLOCK / 64) * NS * 64) +
@@ -81,7 +80,7 @@ __device__ __forceinline__ void sweep_body(const McmcParams<NS>& p, int iter0, i
                                              (size_t)(MCMC_BLOCK / 64) * NS * NS * 64);   // [ktab][2][NS] (ks only)
   __shared__ double s_ltab[2 * PHM_LOGTAB_N];                 // (1/c_j, log c_j) of the exponential variates (neglog_u32)
   for (int i = threadIdx.x; i < 2 * PHM_LOGTAB_N; i += MCMC_BLOCK) s_ltab[i] = logtab_entry(i);
-  for (int i = threadIdx.x; i < p.ktab * NS * NS; i += MCMC_BLOCK) { s_col[i] = p.colpow[i]; s_row[i] = p.rowpow[i]; }
+  for (int i = threadIdx.x; i < p.ktab * NS * NS; i += MCMC_BLOCK) s_col[i] = p.colpow[i];
   if (KS && p.tip_masks) for (int i = threadIdx.x; i < p.ktab * 2 * NS; i += MCMC_BLOCK) s_mask[i] = p.maskpow[i];
   if (threadIdx.x < NS * NS) s_B2[threadIdx.x] = p.B2[threadIdx.x];
   if (threadIdx.x < NS) s_scale[threadIdx.x] = p.scale[threadIdx.x];
@@ -177,11 +176,7 @@ __device__ __forceinline__ void sweep_body(const McmcParams<NS>& p, int iter0, i
         double w[NS];
         int kk = m - 1;
         int kt = kk < p.klong ? kk : p.klong - 1;
-        if (kt < p.ktab) {
-          const double* src = s_row + (kt * NS + ps) * NS;
-#pragma unroll
-          for (int c = 0; c < NS; ++c) w[c] = src[c];
-        } else {
+        {      // one row per child draw: read from the full-length table in global memory (L2); LDS holds the column table only
           const double* __restrict__ src = p.rowpow + ((size_t)kt * NS + ps) * NS;
 #pragma unroll
           for (int c = 0; c < NS; ++c) w[c] = src[c];
@@ -408,7 +403,7 @@ __device__ __forceinline__ void sweep_body(const McmcParams<NS>& p, int iter0, i
 }
 
 template <int NS, bool KS, bool RING>
-__global__ __launch_bounds__(MCMC_BLOCK, 5) void mcmc_sweep_kernel(McmcParams<NS> p, int iter0, int n_iters) {
+__global__ __launch_bounds__(MCMC_BLOCK, 6) void mcmc_sweep_kernel(McmcParams<NS> p, int iter0, int n_iters) {
   sweep_body<NS, KS, RING>(p, iter0, n_iters);
 }
 
@@ -457,7 +452,7 @@ template <int NS>
 size_t mcmc_lds_bytes(int ktab, bool ks) {
   const size_t ncnt = ks ? NS * NS : NS * (NS - 1);
   // the mask-chain table sits behind a full n x n counter block (kernel carve-up), so ks reserves that much
-  return sizeof(double) * ((size_t)2 * ktab * NS * NS + NS * NS + NS + (size_t)(MCMC_BLOCK / 64) * NS * 64) +
+  return sizeof(double) * ((size_t)ktab * NS * NS + NS * NS + NS + (size_t)(MCMC_BLOCK / 64) * NS * 64) +
          sizeof(uint32_t) * (size_t)(MCMC_BLOCK / 64) * (ks ? NS * NS : ncnt) * 64 +
          (ks ? sizeof(double) * (size_t)ktab * 2 * NS : 0);
 }
