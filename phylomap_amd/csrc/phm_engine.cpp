@@ -9,10 +9,10 @@
 namespace {
 
 // Automatic choice of the mapping (measured on C2, profiles/r01_probe_mapping.log; ms per sweep):
-//   chains                  1     64    256   1024   4096   16384   65536   131072   196608   327680
+//   chains                  1     64    256   1024   4096   16384   65536   131072   196608   327680   393216
 //   lane = branch         0.29   0.41   0.87   2.5    9.4
 //   wave = tile x branch         0.33   0.36   0.50   1.1     3.8    13.7     27.3     39.8   (does not fit)
-//   lane = replica        23.0          24.3   28.4   30.0    29.6    30.8     37.9     44.4     58.5
+//   lane = replica        23.0          24.3   28.4   30.0    29.6    30.8     37.9     44.4     58.5     59.3
 // One lane per branch for a handful of chains; one wave per (tile, branch) as long as its slots fit in HBM; the replica
 // mapping (a single wave per tile, compact sequential streams) for the largest replica counts.
 constexpr int NARROW_AUTO_MAX_REPLICAS = 47;
