@@ -36,17 +36,20 @@ __device__ __forceinline__ void child_vector(const McmcParams<NS>& p, const doub
     int st = p.tips_per_replica ? tips_t[tip * 64 + lane] : p.tips[tip];
     // chains of up to ktab - 1 steps from the LDS copy; longer ones from the full-length table in global memory (L2), whose
     // rows are the same chain run on the host; only beyond that table (never, by construction of klong) is the chain continued
-    int kt = k < p.klong ? k : p.klong - 1;
-    if (kt < p.ktab) {                       // separate branches: an LDS read and a global read, never a generic pointer
-      const double* src = (KS && p.tip_masks) ? s_mask + (kt * 2 + (st & 1)) * NS : s_col + (kt * NS + st) * NS;
+    // The host sizes the full-length table past every count a branch can hold (klong > capacity), so k < klong always;
+    // the clamp only keeps a corrupted count from reading outside the table.
+    const int kt = k < p.klong ? k : p.klong - 1;
+    const int kl = kt < p.ktab ? kt : p.ktab - 1;
+    {                                        // always an LDS read (ds_read); the rare long chain overwrites it from global
+      const double* src = (KS && p.tip_masks) ? s_mask + (kl * 2 + (st & 1)) * NS : s_col + (kl * NS + st) * NS;
 #pragma unroll
       for (int c = 0; c < NS; ++c) v[c] = src[c];
-    } else {
+    }
+    if (kt >= p.ktab) {
       const double* __restrict__ src = (KS && p.tip_masks) ? p.maskpow + ((size_t)kt * 2 + (st & 1)) * NS : p.colpow + ((size_t)kt * NS + st) * NS;
 #pragma unroll
       for (int c = 0; c < NS; ++c) v[c] = src[c];
     }
-    for (int i = kt; i < k; ++i) matvec_u<NS>(p.Bc, v);
   } else {
 #pragma unroll
     for (int c = 0; c < NS; ++c) v[c] = PLt[(child * NS + c) * 64 + lane];
@@ -174,24 +177,12 @@ __device__ __forceinline__ void sweep_body(const McmcParams<NS>& p, int iter0, i
       if (ds.child >= 0 || (KS && p.tip_masks)) {
         // child ~ e_ps^T B^(m-1) (.) PL[child]   (Tvmmp :431-436, :651); ks: tips too, against their mask (:1384-1397)
         double w[NS];
-        int kk = m - 1;
-        int kt = kk < p.klong ? kk : p.klong - 1;
+        const int kk = m - 1;
+        const int kt = kk < p.klong ? kk : p.klong - 1;      // kk < klong by construction (see child_vector)
         {      // one row per child draw: read from the full-length table in global memory (L2); LDS holds the column table only
           const double* __restrict__ src = p.rowpow + ((size_t)kt * NS + ps) * NS;
 #pragma unroll
           for (int c = 0; c < NS; ++c) w[c] = src[c];
-        }
-        for (int i = kt; i < kk; ++i) {           // beyond the table: continue the same chain, w <- B^T w
-          double yv[NS];
-#pragma unroll
-          for (int c = 0; c < NS; ++c) {
-            double acc = p.Bc[c] * w[0];
-#pragma unroll
-            for (int r = 1; r < NS; ++r) acc += p.Bc[r * NS + c] * w[r];
-            yv[c] = acc;
-          }
-#pragma unroll
-          for (int c = 0; c < NS; ++c) w[c] = yv[c];
         }
         uint32_t node_id;
         if (ds.child >= 0) {
@@ -228,19 +219,20 @@ __device__ __forceinline__ void sweep_body(const McmcParams<NS>& p, int iter0, i
 
       // s_i ~ B[s_{i-1},:] (.) B^(m-i-1) e_end          (resamplebranchstates :290, :301-304)
       auto draw_state = [&](int i, int sprev) -> int {
-        int kk = m - i - 1;
+        const int kk = m - i - 1;
         double pr[NS];
-        int kt = kk < p.klong ? kk : p.klong - 1;
-        if (kt < p.ktab) {
-          const double* beta = s_col + (kt * NS + cs) * NS;
+        const int kt = kk < p.klong ? kk : p.klong - 1;
+        const int kl = kt < p.ktab ? kt : p.ktab - 1;
+        {
+          const double* beta = s_col + (kl * NS + cs) * NS;
 #pragma unroll
           for (int c = 0; c < NS; ++c) pr[c] = beta[c];
-        } else {
+        }
+        if (kt >= p.ktab) {
           const double* __restrict__ beta = p.colpow + ((size_t)kt * NS + cs) * NS;
 #pragma unroll
           for (int c = 0; c < NS; ++c) pr[c] = beta[c];
         }
-        for (int q = kt; q < kk; ++q) matvec_u<NS>(p.Bc, pr);
         const double* row = s_B2 + sprev * NS;
 #pragma unroll
         for (int c = 0; c < NS; ++c) pr[c] = row[c] * pr[c];
