@@ -655,6 +655,11 @@ int32_t phm_engine_create_multi(const phm_tree* trees, int32_t n_trees, const ph
     for (int t = 0; t < T; ++t) e->tips_host[t] = (uint8_t)(x->states[t] - 1);
   }
 
+  // The n <= 4 replica kernel addresses a tile's arrays with 32-bit byte offsets from a scalar base (phm_mcmc.hip `at`).
+  if (!e->wide && ((uint64_t)rows * 512u >= (1ull << 32) || (uint64_t)s.n_node * n * 512u >= (1ull << 32) ||
+                   (uint64_t)s.n_edge * 128u >= (1ull << 32)))
+    return fail(PHM_ERR_UNSUPPORTED, "tree too large for the replica layout (a tile's dwell stream or PL rows exceed 4 GB); use mapping=tiles");
+
   std::vector<double> col, row;
   // Full-length chain tables in global memory: the LDS copies of the replica kernels hold MCMC_KTAB rows, a longer chain
   // reads row k of these instead of being continued step by step (which made a draw on an m-segment branch cost O(m)).

@@ -23,6 +23,17 @@
 
 namespace phm {
 
+// Per-tile arrays are addressed as a wave-uniform base (scalar registers) plus a 32-bit byte offset: one address register
+// per access instead of a 64-bit vector address computed for each (the host keeps every per-tile array below 4 GB).
+template <class T>
+__device__ __forceinline__ T& at(T* base, uint32_t byte_off) {
+  return *reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(base) + byte_off);
+}
+template <class T>
+__device__ __forceinline__ const T& at(const T* base, uint32_t byte_off) {
+  return *reinterpret_cast<const T*>(reinterpret_cast<const unsigned char*>(base) + byte_off);
+}
+
 // B^k applied to a child's partial-likelihood vector (mmmmvFORpl, src/phylomap.cpp:446-450)
 template <int NS, bool KS>
 __device__ __forceinline__ void child_vector(const McmcParams<NS>& p, const double* __restrict__ s_col,
@@ -33,7 +44,7 @@ __device__ __forceinline__ void child_vector(const McmcParams<NS>& p, const doub
     // tip: the chain started from the tip's PL row is a table entry (bit-identical to running it):
     // one-hot row -> column `state` of B^k; ks: parity mask row (:1838-1845) -> B^k applied to that mask
     int tip = ~child;
-    int st = p.tips_per_replica ? tips_t[tip * 64 + lane] : p.tips[tip];
+    int st = p.tips_per_replica ? at(tips_t, (uint32_t)tip * 64u + (uint32_t)lane) : p.tips[tip];
     // chains of up to ktab - 1 steps from the LDS copy; longer ones from the full-length table in global memory (L2), whose
     // rows are the same chain run on the host; only beyond that table (never, by construction of klong) is the chain continued
     // The host sizes the full-length table past every count a branch can hold (klong > capacity), so k < klong always;
@@ -52,7 +63,7 @@ __device__ __forceinline__ void child_vector(const McmcParams<NS>& p, const doub
     }
   } else {
 #pragma unroll
-    for (int c = 0; c < NS; ++c) v[c] = PLt[(child * NS + c) * 64 + lane];
+    for (int c = 0; c < NS; ++c) v[c] = at(PLt, (uint32_t)(child * NS + c) * 512u + (uint32_t)lane * 8u);
     for (int i = 0; i < k; ++i) matvec_u<NS>(p.Bc, v);
   }
 }
@@ -68,8 +79,9 @@ template <int NS, bool KS, bool RING, bool MT = false>
 __device__ __forceinline__ void sweep_body(const McmcParams<NS>& p, int iter0, int n_iters) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: per-tile bases live in scalar registers
   const int tile = blockIdx.x * (MCMC_BLOCK / 64) + wave;
+  const uint32_t lane8 = (uint32_t)lane * 8u;
   constexpr int NCNT = KS ? NS * NS : NS * (NS - 1);
 
   // ---- LDS carve-up: tables shared by the workgroup, accumulators private to each lane ----
@@ -119,12 +131,12 @@ __device__ __forceinline__ void sweep_body(const McmcParams<NS>& p, int iter0, i
     auto IN = [&](int k) -> double& {
       int idx = k;
       if (RING) { idx = rbase + k; idx = idx >= C ? idx - C : idx; }
-      return buf_in[idx * 64 + lane];
+      return at(buf_in, (uint32_t)idx * 512u + lane8);
     };
     auto OUT = [&](int k) -> double& {
       int idx = k;
       if (RING) { idx = wbase + k; idx = idx >= C ? idx - C : idx; }
-      return buf_out[idx * 64 + lane];
+      return at(buf_out, (uint32_t)idx * 512u + lane8);
     };
 #pragma unroll
     for (int c = 0; c < NS; ++c) s_dw[c * 64 + lane] = 0.0;
@@ -137,8 +149,8 @@ __device__ __forceinline__ void sweep_body(const McmcParams<NS>& p, int iter0, i
     for (int k = 0; k < p.n_node; ++k) {
       const UpStep st = up[k];
       double x[NS], y[NS];
-      int ma = mct[st.edge[0] * 64 + lane];
-      int mb = mct[st.edge[1] * 64 + lane];
+      int ma = at(mct, (uint32_t)st.edge[0] * 128u + (uint32_t)lane * 2u);
+      int mb = at(mct, (uint32_t)st.edge[1] * 128u + (uint32_t)lane * 2u);
       child_vector<NS, KS>(p, s_col, s_mask, PLt, tips_t, st.child[1], mb - 1, lane, x);   // "first"  (:508)
       child_vector<NS, KS>(p, s_col, s_mask, PLt, tips_t, st.child[0], ma - 1, lane, y);   // "second" (:509)
 #pragma unroll
@@ -151,7 +163,7 @@ __device__ __forceinline__ void sweep_body(const McmcParams<NS>& p, int iter0, i
         for (int c = 0; c < NS; ++c) x[c] = x[c] / s;
       }
 #pragma unroll
-      for (int c = 0; c < NS; ++c) PLt[(st.parent * NS + c) * 64 + lane] = x[c];
+      for (int c = 0; c < NS; ++c) at(PLt, (uint32_t)(st.parent * NS + c) * 512u + (uint32_t)lane * 8u) = x[c];
     }
 
     if (p.prune_only) continue;      // wave-uniform: the pruning sweep alone (bench.py "pruning" roofline)
@@ -161,18 +173,18 @@ __device__ __forceinline__ void sweep_body(const McmcParams<NS>& p, int iter0, i
     {
       double pr[NS];
 #pragma unroll
-      for (int c = 0; c < NS; ++c) pr[c] = p.pid[c] * PLt[(root * NS + c) * 64 + lane];   // :618
+      for (int c = 0; c < NS; ++c) pr[c] = p.pid[c] * at(PLt, (uint32_t)(root * NS + c) * 512u + (uint32_t)lane * 8u);   // :618
       double u = stream_u(p.seed_lo, p.seed_hi, rep, (uint32_t)it, ENT_NODE | (uint32_t)(root + p.n_tips), 0);
       my_root = sample_cat<NS>(pr, u, err);                                                 // :627
-      nst[root * 64 + lane] = (uint8_t)my_root;
+      at(nst, (uint32_t)root * 64u + (uint32_t)lane) = (uint8_t)my_root;
     }
 
     // ------------------------------ down sweep: node states + branch paths ------------------------------
     for (int k = 0; k < p.n_edge; ++k) {
       const DownStep ds = down[k];
       const int b = ds.edge;
-      const int m = mct[b * 64 + lane];
-      const int ps = nst[ds.parent * 64 + lane];
+      const int m = at(mct, (uint32_t)b * 128u + (uint32_t)lane * 2u);
+      const int ps = at(nst, (uint32_t)ds.parent * 64u + (uint32_t)lane);
       int cs;
       if (ds.child >= 0 || (KS && p.tip_masks)) {
         // child ~ e_ps^T B^(m-1) (.) PL[child]   (Tvmmp :431-436, :651); ks: tips too, against their mask (:1384-1397)
@@ -187,21 +199,21 @@ __device__ __forceinline__ void sweep_body(const McmcParams<NS>& p, int iter0, i
         uint32_t node_id;
         if (ds.child >= 0) {
 #pragma unroll
-          for (int c = 0; c < NS; ++c) w[c] = w[c] * PLt[(ds.child * NS + c) * 64 + lane];
+          for (int c = 0; c < NS; ++c) w[c] = w[c] * at(PLt, (uint32_t)(ds.child * NS + c) * 512u + (uint32_t)lane * 8u);
           node_id = (uint32_t)(ds.child + p.n_tips);
         } else {
           int tip = ~ds.child;
-          int par = (p.tips_per_replica ? tips_t[tip * 64 + lane] : p.tips[tip]) & 1;
+          int par = (p.tips_per_replica ? at(tips_t, (uint32_t)tip * 64u + (uint32_t)lane) : p.tips[tip]) & 1;
 #pragma unroll
           for (int c = 0; c < NS; ++c) w[c] = w[c] * (((c & 1) == par) ? 1.0 : 0.0);
           node_id = (uint32_t)tip;
         }
         double u = stream_u(p.seed_lo, p.seed_hi, rep, (uint32_t)it, ENT_NODE | node_id, 0);
         cs = sample_cat<NS>(w, u, err);                                        // :655
-        if (ds.child >= 0) nst[ds.child * 64 + lane] = (uint8_t)cs;
+        if (ds.child >= 0) at(nst, (uint32_t)ds.child * 64u + (uint32_t)lane) = (uint8_t)cs;
       } else {
         int tip = ~ds.child;
-        cs = p.tips_per_replica ? tips_t[tip * 64 + lane] : p.tips[tip];        // :612
+        cs = p.tips_per_replica ? at(tips_t, (uint32_t)tip * 64u + (uint32_t)lane) : p.tips[tip];        // :612
       }
 
       // ---- branch path: resample states, merge, count, re-insert virtual jumps ----
@@ -351,7 +363,7 @@ __device__ __forceinline__ void sweep_body(const McmcParams<NS>& p, int iter0, i
         }
       }
       if (mnew > 65535) { err |= DERR_CAPACITY; mnew = 65535; }
-      mct[b * 64 + lane] = (uint16_t)mnew;
+      at(mct, (uint32_t)b * 128u + (uint32_t)lane * 2u) = (uint16_t)mnew;
       seg_rw += (uint32_t)(m + mnew);
       in_row += mmax;
       out_row += wave_max_count(mnew);
