@@ -87,14 +87,15 @@ __device__ __forceinline__ double stream_u(uint32_t seed_lo, uint32_t seed_hi, u
 // (tools/gen_log_table.py, tests/test_oracle_cpu.py); 40 operations instead of the 65 of a general log.  `tab` holds the
 // PHM_LOGTAB_N pairs (1/c_j, log c_j); the oracle and the Python restatement evaluate the same expression on the same table.
 __device__ __forceinline__ double neglog_u32(uint32_t k, const double* __restrict__ tab) {
-  const double y = (double)k * 2.0 + 1.0;
+  const double y = __builtin_fma((double)k, 2.0, 1.0);            // 2k + 1 < 2^33: exact, fused or not
   int e;
   const double f = frexp(y, &e);
   const bool top = (e == 33) && (f >= 0.99609375);
-  const int j = (int)((f - 0.5) * 256.0);
-  const double c = 0.501953125 + (double)j * 0.00390625;
-  const double r = top ? f - 1.0 : (f - c) * tab[2 * j];
-  const double c0 = top ? 0.0 : tab[2 * j + 1];
+  const int j = (int)((f - 0.5) * 256.0);                         // 0 .. 127 for every f in [0.5, 1)
+  const double c = __builtin_fma((double)j, 0.00390625, 0.501953125);   // (2j + 257)/512: exact
+  const double2 t = *reinterpret_cast<const double2*>(tab + 2 * j);     // one 16-byte read, no branch around it (tab 16-byte aligned)
+  const double r = top ? f - 1.0 : (f - c) * t.x;
+  const double c0 = top ? 0.0 : t.y;
   const double ee = top ? 0.0 : (double)(e - 33);
   double p = 1.0 / 7.0;
   p = p * r - 1.0 / 6.0;

@@ -93,7 +93,7 @@ __device__ __forceinline__ void sweep_body(const McmcParams<NS>& p, int iter0, i
                     (size_t)wave * NCNT * 64;                 // [NCNT][64] transition counters of this wave
   double* s_mask = reinterpret_cast<double*>(reinterpret_cast<uint32_t*>(s_scale + NS + (size_t)(MCMC_BLOCK / 64) * NS * 64) +
                                              (size_t)(MCMC_BLOCK / 64) * NS * NS * 64);   // [ktab][2][NS] (ks only)
-  __shared__ double s_ltab[2 * PHM_LOGTAB_N];                 // (1/c_j, log c_j) of the exponential variates (neglog_u32)
+  __shared__ __align__(16) double s_ltab[2 * PHM_LOGTAB_N];                 // (1/c_j, log c_j) of the exponential variates (neglog_u32)
   for (int i = threadIdx.x; i < 2 * PHM_LOGTAB_N; i += MCMC_BLOCK) s_ltab[i] = logtab_entry(i);
   for (int i = threadIdx.x; i < p.ktab * NS * NS; i += MCMC_BLOCK) s_col[i] = p.colpow[i];
   if (KS && p.tip_masks) for (int i = threadIdx.x; i < p.ktab * 2 * NS; i += MCMC_BLOCK) s_mask[i] = p.maskpow[i];
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(MCMC_BLOCK, 5) void mcmc_sweep_trees_kernel(McmcPar
 
 // The pruning (up) sweep alone, under its own name so that profiles separate it from the full sweep (p.prune_only = 1).
 template <int NS, bool KS, bool RING>
-__global__ __launch_bounds__(MCMC_BLOCK, 5) void mcmc_pruning_kernel(McmcParams<NS> p, int iter0, int n_iters) {
+__global__ __launch_bounds__(MCMC_BLOCK, 6) void mcmc_pruning_kernel(McmcParams<NS> p, int iter0, int n_iters) {
   sweep_body<NS, KS, RING>(p, iter0, n_iters);
 }
 

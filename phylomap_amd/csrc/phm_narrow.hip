@@ -146,7 +146,7 @@ template <int NS>
 __global__ __launch_bounds__(NARROW_BLOCK) void narrow_branch_kernel(NarrowParams<NS> p, int it) {
   __shared__ double s_dw[NS * NARROW_BLOCK];
   __shared__ uint32_t s_cnt[NS * NS * NARROW_BLOCK];
-  __shared__ double s_ltab[2 * PHM_LOGTAB_N];        // (1/c_j, log c_j) of the exponential variates (neglog_u32)
+  __shared__ __align__(16) double s_ltab[2 * PHM_LOGTAB_N];        // (1/c_j, log c_j) of the exponential variates (neglog_u32)
   const int lane = threadIdx.x;
   const int idx = blockIdx.x * NARROW_BLOCK + lane;
   const int r = blockIdx.y;

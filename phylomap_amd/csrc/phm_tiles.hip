@@ -126,7 +126,7 @@ __global__ __launch_bounds__(TILES_BLOCK) void tiles_branch_kernel(TileParams<NS
   __shared__ uint32_t s_cnt_all[(TILES_BLOCK / 64) * NCNT * 64];
   __shared__ double s_B2[NS * NS], s_scale[NS];      // indexed by a per-lane state: LDS, not the kernarg segment
   __shared__ double s_col[TILES_KTAB * NS * NS];     // B^k e_j for the short chains (most draws); longer ones go to L2
-  __shared__ double s_ltab[2 * PHM_LOGTAB_N];        // (1/c_j, log c_j) of the exponential variates (neglog_u32)
+  __shared__ __align__(16) double s_ltab[2 * PHM_LOGTAB_N];        // (1/c_j, log c_j) of the exponential variates (neglog_u32)
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int item = blockIdx.x * (TILES_BLOCK / 64) + wave;

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(WB_BLOCK) void wb_down_kernel(WideBranchParams p, i
 // sampleabranch :391-410, dwell sums updatedwelltimes :745-757.
 __global__ __launch_bounds__(WB_BLOCK) void wb_branch_kernel(WideBranchParams p, int it) {
   extern __shared__ __align__(16) unsigned char smem[];
-  __shared__ double s_ltab[2 * PHM_LOGTAB_N];        // (1/c_j, log c_j) of the exponential variates (neglog_u32)
+  __shared__ __align__(16) double s_ltab[2 * PHM_LOGTAB_N];        // (1/c_j, log c_j) of the exponential variates (neglog_u32)
   for (int i = threadIdx.x; i < 2 * PHM_LOGTAB_N; i += WB_BLOCK) s_ltab[i] = logtab_entry(i);
   const Lds l = stage_model(p, smem);
   const int n = p.n_states, lane = threadIdx.x & 63;
