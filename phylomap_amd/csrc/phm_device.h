@@ -48,6 +48,17 @@ __device__ __forceinline__ double u01(uint32_t x) {
   return ((double)x + 0.5) * 2.3283064365386962890625e-10;
 }
 
+// Per-tile arrays are addressed as a wave-uniform base (scalar registers) plus a 32-bit byte offset: one address register
+// per access instead of a 64-bit vector address computed for each (the host keeps every array addressed this way below 4 GB).
+template <class T>
+__device__ __forceinline__ T& at(T* base, uint32_t byte_off) {
+  return *reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(base) + byte_off);
+}
+template <class T>
+__device__ __forceinline__ const T& at(const T* base, uint32_t byte_off) {
+  return *reinterpret_cast<const T*>(reinterpret_cast<const unsigned char*>(base) + byte_off);
+}
+
 // Sequential draws of one stream (replica, iteration, entity): draw d is word d & 3 of Philox block d >> 2.
 struct Stream {
   uint32_t ent, iter, rep, k0, k1;

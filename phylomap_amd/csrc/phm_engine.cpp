@@ -9,13 +9,13 @@
 namespace {
 
 // Automatic choice of the mapping (measured on C2, profiles/r01_probe_mapping.log; ms per sweep):
-//   chains                  1     64    256   1024   4096   16384   65536   131072   196608   327680   393216
-//   lane = branch         0.29   0.41   0.87   2.5    9.4
-//   wave = tile x branch         0.33   0.36   0.50   1.1     3.8    13.7     27.3     39.8   (does not fit)
-//   lane = replica        23.0          24.3   28.4   30.0    29.6    30.8     37.9     44.4     58.5     59.3
+//   chains                  1     32     64    256   1024   4096   16384   65536   131072   196608   327680   393216
+//   lane = branch         0.25   0.33   0.46   1.5    5.9    24
+//   wave = tile x branch         0.31   0.31   0.35   0.47   1.0     3.3    12.7     25.0   (does not fit)
+//   lane = replica        19.6                 22.2   26.3   27.6    27.3    28.6     34.5     41.0     49.2     54.7
 // One lane per branch for a handful of chains; one wave per (tile, branch) as long as its slots fit in HBM; the replica
 // mapping (a single wave per tile, compact sequential streams) for the largest replica counts.
-constexpr int NARROW_AUTO_MAX_REPLICAS = 47;
+constexpr int NARROW_AUTO_MAX_REPLICAS = 24;
 constexpr int TILES_AUTO_MAX_REPLICAS = 262144;
 
 bool ks_layout(int v) { return v == PHM_MCMC_KS || v == PHM_MCMC_BF || v == PHM_MCMC_MT || v == PHM_MCMC_KSMT; }   // n x n counts, root column
@@ -358,6 +358,7 @@ int32_t tiles_setup(phm_engine* e, const phm_tree* x, const phm_model* model, co
     const int m0 = x->map_off[b + 1] - x->map_off[b];
     const int q = phm::poisson_capacity(model->Omega * tb, tail);
     cap[b] = std::max(q, m0 + q - 1) + 2;
+    if (cap[b] >= (1 << 23)) return fail(PHM_ERR_UNSUPPORTED, "branch too long: a slot of the (tile, branch) mapping exceeds 4 GB");   // 32-bit offsets, phm_tiles.hip
     max_cap = std::max(max_cap, cap[b]);
     rows += cap[b];
     if (rows > 0x7fffff00ll / 64) return fail(PHM_ERR_UNSUPPORTED, "tree too large: dwell rows per replica tile exceed 32-bit indexing");

@@ -23,17 +23,6 @@
 
 namespace phm {
 
-// Per-tile arrays are addressed as a wave-uniform base (scalar registers) plus a 32-bit byte offset: one address register
-// per access instead of a 64-bit vector address computed for each (the host keeps every per-tile array below 4 GB).
-template <class T>
-__device__ __forceinline__ T& at(T* base, uint32_t byte_off) {
-  return *reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(base) + byte_off);
-}
-template <class T>
-__device__ __forceinline__ const T& at(const T* base, uint32_t byte_off) {
-  return *reinterpret_cast<const T*>(reinterpret_cast<const unsigned char*>(base) + byte_off);
-}
-
 // B^k applied to a child's partial-likelihood vector (mmmmvFORpl, src/phylomap.cpp:446-450)
 template <int NS, bool KS>
 __device__ __forceinline__ void child_vector(const McmcParams<NS>& p, const double* __restrict__ s_col,

@@ -128,8 +128,9 @@ __global__ __launch_bounds__(TILES_BLOCK) void tiles_branch_kernel(TileParams<NS
   __shared__ double s_col[TILES_KTAB * NS * NS];     // B^k e_j for the short chains (most draws); longer ones go to L2
   __shared__ __align__(16) double s_ltab[2 * PHM_LOGTAB_N];        // (1/c_j, log c_j) of the exponential variates (neglog_u32)
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: slot bases live in scalar registers
   const int item = blockIdx.x * (TILES_BLOCK / 64) + wave;
+  const uint32_t lane8 = (uint32_t)lane * 8u;
   const int ktab = min(TILES_KTAB, p.klong);
   for (int i = threadIdx.x; i < ktab * NS * NS; i += TILES_BLOCK) s_col[i] = p.colL[i];
   for (int i = threadIdx.x; i < 2 * PHM_LOGTAB_N; i += TILES_BLOCK) s_ltab[i] = logtab_entry(i);
@@ -149,9 +150,10 @@ __global__ __launch_bounds__(TILES_BLOCK) void tiles_branch_kernel(TileParams<NS
   const int ps = es & 15, cs = es >> 4;
   const int roff = p.slot[b];
   const int cap = p.slot[b + 1] - roff;
-  double* __restrict__ in = p.dw[it & 1] + ((size_t)tile * p.rows + roff) * 64 + lane;
-  double* __restrict__ out = p.dw[(it & 1) ^ 1] + ((size_t)tile * p.rows + roff) * 64 + lane;
-  auto IN = [&](int k) -> double& { return in[(size_t)k * 64]; };
+  // the slot of this (tile, branch): scalar base + 32-bit byte offset (a slot holds at most 65 535 rows of 512 B)
+  double* __restrict__ in = p.dw[it & 1] + ((size_t)tile * p.rows + roff) * 64;
+  double* __restrict__ out = p.dw[(it & 1) ^ 1] + ((size_t)tile * p.rows + roff) * 64;
+  auto IN = [&](int k) -> double& { return at(in, (uint32_t)k * 512u + lane8); };
   uint32_t err = 0;
 #pragma unroll
   for (int c = 0; c < NS; ++c) s_dw[c * 64 + lane] = 0.0;
@@ -169,12 +171,13 @@ __global__ __launch_bounds__(TILES_BLOCK) void tiles_branch_kernel(TileParams<NS
     int kk = m - i - 1;
     if (kk >= p.klong) { err |= DERR_CAPACITY; kk = p.klong - 1; }
     double pr[NS];
-    if (kk < ktab) {
-      const double* beta = s_col + (kk * NS + cs) * NS;
+    {                                          // always an LDS read (ds_read); the rare long chain overwrites it from global
+      const double* beta = s_col + ((kk < ktab ? kk : ktab - 1) * NS + cs) * NS;
 #pragma unroll
       for (int c = 0; c < NS; ++c) pr[c] = beta[c];
-    } else {
-      const double* beta = p.colL + ((size_t)kk * NS + cs) * NS;
+    }
+    if (kk >= ktab) {
+      const double* __restrict__ beta = p.colL + ((size_t)kk * NS + cs) * NS;
 #pragma unroll
       for (int c = 0; c < NS; ++c) pr[c] = beta[c];
     }
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(TILES_BLOCK) void tiles_branch_kernel(TileParams<NS
         if ((tot + rl) < len) { piece = rl; tot += rl; adv = false; }
         else { piece = len - tot; adv = true; }
       }
-      if (mnew < cap) out[(size_t)mnew * 64] = piece; else err |= DERR_CAPACITY;
+      if (mnew < cap) at(out, (uint32_t)mnew * 512u + lane8) = piece; else err |= DERR_CAPACITY;
       acc += piece;                                                        // updatedwelltimes :752
       ++mnew;
       if (adv) {
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(TILES_BLOCK) void tiles_branch_kernel(TileParams<NS
     auto finalize = [&](int s, double len) {
       if (stuck || !(0.0 < len)) {
         stuck = true;
-        if (mnew < cap) out[(size_t)mnew * 64] = len; else err |= DERR_CAPACITY;
+        if (mnew < cap) at(out, (uint32_t)mnew * 512u + lane8) = len; else err |= DERR_CAPACITY;
         s_dw[s * 64 + lane] += len;
         ++mnew;
         return;
@@ -263,7 +266,7 @@ __global__ __launch_bounds__(TILES_BLOCK) void tiles_branch_kernel(TileParams<NS
         double piece;
         if ((tot + rl) < len) { piece = rl; tot += rl; }
         else { piece = len - tot; tot = len; }
-        if (mnew < cap) out[(size_t)mnew * 64] = piece; else err |= DERR_CAPACITY;
+        if (mnew < cap) at(out, (uint32_t)mnew * 512u + lane8) = piece; else err |= DERR_CAPACITY;
         acc += piece;
         ++mnew;
       }
