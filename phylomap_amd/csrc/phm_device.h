@@ -180,12 +180,14 @@ __device__ __forceinline__ int sample_cat(const double (&p)[NS], double u, uint3
 #pragma unroll
   for (int j = 1; j < NS; ++j) total += p[j];
   if (!(total > 0.0) || isinf(total)) err |= DERR_ZERO_PROB;
+  // first j with u * total <= p_0 + .. + p_j.  u < 1, so the threshold never exceeds the last partial sum (= total) and the
+  // last comparison is always true; NS - 1 comparisons give the same index (and NS - 1 for a NaN total, flagged above).
   double thr = u * total;
   double cum = p[0];
   int idx = (thr <= cum) ? 0 : 1;
 #pragma unroll
-  for (int j = 1; j < NS; ++j) { cum += p[j]; idx += (thr <= cum) ? 0 : 1; }
-  return idx < NS ? idx : NS - 1;
+  for (int j = 1; j < NS - 1; ++j) { cum += p[j]; idx += (thr <= cum) ? 0 : 1; }
+  return idx;
 }
 
 template <int NS>

@@ -36,16 +36,16 @@ __device__ __forceinline__ void child_vector(const McmcParams<NS>& p, const doub
     int st = p.tips_per_replica ? at(tips_t, (uint32_t)tip * 64u + (uint32_t)lane) : p.tips[tip];
     // chains of up to ktab - 1 steps from the LDS copy; longer ones from the full-length table in global memory (L2), whose
     // rows are the same chain run on the host; only beyond that table (never, by construction of klong) is the chain continued
-    // The host sizes the full-length table past every count a branch can hold (klong > capacity), so k < klong always;
-    // the clamp only keeps a corrupted count from reading outside the table.
-    const int kt = k < p.klong ? k : p.klong - 1;
-    const int kl = kt < p.ktab ? kt : p.ktab - 1;
+    // The host sizes the full-length table past every count a branch can hold (klong > capacity) and the sweep never stores
+    // a count above the capacity, so k < klong always.
+    const int kt = k;
+    const int kl = kt < MCMC_KTAB ? kt : MCMC_KTAB - 1;
     {                                        // always an LDS read (ds_read); the rare long chain overwrites it from global
       const double* src = (KS && p.tip_masks) ? s_mask + (kl * 2 + (st & 1)) * NS : s_col + (kl * NS + st) * NS;
 #pragma unroll
       for (int c = 0; c < NS; ++c) v[c] = src[c];
     }
-    if (kt >= p.ktab) {
+    if (kt >= MCMC_KTAB) {
       const double* __restrict__ src = (KS && p.tip_masks) ? p.maskpow + ((size_t)kt * 2 + (st & 1)) * NS : p.colpow + ((size_t)kt * NS + st) * NS;
 #pragma unroll
       for (int c = 0; c < NS; ++c) v[c] = src[c];
@@ -75,7 +75,7 @@ __device__ __forceinline__ void sweep_body(const McmcParams<NS>& p, int iter0, i
 
   // ---- LDS carve-up: tables shared by the workgroup, accumulators private to each lane ----
   double* s_col = reinterpret_cast<double*>(smem);            // [ktab][NS][NS]  B^k e_j      (column chains)
-  double* s_B2 = s_col + p.ktab * NS * NS;                    // [NS][NS] dense B, rows for the forward step
+  double* s_B2 = s_col + MCMC_KTAB * NS * NS;                    // [NS][NS] dense B, rows for the forward step
   double* s_scale = s_B2 + NS * NS;                           // [NS] 1/(Omega+q_ss)
   double* s_dw = s_scale + NS + (size_t)wave * NS * 64;       // [NS][64] dwell accumulators of this wave
   uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_scale + NS + (size_t)(MCMC_BLOCK / 64) * NS * 64) +
@@ -84,8 +84,8 @@ __device__ __forceinline__ void sweep_body(const McmcParams<NS>& p, int iter0, i
                                              (size_t)(MCMC_BLOCK / 64) * NS * NS * 64);   // [ktab][2][NS] (ks only)
   __shared__ __align__(16) double s_ltab[2 * PHM_LOGTAB_N];                 // (1/c_j, log c_j) of the exponential variates (neglog_u32)
   for (int i = threadIdx.x; i < 2 * PHM_LOGTAB_N; i += MCMC_BLOCK) s_ltab[i] = logtab_entry(i);
-  for (int i = threadIdx.x; i < p.ktab * NS * NS; i += MCMC_BLOCK) s_col[i] = p.colpow[i];
-  if (KS && p.tip_masks) for (int i = threadIdx.x; i < p.ktab * 2 * NS; i += MCMC_BLOCK) s_mask[i] = p.maskpow[i];
+  for (int i = threadIdx.x; i < MCMC_KTAB * NS * NS; i += MCMC_BLOCK) s_col[i] = p.colpow[i];      // the host passes ktab = MCMC_KTAB
+  if (KS && p.tip_masks) for (int i = threadIdx.x; i < MCMC_KTAB * 2 * NS; i += MCMC_BLOCK) s_mask[i] = p.maskpow[i];
   if (threadIdx.x < NS * NS) s_B2[threadIdx.x] = p.B2[threadIdx.x];
   if (threadIdx.x < NS) s_scale[threadIdx.x] = p.scale[threadIdx.x];
   __syncthreads();
@@ -179,7 +179,7 @@ __device__ __forceinline__ void sweep_body(const McmcParams<NS>& p, int iter0, i
         // child ~ e_ps^T B^(m-1) (.) PL[child]   (Tvmmp :431-436, :651); ks: tips too, against their mask (:1384-1397)
         double w[NS];
         const int kk = m - 1;
-        const int kt = kk < p.klong ? kk : p.klong - 1;      // kk < klong by construction (see child_vector)
+        const int kt = kk;                                   // kk < klong by construction (see child_vector)
         {      // one row per child draw: read from the full-length table in global memory (L2); LDS holds the column table only
           const double* __restrict__ src = p.rowpow + ((size_t)kt * NS + ps) * NS;
 #pragma unroll
@@ -222,14 +222,14 @@ __device__ __forceinline__ void sweep_body(const McmcParams<NS>& p, int iter0, i
       auto draw_state = [&](int i, int sprev) -> int {
         const int kk = m - i - 1;
         double pr[NS];
-        const int kt = kk < p.klong ? kk : p.klong - 1;
-        const int kl = kt < p.ktab ? kt : p.ktab - 1;
+        const int kt = kk;
+        const int kl = kt < MCMC_KTAB ? kt : MCMC_KTAB - 1;
         {
           const double* beta = s_col + (kl * NS + cs) * NS;
 #pragma unroll
           for (int c = 0; c < NS; ++c) pr[c] = beta[c];
         }
-        if (kt >= p.ktab) {
+        if (kt >= MCMC_KTAB) {
           const double* __restrict__ beta = p.colpow + ((size_t)kt * NS + cs) * NS;
 #pragma unroll
           for (int c = 0; c < NS; ++c) pr[c] = beta[c];
@@ -352,6 +352,7 @@ __device__ __forceinline__ void sweep_body(const McmcParams<NS>& p, int iter0, i
         }
       }
       if (mnew > 65535) { err |= DERR_CAPACITY; mnew = 65535; }
+      if (mnew > cap) mnew = cap > 1 ? cap : 1;      // after a capacity error: keep the stored count inside the stream (and the chain tables)
       at(mct, (uint32_t)b * 128u + (uint32_t)lane * 2u) = (uint16_t)mnew;
       seg_rw += (uint32_t)(m + mnew);
       in_row += mmax;
@@ -454,6 +455,7 @@ template <int NS>
 hipError_t launch_mcmc(const McmcParams<NS>& p, int iter0, int n_iters, hipStream_t stream) {
   const int waves_per_block = MCMC_BLOCK / 64;
   dim3 grid((p.n_tiles + waves_per_block - 1) / waves_per_block);
+  if (p.ktab != MCMC_KTAB || p.klong < MCMC_KTAB) return hipErrorInvalidValue;      // the kernels carve LDS for MCMC_KTAB rows
   size_t lds = mcmc_lds_bytes<NS>(p.ktab, p.ks != 0);
   const bool ring = p.dwell1 == nullptr;
   if (p.tiles_per_tree) {
