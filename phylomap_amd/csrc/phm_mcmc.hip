@@ -219,7 +219,7 @@ __device__ __forceinline__ void sweep_body(const McmcParams<NS>& p, int iter0, i
       int mnew = 0;                              // pieces emitted = new segment count
 
       // s_i ~ B[s_{i-1},:] (.) B^(m-i-1) e_end          (resamplebranchstates :290, :301-304)
-      auto draw_state = [&](int i, int sprev) -> int {
+      auto draw_state_w = [&](int i, int sprev, uint32_t word) -> int {
         const int kk = m - i - 1;
         double pr[NS];
         const int kt = kk;
@@ -237,8 +237,9 @@ __device__ __forceinline__ void sweep_body(const McmcParams<NS>& p, int iter0, i
         const double* row = s_B2 + sprev * NS;
 #pragma unroll
         for (int c = 0; c < NS; ++c) pr[c] = row[c] * pr[c];
-        return sample_cat<NS>(pr, su.draw((uint32_t)(i - 1)), err);
+        return sample_cat<NS>(pr, u01(word), err);
       };
+      auto draw_state = [&](int i, int sprev) -> int { return draw_state_w(i, sprev, su.draw_word((uint32_t)(i - 1))); };
 
       if (mmax <= 64 && NS <= 4) {
         // Two flat passes, so that a wave pays max-over-lanes ONCE per pass instead of once per nesting level.
@@ -249,9 +250,17 @@ __device__ __forceinline__ void sweep_body(const McmcParams<NS>& p, int iter0, i
         int cur_s = (m == 1) ? cs : ps;            // updatenodestates :469-472 (m==1: child wins)
         double cur_len = IN(roff);
         double dnext = (m > 1) ? IN(roff + 1) : 0.0;
-        for (int i = 1; i < mmax; ++i) {
+        // Four steps per Philox block of the state stream: the step index is wave-uniform here, so the block is computed
+        // once per group by every lane and draw i - 1 is a fixed word of it (no per-step block test or word select).
+        for (int i0 = 1; i0 < mmax; i0 += 4) {
+          uint32_t wd[4] = {0u, 0u, 0u, 0u};
+          if (i0 < mmax - 1)                       // some lane still draws in this group (draws exist for i < m - 1)
+            philox4x32_10((uint32_t)((i0 - 1) >> 2), ENT_BSTATE | (uint32_t)b, (uint32_t)it, rep, p.seed_lo, p.seed_hi, wd);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+          const int i = i0 + q;
           if (i < m) {
-            int si = (i == m - 1) ? cs : draw_state(i, cur_s);
+            int si = (i == m - 1) ? cs : draw_state_w(i, cur_s, wd[q]);
             double di = dnext;
             if (i + 1 < m) dnext = IN(roff + i + 1);
             if (KS) s_cnt[(cur_s * NS + si) * 64 + lane] += 1u;               // shortenerbf :1010-1014
@@ -265,6 +274,7 @@ __device__ __forceinline__ void sweep_body(const McmcParams<NS>& p, int iter0, i
               }
               ++w; cur_s = si; cur_len = di;
             }
+          }
           }
         }
         if (w < 32) pk0 |= (uint64_t)cur_s << (2 * w); else pk1 |= (uint64_t)cur_s << (2 * (w - 32));
