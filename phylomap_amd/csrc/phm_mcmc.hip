@@ -288,29 +288,37 @@ __device__ __forceinline__ void sweep_body(const McmcParams<NS>& p, int iter0, i
         double len = len0;
         double lnext = (nmerged > 1) ? ((w == 1) ? cur_len : IN(roff + 1)) : 0.0;
         double tot = 0.0, scale = s_scale[s], acc = s_dw[s * 64 + lane];
-        uint32_t edraw = 0;
         bool stuck = false, done = false;
-        while (!done) {
-          double piece;
-          bool adv;
-          if (stuck || !(0.0 < len)) { stuck = true; piece = len; adv = true; }
-          else {
-            double rl = scale * neglog_u32(se.draw_word(edraw++), s_ltab);        // :398
-            if ((tot + rl) < len) { piece = rl; tot += rl; adv = false; }
-            else { piece = len - tot; adv = true; }
-          }
-          if (mnew < cap) OUT(woff + mnew) = piece; else err |= DERR_CAPACITY;
-          acc += piece;                                                        // updatedwelltimes :752
-          ++mnew;
-          if (adv) {
-            s_dw[s * 64 + lane] = acc;
-            ++j;
-            if (j >= nmerged) done = true;
+        // Four steps per Philox block of the exponential stream.  A lane emits one piece per step and draws one variate for
+        // it until it meets a zero-length segment, after which it draws no more on this branch (`stuck`): its draw counter
+        // equals the step index whenever it draws, so draw t0 + q is word q of the group's block.
+        for (uint32_t t0 = 0; __any(!done); t0 += 4) {
+          uint32_t wd[4];
+          philox4x32_10(t0 >> 2, ENT_BEXP | (uint32_t)b, (uint32_t)it, rep, p.seed_lo, p.seed_hi, wd);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (done) continue;
+            double piece;
+            bool adv;
+            if (stuck || !(0.0 < len)) { stuck = true; piece = len; adv = true; }
             else {
-              len = lnext;
-              if (j + 1 < nmerged) lnext = IN(roff + j + 1);
-              s = (int)(((j < 32) ? (pk0 >> (2 * j)) : (pk1 >> (2 * (j - 32)))) & 3u);
-              scale = s_scale[s]; tot = 0.0; acc = s_dw[s * 64 + lane];
+              double rl = scale * neglog_u32(wd[q], s_ltab);                       // :398
+              if ((tot + rl) < len) { piece = rl; tot += rl; adv = false; }
+              else { piece = len - tot; adv = true; }
+            }
+            if (mnew < cap) OUT(woff + mnew) = piece; else err |= DERR_CAPACITY;
+            acc += piece;                                                        // updatedwelltimes :752
+            ++mnew;
+            if (adv) {
+              s_dw[s * 64 + lane] = acc;
+              ++j;
+              if (j >= nmerged) done = true;
+              else {
+                len = lnext;
+                if (j + 1 < nmerged) lnext = IN(roff + j + 1);
+                s = (int)(((j < 32) ? (pk0 >> (2 * j)) : (pk1 >> (2 * (j - 32)))) & 3u);
+                scale = s_scale[s]; tot = 0.0; acc = s_dw[s * 64 + lane];
+              }
             }
           }
         }
