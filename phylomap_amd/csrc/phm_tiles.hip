@@ -167,7 +167,7 @@ __global__ __launch_bounds__(TILES_BLOCK) void tiles_branch_kernel(TileParams<NS
   int mnew = 0;
 
   // s_i ~ B[s_{i-1},:] (.) B^(m-i-1) e_end          (resamplebranchstates :290, :301-304)
-  auto draw_state = [&](int i, int sprev) -> int {
+  auto draw_state_w = [&](int i, int sprev, uint32_t word) -> int {
     int kk = m - i - 1;
     if (kk >= p.klong) { err |= DERR_CAPACITY; kk = p.klong - 1; }
     double pr[NS];
@@ -183,8 +183,9 @@ __global__ __launch_bounds__(TILES_BLOCK) void tiles_branch_kernel(TileParams<NS
     }
 #pragma unroll
     for (int c = 0; c < NS; ++c) pr[c] = s_B2[sprev * NS + c] * pr[c];
-    return sample_cat<NS>(pr, su.draw((uint32_t)(i - 1)), err);
+    return sample_cat<NS>(pr, u01(word), err);
   };
+  auto draw_state = [&](int i, int sprev) -> int { return draw_state_w(i, sprev, su.draw_word((uint32_t)(i - 1))); };
 
   if (mmax <= 64) {
     // Pass A: one old segment per step for every lane; merged segments written back in place over the consumed rows of the
@@ -194,9 +195,16 @@ __global__ __launch_bounds__(TILES_BLOCK) void tiles_branch_kernel(TileParams<NS
     int cur_s = (m == 1) ? cs : ps;            // updatenodestates :469-472 (m==1: child wins)
     double cur_len = IN(0);
     double dnext = (m > 1) ? IN(1) : 0.0;
-    for (int i = 1; i < mmax; ++i) {
+    // Four steps per Philox block of the state stream (the step index is wave-uniform: draw i - 1 is a fixed word of it).
+    for (int i0 = 1; i0 < mmax; i0 += 4) {
+      uint32_t wd[4] = {0u, 0u, 0u, 0u};
+      if (i0 < mmax - 1)                       // some lane still draws in this group (draws exist for i < m - 1)
+        philox4x32_10((uint32_t)((i0 - 1) >> 2), ENT_BSTATE | (uint32_t)b, (uint32_t)it, rep, p.seed_lo, p.seed_hi, wd);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+      const int i = i0 + q;
       if (i < m) {
-        int si = (i == m - 1) ? cs : draw_state(i, cur_s);
+        int si = (i == m - 1) ? cs : draw_state_w(i, cur_s, wd[q]);
         double di = dnext;
         if (i + 1 < m) dnext = IN(i + 1);
         if (KS) s_cnt[(cur_s * NS + si) * 64 + lane] += 1u;               // shortenerbf :1010-1014
@@ -207,6 +215,7 @@ __global__ __launch_bounds__(TILES_BLOCK) void tiles_branch_kernel(TileParams<NS
           if (!KS) s_cnt[(cur_s * (NS - 1) + (si > cur_s ? si - 1 : si)) * 64 + lane] += 1u;   // shortener :65-66
           ++w; cur_s = si; cur_len = di;
         }
+      }
       }
     }
     if (w < 32) pk0 |= (uint64_t)cur_s << (2 * w); else pk1 |= (uint64_t)cur_s << (2 * (w - 32));
@@ -220,29 +229,36 @@ __global__ __launch_bounds__(TILES_BLOCK) void tiles_branch_kernel(TileParams<NS
     double len = len0;
     double lnext = (nmerged > 1) ? ((w == 1) ? cur_len : IN(1)) : 0.0;
     double tot = 0.0, scale = s_scale[s], acc = s_dw[s * 64 + lane];
-    uint32_t edraw = 0;
     bool stuck = false, done = false;
-    while (!done) {
-      double piece;
-      bool adv;
-      if (stuck || !(0.0 < len)) { stuck = true; piece = len; adv = true; }
-      else {
-        double rl = scale * neglog_u32(se.draw_word(edraw++), s_ltab);        // :398
-        if ((tot + rl) < len) { piece = rl; tot += rl; adv = false; }
-        else { piece = len - tot; adv = true; }
-      }
-      if (mnew < cap) at(out, (uint32_t)mnew * 512u + lane8) = piece; else err |= DERR_CAPACITY;
-      acc += piece;                                                        // updatedwelltimes :752
-      ++mnew;
-      if (adv) {
-        s_dw[s * 64 + lane] = acc;
-        ++j;
-        if (j >= nmerged) done = true;
+    // Four steps per Philox block of the exponential stream: a lane draws one variate per piece until it meets a zero-length
+    // segment and none after (`stuck`), so whenever it draws its draw counter equals the step index.
+    for (uint32_t t0 = 0; __any(!done); t0 += 4) {
+      uint32_t wd[4];
+      philox4x32_10(t0 >> 2, ENT_BEXP | (uint32_t)b, (uint32_t)it, rep, p.seed_lo, p.seed_hi, wd);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (done) continue;
+        double piece;
+        bool adv;
+        if (stuck || !(0.0 < len)) { stuck = true; piece = len; adv = true; }
         else {
-          len = lnext;
-          if (j + 1 < nmerged) lnext = IN(j + 1);
-          s = (int)(((j < 32) ? (pk0 >> (2 * j)) : (pk1 >> (2 * (j - 32)))) & 3u);
-          scale = s_scale[s]; tot = 0.0; acc = s_dw[s * 64 + lane];
+          double rl = scale * neglog_u32(wd[q], s_ltab);                       // :398
+          if ((tot + rl) < len) { piece = rl; tot += rl; adv = false; }
+          else { piece = len - tot; adv = true; }
+        }
+        if (mnew < cap) at(out, (uint32_t)mnew * 512u + lane8) = piece; else err |= DERR_CAPACITY;
+        acc += piece;                                                        // updatedwelltimes :752
+        ++mnew;
+        if (adv) {
+          s_dw[s * 64 + lane] = acc;
+          ++j;
+          if (j >= nmerged) done = true;
+          else {
+            len = lnext;
+            if (j + 1 < nmerged) lnext = IN(j + 1);
+            s = (int)(((j < 32) ? (pk0 >> (2 * j)) : (pk1 >> (2 * (j - 32)))) & 3u);
+            scale = s_scale[s]; tot = 0.0; acc = s_dw[s * 64 + lane];
+          }
         }
       }
     }
