@@ -116,8 +116,9 @@ __global__ __launch_bounds__(NARROW_BLOCK) void narrow_down_kernel(NarrowParams<
 }
 
 // The levels near the root hold a handful of nodes each; one workgroup per chain walks them in a single launch -- the top
-// of the pruning sweep, the root draw, the first levels of the sampling sweep -- with a device-scope fence and a barrier
-// between levels (the next level reads what this one wrote through L2).
+// of the pruning sweep, the root draw, the first levels of the sampling sweep -- with a WORKGROUP-scope fence and a barrier
+// between levels: producer and consumer are waves of one workgroup on one CU, and a device-scope fence would write back and
+// invalidate the XCD's L2 at every level (the kernel boundary publishes the results to the other kernels).
 constexpr int NARROW_MID_BLOCK = 256;
 template <int NS>
 __global__ __launch_bounds__(NARROW_MID_BLOCK) void narrow_mid_kernel(NarrowParams<NS> p, int it, int up_first, int up_levels,
@@ -126,15 +127,15 @@ __global__ __launch_bounds__(NARROW_MID_BLOCK) void narrow_mid_kernel(NarrowPara
   uint32_t err = 0;
   for (int l = up_first; l < up_levels; ++l) {
     for (int idx = p.up_off[l] + threadIdx.x; idx < p.up_off[l + 1]; idx += NARROW_MID_BLOCK) up_node<NS>(p, r, idx, err);
-    __threadfence();
+    __threadfence_block();
     __syncthreads();
   }
   if (threadIdx.x == 0) root_node<NS>(p, r, it, err);
-  __threadfence();
+  __threadfence_block();
   __syncthreads();
   for (int l = 0; l < down_levels; ++l) {
     for (int idx = p.down_off[l] + threadIdx.x; idx < p.down_off[l + 1]; idx += NARROW_MID_BLOCK) down_edge<NS>(p, r, it, idx, err);
-    __threadfence();
+    __threadfence_block();
     __syncthreads();
   }
   if (err) atomicOr(p.err, err);
@@ -263,31 +264,30 @@ __global__ __launch_bounds__(NARROW_BLOCK) void narrow_branch_kernel(NarrowParam
 
 // Statistics row of one chain: every column is the sum of the per-branch values, added in a fixed order (thread t takes
 // branches t, t+256, ... in edge order, then a fixed tree over the 256 partial sums) -> identical from run to run.
+// One workgroup per (chain, column): the columns of a row are reduced side by side (blockIdx.y), not one after the other.
 template <int NS>
 __global__ __launch_bounds__(256) void narrow_stats_kernel(NarrowParams<NS> p) {
   __shared__ double red[256];
   const int r = blockIdx.x;
+  const int c = blockIdx.y;                          // 0 .. NS + ncnt; the last one adds the segment counts (column pc - 1)
   const int ncnt = p.ks ? NS * NS : NS * (NS - 1);
   const int pc = NS + NS * NS + 1;
   const double* part = p.part + (size_t)r * p.n_edge * pc;
-  for (int c = 0; c <= NS + ncnt; ++c) {             // the last round adds the segment counts (column pc - 1)
-    const int src_c = (c == NS + ncnt) ? pc - 1 : c;
-    double s = 0.0;
-    for (int e = threadIdx.x; e < p.n_edge; e += 256) s += part[(size_t)e * pc + src_c];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int half = 128; half >= 1; half >>= 1) {
-      if ((int)threadIdx.x < half) red[threadIdx.x] = red[threadIdx.x] + red[threadIdx.x + half];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-      if (c < NS + ncnt) p.rowbuf[(size_t)r * p.n_cols + c] = red[0];
-      else atomicAdd(p.segcnt, (unsigned long long)red[0]);
-    }
+  const int src_c = (c == NS + ncnt) ? pc - 1 : c;
+  double s = 0.0;
+  for (int e = threadIdx.x; e < p.n_edge; e += 256) s += part[(size_t)e * pc + src_c];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int half = 128; half >= 1; half >>= 1) {
+    if ((int)threadIdx.x < half) red[threadIdx.x] = red[threadIdx.x] + red[threadIdx.x + half];
     __syncthreads();
   }
-  if (p.ks && threadIdx.x == 0)                                                // root state, 0-based (:1350-1352)
-    p.rowbuf[(size_t)r * p.n_cols + NS + ncnt] = (double)p.nstate[(size_t)r * p.n_node + p.root];
+  if (threadIdx.x == 0) {
+    if (c < NS + ncnt) p.rowbuf[(size_t)r * p.n_cols + c] = red[0];
+    else atomicAdd(p.segcnt, (unsigned long long)red[0]);
+    if (p.ks && c == 0)                                                        // root state, 0-based (:1350-1352)
+      p.rowbuf[(size_t)r * p.n_cols + NS + ncnt] = (double)p.nstate[(size_t)r * p.n_node + p.root];
+  }
 }
 
 // rows -> the engine's statistics layout (per replica, or summed over each 64-replica tile in replica order)
@@ -333,7 +333,7 @@ hipError_t launch_narrow_sweep(const NarrowParams<NS>& p, const std::vector<int3
   }
   hipLaunchKernelGGL(narrow_branch_kernel<NS>, dim3((p.n_edge + NARROW_BLOCK - 1) / NARROW_BLOCK, S), dim3(NARROW_BLOCK), 0,
                      stream, p, it);
-  hipLaunchKernelGGL(narrow_stats_kernel<NS>, dim3(S), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL(narrow_stats_kernel<NS>, dim3(S, NS + (p.ks ? NS * NS : NS * (NS - 1)) + 1), dim3(256), 0, stream, p);
   const int items = (p.reduce ? p.n_tiles : p.n_rep) * p.n_cols;
   hipLaunchKernelGGL(narrow_emit_kernel<NS>, dim3((items + 255) / 256), dim3(256), 0, stream, p, it);
   return hipGetLastError();
