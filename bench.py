@@ -23,6 +23,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (about 6.3 TB/s achievable)
+MEASURED_TRIAD_GBS = 5751.9   # tools/device_peaks/device_peaks.hip on an MI355X of this pool (read-only 6382, copy 4956 GB/s; FP64 vector 65.5 TFLOP/s)
 
 
 def cpu_baseline(z, Q, pid, Omega, target_s=12.0):
@@ -188,7 +189,9 @@ def main():
                          "kernel": "mcmc_sweep_kernel<4>", "launches": info.last_run_launches,
                          "avg_launch_ms": info.last_run_ms / max(1, info.last_run_launches),
                          "alg_bytes_per_unit": b_alg, "mean_segments_read_plus_written": seg,
-                         "units_per_launch": E * S * args.ipl},
+                         "units_per_launch": E * S * args.ipl,
+                         # attainable bandwidth measured on this pool with a stream triad (tools/device_peaks, profiles/r01_device_peaks.log)
+                         "measured_triad_peak": MEASURED_TRIAD_GBS, "frac_of_measured_triad": achieved / MEASURED_TRIAD_GBS},
             "pruning_sweep": None if prune_ms is None else {
                 "kernel": "mcmc_sweep_kernel<4> (up sweep only)", "ms_per_sweep": prune_ms, "alg_bytes_per_unit": 12 * n + 12,
                 "achieved": E * S * (12 * n + 12) / (prune_ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS,
