@@ -26,7 +26,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (about 6
 MEASURED_TRIAD_GBS = 5751.9   # tools/device_peaks/device_peaks.hip on an MI355X of this pool (read-only 6382, copy 4956 GB/s; FP64 vector 65.5 TFLOP/s)
 
 
-def cpu_baseline(z, Q, pid, Omega, target_s=12.0):
+def cpu_baseline(z, Q, pid, Omega, target_s=12.0, what="C2"):
     """The CPU oracle (oracle/phm_oracle.c, a restatement of src/phylomap.cpp) timed on one host core."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
@@ -43,13 +43,14 @@ def cpu_baseline(z, Q, pid, Omega, target_s=12.0):
         assert rc == 0
         return dt
 
-    probe = run(100, False)
-    n_it = max(100, int(target_s / (probe / 100)))
+    n_probe = 100 if E < 5000 else 20
+    probe = run(n_probe, False)
+    n_it = max(n_probe, int(target_s / (probe / n_probe)))
     dt = run(n_it, False)
-    n_f = max(50, n_it // 4)
+    n_f = max(50, n_it // 4) if E < 5000 else max(10, n_it // 16)
     dtf = run(n_f, True)
     return {"value": E * n_it / dt, "unit": "branch-site realisations/s", "cores": 1, "kind": "port",
-            "sample": f"same C2 tree and Q, 1 chain, {n_it} sweeps (edge lookup table); "
+            "sample": f"same {what} tree and Q, 1 chain, {n_it} sweeps (edge lookup table); "
                       f"with the reference's O(E) edge search per node (src/phylomap.cpp:643): "
                       f"{E * n_f / dtf:.4g}/s over {n_f} sweeps",
             "faithful_value": E * n_f / dtf}
@@ -67,6 +68,7 @@ def main():
     ap.add_argument("--mapping", default="replicas", choices=["replicas", "tiles", "branches", "auto"],
                     help="how a sweep is laid over the lanes (DESIGN.md 4b); the headline configuration streams with one lane per replica")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-c3", action="store_true", help="skip the extra 10 000-tip measurement")
     ap.add_argument("--force-collective", action="store_true", help="exercise the statistics hand-over to torch at N=1")
     args = ap.parse_args()
 
@@ -218,6 +220,35 @@ def main():
         mid.close()
         out["replicas_4096"] = {"mapping": "one wave per (tile, branch)", "ms_per_sweep": d1 / 40 * 1e3,
                                 "realisations_per_s": E * 4096 * 40 / d1}
+
+    if rank == 0 and world == 1 and n <= 4 and args.config == 2 and not args.no_c3:
+        # BASELINE.json's stated target is quoted on the 10 000-tip 4-state tree (C3): the same sweep with one wave per
+        # (tile, branch), as many replicas as fit (at most 16 384), next to the CPU oracle on that same tree.
+        z3, Q3, pid3, Om3 = synth.config_problem(3)
+        E3 = z3["edge"].shape[0]
+        free_b, _ = torch.cuda.mem_get_info()
+        probe = _lib.Engine(z3, Q3, pid3, Om3, 1, variant=_lib.PHM_MCMC_BIGTREE, seed=1, n_replicas=64, reduce=True,
+                            device=local_rank, mapping="tiles")
+        per_tile = probe.info().device_bytes
+        probe.close()
+        S3 = int(min(16384, (0.80 * free_b) // per_tile * 64))
+        S3 = max(64, S3 // 1024 * 1024 if S3 >= 1024 else S3 // 64 * 64)
+        big = _lib.Engine(z3, Q3, pid3, Om3, 24, variant=_lib.PHM_MCMC_BIGTREE, seed=0x5EED0003, n_replicas=S3, reduce=True,
+                          device=local_rank, mapping="tiles")
+        big.run(8); big.sync()
+        t1 = time.perf_counter(); big.run(16); big.sync(); d1 = time.perf_counter() - t1
+        st3 = big.stats(8, 16)
+        assert np.allclose(st3[:, :4].sum(1), S3 * z3["edge.length"].sum(), rtol=1e-9)
+        gib3 = big.info().device_bytes / 2 ** 30
+        big.close()
+        out["ten_k_tip_tree"] = {"workload": "C3: sumstatMCMC_bigtree sweep, 4-state Q, 10000-tip synthetic tree",
+                                 "mapping": "one wave per (tile, branch)", "replicas": S3, "ms_per_sweep": d1 / 16 * 1e3,
+                                 "realisations_per_s": E3 * S3 * 16 / d1, "hbm_gib_resident": gib3}
+        if not args.no_cpu:
+            c3 = cpu_baseline(z3, Q3, pid3, Om3, target_s=3.0, what="C3")
+            out["ten_k_tip_tree"]["cpu_baseline"] = c3
+            out["ten_k_tip_tree"]["speedup_vs_cpu_1core"] = out["ten_k_tip_tree"]["realisations_per_s"] / c3["value"]
+            out["ten_k_tip_tree"]["speedup_vs_cpu_1core_faithful"] = out["ten_k_tip_tree"]["realisations_per_s"] / c3["faithful_value"]
 
     if rank == 0:
         # secondary metric of BASELINE.json: expm(Q t)/s (batched 4x4 transition matrices, kernel time)
