@@ -10,7 +10,7 @@
 namespace phm {
 
 constexpr int MCMC_BLOCK = 256;   // 4 wavefronts share one copy of the LDS tables
-constexpr int MCMC_KTAB = 32;     // chain tables hold B^k e_j for k < KTAB; longer chains continue from the last entry
+constexpr int MCMC_KTAB = 32;     // rows of the column-chain table B^k e_j kept in LDS; longer chains read the full-length table
 
 // Passed by value: lives in the kernarg segment, so B / pid are read through scalar loads.
 template <int NS>
@@ -18,7 +18,7 @@ struct McmcParams {
   int32_t n_tips, n_node, n_edge, root;      // root: internal index
   int32_t n_tiles, n_rep, n_rep_pad, replica_offset;
   int32_t normalise, tips_per_replica, reduce, n_cols;
-  int32_t ktab;                              // rows of the chain tables staged in LDS
+  int32_t ktab;                              // rows of the column-chain table staged in LDS (= MCMC_KTAB, checked at launch)
   int32_t klong;                             // rows of the tables in global memory (>= ktab; covers every possible segment count)
   int32_t ks;                                // 1: bf/ks layout: n x n counts incl. self pairs (shortenerbf), root-state column
   int32_t tip_masks;                         // 1 (ks): tips observed up to parity and re-sampled; 0 (bf): tips observed
@@ -33,9 +33,9 @@ struct McmcParams {
   double pid[NS];
   const UpStep* up;
   const DownStep* down;
-  const double* colpow;                      // [ktab][NS][NS]: (Bc^k e_j)[r]
-  const double* rowpow;                      // [ktab][NS][NS]: ((Bc^T)^k e_j)[c]
-  const double* maskpow;                     // [ktab][2][NS]: Bc^k applied to the even / odd state mask (ks only)
+  const double* colpow;                      // [klong][NS][NS]: (Bc^k e_j)[r]; the first ktab rows are copied to LDS
+  const double* rowpow;                      // [klong][NS][NS]: ((Bc^T)^k e_j)[c]; read from here (one row per node draw)
+  const double* maskpow;                     // [klong][2][NS]: Bc^k applied to the even / odd state mask (ks only)
   const uint8_t* tips;                       // 0-based tip states: [n_tips] or [tile][n_tips][64]
   uint16_t* mcount;                          // [tile][n_edge][64] segments per branch
   double* dwell0;                            // [tile][rows][64] ring holding the consumed and the produced dwell stream
