@@ -214,32 +214,30 @@ __global__ __launch_bounds__(WB_BLOCK) void wb_branch_kernel(WideBranchParams p,
   if (err) atomicOr(p.err, err);
 }
 
-// Statistics row of one replica: dwell columns = fixed-order sums of the per-branch values (thread t takes branches t,
-// t+256, ... then a fixed tree), counters copied out of the atomic buffer (and cleared), (ks) the root state.
+// Statistics row of one replica: dwell columns = sums of the per-branch values in edge order (thread c owns column c and
+// adds the branches one after the other: a fixed order, identical from run to run).  The [edge][column] block of a replica
+// is streamed through LDS in chunks of 64 edges, so every cache line is read once and coalesced; counters are copied out
+// of the atomic buffer (and cleared), (ks) the root state appended.
+constexpr int WB_STATS_CHUNK = 64;
 __global__ __launch_bounds__(256) void wb_stats_kernel(WideBranchParams p) {
-  __shared__ double red[256];
-  const int r = blockIdx.x, n = p.n_states;
+  extern __shared__ double s_chunk[];               // [WB_STATS_CHUNK][n + 1]
+  const int r = blockIdx.x, n = p.n_states, tid = threadIdx.x;
   const int ncnt = p.count_self ? n * n : n * (n - 1);
-  const int pc = n + 1;
-  const double* part = p.part + (size_t)r * p.n_edge * pc;
-  for (int c = 0; c <= n; ++c) {                    // c == n: segments read + written
-    double s = 0.0;
-    for (int e = threadIdx.x; e < p.n_edge; e += 256) s += part[(size_t)e * pc + c];
-    red[threadIdx.x] = s;
+  const int pc = n + 1;                             // column n: segments read + written
+  const double* __restrict__ part = p.part + (size_t)r * p.n_edge * pc;
+  double acc = 0.0;
+  for (int e0 = 0; e0 < p.n_edge; e0 += WB_STATS_CHUNK) {
+    const int ne = min(WB_STATS_CHUNK, p.n_edge - e0);
+    for (int i = tid; i < ne * pc; i += 256) s_chunk[i] = part[(size_t)e0 * pc + i];
     __syncthreads();
-    for (int half = 128; half >= 1; half >>= 1) {
-      if ((int)threadIdx.x < half) red[threadIdx.x] = red[threadIdx.x] + red[threadIdx.x + half];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-      if (c < n) p.rowbuf[(size_t)r * p.n_cols + c] = red[0];
-      else atomicAdd(p.segcnt, (unsigned long long)red[0]);
-    }
+    if (tid < pc) for (int k = 0; k < ne; ++k) acc += s_chunk[k * pc + tid];
     __syncthreads();
   }
+  if (tid < n) p.rowbuf[(size_t)r * p.n_cols + tid] = acc;
+  else if (tid == n) atomicAdd(p.segcnt, (unsigned long long)acc);
   double* cnt = p.cnt + (size_t)r * p.n_cols + n;
-  for (int c = threadIdx.x; c < ncnt; c += 256) { p.rowbuf[(size_t)r * p.n_cols + n + c] = cnt[c]; cnt[c] = 0.0; }
-  if (p.ks && threadIdx.x == 0)                                                // root state, 0-based (:1350-1352)
+  for (int k = tid; k < ncnt; k += 256) { p.rowbuf[(size_t)r * p.n_cols + n + k] = cnt[k]; cnt[k] = 0.0; }
+  if (p.ks && tid == 0)                                                        // root state, 0-based (:1350-1352)
     p.rowbuf[(size_t)r * p.n_cols + n + ncnt] = (double)p.nstate[(size_t)r * p.n_node + p.root];
 }
 
@@ -283,7 +281,7 @@ hipError_t launch_wbranch_sweep(const WideBranchParams& p, const std::vector<int
     if (cnt > 0) hipLaunchKernelGGL(wb_down_kernel, dim3((cnt + WPB - 1) / WPB, S), dim3(WB_BLOCK), 0, stream, p, it, down_off[l], down_off[l + 1]);
   }
   hipLaunchKernelGGL(wb_branch_kernel, dim3((p.n_edge + WPB - 1) / WPB, S), dim3(WB_BLOCK), lds, stream, p, it);
-  hipLaunchKernelGGL(wb_stats_kernel, dim3(S), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL(wb_stats_kernel, dim3(S), dim3(256), sizeof(double) * WB_STATS_CHUNK * (p.n_states + 1), stream, p);
   const int64_t items = (int64_t)(p.reduce ? p.n_tiles : p.n_rep) * p.n_cols;
   hipLaunchKernelGGL(wb_emit_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, p, it);
   return hipGetLastError();
