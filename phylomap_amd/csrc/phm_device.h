@@ -82,6 +82,15 @@ struct Stream {
   __device__ __forceinline__ double draw(uint32_t d) { return u01(draw_word(d)); }
 };
 
+// the 32 random bits of draw d of a stream, computed afresh (no block kept): lanes of a wave may ask for different draws
+__device__ __forceinline__ uint32_t stream_word(uint32_t seed_lo, uint32_t seed_hi, uint32_t rep, uint32_t iter,
+                                                uint32_t ent, uint32_t d) {
+  uint32_t o[4];
+  philox4x32_10(d >> 2, ent, iter, rep, seed_lo, seed_hi, o);
+  const uint32_t lo = (d & 1u) ? o[1] : o[0], hi = (d & 1u) ? o[3] : o[2];
+  return (d & 2u) ? hi : lo;
+}
+
 // one-off draw (node states)
 __device__ __forceinline__ double stream_u(uint32_t seed_lo, uint32_t seed_hi, uint32_t rep, uint32_t iter,
                                            uint32_t ent, uint32_t d) {

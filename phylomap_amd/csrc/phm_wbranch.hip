@@ -148,9 +148,8 @@ __global__ __launch_bounds__(WB_BLOCK) void wb_branch_kernel(WideBranchParams p,
   double* cnt = p.cnt + (size_t)r * p.n_cols + n;           // transition counters start after the n dwell columns
   uint32_t err = 0;
 
-  Stream su, se;
+  Stream su;
   su.open(ENT_BSTATE | (uint32_t)b, (uint32_t)it, rep, p.seed_lo, p.seed_hi);
-  se.open(ENT_BEXP | (uint32_t)b, (uint32_t)it, rep, p.seed_lo, p.seed_hi);
 
   // pass A: interior states s_i ~ B[s_{i-1},:] (.) B^(m-i-1) e_end (:290, :301-304), neighbours merged (:54)
   int w = 0;
@@ -180,9 +179,14 @@ __global__ __launch_bounds__(WB_BLOCK) void wb_branch_kernel(WideBranchParams p,
 
   // pass B: virtual jumps, gaps ~ Exp(Omega + q_ss) until each merged segment is used up (:391-410); a segment that is not
   // positive leaves itself and everything after it untouched (:397, :405-406).  Lane s carries the dwell sum of state s.
+  // The control flow of a branch is wave-uniform, so the exponential variates are produced 64 at a time -- lane t computes
+  // -log(U) of draw gen_base + t from its own Philox block -- and consumed one by one through v_readlane; `tot` is still
+  // accumulated draw by draw, in order, so every comparison sees the bits the sequential loop would.
   double mine = 0.0;
   int mnew = 0;
-  uint32_t edraw = 0;
+  uint32_t edraw = 0, gen_base = 0;
+  double nl = 0.0;
+  bool have_gen = false;
   bool stuck = false;
   for (int j = 0; j < nmerged; ++j) {
     const int s = ms[j];
@@ -196,7 +200,12 @@ __global__ __launch_bounds__(WB_BLOCK) void wb_branch_kernel(WideBranchParams p,
       const double scale = l.scale[s];
       double tot = 0.0;
       while (tot < len) {
-        const double rl = scale * neglog_u32(se.draw_word(edraw++), s_ltab);   // :398
+        if (!have_gen || edraw - gen_base >= 64u) {
+          gen_base = edraw; have_gen = true;
+          nl = neglog_u32(stream_word(p.seed_lo, p.seed_hi, rep, (uint32_t)it, ENT_BEXP | (uint32_t)b, edraw + (uint32_t)lane), s_ltab);
+        }
+        const double rl = scale * readlane_f64(nl, (int)(edraw - gen_base));   // :398
+        ++edraw;
         double piece;
         if ((tot + rl) < len) { piece = rl; tot += rl; }
         else { piece = len - tot; tot = len; }
