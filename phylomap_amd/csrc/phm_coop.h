@@ -32,6 +32,16 @@ __device__ __forceinline__ double coop_matvec(const double* __restrict__ M, doub
   return acc;
 }
 
+// the same product for a matrix with at most w non-zeros per row, kept in ELLPACK form (columns ascending; padding entries
+// have value 0): lane c gathers v[col] of its own non-zeros.  Skipping the exact zeros of a row leaves its left-to-right sum
+// unchanged bit for bit -- every term is a product of non-negative finite numbers, so the skipped terms are +0.
+__device__ __forceinline__ double coop_matvec_ell(const int32_t* __restrict__ ecol, const double* __restrict__ eval, double v,
+                                                  int w, int c) {
+  double acc = eval[c * w] * __shfl(v, ecol[c * w], 64);
+  for (int t = 1; t < w; ++t) acc += eval[c * w + t] * __shfl(v, ecol[c * w + t], 64);
+  return acc;
+}
+
 // first j with u*sum(p) <= p_0+..+p_j (index order); lanes >= n carry p = 0 and never count
 __device__ __forceinline__ int coop_sample(double p, double u, int n, int lane, uint32_t& err) {
   double run = readlane_f64(p, 0);

@@ -103,6 +103,26 @@ int32_t upload_model(phm_engine* e) {
       HIPCHK(hipMemcpy(e->d_B2.p, e->hB2.data(), sizeof(double) * n * n, hipMemcpyHostToDevice));
       HIPCHK(hipMemcpy(e->d_Bc.p, e->hBc.data(), sizeof(double) * n * n, hipMemcpyHostToDevice));
       HIPCHK(hipMemcpy(e->d_scale.p, e->hscale.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+      // A chain matrix with few non-zeros per row (tridiagonal amino-acid-style Q, the SPARSE threshold) also goes up in
+      // ELLPACK form: skipping exact zeros leaves every left-to-right row sum bit-identical (all terms are >= +0).
+      int w = 0;
+      for (int i = 0; i < n; ++i) {
+        int cnt = 0;
+        for (int j = 0; j < n; ++j) cnt += e->hBc[(size_t)i * n + j] != 0.0;
+        w = std::max(w, cnt);
+      }
+      e->pwb.ell_w = (w >= 1 && w <= phm::WB_ELL_MAX && 3 * w <= n) ? w : 0;
+      if (e->pwb.ell_w) {
+        std::vector<int32_t> ec((size_t)n * w);
+        std::vector<double> ev((size_t)n * w, 0.0);
+        for (int i = 0; i < n; ++i) {
+          int t = 0;
+          for (int j = 0; j < n; ++j) if (e->hBc[(size_t)i * n + j] != 0.0) { ec[(size_t)i * w + t] = j; ev[(size_t)i * w + t] = e->hBc[(size_t)i * n + j]; ++t; }
+          for (; t < w; ++t) ec[(size_t)i * w + t] = i;
+        }
+        HIPCHK(hipMemcpy(e->d_ell_col.p, ec.data(), sizeof(int32_t) * ec.size(), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(e->d_ell_val.p, ev.data(), sizeof(double) * ev.size(), hipMemcpyHostToDevice));
+      }
       return PHM_OK;
     }
     auto refresh_n = [&](auto& p) {
@@ -292,6 +312,7 @@ int32_t narrow_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
     HIPCHK(e->d_wb_cnt.alloc(sizeof(double) * (size_t)S * e->dcols));
     HIPCHK(hipMemset(e->d_wb_cnt.p, 0, e->d_wb_cnt.bytes));
     HIPCHK(e->d_B2.alloc(sizeof(double) * n * n)); HIPCHK(e->d_Bc.alloc(sizeof(double) * n * n));
+    HIPCHK(e->d_ell_col.alloc(sizeof(int32_t) * n * phm::WB_ELL_MAX)); HIPCHK(e->d_ell_val.alloc(sizeof(double) * n * phm::WB_ELL_MAX));
     HIPCHK(e->d_scale.alloc(sizeof(double) * n)); HIPCHK(e->d_pid.alloc(sizeof(double) * n));
     HIPCHK(hipMemcpy(e->d_pid.p, e->hpid.data(), e->d_pid.bytes, hipMemcpyHostToDevice));
     phm::WideBranchParams& p = e->pwb;
@@ -303,6 +324,7 @@ int32_t narrow_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
     p.seed_lo = (uint32_t)(o.seed & 0xFFFFFFFFull); p.seed_hi = (uint32_t)(o.seed >> 32);
     p.total_cap = e->nw_total_cap;
     p.B2 = e->d_B2.as<double>(); p.Bc = e->d_Bc.as<double>(); p.scale = e->d_scale.as<double>(); p.pid = e->d_pid.as<double>();
+    p.ell_w = 0; p.ell_col = e->d_ell_col.as<int32_t>(); p.ell_val = e->d_ell_val.as<double>();
     p.up = e->d_up.as<phm::UpStep>(); p.down = e->d_down.as<phm::DownStep>();
     p.up_order = e->d_nw_up_order.as<int32_t>(); p.down_order = e->d_nw_down_order.as<int32_t>();
     p.branch_order = e->d_nw_border.as<int32_t>(); p.off = e->d_nw_off.as<int64_t>();

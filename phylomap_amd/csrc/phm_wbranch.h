@@ -26,6 +26,7 @@
 
 namespace phm {
 
+constexpr int WB_ELL_MAX = 16;          // widest ELLPACK row the pruning kernel keeps in LDS
 constexpr int WB_BLOCK = 256;          // four waves = four (item, replica) pairs share the LDS copy of B
 
 struct WideBranchParams {
@@ -34,11 +35,14 @@ struct WideBranchParams {
   int32_t n_rep, n_rep_pad, replica_offset, n_tiles;
   int32_t normalise, tips_per_replica, sparse, ks, tip_masks, count_self, reduce, n_cols;
   int32_t klong;                             // rows of the chain tables
+  int32_t ell_w;                             // > 0: the chain matrix has at most ell_w non-zeros per row (ELLPACK copy below)
   uint32_t seed_lo, seed_hi;
   int64_t total_cap;                         // doubles per replica in one dwell buffer
   const double* B2;                          // [n][n] dense B, row-major
   const double* Bc;                          // [n][n] chain matrix (B, or thresholded B for SPARSE)
   const double* scale;                       // [n] 1/(Omega+q_ss)
+  const int32_t* ell_col;                    // [n][ell_w] column of the t-th non-zero of a row, ascending; padding: own row, value 0
+  const double* ell_val;                     // [n][ell_w]
   const double* pid;                         // [n]
   const UpStep* up;
   const DownStep* down;

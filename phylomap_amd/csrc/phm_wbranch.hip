@@ -11,6 +11,10 @@ namespace phm {
 
 namespace {
 
+__host__ __device__ inline size_t wb_model_lds_bytes(int n, bool sparse) {
+  return sizeof(double) * ((size_t)(sparse ? 2 : 1) * n * (n | 1) + n);
+}
+
 struct Lds {
   double* Bc;      // [n][ldn] chain matrix
   double* B2;      // [n][ldn] dense rows for the forward step (= Bc unless SPARSE)
@@ -38,7 +42,11 @@ __device__ __forceinline__ Lds stage_model(const WideBranchParams& p, unsigned c
 
 __global__ __launch_bounds__(WB_BLOCK) void wb_up_kernel(WideBranchParams p, int begin, int end) {
   extern __shared__ __align__(16) unsigned char smem[];
-  const Lds l = stage_model(p, smem);
+  const int ell_w = p.ell_w;                 // the ELLPACK copy sits behind the model matrices (dynamic LDS, only when used)
+  double* s_eval = reinterpret_cast<double*>(smem + wb_model_lds_bytes(p.n_states, p.sparse != 0));
+  int32_t* s_ecol = reinterpret_cast<int32_t*>(s_eval + p.n_states * ell_w);
+  for (int i = threadIdx.x; i < p.n_states * ell_w; i += WB_BLOCK) { s_ecol[i] = p.ell_col[i]; s_eval[i] = p.ell_val[i]; }
+  const Lds l = stage_model(p, smem);      // ends with a barrier
   const int n = p.n_states, lane = threadIdx.x & 63;
   const int idx = begin + blockIdx.x * (WB_BLOCK / 64) + (threadIdx.x >> 6);
   const int r = blockIdx.y;
@@ -57,7 +65,8 @@ __global__ __launch_bounds__(WB_BLOCK) void wb_up_kernel(WideBranchParams p, int
       return p.tip_masks ? p.maskL[((size_t)k * 2 + (ts & 1)) * n + c] : p.colL[((size_t)k * n + ts) * n + c];
     }
     double v = PLr[(size_t)child * n + c];
-    for (int i = 0; i < k; ++i) v = coop_matvec(l.Bc, v, n, l.ldn, c);
+    if (ell_w > 0) for (int i = 0; i < k; ++i) v = coop_matvec_ell(s_ecol, s_eval, v, ell_w, c);
+    else for (int i = 0; i < k; ++i) v = coop_matvec(l.Bc, v, n, l.ldn, c);
     return v;
   };
   double x = child_vec(st.child[1], mc[st.edge[1]] - 1);        // "first"  (:508)
@@ -267,7 +276,7 @@ __global__ void wb_emit_kernel(WideBranchParams p, int it) {
 
 }  // namespace
 
-size_t wbranch_lds_bytes(int n, bool sparse) { return sizeof(double) * ((size_t)(sparse ? 2 : 1) * n * (n | 1) + n); }
+size_t wbranch_lds_bytes(int n, bool sparse) { return wb_model_lds_bytes(n, sparse); }
 
 hipError_t launch_wbranch_sweep(const WideBranchParams& p, const std::vector<int32_t>& up_off,
                                 const std::vector<int32_t>& down_off, int it, hipStream_t stream) {
@@ -275,14 +284,14 @@ hipError_t launch_wbranch_sweep(const WideBranchParams& p, const std::vector<int
   const unsigned S = (unsigned)p.n_rep;
   const size_t lds = wbranch_lds_bytes(p.n_states, p.sparse != 0);
   if (lds > 48 * 1024) {      // SPARSE with ~60 states: two copies of B
-    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(wb_up_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(wb_up_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + (size_t)p.n_states * WB_ELL_MAX * 12));
     hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(wb_branch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e1 != hipSuccess) return e1;
     if (e2 != hipSuccess) return e2;
   }
   for (size_t l = 0; l + 1 < up_off.size(); ++l) {
     const int cnt = up_off[l + 1] - up_off[l];
-    if (cnt > 0) hipLaunchKernelGGL(wb_up_kernel, dim3((cnt + WPB - 1) / WPB, S), dim3(WB_BLOCK), lds, stream, p, up_off[l], up_off[l + 1]);
+    if (cnt > 0) hipLaunchKernelGGL(wb_up_kernel, dim3((cnt + WPB - 1) / WPB, S), dim3(WB_BLOCK), lds + (size_t)p.n_states * p.ell_w * 12, stream, p, up_off[l], up_off[l + 1]);
   }
   hipLaunchKernelGGL(wb_root_kernel, dim3((S + WPB - 1) / WPB), dim3(WB_BLOCK), 0, stream, p, it);
   for (size_t l = 0; l + 1 < down_off.size(); ++l) {
