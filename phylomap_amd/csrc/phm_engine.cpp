@@ -105,24 +105,28 @@ int32_t upload_model(phm_engine* e) {
       HIPCHK(hipMemcpy(e->d_scale.p, e->hscale.data(), sizeof(double) * n, hipMemcpyHostToDevice));
       // A chain matrix with few non-zeros per row (tridiagonal amino-acid-style Q, the SPARSE threshold) also goes up in
       // ELLPACK form: skipping exact zeros leaves every left-to-right row sum bit-identical (all terms are >= +0).
-      int w = 0;
-      for (int i = 0; i < n; ++i) {
-        int cnt = 0;
-        for (int j = 0; j < n; ++j) cnt += e->hBc[(size_t)i * n + j] != 0.0;
-        w = std::max(w, cnt);
-      }
-      e->pwb.ell_w = (w >= 1 && w <= phm::WB_ELL_MAX && 3 * w <= n) ? w : 0;
-      if (e->pwb.ell_w) {
+      auto ellpack = [&](const std::vector<double>& M, DevBuf& dcol, DevBuf& dval, int32_t& w_out) -> int32_t {
+        int w = 0;
+        for (int i = 0; i < n; ++i) {
+          int cnt = 0;
+          for (int j = 0; j < n; ++j) cnt += M[(size_t)i * n + j] != 0.0;
+          w = std::max(w, cnt);
+        }
+        w_out = (w >= 1 && w <= phm::WB_ELL_MAX && 3 * w <= n) ? w : 0;
+        if (!w_out) return PHM_OK;
         std::vector<int32_t> ec((size_t)n * w);
         std::vector<double> ev((size_t)n * w, 0.0);
         for (int i = 0; i < n; ++i) {
           int t = 0;
-          for (int j = 0; j < n; ++j) if (e->hBc[(size_t)i * n + j] != 0.0) { ec[(size_t)i * w + t] = j; ev[(size_t)i * w + t] = e->hBc[(size_t)i * n + j]; ++t; }
+          for (int j = 0; j < n; ++j) if (M[(size_t)i * n + j] != 0.0) { ec[(size_t)i * w + t] = j; ev[(size_t)i * w + t] = M[(size_t)i * n + j]; ++t; }
           for (; t < w; ++t) ec[(size_t)i * w + t] = i;
         }
-        HIPCHK(hipMemcpy(e->d_ell_col.p, ec.data(), sizeof(int32_t) * ec.size(), hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(e->d_ell_val.p, ev.data(), sizeof(double) * ev.size(), hipMemcpyHostToDevice));
-      }
+        HIPCHK(hipMemcpy(dcol.p, ec.data(), sizeof(int32_t) * ec.size(), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dval.p, ev.data(), sizeof(double) * ev.size(), hipMemcpyHostToDevice));
+        return PHM_OK;
+      };
+      { int32_t st = ellpack(e->hBc, e->d_ell_col, e->d_ell_val, e->pwb.ell_w); if (st) return st; }
+      { int32_t st = ellpack(e->hB2, e->d_ell2_col, e->d_ell2_val, e->pwb.ell2_w); if (st) return st; }
       return PHM_OK;
     }
     auto refresh_n = [&](auto& p) {
@@ -313,6 +317,7 @@ int32_t narrow_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
     HIPCHK(hipMemset(e->d_wb_cnt.p, 0, e->d_wb_cnt.bytes));
     HIPCHK(e->d_B2.alloc(sizeof(double) * n * n)); HIPCHK(e->d_Bc.alloc(sizeof(double) * n * n));
     HIPCHK(e->d_ell_col.alloc(sizeof(int32_t) * n * phm::WB_ELL_MAX)); HIPCHK(e->d_ell_val.alloc(sizeof(double) * n * phm::WB_ELL_MAX));
+    HIPCHK(e->d_ell2_col.alloc(sizeof(int32_t) * n * phm::WB_ELL_MAX)); HIPCHK(e->d_ell2_val.alloc(sizeof(double) * n * phm::WB_ELL_MAX));
     HIPCHK(e->d_scale.alloc(sizeof(double) * n)); HIPCHK(e->d_pid.alloc(sizeof(double) * n));
     HIPCHK(hipMemcpy(e->d_pid.p, e->hpid.data(), e->d_pid.bytes, hipMemcpyHostToDevice));
     phm::WideBranchParams& p = e->pwb;
@@ -325,6 +330,7 @@ int32_t narrow_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
     p.total_cap = e->nw_total_cap;
     p.B2 = e->d_B2.as<double>(); p.Bc = e->d_Bc.as<double>(); p.scale = e->d_scale.as<double>(); p.pid = e->d_pid.as<double>();
     p.ell_w = 0; p.ell_col = e->d_ell_col.as<int32_t>(); p.ell_val = e->d_ell_val.as<double>();
+    p.ell2_w = 0; p.ell2_col = e->d_ell2_col.as<int32_t>(); p.ell2_val = e->d_ell2_val.as<double>();
     p.up = e->d_up.as<phm::UpStep>(); p.down = e->d_down.as<phm::DownStep>();
     p.up_order = e->d_nw_up_order.as<int32_t>(); p.down_order = e->d_nw_down_order.as<int32_t>();
     p.branch_order = e->d_nw_border.as<int32_t>(); p.off = e->d_nw_off.as<int64_t>();

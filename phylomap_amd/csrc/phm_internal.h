@@ -160,7 +160,7 @@ struct phm_engine {
   int nw_klong = 0;
   int64_t nw_total_cap = 0;
   DevBuf d_nw_up_off, d_nw_down_off, d_nw_up_order, d_nw_down_order, d_nw_border, d_nw_off, d_nw_colL, d_nw_rowL, d_nw_maskL, d_nw_mcount, d_nw_dwA, d_nw_dwB,
-      d_nw_mstate, d_nw_mlen, d_nw_estate, d_nw_part, d_nw_rowbuf, d_ell_col, d_ell_val;
+      d_nw_mstate, d_nw_mlen, d_nw_estate, d_nw_part, d_nw_rowbuf, d_ell_col, d_ell_val, d_ell2_col, d_ell2_val;
   DevBuf d_wb_cnt;
   phm::WideBranchParams pwb;                  // n > 4 with `narrow` set: one wave per (replica, branch) (phm_wbranch.hip)
   phm::NarrowParams<2> n2;

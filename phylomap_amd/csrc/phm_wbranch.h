@@ -36,6 +36,7 @@ struct WideBranchParams {
   int32_t normalise, tips_per_replica, sparse, ks, tip_masks, count_self, reduce, n_cols;
   int32_t klong;                             // rows of the chain tables
   int32_t ell_w;                             // > 0: the chain matrix has at most ell_w non-zeros per row (ELLPACK copy below)
+  int32_t ell2_w;                            // the same for the dense-step matrix B2 (rows of the forward draws)
   uint32_t seed_lo, seed_hi;
   int64_t total_cap;                         // doubles per replica in one dwell buffer
   const double* B2;                          // [n][n] dense B, row-major
@@ -43,6 +44,8 @@ struct WideBranchParams {
   const double* scale;                       // [n] 1/(Omega+q_ss)
   const int32_t* ell_col;                    // [n][ell_w] column of the t-th non-zero of a row, ascending; padding: own row, value 0
   const double* ell_val;                     // [n][ell_w]
+  const int32_t* ell2_col;                   // [n][ell2_w]
+  const double* ell2_val;                    // [n][ell2_w]
   const double* pid;                         // [n]
   const UpStep* up;
   const DownStep* down;

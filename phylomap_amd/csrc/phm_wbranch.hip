@@ -136,7 +136,11 @@ __global__ __launch_bounds__(WB_BLOCK) void wb_branch_kernel(WideBranchParams p,
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ __align__(16) double s_ltab[2 * PHM_LOGTAB_N];        // (1/c_j, log c_j) of the exponential variates (neglog_u32)
   for (int i = threadIdx.x; i < 2 * PHM_LOGTAB_N; i += WB_BLOCK) s_ltab[i] = logtab_entry(i);
-  const Lds l = stage_model(p, smem);
+  const int w2 = p.ell2_w;                   // ELLPACK rows of the forward-step matrix behind the model matrices (when used)
+  double* s_e2val = reinterpret_cast<double*>(smem + wb_model_lds_bytes(p.n_states, p.sparse != 0));
+  int32_t* s_e2col = reinterpret_cast<int32_t*>(s_e2val + p.n_states * w2);
+  for (int i = threadIdx.x; i < p.n_states * w2; i += WB_BLOCK) { s_e2col[i] = p.ell2_col[i]; s_e2val[i] = p.ell2_val[i]; }
+  const Lds l = stage_model(p, smem);        // ends with a barrier
   const int n = p.n_states, lane = threadIdx.x & 63;
   const int idx = blockIdx.x * (WB_BLOCK / 64) + (threadIdx.x >> 6);
   const int r = blockIdx.y;
@@ -170,9 +174,19 @@ __global__ __launch_bounds__(WB_BLOCK) void wb_branch_kernel(WideBranchParams p,
     else {
       int kk = m - i - 1;
       if (kk >= p.klong) { err |= DERR_CAPACITY; kk = p.klong - 1; }
-      const double beta = p.colL[((size_t)kk * n + cs) * n + c];
-      const double pr = (lane < n) ? l.B2[cur_s * l.ldn + c] * beta : 0.0;
-      si = coop_sample(pr, su.draw((uint32_t)(i - 1)), n, lane, err);
+      if (w2 > 0) {
+        // Sparse forward row: lanes are the row's non-zero slots (columns ascending).  The zero entries of the dense vector
+        // add +0 to every partial sum, so the draw over the slots picks the same column as the draw over all n states.
+        const int slot = lane < w2 ? cur_s * w2 + lane : cur_s * w2;
+        const int mycol = s_e2col[slot];
+        const double pr = (lane < w2) ? s_e2val[slot] * p.colL[((size_t)kk * n + cs) * n + mycol] : 0.0;
+        const int t = coop_sample(pr, su.draw((uint32_t)(i - 1)), w2, lane, err);
+        si = __builtin_amdgcn_readlane(mycol, t);
+      } else {
+        const double beta = p.colL[((size_t)kk * n + cs) * n + c];
+        const double pr = (lane < n) ? l.B2[cur_s * l.ldn + c] * beta : 0.0;
+        si = coop_sample(pr, su.draw((uint32_t)(i - 1)), n, lane, err);
+      }
     }
     const double di = in[i];
     if (p.count_self && lane == 0) atomicAdd(cnt + cur_s * n + si, 1.0);                    // shortenerbf :1010-1014
@@ -285,7 +299,7 @@ hipError_t launch_wbranch_sweep(const WideBranchParams& p, const std::vector<int
   const size_t lds = wbranch_lds_bytes(p.n_states, p.sparse != 0);
   if (lds > 48 * 1024) {      // SPARSE with ~60 states: two copies of B
     hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(wb_up_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + (size_t)p.n_states * WB_ELL_MAX * 12));
-    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(wb_branch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(wb_branch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + (size_t)p.n_states * WB_ELL_MAX * 12));
     if (e1 != hipSuccess) return e1;
     if (e2 != hipSuccess) return e2;
   }
@@ -298,7 +312,7 @@ hipError_t launch_wbranch_sweep(const WideBranchParams& p, const std::vector<int
     const int cnt = down_off[l + 1] - down_off[l];
     if (cnt > 0) hipLaunchKernelGGL(wb_down_kernel, dim3((cnt + WPB - 1) / WPB, S), dim3(WB_BLOCK), 0, stream, p, it, down_off[l], down_off[l + 1]);
   }
-  hipLaunchKernelGGL(wb_branch_kernel, dim3((p.n_edge + WPB - 1) / WPB, S), dim3(WB_BLOCK), lds, stream, p, it);
+  hipLaunchKernelGGL(wb_branch_kernel, dim3((p.n_edge + WPB - 1) / WPB, S), dim3(WB_BLOCK), lds + (size_t)p.n_states * p.ell2_w * 12, stream, p, it);
   hipLaunchKernelGGL(wb_stats_kernel, dim3(S), dim3(256), sizeof(double) * WB_STATS_CHUNK * (p.n_states + 1), stream, p);
   const int64_t items = (int64_t)(p.reduce ? p.n_tiles : p.n_rep) * p.n_cols;
   hipLaunchKernelGGL(wb_emit_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, p, it);
