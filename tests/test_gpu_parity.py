@@ -316,6 +316,33 @@ def test_wide_kernel_matches_oracle(n, fn, variant, mapping):
     np.testing.assert_allclose(red[:, :n], got.sum(0)[:, :n], rtol=1e-12)
 
 
+@pytest.mark.parametrize("n,band", [(9, 1), (33, 1), (64, 1), (16, 2), (48, 7)])
+@pytest.mark.parametrize("fn,variant", [("sumstatMCMC", O.PLAIN), ("SPARSEsumstatMCMC", O.SPARSE)])
+def test_wide_branch_mapping_sparse_rows_match_oracle(n, band, fn, variant):
+    """Banded rate matrices: the (replica, branch) kernels apply the chain matrix in ELLPACK form and draw the forward states
+    over the non-zero slots of a row (phm_wbranch.hip) -- the exact zeros they skip must not move a single count."""
+    rs = np.random.default_rng(1000 * n + band)
+    Q = np.zeros((n, n))
+    for i in range(n):
+        for j in range(max(0, i - band), min(n, i + band + 1)):
+            if i != j:
+                Q[i, j] = rs.uniform(0.01, 0.05)
+    if band == 1:
+        Q[3, 4] = 0.0                                   # a row with fewer non-zeros than its neighbours (padding slots)
+    np.fill_diagonal(Q, -Q.sum(1))
+    Omega = 1.25 * float(np.max(np.abs(np.diag(Q))))
+    pid = rs.dirichlet(np.ones(n))
+    z = synth.make_tree(12, Q, Omega, 77 + n, pid, init_segments=7)
+    nen, nodelist, root = _orders(z)
+    N, S, seed = 8, 3, 5
+    got = getattr(api, fn)(z, Q, pid, Omega, N, seed=seed, n_replicas=S, mapping="branches")
+    for r in range(S):
+        want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(n) + Q / Omega, Omega, nen, nodelist, root, N, variant=variant,
+                                      seed=seed, replica=r)
+        assert rc == 0
+        _same(got[r], want, n, "branches")
+
+
 def test_wide_kernel_chain_state_and_golden():
     from golden.make_golden import unpack_tree
     import os
