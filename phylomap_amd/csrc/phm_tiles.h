@@ -28,7 +28,7 @@ namespace phm {
 
 constexpr int TILES_BLOCK = 256;          // four waves = four (tile, item) pairs per workgroup
 constexpr int TILES_CHUNK = 64;           // branches per first-stage partial sum of the dwell reduction
-constexpr int TILES_KTAB = 32;            // chain-table rows staged in LDS by the branch kernel
+constexpr int TILES_KTAB = 24;            // chain-table rows staged in LDS by the branch kernel (longer chains: full table in L2)
 
 template <int NS>
 struct TileParams {

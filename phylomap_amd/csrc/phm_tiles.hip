@@ -123,7 +123,7 @@ template <int NS, bool KS>
 __global__ __launch_bounds__(TILES_BLOCK) void tiles_branch_kernel(TileParams<NS> p, int it) {
   constexpr int NCNT = KS ? NS * NS : NS * (NS - 1);
   __shared__ double s_dw_all[(TILES_BLOCK / 64) * NS * 64];
-  __shared__ uint32_t s_cnt_all[(TILES_BLOCK / 64) * NCNT * 64];
+  __shared__ uint16_t s_cnt_all[(TILES_BLOCK / 64) * NCNT * 64];      // counts of ONE branch (<= 65 535 segments): 16 bits keep the block under 20 KB of LDS, 8 waves per SIMD
   __shared__ double s_B2[NS * NS], s_scale[NS];      // indexed by a per-lane state: LDS, not the kernarg segment
   __shared__ double s_col[TILES_KTAB * NS * NS];     // B^k e_j for the short chains (most draws); longer ones go to L2
   __shared__ __align__(16) double s_ltab[2 * PHM_LOGTAB_N];        // (1/c_j, log c_j) of the exponential variates (neglog_u32)
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(TILES_BLOCK) void tiles_branch_kernel(TileParams<NS
   const int tile = item % p.n_tiles;
   const int b = p.branch_order[item / p.n_tiles];
   double* s_dw = s_dw_all + wave * NS * 64;
-  uint32_t* s_cnt = s_cnt_all + wave * NCNT * 64;
+  uint16_t* s_cnt = s_cnt_all + wave * NCNT * 64;
   const uint32_t rep = (uint32_t)(p.replica_offset + tile * 64 + lane);
   uint16_t* __restrict__ mct = p.mcount + (size_t)tile * p.n_edge * 64;
   const int m = mct[b * 64 + lane];
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(TILES_BLOCK) void tiles_branch_kernel(TileParams<NS
 #pragma unroll
   for (int c = 0; c < NS; ++c) s_dw[c * 64 + lane] = 0.0;
 #pragma unroll
-  for (int c = 0; c < NCNT; ++c) s_cnt[c * 64 + lane] = 0u;
+  for (int c = 0; c < NCNT; ++c) s_cnt[c * 64 + lane] = (uint16_t)0;
 
   Stream su, se;
   su.open(ENT_BSTATE | (uint32_t)b, (uint32_t)it, rep, p.seed_lo, p.seed_hi);
@@ -207,12 +207,12 @@ __global__ __launch_bounds__(TILES_BLOCK) void tiles_branch_kernel(TileParams<NS
         int si = (i == m - 1) ? cs : draw_state_w(i, cur_s, wd[q]);
         double di = dnext;
         if (i + 1 < m) dnext = IN(i + 1);
-        if (KS) s_cnt[(cur_s * NS + si) * 64 + lane] += 1u;               // shortenerbf :1010-1014
+        if (KS) s_cnt[(cur_s * NS + si) * 64 + lane] = (uint16_t)(s_cnt[(cur_s * NS + si) * 64 + lane] + 1u);               // shortenerbf :1010-1014
         if (si == cur_s) cur_len = cur_len + di;                           // shortener :54
         else {
           IN(w) = cur_len;
           if (w < 32) pk0 |= (uint64_t)cur_s << (2 * w); else pk1 |= (uint64_t)cur_s << (2 * (w - 32));
-          if (!KS) s_cnt[(cur_s * (NS - 1) + (si > cur_s ? si - 1 : si)) * 64 + lane] += 1u;   // shortener :65-66
+          if (!KS) s_cnt[(cur_s * (NS - 1) + (si > cur_s ? si - 1 : si)) * 64 + lane] = (uint16_t)(s_cnt[(cur_s * (NS - 1) + (si > cur_s ? si - 1 : si)) * 64 + lane] + 1u);   // shortener :65-66
           ++w; cur_s = si; cur_len = di;
         }
       }
@@ -297,11 +297,11 @@ __global__ __launch_bounds__(TILES_BLOCK) void tiles_branch_kernel(TileParams<NS
         si = (i == m - 1) ? cs : draw_state(i, cur_s);
         di = IN(i);
       }
-      if (KS && si >= 0) s_cnt[(cur_s * NS + si) * 64 + lane] += 1u;
+      if (KS && si >= 0) s_cnt[(cur_s * NS + si) * 64 + lane] = (uint16_t)(s_cnt[(cur_s * NS + si) * 64 + lane] + 1u);
       if (si == cur_s) cur_len = cur_len + di;
       else {
         finalize(cur_s, cur_len);
-        if (!KS && si >= 0) s_cnt[(cur_s * (NS - 1) + (si > cur_s ? si - 1 : si)) * 64 + lane] += 1u;
+        if (!KS && si >= 0) s_cnt[(cur_s * (NS - 1) + (si > cur_s ? si - 1 : si)) * 64 + lane] = (uint16_t)(s_cnt[(cur_s * (NS - 1) + (si > cur_s ? si - 1 : si)) * 64 + lane] + 1u);
         cur_s = si; cur_len = di;
       }
     }
