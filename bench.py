@@ -130,7 +130,7 @@ def main():
             class _Dev:
                 __cuda_array_interface__ = {"shape": (K, cols), "typestr": "<f8", "data": (red_ptr, False), "version": 3}
             total = torch.as_tensor(_Dev(), device=torch.device("cuda", local_rank))
-        except Exception:                                # no zero-copy view: one 30 KB host round trip instead
+        except (TypeError, ValueError, RuntimeError):    # no zero-copy view: one 30 KB host round trip instead
             eng.sync()
             total = torch.from_numpy(np.ascontiguousarray(eng.stats(W, K))).to(torch.device("cuda", local_rank))
         if backend != "nccl":
