@@ -353,7 +353,11 @@ void fill_tile_params(phm_engine* e, phm::TileParams<NS>& p, const phm_options& 
   p.n_tiles = e->tiles; p.n_rep = e->S; p.n_rep_pad = e->S_pad; p.replica_offset = o.replica_offset;
   p.normalise = normalised(e->variant); p.tips_per_replica = e->tips_per_replica ? 1 : 0;
   p.ks = ks_layout(e->variant); p.tip_masks = hidden_rates(e->variant); p.reduce = e->reduce; p.n_cols = e->dcols;
-  p.klong = e->nw_klong; p.n_chunks = (s.n_edge + phm::TILES_CHUNK - 1) / phm::TILES_CHUNK;
+  p.klong = e->nw_klong;
+  // branches per wave of the branch kernel: one while waves are scarce, up to 16 once there are 65 536 of them anyway
+  p.group = (int32_t)std::max<int64_t>(1, std::min<int64_t>(16, (int64_t)e->tiles * s.n_edge / 65536));
+  p.n_groups = (s.n_edge + p.group - 1) / p.group;
+  p.n_chunks = (p.n_groups + phm::TILES_CHUNK - 1) / phm::TILES_CHUNK;
   p.seed_lo = (uint32_t)(o.seed & 0xFFFFFFFFull); p.seed_hi = (uint32_t)(o.seed >> 32);
   p.rows = e->nw_total_cap;
   for (int i = 0; i < NS * NS; ++i) { p.B2[i] = e->hB2[i]; p.Bc[i] = e->hBc[i]; }

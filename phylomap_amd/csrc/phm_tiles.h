@@ -27,7 +27,7 @@
 namespace phm {
 
 constexpr int TILES_BLOCK = 256;          // four waves = four (tile, item) pairs per workgroup
-constexpr int TILES_CHUNK = 64;           // branches per first-stage partial sum of the dwell reduction
+constexpr int TILES_CHUNK = 64;           // group partials per second-stage sum of the dwell reduction
 constexpr int TILES_KTAB = 24;            // chain-table rows staged in LDS by the branch kernel (longer chains: full table in L2)
 
 template <int NS>
@@ -36,7 +36,8 @@ struct TileParams {
   int32_t n_tiles, n_rep, n_rep_pad, replica_offset;
   int32_t normalise, tips_per_replica, ks, tip_masks, reduce, n_cols;
   int32_t klong;                             // rows of the long chain tables
-  int32_t n_chunks;                          // ceil(n_edge / TILES_CHUNK)
+  int32_t group, n_groups;                   // branches walked by one wave of the branch kernel; ceil(n_edge / group)
+  int32_t n_chunks;                          // ceil(n_groups / TILES_CHUNK)
   uint32_t seed_lo, seed_hi;
   int64_t rows;                              // rows of one tile in one dwell buffer (sum of the slot sizes)
   double B2[NS * NS], Bc[NS * NS], scale[NS], pid[NS];
@@ -55,7 +56,7 @@ struct TileParams {
   uint8_t* estate;                           // [tile][n_edge][64]: parent-side state | child-side state << 4
   double* PL;                                // [tile][n_node][NS][64]
   uint8_t* nstate;                           // [tile][n_node][64]
-  double* pdw;                               // [tile][n_edge][NS][64] dwell sums of every branch
+  double* pdw;                               // [tile][n_edge][NS][64] dwell sums of every group of branches (n_groups rows used)
   double* pchunk;                            // [tile][n_chunks][NS][64] first-stage sums
   uint32_t* cnt;                             // [tile][NS*NS][64] transition counters of the sweep (integer atomics)
   uint32_t* pseg;                            // [tile][n_chunks][64] segments held by each chunk of branches after the sweep

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(TILES_BLOCK) void tiles_down_kernel(TileParams<NS> 
 // One branch for the 64 replicas of a tile: resamplebranchstates :264-308, shortener :44-73 (shortenerbf :997-1030),
 // virtual jumps sampleabranch :391-410, dwell sums updatedwelltimes :745-757.
 template <int NS, bool KS>
-__global__ __launch_bounds__(TILES_BLOCK) void tiles_branch_kernel(TileParams<NS> p, int it) {
+__global__ __launch_bounds__(TILES_BLOCK, 8) void tiles_branch_kernel(TileParams<NS> p, int it) {
   constexpr int NCNT = KS ? NS * NS : NS * (NS - 1);
   __shared__ double s_dw_all[(TILES_BLOCK / 64) * NS * 64];
   __shared__ uint16_t s_cnt_all[(TILES_BLOCK / 64) * NCNT * 64];      // counts of ONE branch (<= 65 535 segments): 16 bits keep the block under 20 KB of LDS, 8 waves per SIMD
@@ -137,14 +137,25 @@ __global__ __launch_bounds__(TILES_BLOCK) void tiles_branch_kernel(TileParams<NS
   if (threadIdx.x < NS * NS) s_B2[threadIdx.x] = p.B2[threadIdx.x];
   if (threadIdx.x < NS) s_scale[threadIdx.x] = p.scale[threadIdx.x];
   __syncthreads();
-  if (item >= p.n_edge * p.n_tiles) return;          // whole waves only; no barrier below this line
-  // neighbouring waves take the same branch of different tiles: similar run times inside a workgroup, longest branches first
+  if (item >= p.n_groups * p.n_tiles) return;        // whole waves only; no barrier below this line
+  // neighbouring waves take the same branches of different tiles: similar run times inside a workgroup, longest branches
+  // first.  A wave walks `group` consecutive entries of the order (1 when replicas are few, up to 16 when there are plenty of
+  // waves anyway) and writes ONE partial dwell sum for all of them.
   const int tile = item % p.n_tiles;
-  const int b = p.branch_order[item / p.n_tiles];
+  const int grp = item / p.n_tiles;
   double* s_dw = s_dw_all + wave * NS * 64;
   uint16_t* s_cnt = s_cnt_all + wave * NCNT * 64;
   const uint32_t rep = (uint32_t)(p.replica_offset + tile * 64 + lane);
   uint16_t* __restrict__ mct = p.mcount + (size_t)tile * p.n_edge * 64;
+  uint32_t* gc = p.cnt + ((size_t)tile * NS * NS) * 64 + lane;
+  uint32_t err = 0;
+#pragma unroll
+  for (int c = 0; c < NS; ++c) s_dw[c * 64 + lane] = 0.0;
+#pragma unroll
+  for (int c = 0; c < NCNT; ++c) s_cnt[c * 64 + lane] = (uint16_t)0;
+  const int q1 = min((grp + 1) * p.group, p.n_edge);
+  for (int q = grp * p.group; q < q1; ++q) {
+  const int b = p.branch_order[q];
   const int m = mct[b * 64 + lane];
   const int es = p.estate[((size_t)tile * p.n_edge + b) * 64 + lane];
   const int ps = es & 15, cs = es >> 4;
@@ -154,11 +165,6 @@ __global__ __launch_bounds__(TILES_BLOCK) void tiles_branch_kernel(TileParams<NS
   double* __restrict__ in = p.dw[it & 1] + ((size_t)tile * p.rows + roff) * 64;
   double* __restrict__ out = p.dw[(it & 1) ^ 1] + ((size_t)tile * p.rows + roff) * 64;
   auto IN = [&](int k) -> double& { return at(in, (uint32_t)k * 512u + lane8); };
-  uint32_t err = 0;
-#pragma unroll
-  for (int c = 0; c < NS; ++c) s_dw[c * 64 + lane] = 0.0;
-#pragma unroll
-  for (int c = 0; c < NCNT; ++c) s_cnt[c * 64 + lane] = (uint16_t)0;
 
   Stream su, se;
   su.open(ENT_BSTATE | (uint32_t)b, (uint32_t)it, rep, p.seed_lo, p.seed_hi);
@@ -309,24 +315,29 @@ __global__ __launch_bounds__(TILES_BLOCK) void tiles_branch_kernel(TileParams<NS
   if (mnew > cap) mnew = cap;
   if (mnew > 65535) { err |= DERR_CAPACITY; mnew = 65535; }
   mct[b * 64 + lane] = (uint16_t)mnew;
+  // the 16-bit counters hold one branch: hand them over (integer atomics, exact in any order) and clear them
+#pragma unroll
+  for (int c = 0; c < NCNT; ++c) {
+    const uint32_t v = s_cnt[c * 64 + lane];
+    if (v) { atomicAdd(gc + c * 64, v); s_cnt[c * 64 + lane] = (uint16_t)0; }
+  }
+  }      // next branch of the group
 
-  double* pd = p.pdw + (((size_t)tile * p.n_edge + b) * NS) * 64 + lane;
+  double* pd = p.pdw + (((size_t)tile * p.n_edge + grp) * NS) * 64 + lane;      // [tile][group][NS][64] (n_edge rows reserved)
 #pragma unroll
   for (int c = 0; c < NS; ++c) pd[c * 64] = s_dw[c * 64 + lane];
-  uint32_t* gc = p.cnt + ((size_t)tile * NS * NS) * 64 + lane;
-#pragma unroll
-  for (int c = 0; c < NCNT; ++c) { const uint32_t v = s_cnt[c * 64 + lane]; if (v) atomicAdd(gc + c * 64, v); }
   if (err) atomicOr(p.err, err);
 }
 
-// Dwell sums, first stage: a wave per (tile, chunk of TILES_CHUNK branches), branches added in edge order.
+// Dwell sums, second stage: a wave per (tile, chunk of TILES_CHUNK group partials), added in group order; the segments now
+// held by an equal share of the edges (for the read + written counter; one global atomic per wave would serialise).
 template <int NS>
 __global__ __launch_bounds__(TILES_BLOCK) void tiles_chunk_kernel(TileParams<NS> p) {
   const int lane = threadIdx.x & 63;
   const int item = blockIdx.x * (TILES_BLOCK / 64) + (threadIdx.x >> 6);
   if (item >= p.n_chunks * p.n_tiles) return;
   const int tile = item / p.n_chunks, chunk = item % p.n_chunks;
-  const int b0 = chunk * TILES_CHUNK, b1 = min(b0 + TILES_CHUNK, p.n_edge);
+  const int b0 = chunk * TILES_CHUNK, b1 = min(b0 + TILES_CHUNK, p.n_groups);
   double s[NS];
 #pragma unroll
   for (int c = 0; c < NS; ++c) s[c] = 0.0;
@@ -337,10 +348,10 @@ __global__ __launch_bounds__(TILES_BLOCK) void tiles_chunk_kernel(TileParams<NS>
   double* dst = p.pchunk + (((size_t)tile * p.n_chunks + chunk) * NS) * 64 + lane;
 #pragma unroll
   for (int c = 0; c < NS; ++c) dst[c * 64] = s[c];
-  // segments now held by these branches (for the read + written counter; one global atomic per wave would serialise)
   uint32_t segs = 0;
   const uint16_t* mc = p.mcount + ((size_t)tile * p.n_edge) * 64 + lane;
-  for (int b = b0; b < b1; ++b) segs += mc[(size_t)b * 64];
+  const int per = (p.n_edge + p.n_chunks - 1) / p.n_chunks;
+  for (int b = chunk * per; b < min((chunk + 1) * per, p.n_edge); ++b) segs += mc[(size_t)b * 64];
   p.pseg[((size_t)tile * p.n_chunks + chunk) * 64 + lane] = segs;
 }
 
@@ -426,8 +437,8 @@ hipError_t launch_tiles_sweep(const TileParams<NS>& p, const std::vector<int32_t
     const int n = down_off[l + 1] - down_off[l];
     if (n > 0) hipLaunchKernelGGL(tiles_down_kernel<NS>, blocks((int64_t)n * p.n_tiles), dim3(TILES_BLOCK), 0, stream, p, it, down_off[l], down_off[l + 1]);
   }
-  if (p.ks) hipLaunchKernelGGL((tiles_branch_kernel<NS, true>), blocks((int64_t)p.n_edge * p.n_tiles), dim3(TILES_BLOCK), 0, stream, p, it);
-  else hipLaunchKernelGGL((tiles_branch_kernel<NS, false>), blocks((int64_t)p.n_edge * p.n_tiles), dim3(TILES_BLOCK), 0, stream, p, it);
+  if (p.ks) hipLaunchKernelGGL((tiles_branch_kernel<NS, true>), blocks((int64_t)p.n_groups * p.n_tiles), dim3(TILES_BLOCK), 0, stream, p, it);
+  else hipLaunchKernelGGL((tiles_branch_kernel<NS, false>), blocks((int64_t)p.n_groups * p.n_tiles), dim3(TILES_BLOCK), 0, stream, p, it);
   hipLaunchKernelGGL(tiles_chunk_kernel<NS>, blocks((int64_t)p.n_chunks * p.n_tiles), dim3(TILES_BLOCK), 0, stream, p);
   if (p.ks) hipLaunchKernelGGL((tiles_stats_kernel<NS, true>), blocks(p.n_tiles), dim3(TILES_BLOCK), 0, stream, p, it);
   else hipLaunchKernelGGL((tiles_stats_kernel<NS, false>), blocks(p.n_tiles), dim3(TILES_BLOCK), 0, stream, p, it);
