@@ -10,12 +10,12 @@ namespace {
 
 // Automatic choice of the mapping (measured on C2, profiles/r01_probe_mapping.log; ms per sweep):
 //   chains                  1     32     64    256   1024   4096   16384   65536   131072   196608   327680   393216
-//   lane = branch         0.25   0.33   0.46   1.5    5.9    24
-//   wave = tile x branch         0.31   0.31   0.35   0.47   1.0     3.3    12.7     25.0   (does not fit)
-//   lane = replica        19.6                 22.2   26.3   27.6    27.3    28.6     34.5     41.0     49.2     54.7
+//   lane = branch         0.17   0.22   0.25   0.62   2.4    9.3
+//   wave = tile x branch         0.32   0.32   0.36   0.48   1.0     3.0    10.0     19.3    (28.5 at 182 GiB; 262 144: 37.5)
+//   lane = replica        19.0                 21.4   25.8   26.7    26.7    28.2     34.4     39.0     48.6     53.2
 // One lane per branch for a handful of chains; one wave per (tile, branch) as long as its slots fit in HBM; the replica
 // mapping (a single wave per tile, compact sequential streams) for the largest replica counts.
-constexpr int NARROW_AUTO_MAX_REPLICAS = 24;
+constexpr int NARROW_AUTO_MAX_REPLICAS = 95;
 constexpr int TILES_AUTO_MAX_REPLICAS = 262144;
 
 bool ks_layout(int v) { return v == PHM_MCMC_KS || v == PHM_MCMC_BF || v == PHM_MCMC_MT || v == PHM_MCMC_KSMT; }   // n x n counts, root column
