@@ -691,6 +691,28 @@ def test_full_size_invariants(mapping):
         np.testing.assert_allclose(outs[0][:, :4], lanes[:, :4], rtol=1e-10)
 
 
+@pytest.mark.parametrize("variant", ["bigtree", "ks"])
+def test_tiles_mapping_with_grouped_branches_matches_the_replica_mapping(variant):
+    """With many tiles a wave of the (tile, branch) kernel walks several consecutive branches and writes one partial dwell sum
+    for the group (phm_tiles.hip); 16 384 replicas on the C2 tree put 7 branches in a group.  The replica mapping (checked
+    against the oracle elsewhere) samples the same histories: every count equal, dwell sums equal to rounding -- per replica."""
+    z, Q, pid, Omega = synth.config_problem(2)
+    S, N = 16384, 4
+    v = _lib.PHM_MCMC_BIGTREE if variant == "bigtree" else _lib.PHM_MCMC_KS
+    n = Q.shape[0]
+    outs = {}
+    for mapping in ("tiles", "replicas"):
+        eng = _lib.Engine(z, Q, pid, Omega, N, variant=v, seed=11, n_replicas=S, reduce=False, mapping=mapping)
+        eng.run(N); eng.sync()
+        outs[mapping] = eng.stats(0, N)
+        eng.close()
+    a, b = outs["tiles"], outs["replicas"]
+    assert a.shape == b.shape and a.shape[0] == S
+    np.testing.assert_array_equal(a[:, :, n:], b[:, :, n:])
+    np.testing.assert_allclose(a[:, :, :n], b[:, :, :n], rtol=1e-10, atol=0)
+    np.testing.assert_allclose(a[:, :, :n].sum(2), z["edge.length"].sum(), rtol=1e-11)
+
+
 def test_errors_are_loud():
     z, Q, pid, Omega = _problem(4, 12, 1)
     with pytest.raises(_lib.PhmError) as e:
