@@ -42,11 +42,16 @@ __device__ __forceinline__ Lds stage_model(const WideBranchParams& p, unsigned c
 
 __global__ __launch_bounds__(WB_BLOCK) void wb_up_kernel(WideBranchParams p, int begin, int end) {
   extern __shared__ __align__(16) unsigned char smem[];
-  const int ell_w = p.ell_w;                 // the ELLPACK copy sits behind the model matrices (dynamic LDS, only when used)
-  double* s_eval = reinterpret_cast<double*>(smem + wb_model_lds_bytes(p.n_states, p.sparse != 0));
+  const int ell_w = p.ell_w;                 // sparse chain matrix: only its ELLPACK rows are staged; else the dense matrix
+  double* s_eval = reinterpret_cast<double*>(smem);
   int32_t* s_ecol = reinterpret_cast<int32_t*>(s_eval + p.n_states * ell_w);
-  for (int i = threadIdx.x; i < p.n_states * ell_w; i += WB_BLOCK) { s_ecol[i] = p.ell_col[i]; s_eval[i] = p.ell_val[i]; }
-  const Lds l = stage_model(p, smem);      // ends with a barrier
+  Lds l = {nullptr, nullptr, nullptr, 0};
+  if (ell_w > 0) {
+    for (int i = threadIdx.x; i < p.n_states * ell_w; i += WB_BLOCK) { s_ecol[i] = p.ell_col[i]; s_eval[i] = p.ell_val[i]; }
+    __syncthreads();
+  } else {
+    l = stage_model(p, smem);              // ends with a barrier
+  }
   const int n = p.n_states, lane = threadIdx.x & 63;
   const int idx = begin + blockIdx.x * (WB_BLOCK / 64) + (threadIdx.x >> 6);
   const int r = blockIdx.y;
@@ -136,11 +141,14 @@ __global__ __launch_bounds__(WB_BLOCK) void wb_branch_kernel(WideBranchParams p,
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ __align__(16) double s_ltab[2 * PHM_LOGTAB_N];        // (1/c_j, log c_j) of the exponential variates (neglog_u32)
   for (int i = threadIdx.x; i < 2 * PHM_LOGTAB_N; i += WB_BLOCK) s_ltab[i] = logtab_entry(i);
-  const int w2 = p.ell2_w;                   // ELLPACK rows of the forward-step matrix behind the model matrices (when used)
-  double* s_e2val = reinterpret_cast<double*>(smem + wb_model_lds_bytes(p.n_states, p.sparse != 0));
+  // This kernel touches one row of the forward-step matrix per draw: it reads that row from global memory (L2) instead of
+  // staging the whole matrix per workgroup -- n^2 loads for four waves that use a handful of rows -- which also leaves the
+  // LDS to the log table and the ELLPACK rows (when used), i.e. full occupancy.
+  const int w2 = p.ell2_w;
+  double* s_e2val = reinterpret_cast<double*>(smem);
   int32_t* s_e2col = reinterpret_cast<int32_t*>(s_e2val + p.n_states * w2);
   for (int i = threadIdx.x; i < p.n_states * w2; i += WB_BLOCK) { s_e2col[i] = p.ell2_col[i]; s_e2val[i] = p.ell2_val[i]; }
-  const Lds l = stage_model(p, smem);        // ends with a barrier
+  __syncthreads();
   const int n = p.n_states, lane = threadIdx.x & 63;
   const int idx = blockIdx.x * (WB_BLOCK / 64) + (threadIdx.x >> 6);
   const int r = blockIdx.y;
@@ -184,7 +192,7 @@ __global__ __launch_bounds__(WB_BLOCK) void wb_branch_kernel(WideBranchParams p,
         si = __builtin_amdgcn_readlane(mycol, t);
       } else {
         const double beta = p.colL[((size_t)kk * n + cs) * n + c];
-        const double pr = (lane < n) ? l.B2[cur_s * l.ldn + c] * beta : 0.0;
+        const double pr = (lane < n) ? p.B2[cur_s * n + c] * beta : 0.0;
         si = coop_sample(pr, su.draw((uint32_t)(i - 1)), n, lane, err);
       }
     }
@@ -220,7 +228,7 @@ __global__ __launch_bounds__(WB_BLOCK) void wb_branch_kernel(WideBranchParams p,
       if (lane == s) mine += len;
       ++mnew;
     } else {
-      const double scale = l.scale[s];
+      const double scale = p.scale[s];
       double tot = 0.0;
       while (tot < len) {
         if (!have_gen || edraw - gen_base >= 64u) {
@@ -298,21 +306,19 @@ hipError_t launch_wbranch_sweep(const WideBranchParams& p, const std::vector<int
   const unsigned S = (unsigned)p.n_rep;
   const size_t lds = wbranch_lds_bytes(p.n_states, p.sparse != 0);
   if (lds > 48 * 1024) {      // SPARSE with ~60 states: two copies of B
-    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(wb_up_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + (size_t)p.n_states * WB_ELL_MAX * 12));
-    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(wb_branch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + (size_t)p.n_states * WB_ELL_MAX * 12));
+    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(wb_up_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e1 != hipSuccess) return e1;
-    if (e2 != hipSuccess) return e2;
   }
   for (size_t l = 0; l + 1 < up_off.size(); ++l) {
     const int cnt = up_off[l + 1] - up_off[l];
-    if (cnt > 0) hipLaunchKernelGGL(wb_up_kernel, dim3((cnt + WPB - 1) / WPB, S), dim3(WB_BLOCK), lds + (size_t)p.n_states * p.ell_w * 12, stream, p, up_off[l], up_off[l + 1]);
+    if (cnt > 0) hipLaunchKernelGGL(wb_up_kernel, dim3((cnt + WPB - 1) / WPB, S), dim3(WB_BLOCK), p.ell_w > 0 ? (size_t)p.n_states * p.ell_w * 12 : lds, stream, p, up_off[l], up_off[l + 1]);
   }
   hipLaunchKernelGGL(wb_root_kernel, dim3((S + WPB - 1) / WPB), dim3(WB_BLOCK), 0, stream, p, it);
   for (size_t l = 0; l + 1 < down_off.size(); ++l) {
     const int cnt = down_off[l + 1] - down_off[l];
     if (cnt > 0) hipLaunchKernelGGL(wb_down_kernel, dim3((cnt + WPB - 1) / WPB, S), dim3(WB_BLOCK), 0, stream, p, it, down_off[l], down_off[l + 1]);
   }
-  hipLaunchKernelGGL(wb_branch_kernel, dim3((p.n_edge + WPB - 1) / WPB, S), dim3(WB_BLOCK), lds + (size_t)p.n_states * p.ell2_w * 12, stream, p, it);
+  hipLaunchKernelGGL(wb_branch_kernel, dim3((p.n_edge + WPB - 1) / WPB, S), dim3(WB_BLOCK), (size_t)p.n_states * p.ell2_w * 12, stream, p, it);
   hipLaunchKernelGGL(wb_stats_kernel, dim3(S), dim3(256), sizeof(double) * WB_STATS_CHUNK * (p.n_states + 1), stream, p);
   const int64_t items = (int64_t)(p.reduce ? p.n_tiles : p.n_rep) * p.n_cols;
   hipLaunchKernelGGL(wb_emit_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, p, it);
