@@ -246,7 +246,9 @@ int32_t phm_engine_sync(phm_engine* e);
  * reduce = 1: one n x cols column-major matrix (sum over replicas) */
 int32_t phm_engine_read_stats(phm_engine* e, int32_t iter0, int32_t n, double* out);
 /* reduce = 1 only: run the tile reduction on `hip_stream` and return a DEVICE pointer to n x cols doubles,
- * row-major [iteration][column] (for handing to RCCL without a host round trip); valid until the next call */
+ * row-major [iteration][column] (for handing to RCCL without a host round trip).  The buffer belongs to this entry point
+ * alone: it stays as the caller (or an in-place all-reduce) left it until the next phm_engine_reduced_stats_device call;
+ * phm_engine_read_stats does not touch it */
 int32_t phm_engine_reduced_stats_device(phm_engine* e, int32_t iter0, int32_t n, void* hip_stream, void** out_dev);
 /* measurement aid: HIP-event time (ms) of n_iters repetitions of the pruning sweep alone (makePLrcpp*,
  * src/phylomap.cpp:503-529) on the current chain state; segment counts and paths are not modified */

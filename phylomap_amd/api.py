@@ -160,13 +160,14 @@ def eigen_decompose(Q):
     return lefts, rights, np.diag(np.real(vals))
 
 
-def sumstatEXP(z, Q, pid, N, **opt):
-    """R/sumstatEXP.R:21-33 -> phm_maketreelistEXP."""
+def sumstatEXP(z, Q, pid, N, eig=None, **opt):
+    """R/sumstatEXP.R:21-33 -> phm_maketreelistEXP.  ``eig`` = (lefts, rights, d) overrides the eigendecomposition
+    R/sumstatEXP.R:26-29 computes (LAPACK results differ between machines in the last bits)."""
     L = _lib.load()
     Q = np.asfortranarray(np.asarray(Q, dtype=np.float64))
     n = Q.shape[0]
     nen, nodelist, root = _lib.tree_orders(z)
-    lefts, rights, d = (np.asfortranarray(a) for a in eigen_decompose(Q))
+    lefts, rights, d = (np.asfortranarray(np.asarray(a, dtype=np.float64)) for a in (eigen_decompose(Q) if eig is None else eig))
     pid = np.ascontiguousarray(pid, dtype=np.float64)
     ft = _lib.FlatTree(z)
     o = _lib.make_options(**opt)

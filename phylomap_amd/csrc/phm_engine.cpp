@@ -1019,9 +1019,12 @@ extern "C" int32_t phm_engine_reduced_stats_device(phm_engine* e, int32_t iter0,
   if (!e->reduce) return fail(PHM_ERR_STATE, "engine was not created with reduce = 1");
   if (iter0 < 0 || n < 1 || iter0 + n > e->iters_done) return fail(PHM_ERR_STATE, "statistics requested for iterations that have not run");
   HIPCHK(hipSetDevice(e->device));
+  // its own buffer: phm_engine_read_stats reduces into d_red, which must not overwrite a matrix the caller has already
+  // handed to (and had all-reduced in place by) RCCL
+  if (!e->d_red_out.p) HIPCHK(e->d_red_out.alloc(sizeof(double) * (size_t)e->max_iters * e->dcols));
   HIPCHK(phm::launch_stats_reduce(e->d_stats.as<double>() + (size_t)iter0 * e->tiles * e->dcols, n, e->tiles, e->dcols,
-                                    e->d_red.as<double>(), reinterpret_cast<hipStream_t>(hip_stream)));
-  *out_dev = e->d_red.p;
+                                    e->d_red_out.as<double>(), reinterpret_cast<hipStream_t>(hip_stream)));
+  *out_dev = e->d_red_out.p;
   return PHM_OK;
 }
 

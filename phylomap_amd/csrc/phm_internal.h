@@ -40,7 +40,15 @@ struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;
   ~DevBuf() { if (p) (void)hipFree(p); }
-  hipError_t alloc(size_t n) { bytes = n; return hipMalloc(&p, n ? n : 16); }
+  void reset() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+  // re-allocating frees the previous block first (the automatic mapping fallback of phm_engine_create_multi sets the same
+  // members up again after an out-of-memory attempt)
+  hipError_t alloc(size_t n) {
+    reset();
+    hipError_t e = hipMalloc(&p, n ? n : 16);
+    if (e == hipSuccess) bytes = n; else p = nullptr;
+    return e;
+  }
   template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
@@ -145,7 +153,7 @@ struct phm_engine {
   bool tips_per_replica = false;
   int64_t rows = 0;
   DevBuf d_mask;
-  DevBuf d_up, d_down, d_col, d_row, d_tips, d_mcount, d_dw0, d_dw1, d_cursor, d_PL, d_nstate, d_stats, d_err, d_seg, d_red;
+  DevBuf d_up, d_down, d_col, d_row, d_tips, d_mcount, d_dw0, d_dw1, d_cursor, d_PL, d_nstate, d_stats, d_err, d_seg, d_red, d_red_out;
   phm::McmcParams<2> p2;
   phm::McmcParams<3> p3;
   phm::McmcParams<4> p4;

@@ -1,0 +1,175 @@
+"""Every BASELINE.json configuration at its STATED size on the GPU, against the CPU oracle.
+
+C1 100 tips / 2 states / sumstatEXP; C2 1 000 tips / 4 states / sumstatMCMC; C3 10 000 tips / 4 states /
+sumstatMCMC_bigtree (src/phylomap.cpp:942-986); C4 500 tips / dense 61-state Q; C5 5 000 tips / sparse 20-state Q
+(SPARSEsumstatMCMC, src/phylomap.cpp:822-870).  Per configuration: >= 8 sweeps, replicas {0, 63, last} against
+`O.maketreelistMCMC` (counts array_equal, dwell <= 1e-10), a chain-state dump of one replica, and every mapping that
+serves the state count.  The golden fixtures of tests/golden/ are replayed through the C-ABI as well."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from phylomap_amd import _lib, api, synth, treeorder
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_CACHE = {}
+
+
+def _config(cfg):
+    """(z, Q, pid, Omega, nen, nodelist, root) of a BASELINE configuration; built once per session."""
+    if cfg not in _CACHE:
+        z, Q, pid, Omega = synth.config_problem(cfg)
+        _CACHE[cfg] = (z, Q, pid, Omega, treeorder.pruningwiseedgeorder(z), treeorder.makenodelist(z), treeorder.myreorder(z))
+    return _CACHE[cfg]
+
+
+def _check_rows(got, want, n, exact_dwell):
+    np.testing.assert_array_equal(got[:, n:], want[:, n:])            # transition counts: bit-exact
+    if exact_dwell:
+        np.testing.assert_array_equal(got[:, :n], want[:, :n])
+    else:
+        np.testing.assert_allclose(got[:, :n], want[:, :n], rtol=1e-10, atol=0)
+
+
+def _check_dump(d, dump):
+    np.testing.assert_array_equal(d["seg_count"], dump.seg_count)
+    np.testing.assert_array_equal(d["node_states"], dump.node_states)
+    np.testing.assert_array_equal(d["PL"], dump.PL)
+    for b in range(len(dump.seg_count)):
+        np.testing.assert_array_equal(d["seg_dwell"][b, :dump.seg_count[b]], dump.seg_dwell[b, :dump.seg_count[b]])
+
+
+def _run_config(cfg, variant, orc_variant, mapping, S, N, seed, exact_dwell, dump_replica=None, **opt):
+    z, Q, pid, Omega, nen, nodelist, root = _config(cfg)
+    n = Q.shape[0]
+    B = np.eye(n) + Q / Omega
+    eng = _lib.Engine(z, Q, pid, Omega, N, variant=variant, seed=seed, n_replicas=S, mapping=mapping, **opt)
+    eng.run(N); eng.sync()
+    st = eng.stats(0, N)
+    assert st.shape == (S, N, n + n * (n - 1))
+    for r in sorted({0, min(63, S - 1), S - 1}):
+        want, rc = O.maketreelistMCMC(z, Q, pid, B, Omega, nen, nodelist, root, N, variant=orc_variant, seed=seed, replica=r)
+        assert rc == 0
+        _check_rows(st[r], want, n, exact_dwell)
+    np.testing.assert_allclose(st[:, :, :n].sum(2), z["edge.length"].sum(), rtol=1e-11)      # every replica, every sweep
+    if dump_replica is not None:
+        _, rc, dump = O.maketreelistMCMC(z, Q, pid, B, Omega, nen, nodelist, root, N, variant=orc_variant, seed=seed,
+                                         replica=dump_replica, dump=True)
+        assert rc == 0
+        _check_dump(eng.dump(dump_replica), dump)
+    eng.close()
+    return st
+
+
+def test_c1_sumstatEXP_100_tips():
+    """C1: simulate_2_state_tree-shaped problem, ~100 tips, sumstatEXP (src/phylomap.cpp:3001-3051)."""
+    z, Q, pid, Omega, nen, nodelist, root = _config(1)
+    lefts, rights, d = api.eigen_decompose(Q)
+    N = 256
+    got = api.sumstatEXP(z, Q, pid, N, seed=11)
+    want, rc = O.maketreelistEXP(z, Q, pid, nen, nodelist, root, N, lefts, rights, d, seed=11)
+    assert rc == 0 and got.shape == (N, 4)
+    np.testing.assert_array_equal(got[:, 2:], want[:, 2:])
+    np.testing.assert_allclose(got[:, :2], want[:, :2], rtol=1e-10, atol=0)
+    np.testing.assert_allclose(got[:, :2].sum(1), z["edge.length"].sum(), rtol=1e-12)
+    # the same tree through the MCMC drivers (the configuration's tree is small enough for the plain variant)
+    for mapping in ("replicas", "branches", "tiles"):
+        gm = api.sumstatMCMC(z, Q, pid, Omega, 16, seed=5, n_replicas=2, mapping=mapping)
+        for r in range(2):
+            wm, rc = O.maketreelistMCMC(z, Q, pid, np.eye(2) + Q / Omega, Omega, nen, nodelist, root, 16, seed=5, replica=r)
+            assert rc == 0
+            _check_rows(gm[r], wm, 2, mapping == "replicas")
+
+
+@pytest.mark.parametrize("mapping", ["replicas", "tiles", "branches"])
+def test_c2_sumstatMCMC_1000_tips(mapping):
+    S = {"replicas": 128, "tiles": 128, "branches": 3}[mapping]
+    _run_config(2, _lib.PHM_MCMC_BIGTREE, O.BIGTREE, mapping, S, 10, 2024, mapping == "replicas", dump_replica=S - 1)
+
+
+def test_c3_bigtree_10000_tips_replica_mapping():
+    """C3 as stated (4 states, 10 000 tips, _bigtree): the streaming layout, one ring per tile."""
+    _run_config(3, _lib.PHM_MCMC_BIGTREE, O.BIGTREE, "replicas", 128, 8, 31337, True, dump_replica=127, storage=1)
+
+
+def test_c3_bigtree_10000_tips_tiles_mapping_with_grouped_branches():
+    """1 024 replicas = 16 tiles x 19 998 branches: tiles_branch_kernel walks 4 branches per wave (group > 1); every replica
+    is compared with the replica mapping, replicas {0, 63, 1023} with the oracle, one replica's chain state dumped."""
+    z, Q, pid, Omega = _config(3)[:4]
+    S, N, seed = 1024, 8, 31337
+    st = _run_config(3, _lib.PHM_MCMC_BIGTREE, O.BIGTREE, "tiles", S, N, seed, False, dump_replica=1000)
+    eng = _lib.Engine(z, Q, pid, Omega, N, variant=_lib.PHM_MCMC_BIGTREE, seed=seed, n_replicas=S, mapping="replicas", storage=1)
+    eng.run(N); eng.sync()
+    ref = eng.stats(0, N)
+    eng.close()
+    np.testing.assert_array_equal(st[:, :, 4:], ref[:, :, 4:])
+    np.testing.assert_allclose(st[:, :, :4], ref[:, :, :4], rtol=1e-10, atol=0)
+
+
+def test_c3_one_chain_branch_mapping():
+    """the reference's own calling pattern on C3: ONE chain (R/sumstatMCMC_bigtree.R), lane = branch"""
+    _run_config(3, _lib.PHM_MCMC_BIGTREE, O.BIGTREE, "branches", 1, 8, 99, False, dump_replica=0)
+
+
+WIDE_MAPPINGS = ["replicas", "branches", "tiles"]
+
+
+@pytest.mark.parametrize("mapping", WIDE_MAPPINGS)
+def test_c4_dense_61_states_500_tips(mapping):
+    """C4: dense 61-state Q on a 500-tip tree (row-normalised pruning: 61-state partial likelihoods underflow without)."""
+    S = {"replicas": 128, "branches": 66, "tiles": 128}[mapping]
+    _run_config(4, _lib.PHM_MCMC_BIGTREE, O.BIGTREE, mapping, S, 8, 4242, False, dump_replica=S - 1)
+
+
+@pytest.mark.parametrize("mapping", WIDE_MAPPINGS)
+def test_c5_sparse_20_states_5000_tips(mapping):
+    """C5: tridiagonal 20-state Q on a 5 000-tip tree.  SPARSEsumstatMCMC has no rescaling (src/phylomap.cpp:490-501), so at
+    this size the reference's arithmetic underflows -- oracle and GPU must both say so -- and the sweep itself is checked
+    with the row-normalised pruning on the same sparse matrix (no entry of this B is below the 1e-7 threshold of :811, so
+    the thresholded and the dense matrix coincide and every other step is the SPARSE driver's)."""
+    z, Q, pid, Omega, nen, nodelist, root = _config(5)
+    _, rc = O.maketreelistMCMC(z, Q, pid, np.eye(20) + Q / Omega, Omega, nen, nodelist, root, 2, variant=O.SPARSE, seed=1)
+    assert rc & O.ERR_ZERO_PROB
+    with pytest.raises(_lib.PhmError) as e:
+        api.SPARSEsumstatMCMC(z, Q, pid, Omega, 2, seed=1, n_replicas=2, mapping=mapping)
+    assert e.value.status == 5
+    S = {"replicas": 128, "branches": 66, "tiles": 128}[mapping]
+    _run_config(5, _lib.PHM_MCMC_BIGTREE, O.BIGTREE, mapping, S, 8, 5151, False, dump_replica=S - 1)
+
+
+@pytest.mark.parametrize("mapping", WIDE_MAPPINGS)
+def test_c5_sparse_variant_on_the_largest_tree_it_survives(mapping):
+    """the SPARSE driver proper (thresholded chain matrix, dense forward rows, no rescaling) on a 200-tip tree"""
+    z, Q, pid, Omega = synth.config_problem(5, n_tips=200)
+    nen, nodelist, root = treeorder.pruningwiseedgeorder(z), treeorder.makenodelist(z), treeorder.myreorder(z)
+    N, S, seed = 8, 70, 77
+    got = api.SPARSEsumstatMCMC(z, Q, pid, Omega, N, seed=seed, n_replicas=S, mapping=mapping)
+    for r in (0, 63, S - 1):
+        want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(20) + Q / Omega, Omega, nen, nodelist, root, N, variant=O.SPARSE,
+                                      seed=seed, replica=r)
+        assert rc == 0
+        _check_rows(got[r], want, 20, False)
+
+
+@pytest.mark.parametrize("name", ["n2_t16", "n3_t16", "n4_t16", "n4_t64", "n20_t12"])
+def test_golden_fixtures_through_the_c_abi(name):
+    """tests/golden/*.npz (inputs + expected matrices, generated by tests/golden/make_golden.py) replayed on the GPU"""
+    from golden.make_golden import unpack_tree
+    g = np.load(os.path.join(HERE, "golden", name + ".npz"))
+    z = unpack_tree(g)
+    Q, pid, Omega, seed = g["Q"], g["pid"], float(g["Omega"]), int(g["seed"])
+    n = Q.shape[0]
+    mappings = ["replicas", "branches", "tiles"]
+    for key, fn in (("mcmc", api.sumstatMCMC), ("bigtree", api.sumstatMCMC_bigtree), ("sparse", api.SPARSEsumstatMCMC)):
+        for mapping in mappings:
+            got = fn(z, Q, pid, Omega, 24, seed=seed, n_replicas=6, mapping=mapping)
+            for r in (0, 5):
+                _check_rows(got[r], g[f"{key}_r{r}"], n, mapping == "replicas" and n <= 4)
+    if "exp_r0" in g.files:
+        got = api.sumstatEXP(z, Q, pid, int(g["exp_r0"].shape[0]), seed=seed, eig=(g["lefts"], g["rights"], g["d"]))
+        np.testing.assert_array_equal(got[:, n:], g["exp_r0"][:, n:])
+        np.testing.assert_allclose(got[:, :n], g["exp_r0"][:, :n], rtol=1e-10, atol=0)
