@@ -1,22 +1,31 @@
 # Builds the HIP library (C-ABI: include/phylomap_hip.h) and the CPU oracle.
-# -ffp-contract=off is part of the arithmetic spec (no fused multiply-add on either side).
+# -ffp-contract=off is part of the arithmetic spec (no fused multiply-add on either side unless written as one).
+# One object per source so that `make -j` compiles the kernels side by side.
 HIPCC   ?= /opt/rocm/bin/hipcc
 ARCH    ?= gfx950
 CSRC    := phylomap_amd/csrc
 LIB     := phylomap_amd/libphylomap_hip.so
-SRCS    := $(CSRC)/phm_engine.cpp $(CSRC)/phm_drivers.cpp $(CSRC)/phm_expm_api.cpp $(CSRC)/phm_sched.cpp $(CSRC)/phm_qupdate.cpp $(CSRC)/phm_mcmc.hip $(CSRC)/phm_wide.hip $(CSRC)/phm_narrow.hip $(CSRC)/phm_tiles.hip $(CSRC)/phm_wbranch.hip $(CSRC)/phm_exp.hip
+OBJDIR  := build/obj
+SRCS    := $(CSRC)/phm_engine.cpp $(CSRC)/phm_drivers.cpp $(CSRC)/phm_expm_api.cpp $(CSRC)/phm_sched.cpp $(CSRC)/phm_qupdate.cpp $(CSRC)/phm_mcmc.hip $(CSRC)/phm_wide.hip $(CSRC)/phm_narrow.hip $(CSRC)/phm_tiles.hip $(CSRC)/phm_wbranch.hip $(CSRC)/phm_wtiles.hip $(CSRC)/phm_exp.hip
+OBJS    := $(patsubst $(CSRC)/%,$(OBJDIR)/%.o,$(SRCS))
 HDRS    := $(wildcard $(CSRC)/*.h) include/phylomap_hip.h
 FLAGS   := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function
 
-all: $(LIB) oracle
+all:
+	$(MAKE) -j8 $(LIB)
+	$(MAKE) oracle
 
-$(LIB): $(SRCS) $(HDRS)
-	$(HIPCC) $(FLAGS) -x hip -shared -o $@ $(SRCS)
+$(OBJDIR)/%.o: $(CSRC)/% $(HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(FLAGS) -x hip -c -o $@ $<
+
+$(LIB): $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
 
 oracle:
 	$(MAKE) -C oracle
 
 clean:
-	rm -f $(LIB); $(MAKE) -C oracle clean
+	rm -rf $(LIB) build; $(MAKE) -C oracle clean
 
 .PHONY: all oracle clean

@@ -280,13 +280,48 @@ static void matTvec(const double* M, const double* x, double* y, int n) {
     y[c] = acc;
   }
 }
+/*
+ * Mat-vec of the MCMC sweep (chains of B).  n <= 4: Armadillo's gemv_emul_tinysq, i.e. the unfused left-to-right sums above.
+ * n > 4: the reference calls BLAS dgemv, whose summation order is unknowable, so the spec is the order
+ * the MI355X matrix cores produce: one FUSED multiply-add per term, j ascending, starting from +0
+ * (v_mfma_f64_16x16x4 accumulates its k-slices exactly like this; orc_matexp_fma is the precedent).
+ */
+static void mcmc_matvec(const double* M, const double* x, double* y, int n) {
+  if (n <= 4) { matvec(M, x, y, n); return; }
+  for (int i = 0; i < n; ++i) {
+    double acc = 0.0;
+    for (int j = 0; j < n; ++j) acc = fma(M[i * n + j], x[j], acc);
+    y[i] = acc;
+  }
+}
+static void mcmc_matTvec(const double* M, const double* x, double* y, int n) {
+  if (n <= 4) { matTvec(M, x, y, n); return; }
+  for (int c = 0; c < n; ++c) {
+    double acc = 0.0;
+    for (int r = 0; r < n; ++r) acc = fma(M[r * n + c], x[r], acc);
+    y[c] = acc;
+  }
+}
+/* Sum of a partial-likelihood row for the normalisation of :525.  n <= 4: left to right.  n > 4: four interleaved partial
+ * sums t_g = p_g + p_{g+4} + p_{g+8} + ... (ascending), combined as (t_0 + t_1) + (t_2 + t_3) -- the order in which the
+ * accumulator tiles of the matrix cores hold a column (rows g, g+4, ... in lane group g). */
+static double mcmc_rowsum(const double* p, int n) {
+  if (n <= 4) {
+    double s = p[0];
+    for (int c = 1; c < n; ++c) s += p[c];
+    return s;
+  }
+  double t[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int c = 0; c < n; ++c) t[c & 3] += p[c];
+  return (t[0] + t[1]) + (t[2] + t[3]);
+}
 /* v <- M^k v : mmmmvFORpl / spmmmmvFORpl, src/phylomap.cpp:446-457 */
 static void chain(const double* M, double* v, int k, int n, double* tmp) {
-  for (int i = 0; i < k; ++i) { matvec(M, v, tmp, n); memcpy(v, tmp, sizeof(double) * n); }
+  for (int i = 0; i < k; ++i) { mcmc_matvec(M, v, tmp, n); memcpy(v, tmp, sizeof(double) * n); }
 }
 /* v <- (M^T)^k v : Tvmmp / spvmmmm, src/phylomap.cpp:431-444 */
 static void chainT(const double* M, double* v, int k, int n, double* tmp) {
-  for (int i = 0; i < k; ++i) { matTvec(M, v, tmp, n); memcpy(v, tmp, sizeof(double) * n); }
+  for (int i = 0; i < k; ++i) { mcmc_matTvec(M, v, tmp, n); memcpy(v, tmp, sizeof(double) * n); }
 }
 
 /*
@@ -390,7 +425,7 @@ static void resamplebranchstates(Branch* br, const double* Bchain, const double*
   double* p = scratch + (size_t)n * ss;
   for (int i = 0; i < n; ++i) bpws[i] = 0.0;
   bpws[br->s[ss - 1]] = 1.0;                                   /* :280 */
-  for (int j = 1; j < ss - 1; ++j) matvec(Bchain, bpws + (size_t)(j - 1) * n, bpws + (size_t)j * n, n);   /* :290 */
+  for (int j = 1; j < ss - 1; ++j) mcmc_matvec(Bchain, bpws + (size_t)(j - 1) * n, bpws + (size_t)j * n, n);   /* :290 */
   for (int i = 1; i < ss - 1; ++i) {
     const double* row = Brow + (size_t)br->s[i - 1] * n;
     const double* beta = bpws + (size_t)(ss - i - 1) * n;
@@ -481,8 +516,7 @@ static void makePL(const int32_t* edge1, const int32_t* edge2, int Nnode, double
     double* row = PL + (size_t)(edge1[ea] - 1) * n;
     for (int c = 0; c < n; ++c) row[c] = first[c] * second[c];               /* :510 */
     if (normalise) {                                                         /* :525 */
-      double s = row[0];
-      for (int c = 1; c < n; ++c) s += row[c];
+      double s = mcmc_rowsum(row, n);
       for (int c = 0; c < n; ++c) row[c] = row[c] / s;
     }
   }

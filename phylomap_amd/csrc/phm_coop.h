@@ -1,6 +1,8 @@
-// phm_coop.h -- wave-cooperative n-vector primitives of the 5..64-state kernels: one STATE per lane, scalars broadcast
-// with v_readlane.  Summation orders are the spec's left-to-right ones (lane c accumulates while x_j is broadcast with j
-// ascending; prefix sums of a probability vector are formed in index order), so results equal the oracle bit for bit.
+// phm_coop.h -- wave-cooperative n-vector primitives of the 5..64-state kernels that keep one STATE per lane (phm_wbranch.hip,
+// phm_wide.hip), scalars broadcast with v_readlane.  Arithmetic = the n > 4 spec of DESIGN.md section 2: a chain product is
+// one FUSED multiply-add per term with j ascending from +0 (what the matrix cores compute in phm_wtiles.hip), the
+// normalisation sum is four interleaved partial sums combined pairwise, prefix sums of a probability vector are formed in
+// index order, unfused -- so results equal the oracle bit for bit.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -27,18 +29,18 @@ __device__ __forceinline__ int wave_max_w(int v) {
 // (stride ldn doubles) fall on distinct banks, and the transposed access M[q][c] is contiguous anyway
 __device__ __forceinline__ double coop_matvec(const double* __restrict__ M, double v, int n, int ldn, int c) {
   const double* row = M + c * ldn;
-  double acc = row[0] * readlane_f64(v, 0);
-  for (int j = 1; j < n; ++j) acc += row[j] * readlane_f64(v, j);
+  double acc = 0.0;
+  for (int j = 0; j < n; ++j) acc = __builtin_fma(row[j], readlane_f64(v, j), acc);
   return acc;
 }
 
 // the same product for a matrix with at most w non-zeros per row, kept in ELLPACK form (columns ascending; padding entries
-// have value 0): lane c gathers v[col] of its own non-zeros.  Skipping the exact zeros of a row leaves its left-to-right sum
-// unchanged bit for bit -- every term is a product of non-negative finite numbers, so the skipped terms are +0.
+// have value 0): lane c gathers v[col] of its own non-zeros.  Skipping the exact zeros of a row leaves its fused chain
+// unchanged bit for bit -- fma(0, x, acc) = acc for finite x.
 __device__ __forceinline__ double coop_matvec_ell(const int32_t* __restrict__ ecol, const double* __restrict__ eval, double v,
                                                   int w, int c) {
-  double acc = eval[c * w] * __shfl(v, ecol[c * w], 64);
-  for (int t = 1; t < w; ++t) acc += eval[c * w + t] * __shfl(v, ecol[c * w + t], 64);
+  double acc = 0.0;
+  for (int t = 0; t < w; ++t) acc = __builtin_fma(eval[c * w + t], __shfl(v, ecol[c * w + t], 64), acc);
   return acc;
 }
 
@@ -57,10 +59,16 @@ __device__ __forceinline__ int coop_sample(double p, double u, int n, int lane, 
   return idx < n ? idx : n - 1;
 }
 
+// normalisation sum of a partial-likelihood row (:525): t_g = x_g + x_{g+4} + ... (ascending), then (t_0 + t_1) + (t_2 + t_3)
 __device__ __forceinline__ double coop_sum(double x, int n) {
-  double run = readlane_f64(x, 0);
-  for (int j = 1; j < n; ++j) run += readlane_f64(x, j);
-  return run;
+  double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+  for (int j = 0; j < n; j += 4) {
+    t0 += readlane_f64(x, j);
+    if (j + 1 < n) t1 += readlane_f64(x, j + 1);
+    if (j + 2 < n) t2 += readlane_f64(x, j + 2);
+    if (j + 3 < n) t3 += readlane_f64(x, j + 3);
+  }
+  return (t0 + t1) + (t2 + t3);
 }
 
 }  // namespace phm

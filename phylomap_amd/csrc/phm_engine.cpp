@@ -17,6 +17,7 @@ namespace {
 // mapping (a single wave per tile, compact sequential streams) for the largest replica counts.
 constexpr int NARROW_AUTO_MAX_REPLICAS = 95;
 constexpr int TILES_AUTO_MAX_REPLICAS = 262144;
+constexpr int WBRANCH_AUTO_MAX_REPLICAS = 32;     // 5..64 states: up to here a wave per (replica, branch), beyond it lanes = replicas
 
 bool ks_layout(int v) { return v == PHM_MCMC_KS || v == PHM_MCMC_BF || v == PHM_MCMC_MT || v == PHM_MCMC_KSMT; }   // n x n counts, root column
 bool hidden_rates(int v) { return v == PHM_MCMC_KS || v == PHM_MCMC_KSMT; }                                         // parity tip masks
@@ -85,15 +86,25 @@ int32_t upload_model(phm_engine* e) {
   std::vector<double> maskpow((size_t)ktab * 2 * n, 0.0);      // ks: Bc^k applied to the even / odd state masks (:1838-1845)
   for (int par = 0; par < 2; ++par) {
     for (int c = 0; c < n; ++c) maskpow[(size_t)par * n + c] = ((c & 1) == par) ? 1.0 : 0.0;
-    for (int k = 1; k < ktab; ++k) {
-      const double* v = &maskpow[((size_t)(k - 1) * 2 + par) * n];
-      double* y = &maskpow[((size_t)k * 2 + par) * n];
-      for (int i = 0; i < n; ++i) {
-        double acc = Bc[i * n] * v[0];
-        for (int c = 1; c < n; ++c) acc += Bc[i * n + c] * v[c];
-        y[i] = acc;
-      }
-    }
+    for (int k = 1; k < ktab; ++k)
+      host_chain_matvec(Bc, n, &maskpow[((size_t)(k - 1) * 2 + par) * n], &maskpow[((size_t)k * 2 + par) * n]);
+  }
+  if (e->tiled && e->wide) {        // phm_wtiles.hip: table rows padded to an even length (16-byte rows), model in global memory
+    const int ldt = e->pwt.ldt;
+    auto padded = [&](const std::vector<double>& src, size_t rows) {
+      std::vector<double> dst(rows * ldt, 0.0);
+      for (size_t r = 0; r < rows; ++r) std::memcpy(&dst[r * ldt], &src[r * n], sizeof(double) * n);
+      return dst;
+    };
+    const std::vector<double> colp = padded(col, (size_t)ktab * n), rowp = padded(row, (size_t)ktab * n),
+                              maskp = padded(maskpow, (size_t)ktab * 2), b2p = padded(e->hB2, (size_t)n);
+    HIPCHK(hipMemcpy(e->d_nw_colL.p, colp.data(), sizeof(double) * colp.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_nw_rowL.p, rowp.data(), sizeof(double) * rowp.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_nw_maskL.p, maskp.data(), sizeof(double) * maskp.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_wt_B2.p, b2p.data(), sizeof(double) * b2p.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_Bc.p, e->hBc.data(), sizeof(double) * n * n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_scale.p, e->hscale.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+    return PHM_OK;
   }
   if (e->narrow || e->tiled) {      // tables long enough for every possible segment count, read from global memory / L2
     HIPCHK(hipMemcpy(e->d_nw_colL.p, col.data(), sizeof(double) * col.size(), hipMemcpyHostToDevice));
@@ -478,6 +489,138 @@ int32_t tiles_setup(phm_engine* e, const phm_tree* x, const phm_model* model, co
   return PHM_OK;
 }
 
+// Engine state of the lane-per-replica mapping for 5..64 states (phm_wtiles.hip): the slot layout of tiles_setup, the
+// statistics in integer accumulators per tile.
+int32_t wtiles_setup(phm_engine* e, const phm_tree* x, const phm_model* model, const phm_options& o, int32_t max_iters) {
+  const phm::Schedule& s = e->sched;
+  const int E = s.n_edge, T = s.n_tips, Nn = s.n_node, n = e->n, tiles = e->tiles;
+  const double tail = o.cap_tail > 0.0 ? o.cap_tail : 1e-12;
+  e->tl_slot.assign(E + 1, 0);
+  std::vector<int32_t> cap(E);
+  int max_cap = 0;
+  int64_t rows = 0;
+  double tree_len = 0.0;
+  for (int b = 0; b < E; ++b) {
+    double tb = 0.0;
+    for (int i = x->map_off[b]; i < x->map_off[b + 1]; ++i) tb += x->maps[i];
+    tree_len += tb;
+    const int m0 = x->map_off[b + 1] - x->map_off[b];
+    const int q = phm::poisson_capacity(model->Omega * tb, tail);
+    cap[b] = std::max(q, m0 + q - 1) + 2;
+    if (cap[b] >= (1 << 23)) return fail(PHM_ERR_UNSUPPORTED, "branch too long: a slot of the (tile, branch) mapping exceeds 4 GB");
+    max_cap = std::max(max_cap, cap[b]);
+    rows += cap[b];
+    if (rows > 0x7fffff00ll / 64) return fail(PHM_ERR_UNSUPPORTED, "tree too large: dwell rows per replica tile exceed 32-bit indexing");
+    e->tl_slot[b + 1] = (int32_t)rows;
+  }
+  e->nw_total_cap = rows;
+  e->nw_klong = max_cap + 1;
+  e->rows = rows;
+  std::vector<int32_t> border(E);
+  for (int b = 0; b < E; ++b) border[b] = b;
+  std::stable_sort(border.begin(), border.end(), [&](int a, int b) { return cap[a] > cap[b]; });
+
+  if (e->tips_per_replica) {
+    e->tips_host.assign((size_t)tiles * T * 64, 0);
+    for (int r = 0; r < e->S_pad; ++r) {
+      const int src = r < e->S ? r : e->S - 1;
+      for (int t = 0; t < T; ++t) e->tips_host[((size_t)(r / 64) * T + t) * 64 + (r % 64)] = (uint8_t)(x->states[(size_t)src * T + t] - 1);
+    }
+  } else {
+    e->tips_host.resize(T);
+    for (int t = 0; t < T; ++t) e->tips_host[t] = (uint8_t)(x->states[t] - 1);
+  }
+
+  const int ldt = (n + 1) & ~1;
+  const size_t stats_bytes = e->reduce ? sizeof(double) * (size_t)max_iters * tiles * e->dcols
+                                       : sizeof(double) * (size_t)max_iters * e->dcols * e->S_pad;
+  const size_t dw_bytes = sizeof(double) * (size_t)tiles * rows * 64;
+  const size_t tab = (size_t)e->nw_klong * n * ldt;
+  const size_t pl_bytes = sizeof(double) * (size_t)tiles * Nn * n * 64;
+  const size_t cnt_bytes = sizeof(uint32_t) * (size_t)tiles * n * n * 64;
+  size_t free_b = 0, total_b = 0;
+  HIPCHK(hipMemGetInfo(&free_b, &total_b));
+  const size_t need = 2 * dw_bytes + pl_bytes + cnt_bytes + stats_bytes + sizeof(double) * 3 * tab + (size_t)tiles * (5 * (size_t)E + Nn + 8 * (size_t)n) * 64;
+  if (need + (64u << 20) > free_b) {
+    char buf[256];
+    std::snprintf(buf, sizeof buf, "engine needs %.2f GiB of HBM, %.2f GiB free (reduce n_replicas or max_iters)", need / 1073741824.0, free_b / 1073741824.0);
+    return fail(PHM_ERR_OOM, buf);
+  }
+  HIPCHK(e->d_up.alloc(sizeof(phm::UpStep) * Nn)); HIPCHK(e->d_down.alloc(sizeof(phm::DownStep) * E));
+  { int32_t lst = build_level_orders(e); if (lst) return lst; }
+  HIPCHK(e->d_nw_border.alloc(sizeof(int32_t) * E)); HIPCHK(e->d_tl_slot.alloc(sizeof(int32_t) * (E + 1)));
+  HIPCHK(e->d_nw_colL.alloc(sizeof(double) * tab)); HIPCHK(e->d_nw_rowL.alloc(sizeof(double) * tab));
+  HIPCHK(e->d_nw_maskL.alloc(sizeof(double) * (size_t)e->nw_klong * 2 * ldt));
+  HIPCHK(e->d_wt_B2.alloc(sizeof(double) * (size_t)n * ldt)); HIPCHK(e->d_Bc.alloc(sizeof(double) * n * n));
+  HIPCHK(e->d_scale.alloc(sizeof(double) * n)); HIPCHK(e->d_pid.alloc(sizeof(double) * n));
+  HIPCHK(hipMemcpy(e->d_pid.p, e->hpid.data(), e->d_pid.bytes, hipMemcpyHostToDevice));
+  HIPCHK(e->d_tips.alloc(e->tips_host.size()));
+  HIPCHK(e->d_mcount.alloc(sizeof(uint16_t) * (size_t)tiles * E * 64));
+  HIPCHK(e->d_dw0.alloc(dw_bytes)); HIPCHK(e->d_dw1.alloc(dw_bytes));
+  HIPCHK(e->d_tl_estate.alloc(sizeof(uint16_t) * (size_t)tiles * E * 64));
+  HIPCHK(e->d_PL.alloc(pl_bytes));
+  HIPCHK(e->d_nstate.alloc((size_t)tiles * Nn * 64));
+  HIPCHK(e->d_tl_cnt.alloc(cnt_bytes));
+  HIPCHK(e->d_wt_dwfx.alloc(sizeof(unsigned long long) * (size_t)tiles * n * 64));
+  HIPCHK(e->d_wt_segacc.alloc(sizeof(unsigned long long) * (size_t)tiles * 64));
+  HIPCHK(e->d_stats.alloc(stats_bytes));
+  HIPCHK(e->d_err.alloc(sizeof(uint32_t))); HIPCHK(e->d_seg.alloc(sizeof(unsigned long long)));
+  if (e->reduce) HIPCHK(e->d_red.alloc(sizeof(double) * (size_t)max_iters * e->dcols));
+  e->bytes = (int64_t)(2 * dw_bytes + pl_bytes + cnt_bytes + e->d_stats.bytes + e->d_red.bytes + e->d_mcount.bytes + e->d_tl_estate.bytes +
+                       e->d_nstate.bytes + e->d_wt_dwfx.bytes + sizeof(double) * 3 * tab);
+  HIPCHK(hipMemcpy(e->d_up.p, s.up.data(), e->d_up.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(e->d_down.p, s.down.data(), e->d_down.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(e->d_nw_border.p, border.data(), e->d_nw_border.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(e->d_tl_slot.p, e->tl_slot.data(), e->d_tl_slot.bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(e->d_tips.p, e->tips_host.data(), e->tips_host.size(), hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(e->d_err.p, 0, sizeof(uint32_t)));
+  HIPCHK(hipMemset(e->d_seg.p, 0, sizeof(unsigned long long)));
+  HIPCHK(hipMemset(e->d_stats.p, 0, stats_bytes));
+  HIPCHK(hipMemset(e->d_nstate.p, 0, e->d_nstate.bytes));
+  HIPCHK(hipMemset(e->d_tl_cnt.p, 0, e->d_tl_cnt.bytes));
+  HIPCHK(hipMemset(e->d_wt_dwfx.p, 0, e->d_wt_dwfx.bytes));
+  HIPCHK(hipMemset(e->d_wt_segacc.p, 0, e->d_wt_segacc.bytes));
+  {   // initial paths -> every replica (makeabranch, src/phylomap.cpp:24-34, :901)
+    DevBuf d_off, d_maps;
+    HIPCHK(d_off.alloc(sizeof(int32_t) * (E + 1)));
+    HIPCHK(d_maps.alloc(sizeof(double) * (size_t)x->map_off[E]));
+    HIPCHK(hipMemcpy(d_off.p, x->map_off, d_off.bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_maps.p, x->maps, d_maps.bytes, hipMemcpyHostToDevice));
+    HIPCHK(phm::launch_tiles_init(E, tiles, rows, e->d_tl_slot.as<int32_t>(), d_off.as<int32_t>(), d_maps.as<double>(),
+                                  e->d_dw0.as<double>(), e->d_mcount.as<uint16_t>(), nullptr));
+    HIPCHK(hipDeviceSynchronize());
+  }
+  phm::WtParams& p = e->pwt;
+  p.n_states = n; p.ldt = ldt;
+  p.n_tips = s.n_tips; p.n_node = s.n_node; p.n_edge = s.n_edge; p.root = s.root;
+  p.n_tiles = tiles; p.n_rep = e->S; p.n_rep_pad = e->S_pad; p.replica_offset = o.replica_offset;
+  p.normalise = normalised(e->variant); p.tips_per_replica = e->tips_per_replica ? 1 : 0;
+  p.ks = ks_layout(e->variant); p.tip_masks = hidden_rates(e->variant); p.reduce = e->reduce; p.n_cols = e->dcols;
+  p.klong = e->nw_klong;
+  // branches per wave of the branch kernel: one while waves are scarce, up to 8 once there are 65 536 of them anyway
+  p.group = (int32_t)std::max<int64_t>(1, std::min<int64_t>(8, (int64_t)tiles * E / 65536));
+  p.n_groups = (E + p.group - 1) / p.group;
+  p.seed_lo = (uint32_t)(o.seed & 0xFFFFFFFFull); p.seed_hi = (uint32_t)(o.seed >> 32);
+  p.rows = rows;
+  {   // dwell accumulators: 64-bit fixed point, a replica's column never exceeds the tree length
+    int ex = 0;
+    (void)std::frexp(std::max(tree_len, 1.0), &ex);       // tree_len < 2^ex
+    p.fx_scale = std::ldexp(1.0, 61 - ex); p.fx_inv = std::ldexp(1.0, ex - 61);
+  }
+  p.B2 = e->d_wt_B2.as<double>(); p.Bc = e->d_Bc.as<double>(); p.scale = e->d_scale.as<double>(); p.pid = e->d_pid.as<double>();
+  p.up = e->d_up.as<phm::UpStep>(); p.down = e->d_down.as<phm::DownStep>();
+  p.up_order = e->d_nw_up_order.as<int32_t>(); p.down_order = e->d_nw_down_order.as<int32_t>();
+  p.branch_order = e->d_nw_border.as<int32_t>(); p.slot = e->d_tl_slot.as<int32_t>();
+  p.colL = e->d_nw_colL.as<double>(); p.rowL = e->d_nw_rowL.as<double>(); p.maskL = e->d_nw_maskL.as<double>();
+  p.tips = e->d_tips.as<uint8_t>(); p.mcount = e->d_mcount.as<uint16_t>();
+  p.dw[0] = e->d_dw0.as<double>(); p.dw[1] = e->d_dw1.as<double>();
+  p.estate = e->d_tl_estate.as<uint16_t>(); p.PL = e->d_PL.as<double>(); p.nstate = e->d_nstate.as<uint8_t>();
+  p.dwfx = e->d_wt_dwfx.as<unsigned long long>(); p.cnt = e->d_tl_cnt.as<uint32_t>();
+  p.segacc = e->d_wt_segacc.as<unsigned long long>();
+  p.stats = e->d_stats.as<double>(); p.err = e->d_err.as<uint32_t>(); p.segcnt = e->d_seg.as<unsigned long long>();
+  return PHM_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -587,23 +730,23 @@ int32_t phm_engine_create_multi(const phm_tree* trees, int32_t n_trees, const ph
   const bool small_n = !e->wide && n_trees == 1;
   const bool auto_map = o.reserved[1] == 0 && o.reserved[0] == 0;      // a ring / two-buffer request names the replica layout
   if ((o.reserved[1] == 2 || o.reserved[1] == 3) && n_trees != 1) return fail(PHM_ERR_UNSUPPORTED, "the branch-parallel mappings take a single tree");
-  if (e->wide) {      // 5..64 states: one wave per (replica, branch) unless the replica kernel is asked for or memory is short
-    e->narrow = n_trees == 1 && (o.reserved[1] == 2 || o.reserved[1] == 3 || auto_map);
-    e->tiled = false;
+  if (e->wide) {      // 5..64 states: lane = replica, wave per (tile, item) (phm_wtiles.hip); a handful of chains: wave per (replica, branch)
+    e->tiled = n_trees == 1 && (o.reserved[1] == 3 || (auto_map && e->S > WBRANCH_AUTO_MAX_REPLICAS));
+    e->narrow = n_trees == 1 && !e->tiled && (o.reserved[1] == 2 || auto_map);
   } else {
     e->narrow = small_n && (o.reserved[1] == 2 || (auto_map && e->S <= NARROW_AUTO_MAX_REPLICAS));
     e->tiled = small_n && !e->narrow && (o.reserved[1] == 3 || (auto_map && e->S <= TILES_AUTO_MAX_REPLICAS));
   }
   if (e->narrow && e->S > 65535) {      // the replica index is the grid's y dimension in these kernels
     if (!auto_map) return fail(PHM_ERR_UNSUPPORTED, "the one-lane-per-branch / wave-per-(replica, branch) mappings take at most 65 535 replicas");
-    e->narrow = false; e->tiled = !e->wide && e->S <= TILES_AUTO_MAX_REPLICAS;
+    e->narrow = false; e->tiled = e->wide || e->S <= TILES_AUTO_MAX_REPLICAS;
   }
   if (e->narrow) {
     st = narrow_setup(e, x, model, o, max_iters);
-    if (st == PHM_ERR_OOM && auto_map) { e->narrow = false; e->tiled = !e->wide; st = PHM_OK; }
+    if (st == PHM_ERR_OOM && auto_map) { e->narrow = false; e->tiled = true; st = PHM_OK; }
   }
   if (e->tiled) {
-    st = tiles_setup(e, x, model, o, max_iters);
+    st = e->wide ? wtiles_setup(e, x, model, o, max_iters) : tiles_setup(e, x, model, o, max_iters);
     if (st == PHM_ERR_OOM && auto_map) { e->tiled = false; st = PHM_OK; }     // automatic choice: fall back to the replica layout
   }
   if (e->narrow || e->tiled) {
@@ -830,6 +973,7 @@ int32_t phm_engine_run(phm_engine* e, int32_t n_iters, void* hip_stream) {
       if (e->n == 2) le = phm::launch_tiles_sweep<2>(e->t2, e->nw_up_off, e->nw_down_off, it, stream);
       if (e->n == 3) le = phm::launch_tiles_sweep<3>(e->t3, e->nw_up_off, e->nw_down_off, it, stream);
       if (e->n == 4) le = phm::launch_tiles_sweep<4>(e->t4, e->nw_up_off, e->nw_down_off, it, stream);
+      if (e->wide) le = phm::launch_wtiles_sweep(e->pwt, e->nw_up_off, e->nw_down_off, it, stream);
       launches += (int)(e->nw_up_off.size() + e->nw_down_off.size()) + 2;
     }
     HIPCHK(le);
@@ -989,7 +1133,7 @@ int32_t phm_engine_dump(phm_engine* e, int32_t replica, int32_t* seg_count, doub
       for (int c = 0; c < n; ++c) PL[(size_t)t * n + c] = (c == tip_state(t)) ? 1.0 : 0.0;
     for (int v = 0; v < s.n_node; ++v)
       for (int c = 0; c < n; ++c)
-        PL[(size_t)(T + v) * n + c] = e->wide ? pl[((size_t)v * 64 + lane) * n + c] : pl[((size_t)v * n + c) * 64 + lane];
+        PL[(size_t)(T + v) * n + c] = (e->wide && !e->tiled) ? pl[((size_t)v * 64 + lane) * n + c] : pl[((size_t)v * n + c) * 64 + lane];
   }
   return PHM_OK;
 }
@@ -1033,14 +1177,16 @@ extern "C" int32_t phm_engine_reduced_stats_device(phm_engine* e, int32_t iter0,
 // Returns the HIP-event time in milliseconds.  n <= 4 kernels only.
 extern "C" int32_t phm_engine_time_pruning(phm_engine* e, int32_t n_iters, void* hip_stream, double* ms_out) {
   if (!e || !ms_out) return fail(PHM_ERR_STATE, "engine/ms_out is NULL");
-  if (e->wide || e->narrow || e->tiled || e->n_trees > 1) return fail(PHM_ERR_UNSUPPORTED, "pruning-only timing is implemented for the replica mapping with n_states <= 4 and one tree");
+  const bool wt = e->wide && e->tiled;
+  if (!wt && (e->wide || e->narrow || e->tiled || e->n_trees > 1)) return fail(PHM_ERR_UNSUPPORTED, "pruning-only timing is implemented for the replica mapping with n_states <= 4 and the lane-per-replica mapping of 5..64 states");
   if (n_iters < 1) return fail(PHM_ERR_BAD_INPUT, "n_iters must be >= 1");
   HIPCHK(hipSetDevice(e->device));
   hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
   HIPCHK(hipEventRecord(e->ev0, stream));
   hipError_t le = hipSuccess;
+  if (wt) for (int i = 0; i < n_iters && le == hipSuccess; ++i) le = phm::launch_wtiles_up(e->pwt, e->nw_up_off, stream);
   // iteration index = iters_done keeps the dwell ping-pong parity; nothing but PL is written
-  if (e->n == 2) { auto p = e->p2; p.prune_only = 1; for (int i = 0; i < n_iters && le == hipSuccess; ++i) le = phm::launch_mcmc<2>(p, e->iters_done, 1, stream); }
+  if (!wt && e->n == 2) { auto p = e->p2; p.prune_only = 1; for (int i = 0; i < n_iters && le == hipSuccess; ++i) le = phm::launch_mcmc<2>(p, e->iters_done, 1, stream); }
   if (e->n == 3) { auto p = e->p3; p.prune_only = 1; for (int i = 0; i < n_iters && le == hipSuccess; ++i) le = phm::launch_mcmc<3>(p, e->iters_done, 1, stream); }
   if (e->n == 4) { auto p = e->p4; p.prune_only = 1; for (int i = 0; i < n_iters && le == hipSuccess; ++i) le = phm::launch_mcmc<4>(p, e->iters_done, 1, stream); }
   HIPCHK(le);

@@ -22,6 +22,7 @@
 #include "phm_tiles.h"
 #include "phm_wbranch.h"
 #include "phm_wide.h"
+#include "phm_wtiles.h"
 
 inline thread_local std::string g_phm_err;      // phm_last_error()
 
@@ -91,28 +92,47 @@ inline int pade_squarings(const double* Q_rm, int n, double t) {
   return std::max(0, ex + 1);
 }
 
+// Mat-vec of the MCMC chains on the host.  n <= 4: unfused left-to-right sums, what the n <= 4 kernels'
+// matvec_u does.  n > 4: one fused multiply-add per term, j ascending, from +0 -- what v_mfma_f64_16x16x4 accumulates in
+// the pruning kernel of phm_wtiles.hip and what phm_coop.h does lane-wise.  y = M x (row-major M).
+inline void host_chain_matvec(const double* M, int n, const double* x, double* y) {
+  for (int i = 0; i < n; ++i) {
+    if (n > 4) {
+      double acc = 0.0;
+      for (int c = 0; c < n; ++c) acc = std::fma(M[(size_t)i * n + c], x[c], acc);
+      y[i] = acc;
+    } else {
+      double acc = M[i * n] * x[0];
+      for (int c = 1; c < n; ++c) acc += M[i * n + c] * x[c];
+      y[i] = acc;
+    }
+  }
+}
+// y = M^T x
+inline void host_chain_matTvec(const double* M, int n, const double* x, double* y) {
+  for (int c = 0; c < n; ++c) {
+    if (n > 4) {
+      double acc = 0.0;
+      for (int r = 0; r < n; ++r) acc = std::fma(M[(size_t)r * n + c], x[r], acc);
+      y[c] = acc;
+    } else {
+      double acc = M[c] * x[0];
+      for (int r = 1; r < n; ++r) acc += M[r * n + c] * x[r];
+      y[c] = acc;
+    }
+  }
+}
+
 // chain tables: col[k][j][:] = Bc^k e_j  (v <- Bc v), row[k][j][:] = (Bc^T)^k e_j (w <- Bc^T w);
-// same left-to-right unfused sums as the kernels' matvec_u, so entries are bit-identical to running the chain.
+// the same sums as the kernels' own chains, so entries are bit-identical to running the chain.
 inline void build_chain_tables(const double* Bc, int n, int ktab, std::vector<double>& col, std::vector<double>& row) {
   col.assign((size_t)ktab * n * n, 0.0);
   row.assign((size_t)ktab * n * n, 0.0);
   for (int j = 0; j < n; ++j) { col[(size_t)j * n + j] = 1.0; row[(size_t)j * n + j] = 1.0; }
   for (int k = 1; k < ktab; ++k)
     for (int j = 0; j < n; ++j) {
-      const double* v = &col[((size_t)(k - 1) * n + j) * n];
-      double* y = &col[((size_t)k * n + j) * n];
-      for (int i = 0; i < n; ++i) {
-        double acc = Bc[i * n] * v[0];
-        for (int c = 1; c < n; ++c) acc += Bc[i * n + c] * v[c];
-        y[i] = acc;
-      }
-      const double* w = &row[((size_t)(k - 1) * n + j) * n];
-      double* z = &row[((size_t)k * n + j) * n];
-      for (int c = 0; c < n; ++c) {
-        double acc = Bc[c] * w[0];
-        for (int r = 1; r < n; ++r) acc += Bc[r * n + c] * w[r];
-        z[c] = acc;
-      }
+      host_chain_matvec(Bc, n, &col[((size_t)(k - 1) * n + j) * n], &col[((size_t)k * n + j) * n]);
+      host_chain_matTvec(Bc, n, &row[((size_t)(k - 1) * n + j) * n], &row[((size_t)k * n + j) * n]);
     }
 }
 
@@ -181,6 +201,9 @@ struct phm_engine {
   phm::TileParams<2> t2;
   phm::TileParams<3> t3;
   phm::TileParams<4> t4;
+  // 5..64 states with `tiled` set: one lane per replica, wave per (tile, item), pruning on the matrix cores (phm_wtiles.hip)
+  phm::WtParams pwt;
+  DevBuf d_wt_dwfx, d_wt_segacc, d_wt_B2;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipStream_t last_stream = nullptr;
   bool timing_pending = false;

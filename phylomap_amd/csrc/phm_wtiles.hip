@@ -1,0 +1,460 @@
+// phm_wtiles.hip -- 5..64 states, one lane per replica, a wavefront per (tile of 64 replicas, item); see phm_wtiles.h.
+#include "phm_wtiles.h"
+
+namespace phm {
+
+namespace {
+
+using d4_t = __attribute__((ext_vector_type(4))) double;
+
+// Categorical draw of one lane from a probability vector given term by term (term(c) = p_c, c = 0 .. n-1):
+// first j with u * sum(p) <= p_0 + .. + p_j, index order, unfused left-to-right sums (categorical draw).
+// Two passes over the terms -- the total, then the running sum against the threshold -- so nothing is kept per state.
+template <class Term>
+__device__ __forceinline__ int sample_terms(int n, double u, Term term, uint32_t& err) {
+  double total = 0.0;                                  // 0 + p_0 = p_0 exactly
+  for (int c = 0; c < n; ++c) total += term(c);
+  if (!(total > 0.0) || isinf(total)) err |= DERR_ZERO_PROB;
+  const double thr = u * total;
+  double cum = 0.0;
+  int idx = 0;
+  // u < 1: the last partial sum (= total) always passes, so n - 1 comparisons decide (sample_cat of phm_device.h)
+  for (int c = 0; c < n - 1; ++c) {
+    cum += term(c);
+    const bool past = !(thr <= cum);
+    idx += past ? 1 : 0;
+    if ((c & 7) == 7 && !__any(past)) break;           // every lane of the wave has found its state
+  }
+  return idx;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Pruning, one HEIGHT level: PL[parent] = (Bc^(m1-1) PL[c1]) (.) (Bc^(m0-1) PL[c0]), optionally / sum   (:503-529).
+// A wave owns 16 replicas of a tile at one node.  MFMA fragment maps (cdna_hip_programming.md, f64 16x16x4):
+//   A: lane l holds A[row = l & 15][k = l >> 4];  B: lane l holds B[k = l >> 4][col = l & 15];
+//   C/D: col = l & 15, row = (l >> 4) + 4 * reg.
+// With M = output state, K = input state, N = replica, register q of row block i of an accumulator holds state
+// 16 i + (l >> 4) + 4 q = 4 (4 i + q) + (l >> 4): exactly the B-operand slice of k-step 4 i + q.  So X <- Bc X is
+// MT * 4 MT MFMAs and the result feeds the next step as it stands; each output entry is the fused chain
+// fma(Bc[r][j], x[j], acc) with j ascending from +0 (k-steps in order, four k per MFMA in order).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(WT_BLOCK) void wt_up_kernel(WtParams p, int begin, int end) {
+  constexpr int KS = 4 * MT;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int n = p.n_states, ldt = p.ldt;
+  double Af[MT][KS];                                   // the chain matrix as A-operand fragments, for the whole launch
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int row = 16 * i + lr, k = 4 * s + lk;
+      Af[i][s] = (row < n && k < n) ? p.Bc[row * n + k] : 0.0;
+    }
+  const int n_lvl = end - begin;
+  const int64_t items = (int64_t)n_lvl * p.n_tiles * 4;
+  uint32_t err = 0;
+  for (int64_t item = (int64_t)blockIdx.x * (WT_BLOCK / 64) + wave; item < items; item += (int64_t)gridDim.x * (WT_BLOCK / 64)) {
+    const int nt = (int)(item & 3);
+    const int64_t q4 = item >> 2;
+    const int tile = (int)(q4 % p.n_tiles), li = (int)(q4 / p.n_tiles);
+    const UpStep st = p.up[p.up_order[begin + li]];
+    const int j = 16 * nt + lr;                        // this lane's replica within the tile
+    double* __restrict__ PLt = p.PL + (size_t)tile * p.n_node * n * 64;
+    const uint16_t* __restrict__ mct = p.mcount + (size_t)tile * p.n_edge * 64;
+    const uint8_t* __restrict__ tips_t = p.tips_per_replica ? p.tips + (size_t)tile * p.n_tips * 64 : p.tips;
+    d4_t R[2][MT];
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {                   // ch 0: "first" = child[1] (:508); ch 1: "second" = child[0] (:509)
+      const int child = st.child[1 - ch], edge = st.edge[1 - ch];
+      int k = (int)mct[edge * 64 + j] - 1;
+      if (child < 0) {                                 // tip: a row of the chain table (the chain run from a unit vector)
+        const int tip = ~child;
+        const int ts = p.tips_per_replica ? tips_t[tip * 64 + j] : p.tips[tip];
+        if (k >= p.klong) { err |= DERR_CAPACITY; k = p.klong - 1; }
+        const double* __restrict__ src = p.tip_masks ? p.maskL + ((size_t)k * 2 + (ts & 1)) * ldt : p.colL + ((size_t)k * n + ts) * ldt;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int row = 16 * i + lk + 4 * q;
+            R[ch][i][q] = (row < n) ? src[row] : 0.0;
+          }
+      } else {                                         // internal child: the chain itself, on the matrix cores
+        d4_t X[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int row = 16 * i + lk + 4 * q;
+            X[i][q] = (row < n) ? PLt[((size_t)child * n + row) * 64 + j] : 0.0;
+          }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) R[ch][i] = X[i];
+        const int kmax = wave_max_count(k);            // segment counts differ per replica: run to the longest, keep step k
+        for (int step = 1; step <= kmax; ++step) {
+          d4_t Y[MT];
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+            d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Af[i][s], X[s >> 2][s & 3], acc, 0, 0, 0);
+            Y[i] = acc;
+          }
+          const bool mine = (k == step);
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+            X[i] = Y[i];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) R[ch][i][q] = mine ? Y[i][q] : R[ch][i][q];
+          }
+        }
+      }
+    }
+    d4_t P[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) P[i] = R[0][i] * R[1][i];                     // :510
+    if (p.normalise) {                                                         // :525
+      double t = 0.0;                                  // states lk, lk + 4, lk + 8, ... ascending: partial sum t_lk
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t += P[i][q];
+      t = t + __shfl_xor(t, 16, 64);                   // t_0 + t_1 | t_2 + t_3
+      t = t + __shfl_xor(t, 32, 64);                   // (t_0 + t_1) + (t_2 + t_3)
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) P[i][q] = P[i][q] / t;
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = 16 * i + lk + 4 * q;
+        if (row < n) PLt[((size_t)st.parent * n + row) * 64 + j] = P[i][q];
+      }
+  }
+  if (err) atomicOr(p.err, err);
+}
+
+__global__ __launch_bounds__(WT_BLOCK) void wt_root_kernel(WtParams p, int it) {
+  const int lane = threadIdx.x & 63;
+  const int tile = blockIdx.x * (WT_BLOCK / 64) + (threadIdx.x >> 6);
+  if (tile >= p.n_tiles) return;
+  const int n = p.n_states;
+  const double* __restrict__ PLr = p.PL + ((size_t)tile * p.n_node + p.root) * n * 64 + lane;
+  const uint32_t rep = (uint32_t)(p.replica_offset + tile * 64 + lane);
+  uint32_t err = 0;
+  const double u = stream_u(p.seed_lo, p.seed_hi, rep, (uint32_t)it, ENT_NODE | (uint32_t)(p.root + p.n_tips), 0);
+  const int rs = sample_terms(n, u, [&](int c) { return p.pid[c] * PLr[(size_t)c * 64]; }, err);   // :618, :627
+  p.nstate[((size_t)tile * p.n_node + p.root) * 64 + lane] = (uint8_t)rs;
+  if (err) atomicOr(p.err, err);
+}
+
+// child ~ e_ps^T B^(m-1) (.) PL[child]   (Tvmmp :431-436, :651); ks: tips too, against their parity mask (:1384-1397)
+__global__ __launch_bounds__(WT_BLOCK) void wt_down_kernel(WtParams p, int it, int begin, int end) {
+  const int lane = threadIdx.x & 63;
+  const int item = blockIdx.x * (WT_BLOCK / 64) + (threadIdx.x >> 6);
+  const int n_lvl = end - begin;
+  if (item >= n_lvl * p.n_tiles) return;
+  const int n = p.n_states, ldt = p.ldt;
+  const int tile = item / n_lvl;
+  const DownStep ds = p.down[p.down_order[begin + item % n_lvl]];
+  const int b = ds.edge;
+  const double* __restrict__ PLt = p.PL + (size_t)tile * p.n_node * n * 64;
+  uint8_t* __restrict__ nst = p.nstate + (size_t)tile * p.n_node * 64;
+  const uint8_t* __restrict__ tips_t = p.tips_per_replica ? p.tips + (size_t)tile * p.n_tips * 64 : p.tips;
+  const uint32_t rep = (uint32_t)(p.replica_offset + tile * 64 + lane);
+  const int m = p.mcount[((size_t)tile * p.n_edge + b) * 64 + lane];
+  const int ps = nst[ds.parent * 64 + lane];
+  uint32_t err = 0;
+  int cs;
+  if (ds.child >= 0 || p.tip_masks) {
+    int kk = m - 1;
+    if (kk >= p.klong) { err |= DERR_CAPACITY; kk = p.klong - 1; }
+    const double* __restrict__ src = p.rowL + ((size_t)kk * n + ps) * ldt;
+    if (ds.child >= 0) {
+      const double* __restrict__ PLc = PLt + (size_t)ds.child * n * 64 + lane;
+      const double u = stream_u(p.seed_lo, p.seed_hi, rep, (uint32_t)it, ENT_NODE | (uint32_t)(ds.child + p.n_tips), 0);
+      cs = sample_terms(n, u, [&](int c) { return src[c] * PLc[(size_t)c * 64]; }, err);        // :655
+      nst[ds.child * 64 + lane] = (uint8_t)cs;
+    } else {
+      const int tip = ~ds.child;
+      const int par = (p.tips_per_replica ? tips_t[tip * 64 + lane] : p.tips[tip]) & 1;
+      const double u = stream_u(p.seed_lo, p.seed_hi, rep, (uint32_t)it, ENT_NODE | (uint32_t)tip, 0);
+      cs = sample_terms(n, u, [&](int c) { return src[c] * (((c & 1) == par) ? 1.0 : 0.0); }, err);
+    }
+  } else {
+    const int tip = ~ds.child;
+    cs = p.tips_per_replica ? tips_t[tip * 64 + lane] : p.tips[tip];            // :612
+  }
+  p.estate[((size_t)tile * p.n_edge + b) * 64 + lane] = (uint16_t)(ps | (cs << 8));   // updatenodestates :460-475
+  if (err) atomicOr(p.err, err);
+}
+
+// One branch for the 64 replicas of a tile: resamplebranchstates :264-308, shortener :44-73 (shortenerbf :997-1030),
+// virtual jumps sampleabranch :391-410, dwell sums updatedwelltimes :745-757.  The two-flat-pass scheme of phm_tiles.hip;
+// the states of the merged segments live in LDS (a byte per segment and lane), transition counts and dwell sums go
+// straight to the tile's accumulators (integer atomics: exact in any order).
+template <bool KS>
+__global__ __launch_bounds__(WT_BLOCK) void wt_branch_kernel(WtParams p, int it) {
+  __shared__ uint8_t s_ms_all[(WT_BLOCK / 64) * 64 * 64];           // [wave][segment][lane]
+  __shared__ double s_scale[64];
+  __shared__ __align__(16) double s_ltab[2 * PHM_LOGTAB_N];        // (1/c_j, log c_j) of the exponential variates (neglog_u32)
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int item = blockIdx.x * (WT_BLOCK / 64) + wave;
+  const uint32_t lane8 = (uint32_t)lane * 8u;
+  const int n = p.n_states, ldt = p.ldt;
+  for (int i = threadIdx.x; i < 2 * PHM_LOGTAB_N; i += WT_BLOCK) s_ltab[i] = logtab_entry(i);
+  if ((int)threadIdx.x < n) s_scale[threadIdx.x] = p.scale[threadIdx.x];
+  __syncthreads();
+  if (item >= p.n_groups * p.n_tiles) return;        // whole waves only; no barrier below this line
+  const int tile = item % p.n_tiles;
+  const int grp = item / p.n_tiles;
+  uint8_t* s_ms = s_ms_all + wave * 64 * 64 + lane;
+  const uint32_t rep = (uint32_t)(p.replica_offset + tile * 64 + lane);
+  const bool valid = tile * 64 + lane < p.n_rep;
+  uint16_t* __restrict__ mct = p.mcount + (size_t)tile * p.n_edge * 64;
+  uint32_t* gc = p.cnt + ((size_t)tile * n * n) * 64 + lane;
+  unsigned long long* gdw = p.dwfx + ((size_t)tile * n) * 64 + lane;
+  uint32_t err = 0;
+  uint32_t segs = 0;
+  auto add_dwell = [&](int s, double len) {                                    // updatedwelltimes :752, per merged segment
+    atomicAdd(gdw + s * 64, (unsigned long long)__double2ll_rn(len * p.fx_scale));
+  };
+  auto count = [&](int a, int c) {                                             // shortener :65-66 / shortenerbf :1010-1014
+    atomicAdd(gc + (KS ? a * n + c : a * (n - 1) + (c > a ? c - 1 : c)) * 64, 1u);
+  };
+  const int q1 = min((grp + 1) * p.group, p.n_edge);
+  for (int q = grp * p.group; q < q1; ++q) {
+  const int b = p.branch_order[q];
+  const int m = mct[b * 64 + lane];
+  const int es = p.estate[((size_t)tile * p.n_edge + b) * 64 + lane];
+  const int ps = es & 255, cs = es >> 8;
+  const int roff = p.slot[b];
+  const int cap = p.slot[b + 1] - roff;
+  double* __restrict__ in = p.dw[it & 1] + ((size_t)tile * p.rows + roff) * 64;
+  double* __restrict__ out = p.dw[(it & 1) ^ 1] + ((size_t)tile * p.rows + roff) * 64;
+  auto IN = [&](int k) -> double& { return at(in, (uint32_t)k * 512u + lane8); };
+
+  Stream su, se;
+  su.open(ENT_BSTATE | (uint32_t)b, (uint32_t)it, rep, p.seed_lo, p.seed_hi);
+  se.open(ENT_BEXP | (uint32_t)b, (uint32_t)it, rep, p.seed_lo, p.seed_hi);
+  const int mmax = wave_max_count(m);
+  int mnew = 0;
+
+  // s_i ~ B[s_{i-1},:] (.) B^(m-i-1) e_end          (resamplebranchstates :290, :301-304)
+  auto draw_state_w = [&](int i, int sprev, uint32_t word) -> int {
+    int kk = m - i - 1;
+    if (kk >= p.klong) { err |= DERR_CAPACITY; kk = p.klong - 1; }
+    const double* __restrict__ beta = p.colL + ((size_t)kk * n + cs) * ldt;
+    const double* __restrict__ brow = p.B2 + (size_t)sprev * ldt;
+    return sample_terms(n, u01(word), [&](int c) { return brow[c] * beta[c]; }, err);
+  };
+
+  if (mmax <= 64) {
+    // Pass A: one old segment per step for every lane; merged segments written back in place over the consumed rows.
+    int w = 0;
+    int cur_s = (m == 1) ? cs : ps;            // updatenodestates :469-472 (m==1: child wins)
+    double cur_len = IN(0);
+    double dnext = (m > 1) ? IN(1) : 0.0;
+    for (int i0 = 1; i0 < mmax; i0 += 4) {
+      uint32_t wd[4] = {0u, 0u, 0u, 0u};
+      if (i0 < mmax - 1)                       // some lane still draws in this group (draws exist for i < m - 1)
+        philox4x32_10((uint32_t)((i0 - 1) >> 2), ENT_BSTATE | (uint32_t)b, (uint32_t)it, rep, p.seed_lo, p.seed_hi, wd);
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        const int i = i0 + qq;
+        if (i < m) {
+          const int si = (i == m - 1) ? cs : draw_state_w(i, cur_s, wd[qq]);
+          const double di = dnext;
+          if (i + 1 < m) dnext = IN(i + 1);
+          if (KS) count(cur_s, si);
+          if (si == cur_s) cur_len = cur_len + di;                           // shortener :54
+          else {
+            IN(w) = cur_len;
+            s_ms[w * 64] = (uint8_t)cur_s;
+            if (!KS) count(cur_s, si);
+            ++w; cur_s = si; cur_len = di;
+          }
+        }
+      }
+    }
+    s_ms[w * 64] = (uint8_t)cur_s;
+    const int nmerged = w + 1;
+    const double len0 = (w == 0) ? cur_len : IN(0);
+    if (w > 0) IN(w) = cur_len;
+
+    // Pass B: one new piece per step for every lane (virtual jumps :391-410).
+    int j = 0;
+    int s = s_ms[0];
+    double len = len0;
+    double lnext = (nmerged > 1) ? ((w == 1) ? cur_len : IN(1)) : 0.0;
+    double tot = 0.0, scale = s_scale[s];
+    bool stuck = false, done = false;
+    for (uint32_t t0 = 0; __any(!done); t0 += 4) {
+      uint32_t wd[4];
+      philox4x32_10(t0 >> 2, ENT_BEXP | (uint32_t)b, (uint32_t)it, rep, p.seed_lo, p.seed_hi, wd);
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        if (done) continue;
+        double piece;
+        bool adv;
+        if (stuck || !(0.0 < len)) { stuck = true; piece = len; adv = true; }
+        else {
+          const double rl = scale * neglog_u32(wd[qq], s_ltab);                // :398
+          if ((tot + rl) < len) { piece = rl; tot += rl; adv = false; }
+          else { piece = len - tot; adv = true; }
+        }
+        if (mnew < cap) at(out, (uint32_t)mnew * 512u + lane8) = piece; else err |= DERR_CAPACITY;
+        ++mnew;
+        if (adv) {
+          add_dwell(s, len);
+          ++j;
+          if (j >= nmerged) done = true;
+          else {
+            len = lnext;
+            if (j + 1 < nmerged) lnext = IN(j + 1);
+            s = s_ms[j * 64];
+            scale = s_scale[s]; tot = 0.0;
+          }
+        }
+      }
+    }
+  } else {
+    // General path (a lane with more than 64 segments on this branch): the reference's loop nest as written.
+    uint32_t edraw = 0;
+    bool stuck = false;
+    auto finalize = [&](int s, double len) {
+      add_dwell(s, len);
+      if (stuck || !(0.0 < len)) {
+        stuck = true;
+        if (mnew < cap) at(out, (uint32_t)mnew * 512u + lane8) = len; else err |= DERR_CAPACITY;
+        ++mnew;
+        return;
+      }
+      const double scale = s_scale[s];
+      double tot = 0.0;
+      while (tot < len) {
+        const double rl = scale * neglog_u32(se.draw_word(edraw++), s_ltab);
+        double piece;
+        if ((tot + rl) < len) { piece = rl; tot += rl; }
+        else { piece = len - tot; tot = len; }
+        if (mnew < cap) at(out, (uint32_t)mnew * 512u + lane8) = piece; else err |= DERR_CAPACITY;
+        ++mnew;
+      }
+    };
+    int cur_s = (m == 1) ? cs : ps;
+    double cur_len = IN(0);
+    for (int i = 1; i <= m; ++i) {              // i == m: sentinel that flushes the last merged segment
+      int si = -1;
+      double di = 0.0;
+      if (i < m) {
+        si = (i == m - 1) ? cs : draw_state_w(i, cur_s, su.draw_word((uint32_t)(i - 1)));
+        di = IN(i);
+      }
+      if (KS && si >= 0) count(cur_s, si);
+      if (si == cur_s) cur_len = cur_len + di;
+      else {
+        finalize(cur_s, cur_len);
+        if (!KS && si >= 0) count(cur_s, si);
+        cur_s = si; cur_len = di;
+      }
+    }
+  }
+  if (mnew > cap) mnew = cap;
+  if (mnew > 65535) { err |= DERR_CAPACITY; mnew = 65535; }
+  mct[b * 64 + lane] = (uint16_t)mnew;
+  if (valid) segs += (uint32_t)(m + mnew);
+  }      // next branch of the group
+
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) segs += __shfl_xor(segs, off, 64);
+  if (lane == 0) atomicAdd(p.segacc + (size_t)tile * 64 + (grp & 63), (unsigned long long)segs);
+  if (err) atomicOr(p.err, err);
+}
+
+// The statistics row: a wave per (tile, chunk of 64 columns).  Columns: n dwell sums (fixed point -> double), the counters,
+// (ks) the root state; the accumulators are cleared for the next sweep.
+__global__ __launch_bounds__(WT_BLOCK) void wt_stats_kernel(WtParams p, int it, int n_chunks) {
+  const int lane = threadIdx.x & 63;
+  const int item = blockIdx.x * (WT_BLOCK / 64) + (threadIdx.x >> 6);
+  if (item >= n_chunks * p.n_tiles) return;
+  const int tile = item / n_chunks, chunk = item % n_chunks;
+  const int n = p.n_states;
+  const int ncnt = p.ks ? n * n : n * (n - 1);
+  const int dcols = n + ncnt + (p.ks ? 1 : 0);
+  const int rep_local = tile * 64 + lane;
+  const bool valid = rep_local < p.n_rep;
+  unsigned long long* gdw = p.dwfx + ((size_t)tile * n) * 64 + lane;
+  uint32_t* gc = p.cnt + ((size_t)tile * n * n) * 64 + lane;
+  const int c1 = min(dcols, (chunk + 1) * 64);
+  for (int c = chunk * 64; c < c1; ++c) {
+    double v;
+    if (c < n) { v = (double)(long long)gdw[c * 64] * p.fx_inv; gdw[c * 64] = 0ull; }
+    else if (c < n + ncnt) { v = (double)gc[(c - n) * 64]; gc[(c - n) * 64] = 0u; }
+    else v = (double)p.nstate[((size_t)tile * p.n_node + p.root) * 64 + lane];   // :1350-1352
+    if (p.reduce) {
+      v = valid ? v : 0.0;
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane == 0) p.stats[((size_t)it * p.n_tiles + tile) * p.n_cols + c] = v;
+    } else {
+      p.stats[((size_t)it * p.n_cols + c) * p.n_rep_pad + rep_local] = v;
+    }
+  }
+  if (chunk == 0) {
+    unsigned long long sg = p.segacc[(size_t)tile * 64 + lane];
+    p.segacc[(size_t)tile * 64 + lane] = 0ull;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sg += __shfl_xor(sg, off, 64);
+    if (lane == 0) atomicAdd(p.segcnt, sg);
+  }
+}
+
+template <int MT>
+void launch_up_levels(const WtParams& p, const std::vector<int32_t>& up_off, hipStream_t stream) {
+  for (size_t l = 0; l + 1 < up_off.size(); ++l) {
+    const int cnt = up_off[l + 1] - up_off[l];
+    if (cnt <= 0) continue;
+    const int64_t items = (int64_t)cnt * p.n_tiles * 4;
+    const unsigned grid = (unsigned)std::min<int64_t>((items + 3) / 4, 2048);      // persistent waves: the matrix fragments load once
+    hipLaunchKernelGGL(wt_up_kernel<MT>, dim3(grid), dim3(WT_BLOCK), 0, stream, p, up_off[l], up_off[l + 1]);
+  }
+}
+
+}  // namespace
+
+hipError_t launch_wtiles_up(const WtParams& p, const std::vector<int32_t>& up_off, hipStream_t stream) {
+  const int mt = (p.n_states + 15) / 16;
+  if (mt == 1) launch_up_levels<1>(p, up_off, stream);
+  else if (mt == 2) launch_up_levels<2>(p, up_off, stream);
+  else if (mt == 3) launch_up_levels<3>(p, up_off, stream);
+  else launch_up_levels<4>(p, up_off, stream);
+  return hipGetLastError();
+}
+
+hipError_t launch_wtiles_sweep(const WtParams& p, const std::vector<int32_t>& up_off,
+                               const std::vector<int32_t>& down_off, int it, hipStream_t stream) {
+  constexpr int WPB = WT_BLOCK / 64;
+  auto blocks = [&](int64_t items) { return dim3((unsigned)((items + WPB - 1) / WPB)); };
+  hipError_t e = launch_wtiles_up(p, up_off, stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(wt_root_kernel, blocks(p.n_tiles), dim3(WT_BLOCK), 0, stream, p, it);
+  for (size_t l = 0; l + 1 < down_off.size(); ++l) {
+    const int n = down_off[l + 1] - down_off[l];
+    if (n > 0) hipLaunchKernelGGL(wt_down_kernel, blocks((int64_t)n * p.n_tiles), dim3(WT_BLOCK), 0, stream, p, it, down_off[l], down_off[l + 1]);
+  }
+  if (p.ks) hipLaunchKernelGGL((wt_branch_kernel<true>), blocks((int64_t)p.n_groups * p.n_tiles), dim3(WT_BLOCK), 0, stream, p, it);
+  else hipLaunchKernelGGL((wt_branch_kernel<false>), blocks((int64_t)p.n_groups * p.n_tiles), dim3(WT_BLOCK), 0, stream, p, it);
+  const int ncnt = p.ks ? p.n_states * p.n_states : p.n_states * (p.n_states - 1);
+  const int dcols = p.n_states + ncnt + (p.ks ? 1 : 0);
+  const int n_chunks = (dcols + 63) / 64;
+  hipLaunchKernelGGL(wt_stats_kernel, blocks((int64_t)n_chunks * p.n_tiles), dim3(WT_BLOCK), 0, stream, p, it, n_chunks);
+  return hipGetLastError();
+}
+
+}  // namespace phm

@@ -6,6 +6,7 @@ TEST INFRASTRUCTURE ONLY.
 """
 import math
 import struct
+from fractions import Fraction
 
 M32 = 0xFFFFFFFF
 ENT_NODE, ENT_BSTATE, ENT_BEXP, ENT_BUNIF = 0, 1 << 30, 2 << 30, 3 << 30
@@ -127,7 +128,17 @@ class Rng:
         return neglog_u32(o[d & 3])
 
 
-def matvec(M, v):
+def fma(a, b, c):
+    """round(a*b + c) with ONE rounding: exact rational arithmetic, then int/int true division, which CPython rounds
+    correctly (ties to even).  All operands here are finite and non-negative."""
+    if a == 0.0 or b == 0.0:
+        return c
+    x = Fraction(a) * Fraction(b) + Fraction(c)
+    return x.numerator / x.denominator
+
+
+def matvec_lr(M, v):
+    """unfused left-to-right sums for every n: the EXP path (makePLexp :2899-2906, newunifSample :127)"""
     n = len(v)
     out = []
     for i in range(n):
@@ -138,15 +149,52 @@ def matvec(M, v):
     return out
 
 
+def matvec(M, v):
+    """The MCMC sweep's chains.  n <= 4: unfused left-to-right sums (Armadillo gemv_emul_tinysq).  n > 4: the reference's order is BLAS dgemv
+    (unknowable), so the spec is what the MI355X matrix cores compute: a fused multiply-add per term, j ascending, from +0."""
+    n = len(v)
+    out = []
+    for i in range(n):
+        if n > 4:
+            acc = 0.0
+            for j in range(n):
+                acc = fma(M[i][j], v[j], acc)
+        else:
+            acc = M[i][0] * v[0]
+            for j in range(1, n):
+                acc += M[i][j] * v[j]
+        out.append(acc)
+    return out
+
+
 def matTvec(M, v):
     n = len(v)
     out = []
     for c in range(n):
-        acc = M[0][c] * v[0]
-        for r in range(1, n):
-            acc += M[r][c] * v[r]
+        if n > 4:
+            acc = 0.0
+            for r in range(n):
+                acc = fma(M[r][c], v[r], acc)
+        else:
+            acc = M[0][c] * v[0]
+            for r in range(1, n):
+                acc += M[r][c] * v[r]
         out.append(acc)
     return out
+
+
+def rowsum(p):
+    """normalisation sum (:525).  n > 4: four interleaved partial sums (states g, g+4, ...), then (t0+t1)+(t2+t3)."""
+    n = len(p)
+    if n <= 4:
+        s = p[0]
+        for c in range(1, n):
+            s += p[c]
+        return s
+    t = [0.0, 0.0, 0.0, 0.0]
+    for c in range(n):
+        t[c & 3] += p[c]
+    return (t[0] + t[1]) + (t[2] + t[3])
 
 
 def sample(p, u):
@@ -207,9 +255,7 @@ def sumstatMCMC(z, Q, pid, Omega, N, nen, nodelist, root, seed, replica, variant
                 second = matvec(Bc, second)
             row = [first[c] * second[c] for c in range(n)]
             if variant == "bigtree" or ks:                                                      # :525 / :1085
-                s = row[0]
-                for c in range(1, n):
-                    s += row[c]
+                s = rowsum(row)
                 row = [x / s for x in row]
             PL[e1[ea] - 1] = row
         rm = [0] * (2 * T - 1)
@@ -309,8 +355,8 @@ def sumstatEXP(z, Q, pid, N, nen, nodelist, root, L, R, dv, seed, replica):
         PL[i][int(z["states"][i]) - 1] = 1.0
     for i in range(T - 1):                                                                      # makePLold :2891-2893
         ea, eb = nen[2 * i] - 1, nen[2 * i + 1] - 1
-        a = matvec(P[ea], PL[e2[ea] - 1])
-        b = matvec(P[eb], PL[e2[eb] - 1])
+        a = matvec_lr(P[ea], PL[e2[ea] - 1])
+        b = matvec_lr(P[eb], PL[e2[eb] - 1])
         PL[e1[ea] - 1] = [a[c] * b[c] for c in range(n)]
     cols = n + n * (n - 1)
     out = [[0.0] * cols for _ in range(N)]
@@ -337,7 +383,7 @@ def sumstatEXP(z, Q, pid, N, nen, nodelist, root, L, R, dv, seed, replica):
             while not cum > rU:
                 k += 1
                 assert k <= 300
-                beta.append(matvec(B2, beta[k - 1]))
+                beta.append(matvec_lr(B2, beta[k - 1]))
                 pk = pk * lam / float(k)
                 cum += pk * beta[k][a] / tp
             if k == 0 or (k == 1 and a == e):

@@ -277,7 +277,7 @@ def test_wide_kernel_per_site_tips_on_thinly_filled_tiles():
         np.testing.assert_array_equal(eng.dump(r)["node_states"], dump.node_states)
         total += want
     eng.close()
-    for mapping in ("replicas", "branches"):      # branches: one wave per (replica, branch) with per-replica tip vectors
+    for mapping in ("replicas", "branches", "tiles"):      # branches: one wave per (replica, branch) with per-replica tip vectors; tiles: lanes = replicas
         eng = _lib.Engine(z, Q, pid, Omega, N, variant=_lib.PHM_MCMC_BIGTREE, seed=seed, n_replicas=S, tips_per_replica=True, states=sites,
                           reduce=True, mapping=mapping)
         eng.run(N); eng.sync()
@@ -287,7 +287,7 @@ def test_wide_kernel_per_site_tips_on_thinly_filled_tiles():
         np.testing.assert_allclose(red[:, :n], total[:, :n], rtol=1e-12)
 
 
-@pytest.mark.parametrize("mapping", ["replicas", "branches"])     # wave per 64-replica tile / wave per (replica, branch)
+@pytest.mark.parametrize("mapping", ["replicas", "branches", "tiles"])     # wave per 64-replica tile, replicas in turn / wave per (replica, branch) / lane per replica, wave per (tile, item)
 @pytest.mark.parametrize("n,fn,variant", [(20, "sumstatMCMC", O.PLAIN), (20, "SPARSEsumstatMCMC", O.SPARSE),
                                           (20, "sumstatMCMC_bigtree", O.BIGTREE), (5, "sumstatMCMC", O.PLAIN),
                                           (61, "sumstatMCMC_bigtree", O.BIGTREE), (64, "sumstatMCMC", O.PLAIN)])
@@ -350,14 +350,15 @@ def test_wide_kernel_chain_state_and_golden():
     z = unpack_tree(g)
     Q, pid, Omega, seed = g["Q"], g["pid"], float(g["Omega"]), int(g["seed"])
     got = api.SPARSEsumstatMCMC(z, Q, pid, Omega, 24, seed=seed, n_replicas=6, mapping="replicas")
-    gotb = api.SPARSEsumstatMCMC(z, Q, pid, Omega, 24, seed=seed, n_replicas=6, mapping="branches")
-    _same(gotb[0], g["sparse_r0"], 20, "branches")
-    _same(gotb[5], g["sparse_r5"], 20, "branches")
+    for mp in ("branches", "tiles"):
+        gotb = api.SPARSEsumstatMCMC(z, Q, pid, Omega, 24, seed=seed, n_replicas=6, mapping=mp)
+        _same(gotb[0], g["sparse_r0"], 20, mp)
+        _same(gotb[5], g["sparse_r5"], 20, mp)
     np.testing.assert_array_equal(got[0], g["sparse_r0"])
     np.testing.assert_array_equal(got[5], g["sparse_r5"])
     want, rc, dump = O.maketreelistMCMC(z, Q, pid, np.eye(20) + Q / Omega, Omega, g["nen"], g["nodelist"], int(g["root"]), 9,
                                         variant=O.BIGTREE, seed=seed, replica=1, dump=True)
-    for mapping in ("replicas", "branches"):
+    for mapping in ("replicas", "branches", "tiles"):
         eng = _lib.Engine(z, Q, pid, Omega, 9, variant=_lib.PHM_MCMC_BIGTREE, seed=seed, n_replicas=2, mapping=mapping)
         eng.run(9); eng.sync()
         d = eng.dump(1)
@@ -369,11 +370,12 @@ def test_wide_kernel_chain_state_and_golden():
             np.testing.assert_array_equal(d["seg_dwell"][b, :dump.seg_count[b]], dump.seg_dwell[b, :dump.seg_count[b]])
 
 
-@pytest.mark.parametrize("n,mapping", [(2, "replicas"), (4, "replicas"), (2, "branches"), (4, "branches"), (2, "tiles"), (4, "tiles"), (6, "replicas"), (6, "branches")])
+@pytest.mark.parametrize("n,mapping", [(2, "replicas"), (4, "replicas"), (2, "branches"), (4, "branches"), (2, "tiles"), (4, "tiles"), (6, "replicas"), (6, "branches"), (6, "tiles"), (8, "tiles")])
 def test_ks_sweep_matches_oracle(n, mapping):
     """Tree sweep of sumstatMCMCks with Q fixed (hidden-rates Q = make2sQ, binary trait observed): n<=4 kernel and,
     for k=2 (n=6), the wide kernel."""
-    Q = {2: synth.config_Q(1), 4: synth.make2sQ(.1, .1, .2, .2, 10), 6: synth.make2sQ(.1, .3, [.2, .4], [.5, .6], [2, 3])}[n]
+    Q = {2: synth.config_Q(1), 4: synth.make2sQ(.1, .1, .2, .2, 10), 6: synth.make2sQ(.1, .3, [.2, .4], [.5, .6], [2, 3]),
+         8: synth.make2sQ(.1, .3, [.2, .4, .3], [.5, .6, .2], [2, 3, 1.5])}[n]
     Omega = 1.25 * float(np.max(np.abs(np.diag(Q))))
     pid = np.full(n, 1.0 / n)
     z = synth.make_tree(20, Q, Omega, 900 + n, pid)
@@ -772,7 +774,7 @@ def test_capacity_overflow_is_reported_not_written_out_of_bounds(mapping):
     np.testing.assert_allclose(ok[:, :, :4].sum(2), z["edge.length"].sum(), rtol=1e-12)
 
 
-@pytest.mark.parametrize("mapping", ["replicas", "branches"])
+@pytest.mark.parametrize("mapping", ["replicas", "branches", "tiles"])
 def test_capacity_overflow_is_reported_for_wide_state_spaces(mapping):
     n = 6
     Q = synth.dense_Q(n, 0.02, 0.08, seed=66)

@@ -193,9 +193,12 @@ def test_matexp_and_pade_against_scipy():
 
 # ---- independent restatement: bit-for-bit -----------------------------------------------------------------
 @pytest.mark.parametrize("n,variant,ov", [(2, "plain", O.PLAIN), (4, "plain", O.PLAIN), (4, "bigtree", O.BIGTREE),
-                                          (4, "sparse", O.SPARSE), (3, "bigtree", O.BIGTREE)])
+                                          (4, "sparse", O.SPARSE), (3, "bigtree", O.BIGTREE),
+                                          # n > 4: fused k-ordered chains, interleaved normalisation sums
+                                          (5, "plain", O.PLAIN), (7, "bigtree", O.BIGTREE), (6, "sparse", O.SPARSE)])
 def test_mcmc_oracle_equals_python_restatement(n, variant, ov):
-    Q = {2: synth.config_Q(1), 3: np.array([[-.3, .2, .1], [.05, -.15, .1], [.2, .2, -.4]]), 4: synth.config_Q(2)}[n]
+    Q = {2: synth.config_Q(1), 3: np.array([[-.3, .2, .1], [.05, -.15, .1], [.2, .2, -.4]]), 4: synth.config_Q(2),
+         5: synth.dense_Q(5, 0.02, 0.08, seed=5), 6: synth.dense_Q(6, 0.02, 0.08, seed=6), 7: synth.dense_Q(7, 0.02, 0.08, seed=7)}[n]
     Omega = 1.25 * float(np.max(np.abs(np.diag(Q))))
     pid = np.full(n, 1.0 / n)
     z = synth.make_tree(10, Q, Omega, 700 + n)

@@ -46,7 +46,7 @@ def run(seed, n_cases):
         S, N, seed = int(rs.choice([1, 2, 3, 70])), int(rs.integers(3, 12)), int(rs.integers(1 << 40))
         B = np.eye(n) + Q / Omega
         wants = [O.maketreelistMCMC(z, Q, pid, B, Omega, nen, nodelist, root, N, variant=var, seed=seed, replica=r) for r in range(min(S, 3))]
-        for mapping in (["replicas", "branches", "tiles"] if n <= 4 else ["replicas", "branches"]):
+        for mapping in ["replicas", "branches", "tiles"]:
             try:
                 got = getattr(api, fn)(z, Q, pid, Omega, N, seed=seed, n_replicas=S, mapping=mapping)
                 if S == 1:
