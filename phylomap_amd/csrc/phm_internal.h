@@ -203,7 +203,7 @@ struct phm_engine {
   phm::TileParams<4> t4;
   // 5..64 states with `tiled` set: one lane per replica, wave per (tile, item), pruning on the matrix cores (phm_wtiles.hip)
   phm::WtParams pwt;
-  DevBuf d_wt_dwfx, d_wt_segacc, d_wt_B2;
+  DevBuf d_wt_dwfx, d_wt_segacc, d_wt_B2, d_wt_totL;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipStream_t last_stream = nullptr;
   bool timing_pending = false;

@@ -57,6 +57,8 @@ struct WtParams {
   const double* colL;                        // [klong][n][ldt]  (Bc^k e_j)[r]
   const double* rowL;                        // [klong][n][ldt]  ((Bc^T)^k e_j)[c]
   const double* maskL;                       // [klong][2][ldt]
+  const double* totL;                        // [klong][n][ldt]  totL[k][s][e] = sum_c B2[s][c] * colL[k][e][c], left to right, unfused:
+                                             //                  the total of the forward draw's probability vector (:301)
   const uint8_t* tips;                       // [n_tips] or [tile][n_tips][64]
   uint16_t* mcount;                          // [tile][n_edge][64]
   double* dw[2];                             // [tile][rows][64]; sweep `it` reads dw[it & 1], writes the other

@@ -153,8 +153,12 @@ __global__ __launch_bounds__(WT_BLOCK) void wt_root_kernel(WtParams p, int it) {
   if (err) atomicOr(p.err, err);
 }
 
-// child ~ e_ps^T B^(m-1) (.) PL[child]   (Tvmmp :431-436, :651); ks: tips too, against their parity mask (:1384-1397)
+// child ~ e_ps^T B^(m-1) (.) PL[child]   (Tvmmp :431-436, :651); ks: tips too, against their parity mask (:1384-1397).
+// The probability vector of a lane lives in registers (16 MT >= n of them): one pass forms it and its total, the second
+// walks the running sum -- the table row of a lane is read once, two states per 16-byte load.
+template <int MT>
 __global__ __launch_bounds__(WT_BLOCK) void wt_down_kernel(WtParams p, int it, int begin, int end) {
+  constexpr int NP = 16 * MT;
   const int lane = threadIdx.x & 63;
   const int item = blockIdx.x * (WT_BLOCK / 64) + (threadIdx.x >> 6);
   const int n_lvl = end - begin;
@@ -174,18 +178,47 @@ __global__ __launch_bounds__(WT_BLOCK) void wt_down_kernel(WtParams p, int it, i
   if (ds.child >= 0 || p.tip_masks) {
     int kk = m - 1;
     if (kk >= p.klong) { err |= DERR_CAPACITY; kk = p.klong - 1; }
-    const double* __restrict__ src = p.rowL + ((size_t)kk * n + ps) * ldt;
+    const double2* __restrict__ src = reinterpret_cast<const double2*>(p.rowL + ((size_t)kk * n + ps) * ldt);
+    double pr[NP];
+    uint32_t node_id;
     if (ds.child >= 0) {
       const double* __restrict__ PLc = PLt + (size_t)ds.child * n * 64 + lane;
-      const double u = stream_u(p.seed_lo, p.seed_hi, rep, (uint32_t)it, ENT_NODE | (uint32_t)(ds.child + p.n_tips), 0);
-      cs = sample_terms(n, u, [&](int c) { return src[c] * PLc[(size_t)c * 64]; }, err);        // :655
-      nst[ds.child * 64 + lane] = (uint8_t)cs;
+#pragma unroll
+      for (int c2 = 0; c2 < NP / 2; ++c2) {
+        const int c = 2 * c2;
+        double2 r = {0.0, 0.0};
+        if (c < n) r = src[c2];                          // the padding entry of an odd-length row is 0
+        pr[c] = (c < n) ? r.x * PLc[(size_t)c * 64] : 0.0;
+        pr[c + 1] = (c + 1 < n) ? r.y * PLc[(size_t)(c + 1) * 64] : 0.0;
+      }
+      node_id = (uint32_t)(ds.child + p.n_tips);
     } else {
       const int tip = ~ds.child;
       const int par = (p.tips_per_replica ? tips_t[tip * 64 + lane] : p.tips[tip]) & 1;
-      const double u = stream_u(p.seed_lo, p.seed_hi, rep, (uint32_t)it, ENT_NODE | (uint32_t)tip, 0);
-      cs = sample_terms(n, u, [&](int c) { return src[c] * (((c & 1) == par) ? 1.0 : 0.0); }, err);
+#pragma unroll
+      for (int c2 = 0; c2 < NP / 2; ++c2) {
+        const int c = 2 * c2;
+        double2 r = {0.0, 0.0};
+        if (c < n) r = src[c2];
+        pr[c] = (c < n) ? r.x * ((par == 0) ? 1.0 : 0.0) : 0.0;
+        pr[c + 1] = (c + 1 < n) ? r.y * ((par == 1) ? 1.0 : 0.0) : 0.0;
+      }
+      node_id = (uint32_t)tip;
     }
+    const double u = stream_u(p.seed_lo, p.seed_hi, rep, (uint32_t)it, ENT_NODE | node_id, 0);
+    double total = 0.0;                                  // 0 + p_0 = p_0, x + 0 = x: the padding never shows
+#pragma unroll
+    for (int c = 0; c < NP; ++c) total += pr[c];
+    if (!(total > 0.0) || isinf(total)) err |= DERR_ZERO_PROB;
+    const double thr = u * total;
+    double cum = 0.0;
+    cs = 0;
+#pragma unroll
+    for (int c = 0; c < NP - 1; ++c) {                   // comparisons at states 0 .. n-2 decide (sample_cat)
+      cum += pr[c];
+      cs += (c < n - 1 && !(thr <= cum)) ? 1 : 0;
+    }
+    if (ds.child >= 0) nst[ds.child * 64 + lane] = (uint8_t)cs;                                   // :655
   } else {
     const int tip = ~ds.child;
     cs = p.tips_per_replica ? tips_t[tip * 64 + lane] : p.tips[tip];            // :612
@@ -200,6 +233,7 @@ __global__ __launch_bounds__(WT_BLOCK) void wt_down_kernel(WtParams p, int it, i
 // straight to the tile's accumulators (integer atomics: exact in any order).
 template <bool KS>
 __global__ __launch_bounds__(WT_BLOCK) void wt_branch_kernel(WtParams p, int it) {
+  extern __shared__ __align__(16) double s_B2[];                    // [n][ldt] dense rows of the forward draws
   __shared__ uint8_t s_ms_all[(WT_BLOCK / 64) * 64 * 64];           // [wave][segment][lane]
   __shared__ double s_scale[64];
   __shared__ __align__(16) double s_ltab[2 * PHM_LOGTAB_N];        // (1/c_j, log c_j) of the exponential variates (neglog_u32)
@@ -210,6 +244,7 @@ __global__ __launch_bounds__(WT_BLOCK) void wt_branch_kernel(WtParams p, int it)
   const int n = p.n_states, ldt = p.ldt;
   for (int i = threadIdx.x; i < 2 * PHM_LOGTAB_N; i += WT_BLOCK) s_ltab[i] = logtab_entry(i);
   if ((int)threadIdx.x < n) s_scale[threadIdx.x] = p.scale[threadIdx.x];
+  for (int i = threadIdx.x; i < n * ldt; i += WT_BLOCK) s_B2[i] = p.B2[i];
   __syncthreads();
   if (item >= p.n_groups * p.n_tiles) return;        // whole waves only; no barrier below this line
   const int tile = item % p.n_tiles;
@@ -250,9 +285,30 @@ __global__ __launch_bounds__(WT_BLOCK) void wt_branch_kernel(WtParams p, int it)
   auto draw_state_w = [&](int i, int sprev, uint32_t word) -> int {
     int kk = m - i - 1;
     if (kk >= p.klong) { err |= DERR_CAPACITY; kk = p.klong - 1; }
-    const double* __restrict__ beta = p.colL + ((size_t)kk * n + cs) * ldt;
-    const double* __restrict__ brow = p.B2 + (size_t)sprev * ldt;
-    return sample_terms(n, u01(word), [&](int c) { return brow[c] * beta[c]; }, err);
+    // The total of the probability vector is a function of (kk, s_{i-1}, end state) alone: the host has formed it with the
+    // very sums a first pass would (totL), so one pass decides -- the running sum against u * total, two states per
+    // 16-byte read (beta: the lane's own table row through L1/L2; B row: LDS), until every lane has found its state.
+    const double2* __restrict__ beta = reinterpret_cast<const double2*>(p.colL + ((size_t)kk * n + cs) * ldt);
+    const double2* __restrict__ brow = reinterpret_cast<const double2*>(s_B2 + sprev * ldt);
+    const double total = p.totL[((size_t)kk * n + sprev) * ldt + cs];
+    if (!(total > 0.0) || isinf(total)) err |= DERR_ZERO_PROB;
+    const double thr = u01(word) * total;
+    double cum = 0.0;
+    int idx = 0;
+    for (int c2 = 0; 2 * c2 < n - 1; ++c2) {           // comparisons at states 0 .. n-2 decide (sample_cat)
+      const double2 bt = beta[c2], br = brow[c2];
+      cum += br.x * bt.x;
+      const bool past0 = !(thr <= cum);
+      idx += past0 ? 1 : 0;
+      bool past1 = false;
+      if (2 * c2 + 1 < n - 1) {
+        cum += br.y * bt.y;
+        past1 = !(thr <= cum);
+        idx += past1 ? 1 : 0;
+      }
+      if ((c2 & 3) == 3 && !__any(past0 || past1)) break;
+    }
+    return idx;
   };
 
   if (mmax <= 64) {
@@ -444,12 +500,19 @@ hipError_t launch_wtiles_sweep(const WtParams& p, const std::vector<int32_t>& up
   hipError_t e = launch_wtiles_up(p, up_off, stream);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(wt_root_kernel, blocks(p.n_tiles), dim3(WT_BLOCK), 0, stream, p, it);
+  const int mt = (p.n_states + 15) / 16;
   for (size_t l = 0; l + 1 < down_off.size(); ++l) {
     const int n = down_off[l + 1] - down_off[l];
-    if (n > 0) hipLaunchKernelGGL(wt_down_kernel, blocks((int64_t)n * p.n_tiles), dim3(WT_BLOCK), 0, stream, p, it, down_off[l], down_off[l + 1]);
+    if (n <= 0) continue;
+    const dim3 g = blocks((int64_t)n * p.n_tiles);
+    if (mt == 1) hipLaunchKernelGGL(wt_down_kernel<1>, g, dim3(WT_BLOCK), 0, stream, p, it, down_off[l], down_off[l + 1]);
+    else if (mt == 2) hipLaunchKernelGGL(wt_down_kernel<2>, g, dim3(WT_BLOCK), 0, stream, p, it, down_off[l], down_off[l + 1]);
+    else if (mt == 3) hipLaunchKernelGGL(wt_down_kernel<3>, g, dim3(WT_BLOCK), 0, stream, p, it, down_off[l], down_off[l + 1]);
+    else hipLaunchKernelGGL(wt_down_kernel<4>, g, dim3(WT_BLOCK), 0, stream, p, it, down_off[l], down_off[l + 1]);
   }
-  if (p.ks) hipLaunchKernelGGL((wt_branch_kernel<true>), blocks((int64_t)p.n_groups * p.n_tiles), dim3(WT_BLOCK), 0, stream, p, it);
-  else hipLaunchKernelGGL((wt_branch_kernel<false>), blocks((int64_t)p.n_groups * p.n_tiles), dim3(WT_BLOCK), 0, stream, p, it);
+  const size_t lds_b2 = sizeof(double) * (size_t)p.n_states * p.ldt;
+  if (p.ks) hipLaunchKernelGGL((wt_branch_kernel<true>), blocks((int64_t)p.n_groups * p.n_tiles), dim3(WT_BLOCK), lds_b2, stream, p, it);
+  else hipLaunchKernelGGL((wt_branch_kernel<false>), blocks((int64_t)p.n_groups * p.n_tiles), dim3(WT_BLOCK), lds_b2, stream, p, it);
   const int ncnt = p.ks ? p.n_states * p.n_states : p.n_states * (p.n_states - 1);
   const int dcols = p.n_states + ncnt + (p.ks ? 1 : 0);
   const int n_chunks = (dcols + 63) / 64;
