@@ -106,7 +106,16 @@ typedef struct phm_options {
                                        for 5..64 states (one state per lane): 1 = one wave per 64-replica tile, replicas in turn,
                                        2 or 3 = one wave per (replica, branch) (the automatic choice while its memory fits).
                                        Same draws and counts in every mapping; dwell sums differ in the last bits between
-                                       1 and 2/3 (summation order).  cap_tail defaults to 1e-12 for 2 and 3 (fixed slots). */
+                                       1 and 2/3 (summation order).  cap_tail defaults to 1e-12 for 2 and 3 (fixed slots).
+                                       5..64 states: 1 = one wave per 64-replica tile, replicas in turn, lanes = states (phm_wide.hip),
+                                       2 = one wave per (replica, branch), lanes = states (a handful of chains),
+                                       3 = one lane per replica, one wave per (tile, item), pruning on the matrix cores (the default
+                                       beyond 32 replicas)
+                                  [2]: 1 = record HIP events between the phases of a sweep (phm_engine_phase_ms)
+                                  [3]: phm_maketreelistEXP: 1 = divide every internal partial-likelihood row by its sum in the
+                                       pruning pass.  The reference's makePLexp (src/phylomap.cpp:2899-2906) does not rescale, so
+                                       sumstatEXP underflows (PHM_ERR_ZERO_PROB) beyond a few hundred tips; node draws do not
+                                       depend on a row's scale, so this is the same sampler in exact arithmetic */
 } phm_options;
 
 typedef struct phm_info {
@@ -128,6 +137,8 @@ int32_t     phm_version(void);
 int32_t     phm_device_count(void);
 const char* phm_last_error(void);
 const char* phm_status_string(int32_t status);
+/* measurement aid: HIP-event milliseconds of the sampling kernel of this thread's last phm_maketreelistEXP call */
+double      phm_last_kernel_ms(void);
 
 /* ---- reference-shaped one-shot entry points (what the Rcpp shim binds) ----
  * Each mirrors the argument list of the exported C++ driver it replaces; `out` is the caller-allocated
@@ -261,6 +272,10 @@ int32_t phm_engine_set_model(phm_engine* e, const double* Q);
 int32_t phm_engine_dump(phm_engine* e, int32_t replica, int32_t* seg_count, double* seg_dwell, int32_t seg_cap,
                         int32_t* node_states, double* PL);
 int32_t phm_engine_info(phm_engine* e, phm_info* info);
+/* measurement aid (phm_options.reserved[2] = 1, (tile, item) mappings): HIP-event milliseconds of the last phm_engine_run, summed over
+ * its sweeps, for the four phases of a sweep: pruning levels (makePLrcpp*), root + node draws (sampleinternalnodes*), the branch
+ * kernel (sampleabranch + updatedwelltimes), the statistics reductions.  Valid after phm_engine_sync. */
+int32_t phm_engine_phase_ms(phm_engine* e, double* out4);
 void    phm_engine_destroy(phm_engine* e);
 
 #ifdef __cplusplus

@@ -536,8 +536,11 @@ int orc_makePL(const orc_tree* x, int n, const double* Bchain, const int32_t* ne
 }
 
 /* makePLold :2877-2895 / makePLexp :2899-2906: P_b = TransProb.slice(b), row-major n x n per edge */
+/* rescale != 0: every internal row is divided by its sum (left to right) -- NOT in the reference (makePLexp has no rescaling,
+ * so sumstatEXP underflows on multi-hundred-tip trees); the node draws are invariant to positive scaling of a row, so this
+ * is the same sampler in exact arithmetic (what makePLrcpp_bigtree :525 does for the MCMC side). */
 static void makePLexp(const int32_t* edge1, const int32_t* edge2, int Nnode, double* PL, const int32_t* ne,
-                      const double* P, int n, double* w) {
+                      const double* P, int n, double* w, int rescale) {
   double* a = w; double* b = w + n;
   for (int i = 0; i < Nnode; ++i) {
     int ea = ne[2 * i] - 1, eb = ne[2 * i + 1] - 1;
@@ -545,6 +548,11 @@ static void makePLexp(const int32_t* edge1, const int32_t* edge2, int Nnode, dou
     matvec(P + (size_t)eb * n * n, PL + (size_t)(edge2[eb] - 1) * n, b, n);
     double* row = PL + (size_t)(edge1[ea] - 1) * n;
     for (int c = 0; c < n; ++c) row[c] = a[c] * b[c];                        /* :2903 */
+    if (rescale) {
+      double s = row[0];
+      for (int c = 1; c < n; ++c) s += row[c];
+      for (int c = 0; c < n; ++c) row[c] = row[c] / s;
+    }
   }
 }
 int orc_makePLexp(const orc_tree* x, int n, const double* P, const int32_t* nen, double* PL) {
@@ -553,7 +561,7 @@ int orc_makePLexp(const orc_tree* x, int n, const double* P, const int32_t* nen,
   memset(PL, 0, sizeof(double) * (size_t)(2 * x->n_node + 1) * n);
   for (int i = 0; i < T; ++i) PL[(size_t)i * n + (x->states[i] - 1)] = 1.0;
   double* w = (double*)malloc(sizeof(double) * 2 * n);
-  makePLexp(x->edge, x->edge + E, x->n_node, PL, nen, P, n, w);
+  makePLexp(x->edge, x->edge + E, x->n_node, PL, nen, P, n, w, 0);
   free(w);
   return 0;
 }
@@ -1350,7 +1358,8 @@ int orc_maketreelistEXP(const orc_tree* x, int n, const double* Q_cm, const doub
   double* PL = (double*)calloc(pl_len, sizeof(double));
   for (int i = 0; i < T; ++i) PL[(size_t)i * n + (x->states[i] - 1)] = 1.0;
   double* w = (double*)malloc(sizeof(double) * 2 * n);
-  makePLexp(edge1, edge2, Nnode, PL, nen, P, n, w);                          /* :3043 */
+  const int rescale = (recompute_expm_each_iter & 2) != 0;                   /* bit 1: rescaled pruning (not in the reference) */
+  makePLexp(edge1, edge2, Nnode, PL, nen, P, n, w, rescale);                 /* :3043 */
   int32_t* rm = (int32_t*)calloc(2 * T - 1, sizeof(int32_t));
   int32_t* eoc = (int32_t*)calloc(2 * T - 1, sizeof(int32_t));
   for (int i = 0; i < E; ++i) eoc[edge2[i] - 1] = i;
@@ -1361,9 +1370,9 @@ int orc_maketreelistEXP(const orc_tree* x, int n, const double* Q_cm, const doub
   memset(out, 0, sizeof(double) * (size_t)N * cols);
 
   if (!e) for (int it = 0; it < N; ++it) {
-    if (recompute_expm_each_iter) {                                          /* :2980-2981 (Q never changes) */
+    if (recompute_expm_each_iter & 1) {                                      /* :2980-2981 (Q never changes) */
       for (int i = 0; i < E; ++i) orc_matexp(L, R, dv, n, x->edge_length[i], P + nn * i);
-      makePLexp(edge1, edge2, Nnode, PL, nen, P, n, w);
+      makePLexp(edge1, edge2, Nnode, PL, nen, P, n, w, rescale);
     }
     sampleinternalnodesEXP(edge1, edge2, x->states, T, PL, pid, root, nodelist, Nnode - 1, P, n,
                            faithful_search, eoc, &rc, (uint32_t)it, rm, w);

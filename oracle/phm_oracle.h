@@ -139,7 +139,9 @@ int orc_maketreelistMCMCmt(const orc_tree* const* xs, int treecount, int n, cons
                            const int32_t* roots, int32_t N, int variant, const double* prior, int faithful_search,
                            orc_rng* rng, double* out);
 
-/* maketreelistEXP src/phylomap.cpp:3001-3051. lefts/rights column-major, d = n x n col-major (diag used). */
+/* maketreelistEXP src/phylomap.cpp:3001-3051. lefts/rights column-major, d = n x n col-major (diag used).
+ * recompute_expm_each_iter: bit 0 = recompute P(t_b) and the pruning pass every iteration as the reference does (:2980-2981);
+ * bit 1 = divide every internal partial-likelihood row by its sum (not in the reference: same sampler, no underflow). */
 int orc_maketreelistEXP(const orc_tree* x, int n, const double* Q_cm, const double* pid,
                         const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
                         const double* lefts_cm, const double* rights_cm, const double* d_cm,

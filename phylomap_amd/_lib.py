@@ -23,7 +23,8 @@ EXPORTS = [
     "phm_engine_create", "phm_engine_run", "phm_engine_sync", "phm_engine_read_stats", "phm_engine_dump",
     "phm_engine_info", "phm_engine_destroy", "phm_engine_reduced_stats_device",
     "phm_engine_time_pruning", "phm_tree_orders",
-    "phm_engine_create_multi", "phm_maketreelistMCMCmt", "phm_maketreelistMCMCksmt",
+    "phm_engine_create_multi", "phm_maketreelistMCMCmt", "phm_maketreelistMCMCksmt", "phm_engine_phase_ms",
+    "phm_last_kernel_ms",
 ]
 
 
@@ -77,6 +78,7 @@ def load():
         L.phm_last_error.restype = C.c_char_p
         L.phm_status_string.restype = C.c_char_p
         L.phm_status_string.argtypes = [C.c_int32]
+        L.phm_last_kernel_ms.restype = C.c_double
         L.phm_engine_create.argtypes = [C.POINTER(Tree), C.POINTER(Model), C.POINTER(Options), C.c_int32,
                                         C.POINTER(C.c_void_p)]
         L.phm_engine_create_multi.argtypes = [C.POINTER(Tree), C.c_int32, C.POINTER(Model), C.POINTER(Options), C.c_int32,
@@ -92,6 +94,7 @@ def load():
         L.phm_engine_time_pruning.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_double)]
         L.phm_engine_reduced_stats_device.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                                       C.POINTER(C.c_void_p)]
+        L.phm_engine_phase_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         L.phm_engine_destroy.argtypes = [C.c_void_p]
         L.phm_engine_destroy.restype = None
         mc = [C.POINTER(Tree), C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
@@ -187,15 +190,17 @@ MAPPING = {"auto": 0, "replicas": 1, "branches": 2, "tiles": 3}
 
 
 def make_options(seed=0, n_replicas=1, replica_offset=0, reduce=False, tips_per_replica=False, device=-1,
-                 iters_per_launch=0, cap_tail=0.0, storage=0, mapping="auto"):
+                 iters_per_launch=0, cap_tail=0.0, storage=0, mapping="auto", phase_timing=False, rescale=False):
     """``mapping``: how a sweep is laid over the lanes -- "replicas" (one lane per chain: the throughput layout for many
-    replicas), "branches" (one lane per branch: few chains on a large tree, n <= 4), "tiles" (one wave per tile of 64 replicas and
-    branch: 10^2 .. 10^5 replicas, n <= 4) or "auto"."""
+    replicas), "branches" (one lane per branch, n <= 4; one wave per (replica, branch) for 5..64 states: few chains on a large
+    tree), "tiles" (lanes = replicas, one wave per tile of 64 replicas and branch: 10^2 .. 10^5 replicas) or "auto"."""
     o = Options()
     o.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
     o.n_replicas, o.replica_offset, o.reduce = int(n_replicas), int(replica_offset), int(bool(reduce))
     o.reserved[0] = int(storage)          # 0 automatic, 1 ring, 2 two buffers
     o.reserved[1] = MAPPING[mapping] if isinstance(mapping, str) else int(mapping)
+    o.reserved[2] = int(bool(phase_timing))
+    o.reserved[3] = int(bool(rescale))      # sumstatEXP: rescaled pruning pass
     o.tips_per_replica, o.device, o.iters_per_launch, o.cap_tail = int(bool(tips_per_replica)), int(device), int(iters_per_launch), float(cap_tail)
     return o
 
@@ -265,6 +270,12 @@ class Engine:
         check(load().phm_engine_reduced_stats_device(self.h, int(iter0), int(n), C.c_void_p(stream) if stream else None,
                                                      C.byref(ptr)))
         return ptr.value
+
+    def phase_ms(self):
+        """(pruning levels, node draws, branch kernel, reductions): HIP-event ms of the last run, summed over its sweeps."""
+        out = (C.c_double * 4)()
+        check(load().phm_engine_phase_ms(self.h, out))
+        return [float(v) for v in out]
 
     def time_pruning(self, n_iters, stream=None):
         """HIP-event milliseconds for n_iters repetitions of the pruning sweep alone (chain state untouched)."""

@@ -82,12 +82,12 @@ int32_t upload_model(phm_engine* e) {
   const int ktab = (e->narrow || e->tiled) ? e->nw_klong : std::max(e->nw_klong, e->wide ? phm::WIDE_KTAB : phm::MCMC_KTAB);      // narrow covers both branch mappings (n <= 4 and 5..64)
   const double* Bc = e->hBc.data();
   std::vector<double> col, row;
-  build_chain_tables(Bc, n, ktab, col, row);
+  build_chain_tables(Bc, n, ktab, col, row, n > 4);
   std::vector<double> maskpow((size_t)ktab * 2 * n, 0.0);      // ks: Bc^k applied to the even / odd state masks (:1838-1845)
   for (int par = 0; par < 2; ++par) {
     for (int c = 0; c < n; ++c) maskpow[(size_t)par * n + c] = ((c & 1) == par) ? 1.0 : 0.0;
     for (int k = 1; k < ktab; ++k)
-      host_chain_matvec(Bc, n, &maskpow[((size_t)(k - 1) * 2 + par) * n], &maskpow[((size_t)k * 2 + par) * n]);
+      host_chain_matvec(Bc, n, &maskpow[((size_t)(k - 1) * 2 + par) * n], &maskpow[((size_t)k * 2 + par) * n], n > 4);
   }
   if (e->tiled && e->wide) {        // phm_wtiles.hip: table rows padded to an even length (16-byte rows), model in global memory
     const int ldt = e->pwt.ldt;
@@ -729,6 +729,7 @@ int32_t phm_engine_create_multi(const phm_tree* trees, int32_t n_trees, const ph
   e->max_iters = max_iters; e->reduce = o.reduce ? 1 : 0;
   e->ipl = o.iters_per_launch > 0 ? o.iters_per_launch : 8;
   e->tips_per_replica = o.tips_per_replica != 0 || n_trees > 1;      // a list of trees: tip data per tile
+  e->phase_timing = o.reserved[2] != 0;
 
   std::string serr;
   e->scheds.resize(n_trees);
@@ -984,12 +985,18 @@ int32_t phm_engine_run(phm_engine* e, int32_t n_iters, void* hip_stream) {
   }
   if (e->tiled) {
     hipError_t le = hipSuccess;
+    e->phase_iters = 0;
+    if (e->phase_timing) {
+      while ((int)e->phase_ev.size() < 5 * n_iters) { hipEvent_t ev; HIPCHK(hipEventCreate(&ev)); e->phase_ev.push_back(ev); }
+      e->phase_iters = n_iters;
+    }
     for (int i = 0; i < n_iters && le == hipSuccess; ++i) {
       const int it = e->iters_done + i;
-      if (e->n == 2) le = phm::launch_tiles_sweep<2>(e->t2, e->nw_up_off, e->nw_down_off, it, stream);
-      if (e->n == 3) le = phm::launch_tiles_sweep<3>(e->t3, e->nw_up_off, e->nw_down_off, it, stream);
-      if (e->n == 4) le = phm::launch_tiles_sweep<4>(e->t4, e->nw_up_off, e->nw_down_off, it, stream);
-      if (e->wide) le = phm::launch_wtiles_sweep(e->pwt, e->nw_up_off, e->nw_down_off, it, stream);
+      hipEvent_t* pev = e->phase_timing ? &e->phase_ev[5 * (size_t)i] : nullptr;
+      if (e->n == 2) le = phm::launch_tiles_sweep<2>(e->t2, e->nw_up_off, e->nw_down_off, it, stream, pev);
+      if (e->n == 3) le = phm::launch_tiles_sweep<3>(e->t3, e->nw_up_off, e->nw_down_off, it, stream, pev);
+      if (e->n == 4) le = phm::launch_tiles_sweep<4>(e->t4, e->nw_up_off, e->nw_down_off, it, stream, pev);
+      if (e->wide) le = phm::launch_wtiles_sweep(e->pwt, e->nw_up_off, e->nw_down_off, it, stream, pev);
       launches += (int)(e->nw_up_off.size() + e->nw_down_off.size()) + 2;
     }
     HIPCHK(le);
@@ -1023,6 +1030,13 @@ int32_t phm_engine_sync(phm_engine* e) {
     HIPCHK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
     e->last_ms = ms;
     e->timing_pending = false;
+    for (double& v : e->phase_ms) v = 0.0;
+    for (int i = 0; i < e->phase_iters; ++i)
+      for (int ph = 0; ph < 4; ++ph) {
+        float pm = 0.f;
+        HIPCHK(hipEventElapsedTime(&pm, e->phase_ev[5 * (size_t)i + ph], e->phase_ev[5 * (size_t)i + ph + 1]));
+        e->phase_ms[ph] += pm;
+      }
   }
   uint32_t derr = 0;
   HIPCHK(hipMemcpy(&derr, e->d_err.p, sizeof derr, hipMemcpyDeviceToHost));
@@ -1166,6 +1180,13 @@ int32_t phm_engine_info(phm_engine* e, phm_info* info) {
 }
 
 void phm_engine_destroy(phm_engine* e) { delete e; }
+
+int32_t phm_engine_phase_ms(phm_engine* e, double* out4) {
+  if (!e || !out4) return fail(PHM_ERR_STATE, "engine/out is NULL");
+  if (!e->phase_timing || !e->tiled) return fail(PHM_ERR_STATE, "phase timing needs phm_options.reserved[2] = 1 and a (tile, item) mapping");
+  for (int i = 0; i < 4; ++i) out4[i] = e->phase_ms[i];
+  return PHM_OK;
+}
 
 }  // extern "C"
 

@@ -32,8 +32,9 @@ hipError_t launch_expm_pade(int n, const double* Q, const double* t, const int32
 hipError_t launch_expm_pade_mfma(int n, const double* Q, const double* t, const int32_t* s, int n_t, double* out,
                                  uint32_t* err, hipStream_t stream);
 
-// PL[parent] = (P_a PL[child_a]) (.) (P_b PL[child_b]); PL is (2T-1) x n row-major, tips pre-filled one-hot
-hipError_t launch_exp_pl(int n, int n_node, int n_tips, const UpStep* up, const double* P, double* PL,
+// PL[parent] = (P_a PL[child_a]) (.) (P_b PL[child_b]); PL is (2T-1) x n row-major, tips pre-filled one-hot;
+// rescale: every internal row divided by its sum (not in the reference; the node draws do not depend on a row's scale)
+hipError_t launch_exp_pl(int n, int n_node, int n_tips, const UpStep* up, const double* P, double* PL, int rescale,
                          hipStream_t stream);
 
 // log p(y|Q): pruning with P(t_b), rows normalised, log scale factors summed in the order of `up` (DIC drivers).

@@ -152,7 +152,7 @@ hipError_t launch_expm_pade(int n, const double* Q, const double* t, const int32
 // K2e: pruning with P(t_b); the result is shared by every sample, so one thread walks the tree once.
 // ------------------------------------------------------------------------------------------------
 __global__ void exp_pl_kernel(int n, int n_node, int n_tips, const UpStep* __restrict__ up, const double* __restrict__ P,
-                              double* __restrict__ PL) {
+                              double* __restrict__ PL, int rescale) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   for (int k = 0; k < n_node; ++k) {
     const UpStep st = up[k];
@@ -170,12 +170,17 @@ __global__ void exp_pl_kernel(int n, int n_node, int n_tips, const UpStep* __res
       for (int j = 1; j < n; ++j) b += Pb[i * n + j] * vb[j];
       dst[i] = a * b;                                                           // :2903
     }
+    if (rescale) {      // not in the reference: row / sum(row), the sampler-equivalent rescaling of makePLrcpp_bigtree :525
+      double sum = dst[0];
+      for (int i = 1; i < n; ++i) sum += dst[i];
+      for (int i = 0; i < n; ++i) dst[i] = dst[i] / sum;
+    }
   }
 }
 
-hipError_t launch_exp_pl(int n, int n_node, int n_tips, const UpStep* up, const double* P, double* PL,
+hipError_t launch_exp_pl(int n, int n_node, int n_tips, const UpStep* up, const double* P, double* PL, int rescale,
                          hipStream_t stream) {
-  hipLaunchKernelGGL(exp_pl_kernel, dim3(1), dim3(64), 0, stream, n, n_node, n_tips, up, P, PL);
+  hipLaunchKernelGGL(exp_pl_kernel, dim3(1), dim3(64), 0, stream, n, n_node, n_tips, up, P, PL, rescale);
   return hipGetLastError();
 }
 

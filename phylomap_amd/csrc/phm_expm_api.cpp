@@ -131,7 +131,7 @@ int32_t phm_maketreelistEXP(const phm_tree* x, int32_t n, const double* Q, const
       B2[(size_t)i * n + j] = b;
     }
   std::vector<double> col, rowtab;
-  build_chain_tables(B2.data(), n, phm::UNIF_CAP + 1, col, rowtab);
+  build_chain_tables(B2.data(), n, phm::UNIF_CAP + 1, col, rowtab, false);      // newunifSample :127: unfused sums for every n
 
   st = select_device(o.device);
   if (st) return st;
@@ -163,7 +163,10 @@ int32_t phm_maketreelistEXP(const phm_tree* x, int32_t n, const double* Q, const
   HIPCHK(hipMemset(dnst.p, 0, dnst.bytes));
 
   HIPCHK(phm::launch_expm_eigen(n, dL.as<double>(), dR.as<double>(), dd.as<double>(), dt.as<double>(), E, dP.as<double>(), nullptr));   // :3042
-  HIPCHK(phm::launch_exp_pl(n, s.n_node, T, dup.as<phm::UpStep>(), dP.as<double>(), dPL.as<double>(), nullptr));                       // :3043
+  HIPCHK(phm::launch_exp_pl(n, s.n_node, T, dup.as<phm::UpStep>(), dP.as<double>(), dPL.as<double>(), o.reserved[3] != 0, nullptr));   // :3043
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;      // time of the sampling kernel alone (phm_last_kernel_ms)
+  HIPCHK(hipEventCreate(&ev0)); HIPCHK(hipEventCreate(&ev1));
+  HIPCHK(hipEventRecord(ev0, nullptr));
 
   auto fill = [&](auto& p) {
     p.n_tips = T; p.n_node = s.n_node; p.n_edge = E; p.root = s.root; p.N = N; p.n_tiles = tiles;
@@ -195,10 +198,16 @@ int32_t phm_maketreelistEXP(const phm_tree* x, int32_t n, const double* Q, const
     HIPCHK(hipDeviceSynchronize());
   }
   HIPCHK(le);
+  HIPCHK(hipEventRecord(ev1, nullptr));
+  HIPCHK(hipEventSynchronize(ev1));
+  { float ms = 0.f; if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) g_phm_last_kernel_ms = ms; }
+  (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
   HIPCHK(hipMemcpy(out, dout.p, dout.bytes, hipMemcpyDeviceToHost));
   uint32_t derrh = 0;
   HIPCHK(hipMemcpy(&derrh, derr.p, sizeof derrh, hipMemcpyDeviceToHost));
   return device_status(derrh);
 }
+
+double phm_last_kernel_ms(void) { return g_phm_last_kernel_ms; }
 
 }  // extern "C"

@@ -25,6 +25,7 @@
 #include "phm_wtiles.h"
 
 inline thread_local std::string g_phm_err;      // phm_last_error()
+inline thread_local double g_phm_last_kernel_ms = 0.0;      // phm_last_kernel_ms()
 
 inline int32_t fail(int32_t st, const std::string& msg) { g_phm_err = msg; return st; }
 
@@ -95,9 +96,9 @@ inline int pade_squarings(const double* Q_rm, int n, double t) {
 // Mat-vec of the MCMC chains on the host.  n <= 4: unfused left-to-right sums, what the n <= 4 kernels'
 // matvec_u does.  n > 4: one fused multiply-add per term, j ascending, from +0 -- what v_mfma_f64_16x16x4 accumulates in
 // the pruning kernel of phm_wtiles.hip and what phm_coop.h does lane-wise.  y = M x (row-major M).
-inline void host_chain_matvec(const double* M, int n, const double* x, double* y) {
+inline void host_chain_matvec(const double* M, int n, const double* x, double* y, bool fused) {
   for (int i = 0; i < n; ++i) {
-    if (n > 4) {
+    if (fused) {
       double acc = 0.0;
       for (int c = 0; c < n; ++c) acc = std::fma(M[(size_t)i * n + c], x[c], acc);
       y[i] = acc;
@@ -109,9 +110,9 @@ inline void host_chain_matvec(const double* M, int n, const double* x, double* y
   }
 }
 // y = M^T x
-inline void host_chain_matTvec(const double* M, int n, const double* x, double* y) {
+inline void host_chain_matTvec(const double* M, int n, const double* x, double* y, bool fused) {
   for (int c = 0; c < n; ++c) {
-    if (n > 4) {
+    if (fused) {
       double acc = 0.0;
       for (int r = 0; r < n; ++r) acc = std::fma(M[(size_t)r * n + c], x[r], acc);
       y[c] = acc;
@@ -124,15 +125,16 @@ inline void host_chain_matTvec(const double* M, int n, const double* x, double* 
 }
 
 // chain tables: col[k][j][:] = Bc^k e_j  (v <- Bc v), row[k][j][:] = (Bc^T)^k e_j (w <- Bc^T w);
-// the same sums as the kernels' own chains, so entries are bit-identical to running the chain.
-inline void build_chain_tables(const double* Bc, int n, int ktab, std::vector<double>& col, std::vector<double>& row) {
+// the same sums as the kernels' own chains, so entries are bit-identical to running the chain.  `fused`: the MCMC sweep with
+// n > 4; the sumstatEXP path (newunifSample :127) keeps the unfused left-to-right sums for every n.
+inline void build_chain_tables(const double* Bc, int n, int ktab, std::vector<double>& col, std::vector<double>& row, bool fused) {
   col.assign((size_t)ktab * n * n, 0.0);
   row.assign((size_t)ktab * n * n, 0.0);
   for (int j = 0; j < n; ++j) { col[(size_t)j * n + j] = 1.0; row[(size_t)j * n + j] = 1.0; }
   for (int k = 1; k < ktab; ++k)
     for (int j = 0; j < n; ++j) {
-      host_chain_matvec(Bc, n, &col[((size_t)(k - 1) * n + j) * n], &col[((size_t)k * n + j) * n]);
-      host_chain_matTvec(Bc, n, &row[((size_t)(k - 1) * n + j) * n], &row[((size_t)k * n + j) * n]);
+      host_chain_matvec(Bc, n, &col[((size_t)(k - 1) * n + j) * n], &col[((size_t)k * n + j) * n], fused);
+      host_chain_matTvec(Bc, n, &row[((size_t)(k - 1) * n + j) * n], &row[((size_t)k * n + j) * n], fused);
     }
 }
 
@@ -204,6 +206,10 @@ struct phm_engine {
   // 5..64 states with `tiled` set: one lane per replica, wave per (tile, item), pruning on the matrix cores (phm_wtiles.hip)
   phm::WtParams pwt;
   DevBuf d_wt_dwfx, d_wt_segacc, d_wt_B2, d_wt_totL;
+  bool phase_timing = false;                       // phm_options.reserved[2]: HIP events between the phases of a (tile, item) sweep
+  std::vector<hipEvent_t> phase_ev;                // 5 per iteration of the last run
+  int phase_iters = 0;
+  double phase_ms[4] = {0.0, 0.0, 0.0, 0.0};       // pruning levels, node draws, branch kernel, reductions (sums over the last run)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipStream_t last_stream = nullptr;
   bool timing_pending = false;
@@ -214,5 +220,6 @@ struct phm_engine {
   ~phm_engine() {
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
+    for (hipEvent_t ev : phase_ev) (void)hipEventDestroy(ev);
   }
 };

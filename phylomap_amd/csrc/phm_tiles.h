@@ -70,8 +70,10 @@ struct TileParams {
 hipError_t launch_tiles_init(int n_edge, int n_tiles, int64_t rows, const int32_t* slot, const int32_t* map_off,
                              const double* maps, double* dw0, uint16_t* mcount, hipStream_t stream);
 
+// phase_ev: optional 5 events recorded before the pruning levels and after the pruning levels, the node draws, the branch kernel
+// and the reductions (measurement: bench.py's per-kernel roofline)
 template <int NS>
 hipError_t launch_tiles_sweep(const TileParams<NS>& p, const std::vector<int32_t>& up_off,
-                              const std::vector<int32_t>& down_off, int it, hipStream_t stream);
+                              const std::vector<int32_t>& down_off, int it, hipStream_t stream, hipEvent_t* phase_ev = nullptr);
 
 }  // namespace phm

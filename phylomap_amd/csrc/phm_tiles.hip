@@ -425,28 +425,34 @@ hipError_t launch_tiles_init(int n_edge, int n_tiles, int64_t rows, const int32_
 
 template <int NS>
 hipError_t launch_tiles_sweep(const TileParams<NS>& p, const std::vector<int32_t>& up_off,
-                              const std::vector<int32_t>& down_off, int it, hipStream_t stream) {
+                              const std::vector<int32_t>& down_off, int it, hipStream_t stream, hipEvent_t* phase_ev) {
   constexpr int WPB = TILES_BLOCK / 64;
   auto blocks = [&](int64_t items) { return dim3((unsigned)((items + WPB - 1) / WPB)); };
+  auto mark = [&](int i) { if (phase_ev) (void)hipEventRecord(phase_ev[i], stream); };
+  mark(0);
   for (size_t l = 0; l + 1 < up_off.size(); ++l) {
     const int n = up_off[l + 1] - up_off[l];
     if (n > 0) hipLaunchKernelGGL(tiles_up_kernel<NS>, blocks((int64_t)n * p.n_tiles), dim3(TILES_BLOCK), 0, stream, p, up_off[l], up_off[l + 1]);
   }
+  mark(1);
   hipLaunchKernelGGL(tiles_root_kernel<NS>, blocks(p.n_tiles), dim3(TILES_BLOCK), 0, stream, p, it);
   for (size_t l = 0; l + 1 < down_off.size(); ++l) {
     const int n = down_off[l + 1] - down_off[l];
     if (n > 0) hipLaunchKernelGGL(tiles_down_kernel<NS>, blocks((int64_t)n * p.n_tiles), dim3(TILES_BLOCK), 0, stream, p, it, down_off[l], down_off[l + 1]);
   }
+  mark(2);
   if (p.ks) hipLaunchKernelGGL((tiles_branch_kernel<NS, true>), blocks((int64_t)p.n_groups * p.n_tiles), dim3(TILES_BLOCK), 0, stream, p, it);
   else hipLaunchKernelGGL((tiles_branch_kernel<NS, false>), blocks((int64_t)p.n_groups * p.n_tiles), dim3(TILES_BLOCK), 0, stream, p, it);
+  mark(3);
   hipLaunchKernelGGL(tiles_chunk_kernel<NS>, blocks((int64_t)p.n_chunks * p.n_tiles), dim3(TILES_BLOCK), 0, stream, p);
   if (p.ks) hipLaunchKernelGGL((tiles_stats_kernel<NS, true>), blocks(p.n_tiles), dim3(TILES_BLOCK), 0, stream, p, it);
   else hipLaunchKernelGGL((tiles_stats_kernel<NS, false>), blocks(p.n_tiles), dim3(TILES_BLOCK), 0, stream, p, it);
+  mark(4);
   return hipGetLastError();
 }
 
-template hipError_t launch_tiles_sweep<2>(const TileParams<2>&, const std::vector<int32_t>&, const std::vector<int32_t>&, int, hipStream_t);
-template hipError_t launch_tiles_sweep<3>(const TileParams<3>&, const std::vector<int32_t>&, const std::vector<int32_t>&, int, hipStream_t);
-template hipError_t launch_tiles_sweep<4>(const TileParams<4>&, const std::vector<int32_t>&, const std::vector<int32_t>&, int, hipStream_t);
+template hipError_t launch_tiles_sweep<2>(const TileParams<2>&, const std::vector<int32_t>&, const std::vector<int32_t>&, int, hipStream_t, hipEvent_t*);
+template hipError_t launch_tiles_sweep<3>(const TileParams<3>&, const std::vector<int32_t>&, const std::vector<int32_t>&, int, hipStream_t, hipEvent_t*);
+template hipError_t launch_tiles_sweep<4>(const TileParams<4>&, const std::vector<int32_t>&, const std::vector<int32_t>&, int, hipStream_t, hipEvent_t*);
 
 }  // namespace phm

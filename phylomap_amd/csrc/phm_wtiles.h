@@ -73,8 +73,9 @@ struct WtParams {
   unsigned long long* segcnt;
 };
 
+// phase_ev: optional 5 events, as in launch_tiles_sweep
 hipError_t launch_wtiles_sweep(const WtParams& p, const std::vector<int32_t>& up_off,
-                               const std::vector<int32_t>& down_off, int it, hipStream_t stream);
+                               const std::vector<int32_t>& down_off, int it, hipStream_t stream, hipEvent_t* phase_ev = nullptr);
 // the pruning (up) sweep alone, for bench.py's roofline block
 hipError_t launch_wtiles_up(const WtParams& p, const std::vector<int32_t>& up_off, hipStream_t stream);
 

@@ -494,11 +494,14 @@ hipError_t launch_wtiles_up(const WtParams& p, const std::vector<int32_t>& up_of
 }
 
 hipError_t launch_wtiles_sweep(const WtParams& p, const std::vector<int32_t>& up_off,
-                               const std::vector<int32_t>& down_off, int it, hipStream_t stream) {
+                               const std::vector<int32_t>& down_off, int it, hipStream_t stream, hipEvent_t* phase_ev) {
   constexpr int WPB = WT_BLOCK / 64;
   auto blocks = [&](int64_t items) { return dim3((unsigned)((items + WPB - 1) / WPB)); };
+  auto mark = [&](int i) { if (phase_ev) (void)hipEventRecord(phase_ev[i], stream); };
+  mark(0);
   hipError_t e = launch_wtiles_up(p, up_off, stream);
   if (e != hipSuccess) return e;
+  mark(1);
   hipLaunchKernelGGL(wt_root_kernel, blocks(p.n_tiles), dim3(WT_BLOCK), 0, stream, p, it);
   const int mt = (p.n_states + 15) / 16;
   for (size_t l = 0; l + 1 < down_off.size(); ++l) {
@@ -510,13 +513,16 @@ hipError_t launch_wtiles_sweep(const WtParams& p, const std::vector<int32_t>& up
     else if (mt == 3) hipLaunchKernelGGL(wt_down_kernel<3>, g, dim3(WT_BLOCK), 0, stream, p, it, down_off[l], down_off[l + 1]);
     else hipLaunchKernelGGL(wt_down_kernel<4>, g, dim3(WT_BLOCK), 0, stream, p, it, down_off[l], down_off[l + 1]);
   }
+  mark(2);
   const size_t lds_b2 = sizeof(double) * (size_t)p.n_states * p.ldt;
   if (p.ks) hipLaunchKernelGGL((wt_branch_kernel<true>), blocks((int64_t)p.n_groups * p.n_tiles), dim3(WT_BLOCK), lds_b2, stream, p, it);
   else hipLaunchKernelGGL((wt_branch_kernel<false>), blocks((int64_t)p.n_groups * p.n_tiles), dim3(WT_BLOCK), lds_b2, stream, p, it);
+  mark(3);
   const int ncnt = p.ks ? p.n_states * p.n_states : p.n_states * (p.n_states - 1);
   const int dcols = p.n_states + ncnt + (p.ks ? 1 : 0);
   const int n_chunks = (dcols + 63) / 64;
   hipLaunchKernelGGL(wt_stats_kernel, blocks((int64_t)n_chunks * p.n_tiles), dim3(WT_BLOCK), 0, stream, p, it, n_chunks);
+  mark(4);
   return hipGetLastError();
 }
 

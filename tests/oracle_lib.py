@@ -180,7 +180,7 @@ def maketreelistMCMCmt(treelist, Q, pid, B, Omega, nen_m, nodelist_m, roots, N, 
 
 
 def maketreelistEXP(z, Q, pid, nen, nodelist, root, N, lefts, rights, d, seed=1, replica=0,
-                    faithful_search=False, recompute=False, tape_u=None, dump=False):
+                    faithful_search=False, recompute=False, tape_u=None, dump=False, rescale=False):
     Q = np.asarray(Q, dtype=np.float64)
     n = Q.shape[0]
     ft = FlatTree(z)
@@ -196,7 +196,7 @@ def maketreelistEXP(z, Q, pid, nen, nodelist, root, N, lefts, rights, d, seed=1,
     rc = lib().orc_maketreelistEXP(C.byref(ft.c), n, _ptr(Qc, C.c_double), _ptr(pid, C.c_double),
                                    _ptr(nen, C.c_int32), _ptr(nodelist, C.c_int32), int(root), int(N),
                                    _ptr(Lc, C.c_double), _ptr(Rc, C.c_double), _ptr(Dc, C.c_double),
-                                   int(faithful_search), int(recompute), C.byref(rng), _ptr(out, C.c_double),
+                                   int(faithful_search), int(bool(recompute)) | (2 if rescale else 0), C.byref(rng), _ptr(out, C.c_double),
                                    C.byref(db.c) if db else None)
     del keep
     return (out, rc, db) if dump else (out, rc)

@@ -338,7 +338,7 @@ def matexp(L, R, dv, t):
     return P
 
 
-def sumstatEXP(z, Q, pid, N, nen, nodelist, root, L, R, dv, seed, replica):
+def sumstatEXP(z, Q, pid, N, nen, nodelist, root, L, R, dv, seed, replica, rescale=False):
     """maketreelistEXP :3001-3051 with treesampleEXP :2977-2996 and newunifSample :93-208."""
     n = len(Q)
     E = len(z["edge"])
@@ -357,7 +357,13 @@ def sumstatEXP(z, Q, pid, N, nen, nodelist, root, L, R, dv, seed, replica):
         ea, eb = nen[2 * i] - 1, nen[2 * i + 1] - 1
         a = matvec_lr(P[ea], PL[e2[ea] - 1])
         b = matvec_lr(P[eb], PL[e2[eb] - 1])
-        PL[e1[ea] - 1] = [a[c] * b[c] for c in range(n)]
+        row = [a[c] * b[c] for c in range(n)]
+        if rescale:                                   # not in the reference: row / sum(row), left to right (sampler-equivalent)
+            sm = row[0]
+            for c in range(1, n):
+                sm += row[c]
+            row = [x / sm for x in row]
+        PL[e1[ea] - 1] = row
     cols = n + n * (n - 1)
     out = [[0.0] * cols for _ in range(N)]
     for it in range(N):

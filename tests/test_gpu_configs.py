@@ -173,3 +173,35 @@ def test_golden_fixtures_through_the_c_abi(name):
         got = api.sumstatEXP(z, Q, pid, int(g["exp_r0"].shape[0]), seed=seed, eig=(g["lefts"], g["rights"], g["d"]))
         np.testing.assert_array_equal(got[:, n:], g["exp_r0"][:, n:])
         np.testing.assert_allclose(got[:, :n], g["exp_r0"][:, :n], rtol=1e-10, atol=0)
+
+
+def test_exp_rescaled_pruning_at_c2_size_and_equal_to_plain_on_small_trees():
+    """sumstatEXP with the pruning pass rescaled (phm_options.reserved[3]; not in the reference, whose makePLexp
+    src/phylomap.cpp:2899-2906 underflows beyond a few hundred tips): 1 000-tip C2 tree against the oracle; plain raises like
+    RcppArmadillo::sample would; on the 100-tip C1 tree both samplers draw the same histories."""
+    z, Q, pid, Omega, nen, nodelist, root = _config(2)
+    lefts, rights, d = api.eigen_decompose(Q)
+    with pytest.raises(_lib.PhmError) as e:
+        api.sumstatEXP(z, Q, pid, 8, seed=3)
+    assert e.value.status == 5
+    N = 96
+    got = api.sumstatEXP(z, Q, pid, N, seed=3, rescale=True)
+    want, rc = O.maketreelistEXP(z, Q, pid, nen, nodelist, root, N, lefts, rights, d, seed=3, rescale=True)
+    assert rc == 0
+    np.testing.assert_array_equal(got[:, 4:], want[:, 4:])
+    np.testing.assert_allclose(got[:, :4], want[:, :4], rtol=1e-10, atol=0)
+    np.testing.assert_allclose(got[:, :4].sum(1), z["edge.length"].sum(), rtol=1e-12)
+    z1, Q1, pid1 = _config(1)[:3]
+    a = api.sumstatEXP(z1, Q1, pid1, 512, seed=9)
+    b = api.sumstatEXP(z1, Q1, pid1, 512, seed=9, rescale=True)
+    np.testing.assert_array_equal(a[:, 2:], b[:, 2:])
+    np.testing.assert_allclose(a[:, :2], b[:, :2], rtol=1e-10, atol=0)
+    # 20 states (exp_wide_kernel) on a tree the plain pass cannot finish
+    z5, Q5, pid5, _, nen5, nl5, root5 = _config(5)
+    Qs = (Q5 + Q5.T) / 2
+    l5, r5, d5 = api.eigen_decompose(Qs)
+    got5 = api.sumstatEXP(z5, Qs, pid5, 64, seed=4, rescale=True, eig=(l5, r5, d5))
+    want5, rc = O.maketreelistEXP(z5, Qs, pid5, nen5, nl5, root5, 64, l5, r5, d5, seed=4, rescale=True)
+    assert rc == 0
+    np.testing.assert_array_equal(got5[:, 20:], want5[:, 20:])
+    np.testing.assert_allclose(got5[:, :20], want5[:, :20], rtol=1e-10, atol=0)

@@ -278,6 +278,27 @@ def test_exp_oracle_equals_python_restatement(n):
     got2, _ = O.maketreelistEXP(z, Q, pid, nen, nodelist, root, N, lefts, rights, d, seed=seed, replica=1, recompute=True,
                                 faithful_search=True)
     np.testing.assert_array_equal(got, got2)      # re-exponentiating every iteration (:2980) changes nothing
+    # rescaled pruning (not in the reference: row / sum after every node): oracle == Python twin bit for bit, and on a tree this
+    # small the rescaled and the plain sampler pick the same states -- identical counts, identical dwell times
+    got3, rc = O.maketreelistEXP(z, Q, pid, nen, nodelist, root, N, lefts, rights, d, seed=seed, replica=1, rescale=True)
+    assert rc == 0
+    want3 = pyref.sumstatEXP(z, Q.tolist(), pid.tolist(), N, [int(v) for v in nen], [int(v) for v in nodelist], root,
+                             lefts.tolist(), rights.tolist(), np.diag(d).tolist(), seed, 1, rescale=True)
+    np.testing.assert_array_equal(got3, np.array(want3))
+    np.testing.assert_array_equal(got3, got)
+
+
+def test_exp_rescaled_pruning_survives_a_thousand_tips():
+    """makePLexp has no rescaling (src/phylomap.cpp:2899-2906): at 1 000 tips the plain sampler's root vector underflows
+    (RcppArmadillo::sample would throw); with the rows rescaled the same sampler runs and conserves the tree length."""
+    z, Q, pid, Omega = synth.config_problem(2)
+    nen, nodelist, root = _orders(z)
+    lefts, rights, d = api.eigen_decompose(Q)
+    _, rc = O.maketreelistEXP(z, Q, pid, nen, nodelist, root, 2, lefts, rights, d, seed=3)
+    assert rc & O.ERR_ZERO_PROB
+    out, rc = O.maketreelistEXP(z, Q, pid, nen, nodelist, root, 4, lefts, rights, d, seed=3, rescale=True)
+    assert rc == 0
+    np.testing.assert_allclose(out[:, :4].sum(1), z["edge.length"].sum(), rtol=1e-12)
 
 
 # ---- golden fixtures --------------------------------------------------------------------------------------
