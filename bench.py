@@ -3,15 +3,20 @@
 
 Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches one rank per GPU with
 torch.distributed.run.  A *step* is one full MCMC sweep (pruning + node sampling + branch path resampling +
-sufficient statistics) over every replica resident on the GPU.  Workload at N = 1: BASELINE.json configs[1]
-(C2: 4-state Q = make2sQ(.1,.1,.2,.2,10), 1000-tip synthetic tree, sumstatMCMC), run with row-normalised
-partial likelihoods (the `_bigtree` arithmetic) because the plain variant underflows at 1000 tips in the
-reference as well.  Replicas (independent chains / sites) are sharded across ranks with no
-data-path collective; the only exchange is one RCCL all-reduce of the K x cols statistics at the end.
-Inputs are resident in HBM before the timed region starts.
+sufficient statistics) over every replica resident on the GPU.
+
+Workload at N = 1 (and, replica-sharded, at N > 1): BASELINE.json configs[2] = C3, the configuration the north-star target
+is quoted on -- sumstatMCMC_bigtree, 4-state Q = make2sQ(.1,.1,.2,.2,10), 10 000-tip synthetic tree
+(src/phylomap.cpp:942-986).  It fits one GPU (16 384 replicas = 151 GiB with one wave per (tile of 64 replicas, branch)).
+Replicas (independent chains / sites) are sharded across ranks with no data-path collective; the only exchange is one
+RCCL all-reduce of the K x cols statistics at the end.  Inputs are resident in HBM before the timed region starts.
+
+The same JSON line carries, at N = 1, one block per other BASELINE configuration (C2 streaming layout, C4 dense
+61 states, C5 sparse 20 states, sumstatEXP on C1 and on a 1 000-tip tree), each with its own roofline figures measured
+with HIP events inside the library, the batched expm rates, and the CPU oracle timed on this box's host cores
+(1 core, 1 core with the reference's O(E) edge search, all cores).
 """
 import argparse
-import ctypes
 import json
 import os
 import sys
@@ -24,55 +29,96 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (about 6.3 TB/s achievable)
 MEASURED_TRIAD_GBS = 5751.9   # tools/device_peaks/device_peaks.hip on an MI355X of this pool (read-only 6382, copy 4956 GB/s; FP64 vector 65.5 TFLOP/s)
+MFMA_F64_PEAK_TFLOPS = 78.6   # MI355X_MICROARCH.md: dense FP64 matrix peak
 
 
-def cpu_baseline(z, Q, pid, Omega, target_s=12.0, what="C2"):
-    """The CPU oracle (oracle/phm_oracle.c, a restatement of src/phylomap.cpp) timed on one host core."""
+# ----------------------------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (oracle/phm_oracle.c, a restatement of src/phylomap.cpp), timed BEFORE anything touches the GPU
+# (the all-cores figure forks worker processes; a process that has initialised HIP must not fork workers on this pool).
+# ----------------------------------------------------------------------------------------------------------------------
+def _oracle_run(args):
+    cfg, n_it, faithful, replica = args
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    from phylomap_amd import treeorder
+    from phylomap_amd import synth, treeorder
+    z, Q, pid, Omega = synth.config_problem(cfg)
     nen, nodelist, root = treeorder.pruningwiseedgeorder(z), treeorder.makenodelist(z), treeorder.myreorder(z)
     B = np.eye(Q.shape[0]) + Q / Omega
+    t0 = time.perf_counter()
+    _, rc = O.maketreelistMCMC(z, Q, pid, B, Omega, nen, nodelist, root, n_it, variant=O.BIGTREE, seed=1, replica=replica,
+                               faithful_search=faithful)
+    dt = time.perf_counter() - t0
+    assert rc == 0
+    return dt
+
+
+def cpu_baseline(cfg, target_s=3.0, all_cores=False):
+    """The oracle on `cfg`'s tree and Q: one core (edge lookup table), one core with the reference's O(E) edge search per
+    node (src/phylomap.cpp:643), and -- all_cores -- one independent chain per host core."""
+    from phylomap_amd import synth
+    z = synth.config_problem(cfg)[0]
     E = z["edge"].shape[0]
-
-    def run(n_it, faithful):
-        t0 = time.perf_counter()
-        _, rc = O.maketreelistMCMC(z, Q, pid, B, Omega, nen, nodelist, root, n_it, variant=O.BIGTREE, seed=1,
-                                   faithful_search=faithful)
-        dt = time.perf_counter() - t0
-        assert rc == 0
-        return dt
-
-    n_probe = 100 if E < 5000 else 20
-    probe = run(n_probe, False)
+    n_probe = max(2, int(2e5 // E))
+    probe = _oracle_run((cfg, n_probe, False, 0))
     n_it = max(n_probe, int(target_s / (probe / n_probe)))
-    dt = run(n_it, False)
-    n_f = max(50, n_it // 4) if E < 5000 else max(10, n_it // 16)
-    dtf = run(n_f, True)
-    return {"value": E * n_it / dt, "unit": "branch-site realisations/s", "cores": 1, "kind": "port",
-            "sample": f"same {what} tree and Q, 1 chain, {n_it} sweeps (edge lookup table); "
-                      f"with the reference's O(E) edge search per node (src/phylomap.cpp:643): "
-                      f"{E * n_f / dtf:.4g}/s over {n_f} sweeps",
-            "faithful_value": E * n_f / dtf}
+    dt = _oracle_run((cfg, n_it, False, 0))
+    probe_f = _oracle_run((cfg, 2, True, 0))
+    n_f = max(2, int(min(target_s, 3.0) / (probe_f / 2)))
+    dtf = _oracle_run((cfg, n_f, True, 0))
+    out = {"value": E * n_it / dt, "unit": "branch-site realisations/s", "cores": 1, "kind": "port",
+           "sample": f"same C{cfg} tree and Q, 1 chain, {n_it} sweeps (edge lookup table); with the reference's O(E) edge "
+                     f"search per node (src/phylomap.cpp:643): {E * n_f / dtf:.4g}/s over {n_f} sweeps",
+           "faithful_value": E * n_f / dtf}
+    if all_cores:
+        import multiprocessing as mp
+        cores = os.cpu_count() or 1
+        n_all = max(2, n_it // 2)
+        t0 = time.perf_counter()
+        with mp.get_context("fork").Pool(cores) as pool:
+            pool.map(_oracle_run, [(cfg, n_all, False, r) for r in range(cores)])
+        wall = time.perf_counter() - t0           # includes each worker's problem set-up: a lower bound on the rate
+        out["all_cores"] = {"value": cores * E * n_all / wall, "cores": cores,
+                            "sample": f"{cores} independent chains (one process per core), {n_all} sweeps each, wall clock "
+                                      f"including process start and tree generation"}
+    return out
+
+
+def load_traffic():
+    """HBM bytes per launch from the rocprofv3 --pmc passes (tools/summarise_pmc.py -> profiles/r02_traffic.json)."""
+    f = os.path.join(ROOT, "profiles", "r02_traffic.json")
+    return json.load(open(f)) if os.path.exists(f) else {}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=240)
-    ap.add_argument("--warmup", type=int, default=24)
-    ap.add_argument("--replicas", type=int, default=0, help="replicas per GPU (0: sized from free HBM, max 393216 = 6 waves per SIMD)")
-    ap.add_argument("--config", type=int, default=2)
-    ap.add_argument("--ipl", type=int, default=8, help="sweeps fused per kernel launch")
-    ap.add_argument("--storage", type=int, default=2, help="dwell streams: 2 = two buffers (fastest), 1 = one ring (half the HBM)")
-    ap.add_argument("--mapping", default="replicas", choices=["replicas", "tiles", "branches", "auto"],
-                    help="how a sweep is laid over the lanes (DESIGN.md 4b); the headline configuration streams with one lane per replica")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--replicas", type=int, default=0, help="replicas per GPU (0: sized from free HBM)")
+    ap.add_argument("--config", type=int, default=3, help="BASELINE configuration of the headline line (3 = C3, the north-star's; 2 = C2)")
+    ap.add_argument("--ipl", type=int, default=8, help="sweeps fused per kernel launch (replica mapping)")
+    ap.add_argument("--storage", type=int, default=2, help="replica mapping, dwell streams: 2 = two buffers (fastest), 1 = one ring (half the HBM)")
+    ap.add_argument("--mapping", default="", choices=["", "replicas", "tiles", "branches", "auto"],
+                    help="how a sweep is laid over the lanes (DESIGN.md 4b); default: tiles for C3/C4/C5, replicas for C2")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-c3", action="store_true", help="skip the extra 10 000-tip measurement")
+    ap.add_argument("--no-extras", action="store_true", help="headline line only (skip the C2/C4/C5/EXP/expm blocks)")
     ap.add_argument("--force-collective", action="store_true", help="exercise the statistics hand-over to torch at N=1")
     args = ap.parse_args()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={world}: launch N > 1 with "
+                         f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 "
+                         f"--master-port P bench.py --gpus {args.gpus} ...` (one rank per GPU)")
+
+    cpu = {}
+    if rank == 0 and world == 1 and not args.no_cpu:          # before any HIP call: the all-cores figure forks workers
+        cpu[args.config] = cpu_baseline(args.config, target_s=4.0, all_cores=True)
+        if not args.no_extras:
+            for c in (2, 4, 5):
+                if c != args.config:
+                    cpu[c] = cpu_baseline(c, target_s=2.0)
 
     import torch
     import torch.distributed as dist
@@ -88,28 +134,8 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     parallel.init_process_group(backend, device_index=local_rank)
-
-    z, Q, pid, Omega = synth.config_problem(args.config)
-    n = Q.shape[0]
-    E = z["edge"].shape[0]
-    cols = n + n * (n - 1)
-    K, W = args.steps, args.warmup
-
-    S = args.replicas
-    if S <= 0:
-        free_b, _ = torch.cuda.mem_get_info()
-        probe = _lib.Engine(z, Q, pid, Omega, 1, variant=_lib.PHM_MCMC_BIGTREE, seed=1, n_replicas=64, reduce=True,
-                            device=local_rank, storage=args.storage if args.mapping == "replicas" else 0, mapping=args.mapping)
-        per_tile = probe.info().device_bytes
-        probe.close()
-        S = int(min(393216, (0.80 * free_b) // per_tile * 64))
-        S = max(64, S // 16384 * 16384 if S >= 16384 else S // 64 * 64)
-
-    eng = _lib.Engine(z, Q, pid, Omega, K + W, variant=_lib.PHM_MCMC_BIGTREE, seed=0x5EED0000 + args.config,
-                      n_replicas=S, replica_offset=parallel.weak_shard(S, rank)[0], reduce=True, device=local_rank,
-                      iters_per_launch=args.ipl, storage=args.storage if args.mapping == "replicas" else 0,
-                      mapping=args.mapping)   # default: one lane per replica, the streaming layout of the headline configuration
     stream = torch.cuda.current_stream().cuda_stream
+    traffic = load_traffic()
 
     def barrier():
         torch.cuda.synchronize()
@@ -117,154 +143,214 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    eng.run(W, stream)
-    eng.sync()
-    seg0 = eng.info().seg_read
+    def sized_replicas(z, Q, pid, Omega, mapping, cap, frac=0.80, storage=0):
+        """replicas that fit `frac` of the free HBM, in whole groups of tiles, at most `cap`"""
+        free_b, _ = torch.cuda.mem_get_info()
+        probe = _lib.Engine(z, Q, pid, Omega, 1, variant=_lib.PHM_MCMC_BIGTREE, seed=1, n_replicas=64, reduce=True,
+                            device=local_rank, storage=storage, mapping=mapping)
+        per_tile = probe.info().device_bytes
+        probe.close()
+        S = int(min(cap, (frac * free_b) // per_tile * 64))
+        return max(64, S // 1024 * 1024 if S >= 1024 else S // 64 * 64)
 
-    barrier()
-    t0 = time.perf_counter()
-    eng.run(K, stream)                                   # the hot path: K sweeps, N-loop on the device
-    red_ptr = eng.reduced_stats_device(W, K, stream)     # fixed-order reduction over this GPU's replicas
-    if world > 1 or args.force_collective:               # the only collective: K x cols f64 over RCCL/xGMI
-        try:
-            class _Dev:
-                __cuda_array_interface__ = {"shape": (K, cols), "typestr": "<f8", "data": (red_ptr, False), "version": 3}
-            total = torch.as_tensor(_Dev(), device=torch.device("cuda", local_rank))
-        except (TypeError, ValueError, RuntimeError):    # no zero-copy view: one 30 KB host round trip instead
-            eng.sync()
-            total = torch.from_numpy(np.ascontiguousarray(eng.stats(W, K))).to(torch.device("cuda", local_rank))
-        if backend != "nccl":
-            total = total.cpu()
-        parallel.allreduce_stats(total)
-        torch.cuda.synchronize()
-    eng.sync()
-    barrier()
-    dt = time.perf_counter() - t0
+    def measure(cfg, mapping, S, K, W, seed, ipl=8, storage=0, collective=False, offset=0):
+        """K timed sweeps of configuration `cfg` after W warm-up sweeps; returns (block, wall seconds, engine statistics)."""
+        z, Q, pid, Omega = synth.config_problem(cfg)
+        n, E = Q.shape[0], z["edge"].shape[0]
+        cols = n + n * (n - 1)
+        tiled = mapping == "tiles"
+        eng = _lib.Engine(z, Q, pid, Omega, K + W, variant=_lib.PHM_MCMC_BIGTREE, seed=seed, n_replicas=S, replica_offset=offset,
+                          reduce=True, device=local_rank, iters_per_launch=ipl, storage=storage, mapping=mapping,
+                          phase_timing=tiled)
+        eng.run(W, stream)
+        eng.sync()
+        seg0 = eng.info().seg_read
+        barrier()
+        t0 = time.perf_counter()
+        eng.run(K, stream)                                   # the hot path: K sweeps
+        total = None
+        if collective:                                       # the only collective: K x cols f64 over RCCL/xGMI
+            red_ptr = eng.reduced_stats_device(W, K, stream)  # fixed-order reduction over this GPU's replicas
+            try:
+                class _Dev:
+                    __cuda_array_interface__ = {"shape": (K, cols), "typestr": "<f8", "data": (red_ptr, False), "version": 3}
+                total = torch.as_tensor(_Dev(), device=torch.device("cuda", local_rank))
+            except (TypeError, ValueError, RuntimeError):    # no zero-copy view: one host round trip instead
+                eng.sync()
+                total = torch.from_numpy(np.ascontiguousarray(eng.stats(W, K))).to(torch.device("cuda", local_rank))
+            if backend != "nccl":
+                total = total.cpu()
+            parallel.allreduce_stats(total)
+            torch.cuda.synchronize()
+            total = total.cpu().numpy().copy()               # snapshot before the engine is asked for anything else
+        eng.sync()
+        barrier()
+        dt = time.perf_counter() - t0
 
+        info = eng.info()
+        units = E * S * K                                    # branch x replica paths sampled by this rank
+        seg = (info.seg_read - seg0) / units                 # measured mean (m_b + m'_b)
+        b_alg = 16 * n + 12 * seg + 26                       # SURVEY.md 8(d): algorithmic bytes per branch x replica x sweep
+        kernel_s = info.last_run_ms / 1e3
+        stats = eng.stats(W, K)
+        # sanity: dwell row sums = S x tree length; the matrix handed to RCCL is the same matrix (x world)
+        assert np.allclose(stats[:, :n].sum(1), S * z["edge.length"].sum(), rtol=1e-9)
+        if total is not None:
+            assert np.allclose(total[:, :n].sum(1), world * S * z["edge.length"].sum(), rtol=1e-9)
+            if world == 1:
+                assert np.array_equal(total, stats)
+        tkey = f"C{cfg}"
+        tr = traffic.get(tkey, {})
+        blk = {"workload": f"C{cfg}", "n_states": n, "n_tips": int(z["states"].size), "branches": E, "replicas": S, "mapping": mapping,
+               "ms_per_sweep": dt / K * 1e3, "realisations_per_s": units / dt, "hbm_gib_resident": info.device_bytes / 2 ** 30,
+               "mean_segments_read_plus_written": seg}
+        sweep = {"bound": "hbm", "alg_bytes_per_unit": b_alg, "achieved": units * b_alg / kernel_s / 1e9, "peak": HBM_PEAK_GBS,
+                 "unit": "GB/s", "frac": units * b_alg / kernel_s / 1e9 / HBM_PEAK_GBS, "kernel_ms_per_sweep": info.last_run_ms / K,
+                 "launches_per_sweep": info.last_run_launches / K, "frac_of_measured_triad": units * b_alg / kernel_s / 1e9 / MEASURED_TRIAD_GBS}
+        if tiled:
+            up_ms, down_ms, br_ms, st_ms = [v / K for v in eng.phase_ms()]
+            per = E * S                                      # units per launch of the branch kernel = one sweep
+            br_bytes = 12 * seg + 8                          # SURVEY 8(d): the branch step's share of B_alg
+            branch = {"bound": "hbm", "kernel": ("tiles_branch_kernel<4, false>" if n <= 4 else "wt_branch_kernel<false>"),
+                      "achieved": per * br_bytes / (br_ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": per * br_bytes / (br_ms / 1e3) / 1e9 / HBM_PEAK_GBS, "traffic": tr.get("branch_kernel_bytes_per_launch"),
+                      "launches": K, "avg_launch_ms": br_ms, "alg_bytes_per_unit": br_bytes, "units_per_launch": per}
+            n_int = E // 2 - 1                               # branches whose child is an internal node
+            prune = {"bound": "hbm", "kernel": ("tiles_up_kernel<4>" if n <= 4 else f"wt_up_kernel<{(n + 15) // 16}>") + " (all height levels of one sweep)",
+                     "alg_bytes_per_unit": 12 * n + 12, "ms_per_sweep": up_ms,
+                     "achieved": per * (12 * n + 12) / (up_ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": per * (12 * n + 12) / (up_ms / 1e3) / 1e9 / HBM_PEAK_GBS, "traffic": tr.get("up_kernels_bytes_per_sweep")}
+            if tr.get("up_kernels_bytes_per_sweep"):
+                prune["counter_traffic_frac"] = tr["up_kernels_bytes_per_sweep"] / (up_ms / 1e3) / 1e9 / HBM_PEAK_GBS
+            if n > 4:                                        # 5..64 states: the pruning chains run on the matrix cores
+                mbar = seg / 2.0
+                flops = 2.0 * n * n * max(mbar - 1.0, 0.0) * n_int * S      # SURVEY 8(d): 2 n^2 (m - 1) per internal-child branch
+                prune["mfma"] = {"bound": "mfma", "achieved": flops / (up_ms / 1e3) / 1e12, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": flops / (up_ms / 1e3) / 1e12 / MFMA_F64_PEAK_TFLOPS,
+                                 "alg_flops_per_sweep": flops, "note": "algorithmic flops 2 n^2 (mean m - 1) per internal-child branch; the "
+                                 "kernel issues max-over-16-replicas steps of 64-padded tiles"}
+            blk["phases_ms_per_sweep"] = {"pruning_levels": up_ms, "node_draws": down_ms, "branch_kernel": br_ms, "reductions": st_ms}
+            blk["roofline"] = dict(branch, sweep=sweep)
+            blk["pruning_sweep"] = prune
+        else:
+            per = E * S * ipl
+            blk["roofline"] = dict(sweep, kernel=f"mcmc_sweep_kernel<{n}>", traffic=tr.get("sweep_kernel_bytes_per_launch"),
+                                   launches=info.last_run_launches, avg_launch_ms=info.last_run_ms / max(1, info.last_run_launches),
+                                   units_per_launch=per, measured_triad_peak=MEASURED_TRIAD_GBS)
+            if n <= 4 and mapping == "replicas":
+                prune_ms = eng.time_pruning(8, stream) / 8.0
+                blk["pruning_sweep"] = {"kernel": f"mcmc_sweep_kernel<{n}> (up sweep only)", "ms_per_sweep": prune_ms,
+                                        "alg_bytes_per_unit": 12 * n + 12, "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "achieved": E * S * (12 * n + 12) / (prune_ms / 1e3) / 1e9,
+                                        "frac": E * S * (12 * n + 12) / (prune_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
+                                        "traffic": tr.get("pruning_bytes_per_sweep")}
+                if tr.get("pruning_bytes_per_sweep"):
+                    blk["pruning_sweep"]["counter_traffic_frac"] = tr["pruning_bytes_per_sweep"] / (prune_ms / 1e3) / 1e9 / HBM_PEAK_GBS
+        eng.close()
+        return blk, dt
+
+    # ---- headline ------------------------------------------------------------------------------------------------
+    K, W = args.steps, args.warmup
+    cfg = args.config
+    mapping = args.mapping or ("replicas" if cfg == 2 else "tiles")
+    zc, Qc, pidc, Omc = synth.config_problem(cfg)
+    S = args.replicas
+    if S <= 0:
+        cap = {2: 393216, 3: 16384, 4: 65536, 5: 16384}.get(cfg, 16384)
+        S = sized_replicas(zc, Qc, pidc, Omc, mapping, cap, storage=args.storage if mapping == "replicas" else 0)
+    head, dt = measure(cfg, mapping, S, K, W, 0x5EED0000 + cfg, ipl=args.ipl, storage=args.storage if mapping == "replicas" else 0,
+                       collective=(world > 1 or args.force_collective), offset=parallel.weak_shard(S, rank)[0])
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
-    info = eng.info()
-    units_rank = E * S * K                                # branch x replica paths sampled by this rank
-    seg = (info.seg_read - seg0) / units_rank             # measured mean (m_b + m'_b)
-    b_alg = 16 * n + 12 * seg + 26                        # algorithmic bytes per branch x replica x sweep
-    kernel_s = info.last_run_ms / 1e3
-    achieved = units_rank * b_alg / kernel_s / 1e9
-
-    # the pruning sweep alone (12n+12 B per branch); timed for the n <= 4 replica kernel only
-    prune_ms = eng.time_pruning(8, stream) / 8.0 if (n <= 4 and args.mapping == "replicas") else None
-    stats = eng.stats(W, K)
-    # sanity: dwell row sums = S x tree length; the tensor handed to RCCL is the same matrix (x world)
-    assert np.allclose(stats[:, :n].sum(1), S * z["edge.length"].sum(), rtol=1e-9)
-    if world > 1 or args.force_collective:
-        tot = total.cpu().numpy()
-        assert np.allclose(tot[:, :n].sum(1), world * S * z["edge.length"].sum(), rtol=1e-9)
-        if world == 1:
-            assert np.array_equal(tot, stats)
-
-    traffic = None
-    tfile = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if os.path.exists(tfile):          # HBM bytes per unit from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-        tj = json.load(open(tfile))
-        if tj.get("config") == args.config:
-            traffic = tj["hbm_bytes_per_unit"] * E * S * args.ipl
-
     out = None
     if rank == 0:
-        value = units_rank * world / dt
+        n, E = head["n_states"], head["branches"]
+        names = {2: "C2: sumstatMCMC sweep (row-normalised PL)", 3: "C3: sumstatMCMC_bigtree sweep", 4: "C4: dense 61-state sweep (row-normalised PL)",
+                 5: "C5: sparse 20-state sweep (row-normalised PL)"}
         out = {
             "metric": "stochastic-map realisations/sec (branches x sites sampled/s)",
-            "value": value, "unit": "branch-site realisations/s",
+            "value": E * S * K * world / dt, "unit": "branch-site realisations/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"C{args.config}: sumstatMCMC sweep (row-normalised PL), {n}-state Q, "
-                                   f"{z['states'].size}-tip synthetic tree, Omega*mean(t_b)=4",
-                       "n_states": n, "n_tips": int(z["states"].size), "branches": E,
-                       "replicas_per_gpu": S, "sweeps_per_launch": args.ipl,
-                       "dwell_storage": "two buffers" if args.storage == 2 else "ring",
+            "config": {"workload": f"{names.get(cfg, f'C{cfg}')}, {n}-state Q, {head['n_tips']}-tip synthetic tree, Omega*mean(t_b)=4",
+                       "n_states": n, "n_tips": head["n_tips"], "branches": E, "replicas_per_gpu": S,
+                       "mapping": {"tiles": "one wave per (tile of 64 replicas, branch)", "replicas": "one lane per replica, one wave per tile walks the tree"}.get(mapping, mapping),
                        "parallelism": f"replica-sharded x{world}, one RCCL all-reduce of the statistics"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "mcmc_sweep_kernel<4>", "launches": info.last_run_launches,
-                         "avg_launch_ms": info.last_run_ms / max(1, info.last_run_launches),
-                         "alg_bytes_per_unit": b_alg, "mean_segments_read_plus_written": seg,
-                         "units_per_launch": E * S * args.ipl,
-                         # attainable bandwidth measured on this pool with a stream triad (tools/device_peaks, profiles/r01_device_peaks.log)
-                         "measured_triad_peak": MEASURED_TRIAD_GBS, "frac_of_measured_triad": achieved / MEASURED_TRIAD_GBS},
-            "pruning_sweep": None if prune_ms is None else {
-                "kernel": "mcmc_sweep_kernel<4> (up sweep only)", "ms_per_sweep": prune_ms, "alg_bytes_per_unit": 12 * n + 12,
-                "achieved": E * S * (12 * n + 12) / (prune_ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": E * S * (12 * n + 12) / (prune_ms / 1e3) / 1e9 / HBM_PEAK_GBS},
-            "hbm_bytes_resident": int(info.device_bytes),
+            "roofline": head["roofline"],
+            "phases_ms_per_sweep": head.get("phases_ms_per_sweep"),
+            "pruning_sweep": head.get("pruning_sweep"),
+            "hbm_bytes_resident": int(head["hbm_gib_resident"] * 2 ** 30),
         }
-    eng.close()
+        if cfg in cpu:
+            out["cpu_baseline"] = cpu[cfg]
+            out["speedup_vs_cpu_1core"] = out["value"] / cpu[cfg]["value"]
+            out["speedup_vs_cpu_1core_faithful"] = out["value"] / cpu[cfg]["faithful_value"]
+            out["speedup_vs_cpu_all_cores"] = out["value"] / cpu[cfg]["all_cores"]["value"]
 
-    if rank == 0 and n <= 4:
-        # the reference's own calling pattern -- ONE chain -- on the same tree: the branch-parallel mapping (phm_narrow.hip)
-        one = _lib.Engine(z, Q, pid, Omega, 104, variant=_lib.PHM_MCMC_BIGTREE, seed=1, n_replicas=1, device=local_rank,
-                          mapping="branches")
+    # ---- the other BASELINE configurations, one block each (N = 1 only) -----------------------------------------------
+    if rank == 0 and world == 1 and not args.no_extras:
+        blocks = {}
+        plan = [(2, "replicas", 393216, 16, 8, 2), (4, "tiles", 65536, 6, 6, 0), (5, "tiles", 16384, 6, 8, 0)]
+        if cfg == 2:
+            plan[0] = (3, "tiles", 16384, 12, 6, 0)
+        for c, mp, capS, k, w, sto in plan:
+            z, Q, pid, Om = synth.config_problem(c)
+            Sx = sized_replicas(z, Q, pid, Om, mp, capS, frac=0.60, storage=sto)
+            blk, _ = measure(c, mp, Sx, k, w, 0x5EED0000 + c, ipl=8, storage=sto)
+            if c in cpu:
+                blk["cpu_baseline"] = cpu[c]
+                blk["speedup_vs_cpu_1core"] = blk["realisations_per_s"] / cpu[c]["value"]
+            blocks[f"C{c}"] = blk
+        # the reference's own calling pattern -- ONE chain -- and an alignment-sized job, on the C2 tree
+        z, Q, pid, Om = synth.config_problem(2)
+        E2 = z["edge"].shape[0]
+        one = _lib.Engine(z, Q, pid, Om, 104, variant=_lib.PHM_MCMC_BIGTREE, seed=1, n_replicas=1, device=local_rank, mapping="branches")
         one.run(4); one.sync()
         t1 = time.perf_counter(); one.run(100); one.sync(); d1 = time.perf_counter() - t1
         one.close()
-        out["single_chain"] = {"mapping": "one lane per branch", "ms_per_sweep": d1 / 100 * 1e3, "realisations_per_s": E * 100 / d1}
-
-    if rank == 0 and n <= 4:
-        # an alignment-sized job (4 096 sites) on the same tree: one wave per (tile of 64 replicas, branch) (phm_tiles.hip)
-        mid = _lib.Engine(z, Q, pid, Omega, 44, variant=_lib.PHM_MCMC_BIGTREE, seed=1, n_replicas=4096, reduce=True,
-                          device=local_rank, mapping="tiles")
+        blocks["C2_single_chain"] = {"mapping": "one lane per branch", "ms_per_sweep": d1 / 100 * 1e3, "realisations_per_s": E2 * 100 / d1}
+        mid = _lib.Engine(z, Q, pid, Om, 44, variant=_lib.PHM_MCMC_BIGTREE, seed=1, n_replicas=4096, reduce=True, device=local_rank, mapping="tiles")
         mid.run(4); mid.sync()
         t1 = time.perf_counter(); mid.run(40); mid.sync(); d1 = time.perf_counter() - t1
         mid.close()
-        out["replicas_4096"] = {"mapping": "one wave per (tile, branch)", "ms_per_sweep": d1 / 40 * 1e3,
-                                "realisations_per_s": E * 4096 * 40 / d1}
+        blocks["C2_4096_sites"] = {"mapping": "one wave per (tile, branch)", "ms_per_sweep": d1 / 40 * 1e3, "realisations_per_s": E2 * 4096 * 40 / d1}
 
-    if rank == 0 and world == 1 and n <= 4 and args.config == 2 and not args.no_c3:
-        # BASELINE.json's stated target is quoted on the 10 000-tip 4-state tree (C3): the same sweep with one wave per
-        # (tile, branch), as many replicas as fit (at most 16 384), next to the CPU oracle on that same tree.
-        z3, Q3, pid3, Om3 = synth.config_problem(3)
-        E3 = z3["edge"].shape[0]
-        free_b, _ = torch.cuda.mem_get_info()
-        probe = _lib.Engine(z3, Q3, pid3, Om3, 1, variant=_lib.PHM_MCMC_BIGTREE, seed=1, n_replicas=64, reduce=True,
-                            device=local_rank, mapping="tiles")
-        per_tile = probe.info().device_bytes
-        probe.close()
-        S3 = int(min(16384, (0.80 * free_b) // per_tile * 64))
-        S3 = max(64, S3 // 1024 * 1024 if S3 >= 1024 else S3 // 64 * 64)
-        big = _lib.Engine(z3, Q3, pid3, Om3, 24, variant=_lib.PHM_MCMC_BIGTREE, seed=0x5EED0003, n_replicas=S3, reduce=True,
-                          device=local_rank, mapping="tiles")
-        big.run(8); big.sync()
-        t1 = time.perf_counter(); big.run(16); big.sync(); d1 = time.perf_counter() - t1
-        st3 = big.stats(8, 16)
-        assert np.allclose(st3[:, :4].sum(1), S3 * z3["edge.length"].sum(), rtol=1e-9)
-        gib3 = big.info().device_bytes / 2 ** 30
-        big.close()
-        out["ten_k_tip_tree"] = {"workload": "C3: sumstatMCMC_bigtree sweep, 4-state Q, 10000-tip synthetic tree",
-                                 "mapping": "one wave per (tile, branch)", "replicas": S3, "ms_per_sweep": d1 / 16 * 1e3,
-                                 "realisations_per_s": E3 * S3 * 16 / d1, "hbm_gib_resident": gib3}
-        if not args.no_cpu:
-            c3 = cpu_baseline(z3, Q3, pid3, Om3, target_s=3.0, what="C3")
-            out["ten_k_tip_tree"]["cpu_baseline"] = c3
-            out["ten_k_tip_tree"]["speedup_vs_cpu_1core"] = out["ten_k_tip_tree"]["realisations_per_s"] / c3["value"]
-            out["ten_k_tip_tree"]["speedup_vs_cpu_1core_faithful"] = out["ten_k_tip_tree"]["realisations_per_s"] / c3["faithful_value"]
+        # sumstatEXP (src/phylomap.cpp:3001-3051): C1 as stated, and the 1 000-tip 4-state tree with the rescaled pruning pass
+        L = _lib.load()
+        for key, c, N, resc in (("EXP_C1", 1, 1 << 16, False), ("EXP_1000_tips", 2, 1 << 14, True)):
+            z, Q, pid, Om = synth.config_problem(c)
+            n, E = Q.shape[0], z["edge"].shape[0]
+            api.sumstatEXP(z, Q, pid, 64, seed=1, rescale=resc, device=local_rank)
+            t1 = time.perf_counter()
+            st = api.sumstatEXP(z, Q, pid, N, seed=2, rescale=resc, device=local_rank)
+            wall = time.perf_counter() - t1
+            kms = float(L.phm_last_kernel_ms())
+            assert np.allclose(st[:, :n].sum(1), z["edge.length"].sum(), rtol=1e-9)
+            nj = float(st[:, n:].sum()) / (N * E)                    # real jumps per branch
+            alg = 16 * n + 2 + 12 * (1 + nj)                          # DESIGN.md 5: P row 8n + PL row 8n + state 2 B, segments written 12 B each
+            blocks[key] = {"workload": f"sumstatEXP, {n}-state Q, {z['states'].size}-tip tree, N = {N} i.i.d. samples" + (", rescaled pruning pass" if resc else ""),
+                           "realisations_per_s": E * N / (kms / 1e3), "realisations_per_s_incl_setup_and_copies": E * N / wall,
+                           "roofline": {"bound": "hbm", "kernel": f"exp_sample_kernel<{n}>", "launches": 1, "avg_launch_ms": kms,
+                                        "alg_bytes_per_unit": alg, "units_per_launch": E * N, "achieved": E * N * alg / (kms / 1e3) / 1e9,
+                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": E * N * alg / (kms / 1e3) / 1e9 / HBM_PEAK_GBS,
+                                        "traffic": traffic.get(key, {}).get("sample_kernel_bytes_per_launch"),
+                                        "note": "latency / VALU bound: the 300-row B^k e_j table and P(t_b) are L2-resident"}}
+        out["configs"] = blocks
 
-    if rank == 0:
-        # secondary metric of BASELINE.json: expm(Q t)/s (batched 4x4 transition matrices, kernel time)
-        t = np.random.default_rng(0).exponential(4.0 / Omega, 1 << 20)
-        npade = (1 << 18) if n <= 8 else (1 << 13)
-        _, ms_p = api.expm_pade(Q, t[:npade], device=local_rank)
-        _, ms_p = api.expm_pade(Q, t[:npade], device=local_rank)
-        out["expm_per_s"] = {"n_states": n, "pade_route": npade / (ms_p / 1e3)}
-        try:                                          # the eigen route (matexp, R/sumstatEXP.R:26-29) needs a real spectrum
-            lefts, rights, d = api.eigen_decompose(Q)
-            nt = t.size if n <= 8 else (1 << 15)
-            _, ms_e = api.expm_eigen(lefts, rights, d, t[:nt], device=local_rank)
-            _, ms_e = api.expm_eigen(lefts, rights, d, t[:nt], device=local_rank)
-            out["expm_per_s"]["eigen_route"] = nt / (ms_e / 1e3)
-        except ValueError:
-            out["expm_per_s"]["eigen_route"] = None
+        # secondary metric of BASELINE.json: expm(Q t)/s (batched transition matrices, kernel time)
+        n = Qc.shape[0]
+        t = np.random.default_rng(0).exponential(4.0 / Omc, 1 << 20)
+        Q4 = synth.config_Q(2)
+        _, ms_p = api.expm_pade(Q4, t[:1 << 18], device=local_rank)
+        _, ms_p = api.expm_pade(Q4, t[:1 << 18], device=local_rank)
+        lefts, rights, d = api.eigen_decompose(Q4)
+        _, ms_e = api.expm_eigen(lefts, rights, d, t, device=local_rank)
+        _, ms_e = api.expm_eigen(lefts, rights, d, t, device=local_rank)
+        out["expm_per_s"] = {"n_states": 4, "pade_route": (1 << 18) / (ms_p / 1e3), "eigen_route": t.size / (ms_e / 1e3)}
         # the same metric on the dense 61-state shape of C4, where the products fill MFMA f64 tiles
         Q61 = synth.config_Q(4)
         Q61 = (Q61 + Q61.T) / 2                      # matexp handles a real spectrum only (R/sumstatEXP.R:26-29)
@@ -275,13 +361,14 @@ def main():
         api.expm_eigen(l61, r61, d61, t61, device=local_rank, mfma=True)
         _, ms_m = api.expm_eigen(l61, r61, d61, t61, device=local_rank, mfma=True)
         _, ms_x = api.expm_eigen(l61, r61, d61, t61, device=local_rank)
-        out["expm_per_s"]["n61_eigen_route_mfma"] = t61.size / (ms_m / 1e3)
-        out["expm_per_s"]["n61_eigen_route_exact"] = t61.size / (ms_x / 1e3)
-        out["expm_per_s"]["n61_mfma_tflops"] = 2 * 61 ** 3 * t61.size / (ms_m / 1e3) / 1e12
-        out["expm_per_s"]["mfma_f64_peak_tflops"] = 78.6
-        if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(z, Q, pid, Omega)
-            out["speedup_vs_cpu_1core"] = out["value"] / out["cpu_baseline"]["value"]
+        api.expm_pade(Q61, t61[:1 << 13], device=local_rank, mfma=True)
+        _, ms_pm = api.expm_pade(Q61, t61[:1 << 13], device=local_rank, mfma=True)
+        out["expm_per_s"].update({"n61_eigen_route_mfma": t61.size / (ms_m / 1e3), "n61_eigen_route_exact": t61.size / (ms_x / 1e3),
+                                  "n61_pade_route_mfma": (1 << 13) / (ms_pm / 1e3),
+                                  "n61_mfma_tflops": 2 * 61 ** 3 * t61.size / (ms_m / 1e3) / 1e12, "mfma_f64_peak_tflops": MFMA_F64_PEAK_TFLOPS,
+                                  "roofline": {"bound": "mfma", "kernel": "expm_eigen_mfma_kernel", "achieved": 2 * 61 ** 3 * t61.size / (ms_m / 1e3) / 1e12,
+                                               "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": 2 * 61 ** 3 * t61.size / (ms_m / 1e3) / 1e12 / MFMA_F64_PEAK_TFLOPS}})
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -14,10 +14,11 @@ def pytest_configure(config):
 
 
 def _gpu_usable():
-    """A built HIP library that sees a device (no torch import: counting devices must stay cheap on the CPU box)."""
+    """A built HIP library and a GPU device node -- decided WITHOUT a HIP call: the collecting process must not initialise the
+    GPU before tests/test_00_gpu_multirank.py has started its child processes."""
     try:
         from phylomap_amd import _lib
-        return _lib.load().phm_device_count() > 0
+        return os.path.exists(_lib.LIB_PATH) and os.path.exists("/dev/kfd")
     except Exception:
         return False
 

@@ -51,5 +51,12 @@ def test_rccl_allreduce_of_device_statistics():
         dist.destroy_process_group()
     assert float(t.item()) == 1.5
     assert np.array_equal(total.cpu().numpy(), want)
+    # the buffer handed to RCCL belongs to the caller: reading the statistics again (which re-runs the tile reduction into the
+    # engine's own buffer) must not overwrite an all-reduced matrix (bench.py's N > 1 sanity check)
+    total.mul_(3.0)
+    torch.cuda.synchronize()
+    again = eng.stats(0, K)
+    assert np.array_equal(again, want)
+    assert np.array_equal(total.cpu().numpy(), 3.0 * want)
     assert parallel.weak_shard(128, 3) == (384, 128)
     eng.close()
