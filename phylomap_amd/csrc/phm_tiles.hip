@@ -153,10 +153,23 @@ __global__ __launch_bounds__(TILES_BLOCK, 8) void tiles_branch_kernel(TileParams
   for (int c = 0; c < NS; ++c) s_dw[c * 64 + lane] = 0.0;
 #pragma unroll
   for (int c = 0; c < NCNT; ++c) s_cnt[c * 64 + lane] = (uint16_t)0;
+  // The 16-bit LDS counters are handed to the tile's global counters (integer atomics, exact in any order) once per group of
+  // branches -- every atomic instruction leaves L2 as uncached 64-byte requests, which at one flush per branch was a fifth of
+  // the kernel's HBM traffic (profiles/r02_pmc_C3_summary.json) -- or earlier, before a lane could exceed 65 535 transitions.
+  auto flush_counts = [&]() {
+#pragma unroll
+    for (int c = 0; c < NCNT; ++c) {
+      const uint32_t v = s_cnt[c * 64 + lane];
+      if (v) { atomicAdd(gc + c * 64, v); s_cnt[c * 64 + lane] = (uint16_t)0; }
+    }
+  };
+  uint32_t pending = 0;                              // segments whose transitions sit in the 16-bit counters
   const int q1 = min((grp + 1) * p.group, p.n_edge);
   for (int q = grp * p.group; q < q1; ++q) {
   const int b = p.branch_order[q];
   const int m = mct[b * 64 + lane];
+  if (__any(pending + (uint32_t)m > 65535u)) { flush_counts(); pending = 0; }
+  pending += (uint32_t)m;
   const int es = p.estate[((size_t)tile * p.n_edge + b) * 64 + lane];
   const int ps = es & 15, cs = es >> 4;
   const int roff = p.slot[b];
@@ -315,13 +328,8 @@ __global__ __launch_bounds__(TILES_BLOCK, 8) void tiles_branch_kernel(TileParams
   if (mnew > cap) mnew = cap;
   if (mnew > 65535) { err |= DERR_CAPACITY; mnew = 65535; }
   mct[b * 64 + lane] = (uint16_t)mnew;
-  // the 16-bit counters hold one branch: hand them over (integer atomics, exact in any order) and clear them
-#pragma unroll
-  for (int c = 0; c < NCNT; ++c) {
-    const uint32_t v = s_cnt[c * 64 + lane];
-    if (v) { atomicAdd(gc + c * 64, v); s_cnt[c * 64 + lane] = (uint16_t)0; }
-  }
   }      // next branch of the group
+  flush_counts();
 
   double* pd = p.pdw + (((size_t)tile * p.n_edge + grp) * NS) * 64 + lane;      // [tile][group][NS][64] (n_edge rows reserved)
 #pragma unroll

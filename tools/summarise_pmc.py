@@ -1,46 +1,62 @@
-"""Summarise rocprofv3 --pmc passes of `bench.py --steps 16 --warmup 8 --no-cpu` into profiles/r01_final_pmc_summary.json.
+"""rocprofv3 --pmc passes of `bench.py --config C --no-cpu --no-extras` -> per-kernel counter sums and the HBM traffic figures
+bench.py reports as roofline.traffic (profiles/r02_traffic.json).
 
-Usage: python tools/summarise_pmc.py gpurun_out/pmc_a/x_counter_collection.csv [more csv ...] > summary.json
-Per counter: the value of every dispatch of the sweep / pruning kernels, in launch order.  FETCH_SIZE / WRITE_SIZE are in
-KiB; FETCH_SIZE is doubled as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950 (wide coalesced reads are
-reported at half their size).  The timed dispatch is the LAST 8-sweep launch of mcmc_sweep_kernel."""
+Usage: python tools/summarise_pmc.py C STEPS WARMUP pass1_counter_collection.csv [pass2.csv ...]   (one CSV per --pmc pass)
+FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE is doubled as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950
+(wide coalesced reads are tallied at half their size).  Counters are summed per kernel over the TIMED sweeps (the dispatches
+after the warm-up sweeps); per-launch / per-sweep figures divide by the number of timed launches / sweeps."""
 import collections
 import csv
 import json
 import sys
 
-E, SWEEPS = 1998, 8
-out = collections.OrderedDict()
-disp = {}
-for path in sys.argv[1:]:
-    per = collections.defaultdict(lambda: collections.OrderedDict())
-    for r in csv.DictReader(open(path)):
-        k = r["Kernel_Name"]
-        if "mcmc_sweep_kernel" not in k and "mcmc_pruning_kernel" not in k:
-            continue
-        d = per[r["Counter_Name"]]
-        d[r["Dispatch_Id"]] = d.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
-        if "mcmc_sweep_kernel" in k:
-            disp = {x: r[x] for x in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "SGPR_Count", "Scratch_Size")}
-            disp["kernel"] = k[:80]
-    for c, d in per.items():
-        out[c] = [d[i] for i in sorted(d, key=int)]
-sweeps = [i for i, v in enumerate(out.get("SQ_WAVES", out[next(iter(out))])) if True]
-res = {k: v for k, v in out.items()}
-res["dispatch"] = disp
-S = int(disp.get("Grid_Size", 0))
-units = E * S * SWEEPS
-per_launch = {"units": units}
-def timed(c):      # the last of the leading 8-sweep sweep-kernel dispatches = the largest values; take index 2 (warm-up, then two timed)
-    v = out.get(c)
-    return None if not v else v[2] if len(v) > 2 else v[-1]
-if timed("FETCH_SIZE") is not None and timed("WRITE_SIZE") is not None:
-    rd, wr = timed("FETCH_SIZE") * 1024 * 2, timed("WRITE_SIZE") * 1024
-    per_launch.update(hbm_read_bytes_corrected=rd, hbm_write_bytes=wr, hbm_bytes_per_unit=(rd + wr) / units)
-if timed("SQ_INSTS_VALU") is not None:
-    per_launch["valu_insts_per_branch_wave"] = timed("SQ_INSTS_VALU") / (E * (S / 64) * SWEEPS)
-res["per_launch"] = per_launch
-res["note"] = ("rocprofv3 --pmc passes (separate runs, --pmc only) of: python3 bench.py --steps 16 --warmup 8 --no-cpu ; 3 dispatches of 8 "
-               "sweeps (first = warm-up) followed by 8 single-sweep pruning-only dispatches; FETCH_SIZE/WRITE_SIZE in KiB; FETCH_SIZE doubled per "
-               "MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads).")
-json.dump(res, sys.stdout, indent=1)
+
+def short(name):
+    for key in ("tiles_branch_kernel", "tiles_up_kernel", "tiles_down_kernel", "tiles_root_kernel", "tiles_chunk_kernel", "tiles_stats_kernel",
+                "wt_branch_kernel", "wt_up_kernel", "wt_down_kernel", "wt_root_kernel", "wt_stats_kernel", "mcmc_sweep_kernel",
+                "exp_sample_kernel", "exp_wide_kernel", "stats_reduce_kernel"):
+        if key in name:
+            return key
+    return None
+
+
+def main():
+    cfg, steps, warm = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+    sums = collections.defaultdict(lambda: collections.defaultdict(float))      # kernel -> counter -> sum over timed dispatches
+    launches = collections.defaultdict(int)
+    for path in sys.argv[4:]:
+        per = collections.defaultdict(lambda: collections.defaultdict(dict))    # kernel -> counter -> dispatch -> value
+        for r in csv.DictReader(open(path)):
+            k = short(r["Kernel_Name"])
+            if k is None:
+                continue
+            d = per[k][r["Counter_Name"]]
+            d[int(r["Dispatch_Id"])] = d.get(int(r["Dispatch_Id"]), 0.0) + float(r["Counter_Value"])
+        for k, cs in per.items():
+            for c, d in cs.items():
+                ids = sorted(d)
+                n_total = len(ids)
+                # dispatches of this kernel are spread evenly over warm-up and timed sweeps (+ the engine probe for sizing,
+                # which runs no sweep); the pruning-only repetitions of the replica mapping come last
+                per_sweep = n_total / float(steps + warm) if k != "mcmc_sweep_kernel" else None
+                if per_sweep is not None and abs(per_sweep - round(per_sweep)) < 1e-9:
+                    first = int(round(per_sweep)) * warm
+                    timed = ids[first:]
+                else:
+                    timed = ids
+                sums[k][c] = sum(d[i] for i in timed)
+                launches[k] = len(timed)
+    out = {"config": cfg, "steps": steps, "warmup": warm, "kernels": {}}
+    for k, cs in sums.items():
+        e = {"timed_launches": launches[k]}
+        e.update({c: v for c, v in cs.items()})
+        if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+            e["hbm_bytes"] = cs["FETCH_SIZE"] * 1024 * 2 + cs["WRITE_SIZE"] * 1024
+            e["hbm_bytes_per_launch"] = e["hbm_bytes"] / max(1, launches[k])
+            e["hbm_bytes_per_sweep"] = e["hbm_bytes"] / steps
+        out["kernels"][k] = e
+    json.dump(out, sys.stdout, indent=1)
+
+
+if __name__ == "__main__":
+    main()
