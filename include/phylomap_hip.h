@@ -37,8 +37,9 @@ typedef enum phm_status {
   PHM_ERR_NO_DEVICE = 3,      /* no HIP device, or a HIP call failed */
   PHM_ERR_OOM = 4,            /* device memory */
   PHM_ERR_ZERO_PROB = 5,      /* all-zero / non-finite probability vector (RcppArmadillo::sample throws) */
-  PHM_ERR_CAPACITY = 6,       /* a replica tile outgrew its dwell-stream capacity, or (n > 4) a branch exceeded 128 segments
-                                 (std::list in the reference is unbounded) */
+  PHM_ERR_CAPACITY = 6,       /* a sweep outgrew its dwell capacity and could not be recovered (recovery switched off, larger slots
+                                 do not fit in HBM, or the 128-segment scratch of the state-per-lane tile kernel, mapping 1 with
+                                 n > 4); std::list in the reference is unbounded */
   PHM_ERR_UNIF_CAP = 7,       /* newunifSample needed > 300 jumps (src/phylomap.cpp:120-125) */
   PHM_ERR_STATE = 8           /* API misuse (engine not created, iteration range, ...) */
 } phm_status;
@@ -95,8 +96,9 @@ typedef struct phm_options {
   int32_t tips_per_replica;    /* 0: all replicas share x$states; 1: one tip vector per replica (sites) */
   int32_t device;              /* HIP device ordinal; -1 = current device */
   int32_t iters_per_launch;    /* MCMC iterations fused into one kernel launch; 0 -> default */
-  double  cap_tail;            /* dwell-stream capacity of a 64-replica tile = sum over branches of the
-                                  1+Poisson(Omega*t_b) quantile at this tail; 0 -> 1e-3 */
+  double  cap_tail;            /* dwell capacity: the 1+Poisson(Omega*t_b) quantile at this tail, per branch; 0 -> 1e-3 for the
+                                  sequential streams of mapping 1, 1e-14 for the fixed slots of mappings 2 and 3.  An overflow is
+                                  recovered (reserved[5]) */
   int32_t reserved[6];         /* [0]: dwell-stream storage of the replica mapping, 0 = automatic, 1 = one ring per tile (half the
                                        HBM), 2 = two buffers (5 % faster sweep for n <= 4)
                                   [1]: mapping of a sweep onto the lanes (one tree), 0 = automatic by replica count; for n <= 4:
@@ -115,7 +117,12 @@ typedef struct phm_options {
                                   [3]: phm_maketreelistEXP: 1 = divide every internal partial-likelihood row by its sum in the
                                        pruning pass.  The reference's makePLexp (src/phylomap.cpp:2899-2906) does not rescale, so
                                        sumstatEXP underflows (PHM_ERR_ZERO_PROB) beyond a few hundred tips; node draws do not
-                                       depend on a row's scale, so this is the same sampler in exact arithmetic */
+                                       depend on a row's scale, so this is the same sampler in exact arithmetic
+                                  [4]: internal (capacity recovery): log2 of the multiplier applied to the provisioned capacities
+                                  [5]: 1 = no capacity recovery: a sweep that outgrows its slots fails with PHM_ERR_CAPACITY.  Default
+                                       (0): the engine is rebuilt with doubled slots and the iterations run so far are replayed --
+                                       bit-identical, every random number being addressed by (replica, iteration, entity) -- so a
+                                       run cannot abort where the reference's std::list (src/phylomap.cpp:18-21) would grow */
 } phm_options;
 
 typedef struct phm_info {

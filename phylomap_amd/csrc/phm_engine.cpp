@@ -250,8 +250,8 @@ int32_t narrow_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
   const phm::Schedule& s = e->sched;
   const int E = s.n_edge, T = s.n_tips, Nn = s.n_node, n = e->n, S = e->S;
   // One slot per branch: 1 + Poisson(Omega t_b) segments in stationarity, provisioned far into the tail because a slot
-  // has no neighbour to borrow from (default 1e-12 per branch and sweep); longer caller-supplied paths get m0 on top.
-  const double tail = o.cap_tail > 0.0 ? o.cap_tail : 1e-12;
+  // has no neighbour to borrow from (default 1e-14 per branch and sweep; an overflow is recovered by rebuilding with doubled slots); longer caller-supplied paths get m0 on top.
+  const double tail = o.cap_tail > 0.0 ? o.cap_tail : 1e-14;
   e->nw_off.assign(E + 1, 0);
   std::vector<int32_t> cap(E);
   int max_cap = 0;
@@ -260,7 +260,7 @@ int32_t narrow_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
     for (int i = x->map_off[b]; i < x->map_off[b + 1]; ++i) tb += x->maps[i];
     const int m0 = x->map_off[b + 1] - x->map_off[b];
     const int q = phm::poisson_capacity(model->Omega * tb, tail);
-    cap[b] = std::max(q, m0 + q - 1) + 2;
+    cap[b] = (std::max(q, m0 + q - 1) + 2) * e->cap_boost;
     max_cap = std::max(max_cap, cap[b]);
     e->nw_off[b + 1] = e->nw_off[b] + cap[b];
   }
@@ -403,8 +403,8 @@ int32_t tiles_setup(phm_engine* e, const phm_tree* x, const phm_model* model, co
   const phm::Schedule& s = e->sched;
   const int E = s.n_edge, T = s.n_tips, Nn = s.n_node, n = e->n, tiles = e->tiles;
   // One slot of rows per branch; a row holds the 64 replicas of the tile, so the slot must take the LARGEST of 64 segment
-  // counts: provisioned at 1e-12 per replica, branch and sweep (1 + Poisson(Omega t_b), plus the caller's initial length).
-  const double tail = o.cap_tail > 0.0 ? o.cap_tail : 1e-12;
+  // counts: provisioned at 1e-14 per replica, branch and sweep (1 + Poisson(Omega t_b), plus the caller's initial length).
+  const double tail = o.cap_tail > 0.0 ? o.cap_tail : 1e-14;
   e->tl_slot.assign(E + 1, 0);
   std::vector<int32_t> cap(E);
   int max_cap = 0;
@@ -414,7 +414,7 @@ int32_t tiles_setup(phm_engine* e, const phm_tree* x, const phm_model* model, co
     for (int i = x->map_off[b]; i < x->map_off[b + 1]; ++i) tb += x->maps[i];
     const int m0 = x->map_off[b + 1] - x->map_off[b];
     const int q = phm::poisson_capacity(model->Omega * tb, tail);
-    cap[b] = std::max(q, m0 + q - 1) + 2;
+    cap[b] = (std::max(q, m0 + q - 1) + 2) * e->cap_boost;
     if (cap[b] >= (1 << 23)) return fail(PHM_ERR_UNSUPPORTED, "branch too long: a slot of the (tile, branch) mapping exceeds 4 GB");   // 32-bit offsets, phm_tiles.hip
     max_cap = std::max(max_cap, cap[b]);
     rows += cap[b];
@@ -508,7 +508,7 @@ int32_t tiles_setup(phm_engine* e, const phm_tree* x, const phm_model* model, co
 int32_t wtiles_setup(phm_engine* e, const phm_tree* x, const phm_model* model, const phm_options& o, int32_t max_iters) {
   const phm::Schedule& s = e->sched;
   const int E = s.n_edge, T = s.n_tips, Nn = s.n_node, n = e->n, tiles = e->tiles;
-  const double tail = o.cap_tail > 0.0 ? o.cap_tail : 1e-12;
+  const double tail = o.cap_tail > 0.0 ? o.cap_tail : 1e-14;
   e->tl_slot.assign(E + 1, 0);
   std::vector<int32_t> cap(E);
   int max_cap = 0;
@@ -520,7 +520,7 @@ int32_t wtiles_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
     tree_len += tb;
     const int m0 = x->map_off[b + 1] - x->map_off[b];
     const int q = phm::poisson_capacity(model->Omega * tb, tail);
-    cap[b] = std::max(q, m0 + q - 1) + 2;
+    cap[b] = (std::max(q, m0 + q - 1) + 2) * e->cap_boost;
     if (cap[b] >= (1 << 23)) return fail(PHM_ERR_UNSUPPORTED, "branch too long: a slot of the (tile, branch) mapping exceeds 4 GB");
     max_cap = std::max(max_cap, cap[b]);
     rows += cap[b];
@@ -637,6 +637,42 @@ int32_t wtiles_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
   return PHM_OK;
 }
 
+// the engine an entry point works on: the rebuilt one after a capacity recovery
+phm_engine* live(phm_engine* e) {
+  while (e && e->fwd) e = e->fwd;
+  return e;
+}
+
+std::shared_ptr<SavedInput> save_input(const phm_tree* trees, int32_t n_trees, const phm_model* model, const phm_options& o, int32_t max_iters) {
+  auto sv = std::make_shared<SavedInput>();
+  const int n = model->n_states;
+  sv->trees.resize(n_trees);
+  sv->flat.resize(n_trees);
+  for (int j = 0; j < n_trees; ++j) {
+    const phm_tree& x = trees[j];
+    SavedInput::TreeCopy& c = sv->trees[j];
+    const size_t E = (size_t)x.n_edge, nt = (size_t)x.n_tips * (o.tips_per_replica ? std::max(1, o.n_replicas) : 1);
+    c.edge.assign(x.edge, x.edge + 2 * E);
+    c.states.assign(x.states, x.states + nt);
+    c.map_off.assign(x.map_off, x.map_off + E + 1);
+    c.maps.assign(x.maps, x.maps + x.map_off[E]);
+    c.mapnames.assign(x.mapnames, x.mapnames + x.map_off[E]);
+    if (x.edge_length) c.edge_length.assign(x.edge_length, x.edge_length + E);
+    c.t = x;
+    c.t.edge = c.edge.data(); c.t.states = c.states.data(); c.t.map_off = c.map_off.data(); c.t.maps = c.maps.data();
+    c.t.mapnames = c.mapnames.data(); c.t.edge_length = x.edge_length ? c.edge_length.data() : nullptr;
+    sv->flat[j] = c.t;
+  }
+  sv->Q.assign(model->Q, model->Q + (size_t)n * n);
+  sv->pid.assign(model->pid, model->pid + n);
+  if (model->B) sv->B.assign(model->B, model->B + (size_t)n * n);
+  sv->model = *model;
+  sv->model.Q = sv->Q.data(); sv->model.pid = sv->pid.data(); sv->model.B = model->B ? sv->B.data() : nullptr;
+  sv->opt = o;
+  sv->max_iters = max_iters;
+  return sv;
+}
+
 }  // namespace
 
 extern "C" {
@@ -730,6 +766,9 @@ int32_t phm_engine_create_multi(const phm_tree* trees, int32_t n_trees, const ph
   e->ipl = o.iters_per_launch > 0 ? o.iters_per_launch : 8;
   e->tips_per_replica = o.tips_per_replica != 0 || n_trees > 1;      // a list of trees: tip data per tile
   e->phase_timing = o.reserved[2] != 0;
+  e->cap_boost = 1 << std::max(0, std::min(10, (int)o.reserved[4]));      // internal: set by the capacity recovery
+  e->recover = o.reserved[5] == 0;
+  e->saved = save_input(trees, n_trees, model, o, max_iters);
 
   std::string serr;
   e->scheds.resize(n_trees);
@@ -796,8 +835,8 @@ int32_t phm_engine_create_multi(const phm_tree* trees, int32_t n_trees, const ph
       // a sweep keeps at most the m merged segments it was given and adds Poisson(<= Omega t_b) virtual jumps, so a
       // caller-supplied path longer than the stationary quantile (e.g. 100 equal pieces) needs m0 + that quantile
       int q = phm::poisson_capacity(model->Omega * tb, o.cap_tail > 0.0 ? o.cap_tail : 1e-3);
-      rows_j += std::max(q, m0 + q - 1);
-      max_q = std::max<int64_t>(max_q, std::max(q, m0 + q - 1));
+      rows_j += (int64_t)std::max(q, m0 + q - 1) * e->cap_boost;
+      max_q = std::max<int64_t>(max_q, (int64_t)std::max(q, m0 + q - 1) * e->cap_boost);
       sum_lambda += model->Omega * tb;
     }
     // Ring capacity: the stream being read, plus head-room for the stream being written behind it.  While branch k is
@@ -965,6 +1004,7 @@ int32_t phm_engine_create_multi(const phm_tree* trees, int32_t n_trees, const ph
 }
 
 int32_t phm_engine_run(phm_engine* e, int32_t n_iters, void* hip_stream) {
+  e = live(e);
   if (!e) return fail(PHM_ERR_STATE, "engine is NULL");
   if (n_iters < 0 || e->iters_done + n_iters > e->max_iters) return fail(PHM_ERR_STATE, "iteration range exceeds max_iters");
   HIPCHK(hipSetDevice(e->device));
@@ -1021,7 +1061,39 @@ int32_t phm_engine_run(phm_engine* e, int32_t n_iters, void* hip_stream) {
   return PHM_OK;
 }
 
+// A sweep outgrew its slots / streams: free this engine's device memory, build a replacement with doubled capacities from the
+// saved inputs and replay the iterations run so far (bit-identical: streams are addressed, not consumed), model changes of the
+// Q-updating drivers at their iterations included; every later call on the handle continues on the replacement.
+static int32_t recover_capacity(phm_engine* e) {
+  const int T = e->iters_done;
+  std::shared_ptr<SavedInput> sv = e->saved;
+  hipStream_t stream = e->last_stream;
+  int boost_log2 = 0;
+  while ((1 << boost_log2) < e->cap_boost) ++boost_log2;
+  if (boost_log2 >= 8) return fail(PHM_ERR_CAPACITY, "a branch outgrew its dwell capacity after 8 doublings of the slots");
+  e->release_device();
+  phm_options o = sv->opt;
+  o.reserved[4] = boost_log2 + 1;
+  phm_engine* r = nullptr;
+  const std::vector<std::pair<int32_t, std::vector<double>>> hist = sv->model_hist;      // the replay appends its own copy
+  int32_t st = phm_engine_create_multi(sv->flat.data(), (int32_t)sv->flat.size(), &sv->model, &o, sv->max_iters, &r);
+  if (st) return (st == PHM_ERR_OOM) ? fail(PHM_ERR_CAPACITY, "a branch outgrew its dwell capacity and larger slots do not fit in HBM: " + g_phm_err) : st;
+  r->recoveries = e->recoveries + 1;
+  e->fwd = r;
+  size_t h = 0;
+  for (int it = 0; it < T && !st;) {
+    while (h < hist.size() && hist[h].first <= it) { st = phm_engine_set_model(r, hist[h].second.data()); ++h; if (st) return st; }
+    const int next = (h < hist.size()) ? std::min(T, hist[h].first) : T;
+    st = phm_engine_run(r, next - it, stream);
+    it = next;
+  }
+  while (!st && h < hist.size()) { st = phm_engine_set_model(r, hist[h].second.data()); ++h; }
+  if (st) return st;
+  return phm_engine_sync(r);          // may recover again (the replacement forwards in turn)
+}
+
 int32_t phm_engine_sync(phm_engine* e) {
+  e = live(e);
   if (!e) return fail(PHM_ERR_STATE, "engine is NULL");
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipStreamSynchronize(e->last_stream));
@@ -1041,10 +1113,13 @@ int32_t phm_engine_sync(phm_engine* e) {
   uint32_t derr = 0;
   HIPCHK(hipMemcpy(&derr, e->d_err.p, sizeof derr, hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(&e->seg_total, e->d_seg.p, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  if ((derr & phm::DERR_CAPACITY) && !(derr & ~phm::DERR_CAPACITY) && e->recover && e->saved && !(e->wide && !e->narrow && !e->tiled))
+    return recover_capacity(e);      // (the state-per-lane tile kernel of phm_wide.hip has a fixed 128-segment scratch: not recoverable)
   return device_status(derr);
 }
 
 int32_t phm_engine_read_stats(phm_engine* e, int32_t iter0, int32_t n, double* out) {
+  e = live(e);
   if (!e || !out) return fail(PHM_ERR_STATE, "engine/out is NULL");
   if (iter0 < 0 || n < 0 || iter0 + n > e->iters_done) return fail(PHM_ERR_STATE, "statistics requested for iterations that have not run");
   if (n == 0) return PHM_OK;
@@ -1084,6 +1159,7 @@ int32_t phm_engine_read_stats(phm_engine* e, int32_t iter0, int32_t n, double* o
 
 int32_t phm_engine_dump(phm_engine* e, int32_t replica, int32_t* seg_count, double* seg_dwell, int32_t seg_cap,
                         int32_t* node_states, double* PL) {
+  e = live(e);
   if (!e) return fail(PHM_ERR_STATE, "engine is NULL");
   if (replica < 0 || replica >= e->S) return fail(PHM_ERR_BAD_INPUT, "replica out of range");
   HIPCHK(hipSetDevice(e->device));
@@ -1169,6 +1245,7 @@ int32_t phm_engine_dump(phm_engine* e, int32_t replica, int32_t* seg_count, doub
 }
 
 int32_t phm_engine_info(phm_engine* e, phm_info* info) {
+  e = live(e);
   if (!e || !info) return fail(PHM_ERR_STATE, "engine/info is NULL");
   std::memset(info, 0, sizeof(*info));
   info->n_states = e->n; info->n_edge = e->sched.n_edge; info->n_replicas = e->S; info->n_replicas_padded = e->S_pad;
@@ -1179,9 +1256,10 @@ int32_t phm_engine_info(phm_engine* e, phm_info* info) {
   return PHM_OK;
 }
 
-void phm_engine_destroy(phm_engine* e) { delete e; }
+void phm_engine_destroy(phm_engine* e) { delete e; }      // deletes the chain of rebuilt engines too
 
 int32_t phm_engine_phase_ms(phm_engine* e, double* out4) {
+  e = live(e);
   if (!e || !out4) return fail(PHM_ERR_STATE, "engine/out is NULL");
   if (!e->phase_timing || !e->tiled) return fail(PHM_ERR_STATE, "phase timing needs phm_options.reserved[2] = 1 and a (tile, item) mapping");
   for (int i = 0; i < 4; ++i) out4[i] = e->phase_ms[i];
@@ -1196,6 +1274,7 @@ int32_t phm_engine_phase_ms(phm_engine* e, double* out4) {
 // hand the buffer to RCCL without a host round trip.  Valid until the next call on this engine.
 extern "C" int32_t phm_engine_reduced_stats_device(phm_engine* e, int32_t iter0, int32_t n, void* hip_stream,
                                                    void** out_dev) {
+  e = live(e);
   if (!e || !out_dev) return fail(PHM_ERR_STATE, "engine/out is NULL");
   if (!e->reduce) return fail(PHM_ERR_STATE, "engine was not created with reduce = 1");
   if (iter0 < 0 || n < 1 || iter0 + n > e->iters_done) return fail(PHM_ERR_STATE, "statistics requested for iterations that have not run");
@@ -1213,6 +1292,7 @@ extern "C" int32_t phm_engine_reduced_stats_device(phm_engine* e, int32_t iter0,
 // on the engine's current chain state (segment counts are left untouched, so every repetition does the same work).
 // Returns the HIP-event time in milliseconds.  n <= 4 kernels only.
 extern "C" int32_t phm_engine_time_pruning(phm_engine* e, int32_t n_iters, void* hip_stream, double* ms_out) {
+  e = live(e);
   if (!e || !ms_out) return fail(PHM_ERR_STATE, "engine/ms_out is NULL");
   const bool wt = e->wide && e->tiled;
   if (!wt && (e->wide || e->narrow || e->tiled || e->n_trees > 1)) return fail(PHM_ERR_UNSUPPORTED, "pruning-only timing is implemented for the replica mapping with n_states <= 4 and the lane-per-replica mapping of 5..64 states");
@@ -1240,7 +1320,9 @@ extern "C" int32_t phm_engine_time_pruning(phm_engine* e, int32_t n_iters, void*
 // Replace the rate matrix between sweeps (the Q-updating variants edit Q and B after every iteration,
 // src/phylomap.cpp:1212-1217, :1862-1866).  Q column-major; B = I + Q/Omega is recomputed.  The chain state is kept.
 extern "C" int32_t phm_engine_set_model(phm_engine* e, const double* Q) {
+  e = live(e);
   if (!e || !Q) return fail(PHM_ERR_STATE, "engine/Q is NULL");
+  if (e->saved) e->saved->model_hist.emplace_back(e->iters_done, std::vector<double>(Q, Q + (size_t)e->n * e->n));
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipStreamSynchronize(e->last_stream));
   std::vector<double> B2, Bc, scale, qp;

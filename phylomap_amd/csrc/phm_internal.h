@@ -41,6 +41,9 @@ inline int32_t fail(int32_t st, const std::string& msg) { g_phm_err = msg; retur
 struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
   ~DevBuf() { if (p) (void)hipFree(p); }
   void reset() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
   // re-allocating frees the previous block first (the automatic mapping fallback of phm_engine_create_multi sets the same
@@ -155,8 +158,31 @@ inline int32_t validate_tree_paths(const phm_tree* x, int n, int n_tip_vectors) 
   return PHM_OK;
 }
 
+// The caller's inputs, copied at creation: the reference's std::list paths are unbounded (src/phylomap.cpp:18-21), the fixed HBM
+// layouts here are not, so when a sweep outgrows its slots the engine is rebuilt with larger ones and the iterations run so far
+// are replayed (every random number is addressed by (replica, iteration, entity): the replay is bit-identical).
+struct SavedInput {
+  struct TreeCopy {
+    phm_tree t;
+    std::vector<int32_t> edge, states, map_off, mapnames;
+    std::vector<double> edge_length, maps;
+  };
+  std::vector<TreeCopy> trees;
+  std::vector<phm_tree> flat;                      // the phm_tree array handed back to phm_engine_create_multi
+  phm_model model;
+  std::vector<double> Q, pid, B;
+  phm_options opt;
+  int32_t max_iters = 0;
+  std::vector<std::pair<int32_t, std::vector<double>>> model_hist;      // (first iteration it applies to, Q column-major): phm_engine_set_model calls
+};
+
 // -------------------------------------------------------------------------------------------------
 struct phm_engine {
+  std::shared_ptr<SavedInput> saved;
+  phm_engine* fwd = nullptr;                       // set after a capacity recovery: every entry point continues on the rebuilt engine
+  int cap_boost = 1;                               // multiplier of the provisioned slot / stream capacities (doubles per recovery)
+  bool recover = true;                             // phm_options.reserved[5] = 1 switches the recovery off (overflow -> PHM_ERR_CAPACITY)
+  int recoveries = 0;
   int n = 0, cols = 0, dcols = 0, variant = 0;   // cols: result columns; dcols: columns kept on the device
   std::vector<double> qparams;                     // bf/ks: l01, l10, rkappas, lkappas, gammas of the CURRENT Q (recordQks :1789-1798)
   std::vector<std::vector<double>> qhist;          // ... as recorded at the start of every iteration that has run
@@ -217,7 +243,18 @@ struct phm_engine {
   int last_launches = 0;
   int64_t bytes = 0;
   unsigned long long seg_total = 0;
+  // frees every device buffer (the host-side description of the problem stays: sched, cols, ...)
+  void release_device() {
+    DevBuf* all[] = {&d_roots, &d_mask, &d_up, &d_down, &d_col, &d_row, &d_tips, &d_mcount, &d_dw0, &d_dw1, &d_cursor, &d_PL, &d_nstate,
+                     &d_stats, &d_err, &d_seg, &d_red, &d_red_out, &d_B2, &d_Bc, &d_scale, &d_pid, &d_nw_up_off, &d_nw_down_off,
+                     &d_nw_up_order, &d_nw_down_order, &d_nw_border, &d_nw_off, &d_nw_colL, &d_nw_rowL, &d_nw_maskL, &d_nw_mcount,
+                     &d_nw_dwA, &d_nw_dwB, &d_nw_mstate, &d_nw_mlen, &d_nw_estate, &d_nw_part, &d_nw_rowbuf, &d_ell_col, &d_ell_val,
+                     &d_ell2_col, &d_ell2_val, &d_wb_cnt, &d_tl_slot, &d_tl_pdw, &d_tl_pchunk, &d_tl_cnt, &d_tl_estate, &d_tl_pseg,
+                     &d_tl_segprev, &d_wt_dwfx, &d_wt_segacc, &d_wt_B2, &d_wt_totL};
+    for (DevBuf* b : all) b->reset();
+  }
   ~phm_engine() {
+    delete fwd;
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     for (hipEvent_t ev : phase_ev) (void)hipEventDestroy(ev);

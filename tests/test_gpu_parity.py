@@ -760,29 +760,78 @@ def test_random_cases_every_mapping_against_the_oracle():
 
 
 @pytest.mark.parametrize("mapping", MAPPINGS)
-def test_capacity_overflow_is_reported_not_written_out_of_bounds(mapping):
-    """A dwell store that would leave its slot / stream is dropped and reported (PHM_ERR_CAPACITY) -- the reference's
-    std::list is unbounded, a fixed HBM layout is not.  cap_tail = 0.9 provisions far too little on purpose."""
+def test_capacity_overflow_is_recovered_like_an_unbounded_list(mapping):
+    """The reference's std::list paths are unbounded (src/phylomap.cpp:18-21); a fixed HBM layout is not.  cap_tail = 0.9
+    provisions far too little on purpose: the engine rebuilds itself with doubled slots and replays the iterations run so far
+    (bit-identical: every random number is addressed, not consumed), so the run completes and still matches the oracle.  With
+    the recovery switched off the overflow is reported (PHM_ERR_CAPACITY), never written out of bounds."""
     z, Q, pid, Omega = _problem(4, 40, 3)
+    Om = 6.0 * Omega
+    nen, nodelist, root = _orders(z)
+    kw = dict(variant=_lib.PHM_MCMC_BIGTREE, seed=1, n_replicas=70, mapping=mapping, cap_tail=0.9, storage=1 if mapping == "replicas" else 0)
     with pytest.raises(_lib.PhmError) as e:
-        eng = _lib.Engine(z, Q, pid, 6.0 * Omega, 30, variant=_lib.PHM_MCMC_BIGTREE, seed=1, n_replicas=70, mapping=mapping, cap_tail=0.9,
-                          storage=1 if mapping == "replicas" else 0)
+        eng = _lib.Engine(z, Q, pid, Om, 30, recover=False, **kw)
         eng.run(30)
         eng.sync()
     assert e.value.status == 6
-    ok = api.sumstatMCMC_bigtree(z, Q, pid, 6.0 * Omega, 5, seed=1, n_replicas=70, mapping=mapping)      # default capacity: fine
-    np.testing.assert_allclose(ok[:, :, :4].sum(2), z["edge.length"].sum(), rtol=1e-12)
+    eng = _lib.Engine(z, Q, pid, Om, 30, **kw)
+    eng.run(12); eng.sync()                      # overflows and recovers here ...
+    eng.run(18); eng.sync()                      # ... and keeps going on the rebuilt engine
+    got = eng.stats(0, 30)
+    for r in (0, 63, 69):
+        want, rc, dump = O.maketreelistMCMC(z, Q, pid, np.eye(4) + Q / Om, Om, nen, nodelist, root, 30, variant=O.BIGTREE, seed=1, replica=r,
+                                            dump=True)
+        assert rc == 0
+        _same(got[r], want, 4, mapping)
+        np.testing.assert_array_equal(eng.dump(r)["seg_count"], dump.seg_count)
+    eng.close()
+    ok = api.sumstatMCMC_bigtree(z, Q, pid, Om, 5, seed=1, n_replicas=70, mapping=mapping)      # default capacity: no recovery needed
+    np.testing.assert_array_equal(ok[0][:, 4:], got[0][:5, 4:])
 
 
-@pytest.mark.parametrize("mapping", ["replicas", "branches", "tiles"])
-def test_capacity_overflow_is_reported_for_wide_state_spaces(mapping):
+def test_capacity_recovery_replays_the_rate_updates():
+    """sumstatMCMCbf changes Q after every sweep: a recovery has to replay the model changes at their iterations."""
+    z, Q, pid, Omega = _problem(2, 30, 21)
+    nen, nodelist, root = _orders(z)
+    prior = np.array([.55, 1, .56, 1.01])
+    Om = 40.0 * Omega
+    want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(2) + Q / Om, Om, nen, nodelist, root, 25, variant=O.BF, seed=4, prior=prior)
+    assert rc == 0
+    for mapping in ("branches", "tiles"):
+        got = api.sumstatMCMCbf(z, Q, pid, Om, 25, prior, seed=4, mapping=mapping, cap_tail=0.9)
+        _same(got, want, 2, mapping, ks=True)
+
+
+@pytest.mark.parametrize("mapping", ["branches", "tiles"])
+def test_capacity_overflow_is_recovered_for_wide_state_spaces(mapping):
+    n = 6
+    Q = synth.dense_Q(n, 0.02, 0.08, seed=66)
+    Omega = 1.25 * float(np.max(np.abs(np.diag(Q))))
+    pid = np.full(n, 1.0 / n)
+    z = synth.make_tree(20, Q, Omega, 67, pid)
+    nen, nodelist, root = _orders(z)
+    Om = 8.0 * Omega
+    with pytest.raises(_lib.PhmError) as e:
+        eng = _lib.Engine(z, Q, pid, Om, 30, variant=_lib.PHM_MCMC_BIGTREE, seed=1, n_replicas=5, mapping=mapping, cap_tail=0.9, recover=False)
+        eng.run(30)
+        eng.sync()
+    assert e.value.status == 6
+    got = api.sumstatMCMC_bigtree(z, Q, pid, Om, 30, seed=1, n_replicas=5, mapping=mapping, cap_tail=0.9)
+    for r in (0, 4):
+        want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(n) + Q / Om, Om, nen, nodelist, root, 30, variant=O.BIGTREE, seed=1, replica=r)
+        assert rc == 0
+        _same(got[r], want, n, mapping)
+
+
+def test_capacity_overflow_of_the_state_per_lane_tile_kernel_is_reported():
+    """mapping 1 with n > 4 (phm_wide.hip) keeps a fixed 128-segment scratch per branch: not recoverable by regrowth"""
     n = 6
     Q = synth.dense_Q(n, 0.02, 0.08, seed=66)
     Omega = 1.25 * float(np.max(np.abs(np.diag(Q))))
     pid = np.full(n, 1.0 / n)
     z = synth.make_tree(20, Q, Omega, 67, pid)
     with pytest.raises(_lib.PhmError) as e:
-        eng = _lib.Engine(z, Q, pid, 8.0 * Omega, 30, variant=_lib.PHM_MCMC_BIGTREE, seed=1, n_replicas=5, mapping=mapping, cap_tail=0.9)
+        eng = _lib.Engine(z, Q, pid, 8.0 * Omega, 30, variant=_lib.PHM_MCMC_BIGTREE, seed=1, n_replicas=5, mapping="replicas", cap_tail=0.9)
         eng.run(30)
         eng.sync()
     assert e.value.status == 6
