@@ -1,6 +1,6 @@
 // phylomap_shim.cpp -- the ONLY file that includes R headers.  Replaces src/RcppExports.cpp for the hot-path
 // symbols: same `.Call` names, same argument order (src/RcppExports.cpp:11,34,57,80,106,132; R/RcppExports.R:4-30), so
-// R/sumstat*.R and user code run unchanged.  Each export unpacks the SEXPs into the plain structs of
+// R/sumstat*.R and user code run unchanged; plus `phylomap_tree_orders`, the native form of their helper preamble.  Each export unpacks the SEXPs into the plain structs of
 // include/phylomap_hip.h, calls the C-ABI, and returns a fresh N x cols numeric matrix.
 //
 // NOT compiled in this repository's CI: R / Rcpp are not installed in the build image.  Build inside the
@@ -15,10 +15,12 @@ using namespace Rcpp;
 
 namespace {
 
+// The R list `x` flattened into owned arrays; view() builds the phm_tree from the CURRENT addresses of those arrays, so a
+// FlatTree can live in any container (no pointers into itself are kept).
 struct FlatTree {
   std::vector<int32_t> edge, states, map_off, mapnames;
   std::vector<double> edge_length, maps;
-  phm_tree t;
+  int32_t n_node = 0, n_edge = 0;
   explicit FlatTree(List x) {
     IntegerMatrix e = as<IntegerMatrix>(x["edge"]);                 // src/phylomap.cpp:904
     IntegerVector st = as<IntegerVector>(x["states"]);              // :910 (REALSXP in the shipped RDS: coerced)
@@ -38,15 +40,21 @@ struct FlatTree {
       NumericVector el = as<NumericVector>(x["edge.length"]);
       edge_length.assign(el.begin(), el.end());
     }
+    n_node = as<int>(x["Nnode"]);                                   // :907
+    n_edge = e.nrow();
+  }
+  phm_tree view() const {
+    phm_tree t;
     t.n_tips = (int32_t)states.size();
-    t.n_node = as<int>(x["Nnode"]);                                 // :907
-    t.n_edge = e.nrow();
+    t.n_node = n_node;
+    t.n_edge = n_edge;
     t.edge = edge.data();
     t.edge_length = edge_length.empty() ? nullptr : edge_length.data();
     t.states = states.data();
     t.map_off = map_off.data();
     t.maps = maps.data();
     t.mapnames = mapnames.data();
+    return t;
   }
 };
 
@@ -81,7 +89,8 @@ SEXP run_mcmc(mcmc_fn fn, SEXP xSEXP, SEXP QSEXP, SEXP pidSEXP, SEXP BSEXP, SEXP
   const int n = Q.nrow(), N = as<int>(NSEXP);
   NumericMatrix out(N, n + n * (n - 1));                            // :926
   phm_options o = options_from_R();
-  check(fn(&ft.t, n, Q.begin(), pid.begin(), B.begin(), as<double>(OmegaSEXP), nen.begin(), nodelist.begin(),
+  const phm_tree t = ft.view();
+  check(fn(&t, n, Q.begin(), pid.begin(), B.begin(), as<double>(OmegaSEXP), nen.begin(), nodelist.begin(),
            as<int>(rootSEXP), N, &o, out.begin()));
   return out;
 }
@@ -125,7 +134,8 @@ static SEXP run_qupdate(qupd_fn fn, int cols_extra_k, int dic, SEXP xSEXP, SEXP 
   const int k = cols_extra_k ? n / 2 - 1 : 0;
   NumericMatrix out(N, n + n * n + 2 + 3 * k + 1 + dic);            // :1293 (bf), :1857 (ks), :3230 / :3372 (DIC)
   phm_options o = options_from_R();
-  check(fn(&ft.t, n, Q.begin(), pid.begin(), B.begin(), as<double>(OmegaSEXP), nen.begin(), nodelist.begin(),
+  const phm_tree t = ft.view();
+  check(fn(&t, n, Q.begin(), pid.begin(), B.begin(), as<double>(OmegaSEXP), nen.begin(), nodelist.begin(),
            as<int>(rootSEXP), N, prior.begin(), (int32_t)prior.size(), &o, out.begin()));
   return out;
 }
@@ -168,15 +178,9 @@ static SEXP run_qupdate_mt(mt_fn fn, int hidden, SEXP xSEXP, SEXP QSEXP, SEXP pi
   RNGScope scope;
   List xs(xSEXP);
   std::vector<FlatTree> fts;
-  fts.reserve(xs.size());                                           // FlatTree::t points into its own vectors: no reallocation
   for (int j = 0; j < xs.size(); ++j) fts.emplace_back(as<List>(xs[j]));
-  std::vector<phm_tree> trees;
-  for (size_t j = 0; j < fts.size(); ++j) {                          // re-point after the moves into the vector
-    FlatTree& f = fts[j];
-    f.t.edge = f.edge.data(); f.t.edge_length = f.edge_length.empty() ? nullptr : f.edge_length.data();
-    f.t.states = f.states.data(); f.t.map_off = f.map_off.data(); f.t.maps = f.maps.data(); f.t.mapnames = f.mapnames.data();
-    trees.push_back(f.t);
-  }
+  std::vector<phm_tree> trees;                                      // views taken once the container has stopped growing
+  for (const FlatTree& f : fts) trees.push_back(f.view());
   NumericMatrix Q(QSEXP), B(BSEXP);
   NumericVector pid(pidSEXP), prior(priorSEXP);
   IntegerMatrix nen_m(nenSEXP), nodelist_m(nodelistSEXP);
@@ -215,8 +219,25 @@ RcppExport SEXP phylomap_maketreelistEXP(SEXP xSEXP, SEXP QSEXP, SEXP pidSEXP, S
   const int n = Q.nrow(), N = as<int>(NSEXP);
   NumericMatrix out(N, n + n * (n - 1));                            // :3031
   phm_options o = options_from_R();
-  check(phm_maketreelistEXP(&ft.t, n, Q.begin(), pid.begin(), nen.begin(), nodelist.begin(), as<int>(rootSEXP), N,
+  const phm_tree t = ft.view();
+  check(phm_maketreelistEXP(&t, n, Q.begin(), pid.begin(), nen.begin(), nodelist.begin(), as<int>(rootSEXP), N,
                             lefts.begin(), rights.begin(), d.begin(), &o, out.begin()));
   return out;
+  END_RCPP
+}
+
+// O(E) replacement of the helper preamble every R/sumstat*.R file carries (pruningwiseedgeorder / makenodelist / myreorder,
+// R/sumstatMCMC.R:1-18: interpreted O(E^2) loops around ape::reorder(x, "pruningwise")): one call returns all three.
+// R side: shim/R/phylomap_tree_orders.R.  edge: x$edge (E x 2 integer matrix, 1-based), n_tips: length(x$states).
+RcppExport SEXP phylomap_tree_orders(SEXP edgeSEXP, SEXP ntipsSEXP) {
+  BEGIN_RCPP
+  IntegerMatrix edge(edgeSEXP);
+  const int E = edge.nrow(), T = as<int>(ntipsSEXP);
+  IntegerVector nen(E), nodelist(T > 2 ? T - 2 : 0);
+  std::vector<int32_t> nl(T > 1 ? T - 1 : 1);
+  int32_t root = 0;
+  check(phm_tree_orders(T, E, edge.begin(), nen.begin(), nl.data(), &root));
+  for (int i = 0; i < nodelist.size(); ++i) nodelist[i] = nl[i];
+  return List::create(Named("nen") = nen, Named("nodelist") = nodelist, Named("root") = (int)root);
   END_RCPP
 }

@@ -228,3 +228,28 @@ def test_newick_reader_reproduces_the_reference_prepared_squamate_tree():
     for b in (0, 1, 17, 7899):
         np.testing.assert_allclose(mine["maps"][b], np.asarray(z["maps"][b]), rtol=1e-15)
         np.testing.assert_array_equal(mine["mapnames"][b], np.asarray(z["mapnames"][b]).round().astype(np.int32))
+
+
+def test_shim_type_checks_against_a_mock_of_the_rcpp_surface():
+    """R / Rcpp are not installed here, so shim/phylomap_shim.cpp cannot be built; it is at least parsed and type-checked
+    against a declaration-only mock of the Rcpp API it uses (tests/mock_rcpp/Rcpp.h) together with the real C-ABI header,
+    and it must export every `.Call` symbol of src/RcppExports.cpp plus phylomap_tree_orders."""
+    import re
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "shim", "phylomap_shim.cpp")
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-I" + os.path.join(root, "tests", "mock_rcpp"),
+                        "-I" + os.path.join(root, "include"), src], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    text = open(src).read()
+    exported = set(re.findall(r"RcppExport SEXP (phylomap_\w+)\(", text))
+    assert exported == {"phylomap_SPARSEmaketreelistMCMC", "phylomap_maketreelistMCMC", "phylomap_maketreelistMCMC_bigtree",
+                        "phylomap_maketreelistEXP", "phylomap_maketreelistMCMCbf", "phylomap_maketreelistMCMCks",
+                        "phylomap_maketreelistMCMCmt", "phylomap_maketreelistMCMCksmt", "phylomap_maketreelistMCMC2sDICt",
+                        "phylomap_maketreelistMCMCksDICt", "phylomap_tree_orders"}
+    rfile = open(os.path.join(root, "shim", "R", "phylomap_tree_orders.R")).read()
+    for name in ("pruningwiseedgeorder", "makenodelist", "myreorder"):
+        assert re.search(rf"^{name} <- function\(x\)", rfile, re.M)
