@@ -207,21 +207,25 @@ def main():
         sweep = {"bound": "hbm", "alg_bytes_per_unit": b_alg, "achieved": units * b_alg / kernel_s / 1e9, "peak": HBM_PEAK_GBS,
                  "unit": "GB/s", "frac": units * b_alg / kernel_s / 1e9 / HBM_PEAK_GBS, "kernel_ms_per_sweep": info.last_run_ms / K,
                  "launches_per_sweep": info.last_run_launches / K, "frac_of_measured_triad": units * b_alg / kernel_s / 1e9 / MEASURED_TRIAD_GBS}
+        if tr.get("all_kernels_bytes_per_unit"):
+            sweep["traffic"] = tr["all_kernels_bytes_per_unit"] * E * S      # every kernel of one sweep, HBM bytes from the PMC passes
         if tiled:
             up_ms, down_ms, br_ms, st_ms = [v / K for v in eng.phase_ms()]
             per = E * S                                      # units per launch of the branch kernel = one sweep
             br_bytes = 12 * seg + 8                          # the branch step's share of B_alg
             branch = {"bound": "hbm", "kernel": ("tiles_branch_kernel<4, false>" if n <= 4 else "wt_branch_kernel<false>"),
                       "achieved": per * br_bytes / (br_ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                      "frac": per * br_bytes / (br_ms / 1e3) / 1e9 / HBM_PEAK_GBS, "traffic": tr.get("branch_kernel_bytes_per_launch"),
+                      "frac": per * br_bytes / (br_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
+                      "traffic": (tr["branch_kernel_bytes_per_unit"] * per) if tr.get("branch_kernel_bytes_per_unit") else None,
                       "launches": K, "avg_launch_ms": br_ms, "alg_bytes_per_unit": br_bytes, "units_per_launch": per}
             n_int = E // 2 - 1                               # branches whose child is an internal node
             prune = {"bound": "hbm", "kernel": ("tiles_up_kernel<4>" if n <= 4 else f"wt_up_kernel<{(n + 15) // 16}>") + " (all height levels of one sweep)",
                      "alg_bytes_per_unit": 12 * n + 12, "ms_per_sweep": up_ms,
                      "achieved": per * (12 * n + 12) / (up_ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": per * (12 * n + 12) / (up_ms / 1e3) / 1e9 / HBM_PEAK_GBS, "traffic": tr.get("up_kernels_bytes_per_sweep")}
-            if tr.get("up_kernels_bytes_per_sweep"):
-                prune["counter_traffic_frac"] = tr["up_kernels_bytes_per_sweep"] / (up_ms / 1e3) / 1e9 / HBM_PEAK_GBS
+                     "frac": per * (12 * n + 12) / (up_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
+                     "traffic": (tr["up_kernels_bytes_per_unit"] * per) if tr.get("up_kernels_bytes_per_unit") else None}
+            if prune["traffic"]:      # what the pruning levels actually move (tip rows come from u8 states + tables, not from HBM)
+                prune["counter_traffic_frac"] = prune["traffic"] / (up_ms / 1e3) / 1e9 / HBM_PEAK_GBS
             if n > 4:                                        # 5..64 states: the pruning chains run on the matrix cores
                 mbar = seg / 2.0
                 flops = 2.0 * n * n * max(mbar - 1.0, 0.0) * n_int * S      # 2 n^2 (m - 1) per internal-child branch
@@ -234,7 +238,8 @@ def main():
             blk["pruning_sweep"] = prune
         else:
             per = E * S * ipl
-            blk["roofline"] = dict(sweep, kernel=f"mcmc_sweep_kernel<{n}>", traffic=tr.get("sweep_kernel_bytes_per_launch"),
+            blk["roofline"] = dict(sweep, kernel=f"mcmc_sweep_kernel<{n}>",
+                                   traffic=(tr["sweep_kernel_bytes_per_unit"] * per) if tr.get("sweep_kernel_bytes_per_unit") else None,
                                    launches=info.last_run_launches, avg_launch_ms=info.last_run_ms / max(1, info.last_run_launches),
                                    units_per_launch=per, measured_triad_peak=MEASURED_TRIAD_GBS)
             if n <= 4 and mapping == "replicas":
@@ -243,9 +248,9 @@ def main():
                                         "alg_bytes_per_unit": 12 * n + 12, "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "achieved": E * S * (12 * n + 12) / (prune_ms / 1e3) / 1e9,
                                         "frac": E * S * (12 * n + 12) / (prune_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
-                                        "traffic": tr.get("pruning_bytes_per_sweep")}
-                if tr.get("pruning_bytes_per_sweep"):
-                    blk["pruning_sweep"]["counter_traffic_frac"] = tr["pruning_bytes_per_sweep"] / (prune_ms / 1e3) / 1e9 / HBM_PEAK_GBS
+                                        "traffic": (tr["pruning_bytes_per_unit"] * E * S) if tr.get("pruning_bytes_per_unit") else None}
+                if blk["pruning_sweep"]["traffic"]:
+                    blk["pruning_sweep"]["counter_traffic_frac"] = blk["pruning_sweep"]["traffic"] / (prune_ms / 1e3) / 1e9 / HBM_PEAK_GBS
         eng.close()
         return blk, dt
 

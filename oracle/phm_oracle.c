@@ -11,7 +11,7 @@
  *   - categorical draw: first j with u*sum(p) <= p_0+..+p_j (index order, no sort; see
  *     sample_cat below for why RcppArmadillo's descending sort is not restated);
  *   - Exp(rate r) gap = (1/r) * (-phm_log(u))   (Rcpp::rexp(n,rate) multiplies by scale=1/rate);
- *   - uniforms from Philox4x32-10 keyed (seed) with counter (block, entity, iteration, replica); draw d of a stream is
+ *   - uniforms from Philox4x32-7 keyed (seed) with counter (block, entity, iteration, replica); draw d of a stream is
  *     word d%4 of block d/4, mapped to (0,1) as (x + 0.5) 2^-32.
  */
 #include "phm_oracle.h"
@@ -22,12 +22,14 @@
 #include <string.h>
 
 /* ------------------------------------------------------------------------------------------ */
-/* Philox4x32-10 (Salmon et al. 2011, Random123).  Pinned by Random123's kat_vectors.          */
+/* Philox4x32 (Salmon et al. 2011, Random123), `rounds` rounds.  Pinned by Random123's kat_vectors for   */
+/* 7 and 10 rounds.  The streams of the sampler use SEVEN rounds (the fewest that pass BigCrush).          */
 /* ------------------------------------------------------------------------------------------ */
-void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+#define ORC_STREAM_ROUNDS 7
+void orc_philox4x32(const uint32_t ctr[4], const uint32_t key[2], int rounds, uint32_t out[4]) {
   uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
   uint32_t k0 = key[0], k1 = key[1];
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < rounds; ++r) {
     uint64_t p0 = (uint64_t)0xD2511F53u * c0;
     uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
     uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
@@ -39,6 +41,8 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
   }
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { orc_philox4x32(ctr, key, 10, out); }
+static void philox_stream(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { orc_philox4x32(ctr, key, ORC_STREAM_ROUNDS, out); }
 
 /* 32 random bits -> double in the OPEN interval (0,1): (x + 0.5) * 2^-32, exact (the resolution of R's unif_rand). */
 double orc_u01(uint32_t x) {
@@ -51,7 +55,7 @@ double orc_stream_u(uint32_t seed_lo, uint32_t seed_hi, uint32_t replica, uint32
   uint32_t ctr[4] = { draw >> 2, entity, iter, replica };
   uint32_t key[2] = { seed_lo, seed_hi };
   uint32_t o[4];
-  orc_philox4x32_10(ctr, key, o);
+  philox_stream(ctr, key, o);
   return orc_u01(o[draw & 3u]);
 }
 
@@ -61,7 +65,7 @@ uint32_t orc_stream_word(uint32_t seed_lo, uint32_t seed_hi, uint32_t replica, u
   uint32_t ctr[4] = { draw >> 2, entity, iter, replica };
   uint32_t key[2] = { seed_lo, seed_hi };
   uint32_t o[4];
-  orc_philox4x32_10(ctr, key, o);
+  philox_stream(ctr, key, o);
   return o[draw & 3u];
 }
 

@@ -51,7 +51,7 @@ extern "C" {
 #define ORC_MCMC_MT       5   /* maketreelistMCMCmt   src/phylomap.cpp:2267-2365: list of trees, two states, Q updated */
 #define ORC_MCMC_KSMT     6   /* maketreelistMCMCksmt src/phylomap.cpp:2722-2844: list of trees, hidden rates */
 
-/* RNG: mode 0 = counter-based Philox4x32-10 streams (the mode the GPU matches bit for bit);
+/* RNG: mode 0 = counter-based Philox4x32-7 streams (the mode the GPU matches bit for bit);
  *      mode 1 = scripted tapes consumed in the reference's draw order (for hand KATs);
  *      mode 2 = "R stream": set.seed(seed_lo) + unif_rand / exp_rand / sorted RcppArmadillo::sample consumed sequentially
  *               in the reference's order (fixed-Q MCMC variants only).  UNVERIFIED: no R here; see tools/r_parity/. */
@@ -88,6 +88,7 @@ typedef struct orc_dump {
 
 /* ---- deterministic scalar maths (spec shared, by restatement, with the HIP kernels) ---- */
 void   orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+void   orc_philox4x32(const uint32_t ctr[4], const uint32_t key[2], int rounds, uint32_t out[4]);   /* the sampler's streams: 7 rounds */
 double orc_u01(uint32_t x);   /* (x + 0.5) * 2^-32 */
 double orc_log(double x);
 double orc_exp(double x);

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(TILES_BLOCK, 8) void tiles_branch_kernel(TileParams
     for (int i0 = 1; i0 < mmax; i0 += 4) {
       uint32_t wd[4] = {0u, 0u, 0u, 0u};
       if (i0 < mmax - 1)                       // some lane still draws in this group (draws exist for i < m - 1)
-        philox4x32_10((uint32_t)((i0 - 1) >> 2), ENT_BSTATE | (uint32_t)b, (uint32_t)it, rep, p.seed_lo, p.seed_hi, wd);
+        philox4x32((uint32_t)((i0 - 1) >> 2), ENT_BSTATE | (uint32_t)b, (uint32_t)it, rep, p.seed_lo, p.seed_hi, wd);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
       const int i = i0 + q;
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(TILES_BLOCK, 8) void tiles_branch_kernel(TileParams
     // segment and none after (`stuck`), so whenever it draws its draw counter equals the step index.
     for (uint32_t t0 = 0; __any(!done); t0 += 4) {
       uint32_t wd[4];
-      philox4x32_10(t0 >> 2, ENT_BEXP | (uint32_t)b, (uint32_t)it, rep, p.seed_lo, p.seed_hi, wd);
+      philox4x32(t0 >> 2, ENT_BEXP | (uint32_t)b, (uint32_t)it, rep, p.seed_lo, p.seed_hi, wd);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         if (done) continue;

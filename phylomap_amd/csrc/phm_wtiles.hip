@@ -320,7 +320,7 @@ __global__ __launch_bounds__(WT_BLOCK) void wt_branch_kernel(WtParams p, int it)
     for (int i0 = 1; i0 < mmax; i0 += 4) {
       uint32_t wd[4] = {0u, 0u, 0u, 0u};
       if (i0 < mmax - 1)                       // some lane still draws in this group (draws exist for i < m - 1)
-        philox4x32_10((uint32_t)((i0 - 1) >> 2), ENT_BSTATE | (uint32_t)b, (uint32_t)it, rep, p.seed_lo, p.seed_hi, wd);
+        philox4x32((uint32_t)((i0 - 1) >> 2), ENT_BSTATE | (uint32_t)b, (uint32_t)it, rep, p.seed_lo, p.seed_hi, wd);
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
         const int i = i0 + qq;
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(WT_BLOCK) void wt_branch_kernel(WtParams p, int it)
     bool stuck = false, done = false;
     for (uint32_t t0 = 0; __any(!done); t0 += 4) {
       uint32_t wd[4];
-      philox4x32_10(t0 >> 2, ENT_BEXP | (uint32_t)b, (uint32_t)it, rep, p.seed_lo, p.seed_hi, wd);
+      philox4x32(t0 >> 2, ENT_BEXP | (uint32_t)b, (uint32_t)it, rep, p.seed_lo, p.seed_hi, wd);
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
         if (done) continue;

@@ -111,11 +111,11 @@ class DumpBuf:
                       _ptr(self.PL, C.c_double))
 
 
-def philox(ctr, key):
+def philox(ctr, key, rounds=10):
     c = (C.c_uint32 * 4)(*ctr)
     k = (C.c_uint32 * 2)(*key)
     o = (C.c_uint32 * 4)()
-    lib().orc_philox4x32_10(c, k, o)
+    lib().orc_philox4x32(c, k, int(rounds), o)
     return list(o)
 
 

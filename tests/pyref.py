@@ -1,6 +1,6 @@
 """Independent pure-Python restatement of the hot path, written from src/phylomap.cpp (not from the C oracle)
 to pin oracle/phm_oracle.c on small cases: same arithmetic spec (IEEE doubles, left-to-right unfused sums,
-Philox4x32-10 streams, phm_log/phm_exp), so the two must agree BIT FOR BIT.  Small trees only (plain loops).
+Philox4x32-7 streams, phm_log/phm_exp), so the two must agree BIT FOR BIT.  Small trees only (plain loops).
 
 TEST INFRASTRUCTURE ONLY.
 """
@@ -12,10 +12,13 @@ M32 = 0xFFFFFFFF
 ENT_NODE, ENT_BSTATE, ENT_BEXP, ENT_BUNIF = 0, 1 << 30, 2 << 30, 3 << 30
 
 
-def philox(ctr, key):
+STREAM_ROUNDS = 7       # Philox4x32-7: the sampler's streams (the fewest rounds that pass BigCrush; Random123's default is 10)
+
+
+def philox(ctr, key, rounds=STREAM_ROUNDS):
     c0, c1, c2, c3 = ctr
     k0, k1 = key
-    for _ in range(10):
+    for _ in range(rounds):
         p0 = 0xD2511F53 * c0
         p1 = 0xCD9E8D57 * c2
         c0, c1, c2, c3 = ((p1 >> 32) ^ c1 ^ k0) & M32, p1 & M32, ((p0 >> 32) ^ c3 ^ k1) & M32, p0 & M32

@@ -20,15 +20,22 @@ def _orders(z):
 
 # ---- RNG and elementary functions ---------------------------------------------------------------------
 def test_philox_random123_known_answers():
+    """Random123's kat_vectors for philox4x32 with 10 rounds (its default) and with 7 (the sampler's streams)."""
     assert O.philox([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
     assert O.philox([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
     assert O.philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    assert O.philox([0, 0, 0, 0], [0, 0], 7) == [0x5f6fb709, 0x0d893f64, 0x4f121f81, 0x4f730a48]
+    assert O.philox([0xffffffff] * 4, [0xffffffff] * 2, 7) == [0x5207ddc2, 0x45165e59, 0x4d8ee751, 0x8c52f662]
+    assert O.philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0], 7) == \
+        [0x4dfccaba, 0x190a87f0, 0xc47362ba, 0xb6b5242a]
     ctr = np.array([[1, 2, 3, 4], [0xdeadbeef, 5, 6, 7]], dtype=np.uint32)
-    got = synth.philox4x32_10(ctr, (11, 22))
+    got = synth.philox4x32_10(ctr, (11, 22))                 # the synthetic-input generator keeps 10 rounds
     for i in range(2):
         assert list(got[i]) == O.philox([int(v) for v in ctr[i]], [11, 22])
-        assert list(pyref.philox(tuple(int(v) for v in ctr[i]), (11, 22))) == O.philox([int(v) for v in ctr[i]], [11, 22])
+        for rounds in (7, 10):
+            assert list(pyref.philox(tuple(int(v) for v in ctr[i]), (11, 22), rounds)) == O.philox([int(v) for v in ctr[i]], [11, 22], rounds)
+    assert pyref.STREAM_ROUNDS == 7
 
 
 def test_u01_is_open_interval_and_exact():
@@ -37,7 +44,7 @@ def test_u01_is_open_interval_and_exact():
     assert L.orc_u01(0xffffffff) == 1.0 - 2.0 ** -33
     assert L.orc_u01(0x12345678) == pyref.u01(0x12345678) == (0x12345678 + 0.5) / 2.0 ** 32
     # stream layout: draw d -> word d & 3 of Philox block d >> 2
-    o = O.philox([3, 7, 9, 2], [5, 6])
+    o = O.philox([3, 7, 9, 2], [5, 6], 7)
     for w in range(4):
         assert L.orc_stream_u(5, 6, 2, 9, 7, 12 + w) == L.orc_u01(o[w])
 
