@@ -229,40 +229,51 @@ __global__ __launch_bounds__(WT_BLOCK) void wt_down_kernel(WtParams p, int it, i
 
 // One branch for the 64 replicas of a tile: resamplebranchstates :264-308, shortener :44-73 (shortenerbf :997-1030),
 // virtual jumps sampleabranch :391-410, dwell sums updatedwelltimes :745-757.  The two-flat-pass scheme of phm_tiles.hip;
-// the states of the merged segments live in LDS (a byte per segment and lane), transition counts and dwell sums go
-// straight to the tile's accumulators (integer atomics: exact in any order).
-template <bool KS>
+// the states of the merged segments live in LDS (a byte per segment and lane), transition counts go straight to the tile's
+// counters (integer atomics: exact in any order).  The four waves of a workgroup walk four groups of branches of the SAME
+// tile.  SMALL (n <= 32): the rows of B sit in LDS and the dwell sums of the workgroup are collected in one LDS table
+// (64-bit fixed point, ds_add_u64) that is handed to the tile's accumulators once, as coalesced rows -- a scattered atomic
+// leaves L2 as a 64-byte request of its own, and at one per merged segment they were a quarter of the kernel's HBM traffic
+// on C5 (profiles/r02_pmc_C5_summary_v2.json).  Larger n: B rows through L1/L2 (30 KB of LDS would halve the occupancy).
+template <bool KS, bool SMALL>
 __global__ __launch_bounds__(WT_BLOCK) void wt_branch_kernel(WtParams p, int it) {
-  extern __shared__ __align__(16) double s_B2[];                    // [n][ldt] dense rows of the forward draws
+  extern __shared__ __align__(16) unsigned char s_dyn[];            // SMALL: [n][ldt] rows of B, then [n][64] dwell sums (u64)
   __shared__ uint8_t s_ms_all[(WT_BLOCK / 64) * 64 * 64];           // [wave][segment][lane]
   __shared__ double s_scale[64];
   __shared__ __align__(16) double s_ltab[2 * PHM_LOGTAB_N];        // (1/c_j, log c_j) of the exponential variates (neglog_u32)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int item = blockIdx.x * (WT_BLOCK / 64) + wave;
   const uint32_t lane8 = (uint32_t)lane * 8u;
   const int n = p.n_states, ldt = p.ldt;
+  double* s_B2 = reinterpret_cast<double*>(s_dyn);
+  unsigned long long* s_dw = reinterpret_cast<unsigned long long*>(s_dyn + sizeof(double) * (size_t)n * ldt);
   for (int i = threadIdx.x; i < 2 * PHM_LOGTAB_N; i += WT_BLOCK) s_ltab[i] = logtab_entry(i);
   if ((int)threadIdx.x < n) s_scale[threadIdx.x] = p.scale[threadIdx.x];
-  for (int i = threadIdx.x; i < n * ldt; i += WT_BLOCK) s_B2[i] = p.B2[i];
+  if (SMALL) {
+    for (int i = threadIdx.x; i < n * ldt; i += WT_BLOCK) s_B2[i] = p.B2[i];
+    for (int i = threadIdx.x; i < n * 64; i += WT_BLOCK) s_dw[i] = 0ull;
+  }
   __syncthreads();
-  if (item >= p.n_groups * p.n_tiles) return;        // whole waves only; no barrier below this line
-  const int tile = item % p.n_tiles;
-  const int grp = item / p.n_tiles;
+  const int tile = blockIdx.x % p.n_tiles;
+  const int grp = (blockIdx.x / p.n_tiles) * (WT_BLOCK / 64) + wave;
+  const bool active = grp < p.n_groups;              // wave-uniform; every wave reaches the barrier at the end
+  const double* __restrict__ Brows = SMALL ? s_B2 : p.B2;
   uint8_t* s_ms = s_ms_all + wave * 64 * 64 + lane;
   const uint32_t rep = (uint32_t)(p.replica_offset + tile * 64 + lane);
   const bool valid = tile * 64 + lane < p.n_rep;
   uint16_t* __restrict__ mct = p.mcount + (size_t)tile * p.n_edge * 64;
   uint32_t* gc = p.cnt + ((size_t)tile * n * n) * 64 + lane;
-  unsigned long long* gdw = p.dwfx + ((size_t)tile * n) * 64 + lane;
+  unsigned long long* gdw = p.dwfx + ((size_t)tile * n) * 64;
   uint32_t err = 0;
   uint32_t segs = 0;
   auto add_dwell = [&](int s, double len) {                                    // updatedwelltimes :752, per merged segment
-    atomicAdd(gdw + s * 64, (unsigned long long)__double2ll_rn(len * p.fx_scale));
+    const unsigned long long v = (unsigned long long)__double2ll_rn(len * p.fx_scale);
+    if (SMALL) atomicAdd(s_dw + s * 64 + lane, v); else atomicAdd(gdw + s * 64 + lane, v);
   };
   auto count = [&](int a, int c) {                                             // shortener :65-66 / shortenerbf :1010-1014
     atomicAdd(gc + (KS ? a * n + c : a * (n - 1) + (c > a ? c - 1 : c)) * 64, 1u);
   };
+  if (active) {
   const int q1 = min((grp + 1) * p.group, p.n_edge);
   for (int q = grp * p.group; q < q1; ++q) {
   const int b = p.branch_order[q];
@@ -289,24 +300,34 @@ __global__ __launch_bounds__(WT_BLOCK) void wt_branch_kernel(WtParams p, int it)
     // very sums a first pass would (totL), so one pass decides -- the running sum against u * total, two states per
     // 16-byte read (beta: the lane's own table row through L1/L2; B row: LDS), until every lane has found its state.
     const double2* __restrict__ beta = reinterpret_cast<const double2*>(p.colL + ((size_t)kk * n + cs) * ldt);
-    const double2* __restrict__ brow = reinterpret_cast<const double2*>(s_B2 + sprev * ldt);
+    const double2* __restrict__ brow = reinterpret_cast<const double2*>(Brows + sprev * ldt);
     const double total = p.totL[((size_t)kk * n + sprev) * ldt + cs];
     if (!(total > 0.0) || isinf(total)) err |= DERR_ZERO_PROB;
     const double thr = u01(word) * total;
     double cum = 0.0;
     int idx = 0;
-    for (int c2 = 0; 2 * c2 < n - 1; ++c2) {           // comparisons at states 0 .. n-2 decide (sample_cat)
-      const double2 bt = beta[c2], br = brow[c2];
-      cum += br.x * bt.x;
-      const bool past0 = !(thr <= cum);
-      idx += past0 ? 1 : 0;
-      bool past1 = false;
-      if (2 * c2 + 1 < n - 1) {
-        cum += br.y * bt.y;
-        past1 = !(thr <= cum);
-        idx += past1 ? 1 : 0;
+    // comparisons at states 0 .. n-2 decide (sample_cat).  Eight states per round: the four 16-byte reads of each row are
+    // issued together (memory-level parallelism: the walk is latency-bound), then the running sum is carried through them.
+    for (int c0 = 0; 2 * c0 < n - 1; c0 += 4) {
+      double2 bt[4], br[4];
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const bool ok = 2 * (c0 + q4) < n - 1;
+        bt[q4] = ok ? beta[c0 + q4] : double2{0.0, 0.0};
+        br[q4] = ok ? brow[c0 + q4] : double2{0.0, 0.0};
       }
-      if ((c2 & 3) == 3 && !__any(past0 || past1)) break;
+      bool past = false;
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int c = 2 * (c0 + q4);
+        cum += br[q4].x * bt[q4].x;                  // a padding term is +0: the sum keeps its bits
+        past = (c < n - 1) && !(thr <= cum);
+        idx += past ? 1 : 0;
+        cum += br[q4].y * bt[q4].y;
+        past = (c + 1 < n - 1) && !(thr <= cum);
+        idx += past ? 1 : 0;
+      }
+      if (!__any(past)) break;                       // partial sums only grow: every lane of the wave has found its state
     }
     return idx;
   };
@@ -426,10 +447,18 @@ __global__ __launch_bounds__(WT_BLOCK) void wt_branch_kernel(WtParams p, int it)
   mct[b * 64 + lane] = (uint16_t)mnew;
   if (valid) segs += (uint32_t)(m + mnew);
   }      // next branch of the group
+  }      // active
 
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) segs += __shfl_xor(segs, off, 64);
-  if (lane == 0) atomicAdd(p.segacc + (size_t)tile * 64 + (grp & 63), (unsigned long long)segs);
+  if (lane == 0 && active) atomicAdd(p.segacc + (size_t)tile * 64 + (grp & 63), (unsigned long long)segs);
+  if (SMALL) {                                       // the workgroup's dwell sums -> the tile's accumulators, row by row
+    __syncthreads();
+    for (int i = threadIdx.x; i < n * 64; i += WT_BLOCK) {
+      const unsigned long long v = s_dw[i];
+      if (v) atomicAdd(gdw + i, v);
+    }
+  }
   if (err) atomicOr(p.err, err);
 }
 
@@ -514,9 +543,18 @@ hipError_t launch_wtiles_sweep(const WtParams& p, const std::vector<int32_t>& up
     else hipLaunchKernelGGL(wt_down_kernel<4>, g, dim3(WT_BLOCK), 0, stream, p, it, down_off[l], down_off[l + 1]);
   }
   mark(2);
-  const size_t lds_b2 = sizeof(double) * (size_t)p.n_states * p.ldt;
-  if (p.ks) hipLaunchKernelGGL((wt_branch_kernel<true>), blocks((int64_t)p.n_groups * p.n_tiles), dim3(WT_BLOCK), lds_b2, stream, p, it);
-  else hipLaunchKernelGGL((wt_branch_kernel<false>), blocks((int64_t)p.n_groups * p.n_tiles), dim3(WT_BLOCK), lds_b2, stream, p, it);
+  {
+    const bool small = p.n_states <= 32;
+    const size_t lds = small ? sizeof(double) * (size_t)p.n_states * p.ldt + sizeof(unsigned long long) * (size_t)p.n_states * 64 : 0;
+    const dim3 g((unsigned)(((int64_t)p.n_groups + WPB - 1) / WPB * p.n_tiles));
+    if (p.ks) {
+      if (small) hipLaunchKernelGGL((wt_branch_kernel<true, true>), g, dim3(WT_BLOCK), lds, stream, p, it);
+      else hipLaunchKernelGGL((wt_branch_kernel<true, false>), g, dim3(WT_BLOCK), lds, stream, p, it);
+    } else {
+      if (small) hipLaunchKernelGGL((wt_branch_kernel<false, true>), g, dim3(WT_BLOCK), lds, stream, p, it);
+      else hipLaunchKernelGGL((wt_branch_kernel<false, false>), g, dim3(WT_BLOCK), lds, stream, p, it);
+    }
+  }
   mark(3);
   const int ncnt = p.ks ? p.n_states * p.n_states : p.n_states * (p.n_states - 1);
   const int dcols = p.n_states + ncnt + (p.ks ? 1 : 0);
