@@ -11,7 +11,8 @@
 // registers for the whole launch and a 16-replica block of vectors as the B operand; an accumulator tile IS the next
 // step's B-operand slice (row = 4 * reg-block + lane group), so a chain never leaves the register file, and each replica
 // keeps the product of its own step m - 1 (segment counts differ per replica).
-//   up     : one launch per HEIGHT level, a wave per (node, tile, 16-replica block)         makePLrcpp* :503-529   [MFMA]
+//   up     : one launch per HEIGHT level, a wave per (node, tile): four 16-replica MFMA blocks,   makePLrcpp* :503-529   [MFMA]
+//            replicas dealt to the blocks in the order of their chain lengths
 //   root   : a wave per tile                                                               :618-627
 //   down   : one launch per DEPTH level, a wave per (tile, edge)                           :640-657, :460-475
 //   branch : a wave per (tile, group of branches)                                          :264-413, :44-73, :745-757

@@ -40,10 +40,14 @@ __device__ __forceinline__ int sample_terms(int n, double u, Term term, uint32_t
 // ---------------------------------------------------------------------------------------------------------------------
 template <int MT>
 __global__ __launch_bounds__(WT_BLOCK) void wt_up_kernel(WtParams p, int begin, int end) {
-  constexpr int KS = 4 * MT;
+  constexpr int KS = 4 * MT, NP = 16 * MT;
+  extern __shared__ __align__(16) double s_scr_all[];  // [wave][NP][64]: the first child's vectors while the second child's chains run
+  __shared__ uint8_t s_perm_all[WT_BLOCK / 64][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lr = lane & 15, lk = lane >> 4;
   const int n = p.n_states, ldt = p.ldt;
+  double* s_scr = s_scr_all + (size_t)wave * NP * 64;
+  uint8_t* s_perm = s_perm_all[wave];
   double Af[MT][KS];                                   // the chain matrix as A-operand fragments, for the whole launch
 #pragma unroll
   for (int i = 0; i < MT; ++i)
@@ -53,88 +57,149 @@ __global__ __launch_bounds__(WT_BLOCK) void wt_up_kernel(WtParams p, int begin, 
       Af[i][s] = (row < n && k < n) ? p.Bc[row * n + k] : 0.0;
     }
   const int n_lvl = end - begin;
-  const int64_t items = (int64_t)n_lvl * p.n_tiles * 4;
+  const int64_t items = (int64_t)n_lvl * p.n_tiles;
+  const int ks_used = (n + 3) >> 2;                    // wave-uniform: fma(0, 0, acc) = acc, so the skipped steps change nothing
   uint32_t err = 0;
   for (int64_t item = (int64_t)blockIdx.x * (WT_BLOCK / 64) + wave; item < items; item += (int64_t)gridDim.x * (WT_BLOCK / 64)) {
-    const int nt = (int)(item & 3);
-    const int64_t q4 = item >> 2;
-    const int tile = (int)(q4 % p.n_tiles), li = (int)(q4 / p.n_tiles);
+    const int tile = (int)(item % p.n_tiles), li = (int)(item / p.n_tiles);
     const UpStep st = p.up[p.up_order[begin + li]];
-    const int j = 16 * nt + lr;                        // this lane's replica within the tile
     double* __restrict__ PLt = p.PL + (size_t)tile * p.n_node * n * 64;
     const uint16_t* __restrict__ mct = p.mcount + (size_t)tile * p.n_edge * 64;
     const uint8_t* __restrict__ tips_t = p.tips_per_replica ? p.tips + (size_t)tile * p.n_tips * 64 : p.tips;
-    d4_t R[2][MT];
+
+    // The 64 replicas of the tile are dealt to the four 16-column MFMA blocks in the order of their chain lengths
+    // (a block runs to the longest chain of its columns, so equal lengths side by side waste the fewest steps):
+    // s_perm[r] = the lane (replica) of rank r; returns this lane's own chain length.
+    auto sort_by_chain = [&](int edge) -> int {
+      const int k = (int)mct[edge * 64 + lane] - 1;
+      int rank = 0;
+      for (int t = 0; t < 64; ++t) {
+        const int kt = __builtin_amdgcn_readlane(k, t);
+        rank += (kt < k || (kt == k && t < lane)) ? 1 : 0;
+      }
+      s_perm[rank] = (uint8_t)lane;
+      return k;
+    };
+    // Bc^kj applied to the child's vectors of replica column j: kmax steps on the matrix cores, column j keeps step kj
+    auto chain = [&](int child, int j, int kj, d4_t (&R)[MT]) {
+      d4_t X[MT];
 #pragma unroll
-    for (int ch = 0; ch < 2; ++ch) {                   // ch 0: "first" = child[1] (:508); ch 1: "second" = child[0] (:509)
-      const int child = st.child[1 - ch], edge = st.edge[1 - ch];
-      int k = (int)mct[edge * 64 + j] - 1;
-      if (child < 0) {                                 // tip: a row of the chain table (the chain run from a unit vector)
-        const int tip = ~child;
-        const int ts = p.tips_per_replica ? tips_t[tip * 64 + j] : p.tips[tip];
-        if (k >= p.klong) { err |= DERR_CAPACITY; k = p.klong - 1; }
-        const double* __restrict__ src = p.tip_masks ? p.maskL + ((size_t)k * 2 + (ts & 1)) * ldt : p.colL + ((size_t)k * n + ts) * ldt;
+      for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+        for (int q = 0; q < 4; ++q) {
+          const int row = 16 * i + lk + 4 * q;
+          X[i][q] = (row < n) ? PLt[((size_t)child * n + row) * 64 + j] : 0.0;
+        }
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int row = 16 * i + lk + 4 * q;
-            R[ch][i][q] = (row < n) ? src[row] : 0.0;
-          }
-      } else {                                         // internal child: the chain itself, on the matrix cores
-        d4_t X[MT];
+      for (int i = 0; i < MT; ++i) R[i] = X[i];
+      const int kmax = wave_max_count(kj);
+      for (int step = 1; step <= kmax; ++step) {
+        d4_t Y[MT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < MT; ++i) {
+          d4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int row = 16 * i + lk + 4 * q;
-            X[i][q] = (row < n) ? PLt[((size_t)child * n + row) * 64 + j] : 0.0;
-          }
+          for (int s = 0; s < KS; ++s)                 // k-steps whose four input states are all >= n multiply zeros: skipped
+            if (s < ks_used) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Af[i][s], X[s >> 2][s & 3], acc, 0, 0, 0);
+          Y[i] = acc;
+        }
+        const bool mine = (kj == step);
 #pragma unroll
-        for (int i = 0; i < MT; ++i) R[ch][i] = X[i];
-        const int kmax = wave_max_count(k);            // segment counts differ per replica: run to the longest, keep step k
-        for (int step = 1; step <= kmax; ++step) {
-          d4_t Y[MT];
+        for (int i = 0; i < MT; ++i) {
+          X[i] = Y[i];
 #pragma unroll
-          for (int i = 0; i < MT; ++i) {
-            d4_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Af[i][s], X[s >> 2][s & 3], acc, 0, 0, 0);
-            Y[i] = acc;
-          }
-          const bool mine = (k == step);
-#pragma unroll
-          for (int i = 0; i < MT; ++i) {
-            X[i] = Y[i];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) R[ch][i][q] = mine ? Y[i][q] : R[ch][i][q];
-          }
+          for (int q = 0; q < 4; ++q) R[i][q] = mine ? Y[i][q] : R[i][q];
         }
       }
-    }
-    d4_t P[MT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) P[i] = R[0][i] * R[1][i];                     // :510
-    if (p.normalise) {                                                         // :525
-      double t = 0.0;                                  // states lk, lk + 4, lk + 8, ... ascending: partial sum t_lk
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) t += P[i][q];
-      t = t + __shfl_xor(t, 16, 64);                   // t_0 + t_1 | t_2 + t_3
-      t = t + __shfl_xor(t, 32, 64);                   // (t_0 + t_1) + (t_2 + t_3)
+    };
+    // a tip child: a row of the chain table (the chain run from a unit vector / the parity mask)
+    auto tipvec = [&](int child, int edge, int j, d4_t (&R)[MT]) {
+      const int tip = ~child;
+      const int ts = p.tips_per_replica ? tips_t[tip * 64 + j] : p.tips[tip];
+      int k = (int)mct[edge * 64 + j] - 1;
+      if (k >= p.klong) { err |= DERR_CAPACITY; k = p.klong - 1; }
+      const double* __restrict__ src = p.tip_masks ? p.maskL + ((size_t)k * 2 + (ts & 1)) * ldt : p.colL + ((size_t)k * n + ts) * ldt;
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) P[i][q] = P[i][q] / t;
-    }
+        for (int q = 0; q < 4; ++q) {
+          const int row = 16 * i + lk + 4 * q;
+          R[i][q] = (row < n) ? src[row] : 0.0;
+        }
+    };
+    // PL[parent] = first (.) second (:510), / sum (:525), for replica column j
+    auto finish = [&](int j, const d4_t (&R0)[MT], const d4_t (&R1)[MT]) {
+      d4_t P[MT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+      for (int i = 0; i < MT; ++i) P[i] = R0[i] * R1[i];
+      if (p.normalise) {
+        double t = 0.0;                                // states lk, lk + 4, lk + 8, ... ascending: partial sum t_lk
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int row = 16 * i + lk + 4 * q;
-        if (row < n) PLt[((size_t)st.parent * n + row) * 64 + j] = P[i][q];
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) t += P[i][q];
+        t = t + __shfl_xor(t, 16, 64);                 // t_0 + t_1 | t_2 + t_3
+        t = t + __shfl_xor(t, 32, 64);                 // (t_0 + t_1) + (t_2 + t_3)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) P[i][q] = P[i][q] / t;
       }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = 16 * i + lk + 4 * q;
+          if (row < n) PLt[((size_t)st.parent * n + row) * 64 + j] = P[i][q];
+        }
+    };
+
+    // "first" = child[1] (:508), "second" = child[0] (:509)
+    const bool int_first = st.child[1] >= 0, int_second = st.child[0] >= 0;
+    if (!int_first && !int_second) {
+      for (int nt = 0; nt < 4; ++nt) {
+        const int j = 16 * nt + lr;
+        d4_t R0[MT], R1[MT];
+        tipvec(st.child[1], st.edge[1], j, R0);
+        tipvec(st.child[0], st.edge[0], j, R1);
+        finish(j, R0, R1);
+      }
+    } else if (int_first != int_second) {
+      const int ci = int_first ? 1 : 0;                // the internal child
+      const int k = sort_by_chain(st.edge[ci]);
+      for (int nt = 0; nt < 4; ++nt) {
+        const int j = s_perm[16 * nt + lr];
+        const int kj = __shfl(k, j, 64);
+        d4_t Rc[MT], Rt[MT];
+        chain(st.child[ci], j, kj, Rc);
+        tipvec(st.child[1 - ci], st.edge[1 - ci], j, Rt);
+        if (int_first) finish(j, Rc, Rt); else finish(j, Rt, Rc);
+      }
+    } else {
+      const int k1 = sort_by_chain(st.edge[1]);
+      for (int nt = 0; nt < 4; ++nt) {
+        const int j = s_perm[16 * nt + lr];
+        const int kj = __shfl(k1, j, 64);
+        d4_t R0[MT];
+        chain(st.child[1], j, kj, R0);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) s_scr[(16 * i + lk + 4 * q) * 64 + j] = R0[i][q];
+      }
+      const int k0 = sort_by_chain(st.edge[0]);
+      for (int nt = 0; nt < 4; ++nt) {
+        const int j = s_perm[16 * nt + lr];
+        const int kj = __shfl(k0, j, 64);
+        d4_t R0[MT], R1[MT];
+        chain(st.child[0], j, kj, R1);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) R0[i][q] = s_scr[(16 * i + lk + 4 * q) * 64 + j];
+        finish(j, R0, R1);
+      }
+    }
   }
   if (err) atomicOr(p.err, err);
 }
@@ -502,12 +567,18 @@ __global__ __launch_bounds__(WT_BLOCK) void wt_stats_kernel(WtParams p, int it, 
 
 template <int MT>
 void launch_up_levels(const WtParams& p, const std::vector<int32_t>& up_off, hipStream_t stream) {
+  const size_t lds = sizeof(double) * (size_t)(WT_BLOCK / 64) * 16 * MT * 64;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wt_up_kernel<MT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
   for (size_t l = 0; l + 1 < up_off.size(); ++l) {
     const int cnt = up_off[l + 1] - up_off[l];
     if (cnt <= 0) continue;
-    const int64_t items = (int64_t)cnt * p.n_tiles * 4;
+    const int64_t items = (int64_t)cnt * p.n_tiles;    // a wave per (node, tile)
     const unsigned grid = (unsigned)std::min<int64_t>((items + 3) / 4, 2048);      // persistent waves: the matrix fragments load once
-    hipLaunchKernelGGL(wt_up_kernel<MT>, dim3(grid), dim3(WT_BLOCK), 0, stream, p, up_off[l], up_off[l + 1]);
+    hipLaunchKernelGGL(wt_up_kernel<MT>, dim3(grid), dim3(WT_BLOCK), lds, stream, p, up_off[l], up_off[l + 1]);
   }
 }
 
