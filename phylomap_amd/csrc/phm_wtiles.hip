@@ -80,9 +80,8 @@ __global__ __launch_bounds__(WT_BLOCK) void wt_up_kernel(WtParams p, int begin, 
       s_perm[rank] = (uint8_t)lane;
       return k;
     };
-    // Bc^kj applied to the child's vectors of replica column j: kmax steps on the matrix cores, column j keeps step kj
-    auto chain = [&](int child, int j, int kj, d4_t (&R)[MT]) {
-      d4_t X[MT];
+    // the child's vectors of replica column j as B-operand tiles
+    auto load_x = [&](int child, int j, d4_t (&X)[MT]) {
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -90,6 +89,9 @@ __global__ __launch_bounds__(WT_BLOCK) void wt_up_kernel(WtParams p, int begin, 
           const int row = 16 * i + lk + 4 * q;
           X[i][q] = (row < n) ? PLt[((size_t)child * n + row) * 64 + j] : 0.0;
         }
+    };
+    // Bc^kj applied to them: kmax steps on the matrix cores, column j keeps the product of step kj
+    auto run_chain = [&](d4_t (&X)[MT], int kj, d4_t (&R)[MT]) {
 #pragma unroll
       for (int i = 0; i < MT; ++i) R[i] = X[i];
       const int kmax = wave_max_count(kj);
@@ -165,39 +167,61 @@ __global__ __launch_bounds__(WT_BLOCK) void wt_up_kernel(WtParams p, int begin, 
         finish(j, R0, R1);
       }
     } else if (int_first != int_second) {
+      // One wave per SIMD (the fragments of Bc take 128 registers): nothing else hides a load, so the next block's vectors and
+      // this block's tip rows are requested BEFORE the chain of this block starts and arrive while the matrix cores run.
       const int ci = int_first ? 1 : 0;                // the internal child
       const int k = sort_by_chain(st.edge[ci]);
+      d4_t X[MT], Xn[MT];
+      int j = s_perm[lr];
+      load_x(st.child[ci], j, X);
       for (int nt = 0; nt < 4; ++nt) {
-        const int j = s_perm[16 * nt + lr];
         const int kj = __shfl(k, j, 64);
+        const int jn = (nt < 3) ? s_perm[16 * (nt + 1) + lr] : j;
+        if (nt < 3) load_x(st.child[ci], jn, Xn);
         d4_t Rc[MT], Rt[MT];
-        chain(st.child[ci], j, kj, Rc);
         tipvec(st.child[1 - ci], st.edge[1 - ci], j, Rt);
+        run_chain(X, kj, Rc);
         if (int_first) finish(j, Rc, Rt); else finish(j, Rt, Rc);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) X[i] = Xn[i];
+        j = jn;
       }
     } else {
       const int k1 = sort_by_chain(st.edge[1]);
+      d4_t X[MT], Xn[MT];
+      int j = s_perm[lr];
+      load_x(st.child[1], j, X);
       for (int nt = 0; nt < 4; ++nt) {
-        const int j = s_perm[16 * nt + lr];
         const int kj = __shfl(k1, j, 64);
+        const int jn = (nt < 3) ? s_perm[16 * (nt + 1) + lr] : j;
+        if (nt < 3) load_x(st.child[1], jn, Xn);
         d4_t R0[MT];
-        chain(st.child[1], j, kj, R0);
+        run_chain(X, kj, R0);
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int q = 0; q < 4; ++q) s_scr[(16 * i + lk + 4 * q) * 64 + j] = R0[i][q];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) X[i] = Xn[i];
+        j = jn;
       }
       const int k0 = sort_by_chain(st.edge[0]);
+      j = s_perm[lr];
+      load_x(st.child[0], j, X);
       for (int nt = 0; nt < 4; ++nt) {
-        const int j = s_perm[16 * nt + lr];
         const int kj = __shfl(k0, j, 64);
+        const int jn = (nt < 3) ? s_perm[16 * (nt + 1) + lr] : j;
+        if (nt < 3) load_x(st.child[0], jn, Xn);
         d4_t R0[MT], R1[MT];
-        chain(st.child[0], j, kj, R1);
+        run_chain(X, kj, R1);
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int q = 0; q < 4; ++q) R0[i][q] = s_scr[(16 * i + lk + 4 * q) * 64 + j];
         finish(j, R0, R1);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) X[i] = Xn[i];
+        j = jn;
       }
     }
   }
