@@ -120,7 +120,7 @@ __global__ __launch_bounds__(TILES_BLOCK) void tiles_down_kernel(TileParams<NS> 
 // One branch for the 64 replicas of a tile: resamplebranchstates :264-308, shortener :44-73 (shortenerbf :997-1030),
 // virtual jumps sampleabranch :391-410, dwell sums updatedwelltimes :745-757.
 template <int NS, bool KS>
-__global__ __launch_bounds__(TILES_BLOCK, 8) void tiles_branch_kernel(TileParams<NS> p, int it) {
+__global__ __launch_bounds__(TILES_BLOCK, KS ? 7 : 8) void tiles_branch_kernel(TileParams<NS> p, int it) {      // KS: NS*NS counters per lane -> 7 waves per SIMD
   constexpr int NCNT = KS ? NS * NS : NS * (NS - 1);
   __shared__ double s_dw_all[(TILES_BLOCK / 64) * NS * 64];
   __shared__ uint16_t s_cnt_all[(TILES_BLOCK / 64) * NCNT * 64];      // counts of ONE branch (<= 65 535 segments): 16 bits keep the block under 20 KB of LDS, 8 waves per SIMD

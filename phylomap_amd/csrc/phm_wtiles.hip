@@ -397,15 +397,15 @@ __global__ __launch_bounds__(WT_BLOCK) void wt_branch_kernel(WtParams p, int it)
     int idx = 0;
     // comparisons at states 0 .. n-2 decide (sample_cat).  Eight states per round: the four 16-byte reads of each row are
     // issued together (memory-level parallelism: the walk is latency-bound), then the running sum is carried through them.
+    bool past = true;                                  // this lane has not reached its state yet
     for (int c0 = 0; 2 * c0 < n - 1; c0 += 4) {
       double2 bt[4], br[4];
 #pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {
-        const bool ok = 2 * (c0 + q4) < n - 1;
+      for (int q4 = 0; q4 < 4; ++q4) {                 // a lane that has its state asks for nothing more (zeros keep its sum)
+        const bool ok = past && 2 * (c0 + q4) < n - 1;
         bt[q4] = ok ? beta[c0 + q4] : double2{0.0, 0.0};
         br[q4] = ok ? brow[c0 + q4] : double2{0.0, 0.0};
       }
-      bool past = false;
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {
         const int c = 2 * (c0 + q4);
