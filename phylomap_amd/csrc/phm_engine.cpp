@@ -102,19 +102,25 @@ int32_t upload_model(phm_engine* e) {
     HIPCHK(hipMemcpy(e->d_nw_rowL.p, rowp.data(), sizeof(double) * rowp.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(e->d_nw_maskL.p, maskp.data(), sizeof(double) * maskp.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(e->d_wt_B2.p, b2p.data(), sizeof(double) * b2p.size(), hipMemcpyHostToDevice));
-    {   // totals of the forward draws' probability vectors p_c = B2[s][c] * (Bc^k e_end)[c] (resamplebranchstates :301), summed
-        // exactly as the sampler sums them (left to right, unfused; this file is built with -ffp-contract=off)
-      std::vector<double> tot((size_t)ktab * n * ldt, 0.0);
+    {   // running sums of the forward draws' probability vectors p_c = B2[s][c] * (Bc^k e_end)[c] (resamplebranchstates :301),
+        // added exactly as the sampler adds them (left to right, unfused; this file is built with -ffp-contract=off); every
+        // eighth one is kept, and the total
+      const int nb = e->pwt.nblk, ldb = e->pwt.ldb;
+      std::vector<double> blk((size_t)ktab * n * n * ldb, 0.0);
       for (int k = 0; k < ktab; ++k)
         for (int sp = 0; sp < n; ++sp)
           for (int en = 0; en < n; ++en) {
             const double* beta = &col[((size_t)k * n + en) * n];
             const double* brow = &e->hB2[(size_t)sp * n];
+            double* out = &blk[(((size_t)k * n + sp) * n + en) * ldb];
             double t = brow[0] * beta[0];
-            for (int c = 1; c < n; ++c) t += brow[c] * beta[c];
-            tot[((size_t)k * n + sp) * ldt + en] = t;
+            for (int c = 1; c < n; ++c) {
+              if ((c & 7) == 0) out[(c >> 3) - 1] = t;      // the sum after state c - 1 = 8q + 7
+              t += brow[c] * beta[c];
+            }
+            out[nb - 1] = t;
           }
-      HIPCHK(hipMemcpy(e->d_wt_totL.p, tot.data(), sizeof(double) * tot.size(), hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(e->d_wt_totL.p, blk.data(), sizeof(double) * blk.size(), hipMemcpyHostToDevice));
     }
     HIPCHK(hipMemcpy(e->d_Bc.p, e->hBc.data(), sizeof(double) * n * n, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(e->d_scale.p, e->hscale.data(), sizeof(double) * n, hipMemcpyHostToDevice));
@@ -566,7 +572,8 @@ int32_t wtiles_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
   HIPCHK(e->d_nw_colL.alloc(sizeof(double) * tab)); HIPCHK(e->d_nw_rowL.alloc(sizeof(double) * tab));
   HIPCHK(e->d_nw_maskL.alloc(sizeof(double) * (size_t)e->nw_klong * 2 * ldt));
   HIPCHK(e->d_wt_B2.alloc(sizeof(double) * (size_t)n * ldt)); HIPCHK(e->d_Bc.alloc(sizeof(double) * n * n));
-  HIPCHK(e->d_wt_totL.alloc(sizeof(double) * tab));
+  const int nblk = (n + 7) / 8, ldb = (nblk + 1) & ~1;
+  HIPCHK(e->d_wt_totL.alloc(sizeof(double) * (size_t)e->nw_klong * n * n * ldb));
   HIPCHK(e->d_scale.alloc(sizeof(double) * n)); HIPCHK(e->d_pid.alloc(sizeof(double) * n));
   HIPCHK(hipMemcpy(e->d_pid.p, e->hpid.data(), e->d_pid.bytes, hipMemcpyHostToDevice));
   HIPCHK(e->d_tips.alloc(e->tips_host.size()));
@@ -627,7 +634,7 @@ int32_t wtiles_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
   p.up_order = e->d_nw_up_order.as<int32_t>(); p.down_order = e->d_nw_down_order.as<int32_t>();
   p.branch_order = e->d_nw_border.as<int32_t>(); p.slot = e->d_tl_slot.as<int32_t>();
   p.colL = e->d_nw_colL.as<double>(); p.rowL = e->d_nw_rowL.as<double>(); p.maskL = e->d_nw_maskL.as<double>();
-  p.totL = e->d_wt_totL.as<double>();
+  p.blkL = e->d_wt_totL.as<double>(); p.nblk = nblk; p.ldb = ldb;
   p.tips = e->d_tips.as<uint8_t>(); p.mcount = e->d_mcount.as<uint16_t>();
   p.dw[0] = e->d_dw0.as<double>(); p.dw[1] = e->d_dw1.as<double>();
   p.estate = e->d_tl_estate.as<uint16_t>(); p.PL = e->d_PL.as<double>(); p.nstate = e->d_nstate.as<uint8_t>();

@@ -58,8 +58,10 @@ struct WtParams {
   const double* colL;                        // [klong][n][ldt]  (Bc^k e_j)[r]
   const double* rowL;                        // [klong][n][ldt]  ((Bc^T)^k e_j)[c]
   const double* maskL;                       // [klong][2][ldt]
-  const double* totL;                        // [klong][n][ldt]  totL[k][s][e] = sum_c B2[s][c] * colL[k][e][c], left to right, unfused:
-                                             //                  the total of the forward draw's probability vector (:301)
+  const double* blkL;                        // [klong][n s_prev][n end][ldb]: every eighth running sum of the forward draw's probability
+                                             //   vector p_c = B2[s][c] * colL[k][e][c] (left to right, unfused): entry q < nblk-1 = the sum
+                                             //   after state 8q+7, entry nblk-1 = the total (:301)
+  int32_t nblk, ldb;                         // ceil(n / 8); row stride of blkL (nblk rounded up to even: 16-byte reads)
   const uint8_t* tips;                       // [n_tips] or [tile][n_tips][64]
   uint16_t* mcount;                          // [tile][n_edge][64]
   double* dw[2];                             // [tile][rows][64]; sweep `it` reads dw[it & 1], writes the other

@@ -385,38 +385,51 @@ __global__ __launch_bounds__(WT_BLOCK) void wt_branch_kernel(WtParams p, int it)
   auto draw_state_w = [&](int i, int sprev, uint32_t word) -> int {
     int kk = m - i - 1;
     if (kk >= p.klong) { err |= DERR_CAPACITY; kk = p.klong - 1; }
-    // The total of the probability vector is a function of (kk, s_{i-1}, end state) alone: the host has formed it with the
-    // very sums a first pass would (totL), so one pass decides -- the running sum against u * total, two states per
-    // 16-byte read (beta: the lane's own table row through L1/L2; B row: LDS), until every lane has found its state.
-    const double2* __restrict__ beta = reinterpret_cast<const double2*>(p.colL + ((size_t)kk * n + cs) * ldt);
-    const double2* __restrict__ brow = reinterpret_cast<const double2*>(Brows + sprev * ldt);
-    const double total = p.totL[((size_t)kk * n + sprev) * ldt + cs];
+    // The running sums of the probability vector p_c = B[s_prev][c] (B^kk e_end)[c] are a function of (kk, s_prev, end) alone.
+    // The host has formed them with the sampler's own unfused left-to-right additions and keeps every eighth one (blkL: the sum
+    // after states 7, 15, ..., and the total): the lane finds the block of eight states its threshold falls into from that one
+    // cache line, takes the running sum at the block's start from it and walks the eight states of that block only -- the same
+    // partial sums, hence the same state, as the full scan, for 12 instead of ~35 table reads at 61 states.
+    const int nb = p.nblk;                                                     // ceil(n / 8)
+    const double* __restrict__ blk = p.blkL + (((size_t)kk * n + sprev) * n + cs) * p.ldb;
+    double e[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      double2 v = {0.0, 0.0};
+      if (2 * q < nb) v = reinterpret_cast<const double2*>(blk)[q];
+      e[2 * q] = v.x; e[2 * q + 1] = v.y;
+    }
+    double total = e[0];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) total = (q == nb - 1) ? e[q] : total;          // the last kept sum is the total
     if (!(total > 0.0) || isinf(total)) err |= DERR_ZERO_PROB;
     const double thr = u01(word) * total;
+    int b0 = 0;
     double cum = 0.0;
-    int idx = 0;
-    // comparisons at states 0 .. n-2 decide (sample_cat).  Eight states per round: the four 16-byte reads of each row are
-    // issued together (memory-level parallelism: the walk is latency-bound), then the running sum is carried through them.
-    bool past = true;                                  // this lane has not reached its state yet
-    for (int c0 = 0; 2 * c0 < n - 1; c0 += 4) {
-      double2 bt[4], br[4];
 #pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {                 // a lane that has its state asks for nothing more (zeros keep its sum)
-        const bool ok = past && 2 * (c0 + q4) < n - 1;
-        bt[q4] = ok ? beta[c0 + q4] : double2{0.0, 0.0};
-        br[q4] = ok ? brow[c0 + q4] : double2{0.0, 0.0};
-      }
+    for (int q = 0; q < 7; ++q) {                                              // running sums only grow: blocks wholly below thr
+      const bool below = (q < nb - 1) && !(thr <= e[q]);
+      b0 += below ? 1 : 0;
+      cum = below ? e[q] : cum;
+    }
+    const int c0 = 8 * b0;
+    const double2* __restrict__ beta = reinterpret_cast<const double2*>(p.colL + ((size_t)kk * n + cs) * ldt + c0);
+    const double2* __restrict__ brow = reinterpret_cast<const double2*>(Brows + sprev * ldt + c0);
+    double2 bt[4], br[4];
 #pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {
-        const int c = 2 * (c0 + q4);
-        cum += br[q4].x * bt[q4].x;                  // a padding term is +0: the sum keeps its bits
-        past = (c < n - 1) && !(thr <= cum);
-        idx += past ? 1 : 0;
-        cum += br[q4].y * bt[q4].y;
-        past = (c + 1 < n - 1) && !(thr <= cum);
-        idx += past ? 1 : 0;
-      }
-      if (!__any(past)) break;                       // partial sums only grow: every lane of the wave has found its state
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const bool ok = c0 + 2 * q4 < n - 1;
+      bt[q4] = ok ? beta[q4] : double2{0.0, 0.0};
+      br[q4] = ok ? brow[q4] : double2{0.0, 0.0};
+    }
+    int idx = c0;
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {                                           // comparisons at states 0 .. n-2 decide (sample_cat)
+      const int c = c0 + 2 * q4;
+      cum += br[q4].x * bt[q4].x;                      // a padding term is +0: the sum keeps its bits
+      idx += ((c < n - 1) && !(thr <= cum)) ? 1 : 0;
+      cum += br[q4].y * bt[q4].y;
+      idx += ((c + 1 < n - 1) && !(thr <= cum)) ? 1 : 0;
     }
     return idx;
   };
