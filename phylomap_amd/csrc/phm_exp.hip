@@ -634,7 +634,8 @@ __global__ __launch_bounds__(256) void expm_pade_mfma_kernel(int n, const double
   double* sD = reinterpret_cast<double*>(smem);                  // [64][PADE_LDP]
   double* sE = sD + 64 * PADE_LDP;                               // [64][PADE_LDP]  (E, then the solution Y)
   __shared__ double fv[64];
-  __shared__ int s_piv;
+  __shared__ int s_piv, s_bad;
+  __shared__ double sCol[64 * 17], sA[16 * 17], sW[16 * 17];      // block Gauss-Jordan: a column block of D, the diagonal block, its inverse
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, tid = threadIdx.x;
   const int rb = (n + 15) >> 4;
   const int lr = lane & 15, lk = lane >> 4;
@@ -699,7 +700,103 @@ __global__ __launch_bounds__(256) void expm_pade_mfma_kernel(int n, const double
     }
     __syncthreads();
 
-    // ---- solve D Y = E in LDS: elimination with partial pivoting, then column-oriented back substitution ----
+    // ---- solve D Y = E, fast path: block Gauss-Jordan, 16 x 16 blocks, on the matrix cores --------------------------------
+    // D = I -+ A/2 + ... of a scaled A is close to the identity, so its 16 x 16 diagonal blocks can be inverted without row
+    // exchanges; a pivot below 1e-3 (a badly scaled input) abandons the fast path for the pivoted elimination in LDS below.
+    // Step k: wave k publishes its column block of D, inverts the diagonal block (Gauss-Jordan in LDS, one wave) -> W; every
+    // wave multiplies row block k of ITS column blocks of D and E by W (the result tile is a B-operand slice as it stands) and
+    // subtracts D_ik times that from every other row block i -- all in registers, three barriers per step instead of five per
+    // COLUMN.  After the last step E holds Y.
+    if (tid == 0) s_bad = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                      // unrolled: the register tiles are indexed by k
+      if (k >= rb) continue;                           // uniform over the workgroup (the barriers below are too)
+      if (w == k) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) sCol[(16 * i + lk + 4 * q) * 17 + lr] = Dm[i][q];
+      }
+      __syncthreads();
+      if (w == k) {                                    // invert D_kk: lane = (row r, four columns 4 cg .. 4 cg + 3)
+        const int r = lane & 15, cg = lane >> 4;
+        double a[4], wv[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          a[c] = sCol[(16 * k + r) * 17 + 4 * cg + c];
+          wv[c] = (r == 4 * cg + c) ? 1.0 : 0.0;
+          sA[r * 17 + 4 * cg + c] = a[c];
+          sW[r * 17 + 4 * cg + c] = wv[c];
+        }
+        bool bad = false;
+        for (int pv = 0; pv < 16; ++pv) {
+          const double piv = sA[pv * 17 + pv];
+          if (!(fabs(piv) >= 1e-3)) bad = true;
+          const double inv = 1.0 / piv;
+          const double f = sA[r * 17 + pv];
+          double pa[4], pw[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) { pa[c] = sA[pv * 17 + 4 * cg + c] * inv; pw[c] = sW[pv * 17 + 4 * cg + c] * inv; }
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            a[c] = (r == pv) ? pa[c] : a[c] - f * pa[c];
+            wv[c] = (r == pv) ? pw[c] : wv[c] - f * pw[c];
+            sA[r * 17 + 4 * cg + c] = a[c];
+            sW[r * 17 + 4 * cg + c] = wv[c];
+          }
+        }
+        if (bad) s_bad = 1;
+      }
+      __syncthreads();
+      if (w < rb) {
+        double aW[4];
+#pragma unroll
+        for (int sI = 0; sI < 4; ++sI) aW[sI] = sW[lr * 17 + 4 * sI + lk];
+        if (w > k) {
+          d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int sI = 0; sI < 4; ++sI) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aW[sI], Dm[k][sI], acc, 0, 0, 0);
+          Dm[k] = acc;
+        }
+        {
+          d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int sI = 0; sI < 4; ++sI) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aW[sI], Em[k][sI], acc, 0, 0, 0);
+          Em[k] = acc;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (i != k && i < rb) {
+            double aD[4];
+#pragma unroll
+            for (int sI = 0; sI < 4; ++sI) aD[sI] = -sCol[(16 * i + lr) * 17 + 4 * sI + lk];
+            if (w > k) {
+              d4_t acc = Dm[i];
+#pragma unroll
+              for (int sI = 0; sI < 4; ++sI) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aD[sI], Dm[k][sI], acc, 0, 0, 0);
+              Dm[i] = acc;
+            }
+            d4_t acc = Em[i];
+#pragma unroll
+            for (int sI = 0; sI < 4; ++sI) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aD[sI], Em[k][sI], acc, 0, 0, 0);
+            Em[i] = acc;
+          }
+        }
+      }
+      __syncthreads();
+    }
+    const bool fallback = s_bad != 0;
+    if (!fallback) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sE[(16 * i + lk + 4 * q) * PADE_LDP + mycol] = Em[i][q];
+    }
+    __syncthreads();
+
+    // ---- solve D Y = E in LDS (fallback): elimination with partial pivoting, then column-oriented back substitution ----
+    if (fallback) {
     for (int col = 0; col < n; ++col) {
       if (w == 0) {
         double v = (lane >= col && lane < n) ? fabs(sD[lane * PADE_LDP + col]) : -1.0;
@@ -741,6 +838,7 @@ __global__ __launch_bounds__(256) void expm_pade_mfma_kernel(int n, const double
       }
       __syncthreads();
     }
+    }      // fallback
 
     // ---- s squarings: Y <- Y Y, operands re-read from LDS in A- and B-slice layouts ----
     for (int it = 0; it < s; ++it) {
