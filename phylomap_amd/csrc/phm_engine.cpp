@@ -122,6 +122,24 @@ int32_t upload_model(phm_engine* e) {
           }
       HIPCHK(hipMemcpy(e->d_wt_totL.p, blk.data(), sizeof(double) * blk.size(), hipMemcpyHostToDevice));
     }
+    {   // transitions that can occur at all: a -> c with B2[a][c] != 0 (c != a unless self pairs are counted).  Few of them
+        // (a banded rate matrix) and n <= 32: the branch kernel counts them in LDS slots
+      const bool ks = ks_layout(e->variant);
+      std::vector<int16_t> pair_slot((size_t)n * n, (int16_t)-1);
+      std::vector<int32_t> slot_col;
+      for (int a = 0; a < n; ++a)
+        for (int c = 0; c < n; ++c)
+          if ((ks || a != c) && e->hB2[(size_t)a * n + c] != 0.0) {
+            pair_slot[(size_t)a * n + c] = (int16_t)slot_col.size();
+            slot_col.push_back(ks ? a * n + c : a * (n - 1) + (c > a ? c - 1 : c));
+          }
+      int n_slots = (int)slot_col.size();
+      if (n > 32 || n_slots > phm::WT_MAX_SLOTS) { n_slots = 0; std::fill(pair_slot.begin(), pair_slot.end(), (int16_t)-1); }
+      slot_col.resize(phm::WT_MAX_SLOTS, 0);
+      e->pwt.n_slots = n_slots;
+      HIPCHK(hipMemcpy(e->d_wt_pair_slot.p, pair_slot.data(), sizeof(int16_t) * pair_slot.size(), hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(e->d_wt_slot_col.p, slot_col.data(), sizeof(int32_t) * slot_col.size(), hipMemcpyHostToDevice));
+    }
     HIPCHK(hipMemcpy(e->d_Bc.p, e->hBc.data(), sizeof(double) * n * n, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(e->d_scale.p, e->hscale.data(), sizeof(double) * n, hipMemcpyHostToDevice));
     return PHM_OK;
@@ -574,6 +592,7 @@ int32_t wtiles_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
   HIPCHK(e->d_wt_B2.alloc(sizeof(double) * (size_t)n * ldt)); HIPCHK(e->d_Bc.alloc(sizeof(double) * n * n));
   const int nblk = (n + 7) / 8, ldb = (nblk + 1) & ~1;
   HIPCHK(e->d_wt_totL.alloc(sizeof(double) * (size_t)e->nw_klong * n * n * ldb));
+  HIPCHK(e->d_wt_pair_slot.alloc(sizeof(int16_t) * (size_t)n * n)); HIPCHK(e->d_wt_slot_col.alloc(sizeof(int32_t) * phm::WT_MAX_SLOTS));
   HIPCHK(e->d_scale.alloc(sizeof(double) * n)); HIPCHK(e->d_pid.alloc(sizeof(double) * n));
   HIPCHK(hipMemcpy(e->d_pid.p, e->hpid.data(), e->d_pid.bytes, hipMemcpyHostToDevice));
   HIPCHK(e->d_tips.alloc(e->tips_host.size()));
@@ -635,6 +654,7 @@ int32_t wtiles_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
   p.branch_order = e->d_nw_border.as<int32_t>(); p.slot = e->d_tl_slot.as<int32_t>();
   p.colL = e->d_nw_colL.as<double>(); p.rowL = e->d_nw_rowL.as<double>(); p.maskL = e->d_nw_maskL.as<double>();
   p.blkL = e->d_wt_totL.as<double>(); p.nblk = nblk; p.ldb = ldb;
+  p.n_slots = 0; p.pair_slot = e->d_wt_pair_slot.as<int16_t>(); p.slot_col = e->d_wt_slot_col.as<int32_t>();
   p.tips = e->d_tips.as<uint8_t>(); p.mcount = e->d_mcount.as<uint16_t>();
   p.dw[0] = e->d_dw0.as<double>(); p.dw[1] = e->d_dw1.as<double>();
   p.estate = e->d_tl_estate.as<uint16_t>(); p.PL = e->d_PL.as<double>(); p.nstate = e->d_nstate.as<uint8_t>();

@@ -34,6 +34,7 @@
 namespace phm {
 
 constexpr int WT_BLOCK = 256;
+constexpr int WT_MAX_SLOTS = 96;        // possible transitions (non-zero entries of B) up to which the branch kernel counts in LDS
 
 struct WtParams {
   int32_t n_states, ldt;                     // ldt: row stride of the tables (n rounded up to even: 16-byte rows)
@@ -61,6 +62,9 @@ struct WtParams {
   const double* blkL;                        // [klong][n s_prev][n end][ldb]: every eighth running sum of the forward draw's probability
                                              //   vector p_c = B2[s][c] * colL[k][e][c] (left to right, unfused): entry q < nblk-1 = the sum
                                              //   after state 8q+7, entry nblk-1 = the total (:301)
+  int32_t n_slots;                           // n <= 32 and at most WT_MAX_SLOTS countable pairs (a, c) with B2[a][c] != 0: count in LDS; else 0
+  const int16_t* pair_slot;                  // [n*n] pair a*n+c -> slot, -1: none
+  const int32_t* slot_col;                   // [n_slots] slot -> counter column (the index the global counters use)
   int32_t nblk, ldb;                         // ceil(n / 8); row stride of blkL (nblk rounded up to even: 16-byte reads)
   const uint8_t* tips;                       // [n_tips] or [tile][n_tips][64]
   uint16_t* mcount;                          // [tile][n_edge][64]

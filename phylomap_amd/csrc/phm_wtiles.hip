@@ -336,11 +336,18 @@ __global__ __launch_bounds__(WT_BLOCK) void wt_branch_kernel(WtParams p, int it)
   const int n = p.n_states, ldt = p.ldt;
   double* s_B2 = reinterpret_cast<double*>(s_dyn);
   unsigned long long* s_dw = reinterpret_cast<unsigned long long*>(s_dyn + sizeof(double) * (size_t)n * ldt);
+  // SMALL with a sparse B (at most WT_MAX_SLOTS possible transitions, e.g. a banded rate matrix): the workgroup's transition
+  // counts too are collected in LDS, one 32-bit counter per (possible pair, lane), and handed over as coalesced rows
+  uint32_t* s_ct = reinterpret_cast<uint32_t*>(s_dw + (size_t)n * 64);           // [n_slots][64]
+  int16_t* s_slot = reinterpret_cast<int16_t*>(s_ct + (size_t)p.n_slots * 64);   // [n*n] pair -> slot, -1: none
+  const int n_slots = SMALL ? p.n_slots : 0;
   for (int i = threadIdx.x; i < 2 * PHM_LOGTAB_N; i += WT_BLOCK) s_ltab[i] = logtab_entry(i);
   if ((int)threadIdx.x < n) s_scale[threadIdx.x] = p.scale[threadIdx.x];
   if (SMALL) {
     for (int i = threadIdx.x; i < n * ldt; i += WT_BLOCK) s_B2[i] = p.B2[i];
     for (int i = threadIdx.x; i < n * 64; i += WT_BLOCK) s_dw[i] = 0ull;
+    for (int i = threadIdx.x; i < n_slots * 64; i += WT_BLOCK) s_ct[i] = 0u;
+    if (n_slots > 0) for (int i = threadIdx.x; i < n * n; i += WT_BLOCK) s_slot[i] = p.pair_slot[i];
   }
   __syncthreads();
   const int tile = blockIdx.x % p.n_tiles;
@@ -360,6 +367,10 @@ __global__ __launch_bounds__(WT_BLOCK) void wt_branch_kernel(WtParams p, int it)
     if (SMALL) atomicAdd(s_dw + s * 64 + lane, v); else atomicAdd(gdw + s * 64 + lane, v);
   };
   auto count = [&](int a, int c) {                                             // shortener :65-66 / shortenerbf :1010-1014
+    if (n_slots > 0) {
+      const int sl = s_slot[a * n + c];
+      if (sl >= 0) { atomicAdd(s_ct + sl * 64 + lane, 1u); return; }
+    }
     atomicAdd(gc + (KS ? a * n + c : a * (n - 1) + (c > a ? c - 1 : c)) * 64, 1u);
   };
   if (active) {
@@ -560,6 +571,10 @@ __global__ __launch_bounds__(WT_BLOCK) void wt_branch_kernel(WtParams p, int it)
       const unsigned long long v = s_dw[i];
       if (v) atomicAdd(gdw + i, v);
     }
+    for (int i = threadIdx.x; i < n_slots * 64; i += WT_BLOCK) {
+      const uint32_t v = s_ct[i];
+      if (v) atomicAdd(p.cnt + ((size_t)tile * n * n + p.slot_col[i >> 6]) * 64 + (i & 63), v);
+    }
   }
   if (err) atomicOr(p.err, err);
 }
@@ -653,7 +668,8 @@ hipError_t launch_wtiles_sweep(const WtParams& p, const std::vector<int32_t>& up
   mark(2);
   {
     const bool small = p.n_states <= 32;
-    const size_t lds = small ? sizeof(double) * (size_t)p.n_states * p.ldt + sizeof(unsigned long long) * (size_t)p.n_states * 64 : 0;
+    const size_t lds = small ? sizeof(double) * (size_t)p.n_states * p.ldt + sizeof(unsigned long long) * (size_t)p.n_states * 64 +
+                                   sizeof(uint32_t) * (size_t)p.n_slots * 64 + sizeof(int16_t) * (size_t)p.n_states * p.n_states + 16 : 0;
     const dim3 g((unsigned)(((int64_t)p.n_groups + WPB - 1) / WPB * p.n_tiles));
     if (p.ks) {
       if (small) hipLaunchKernelGGL((wt_branch_kernel<true, true>), g, dim3(WT_BLOCK), lds, stream, p, it);
