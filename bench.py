@@ -304,7 +304,7 @@ def main():
             plan[0] = (3, "tiles", 16384, 12, 6, 0)
         for c, mp, capS, k, w, sto in plan:
             z, Q, pid, Om = synth.config_problem(c)
-            Sx = sized_replicas(z, Q, pid, Om, mp, capS, frac=0.60, storage=sto)
+            Sx = sized_replicas(z, Q, pid, Om, mp, capS, frac=0.80, storage=sto)
             blk, _ = measure(c, mp, Sx, k, w, 0x5EED0000 + c, ipl=8, storage=sto)
             if c in cpu:
                 blk["cpu_baseline"] = cpu[c]
@@ -326,7 +326,7 @@ def main():
 
         # sumstatEXP (src/phylomap.cpp:3001-3051): C1 as stated, and the 1 000-tip 4-state tree with the rescaled pruning pass
         L = _lib.load()
-        for key, c, N, resc in (("EXP_C1", 1, 1 << 16, False), ("EXP_1000_tips", 2, 1 << 14, True)):
+        for key, c, N, resc in (("EXP_C1", 1, 1 << 16, False), ("EXP_1000_tips", 2, 1 << 16, True)):
             z, Q, pid, Om = synth.config_problem(c)
             n, E = Q.shape[0], z["edge"].shape[0]
             api.sumstatEXP(z, Q, pid, 64, seed=1, rescale=resc, device=local_rank)

@@ -7,7 +7,8 @@ published format (R Internals, "Serialization Formats"; version 2, XDR): gzip st
 one item = flags word (type in the low byte, has-attr / has-tag / is-object bits) followed by the payload.
 
 Supported items: NULL, symbols, pairlists (attributes), character / logical / integer / real vectors, generic
-vectors (lists) and back references.  R lists come back as ``dict`` (when named) or ``list``; atomic vectors as numpy
+vectors (lists), back references, and the ALTREP forms version-3 files use for ordinary vectors (compact integer / real
+sequences such as ``1:n``, wrapped vectors, deferred ``as.character`` of a number vector).  R lists come back as ``dict`` (when named) or ``list``; atomic vectors as numpy
 arrays; a ``dim`` attribute reshapes (column-major).  Names of atomic vectors are kept in ``RVector.names``.
 """
 from __future__ import annotations
@@ -17,7 +18,7 @@ import struct
 
 import numpy as np
 
-NILVALUE, REFSXP, GLOBALENV, EMPTYENV, BASEENV = 254, 255, 253, 242, 241
+NILVALUE, REFSXP, GLOBALENV, EMPTYENV, BASEENV, ALTREP_SXP = 254, 255, 253, 242, 241, 238
 SYMSXP, LISTSXP, CHARSXP, LGLSXP, INTSXP, REALSXP, STRSXP, VECSXP = 1, 2, 9, 10, 13, 14, 16, 19
 NA_INTEGER = -2147483648
 
@@ -70,6 +71,23 @@ class _Reader:
         if t == CHARSXP:
             n = self.int()
             return None if n == -1 else self.take(n).decode("utf-8", "replace")
+        if t == ALTREP_SXP:                            # version 3: info pairlist (class, package, type), state, attributes
+            info, state, attr = self.item(), self.item(), self.item()
+            cls = info[0][1] if info else None
+            attrs = dict(attr or [])
+            if cls in ("compact_intseq", "compact_realseq"):      # state = c(length, first, increment)
+                n, first, incr = (float(v) for v in np.asarray(state).reshape(-1)[:3])
+                val = first + incr * np.arange(int(n))
+                return _finish(val.astype(np.int32 if cls == "compact_intseq" else np.float64), attrs)
+            if cls in ("wrap_integer", "wrap_real", "wrap_logical", "wrap_string", "wrap_list", "wrap_complex", "wrap_raw"):
+                val = state[0] if isinstance(state, list) else state      # state = list(x, meta)
+                return _finish(val, attrs) if attrs else val
+            if cls == "deferred_string":                # state = (number vector . scientific flag): as.character(x), unevaluated
+                arg = state[0][1] if isinstance(state, list) and state and isinstance(state[0], tuple) else state
+                arr = np.asarray(arg).reshape(-1)
+                val = [str(int(v)) if float(v).is_integer() else repr(float(v)) for v in arr]
+                return _finish(val, attrs)
+            raise ValueError(f"unsupported ALTREP class {cls!r} (re-save with saveRDS(x, file, version = 2))")
         if t == LISTSXP:                               # pairlist: [attr] [tag] car cdr -> list of (tag, value)
             out = []
             while True:

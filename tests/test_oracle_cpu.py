@@ -480,6 +480,20 @@ def test_rds_reader_round_trip_of_hand_built_stream(tmp_path):
     np.testing.assert_array_equal(x["edge"], [[3, 1], [3, 2]])
     np.testing.assert_array_equal(x["maps"][0], [0.25, 0.5])
     assert x["maps"][0].names == ["1", "2"] and x["tip.label"] == ["a", "b"]
+    # version 3 with ALTREP items: a compact integer sequence 1:5, as R >= 3.5 writes `1:n`, and a deferred
+    # as.character(c(7, 8)); item = flags 238, info pairlist (class symbol, package symbol, type), state, attributes
+    def altrep(cls, state, type_code):
+        info = i32(2) + sym(cls) + i32(2) + sym("base") + i32(2) + (i32(13) + i32(1) + i32(type_code)) + i32(254)
+        return i32(238) + info + state + i32(254)
+    seq = altrep("compact_intseq", i32(14) + i32(3) + struct.pack(">ddd", 5.0, 1.0, 1.0), 13)
+    dstr = altrep("deferred_string", i32(2) + (i32(14) + i32(2) + struct.pack(">dd", 7.0, 8.0)) + i32(2) + (i32(13) + i32(1) + i32(0)) + i32(254), 16)
+    lst3 = i32(19 | 0x200) + i32(2) + seq + dstr + attrs([("names", strvec(["idx", "lab"]))])
+    enc = b"UTF-8"
+    path3 = tmp_path / "y.rds"
+    path3.write_bytes(b"X\n" + i32(3) + i32(0x040300) + i32(0x030500) + i32(len(enc)) + enc + lst3)
+    y = rds.read_rds(str(path3))
+    np.testing.assert_array_equal(y["idx"], [1, 2, 3, 4, 5])
+    assert y["idx"].dtype == np.int32 and y["lab"] == ["7", "8"]
 
 
 def test_exponential_variate_table_log_accuracy_and_agreement():
