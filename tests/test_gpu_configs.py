@@ -205,3 +205,30 @@ def test_exp_rescaled_pruning_at_c2_size_and_equal_to_plain_on_small_trees():
     assert rc == 0
     np.testing.assert_array_equal(got5[:, 20:], want5[:, 20:])
     np.testing.assert_allclose(got5[:, :20], want5[:, :20], rtol=1e-10, atol=0)
+
+
+@pytest.mark.parametrize("cfg,S", [(4, 1024), (5, 640)])
+def test_wide_lane_per_replica_mapping_with_many_tiles(cfg, S):
+    """phm_wtiles.hip beyond a couple of tiles: persistent pruning waves striding over (node, tile) items, branch groups per
+    workgroup, per-tile accumulators -- C4 / C5 at their stated sizes with 16 / 10 tiles, replicas from different tiles and
+    different 16-column MFMA blocks against the oracle, tree-length invariant on every replica and sweep."""
+    z, Q, pid, Omega, nen, nodelist, root = _config(cfg)
+    n = Q.shape[0]
+    N, seed = 6, 900 + cfg
+    eng = _lib.Engine(z, Q, pid, Omega, N, variant=_lib.PHM_MCMC_BIGTREE, seed=seed, n_replicas=S, mapping="tiles")
+    eng.run(N); eng.sync()
+    st = eng.stats(0, N)
+    for r in (0, 17, 64 + 33, S // 2 + 50, S - 1):
+        want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(n) + Q / Omega, Omega, nen, nodelist, root, N, variant=O.BIGTREE, seed=seed, replica=r)
+        assert rc == 0
+        _check_rows(st[r], want, n, False)
+    np.testing.assert_allclose(st[:, :, :n].sum(2), z["edge.length"].sum(), rtol=1e-11)
+    assert np.all(st[:, :, n:] == np.round(st[:, :, n:]))
+    # the reduced output (sum over replicas per sweep) equals the sum of the per-replica rows
+    red = _lib.Engine(z, Q, pid, Omega, N, variant=_lib.PHM_MCMC_BIGTREE, seed=seed, n_replicas=S, mapping="tiles", reduce=True)
+    red.run(N); red.sync()
+    tot = red.stats(0, N)
+    red.close()
+    eng.close()
+    np.testing.assert_array_equal(tot[:, n:], st.sum(0)[:, n:])
+    np.testing.assert_allclose(tot[:, :n], st.sum(0)[:, :n], rtol=1e-12)
