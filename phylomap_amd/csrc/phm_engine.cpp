@@ -17,7 +17,11 @@ namespace {
 // mapping (a single wave per tile, compact sequential streams) for the largest replica counts.
 constexpr int NARROW_AUTO_MAX_REPLICAS = 95;
 constexpr int TILES_AUTO_MAX_REPLICAS = 262144;
-constexpr int WBRANCH_AUTO_MAX_REPLICAS = 32;     // 5..64 states: up to here a wave per (replica, branch), beyond it lanes = replicas
+// 5..64 states: a wave per (replica, branch) (phm_wbranch.hip) exposes S x E waves whatever S is; the lane-per-replica mapping
+// (phm_wtiles.hip) needs whole tiles of 64 replicas and pays a fixed serial cost per tree level (one tile: 4.6 ms per sweep on
+// C4, 2.5 ms on C5).  Measured crossover (profiles/r02_probe_small_S_C{4,5}.log): about 60 replicas at 20 states, about 450 at
+// 61 states -- interpolated linearly in the state count.
+inline int wbranch_auto_max_replicas(int n) { return std::max(32, std::min(512, (int)(60.0 + 9.5 * (n - 20)))); }
 
 bool ks_layout(int v) { return v == PHM_MCMC_KS || v == PHM_MCMC_BF || v == PHM_MCMC_MT || v == PHM_MCMC_KSMT; }   // n x n counts, root column
 bool hidden_rates(int v) { return v == PHM_MCMC_KS || v == PHM_MCMC_KSMT; }                                         // parity tip masks
@@ -814,7 +818,7 @@ int32_t phm_engine_create_multi(const phm_tree* trees, int32_t n_trees, const ph
   const bool auto_map = o.reserved[1] == 0 && o.reserved[0] == 0;      // a ring / two-buffer request names the replica layout
   if ((o.reserved[1] == 2 || o.reserved[1] == 3) && n_trees != 1) return fail(PHM_ERR_UNSUPPORTED, "the branch-parallel mappings take a single tree");
   if (e->wide) {      // 5..64 states: lane = replica, wave per (tile, item) (phm_wtiles.hip); a handful of chains: wave per (replica, branch)
-    e->tiled = n_trees == 1 && (o.reserved[1] == 3 || (auto_map && e->S > WBRANCH_AUTO_MAX_REPLICAS));
+    e->tiled = n_trees == 1 && (o.reserved[1] == 3 || (auto_map && e->S > wbranch_auto_max_replicas(n)));
     e->narrow = n_trees == 1 && !e->tiled && (o.reserved[1] == 2 || auto_map);
   } else {
     e->narrow = small_n && (o.reserved[1] == 2 || (auto_map && e->S <= NARROW_AUTO_MAX_REPLICAS));
