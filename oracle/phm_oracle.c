@@ -292,7 +292,17 @@ static void matTvec(const double* M, const double* x, double* y, int n) {
  */
 static void mcmc_matvec(const double* M, const double* x, double* y, int n) {
   if (n <= 4) { matvec(M, x, y, n); return; }
-  for (int i = 0; i < n; ++i) {
+  int i = 0;
+  for (; i + 4 <= n; i += 4) {                     /* four rows side by side: independent chains, each in the spec's order */
+    const double *r0 = M + (size_t)i * n, *r1 = r0 + n, *r2 = r1 + n, *r3 = r2 + n;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (int j = 0; j < n; ++j) {
+      const double xj = x[j];
+      a0 = fma(r0[j], xj, a0); a1 = fma(r1[j], xj, a1); a2 = fma(r2[j], xj, a2); a3 = fma(r3[j], xj, a3);
+    }
+    y[i] = a0; y[i + 1] = a1; y[i + 2] = a2; y[i + 3] = a3;
+  }
+  for (; i < n; ++i) {
     double acc = 0.0;
     for (int j = 0; j < n; ++j) acc = fma(M[i * n + j], x[j], acc);
     y[i] = acc;
@@ -300,10 +310,11 @@ static void mcmc_matvec(const double* M, const double* x, double* y, int n) {
 }
 static void mcmc_matTvec(const double* M, const double* x, double* y, int n) {
   if (n <= 4) { matTvec(M, x, y, n); return; }
-  for (int c = 0; c < n; ++c) {
-    double acc = 0.0;
-    for (int r = 0; r < n; ++r) acc = fma(M[r * n + c], x[r], acc);
-    y[c] = acc;
+  for (int c = 0; c < n; ++c) y[c] = 0.0;           /* row r of M contributes to every y[c]: r ascending per entry = the spec's order */
+  for (int r = 0; r < n; ++r) {
+    const double xr = x[r];
+    const double* row = M + (size_t)r * n;
+    for (int c = 0; c < n; ++c) y[c] = fma(row[c], xr, y[c]);
   }
 }
 /* Sum of a partial-likelihood row for the normalisation of :525.  n <= 4: left to right.  n > 4: four interleaved partial
