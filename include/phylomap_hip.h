@@ -112,7 +112,7 @@ typedef struct phm_options {
                                        5..64 states: 1 = one wave per 64-replica tile, replicas in turn, lanes = states (phm_wide.hip),
                                        2 = one wave per (replica, branch), lanes = states (a handful of chains),
                                        3 = one lane per replica, one wave per (tile, item), pruning on the matrix cores (the default
-                                       beyond 60 replicas at 20 states ... 450 at 61 states, the measured crossover with 2)
+                                       beyond 16 replicas at 20 states ... 100 at 61 states, the measured crossover with 2)
                                   [2]: 1 = record HIP events between the phases of a sweep (phm_engine_phase_ms)
                                   [3]: phm_maketreelistEXP: 1 = divide every internal partial-likelihood row by its sum in the
                                        pruning pass.  The reference's makePLexp (src/phylomap.cpp:2899-2906) does not rescale, so

@@ -18,10 +18,10 @@ namespace {
 constexpr int NARROW_AUTO_MAX_REPLICAS = 95;
 constexpr int TILES_AUTO_MAX_REPLICAS = 262144;
 // 5..64 states: a wave per (replica, branch) (phm_wbranch.hip) exposes S x E waves whatever S is; the lane-per-replica mapping
-// (phm_wtiles.hip) needs whole tiles of 64 replicas and pays a fixed serial cost per tree level (one tile: 4.6 ms per sweep on
-// C4, 2.5 ms on C5).  Measured crossover (profiles/r02_probe_small_S_C{4,5}.log): about 60 replicas at 20 states, about 450 at
-// 61 states -- interpolated linearly in the state count.
-inline int wbranch_auto_max_replicas(int n) { return std::max(32, std::min(512, (int)(60.0 + 9.5 * (n - 20)))); }
+// (phm_wtiles.hip) needs whole tiles of 64 replicas and pays a fixed serial cost per tree level (one tile: 2.25 ms per sweep on
+// C4, 1.28 ms on C5, with a wave per 16-replica block in the pruning pass).  Measured crossover
+// (profiles/r02_probe_small_S_C{4,5}.log): 16 replicas at 20 states, about 100 at 61 states -- interpolated linearly in n.
+inline int wbranch_auto_max_replicas(int n) { return std::max(8, std::min(128, (int)(16.0 + 2.05 * (n - 20)))); }
 
 bool ks_layout(int v) { return v == PHM_MCMC_KS || v == PHM_MCMC_BF || v == PHM_MCMC_MT || v == PHM_MCMC_KSMT; }   // n x n counts, root column
 bool hidden_rates(int v) { return v == PHM_MCMC_KS || v == PHM_MCMC_KSMT; }                                         // parity tip masks

@@ -34,6 +34,7 @@
 namespace phm {
 
 constexpr int WT_BLOCK = 256;
+constexpr int WT_FEW_TILES = 112;       // below this many tiles the pruning pass runs a wave per 16-replica block (latency) instead of per tile (throughput)
 constexpr int WT_MAX_SLOTS = 96;        // possible transitions (non-zero entries of B) up to which the branch kernel counts in LDS
 
 struct WtParams {

@@ -228,6 +228,114 @@ __global__ __launch_bounds__(WT_BLOCK) void wt_up_kernel(WtParams p, int begin, 
   if (err) atomicOr(p.err, err);
 }
 
+// The same pruning step for FEW tiles: a wave per (node, tile, 16-replica block), blocks in replica order, no LDS.  With one
+// tile a height level of the kernel above is a single wave working through four blocks and two children (C4: 168 us per level,
+// 84 % of a 4.6 ms sweep); here the four blocks run on four waves.  With many tiles the sorted blocks of the kernel above win
+// (a block runs to the longest of its 16 chains: 31 against 38 ms per sweep on C4 at 65 536 replicas); measured crossover:
+// 128 tiles on C4, about 80 on C5 (profiles/r02_probe_few_tiles.log).
+template <int MT>
+__global__ __launch_bounds__(WT_BLOCK) void wt_up_blocks_kernel(WtParams p, int begin, int end) {
+  constexpr int KS = 4 * MT;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int n = p.n_states, ldt = p.ldt;
+  double Af[MT][KS];                                   // the chain matrix as A-operand fragments, for the whole launch
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int row = 16 * i + lr, k = 4 * s + lk;
+      Af[i][s] = (row < n && k < n) ? p.Bc[row * n + k] : 0.0;
+    }
+  const int n_lvl = end - begin;
+  const int64_t items = (int64_t)n_lvl * p.n_tiles * 4;
+  const int ks_used = (n + 3) >> 2;                    // k-steps whose four input states are all >= n multiply zeros: skipped
+  uint32_t err = 0;
+  for (int64_t item = (int64_t)blockIdx.x * (WT_BLOCK / 64) + wave; item < items; item += (int64_t)gridDim.x * (WT_BLOCK / 64)) {
+    const int nt = (int)(item & 3);
+    const int64_t q4 = item >> 2;
+    const int tile = (int)(q4 % p.n_tiles), li = (int)(q4 / p.n_tiles);
+    const UpStep st = p.up[p.up_order[begin + li]];
+    const int j = 16 * nt + lr;                        // this lane's replica within the tile
+    double* __restrict__ PLt = p.PL + (size_t)tile * p.n_node * n * 64;
+    const uint16_t* __restrict__ mct = p.mcount + (size_t)tile * p.n_edge * 64;
+    const uint8_t* __restrict__ tips_t = p.tips_per_replica ? p.tips + (size_t)tile * p.n_tips * 64 : p.tips;
+    d4_t R[2][MT];
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {                   // ch 0: "first" = child[1] (:508); ch 1: "second" = child[0] (:509)
+      const int child = st.child[1 - ch], edge = st.edge[1 - ch];
+      int k = (int)mct[edge * 64 + j] - 1;
+      if (child < 0) {                                 // tip: a row of the chain table (the chain run from a unit vector)
+        const int tip = ~child;
+        const int ts = p.tips_per_replica ? tips_t[tip * 64 + j] : p.tips[tip];
+        if (k >= p.klong) { err |= DERR_CAPACITY; k = p.klong - 1; }
+        const double* __restrict__ src = p.tip_masks ? p.maskL + ((size_t)k * 2 + (ts & 1)) * ldt : p.colL + ((size_t)k * n + ts) * ldt;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int row = 16 * i + lk + 4 * q;
+            R[ch][i][q] = (row < n) ? src[row] : 0.0;
+          }
+      } else {                                         // internal child: the chain itself, on the matrix cores
+        d4_t X[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int row = 16 * i + lk + 4 * q;
+            X[i][q] = (row < n) ? PLt[((size_t)child * n + row) * 64 + j] : 0.0;
+          }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) R[ch][i] = X[i];
+        const int kmax = wave_max_count(k);            // segment counts differ per replica: run to the longest, keep step k
+        for (int step = 1; step <= kmax; ++step) {
+          d4_t Y[MT];
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+            d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+              if (s < ks_used) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Af[i][s], X[s >> 2][s & 3], acc, 0, 0, 0);
+            Y[i] = acc;
+          }
+          const bool mine = (k == step);
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+            X[i] = Y[i];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) R[ch][i][q] = mine ? Y[i][q] : R[ch][i][q];
+          }
+        }
+      }
+    }
+    d4_t P[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) P[i] = R[0][i] * R[1][i];                     // :510
+    if (p.normalise) {                                                         // :525
+      double t = 0.0;                                  // states lk, lk + 4, lk + 8, ... ascending: partial sum t_lk
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t += P[i][q];
+      t = t + __shfl_xor(t, 16, 64);                   // t_0 + t_1 | t_2 + t_3
+      t = t + __shfl_xor(t, 32, 64);                   // (t_0 + t_1) + (t_2 + t_3)
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) P[i][q] = P[i][q] / t;
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = 16 * i + lk + 4 * q;
+        if (row < n) PLt[((size_t)st.parent * n + row) * 64 + j] = P[i][q];
+      }
+  }
+  if (err) atomicOr(p.err, err);
+}
+
 __global__ __launch_bounds__(WT_BLOCK) void wt_root_kernel(WtParams p, int it) {
   const int lane = threadIdx.x & 63;
   const int tile = blockIdx.x * (WT_BLOCK / 64) + (threadIdx.x >> 6);
@@ -625,12 +733,19 @@ void launch_up_levels(const WtParams& p, const std::vector<int32_t>& up_off, hip
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wt_up_kernel<MT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
+  const bool few_tiles = p.n_tiles < WT_FEW_TILES;      // not enough (node, tile) items to fill the chip: split them into blocks
   for (size_t l = 0; l + 1 < up_off.size(); ++l) {
     const int cnt = up_off[l + 1] - up_off[l];
     if (cnt <= 0) continue;
-    const int64_t items = (int64_t)cnt * p.n_tiles;    // a wave per (node, tile)
-    const unsigned grid = (unsigned)std::min<int64_t>((items + 3) / 4, 2048);      // persistent waves: the matrix fragments load once
-    hipLaunchKernelGGL(wt_up_kernel<MT>, dim3(grid), dim3(WT_BLOCK), lds, stream, p, up_off[l], up_off[l + 1]);
+    if (few_tiles) {
+      const int64_t items = (int64_t)cnt * p.n_tiles * 4;    // a wave per (node, tile, block)
+      const unsigned grid = (unsigned)std::min<int64_t>((items + 3) / 4, 2048);
+      hipLaunchKernelGGL(wt_up_blocks_kernel<MT>, dim3(grid), dim3(WT_BLOCK), 0, stream, p, up_off[l], up_off[l + 1]);
+    } else {
+      const int64_t items = (int64_t)cnt * p.n_tiles;        // a wave per (node, tile)
+      const unsigned grid = (unsigned)std::min<int64_t>((items + 3) / 4, 2048);      // persistent waves: the matrix fragments load once
+      hipLaunchKernelGGL(wt_up_kernel<MT>, dim3(grid), dim3(WT_BLOCK), lds, stream, p, up_off[l], up_off[l + 1]);
+    }
   }
 }
 

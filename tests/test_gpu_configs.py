@@ -207,7 +207,7 @@ def test_exp_rescaled_pruning_at_c2_size_and_equal_to_plain_on_small_trees():
     np.testing.assert_allclose(got5[:, :20], want5[:, :20], rtol=1e-10, atol=0)
 
 
-@pytest.mark.parametrize("cfg,S", [(4, 1024), (5, 640)])
+@pytest.mark.parametrize("cfg,S", [(4, 1024), (5, 640), (4, 7232), (5, 7232)])      # 16 / 10 tiles: a wave per 16-replica block; 113 tiles: sorted blocks per (node, tile)
 def test_wide_lane_per_replica_mapping_with_many_tiles(cfg, S):
     """phm_wtiles.hip beyond a couple of tiles: persistent pruning waves striding over (node, tile) items, branch groups per
     workgroup, per-tile accumulators -- C4 / C5 at their stated sizes with 16 / 10 tiles, replicas from different tiles and

@@ -1,0 +1,8 @@
+set -e
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_configs.py -m gpu -q -x -k "wide or ks_sweep or c4 or c5 or golden or capacity or random or many_tiles" > gpurun_out/r02_wt_test.log 2>&1 || { tail -60 gpurun_out/r02_wt_test.log; exit 1; }
+tail -2 gpurun_out/r02_wt_test.log
+timeout -k 10 300 python tools/probe_small_S.py 4 2>&1 | tee gpurun_out/r02_probe_small_S_C4.log
+timeout -k 10 300 python tools/probe_small_S.py 5 2>&1 | tee gpurun_out/r02_probe_small_S_C5.log
+for S in 512 1024 2048 4096; do python tools/probe.py $S 8 1 4 tiles | tail -1; python tools/probe.py $S 8 1 4 branches | tail -1; done
