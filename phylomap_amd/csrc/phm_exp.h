@@ -36,6 +36,9 @@ hipError_t launch_expm_pade_mfma(int n, const double* Q, const double* t, const 
 // rescale: every internal row divided by its sum (not in the reference; the node draws do not depend on a row's scale)
 hipError_t launch_exp_pl(int n, int n_node, int n_tips, const UpStep* up, const double* P, double* PL, int rescale,
                          hipStream_t stream);
+// the same values, one launch per height level of the tree, a thread per node (`order`: positions of `up` grouped by height)
+hipError_t launch_exp_pl_levels(int n, int n_tips, const UpStep* up, const int32_t* order, const std::vector<int32_t>& level_off,
+                                const double* P, double* PL, int rescale, hipStream_t stream);
 
 // log p(y|Q): pruning with P(t_b), rows normalised, log scale factors summed in the order of `up` (DIC drivers).
 // `order` (device): positions of `up` grouped by height level, `level_off` (host) the level boundaries; `logs`: n_node doubles.
@@ -86,5 +89,37 @@ struct ExpWideParams {                         // 5 <= n <= 64: runtime state co
   uint32_t* err;
 };
 hipError_t launch_exp_wide(const ExpWideParams& p, hipStream_t stream);
+
+// sumstatEXP with one wavefront per (tile of 64 samples, branch): the mapping for the sample counts the R function is called
+// with (N = 10^3 .. 10^4).  exp_sample_kernel / exp_wide_kernel give a tile of 64 samples ONE wave that walks the whole tree, so
+// N = 1 000 samples keep 16 waves busy on a chip with 1 024 SIMDs; given the node states the branches of a sample are
+// conditionally independent and every random number is addressed by (sample, node | branch), so here the node states are drawn
+// level by level (a wave per (tile, edge)) and newunifSample runs in a wave per (tile, branch).  Same draws, same counts;
+// dwell sums are collected in 64-bit fixed point (integer atomics: exact, order-independent) and agree to 1e-15 of the tree length.
+struct ExpTilesParams {
+  int32_t n_states;
+  int32_t n_tips, n_node, n_edge, root;        // root: internal index
+  int32_t N, n_tiles;
+  uint32_t seed_lo, seed_hi, replica;
+  double poisson_rate;
+  double fx_scale, fx_inv;                     // fixed-point scale of the dwell accumulators (powers of two)
+  const double* pid;                           // [n]
+  const DownStep* down;                        // [n_edge] pre-order
+  const int32_t* node_order;                   // positions into down[] of the edges with an internal child, grouped by depth
+  const double* P;                             // [n_edge][n][n]
+  const double* PL;                            // [2T-1][n]
+  const double* edge_length;
+  const double* colpow;                        // [UNIF_CAP+1][n][n]
+  const double* B2;                            // [n][n]
+  const uint8_t* tips;
+  uint8_t* nstate;                             // [tile][n_node][64]
+  double* times;                               // [resident wave][UNIF_CAP][64] jump-time scratch
+  unsigned long long* dwfx;                    // [n][n_tiles*64] dwell sums, fixed point
+  uint32_t* cnt;                               // [n(n-1)][n_tiles*64]
+  double* out;                                 // N x cols column-major
+  uint32_t* err;
+};
+// level_off: boundaries of the depth levels in node_order (host)
+hipError_t launch_exp_tiles(const ExpTilesParams& p, const std::vector<int32_t>& level_off, int branch_blocks, hipStream_t stream);
 
 }  // namespace phm

@@ -178,6 +178,43 @@ __global__ void exp_pl_kernel(int n, int n_node, int n_tips, const UpStep* __res
   }
 }
 
+// the same pass level by level: a thread per node of one height level (children strictly below); identical values
+__global__ void exp_pl_nodes_kernel(int n, int n_tips, const UpStep* __restrict__ up, const int32_t* __restrict__ order, int begin,
+                                    int end, const double* __restrict__ P, double* __restrict__ PL, int rescale) {
+  const int idx = begin + blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= end) return;
+  const UpStep st = up[order[idx]];
+  const int ca = st.child[0] >= 0 ? st.child[0] + n_tips : ~st.child[0];
+  const int cb = st.child[1] >= 0 ? st.child[1] + n_tips : ~st.child[1];
+  const double* Pa = P + (size_t)st.edge[0] * n * n;
+  const double* Pb = P + (size_t)st.edge[1] * n * n;
+  const double* va = PL + (size_t)ca * n;
+  const double* vb = PL + (size_t)cb * n;
+  double* dst = PL + (size_t)(st.parent + n_tips) * n;
+  for (int i = 0; i < n; ++i) {
+    double a = Pa[i * n] * va[0];
+    for (int j = 1; j < n; ++j) a += Pa[i * n + j] * va[j];
+    double b = Pb[i * n] * vb[0];
+    for (int j = 1; j < n; ++j) b += Pb[i * n + j] * vb[j];
+    dst[i] = a * b;                                                             // :2903
+  }
+  if (rescale) {
+    double sum = dst[0];
+    for (int i = 1; i < n; ++i) sum += dst[i];
+    for (int i = 0; i < n; ++i) dst[i] = dst[i] / sum;
+  }
+}
+
+hipError_t launch_exp_pl_levels(int n, int n_tips, const UpStep* up, const int32_t* order, const std::vector<int32_t>& level_off,
+                                const double* P, double* PL, int rescale, hipStream_t stream) {
+  for (size_t l = 0; l + 1 < level_off.size(); ++l) {
+    const int cnt = level_off[l + 1] - level_off[l];
+    if (cnt > 0) hipLaunchKernelGGL(exp_pl_nodes_kernel, dim3((cnt + 63) / 64), dim3(64), 0, stream, n, n_tips, up, order, level_off[l],
+                                    level_off[l + 1], P, PL, rescale);
+  }
+  return hipGetLastError();
+}
+
 hipError_t launch_exp_pl(int n, int n_node, int n_tips, const UpStep* up, const double* P, double* PL, int rescale,
                          hipStream_t stream) {
   hipLaunchKernelGGL(exp_pl_kernel, dim3(1), dim3(64), 0, stream, n, n_node, n_tips, up, P, PL, rescale);
@@ -555,6 +592,177 @@ hipError_t launch_exp_wide(const ExpWideParams& p, hipStream_t stream) {
   constexpr int W = EXP_BLOCK / 64;
   size_t lds = sizeof(double) * (size_t)p.n_states * p.n_states;
   hipLaunchKernelGGL(exp_wide_kernel, dim3((p.n_tiles + W - 1) / W), dim3(EXP_BLOCK), lds, stream, p);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// sumstatEXP, one wavefront per (tile of 64 samples, item): see ExpTilesParams (phm_exp.h).  Runtime state count (2..64),
+// tables through L1/L2 as in exp_wide_kernel; arithmetic and draw order are those of exp_sample_kernel / exp_wide_kernel.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+// first j with u*sum(w) <= w_0+..+w_j, w_c = a[c]*b[c]   (sample_cat, index order)
+__device__ __forceinline__ int exp_draw_node(const double* __restrict__ a, const double* __restrict__ b, int n, double u, uint32_t& err) {
+  double total = a[0] * b[0];
+  for (int c = 1; c < n; ++c) total += a[c] * b[c];
+  if (!(total > 0.0) || isinf(total)) err |= DERR_ZERO_PROB;
+  const double thr = u * total;
+  double cum = a[0] * b[0];
+  int idx = (thr <= cum) ? 0 : 1;
+  for (int c = 1; c < n; ++c) { cum += a[c] * b[c]; idx += (thr <= cum) ? 0 : 1; }
+  return idx < n ? idx : n - 1;
+}
+
+__global__ __launch_bounds__(EXP_BLOCK) void exp_tiles_root_kernel(ExpTilesParams p) {
+  const int lane = threadIdx.x & 63;
+  const int tile = blockIdx.x * (EXP_BLOCK / 64) + (threadIdx.x >> 6);
+  if (tile >= p.n_tiles) return;
+  const int it = tile * 64 + lane;
+  uint32_t err = 0;
+  const double u = stream_u(p.seed_lo, p.seed_hi, p.replica, (uint32_t)it, ENT_NODE | (uint32_t)(p.root + p.n_tips), 0);
+  p.nstate[((size_t)tile * p.n_node + p.root) * 64 + lane] =
+      (uint8_t)exp_draw_node(p.pid, p.PL + (size_t)(p.root + p.n_tips) * p.n_states, p.n_states, u, err);      // :2926-2934
+  if (err && it < p.N) atomicOr(p.err, err);
+}
+
+__global__ __launch_bounds__(EXP_BLOCK) void exp_tiles_node_kernel(ExpTilesParams p, int begin, int end) {
+  const int lane = threadIdx.x & 63;
+  const int item = blockIdx.x * (EXP_BLOCK / 64) + (threadIdx.x >> 6);
+  const int n_lvl = end - begin;
+  if (item >= n_lvl * p.n_tiles) return;
+  const int n = p.n_states;
+  const int tile = item / n_lvl;
+  const DownStep ds = p.down[p.node_order[begin + item % n_lvl]];
+  const int it = tile * 64 + lane;
+  uint8_t* __restrict__ nst = p.nstate + (size_t)tile * p.n_node * 64;
+  const int a = nst[ds.parent * 64 + lane];
+  uint32_t err = 0;
+  const double u = stream_u(p.seed_lo, p.seed_hi, p.replica, (uint32_t)it, ENT_NODE | (uint32_t)(ds.child + p.n_tips), 0);
+  const int e = exp_draw_node(p.P + ((size_t)ds.edge * n + a) * n, p.PL + (size_t)(ds.child + p.n_tips) * n, n, u, err);   // :2953-2956
+  nst[ds.child * 64 + lane] = (uint8_t)e;
+  if (err && it < p.N) atomicOr(p.err, err);
+}
+
+// newunifSample(a, e, t_b, P_b[a,e]) :93-208 for the 64 samples of a tile on one branch; persistent waves over (tile, branch)
+__global__ __launch_bounds__(EXP_BLOCK) void exp_tiles_branch_kernel(ExpTilesParams p) {
+  const int lane = threadIdx.x & 63;
+  const int wslot = blockIdx.x * (EXP_BLOCK / 64) + (threadIdx.x >> 6);
+  const int n = p.n_states;
+  const int64_t items = (int64_t)p.n_edge * p.n_tiles;
+  const size_t npad = (size_t)p.n_tiles * 64;
+  double* __restrict__ tms = p.times + (size_t)wslot * UNIF_CAP * 64;
+  uint32_t err = 0;
+  for (int64_t item = wslot; item < items; item += (int64_t)gridDim.x * (EXP_BLOCK / 64)) {
+    const int tile = (int)(item % p.n_tiles);
+    const DownStep ds = p.down[item / p.n_tiles];
+    const int b = ds.edge;
+    const int it = tile * 64 + lane;
+    const bool valid = it < p.N;
+    const uint8_t* __restrict__ nst = p.nstate + (size_t)tile * p.n_node * 64;
+    const int a = nst[ds.parent * 64 + lane];
+    const int e = ds.child >= 0 ? (int)nst[ds.child * 64 + lane] : (int)p.tips[~ds.child];
+    const double* Pb = p.P + (size_t)b * n * n;
+    auto stat_add = [&](int col, double v) {           // dwell: fixed point, exact in any order
+      if (valid) atomicAdd(p.dwfx + (size_t)col * npad + it, (unsigned long long)__double2ll_rn(v * p.fx_scale));
+    };
+    auto count = [&](int from, int to) { if (valid) atomicAdd(p.cnt + (size_t)(from * (n - 1) + (to > from ? to - 1 : to)) * npad + it, 1u); };
+
+    const double tb = p.edge_length[b];
+    const double transProb = Pb[(size_t)a * n + e];
+    Stream sr;
+    sr.open(ENT_BUNIF | (uint32_t)b, (uint32_t)it, p.replica, p.seed_lo, p.seed_hi);
+    uint32_t dr = 0;
+    const double rU = sr.draw(dr++);                                            // :103
+    const double lam = p.poisson_rate * tb;
+    double pk = phm_exp(-lam);
+    double cum = 0.0;
+    if (a == e) cum = pk / transProb;                                           // :107
+    bool notExceed = !(cum > rU);
+    int nj = 0;
+    bool capped = false;
+    while (notExceed) {
+      nj++;
+      if (nj > UNIF_CAP) { capped = true; break; }                              // :120
+      pk = pk * lam / (double)nj;
+      const double nextProb = pk * p.colpow[((size_t)nj * n + e) * n + a] / transProb;   // :127-128
+      cum += nextProb;
+      if (cum > rU) notExceed = false;
+    }
+    if (capped) { if (valid) err |= DERR_UNIF_CAP; continue; }
+    if (nj == 0 || (nj == 1 && a == e)) {                                       // :138
+      stat_add(a, tb - 0.0);
+    } else if (nj == 1) {                                                       // :144
+      const double tj = tb * sr.draw(dr++);
+      stat_add(a, tj - 0.0);
+      stat_add(e, tb - tj);
+      count(a, e);
+    } else {
+      for (int i = 0; i < nj; ++i) {                                            // :151-152 jump times, ascending
+        const double v = tb * sr.draw(dr++);
+        int j = i - 1;
+        while (j >= 0) {
+          const double tj = tms[j * 64 + lane];
+          if (!(tj > v)) break;
+          tms[(j + 1) * 64 + lane] = tj;
+          --j;
+        }
+        tms[(j + 1) * 64 + lane] = v;
+      }
+      int prev = a, sprev = a;
+      double tprev = 0.0;
+      for (int i = 1; i <= nj; ++i) {
+        int di = e;
+        if (i < nj) {                                                           // sampleOnce :81-90, :158-160
+          const double* beta = p.colpow + ((size_t)(nj - i) * n + e) * n;
+          const double* row = p.B2 + (size_t)prev * n;
+          double total = row[0] * beta[0];
+          for (int c = 1; c < n; ++c) total += row[c] * beta[c];
+          const double u = sr.draw(dr++);
+          double cw = 0.0;
+          int pick = n;
+          for (int c = 0; c < n; ++c) {
+            cw += (row[c] * beta[c]) / total;
+            if (pick == n && u < cw) pick = c;
+          }
+          if (pick == n) { if (valid) err |= DERR_SAMPLEONCE; pick = n - 1; }
+          di = pick;
+        }
+        if (prev != di) {                                                       // :168-173 drop virtual jumps
+          const double ti = tms[(i - 1) * 64 + lane];
+          stat_add(sprev, ti - tprev);
+          count(sprev, di);
+          tprev = ti; sprev = di;
+        }
+        prev = di;
+      }
+      stat_add(sprev, tb - tprev);
+    }
+  }
+  if (err) atomicOr(p.err, err);
+}
+
+__global__ void exp_tiles_finish_kernel(ExpTilesParams p) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = p.n_states, cols = n + n * (n - 1);
+  if (gid >= (int64_t)cols * p.N) return;
+  const int c = (int)(gid / p.N), it = (int)(gid % p.N);
+  const size_t npad = (size_t)p.n_tiles * 64;
+  p.out[(size_t)c * p.N + it] = c < n ? (double)(long long)p.dwfx[(size_t)c * npad + it] * p.fx_inv
+                                      : (double)p.cnt[(size_t)(c - n) * npad + it];
+}
+
+}  // namespace
+
+hipError_t launch_exp_tiles(const ExpTilesParams& p, const std::vector<int32_t>& level_off, int branch_blocks, hipStream_t stream) {
+  constexpr int W = EXP_BLOCK / 64;
+  hipLaunchKernelGGL(exp_tiles_root_kernel, dim3((p.n_tiles + W - 1) / W), dim3(EXP_BLOCK), 0, stream, p);
+  for (size_t l = 0; l + 1 < level_off.size(); ++l) {
+    const int cnt = level_off[l + 1] - level_off[l];
+    if (cnt > 0) hipLaunchKernelGGL(exp_tiles_node_kernel, dim3((unsigned)(((int64_t)cnt * p.n_tiles + W - 1) / W)), dim3(EXP_BLOCK), 0, stream, p, level_off[l], level_off[l + 1]);
+  }
+  hipLaunchKernelGGL(exp_tiles_branch_kernel, dim3(branch_blocks), dim3(EXP_BLOCK), 0, stream, p);
+  const int64_t cells = (int64_t)(p.n_states + p.n_states * (p.n_states - 1)) * p.N;
+  hipLaunchKernelGGL(exp_tiles_finish_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, stream, p);
   return hipGetLastError();
 }
 

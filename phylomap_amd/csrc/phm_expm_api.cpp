@@ -11,6 +11,8 @@ struct Timer {
 
 }  // namespace
 
+constexpr int EXP_TILES_AUTO_MAX_TILES = 1 << 30;      // see the mapping note in phm_maketreelistEXP
+
 extern "C" {
 
 static int32_t expm_eigen_impl(bool mfma, int32_t n, const double* lefts, const double* rights, const double* d, const double* t,
@@ -163,11 +165,83 @@ int32_t phm_maketreelistEXP(const phm_tree* x, int32_t n, const double* Q, const
   HIPCHK(hipMemset(dnst.p, 0, dnst.bytes));
 
   HIPCHK(phm::launch_expm_eigen(n, dL.as<double>(), dR.as<double>(), dd.as<double>(), dt.as<double>(), E, dP.as<double>(), nullptr));   // :3042
-  HIPCHK(phm::launch_exp_pl(n, s.n_node, T, dup.as<phm::UpStep>(), dP.as<double>(), dPL.as<double>(), o.reserved[3] != 0, nullptr));   // :3043
+  {   // :3043 -- the pruning pass, level by level (heights: children strictly below their parent)
+    std::vector<int32_t> height(s.n_node, 0), uorder, ulevel;
+    std::vector<std::vector<int32_t>> by_h;
+    for (int k = 0; k < s.n_node; ++k) {
+      const phm::UpStep& u = s.up[k];
+      int h = 0;
+      for (int c = 0; c < 2; ++c) if (u.child[c] >= 0) h = std::max(h, height[u.child[c]] + 1);
+      height[u.parent] = h;
+      if ((int)by_h.size() <= h) by_h.resize(h + 1);
+      by_h[h].push_back(k);
+    }
+    ulevel.push_back(0);
+    for (auto& v : by_h) { uorder.insert(uorder.end(), v.begin(), v.end()); ulevel.push_back((int32_t)uorder.size()); }
+    DevBuf duord;
+    HIPCHK(duord.alloc(sizeof(int32_t) * uorder.size()));
+    HIPCHK(hipMemcpy(duord.p, uorder.data(), duord.bytes, hipMemcpyHostToDevice));
+    HIPCHK(phm::launch_exp_pl_levels(n, T, dup.as<phm::UpStep>(), duord.as<int32_t>(), ulevel, dP.as<double>(), dPL.as<double>(),
+                                     o.reserved[3] != 0, nullptr));
+    HIPCHK(hipDeviceSynchronize());      // duord goes out of scope
+  }
   hipEvent_t ev0 = nullptr, ev1 = nullptr;      // time of the sampling kernel alone (phm_last_kernel_ms)
   HIPCHK(hipEventCreate(&ev0)); HIPCHK(hipEventCreate(&ev1));
   HIPCHK(hipEventRecord(ev0, nullptr));
 
+  // Mapping (phm_options.reserved[1]): 1 = one wave per tile of 64 samples walks the tree (exp_sample_kernel / exp_wide_kernel);
+  // 3 = one wave per (tile, branch) (exp_tiles_*); 0 = automatic: the (tile, branch) mapping unless there are so many samples
+  // that the tiles alone fill the chip.
+  const bool use_tiles = o.reserved[1] == 3 || (o.reserved[1] == 0 && tiles < EXP_TILES_AUTO_MAX_TILES);
+  if (use_tiles) {
+    // edges with an internal child, grouped by depth (parents' states are drawn a level earlier)
+    std::vector<int32_t> depth(s.n_node, 0), order, level_off;
+    {
+      std::vector<std::vector<int32_t>> by_depth;
+      for (int k = 0; k < E; ++k) {
+        const phm::DownStep& d = s.down[k];
+        if (d.child < 0) continue;
+        const int dl = depth[d.parent];
+        depth[d.child] = dl + 1;
+        if ((int)by_depth.size() <= dl) by_depth.resize(dl + 1);
+        by_depth[dl].push_back(k);
+      }
+      level_off.push_back(0);
+      for (auto& v : by_depth) { order.insert(order.end(), v.begin(), v.end()); level_off.push_back((int32_t)order.size()); }
+    }
+    double tree_len = 0.0;
+    for (int b = 0; b < E; ++b) tree_len += x->edge_length[b];
+    int ex = 0;
+    (void)std::frexp(std::max(tree_len, 1.0), &ex);
+    const int64_t items = (int64_t)E * tiles;
+    const int branch_blocks = (int)std::min<int64_t>((items + 3) / 4, 2048);
+    const size_t npad = (size_t)tiles * 64;
+    DevBuf dorder, dpid, ddw, dcnt, dtm;
+    HIPCHK(dorder.alloc(sizeof(int32_t) * std::max<size_t>(order.size(), 1))); HIPCHK(dpid.alloc(sizeof(double) * n));
+    HIPCHK(ddw.alloc(sizeof(unsigned long long) * n * npad)); HIPCHK(dcnt.alloc(sizeof(uint32_t) * (size_t)n * (n - 1) * npad));
+    HIPCHK(dtm.alloc(sizeof(double) * (size_t)branch_blocks * 4 * phm::UNIF_CAP * 64));
+    if (!order.empty()) HIPCHK(hipMemcpy(dorder.p, order.data(), sizeof(int32_t) * order.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dpid.p, pid, sizeof(double) * n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(ddw.p, 0, ddw.bytes)); HIPCHK(hipMemset(dcnt.p, 0, dcnt.bytes));
+    phm::ExpTilesParams p;
+    p.n_states = n; p.n_tips = T; p.n_node = s.n_node; p.n_edge = E; p.root = s.root; p.N = N; p.n_tiles = tiles;
+    p.seed_lo = (uint32_t)(o.seed & 0xFFFFFFFFull); p.seed_hi = (uint32_t)(o.seed >> 32); p.replica = (uint32_t)o.replica_offset;
+    p.poisson_rate = rate; p.fx_scale = std::ldexp(1.0, 61 - ex); p.fx_inv = std::ldexp(1.0, ex - 61);
+    p.pid = dpid.as<double>(); p.down = ddown.as<phm::DownStep>(); p.node_order = dorder.as<int32_t>();
+    p.P = dP.as<double>(); p.PL = dPL.as<double>(); p.edge_length = dt.as<double>(); p.colpow = dcol.as<double>(); p.B2 = dB2.as<double>();
+    p.tips = dtips.as<uint8_t>(); p.nstate = dnst.as<uint8_t>(); p.times = dtm.as<double>();
+    p.dwfx = ddw.as<unsigned long long>(); p.cnt = dcnt.as<uint32_t>(); p.out = dout.as<double>(); p.err = derr.as<uint32_t>();
+    HIPCHK(hipEventRecord(ev0, nullptr));      // (re-recorded: the set-up above is not part of the sampler's time)
+    HIPCHK(phm::launch_exp_tiles(p, level_off, branch_blocks, nullptr));
+    HIPCHK(hipEventRecord(ev1, nullptr));
+    HIPCHK(hipEventSynchronize(ev1));
+    { float ms = 0.f; if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) g_phm_last_kernel_ms = ms; }
+    (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
+    HIPCHK(hipMemcpy(out, dout.p, dout.bytes, hipMemcpyDeviceToHost));
+    uint32_t derrh = 0;
+    HIPCHK(hipMemcpy(&derrh, derr.p, sizeof derrh, hipMemcpyDeviceToHost));
+    return device_status(derrh);
+  }
   auto fill = [&](auto& p) {
     p.n_tips = T; p.n_node = s.n_node; p.n_edge = E; p.root = s.root; p.N = N; p.n_tiles = tiles;
     p.seed_lo = (uint32_t)(o.seed & 0xFFFFFFFFull); p.seed_hi = (uint32_t)(o.seed >> 32); p.replica = (uint32_t)o.replica_offset;

@@ -553,22 +553,29 @@ def test_replica_offset_shards_like_one_device(mapping):
     np.testing.assert_array_equal(a[2:], b)
 
 
+EXP_MAPPINGS = ["replicas", "tiles"]      # one wave per tile of 64 samples walks the tree / one wave per (tile, branch)
+
+
+@pytest.mark.parametrize("mapping", EXP_MAPPINGS)
 @pytest.mark.parametrize("n", [2, 4])
-def test_exp_matches_oracle(n):
+def test_exp_matches_oracle(n, mapping):
     z, Q, pid, Omega = _problem(n, 30, 321 + n)
     nen, nodelist, root = _orders(z)
     lefts, rights, d = api.eigen_decompose(Q)
     N, seed = 200, 17
-    got = api.sumstatEXP(z, Q, pid, N, seed=seed)
+    got = api.sumstatEXP(z, Q, pid, N, seed=seed, mapping=mapping)
     want, rc = O.maketreelistEXP(z, Q, pid, nen, nodelist, root, N, lefts, rights, d, seed=seed)
     assert rc == 0
     np.testing.assert_array_equal(got[:, n:], want[:, n:])
     np.testing.assert_allclose(got[:, :n], want[:, :n], rtol=1e-10)
-    np.testing.assert_array_equal(got, want)
+    if mapping == "replicas":                 # the walking wave adds the dwell times in the reference's order
+        np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(api.sumstatEXP(z, Q, pid, N, seed=seed), got if mapping == "tiles" else api.sumstatEXP(z, Q, pid, N, seed=seed, mapping="tiles"))
 
 
+@pytest.mark.parametrize("mapping", EXP_MAPPINGS)
 @pytest.mark.parametrize("n", [5, 20, 61])
-def test_exp_wide_matches_oracle(n):
+def test_exp_wide_matches_oracle(n, mapping):
     """sumstatEXP for 5..64 states (the tutorial's 20-state tridiagonal Q, vignettes/phylomap_tutorial.Rnw:72-134)."""
     if n == 20:
         Q = synth.tridiagonal_Q(20, 0.03)
@@ -582,11 +589,14 @@ def test_exp_wide_matches_oracle(n):
     nen, nodelist, root = _orders(z)
     lefts, rights, d = api.eigen_decompose(Q)
     N = 150
-    got = api.sumstatEXP(z, Q, pid, N, seed=23)
+    got = api.sumstatEXP(z, Q, pid, N, seed=23, mapping=mapping)
     want, rc = O.maketreelistEXP(z, Q, pid, nen, nodelist, root, N, lefts, rights, d, seed=23)
     assert rc == 0
     np.testing.assert_array_equal(got[:, n:], want[:, n:])
-    np.testing.assert_array_equal(got[:, :n], want[:, :n])
+    if mapping == "replicas":
+        np.testing.assert_array_equal(got[:, :n], want[:, :n])
+    else:
+        np.testing.assert_allclose(got[:, :n], want[:, :n], rtol=1e-10, atol=0)
     np.testing.assert_allclose(got[:, :n].sum(1), z["edge.length"].sum(), rtol=1e-12)
 
 

@@ -1,11 +1,16 @@
-"""sumstatEXP throughput probe: python tools/probe_exp.py config n_tips N"""
-import sys, os, time
+"""sumstatEXP throughput by sample count and mapping: python tools/probe_exp.py [cfg]"""
+import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from phylomap_amd import api, synth
-cfg = int(sys.argv[1]); tips = int(sys.argv[2]); N = int(sys.argv[3])
-z, Q, pid, Omega = synth.config_problem(cfg, n_tips=tips)
+from phylomap_amd import _lib, api, synth
+cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+z, Q, pid, Om = synth.config_problem(cfg)
 E = z["edge"].shape[0]
-api.sumstatEXP(z, Q, pid, 64, seed=1)
-t0 = time.time(); out = api.sumstatEXP(z, Q, pid, N, seed=1); dt = time.time() - t0
-print(f"C{cfg} tips={tips} N={N}: {dt:.3f}s wall (incl. upload/download) -> {E*N/dt/1e9:.3f} G branch-sample/s; jumps/sample={out[:, Q.shape[0]:].sum(1).mean():.1f}")
+L = _lib.load()
+resc = cfg != 1
+for N in (1000, 4096, 16384, 65536):
+    for mapping in ("replicas", "tiles"):
+        api.sumstatEXP(z, Q, pid, 64, seed=1, rescale=resc, mapping=mapping)
+        t = time.time(); st = api.sumstatEXP(z, Q, pid, N, seed=2, rescale=resc, mapping=mapping); wall = time.time() - t
+        ms = L.phm_last_kernel_ms()
+        print(f"C{cfg} N={N:6d} {mapping:9s}: kernel {ms:8.3f} ms  {E*N/(ms/1e3)/1e9:7.3f} G/s   whole call {wall*1e3:8.1f} ms", flush=True)
