@@ -113,11 +113,16 @@ typedef struct phm_options {
                                        2 = one wave per (replica, branch), lanes = states (a handful of chains),
                                        3 = one lane per replica, one wave per (tile, item), pruning on the matrix cores (the default
                                        beyond 16 replicas at 20 states ... 100 at 61 states, the measured crossover with 2)
+                                       phm_maketreelistEXP: 0 or 3 = one wave per (tile of 64 samples, branch) (the default), 1 = one
+                                       wave per tile of 64 samples walks the tree (dwell sums then add in the reference's order)
                                   [2]: 1 = record HIP events between the phases of a sweep (phm_engine_phase_ms)
                                   [3]: phm_maketreelistEXP: 1 = divide every internal partial-likelihood row by its sum in the
                                        pruning pass.  The reference's makePLexp (src/phylomap.cpp:2899-2906) does not rescale, so
                                        sumstatEXP underflows (PHM_ERR_ZERO_PROB) beyond a few hundred tips; node draws do not
-                                       depend on a row's scale, so this is the same sampler in exact arithmetic
+                                       depend on a row's scale, so this is the same sampler in exact arithmetic.
+                                       phm_maketreelistMCMC / phm_SPARSEmaketreelistMCMC: 1 = the same for their pruning pass (what
+                                       makePLrcpp_bigtree :525 does; the plain and the SPARSE driver underflow on trees of thousands of
+                                       tips, man/sumstatMCMC_bigtree.Rd:17)
                                   [4]: internal (capacity recovery): log2 of the multiplier applied to the provisioned capacities
                                   [5]: 1 = no capacity recovery: a sweep that outgrows its slots fails with PHM_ERR_CAPACITY.  Default
                                        (0): the engine is rebuilt with doubled slots and the iterations run so far are replayed --

@@ -926,6 +926,11 @@ static int mcmc_driver(const orc_tree* x, int n, const double* Q_cm, const doubl
   int e = check_tree(x); if (e) return e;
   if (dic && (!prior || !x->edge_length)) return ORC_ERR_BAD_INPUT;
   if (n < 2 || N < 0) return ORC_ERR_BAD_INPUT;
+  /* variant | ORC_FORCE_NORMALISE: divide every internal partial-likelihood row by its sum (what makePLrcpp_bigtree :525 does)
+   * in a driver that does not -- NOT in the reference: sumstatMCMC / SPARSEsumstatMCMC underflow on trees of thousands of tips
+   * (man/sumstatMCMC_bigtree.Rd:17); node draws do not depend on a row's scale, so it is the same sampler in exact arithmetic */
+  const int force_norm = (variant & ORC_FORCE_NORMALISE) != 0;
+  variant &= ~ORC_FORCE_NORMALISE;
   int E = x->n_edge, T = x->n_tips, Nnode = x->n_node;
   const int32_t* edge2 = x->edge + E; const int32_t* edge1 = x->edge;
   const int ks = (variant == ORC_MCMC_KS) ? 1 : (variant == ORC_MCMC_BF) ? 2 : 0;   /* 1: ks sweep, 2: bf sweep */
@@ -946,7 +951,7 @@ static int mcmc_driver(const orc_tree* x, int n, const double* Q_cm, const doubl
   for (int i = 0; i < n; ++i) { Qd[i] = Q_cm[i + (size_t)i * n]; for (int j = 0; j < n; ++j) B2[i * n + j] = B_cm[i + (size_t)j * n]; }
   if (variant == ORC_MCMC_SPARSE) orc_matTospmat(B2, n, Bc);  /* :848 */
   else memcpy(Bc, B2, sizeof(double) * n * n);
-  int normalise = (variant == ORC_MCMC_BIGTREE) || ks;        /* makePLnormalized :1085 */
+  int normalise = (variant == ORC_MCMC_BIGTREE) || ks || force_norm;        /* makePLnormalized :1085 */
 
   treechain ch;
   e = chain_init(&ch, x, n, ks == 1);

@@ -50,6 +50,7 @@ extern "C" {
                                  shortenerbf counts, columns l01 l10 root); out: N x 9 */
 #define ORC_MCMC_MT       5   /* maketreelistMCMCmt   src/phylomap.cpp:2267-2365: list of trees, two states, Q updated */
 #define ORC_MCMC_KSMT     6   /* maketreelistMCMCksmt src/phylomap.cpp:2722-2844: list of trees, hidden rates */
+#define ORC_FORCE_NORMALISE 32 /* OR-ed into PLAIN / SPARSE: rows of the pruning pass divided by their sum (:525), not in the reference */
 
 /* RNG: mode 0 = counter-based Philox4x32-7 streams (the mode the GPU matches bit for bit);
  *      mode 1 = scripted tapes consumed in the reference's draw order (for hand KATs);

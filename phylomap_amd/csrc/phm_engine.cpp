@@ -25,7 +25,7 @@ inline int wbranch_auto_max_replicas(int n) { return std::max(8, std::min(128, (
 
 bool ks_layout(int v) { return v == PHM_MCMC_KS || v == PHM_MCMC_BF || v == PHM_MCMC_MT || v == PHM_MCMC_KSMT; }   // n x n counts, root column
 bool hidden_rates(int v) { return v == PHM_MCMC_KS || v == PHM_MCMC_KSMT; }                                         // parity tip masks
-bool normalised(int v) { return v == PHM_MCMC_BIGTREE || v == PHM_MCMC_KS || v == PHM_MCMC_BF; }                   // makePLnormalized :1085
+bool normalised_variant(int v) { return v == PHM_MCMC_BIGTREE || v == PHM_MCMC_KS || v == PHM_MCMC_BF; }           // makePLnormalized :1085
 
 template <int NS>
 void fill_params(phm_engine* e, phm::McmcParams<NS>& p, const double* B2, const double* Bc, const double* scale,
@@ -33,7 +33,7 @@ void fill_params(phm_engine* e, phm::McmcParams<NS>& p, const double* B2, const 
   p.n_tips = e->sched.n_tips; p.n_node = e->sched.n_node; p.n_edge = e->sched.n_edge; p.root = e->sched.root;
   p.n_tiles = e->tiles; p.n_rep = e->n_trees > 1 ? e->S_tree : e->S; p.n_rep_pad = e->S_pad; p.replica_offset = o.replica_offset;
   p.tiles_per_tree = e->n_trees > 1 ? e->tpt : 0; p.roots = e->d_roots.as<int32_t>();
-  p.normalise = normalised(e->variant); p.tips_per_replica = e->tips_per_replica ? 1 : 0;
+  p.normalise = e->normalise; p.tips_per_replica = e->tips_per_replica ? 1 : 0;
   p.reduce = e->reduce; p.n_cols = e->dcols; p.ktab = phm::MCMC_KTAB; p.klong = std::max(e->nw_klong, phm::MCMC_KTAB); p.prune_only = 0;
   p.ks = ks_layout(e->variant); p.tip_masks = hidden_rates(e->variant);
   p.maskpow = e->d_mask.as<double>();
@@ -214,7 +214,7 @@ void fill_narrow_params(phm_engine* e, phm::NarrowParams<NS>& p, const phm_optio
   const phm::Schedule& s = e->sched;
   p.n_tips = s.n_tips; p.n_node = s.n_node; p.n_edge = s.n_edge; p.root = s.root;
   p.n_rep = e->S; p.n_rep_pad = e->S_pad; p.replica_offset = o.replica_offset; p.n_tiles = e->tiles;
-  p.normalise = normalised(e->variant); p.tips_per_replica = e->tips_per_replica ? 1 : 0;
+  p.normalise = e->normalise; p.tips_per_replica = e->tips_per_replica ? 1 : 0;
   p.ks = ks_layout(e->variant); p.tip_masks = hidden_rates(e->variant); p.reduce = e->reduce; p.n_cols = e->dcols;
   p.klong = e->nw_klong;
   p.seed_lo = (uint32_t)(o.seed & 0xFFFFFFFFull); p.seed_hi = (uint32_t)(o.seed >> 32);
@@ -376,7 +376,7 @@ int32_t narrow_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
     phm::WideBranchParams& p = e->pwb;
     p.n_states = n; p.n_tips = s.n_tips; p.n_node = s.n_node; p.n_edge = s.n_edge; p.root = s.root;
     p.n_rep = e->S; p.n_rep_pad = e->S_pad; p.replica_offset = o.replica_offset; p.n_tiles = e->tiles;
-    p.normalise = normalised(e->variant); p.tips_per_replica = e->tips_per_replica ? 1 : 0;
+    p.normalise = e->normalise; p.tips_per_replica = e->tips_per_replica ? 1 : 0;
     p.sparse = (e->variant == PHM_MCMC_SPARSE); p.ks = ks_layout(e->variant); p.tip_masks = hidden_rates(e->variant);
     p.count_self = p.ks; p.reduce = e->reduce; p.n_cols = e->dcols; p.klong = e->nw_klong;
     p.seed_lo = (uint32_t)(o.seed & 0xFFFFFFFFull); p.seed_hi = (uint32_t)(o.seed >> 32);
@@ -404,7 +404,7 @@ void fill_tile_params(phm_engine* e, phm::TileParams<NS>& p, const phm_options& 
   const phm::Schedule& s = e->sched;
   p.n_tips = s.n_tips; p.n_node = s.n_node; p.n_edge = s.n_edge; p.root = s.root;
   p.n_tiles = e->tiles; p.n_rep = e->S; p.n_rep_pad = e->S_pad; p.replica_offset = o.replica_offset;
-  p.normalise = normalised(e->variant); p.tips_per_replica = e->tips_per_replica ? 1 : 0;
+  p.normalise = e->normalise; p.tips_per_replica = e->tips_per_replica ? 1 : 0;
   p.ks = ks_layout(e->variant); p.tip_masks = hidden_rates(e->variant); p.reduce = e->reduce; p.n_cols = e->dcols;
   p.klong = e->nw_klong;
   // branches per wave of the branch kernel: one while waves are scarce, up to 16 once there are 65 536 of them anyway
@@ -639,7 +639,7 @@ int32_t wtiles_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
   p.n_states = n; p.ldt = ldt;
   p.n_tips = s.n_tips; p.n_node = s.n_node; p.n_edge = s.n_edge; p.root = s.root;
   p.n_tiles = tiles; p.n_rep = e->S; p.n_rep_pad = e->S_pad; p.replica_offset = o.replica_offset;
-  p.normalise = normalised(e->variant); p.tips_per_replica = e->tips_per_replica ? 1 : 0;
+  p.normalise = e->normalise; p.tips_per_replica = e->tips_per_replica ? 1 : 0;
   p.ks = ks_layout(e->variant); p.tip_masks = hidden_rates(e->variant); p.reduce = e->reduce; p.n_cols = e->dcols;
   p.klong = e->nw_klong;
   // branches per wave of the branch kernel: one while waves are scarce, up to 8 once there are 65 536 of them anyway
@@ -797,6 +797,8 @@ int32_t phm_engine_create_multi(const phm_tree* trees, int32_t n_trees, const ph
   e->ipl = o.iters_per_launch > 0 ? o.iters_per_launch : 8;
   e->tips_per_replica = o.tips_per_replica != 0 || n_trees > 1;      // a list of trees: tip data per tile
   e->phase_timing = o.reserved[2] != 0;
+  // reserved[3] != 0 with a fixed-Q MCMC variant: the pruning pass of sumstatMCMC / SPARSEsumstatMCMC rescaled like _bigtree's (:525)
+  e->normalise = normalised_variant(e->variant) || (o.reserved[3] != 0 && (e->variant == PHM_MCMC || e->variant == PHM_MCMC_SPARSE));
   e->cap_boost = 1 << std::max(0, std::min(10, (int)o.reserved[4]));      // internal: set by the capacity recovery
   e->recover = o.reserved[5] == 0;
   e->saved = save_input(trees, n_trees, model, o, max_iters);
@@ -1010,7 +1012,7 @@ int32_t phm_engine_create_multi(const phm_tree* trees, int32_t n_trees, const ph
     p.n_states = n; p.n_tips = s.n_tips; p.n_node = s.n_node; p.n_edge = s.n_edge; p.root = s.root;
     p.n_tiles = e->tiles; p.n_rep = n_trees > 1 ? e->S_tree : e->S; p.n_rep_pad = e->S_pad; p.replica_offset = o.replica_offset;
     p.tiles_per_tree = n_trees > 1 ? e->tpt : 0; p.roots = e->d_roots.as<int32_t>(); p.rep_stride = e->rpt;
-    p.normalise = normalised(e->variant); p.tips_per_replica = e->tips_per_replica ? 1 : 0;
+    p.normalise = e->normalise; p.tips_per_replica = e->tips_per_replica ? 1 : 0;
     p.reduce = e->reduce; p.n_cols = e->dcols; p.ktab = std::max(e->nw_klong, phm::WIDE_KTAB); p.sparse = (e->variant == PHM_MCMC_SPARSE); p.ks = ks_layout(e->variant); p.count_self = p.ks; p.tip_masks = hidden_rates(e->variant);
     p.maskpow = e->d_mask.as<double>();
     p.seed_lo = (uint32_t)(o.seed & 0xFFFFFFFFull); p.seed_hi = (uint32_t)(o.seed >> 32);

@@ -190,6 +190,7 @@ struct phm_engine {
   std::vector<double> hB2, hBc, hscale, hpid;      // current model, row-major
   int S = 0, S_pad = 0, tiles = 0, max_iters = 0, iters_done = 0, ipl = 0;
   int reduce = 0, device = 0;
+  bool normalise = false;               // rows of the pruning pass divided by their sum (the variant's own rule, or phm_options.reserved[3])
   phm::Schedule sched;                 // tree 0 (every tree of a list has the same tip / edge counts)
   std::vector<phm::Schedule> scheds;   // one per tree
   int n_trees = 1, S_tree = 0, tpt = 0;   // list of trees: S_tree chains per tree on tpt tiles each; S = n_trees * S_tree

@@ -12,6 +12,7 @@ _SO = os.path.join(_ROOT, "oracle", "_build", "libphm_oracle.so")
 
 ERR_ZERO_PROB, ERR_UNIF_CAP, ERR_BAD_INPUT, ERR_TAPE, ERR_SAMPLEONCE = 1, 2, 4, 8, 16
 PLAIN, BIGTREE, SPARSE, KS, BF, MT, KSMT = 0, 1, 2, 3, 4, 5, 6
+FORCE_NORMALISE = 32      # OR-ed into PLAIN / SPARSE: rescaled pruning pass (not in the reference)
 
 
 class Rng(C.Structure):
@@ -129,9 +130,9 @@ def maketreelistMCMC(z, Q, pid, B, Omega, nen, nodelist, root, N, variant=PLAIN,
     nen = np.ascontiguousarray(nen, dtype=np.int32)
     nodelist = np.ascontiguousarray(nodelist, dtype=np.int32)
     cols = n + n * (n - 1)
-    if variant == KS:
+    if variant & ~FORCE_NORMALISE == KS:
         cols = n + n * n + 2 + 3 * (n // 2 - 1) + 1
-    if variant == BF:
+    if variant & ~FORCE_NORMALISE == BF:
         cols = 9
     if dic:
         cols += 1

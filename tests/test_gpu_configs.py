@@ -139,6 +139,9 @@ def test_c5_sparse_20_states_5000_tips(mapping):
     assert e.value.status == 5
     S = {"replicas": 128, "branches": 66, "tiles": 128}[mapping]
     _run_config(5, _lib.PHM_MCMC_BIGTREE, O.BIGTREE, mapping, S, 8, 5151, False, dump_replica=S - 1)
+    # ... and the SPARSE driver itself at the stated size, with its pruning pass rescaled (phm_options.reserved[3]; oracle:
+    # SPARSE | FORCE_NORMALISE): thresholded chain matrix, dense forward rows, rows divided by their sum
+    _run_config(5, _lib.PHM_MCMC_SPARSE, O.SPARSE | O.FORCE_NORMALISE, mapping, 70, 8, 6161, False, dump_replica=69, rescale=True)
 
 
 @pytest.mark.parametrize("mapping", WIDE_MAPPINGS)

@@ -138,10 +138,12 @@ def test_edge_case_smallest_tree_and_single_segment_branches(segs):
                 assert rc == 0
                 _same(got[r], want, 4, mapping)
     lefts, rights, d = api.eigen_decompose(Q)
-    got = api.sumstatEXP(z, Q, pid, 100, seed=8)
     want, rc = O.maketreelistEXP(z, Q, pid, nen, nodelist, root, 100, lefts, rights, d, seed=8)
     assert rc == 0
-    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(api.sumstatEXP(z, Q, pid, 100, seed=8, mapping="replicas"), want)
+    got = api.sumstatEXP(z, Q, pid, 100, seed=8)          # automatic: one wave per (tile, branch), dwell sums in fixed point
+    np.testing.assert_array_equal(got[:, 4:], want[:, 4:])
+    np.testing.assert_allclose(got[:, :4], want[:, :4], rtol=1e-10, atol=0)
 
 
 def test_edge_case_zero_length_segments_and_omega_on_the_boundary():

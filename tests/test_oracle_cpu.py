@@ -295,6 +295,33 @@ def test_exp_oracle_equals_python_restatement(n):
     np.testing.assert_array_equal(got3, got)
 
 
+def test_forced_normalisation_of_the_plain_and_sparse_drivers():
+    """ORC_FORCE_NORMALISE: the plain driver with its rows rescaled IS the _bigtree driver; the SPARSE driver keeps its thresholded
+    chain matrix; on a small tree (no underflow) the rescaled drivers draw the same histories as the un-rescaled ones."""
+    Q = synth.config_Q(2)
+    Omega = 1.25 * float(np.max(np.abs(np.diag(Q))))
+    pid = np.full(4, 0.25)
+    z = synth.make_tree(30, Q, Omega, 4321, pid)
+    nen, nodelist, root = _orders(z)
+    B = np.eye(4) + Q / Omega
+    run = lambda v: O.maketreelistMCMC(z, Q, pid, B, Omega, nen, nodelist, root, 12, variant=v, seed=6)
+    big, rc = run(O.BIGTREE); assert rc == 0
+    forced, rc = run(O.PLAIN | O.FORCE_NORMALISE); assert rc == 0
+    np.testing.assert_array_equal(big, forced)
+    plain, rc = run(O.PLAIN); assert rc == 0
+    np.testing.assert_array_equal(plain[:, 4:], forced[:, 4:])
+    sp, rc = run(O.SPARSE); assert rc == 0
+    spf, rc = run(O.SPARSE | O.FORCE_NORMALISE); assert rc == 0
+    np.testing.assert_array_equal(sp[:, 4:], spf[:, 4:])
+    z5, Q5, pid5, Om5 = synth.config_problem(5)
+    n5 = _orders(z5)
+    _, rc = O.maketreelistMCMC(z5, Q5, pid5, np.eye(20) + Q5 / Om5, Om5, *n5, 2, variant=O.SPARSE, seed=1)
+    assert rc & O.ERR_ZERO_PROB                        # 5 000 tips: the SPARSE driver underflows ...
+    out, rc = O.maketreelistMCMC(z5, Q5, pid5, np.eye(20) + Q5 / Om5, Om5, *n5, 2, variant=O.SPARSE | O.FORCE_NORMALISE, seed=1)
+    assert rc == 0                                     # ... rescaled it runs
+    np.testing.assert_allclose(out[:, :20].sum(1), z5["edge.length"].sum(), rtol=1e-12)
+
+
 def test_exp_rescaled_pruning_survives_a_thousand_tips():
     """makePLexp has no rescaling (src/phylomap.cpp:2899-2906): at 1 000 tips the plain sampler's root vector underflows
     (RcppArmadillo::sample would throw); with the rows rescaled the same sampler runs and conserves the tree length."""
