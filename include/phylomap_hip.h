@@ -105,14 +105,14 @@ typedef struct phm_options {
                                        1 = one lane per replica, one wave per 64-replica tile walks the tree (largest replica counts),
                                        2 = one lane per branch of one chain (a handful of chains, large trees),
                                        3 = one wave per (64-replica tile, branch) (10^2 .. 10^5 replicas);
-                                       for 5..64 states (one state per lane): 1 = one wave per 64-replica tile, replicas in turn,
-                                       2 or 3 = one wave per (replica, branch) (the automatic choice while its memory fits).
                                        Same draws and counts in every mapping; dwell sums differ in the last bits between
                                        1 and 2/3 (summation order).  cap_tail defaults to 1e-12 for 2 and 3 (fixed slots).
                                        5..64 states: 1 = one wave per 64-replica tile, replicas in turn, lanes = states (phm_wide.hip),
                                        2 = one wave per (replica, branch), lanes = states (a handful of chains),
                                        3 = one lane per replica, one wave per (tile, item), pruning on the matrix cores (the default
-                                       beyond 16 replicas at 20 states ... 100 at 61 states, the measured crossover with 2)
+                                       beyond 8 replicas at 20 states, always at 61 states: the measured crossover with 2);
+                                       bits 8-9 (measurement aid, mapping 3): form of the pruning kernel, 0 = by tile count,
+                                       1 = one wave per (node, tile), 2 = one workgroup / wave per 16-replica block (same bits)
                                        phm_maketreelistEXP: 0 or 3 = one wave per (tile of 64 samples, branch) (the default), 1 = one
                                        wave per tile of 64 samples walks the tree (dwell sums then add in the reference's order)
                                   [2]: 1 = record HIP events between the phases of a sweep (phm_engine_phase_ms)

@@ -190,7 +190,8 @@ MAPPING = {"auto": 0, "replicas": 1, "branches": 2, "tiles": 3}
 
 
 def make_options(seed=0, n_replicas=1, replica_offset=0, reduce=False, tips_per_replica=False, device=-1,
-                 iters_per_launch=0, cap_tail=0.0, storage=0, mapping="auto", phase_timing=False, rescale=False, recover=True):
+                 iters_per_launch=0, cap_tail=0.0, storage=0, mapping="auto", phase_timing=False, rescale=False, recover=True,
+                 pruning_form=0):
     """``mapping``: how a sweep is laid over the lanes -- "replicas" (one lane per chain: the throughput layout for many
     replicas), "branches" (one lane per branch, n <= 4; one wave per (replica, branch) for 5..64 states: few chains on a large
     tree), "tiles" (lanes = replicas, one wave per tile of 64 replicas and branch: 10^2 .. 10^5 replicas) or "auto"."""
@@ -198,7 +199,7 @@ def make_options(seed=0, n_replicas=1, replica_offset=0, reduce=False, tips_per_
     o.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
     o.n_replicas, o.replica_offset, o.reduce = int(n_replicas), int(replica_offset), int(bool(reduce))
     o.reserved[0] = int(storage)          # 0 automatic, 1 ring, 2 two buffers
-    o.reserved[1] = MAPPING[mapping] if isinstance(mapping, str) else int(mapping)
+    o.reserved[1] = (MAPPING[mapping] if isinstance(mapping, str) else int(mapping)) | (int(pruning_form) & 3) << 8      # pruning_form: 5..64 states, tiles: 1 a wave per (node, tile), 2 16-replica blocks, 0 by tile count
     o.reserved[2] = int(bool(phase_timing))
     o.reserved[3] = int(bool(rescale))      # sumstatEXP: rescaled pruning pass
     o.reserved[5] = 0 if recover else 1     # capacity recovery (rebuild with doubled slots + replay)

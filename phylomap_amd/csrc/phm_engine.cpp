@@ -18,10 +18,11 @@ namespace {
 constexpr int NARROW_AUTO_MAX_REPLICAS = 95;
 constexpr int TILES_AUTO_MAX_REPLICAS = 262144;
 // 5..64 states: a wave per (replica, branch) (phm_wbranch.hip) exposes S x E waves whatever S is; the lane-per-replica mapping
-// (phm_wtiles.hip) needs whole tiles of 64 replicas and pays a fixed serial cost per tree level (one tile: 2.25 ms per sweep on
-// C4, 1.28 ms on C5, with a wave per 16-replica block in the pruning pass).  Measured crossover
-// (profiles/r02_probe_small_S_C{4,5}.log): 16 replicas at 20 states, about 100 at 61 states -- interpolated linearly in n.
-inline int wbranch_auto_max_replicas(int n) { return std::max(8, std::min(128, (int)(16.0 + 2.05 * (n - 20)))); }
+// (phm_wtiles.hip) needs whole tiles of 64 replicas and pays a fixed serial cost per tree level (one tile: 1.25 ms per sweep on
+// C4, 1.06 ms on C5, with the pruning products of a 16-replica block split over a wave per row block).  Measured crossover
+// (profiles/r02_probe_small_S_C{4,5}.log): 8 replicas at 20 states, none at 61 states (1.28 ms for one chain there) --
+// interpolated linearly in n.
+inline int wbranch_auto_max_replicas(int n) { return std::max(0, std::min(8, 8 - (n - 20) / 5)); }
 
 bool ks_layout(int v) { return v == PHM_MCMC_KS || v == PHM_MCMC_BF || v == PHM_MCMC_MT || v == PHM_MCMC_KSMT; }   // n x n counts, root column
 bool hidden_rates(int v) { return v == PHM_MCMC_KS || v == PHM_MCMC_KSMT; }                                         // parity tip masks
@@ -645,6 +646,7 @@ int32_t wtiles_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
   // branches per wave of the branch kernel: one while waves are scarce, up to 8 once there are 65 536 of them anyway
   p.group = (int32_t)std::max<int64_t>(1, std::min<int64_t>(8, (int64_t)tiles * E / 65536));
   p.n_groups = (E + p.group - 1) / p.group;
+  p.up_form = (o.reserved[1] >> 8) & 3;
   p.seed_lo = (uint32_t)(o.seed & 0xFFFFFFFFull); p.seed_hi = (uint32_t)(o.seed >> 32);
   p.rows = rows;
   {   // dwell accumulators: 64-bit fixed point, a replica's column never exceeds the tree length
@@ -817,14 +819,15 @@ int32_t phm_engine_create_multi(const phm_tree* trees, int32_t n_trees, const ph
   // Mapping of the sweep onto lanes (reserved[1]: 0 automatic, 1 one lane per replica, 2 one lane per branch): with few
   // chains the replica mapping would leave all but a handful of lanes idle and walk the tree sequentially.
   const bool small_n = !e->wide && n_trees == 1;
-  const bool auto_map = o.reserved[1] == 0 && o.reserved[0] == 0;      // a ring / two-buffer request names the replica layout
-  if ((o.reserved[1] == 2 || o.reserved[1] == 3) && n_trees != 1) return fail(PHM_ERR_UNSUPPORTED, "the branch-parallel mappings take a single tree");
+  const int map_req = o.reserved[1] & 0xff;      // bits 8-9: form of the wide-state pruning kernel (measurement / tests)
+  const bool auto_map = map_req == 0 && o.reserved[0] == 0;      // a ring / two-buffer request names the replica layout
+  if ((map_req == 2 || map_req == 3) && n_trees != 1) return fail(PHM_ERR_UNSUPPORTED, "the branch-parallel mappings take a single tree");
   if (e->wide) {      // 5..64 states: lane = replica, wave per (tile, item) (phm_wtiles.hip); a handful of chains: wave per (replica, branch)
-    e->tiled = n_trees == 1 && (o.reserved[1] == 3 || (auto_map && e->S > wbranch_auto_max_replicas(n)));
-    e->narrow = n_trees == 1 && !e->tiled && (o.reserved[1] == 2 || auto_map);
+    e->tiled = n_trees == 1 && (map_req == 3 || (auto_map && e->S > wbranch_auto_max_replicas(n)));
+    e->narrow = n_trees == 1 && !e->tiled && (map_req == 2 || auto_map);
   } else {
-    e->narrow = small_n && (o.reserved[1] == 2 || (auto_map && e->S <= NARROW_AUTO_MAX_REPLICAS));
-    e->tiled = small_n && !e->narrow && (o.reserved[1] == 3 || (auto_map && e->S <= TILES_AUTO_MAX_REPLICAS));
+    e->narrow = small_n && (map_req == 2 || (auto_map && e->S <= NARROW_AUTO_MAX_REPLICAS));
+    e->tiled = small_n && !e->narrow && (map_req == 3 || (auto_map && e->S <= TILES_AUTO_MAX_REPLICAS));
   }
   if (e->narrow && e->S > 65535) {      // the replica index is the grid's y dimension in these kernels
     if (!auto_map) return fail(PHM_ERR_UNSUPPORTED, "the one-lane-per-branch / wave-per-(replica, branch) mappings take at most 65 535 replicas");

@@ -12,7 +12,8 @@
 // step's B-operand slice (row = 4 * reg-block + lane group), so a chain never leaves the register file, and each replica
 // keeps the product of its own step m - 1 (segment counts differ per replica).
 //   up     : one launch per HEIGHT level, a wave per (node, tile): four 16-replica MFMA blocks,   makePLrcpp* :503-529   [MFMA]
-//            replicas dealt to the blocks in the order of their chain lengths
+//            replicas dealt to the blocks in the order of their chain lengths; with few tiles a
+//            workgroup per (node, tile, block), a wave per 16-state row block of the products
 //   root   : a wave per tile                                                               :618-627
 //   down   : one launch per DEPTH level, a wave per (tile, edge)                           :640-657, :460-475
 //   branch : a wave per (tile, group of branches)                                          :264-413, :44-73, :745-757
@@ -34,7 +35,7 @@
 namespace phm {
 
 constexpr int WT_BLOCK = 256;
-constexpr int WT_FEW_TILES = 112;       // below this many tiles the pruning pass runs a wave per 16-replica block (latency) instead of per tile (throughput)
+constexpr int WT_FEW_TILES = 112;       // n <= 16: below this many tiles the pruning pass runs a wave per 16-replica block (latency) instead of per tile (throughput)
 constexpr int WT_MAX_SLOTS = 96;        // possible transitions (non-zero entries of B) up to which the branch kernel counts in LDS
 
 struct WtParams {
@@ -44,6 +45,7 @@ struct WtParams {
   int32_t normalise, tips_per_replica, ks, tip_masks, reduce, n_cols;
   int32_t klong;                             // rows of the chain tables
   int32_t group, n_groups;                   // branches walked by one wave of the branch kernel; ceil(n_edge / group)
+  int32_t up_form;                           // pruning kernel: 0 chosen by tile count, 1 a wave per (node, tile), 2 split into 16-replica blocks
   uint32_t seed_lo, seed_hi;
   int64_t rows;                              // rows of one tile in one dwell buffer (sum of the slot sizes)
   double fx_scale, fx_inv;                   // fixed-point scale of the dwell accumulators and its inverse (powers of two)

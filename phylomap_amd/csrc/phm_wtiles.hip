@@ -232,7 +232,8 @@ __global__ __launch_bounds__(WT_BLOCK) void wt_up_kernel(WtParams p, int begin, 
 // tile a height level of the kernel above is a single wave working through four blocks and two children (C4: 168 us per level,
 // 84 % of a 4.6 ms sweep); here the four blocks run on four waves.  With many tiles the sorted blocks of the kernel above win
 // (a block runs to the longest of its 16 chains: 31 against 38 ms per sweep on C4 at 65 536 replicas); measured crossover:
-// 128 tiles on C4, about 80 on C5 (profiles/r02_probe_few_tiles.log).
+// 128 tiles on C4, about 80 on C5 (profiles/r02_probe_few_tiles.log).  Used for n <= 16 (one row block); with two or more
+// row blocks the row-split workgroups of wt_up_msplit_kernel are faster still.
 template <int MT>
 __global__ __launch_bounds__(WT_BLOCK) void wt_up_blocks_kernel(WtParams p, int begin, int end) {
   constexpr int KS = 4 * MT;
@@ -332,6 +333,105 @@ __global__ __launch_bounds__(WT_BLOCK) void wt_up_blocks_kernel(WtParams p, int 
         const int row = 16 * i + lk + 4 * q;
         if (row < n) PLt[((size_t)st.parent * n + row) * 64 + j] = P[i][q];
       }
+  }
+  if (err) atomicOr(p.err, err);
+}
+
+// The pruning step for FEW tiles, latency form: a WORKGROUP per (node, tile, 16-replica block), wave w of it owning row block
+// w (16 output states) of every product.  A chain step is then 4 MT MFMAs per wave instead of 4 MT^2 -- a third of the
+// latency at 61 states -- at the price of passing the vectors through LDS between steps (the B-operand slices of a step are
+// the rows all waves wrote in the step before) and of a barrier per step; the fragments of Bc a wave keeps shrink to its own
+// row block (16 registers pairs at 61 states).  Same products, same order of additions, same bits as the kernels above.
+template <int MT>
+__global__ __launch_bounds__(64 * MT) void wt_up_msplit_kernel(WtParams p, int begin, int end) {
+  constexpr int KS = 4 * MT, NP = 16 * MT;
+  __shared__ double sX[2][NP * 16];                     // [buffer][state][replica column]
+  __shared__ double sP[NP * 16];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int n = p.n_states, ldt = p.ldt;
+  double Af[KS];                                        // row block w of the chain matrix as A-operand fragments
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int row = 16 * w + lr, k = 4 * s + lk;
+    Af[s] = (row < n && k < n) ? p.Bc[row * n + k] : 0.0;
+  }
+  const int n_lvl = end - begin;
+  const int64_t items = (int64_t)n_lvl * p.n_tiles * 4;
+  const int ks_used = (n + 3) >> 2;
+  uint32_t err = 0;
+  for (int64_t item = blockIdx.x; item < items; item += gridDim.x) {
+    const int nt = (int)(item & 3);
+    const int64_t q4 = item >> 2;
+    const int tile = (int)(q4 % p.n_tiles), li = (int)(q4 / p.n_tiles);
+    const UpStep st = p.up[p.up_order[begin + li]];
+    double* __restrict__ PLt = p.PL + (size_t)tile * p.n_node * n * 64;
+    const uint16_t* __restrict__ mct = p.mcount + (size_t)tile * p.n_edge * 64;
+    const uint8_t* __restrict__ tips_t = p.tips_per_replica ? p.tips + (size_t)tile * p.n_tips * 64 : p.tips;
+    // (blocks in replica order: dealing the replicas to the blocks by chain length, as the per-tile kernel does, was measured here
+    //  too -- the rank computation and the 8-byte gathers it forces cost more than the shorter chains return: 0.66 vs 0.77 G/s on C4
+    //  at 4 096 replicas)
+    const int j = 16 * nt + lr;                        // this lane's replica within the tile (the same in every wave)
+    d4_t R[2];
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {                   // ch 0: "first" = child[1] (:508); ch 1: "second" = child[0] (:509)
+      const int child = st.child[1 - ch], edge = st.edge[1 - ch];
+      int k = (int)mct[edge * 64 + j] - 1;
+      if (child < 0) {
+        const int tip = ~child;
+        const int ts = p.tips_per_replica ? tips_t[tip * 64 + j] : p.tips[tip];
+        if (k >= p.klong) { err |= DERR_CAPACITY; k = p.klong - 1; }
+        const double* __restrict__ src = p.tip_masks ? p.maskL + ((size_t)k * 2 + (ts & 1)) * ldt : p.colL + ((size_t)k * n + ts) * ldt;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = 16 * w + lk + 4 * q;
+          R[ch][q] = (row < n) ? src[row] : 0.0;
+        }
+      } else {
+        d4_t x;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = 16 * w + lk + 4 * q;
+          x[q] = (row < n) ? PLt[((size_t)child * n + row) * 64 + j] : 0.0;
+          sX[0][row * 16 + lr] = x[q];
+        }
+        R[ch] = x;
+        const int kmax = wave_max_count(k);            // the same 16 chain lengths in every wave of the workgroup
+        __syncthreads();
+        for (int step = 1; step <= kmax; ++step) {
+          const int cur = (step - 1) & 1;
+          d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int s = 0; s < KS; ++s)
+            if (s < ks_used) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Af[s], sX[cur][(4 * s + lk) * 16 + lr], acc, 0, 0, 0);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) sX[cur ^ 1][(16 * w + lk + 4 * q) * 16 + lr] = acc[q];
+          if (k == step) R[ch] = acc;
+          __syncthreads();
+        }
+      }
+    }
+    d4_t P = R[0] * R[1];                                                       // :510
+    if (p.normalise) {                                                         // :525
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sP[(16 * w + lk + 4 * q) * 16 + lr] = P[q];
+      __syncthreads();
+      double t = 0.0;                                  // states lk, lk + 4, lk + 8, ... ascending: partial sum t_lk
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t += sP[(16 * i + lk + 4 * q) * 16 + lr];
+      t = t + __shfl_xor(t, 16, 64);
+      t = t + __shfl_xor(t, 32, 64);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) P[q] = P[q] / t;
+      __syncthreads();                                 // sP is rewritten by the next item
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = 16 * w + lk + 4 * q;
+      if (row < n) PLt[((size_t)st.parent * n + row) * 64 + j] = P[q];
+    }
   }
   if (err) atomicOr(p.err, err);
 }
@@ -733,11 +833,19 @@ void launch_up_levels(const WtParams& p, const std::vector<int32_t>& up_off, hip
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wt_up_kernel<MT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  const bool few_tiles = p.n_tiles < WT_FEW_TILES;      // not enough (node, tile) items to fill the chip: split them into blocks
+  // Measured crossovers (profiles/r02_probe_few_tiles.log): the row-split workgroups win below about 64 tiles at 20 states and
+  // below about 512 tiles at 61 states; the sorted blocks of the per-tile kernel beyond.
+  const int msplit_tiles = MT == 2 ? 64 : MT == 3 ? 192 : 512;
+  const bool few_tiles = p.n_tiles < WT_FEW_TILES;      // n <= 16 (one row block): not enough (node, tile) items to fill the chip -> a wave per block
   for (size_t l = 0; l + 1 < up_off.size(); ++l) {
     const int cnt = up_off[l + 1] - up_off[l];
     if (cnt <= 0) continue;
-    if (few_tiles) {
+    const bool split = p.up_form == 2 || (p.up_form == 0 && (MT >= 2 ? p.n_tiles < msplit_tiles : few_tiles));
+    if (MT >= 2 && split) {
+      const int64_t items = (int64_t)cnt * p.n_tiles * 4;    // a workgroup of MT waves per (node, tile, block)
+      const unsigned grid = (unsigned)std::min<int64_t>(items, 4096);
+      hipLaunchKernelGGL(wt_up_msplit_kernel<MT>, dim3(grid), dim3(64 * MT), 0, stream, p, up_off[l], up_off[l + 1]);
+    } else if (split) {
       const int64_t items = (int64_t)cnt * p.n_tiles * 4;    // a wave per (node, tile, block)
       const unsigned grid = (unsigned)std::min<int64_t>((items + 3) / 4, 2048);
       hipLaunchKernelGGL(wt_up_blocks_kernel<MT>, dim3(grid), dim3(WT_BLOCK), 0, stream, p, up_off[l], up_off[l + 1]);

@@ -210,15 +210,17 @@ def test_exp_rescaled_pruning_at_c2_size_and_equal_to_plain_on_small_trees():
     np.testing.assert_allclose(got5[:, :20], want5[:, :20], rtol=1e-10, atol=0)
 
 
-@pytest.mark.parametrize("cfg,S", [(4, 1024), (5, 640), (4, 7232), (5, 7232)])      # 16 / 10 tiles: a wave per 16-replica block; 113 tiles: sorted blocks per (node, tile)
-def test_wide_lane_per_replica_mapping_with_many_tiles(cfg, S):
+# 16 / 10 tiles: a workgroup per 16-replica block, a wave per 16-state row block; 113 tiles: the same at 61 states, sorted blocks
+# per (node, tile) at 20; forms 1 / 2: each pruning kernel at a tile count the automatic choice gives to the other
+@pytest.mark.parametrize("cfg,S,form", [(4, 1024, 0), (5, 640, 0), (4, 7232, 0), (5, 7232, 0), (4, 7232, 1), (5, 7232, 2), (4, 192, 1)])
+def test_wide_lane_per_replica_mapping_with_many_tiles(cfg, S, form):
     """phm_wtiles.hip beyond a couple of tiles: persistent pruning waves striding over (node, tile) items, branch groups per
     workgroup, per-tile accumulators -- C4 / C5 at their stated sizes with 16 / 10 tiles, replicas from different tiles and
     different 16-column MFMA blocks against the oracle, tree-length invariant on every replica and sweep."""
     z, Q, pid, Omega, nen, nodelist, root = _config(cfg)
     n = Q.shape[0]
     N, seed = 6, 900 + cfg
-    eng = _lib.Engine(z, Q, pid, Omega, N, variant=_lib.PHM_MCMC_BIGTREE, seed=seed, n_replicas=S, mapping="tiles")
+    eng = _lib.Engine(z, Q, pid, Omega, N, variant=_lib.PHM_MCMC_BIGTREE, seed=seed, n_replicas=S, mapping="tiles", pruning_form=form)
     eng.run(N); eng.sync()
     st = eng.stats(0, N)
     for r in (0, 17, 64 + 33, S // 2 + 50, S - 1):
@@ -228,7 +230,7 @@ def test_wide_lane_per_replica_mapping_with_many_tiles(cfg, S):
     np.testing.assert_allclose(st[:, :, :n].sum(2), z["edge.length"].sum(), rtol=1e-11)
     assert np.all(st[:, :, n:] == np.round(st[:, :, n:]))
     # the reduced output (sum over replicas per sweep) equals the sum of the per-replica rows
-    red = _lib.Engine(z, Q, pid, Omega, N, variant=_lib.PHM_MCMC_BIGTREE, seed=seed, n_replicas=S, mapping="tiles", reduce=True)
+    red = _lib.Engine(z, Q, pid, Omega, N, variant=_lib.PHM_MCMC_BIGTREE, seed=seed, n_replicas=S, mapping="tiles", reduce=True, pruning_form=form)
     red.run(N); red.sync()
     tot = red.stats(0, N)
     red.close()
