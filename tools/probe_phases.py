@@ -1,0 +1,16 @@
+"""ms per sweep and per phase (pruning, node draws, branch kernel, reductions) of a (tile, item) mapping: python tools/probe_phases.py cfg S [iters]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from phylomap_amd import _lib, synth
+cfg = int(sys.argv[1]); S = int(sys.argv[2]); N = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+z, Q, pid, Om = synth.config_problem(cfg)
+E = z["edge"].shape[0]
+eng = _lib.Engine(z, Q, pid, Om, N + 10, variant=_lib.PHM_MCMC_BIGTREE, seed=1, n_replicas=S, reduce=True, mapping="tiles", phase_timing=True)
+eng.run(10); eng.sync()
+i0 = eng.info()
+eng.run(N); eng.sync()
+i1 = eng.info()
+ph = [x / N for x in eng.phase_ms()]
+seg = (i1.seg_read - i0.seg_read) / (E * S * N)
+print(f"C{cfg} S={S}: {i1.last_run_ms / N:.2f} ms/sweep = {E * S * N / (i1.last_run_ms / 1e3) / 1e9:.3f} G/s; phases up/down/branch/red = " + " / ".join(f"{x:.2f}" for x in ph) + f"; mean(m+m')={seg:.2f}")
+eng.close()
