@@ -28,9 +28,11 @@ hipError_t launch_expm_eigen_mfma(int n, const double* L, const double* R, const
 hipError_t launch_expm_pade(int n, const double* Q, const double* t, const int32_t* s, int n_t, double* work,
                             double* out, uint32_t* err, hipStream_t stream);
 
-// the same on the matrix cores (16 < n <= 64): Pade powers and squarings as MFMA f64 products, solve(D,E) in LDS
+// the same on the matrix cores (16 < n <= 64): Pade powers, block Gauss-Jordan solve(D,E) and squarings as MFMA f64 products.
+// bad[b] (n_t ints, zeroed by the caller) is set for a matrix with a pivot below piv_min in a diagonal block (out[b] is then
+// not written): the caller hands those to launch_expm_pade.
 hipError_t launch_expm_pade_mfma(int n, const double* Q, const double* t, const int32_t* s, int n_t, double* out,
-                                 uint32_t* err, hipStream_t stream);
+                                 int32_t* bad, double piv_min, hipStream_t stream);
 
 // PL[parent] = (P_a PL[child_a]) (.) (P_b PL[child_b]); PL is (2T-1) x n row-major, tips pre-filled one-hot;
 // rescale: every internal row divided by its sum (not in the reference; the node draws do not depend on a row's scale)

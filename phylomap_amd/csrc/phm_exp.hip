@@ -829,49 +829,48 @@ __global__ __launch_bounds__(256) void expm_eigen_mfma_kernel(int n, const doubl
 // One workgroup (4 waves) per matrix; wave w owns the 16-column block w of every intermediate.  With A as the left
 // operand, the powers X <- A X never leave registers: an MFMA result tile (col = l&15, row = (l>>4) + 4 reg) is
 // exactly the B-operand slice layout (k = 4 s + (l>>4)), so register `reg` of row block kb feeds k-step 4 kb + reg.
-// solve(D, E) runs in LDS (partial pivoting), the squarings re-read the result from LDS in both operand layouts.
-// Fused k-slices: agrees with the exact kernel to rounding (tests: <= 1e-13), not bit for bit.
+// Q is staged in LDS once per workgroup (every matrix of the batch is Q times a scalar); solve(D, E) is a block Gauss-Jordan
+// elimination in registers (16 x 16 diagonal blocks inverted in LDS by one wave); the squarings re-read the result from LDS in
+// both operand layouts.  78.8 KB of LDS and 256 registers: two workgroups per CU.
+// Fused k-slices: agrees with the exact kernel to rounding (tests: <= 2e-13), not bit for bit.  A matrix with a small pivot
+// in a diagonal block is flagged in `bad` and left to the pivoted kernel by the caller.
 // ------------------------------------------------------------------------------------------------
-constexpr int PADE_LDP = 65;      // padded LDS row stride (doubles)
+constexpr int PADE_LDP = 66;      // LDS row stride (doubles): the A-operand reads (row = lane & 15, k = lane >> 4) hit 32 distinct banks per half wave
 
-__global__ __launch_bounds__(256) void expm_pade_mfma_kernel(int n, const double* __restrict__ Q,
+__global__ __launch_bounds__(256, 2) void expm_pade_mfma_kernel(int n, const double* __restrict__ Q,
                                                              const double* __restrict__ t,
                                                              const int32_t* __restrict__ sq, int n_t,
-                                                             double* __restrict__ out, uint32_t* err) {
+                                                             double* __restrict__ out, int32_t* __restrict__ bad, double piv_min) {
   extern __shared__ __align__(16) unsigned char smem[];
-  double* sD = reinterpret_cast<double*>(smem);                  // [64][PADE_LDP]
-  double* sE = sD + 64 * PADE_LDP;                               // [64][PADE_LDP]  (E, then the solution Y)
-  __shared__ double fv[64];
-  __shared__ int s_piv, s_bad;
-  __shared__ double sCol[64 * 17], sA[16 * 17], sW[16 * 17];      // block Gauss-Jordan: a column block of D, the diagonal block, its inverse
+  double* sQ = reinterpret_cast<double*>(smem);                  // [64][PADE_LDP]  Q, zero-padded to 64 x 64
+  double* sE = sQ + 64 * PADE_LDP;                               // [64][PADE_LDP]  Y = solve(D, E), then its squares
+  __shared__ int s_bad;
+  __shared__ double sCol[64 * 17], sA[16 * 17], sW[16 * 17];     // block Gauss-Jordan: a column block of D, the diagonal block, its inverse
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, tid = threadIdx.x;
   const int rb = (n + 15) >> 4;
   const int lr = lane & 15, lk = lane >> 4;
   const int mycol = 16 * w + lr;
 
+  for (int e = tid; e < 64 * 64; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    sQ[r * PADE_LDP + c] = (r < n && c < n) ? Q[r * n + c] : 0.0;
+  }
+  __syncthreads();
+
   for (int b = blockIdx.x; b < n_t; b += gridDim.x) {
-    const double tb = t[b];
     const int s = sq[b];
-    const double inv_sc = ldexp(1.0, -s);
+    const double sc = t[b] * ldexp(1.0, -s);                     // A = Q t / 2^s (the power of two is exact: same bits as (Q t) / 2^s)
     d4_t X[4], Em[4], Dm[4], T[4];
-    {   // every wave fills its column block (blocks beyond n carry the identity), so the LDS images have no holes
-      double Af[4][16];                                          // A = Q t / 2^s, A-operand fragments
-#pragma unroll
-      for (int sI = 0; sI < 16; ++sI) {
-        const int k = 4 * sI + lk;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int row = 16 * i + lr;
-          Af[i][sI] = (row < n && k < n) ? (Q[row * n + k] * tb) * inv_sc : 0.0;
-        }
-      }
+    {   // every wave fills its column block (blocks beyond n carry the identity)
+      // A^k = sc^k Q^k: the products run on the unscaled Q straight from LDS (A-operand fragments read as they are used, so no
+      // 128 registers of fragments: the kernel stays within 256 and two workgroups share a CU), each result scaled once
       double c = 0.5;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int row = 16 * i + lk + 4 * q;
-          const double a = (row < n && mycol < n) ? (Q[row * n + mycol] * tb) * inv_sc : 0.0;
+          const double a = sQ[row * PADE_LDP + mycol] * sc;
           const double dg = (row == mycol) ? 1.0 : 0.0;
           X[i][q] = a;
           Em[i][q] = c * a + dg;
@@ -880,67 +879,61 @@ __global__ __launch_bounds__(256) void expm_pade_mfma_kernel(int n, const double
       bool positive = true;
       for (int pw = 2; pw <= 6; ++pw) {
         c = c * (double)(6 - pw + 1) / (double)(pw * (2 * 6 - pw + 1));
+        int frag = lr * PADE_LDP + lk;
+        asm volatile("" : "+v"(frag));                 // a fresh value every round: the fragment reads stay in the loop (hoisted, they are 128 registers)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           d4_t acc = {0.0, 0.0, 0.0, 0.0};
           if (i < rb && w < rb) {
 #pragma unroll
-            for (int sI = 0; sI < 16; ++sI) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Af[i][sI], X[sI >> 2][sI & 3], acc, 0, 0, 0);
+            for (int sI = 0; sI < 16; ++sI)
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sQ[frag + 16 * i * PADE_LDP + 4 * sI], X[sI >> 2][sI & 3], acc, 0, 0, 0);
           }
           T[i] = acc;
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          X[i] = T[i];
-          Em[i] += c * T[i];
-          if (positive) Dm[i] += c * T[i]; else Dm[i] -= c * T[i];
+          X[i] = sc * T[i];
+          Em[i] += c * X[i];
+          if (positive) Dm[i] += c * X[i]; else Dm[i] -= c * X[i];
         }
         positive = !positive;
       }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int row = 16 * i + lk + 4 * q;
-          sD[row * PADE_LDP + mycol] = Dm[i][q];
-          sE[row * PADE_LDP + mycol] = Em[i][q];
-        }
     }
-    __syncthreads();
 
-    // ---- solve D Y = E, fast path: block Gauss-Jordan, 16 x 16 blocks, on the matrix cores --------------------------------
-    // D = I -+ A/2 + ... of a scaled A is close to the identity, so its 16 x 16 diagonal blocks can be inverted without row
-    // exchanges; a pivot below 1e-3 (a badly scaled input) abandons the fast path for the pivoted elimination in LDS below.
-    // Step k: wave k publishes its column block of D, inverts the diagonal block (Gauss-Jordan in LDS, one wave) -> W; every
+    // ---- solve D Y = E: block Gauss-Jordan, 16 x 16 blocks, on the matrix cores ------------------------------------------
+    // No row exchanges between blocks: D = I -+ A/2 + ... of a rate matrix times a time has its eigenvalues right of 1 and a
+    // dominant diagonal; a pivot below piv_min (1e-3) flags the matrix for the pivoted kernel instead.
+    // Step k: wave k publishes its column block of D and inverts the diagonal block (Gauss-Jordan in LDS, one wave) -> W; every
     // wave multiplies row block k of ITS column blocks of D and E by W (the result tile is a B-operand slice as it stands) and
-    // subtracts D_ik times that from every other row block i -- all in registers, three barriers per step instead of five per
-    // COLUMN.  After the last step E holds Y.
+    // subtracts D_ik times that from every other row block i -- all in registers, two barriers per step.  After the last step
+    // E holds Y.  (Newton-Schulz iterations W <- W (2 I - D_kk W) on the matrix cores were tried for the inversion: with
+    // arma's scaling, s = exponent(log2 ||A||) + 1, ||A / 2^s|| reaches 1 - 4, D_kk is far from the identity and the
+    // iteration needs 6 - 8 steps of three dependent products from W = diag(D_kk)^-1 -- no faster than the elimination.)
     if (tid == 0) s_bad = 0;
-    __syncthreads();
 #pragma unroll
     for (int k = 0; k < 4; ++k) {                      // unrolled: the register tiles are indexed by k
       if (k >= rb) continue;                           // uniform over the workgroup (the barriers below are too)
+      __syncthreads();                                 // the previous step's (or matrix's) readers of sCol / sW are done
       if (w == k) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int q = 0; q < 4; ++q) sCol[(16 * i + lk + 4 * q) * 17 + lr] = Dm[i][q];
-      }
-      __syncthreads();
-      if (w == k) {                                    // invert D_kk: lane = (row r, four columns 4 cg .. 4 cg + 3)
+        // invert D_kk by Gauss-Jordan elimination in LDS: lane = (row r, four columns 4 cg .. 4 cg + 3) of [D_kk | I]
         const int r = lane & 15, cg = lane >> 4;
         double a[4], wv[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          a[c] = sCol[(16 * k + r) * 17 + 4 * cg + c];
+          a[c] = sCol[(16 * k + r) * 17 + 4 * cg + c];             // this wave's own writes, in order
           wv[c] = (r == 4 * cg + c) ? 1.0 : 0.0;
           sA[r * 17 + 4 * cg + c] = a[c];
           sW[r * 17 + 4 * cg + c] = wv[c];
         }
-        bool bad = false;
+        bool bad_piv = false;
         for (int pv = 0; pv < 16; ++pv) {
           const double piv = sA[pv * 17 + pv];
-          if (!(fabs(piv) >= 1e-3)) bad = true;
+          if (!(fabs(piv) >= piv_min)) bad_piv = true;
           const double inv = 1.0 / piv;
           const double f = sA[r * 17 + pv];
           double pa[4], pw[4];
@@ -954,7 +947,7 @@ __global__ __launch_bounds__(256) void expm_pade_mfma_kernel(int n, const double
             sW[r * 17 + 4 * cg + c] = wv[c];
           }
         }
-        if (bad) s_bad = 1;
+        if (bad_piv) s_bad = 1;
       }
       __syncthreads();
       if (w < rb) {
@@ -992,61 +985,17 @@ __global__ __launch_bounds__(256) void expm_pade_mfma_kernel(int n, const double
           }
         }
       }
-      __syncthreads();
     }
-    const bool fallback = s_bad != 0;
-    if (!fallback) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) sE[(16 * i + lk + 4 * q) * PADE_LDP + mycol] = Em[i][q];
-    }
+      for (int q = 0; q < 4; ++q) sE[(16 * i + lk + 4 * q) * PADE_LDP + mycol] = Em[i][q];
     __syncthreads();
-
-    // ---- solve D Y = E in LDS (fallback): elimination with partial pivoting, then column-oriented back substitution ----
-    if (fallback) {
-    for (int col = 0; col < n; ++col) {
-      if (w == 0) {
-        double v = (lane >= col && lane < n) ? fabs(sD[lane * PADE_LDP + col]) : -1.0;
-        int idx = lane;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-          double ov = __shfl_xor(v, off, 64);
-          int oi = __shfl_xor(idx, off, 64);
-          if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-        }
-        if (lane == 0) { s_piv = idx; if (!(v > 0.0)) atomicOr(err, DERR_ZERO_PROB); }
-      }
+    if (s_bad) {                                       // uniform: left to the exact kernel
+      if (tid == 0) bad[b] = 1;
       __syncthreads();
-      const int piv = s_piv;
-      if (piv != col) {
-        if (tid < 64) { double a = sD[col * PADE_LDP + tid]; sD[col * PADE_LDP + tid] = sD[piv * PADE_LDP + tid]; sD[piv * PADE_LDP + tid] = a; }
-        else if (tid < 128) { int k = tid - 64; double a = sE[col * PADE_LDP + k]; sE[col * PADE_LDP + k] = sE[piv * PADE_LDP + k]; sE[piv * PADE_LDP + k] = a; }
-        __syncthreads();
-      }
-      if (tid > col && tid < n) fv[tid] = sD[tid * PADE_LDP + col] / sD[col * PADE_LDP + col];
-      __syncthreads();
-      const int nr = n - col - 1;
-      for (int e = tid; e < nr * 64; e += 256) {
-        const int r = col + 1 + (e >> 6), k = e & 63;
-        if (k < n) {
-          const double f = fv[r];
-          if (k >= col) sD[r * PADE_LDP + k] -= f * sD[col * PADE_LDP + k];
-          sE[r * PADE_LDP + k] -= f * sE[col * PADE_LDP + k];
-        }
-      }
-      __syncthreads();
+      continue;
     }
-    for (int r = n - 1; r >= 0; --r) {
-      if (tid < n) sE[r * PADE_LDP + tid] = sE[r * PADE_LDP + tid] / sD[r * PADE_LDP + r];
-      __syncthreads();
-      for (int e = tid; e < r * 64; e += 256) {
-        const int i = e >> 6, k = e & 63;
-        if (k < n) sE[i * PADE_LDP + k] -= sD[i * PADE_LDP + r] * sE[r * PADE_LDP + k];
-      }
-      __syncthreads();
-    }
-    }      // fallback
 
     // ---- s squarings: Y <- Y Y, operands re-read from LDS in A- and B-slice layouts ----
     for (int it = 0; it < s; ++it) {
@@ -1085,13 +1034,13 @@ __global__ __launch_bounds__(256) void expm_pade_mfma_kernel(int n, const double
 }
 
 hipError_t launch_expm_pade_mfma(int n, const double* Q, const double* t, const int32_t* s, int n_t, double* out,
-                                 uint32_t* err, hipStream_t stream) {
+                                 int32_t* bad, double piv_min, hipStream_t stream) {
   size_t lds = sizeof(double) * 2 * 64 * PADE_LDP;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(expm_pade_mfma_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   int grid = n_t < 1024 ? n_t : 1024;
-  hipLaunchKernelGGL(expm_pade_mfma_kernel, dim3(grid), dim3(256), lds, stream, n, Q, t, s, n_t, out, err);
+  hipLaunchKernelGGL(expm_pade_mfma_kernel, dim3(grid), dim3(256), lds, stream, n, Q, t, s, n_t, out, bad, piv_min);
   return hipGetLastError();
 }
 

@@ -65,19 +65,43 @@ static int32_t expm_pade_impl(bool mfma, int32_t n, const double* Q, const doubl
   std::vector<int32_t> sq(n_t);
   for (int b = 0; b < n_t; ++b) sq[b] = pade_squarings(Qr.data(), n, t[b]);
   const size_t nn = (size_t)n * n;
-  DevBuf dQ, dt, ds, dwork, dout, derr;
+  DevBuf dQ, dt, ds, dwork, dout, derr, dbad;
   HIPCHK(dQ.alloc(sizeof(double) * nn)); HIPCHK(dt.alloc(sizeof(double) * n_t)); HIPCHK(ds.alloc(sizeof(int32_t) * n_t));
   HIPCHK(dwork.alloc(mfma ? 16 : sizeof(double) * nn * 5 * n_t)); HIPCHK(dout.alloc(sizeof(double) * nn * n_t)); HIPCHK(derr.alloc(sizeof(uint32_t)));
   HIPCHK(hipMemcpy(dQ.p, Qr.data(), dQ.bytes, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(dt.p, t, dt.bytes, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(ds.p, sq.data(), ds.bytes, hipMemcpyHostToDevice));
   HIPCHK(hipMemset(derr.p, 0, sizeof(uint32_t)));
+  if (mfma) { HIPCHK(dbad.alloc(sizeof(int32_t) * n_t)); HIPCHK(hipMemset(dbad.p, 0, dbad.bytes)); }
+  // smallest pivot the unpivoted block elimination accepts (test aid: PHM_PADE_PIVOT_MIN=1e300 sends every matrix to the pivoted kernel)
+  double piv_min = 1e-3;
+  if (const char* ev = std::getenv("PHM_PADE_PIVOT_MIN")) piv_min = std::atof(ev);
   Timer tm;
   HIPCHK(hipEventCreate(&tm.a)); HIPCHK(hipEventCreate(&tm.b));
   HIPCHK(hipEventRecord(tm.a, nullptr));
-  if (mfma) HIPCHK(phm::launch_expm_pade_mfma(n, dQ.as<double>(), dt.as<double>(), ds.as<int32_t>(), n_t, dout.as<double>(), derr.as<uint32_t>(), nullptr));
+  if (mfma) HIPCHK(phm::launch_expm_pade_mfma(n, dQ.as<double>(), dt.as<double>(), ds.as<int32_t>(), n_t, dout.as<double>(), dbad.as<int32_t>(), piv_min, nullptr));
   else HIPCHK(phm::launch_expm_pade(n, dQ.as<double>(), dt.as<double>(), ds.as<int32_t>(), n_t, dwork.as<double>(), dout.as<double>(), derr.as<uint32_t>(), nullptr));
   HIPCHK(hipEventRecord(tm.b, nullptr));
+  if (mfma) {      // matrices the matrix-core kernel gave up on (a small pivot in a diagonal block of D): the pivoted kernel
+    std::vector<int32_t> badh(n_t);
+    HIPCHK(hipMemcpy(badh.data(), dbad.p, dbad.bytes, hipMemcpyDeviceToHost));
+    std::vector<int32_t> idx;
+    for (int b = 0; b < n_t; ++b) if (badh[b]) idx.push_back(b);
+    if (!idx.empty()) {
+      const int nb = (int)idx.size();
+      std::vector<double> tb(nb); std::vector<int32_t> sb(nb);
+      for (int i = 0; i < nb; ++i) { tb[i] = t[idx[i]]; sb[i] = sq[idx[i]]; }
+      DevBuf dt2, ds2, dwork2, dout2;
+      HIPCHK(dt2.alloc(sizeof(double) * nb)); HIPCHK(ds2.alloc(sizeof(int32_t) * nb));
+      HIPCHK(dwork2.alloc(sizeof(double) * nn * 5 * nb)); HIPCHK(dout2.alloc(sizeof(double) * nn * nb));
+      HIPCHK(hipMemcpy(dt2.p, tb.data(), dt2.bytes, hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(ds2.p, sb.data(), ds2.bytes, hipMemcpyHostToDevice));
+      HIPCHK(phm::launch_expm_pade(n, dQ.as<double>(), dt2.as<double>(), ds2.as<int32_t>(), nb, dwork2.as<double>(), dout2.as<double>(), derr.as<uint32_t>(), nullptr));
+      for (int i = 0; i < nb; ++i)
+        HIPCHK(hipMemcpy(dout.as<double>() + nn * idx[i], dout2.as<double>() + nn * i, sizeof(double) * nn, hipMemcpyDeviceToDevice));
+      HIPCHK(hipEventRecord(tm.b, nullptr));
+    }
+  }
   HIPCHK(hipMemcpy(out, dout.p, dout.bytes, hipMemcpyDeviceToHost));
   uint32_t derrh = 0;
   HIPCHK(hipMemcpy(&derrh, derr.p, sizeof derrh, hipMemcpyDeviceToHost));

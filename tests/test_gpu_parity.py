@@ -679,6 +679,20 @@ def test_expm_pade_on_matrix_cores(n):
         np.testing.assert_allclose(P_mfma[b].sum(1), 1.0, atol=1e-12)
 
 
+def test_expm_pade_on_matrix_cores_hands_small_pivots_to_the_pivoted_kernel(monkeypatch):
+    """A matrix whose block elimination meets a pivot below the threshold is flagged by the kernel and recomputed by the pivoted
+    one: with the threshold raised above every pivot the call returns the exact kernel's matrices bit for bit."""
+    Q = synth.dense_Q(61, 0.005, 0.015, seed=61)
+    t = np.concatenate([[0.0, 200.0], np.random.default_rng(3).exponential(3.0, 30)])
+    P_exact, _ = api.expm_pade(Q, t)
+    monkeypatch.setenv("PHM_PADE_PIVOT_MIN", "1e300")
+    P_fallback, _ = api.expm_pade(Q, t, mfma=True)
+    np.testing.assert_array_equal(P_fallback, P_exact)
+    monkeypatch.setenv("PHM_PADE_PIVOT_MIN", "1.2")      # some matrices (the ones scaled most) go each way
+    P_mixed, _ = api.expm_pade(Q, t, mfma=True)
+    np.testing.assert_allclose(P_mixed, P_exact, rtol=0, atol=2e-13)
+
+
 @pytest.mark.parametrize("mapping", MAPPINGS)
 def test_full_size_invariants(mapping):
     """BASELINE sizes, size-independent properties: dwell row sums = tree length; counts are integers;
