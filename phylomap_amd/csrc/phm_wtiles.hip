@@ -451,11 +451,15 @@ __global__ __launch_bounds__(WT_BLOCK) void wt_root_kernel(WtParams p, int it) {
 }
 
 // child ~ e_ps^T B^(m-1) (.) PL[child]   (Tvmmp :431-436, :651); ks: tips too, against their parity mask (:1384-1397).
-// The probability vector of a lane lives in registers (16 MT >= n of them): one pass forms it and its total, the second
-// walks the running sum -- the table row of a lane is read once, two states per 16-byte load.
+// Two passes over the lane's table row and the child's partial likelihoods, 8 or 16 states per round of loads: the first
+// forms the total, the second walks the running sum (the same products in the same order) and stops once every lane of the
+// wave has its state.  The kernel waits on memory (a lane's row is its own address): keeping the whole probability vector in
+// registers instead (128 of them at 61 states: two waves per SIMD) read every row once but ran 13.7 ms per sweep on C4 at 65 536
+// replicas, three waves 10.9, this form (55 - 130 registers) 6.8; C5: 5.6 -> 4.1 (profiles/r02_probe_few_tiles.log).
 template <int MT>
 __global__ __launch_bounds__(WT_BLOCK) void wt_down_kernel(WtParams p, int it, int begin, int end) {
   constexpr int NP = 16 * MT;
+  constexpr int CH = MT == 4 ? 32 : MT == 3 ? 16 : 8;   // states per round of loads (measured: 61 states 8.8 / 7.5 / 6.8 ms with 8 / 16 / 32, 20 states 4.1 / 4.4 with 8 / 16)
   const int lane = threadIdx.x & 63;
   const int item = blockIdx.x * (WT_BLOCK / 64) + (threadIdx.x >> 6);
   const int n_lvl = end - begin;
@@ -476,44 +480,47 @@ __global__ __launch_bounds__(WT_BLOCK) void wt_down_kernel(WtParams p, int it, i
     int kk = m - 1;
     if (kk >= p.klong) { err |= DERR_CAPACITY; kk = p.klong - 1; }
     const double2* __restrict__ src = reinterpret_cast<const double2*>(p.rowL + ((size_t)kk * n + ps) * ldt);
-    double pr[NP];
     uint32_t node_id;
-    if (ds.child >= 0) {
-      const double* __restrict__ PLc = PLt + (size_t)ds.child * n * 64 + lane;
-#pragma unroll
-      for (int c2 = 0; c2 < NP / 2; ++c2) {
-        const int c = 2 * c2;
-        double2 r = {0.0, 0.0};
-        if (c < n) r = src[c2];                          // the padding entry of an odd-length row is 0
-        pr[c] = (c < n) ? r.x * PLc[(size_t)c * 64] : 0.0;
-        pr[c + 1] = (c + 1 < n) ? r.y * PLc[(size_t)(c + 1) * 64] : 0.0;
-      }
-      node_id = (uint32_t)(ds.child + p.n_tips);
-    } else {
-      const int tip = ~ds.child;
-      const int par = (p.tips_per_replica ? tips_t[tip * 64 + lane] : p.tips[tip]) & 1;
-#pragma unroll
-      for (int c2 = 0; c2 < NP / 2; ++c2) {
-        const int c = 2 * c2;
-        double2 r = {0.0, 0.0};
-        if (c < n) r = src[c2];
-        pr[c] = (c < n) ? r.x * ((par == 0) ? 1.0 : 0.0) : 0.0;
-        pr[c + 1] = (c + 1 < n) ? r.y * ((par == 1) ? 1.0 : 0.0) : 0.0;
-      }
-      node_id = (uint32_t)tip;
-    }
+    const double* __restrict__ PLc = PLt + (size_t)(ds.child >= 0 ? ds.child : 0) * n * 64 + lane;
+    int par = 0;
+    if (ds.child >= 0) node_id = (uint32_t)(ds.child + p.n_tips);
+    else { const int tip = ~ds.child; par = (p.tips_per_replica ? tips_t[tip * 64 + lane] : p.tips[tip]) & 1; node_id = (uint32_t)tip; }
+    const bool internal = ds.child >= 0;
     const double u = stream_u(p.seed_lo, p.seed_hi, rep, (uint32_t)it, ENT_NODE | node_id, 0);
-    double total = 0.0;                                  // 0 + p_0 = p_0, x + 0 = x: the padding never shows
+    auto chunk = [&](const double2* __restrict__ row, int c0, double (&pr)[CH]) {      // products of states c0 .. c0 + CH - 1 (0 beyond n)
+      double2 r[CH / 2];
+      double pl[CH];
 #pragma unroll
-    for (int c = 0; c < NP; ++c) total += pr[c];
+      for (int j = 0; j < CH / 2; ++j) { r[j].x = 0.0; r[j].y = 0.0; if (c0 + 2 * j < n) r[j] = row[(c0 >> 1) + j]; }
+#pragma unroll
+      for (int j = 0; j < CH; ++j) pl[j] = internal ? ((c0 + j < n) ? PLc[(size_t)(c0 + j) * 64] : 0.0) : ((((c0 + j) & 1) == par) ? 1.0 : 0.0);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) pr[j] = (c0 + j < n) ? ((j & 1) ? r[j >> 1].y : r[j >> 1].x) * pl[j] : 0.0;
+    };
+    double total = 0.0;
+#pragma unroll
+    for (int c0 = 0; c0 < NP; c0 += CH) {
+      if (c0 < n) {
+        double pr[CH];
+        chunk(src, c0, pr);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) total += pr[j];
+      }
+    }
     if (!(total > 0.0) || isinf(total)) err |= DERR_ZERO_PROB;
     const double thr = u * total;
     double cum = 0.0;
     cs = 0;
+    const double2* src2 = src;
+    asm volatile("" : "+v"(src2));                       // second pass: the row is read again (L1 / L2), not kept in 128 registers
 #pragma unroll
-    for (int c = 0; c < NP - 1; ++c) {                   // comparisons at states 0 .. n-2 decide (sample_cat)
-      cum += pr[c];
-      cs += (c < n - 1 && !(thr <= cum)) ? 1 : 0;
+    for (int c0 = 0; c0 < NP; c0 += CH) {
+      if (c0 < n && __any(!(thr <= cum))) {
+        double pr[CH];
+        chunk(src2, c0, pr);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) { cum += pr[j]; cs += (c0 + j < n - 1 && !(thr <= cum)) ? 1 : 0; }
+      }
     }
     if (ds.child >= 0) nst[ds.child * 64 + lane] = (uint8_t)cs;                                   // :655
   } else {
