@@ -35,6 +35,9 @@
 namespace phm {
 
 constexpr int WT_BLOCK = 256;
+#ifndef WT_BRANCH_BLOCK_SMALL
+#define WT_BRANCH_BLOCK_SMALL 512
+#endif
 constexpr int WT_FEW_TILES = 112;       // n <= 16: below this many tiles the pruning pass runs a wave per 16-replica block (latency) instead of per tile (throughput)
 constexpr int WT_MAX_SLOTS = 96;        // possible transitions (non-zero entries of B) up to which the branch kernel counts in LDS
 

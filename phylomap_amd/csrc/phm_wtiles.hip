@@ -540,9 +540,10 @@ __global__ __launch_bounds__(WT_BLOCK) void wt_down_kernel(WtParams p, int it, i
 // leaves L2 as a 64-byte request of its own, and at one per merged segment they were a quarter of the kernel's HBM traffic
 // on C5 (profiles/r02_pmc_C5_summary_v2.json).  Larger n: B rows through L1/L2 (30 KB of LDS would halve the occupancy).
 template <bool KS, bool SMALL>
-__global__ __launch_bounds__(WT_BLOCK) void wt_branch_kernel(WtParams p, int it) {
+__global__ __launch_bounds__(SMALL ? WT_BRANCH_BLOCK_SMALL : WT_BLOCK) void wt_branch_kernel(WtParams p, int it) {
+  constexpr int BLOCK = SMALL ? WT_BRANCH_BLOCK_SMALL : WT_BLOCK;
   extern __shared__ __align__(16) unsigned char s_dyn[];            // SMALL: [n][ldt] rows of B, then [n][64] dwell sums (u64)
-  __shared__ uint8_t s_ms_all[(WT_BLOCK / 64) * 64 * 64];           // [wave][segment][lane]
+  __shared__ uint8_t s_ms_all[(BLOCK / 64) * 64 * 64];           // [wave][segment][lane]
   __shared__ double s_scale[64];
   __shared__ __align__(16) double s_ltab[2 * PHM_LOGTAB_N];        // (1/c_j, log c_j) of the exponential variates (neglog_u32)
   const int lane = threadIdx.x & 63;
@@ -556,17 +557,17 @@ __global__ __launch_bounds__(WT_BLOCK) void wt_branch_kernel(WtParams p, int it)
   uint32_t* s_ct = reinterpret_cast<uint32_t*>(s_dw + (size_t)n * 64);           // [n_slots][64]
   int16_t* s_slot = reinterpret_cast<int16_t*>(s_ct + (size_t)p.n_slots * 64);   // [n*n] pair -> slot, -1: none
   const int n_slots = SMALL ? p.n_slots : 0;
-  for (int i = threadIdx.x; i < 2 * PHM_LOGTAB_N; i += WT_BLOCK) s_ltab[i] = logtab_entry(i);
+  for (int i = threadIdx.x; i < 2 * PHM_LOGTAB_N; i += BLOCK) s_ltab[i] = logtab_entry(i);
   if ((int)threadIdx.x < n) s_scale[threadIdx.x] = p.scale[threadIdx.x];
   if (SMALL) {
-    for (int i = threadIdx.x; i < n * ldt; i += WT_BLOCK) s_B2[i] = p.B2[i];
-    for (int i = threadIdx.x; i < n * 64; i += WT_BLOCK) s_dw[i] = 0ull;
-    for (int i = threadIdx.x; i < n_slots * 64; i += WT_BLOCK) s_ct[i] = 0u;
-    if (n_slots > 0) for (int i = threadIdx.x; i < n * n; i += WT_BLOCK) s_slot[i] = p.pair_slot[i];
+    for (int i = threadIdx.x; i < n * ldt; i += BLOCK) s_B2[i] = p.B2[i];
+    for (int i = threadIdx.x; i < n * 64; i += BLOCK) s_dw[i] = 0ull;
+    for (int i = threadIdx.x; i < n_slots * 64; i += BLOCK) s_ct[i] = 0u;
+    if (n_slots > 0) for (int i = threadIdx.x; i < n * n; i += BLOCK) s_slot[i] = p.pair_slot[i];
   }
   __syncthreads();
   const int tile = blockIdx.x % p.n_tiles;
-  const int grp = (blockIdx.x / p.n_tiles) * (WT_BLOCK / 64) + wave;
+  const int grp = (blockIdx.x / p.n_tiles) * (BLOCK / 64) + wave;
   const bool active = grp < p.n_groups;              // wave-uniform; every wave reaches the barrier at the end
   const double* __restrict__ Brows = SMALL ? s_B2 : p.B2;
   uint8_t* s_ms = s_ms_all + wave * 64 * 64 + lane;
@@ -782,11 +783,11 @@ __global__ __launch_bounds__(WT_BLOCK) void wt_branch_kernel(WtParams p, int it)
   if (lane == 0 && active) atomicAdd(p.segacc + (size_t)tile * 64 + (grp & 63), (unsigned long long)segs);
   if (SMALL) {                                       // the workgroup's dwell sums -> the tile's accumulators, row by row
     __syncthreads();
-    for (int i = threadIdx.x; i < n * 64; i += WT_BLOCK) {
+    for (int i = threadIdx.x; i < n * 64; i += BLOCK) {
       const unsigned long long v = s_dw[i];
       if (v) atomicAdd(gdw + i, v);
     }
-    for (int i = threadIdx.x; i < n_slots * 64; i += WT_BLOCK) {
+    for (int i = threadIdx.x; i < n_slots * 64; i += BLOCK) {
       const uint32_t v = s_ct[i];
       if (v) atomicAdd(p.cnt + ((size_t)tile * n * n + p.slot_col[i >> 6]) * 64 + (i & 63), v);
     }
@@ -900,12 +901,15 @@ hipError_t launch_wtiles_sweep(const WtParams& p, const std::vector<int32_t>& up
     const bool small = p.n_states <= 32;
     const size_t lds = small ? sizeof(double) * (size_t)p.n_states * p.ldt + sizeof(unsigned long long) * (size_t)p.n_states * 64 +
                                    sizeof(uint32_t) * (size_t)p.n_slots * 64 + sizeof(int16_t) * (size_t)p.n_states * p.n_states + 16 : 0;
-    const dim3 g((unsigned)(((int64_t)p.n_groups + WPB - 1) / WPB * p.n_tiles));
+    // n <= 32: eight waves share the workgroup's LDS tables (B rows, dwell and count accumulators: 26 KB at 20 states) -- 58 KB per
+    // workgroup, two per CU, four waves per SIMD where four-wave workgroups (43 KB) gave three
+    const int wpb = small ? WT_BRANCH_BLOCK_SMALL / 64 : WPB;
+    const dim3 g((unsigned)(((int64_t)p.n_groups + wpb - 1) / wpb * p.n_tiles));
     if (p.ks) {
-      if (small) hipLaunchKernelGGL((wt_branch_kernel<true, true>), g, dim3(WT_BLOCK), lds, stream, p, it);
+      if (small) hipLaunchKernelGGL((wt_branch_kernel<true, true>), g, dim3(WT_BRANCH_BLOCK_SMALL), lds, stream, p, it);
       else hipLaunchKernelGGL((wt_branch_kernel<true, false>), g, dim3(WT_BLOCK), lds, stream, p, it);
     } else {
-      if (small) hipLaunchKernelGGL((wt_branch_kernel<false, true>), g, dim3(WT_BLOCK), lds, stream, p, it);
+      if (small) hipLaunchKernelGGL((wt_branch_kernel<false, true>), g, dim3(WT_BRANCH_BLOCK_SMALL), lds, stream, p, it);
       else hipLaunchKernelGGL((wt_branch_kernel<false, false>), g, dim3(WT_BLOCK), lds, stream, p, it);
     }
   }
