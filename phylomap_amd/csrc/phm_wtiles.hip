@@ -538,7 +538,7 @@ __global__ __launch_bounds__(WT_BLOCK) void wt_down_kernel(WtParams p, int it, i
 // tile.  SMALL (n <= 32): the rows of B sit in LDS and the dwell sums of the workgroup are collected in one LDS table
 // (64-bit fixed point, ds_add_u64) that is handed to the tile's accumulators once, as coalesced rows -- a scattered atomic
 // leaves L2 as a 64-byte request of its own, and at one per merged segment they were a quarter of the kernel's HBM traffic
-// on C5 (profiles/r02_pmc_C5_summary_v2.json).  Larger n: B rows through L1/L2 (30 KB of LDS would halve the occupancy).
+// on C5 (profiles/r02_pmc_C5_summary.json).  Larger n: B rows through L1/L2 (30 KB of LDS would halve the occupancy).
 template <bool KS, bool SMALL>
 __global__ __launch_bounds__(SMALL ? WT_BRANCH_BLOCK_SMALL : WT_BLOCK) void wt_branch_kernel(WtParams p, int it) {
   constexpr int BLOCK = SMALL ? WT_BRANCH_BLOCK_SMALL : WT_BLOCK;
