@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-for C in 3 4 5; do
+for C in 5; do
   for P in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CYCLES"; do
     tag=$(echo $P | cut -d' ' -f1)
     timeout -k 10 300 rocprofv3 --pmc $P --output-format csv -d gpurun_out/pmc3_c${C}_${tag} -o x -- python3 bench.py --config $C --steps 3 --warmup 3 --no-cpu --no-extras > gpurun_out/pmc3_c${C}_${tag}.log 2>&1 || { echo "pmc C$C $tag failed"; tail -3 gpurun_out/pmc3_c${C}_${tag}.log; }
