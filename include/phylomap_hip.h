@@ -247,7 +247,10 @@ int32_t phm_expm_eigen_mfma(int32_t n_states, const double* lefts, const double*
 int32_t phm_expm_pade(int32_t n_states, const double* Q, const double* t, int32_t n_t, int32_t device,
                       double* out, double* kernel_ms);
 
-/* phm_expm_pade with every matrix product on the matrix cores (v_mfma_f64_16x16x4_f64), 16 < n_states <= 64 */
+/* phm_expm_pade with every matrix product on the matrix cores (v_mfma_f64_16x16x4_f64), 16 < n_states <= 64: solve(D, E) by
+ * block Gauss-Jordan elimination without row exchanges between the 16 x 16 blocks; a matrix that meets a pivot below 1e-3 there
+ * is recomputed by phm_expm_pade's pivoted kernel inside the same call.  Agrees with phm_expm_pade to rounding (<= 2e-13).
+ * Test aid: the environment variable PHM_PADE_PIVOT_MIN overrides the 1e-3 (1e300 sends every matrix to the pivoted kernel). */
 int32_t phm_expm_pade_mfma(int32_t n_states, const double* Q, const double* t, int32_t n_t, int32_t device,
                            double* out, double* kernel_ms);
 
