@@ -28,6 +28,7 @@ namespace phm {
 
 constexpr int TILES_BLOCK = 256;          // four waves = four (tile, item) pairs per workgroup
 constexpr int TILES_CHUNK = 64;           // group partials per second-stage sum of the dwell reduction
+constexpr int TILES_PERSISTENT_WGS = 2048;      // workgroups of a node-draw launch: 256 CUs x 8 (four waves each: eight waves per SIMD)
 constexpr int TILES_KTAB = 24;            // chain-table rows staged in LDS by the branch kernel (longer chains: full table in L2)
 
 template <int NS>
