@@ -292,6 +292,7 @@ def test_wide_kernel_per_site_tips_on_thinly_filled_tiles():
 @pytest.mark.parametrize("mapping", ["replicas", "branches", "tiles"])     # wave per 64-replica tile, replicas in turn / wave per (replica, branch) / lane per replica, wave per (tile, item)
 @pytest.mark.parametrize("n,fn,variant", [(20, "sumstatMCMC", O.PLAIN), (20, "SPARSEsumstatMCMC", O.SPARSE),
                                           (20, "sumstatMCMC_bigtree", O.BIGTREE), (5, "sumstatMCMC", O.PLAIN),
+                                          (40, "sumstatMCMC_bigtree", O.BIGTREE),      # three 16-state row blocks (MT = 3 kernels)
                                           (61, "sumstatMCMC_bigtree", O.BIGTREE), (64, "sumstatMCMC", O.PLAIN)])
 def test_wide_kernel_matches_oracle(n, fn, variant, mapping):
     """5..64 states (C4: dense 61-state Q; C5: sparse 20-state tridiagonal Q): states-over-lanes kernel."""
@@ -316,6 +317,28 @@ def test_wide_kernel_matches_oracle(n, fn, variant, mapping):
     red = getattr(api, fn)(z, Q, pid, Omega, N, seed=seed, n_replicas=S, reduce=True, mapping=mapping)
     np.testing.assert_array_equal(red[:, n:], got.sum(0)[:, n:])
     np.testing.assert_allclose(red[:, :n], got.sum(0)[:, :n], rtol=1e-12)
+
+
+@pytest.mark.parametrize("form", [1, 2])
+@pytest.mark.parametrize("n", [12, 24, 40, 61])
+def test_wide_tiles_pruning_kernels_agree(n, form):
+    """The pruning pass of the lane-per-replica mapping has three kernels chosen by tile count (a wave per (node, tile) with sorted
+    blocks; for few tiles a workgroup per 16-replica block with a wave per row block, or a wave per block when n <= 16): each
+    forced (pruning_form) on a problem the automatic choice gives to another, 1 / 2 / 3 / 4 row blocks, against the oracle."""
+    Q = synth.dense_Q(n, 0.02, 0.08, seed=n)
+    Omega = 1.25 * float(np.max(np.abs(np.diag(Q))))
+    pid = np.full(n, 1.0 / n)
+    z = synth.make_tree(11, Q, Omega, 700 + n, pid, init_segments=3)
+    nen, nodelist, root = _orders(z)
+    N, S, seed = 6, 150, 77
+    eng = _lib.Engine(z, Q, pid, Omega, N, variant=_lib.PHM_MCMC_BIGTREE, seed=seed, n_replicas=S, mapping="tiles", pruning_form=form)
+    eng.run(N); eng.sync()
+    got = eng.stats(0, N)
+    eng.close()
+    for r in (0, 15, 16, 63, 64, 129, S - 1):
+        want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(n) + Q / Omega, Omega, nen, nodelist, root, N, variant=O.BIGTREE, seed=seed, replica=r)
+        assert rc == 0
+        _same(got[r], want, n, "tiles")
 
 
 @pytest.mark.parametrize("n,band", [(9, 1), (33, 1), (64, 1), (16, 2), (48, 7)])
