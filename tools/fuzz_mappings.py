@@ -16,7 +16,7 @@ def run(seed, n_cases):
     rs = np.random.default_rng(seed)
     bad = 0
     for case in range(n_cases):
-        n = int(rs.choice([2, 3, 4, 4, 5, 6, 8, 12]))
+        n = int(rs.choice([2, 3, 4, 4, 5, 6, 8, 12, 17, 20, 33, 48, 61]))      # 1 .. 4 row blocks of the matrix-core pruning kernels
         Q = synth.dense_Q(n, 0.02, 0.3, seed=int(rs.integers(1 << 30)))
         if rs.random() < 0.3:                                    # some exactly-zero rates (sparse threshold path)
             mask = rs.random((n, n)) < 0.3
@@ -43,18 +43,20 @@ def run(seed, n_cases):
             for b_, (p_, c_) in enumerate(z["edge"]):
                 if c_ <= T:
                     z["mapnames"][b_][-1] = z["states"][c_ - 1]
-        S, N, seed = int(rs.choice([1, 2, 3, 70])), int(rs.integers(3, 12)), int(rs.integers(1 << 40))
+        S, N, seed = int(rs.choice([1, 2, 3, 70, 130])), int(rs.integers(3, 12)), int(rs.integers(1 << 40))
         B = np.eye(n) + Q / Omega
-        wants = [O.maketreelistMCMC(z, Q, pid, B, Omega, nen, nodelist, root, N, variant=var, seed=seed, replica=r) for r in range(min(S, 3))]
+        reps = sorted(set([0, min(S - 1, 1), min(S - 1, 65), S - 1]))          # replicas of different tiles when there are several
+        wants = [O.maketreelistMCMC(z, Q, pid, B, Omega, nen, nodelist, root, N, variant=var, seed=seed, replica=r) for r in reps]
         for mapping in ["replicas", "branches", "tiles"]:
+            form = int(rs.integers(3)) if mapping == "tiles" else 0      # pruning kernel of the 5..64-state tile mapping
             try:
-                got = getattr(api, fn)(z, Q, pid, Omega, N, seed=seed, n_replicas=S, mapping=mapping)
+                got = getattr(api, fn)(z, Q, pid, Omega, N, seed=seed, n_replicas=S, mapping=mapping, pruning_form=form)
                 if S == 1:
                     got = got[None]
                 err = None
             except Exception as ex:      # noqa: BLE001
                 got, err = None, ex
-            for r, (want, rc) in enumerate(wants):
+            for r, (want, rc) in zip(reps, wants):
                 if rc != 0:
                     ok = err is not None
                 elif err is not None:
@@ -68,7 +70,7 @@ def run(seed, n_cases):
                     if got is not None and rc == 0:
                         d = np.argwhere(~np.isclose(got[r], want, rtol=1e-10, atol=0, equal_nan=True))
                         print("   differing (row, col):", d[:6].tolist(), "got", [got[r][tuple(x)] for x in d[:3]], "want", [want[tuple(x)] for x in d[:3]])
-                    print(f"MISMATCH case {case}: n={n} tips={tips} S={S} N={N} {fn} mapping={mapping} replica={r} oracle_rc={rc} err={err}")
+                    print(f"MISMATCH case {case}: n={n} tips={tips} S={S} N={N} {fn} mapping={mapping} form={form} replica={r} oracle_rc={rc} err={err}")
     return bad
 
 
