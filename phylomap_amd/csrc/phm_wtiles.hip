@@ -40,13 +40,13 @@ __device__ __forceinline__ int sample_terms(int n, double u, Term term, uint32_t
 // ---------------------------------------------------------------------------------------------------------------------
 template <int MT>
 __global__ __launch_bounds__(WT_BLOCK) void wt_up_kernel(WtParams p, int begin, int end) {
-  constexpr int KS = 4 * MT, NP = 16 * MT;
-  extern __shared__ __align__(16) double s_scr_all[];  // [wave][NP][64]: the first child's vectors while the second child's chains run
+  constexpr int KS = 4 * MT;
+  extern __shared__ __align__(16) double s_scr_all[];  // [wave][n][64]: the first child's vectors while the second child's chains run
   __shared__ uint8_t s_perm_all[WT_BLOCK / 64][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lr = lane & 15, lk = lane >> 4;
   const int n = p.n_states, ldt = p.ldt;
-  double* s_scr = s_scr_all + (size_t)wave * NP * 64;
+  double* s_scr = s_scr_all + (size_t)wave * n * 64;      // n rows, not 16 MT (C5: pruning 21.0 -> 20.4 ms per sweep)
   uint8_t* s_perm = s_perm_all[wave];
   double Af[MT][KS];                                   // the chain matrix as A-operand fragments, for the whole launch
 #pragma unroll
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(WT_BLOCK) void wt_up_kernel(WtParams p, int begin, 
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) s_scr[(16 * i + lk + 4 * q) * 64 + j] = R0[i][q];
+          for (int q = 0; q < 4; ++q) { const int row = 16 * i + lk + 4 * q; if (row < n) s_scr[row * 64 + j] = R0[i][q]; }
 #pragma unroll
         for (int i = 0; i < MT; ++i) X[i] = Xn[i];
         j = jn;
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(WT_BLOCK) void wt_up_kernel(WtParams p, int begin, 
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) R0[i][q] = s_scr[(16 * i + lk + 4 * q) * 64 + j];
+          for (int q = 0; q < 4; ++q) { const int row = 16 * i + lk + 4 * q; R0[i][q] = (row < n) ? s_scr[row * 64 + j] : 0.0; }
         finish(j, R0, R1);
 #pragma unroll
         for (int i = 0; i < MT; ++i) X[i] = Xn[i];
@@ -835,10 +835,11 @@ __global__ __launch_bounds__(WT_BLOCK) void wt_stats_kernel(WtParams p, int it, 
 
 template <int MT>
 void launch_up_levels(const WtParams& p, const std::vector<int32_t>& up_off, hipStream_t stream) {
-  const size_t lds = sizeof(double) * (size_t)(WT_BLOCK / 64) * 16 * MT * 64;
+  const size_t lds = sizeof(double) * (size_t)(WT_BLOCK / 64) * p.n_states * 64;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wt_up_kernel<MT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wt_up_kernel<MT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(sizeof(double) * (size_t)(WT_BLOCK / 64) * 16 * MT * 64));      // the largest n of this MT
     attr_set = true;
   }
   // Measured crossovers (profiles/r02_probe_few_tiles.log): the row-split workgroups win below about 64 tiles at 20 states and
