@@ -539,7 +539,7 @@ __global__ __launch_bounds__(WT_BLOCK) void wt_down_kernel(WtParams p, int it, i
 // (64-bit fixed point, ds_add_u64) that is handed to the tile's accumulators once, as coalesced rows -- a scattered atomic
 // leaves L2 as a 64-byte request of its own, and at one per merged segment they were a quarter of the kernel's HBM traffic
 // on C5 (profiles/r02_pmc_C5_summary.json).  Larger n: B rows through L1/L2 (30 KB of LDS would halve the occupancy).
-template <bool KS, bool SMALL>
+template <bool KS, bool SMALL, bool B2L>
 __global__ __launch_bounds__(SMALL ? WT_BRANCH_BLOCK_SMALL : WT_BLOCK) void wt_branch_kernel(WtParams p, int it) {
   constexpr int BLOCK = SMALL ? WT_BRANCH_BLOCK_SMALL : WT_BLOCK;
   extern __shared__ __align__(16) unsigned char s_dyn[];            // SMALL: [n][ldt] rows of B, then [n][64] dwell sums (u64)
@@ -559,8 +559,10 @@ __global__ __launch_bounds__(SMALL ? WT_BRANCH_BLOCK_SMALL : WT_BLOCK) void wt_b
   const int n_slots = SMALL ? p.n_slots : 0;
   for (int i = threadIdx.x; i < 2 * PHM_LOGTAB_N; i += BLOCK) s_ltab[i] = logtab_entry(i);
   if ((int)threadIdx.x < n) s_scale[threadIdx.x] = p.scale[threadIdx.x];
+  // B2L: the rows of B in LDS (always for n <= 32; beyond, 30 KB at 61 states, when a workgroup walks enough branches to pay for
+  // staging them -- a third of a draw's per-lane table reads: C4 branch kernel 20.8 -> 18.3-19.8 ms at 65 536 replicas)
+  if (B2L) for (int i = threadIdx.x; i < n * ldt; i += BLOCK) s_B2[i] = p.B2[i];
   if (SMALL) {
-    for (int i = threadIdx.x; i < n * ldt; i += BLOCK) s_B2[i] = p.B2[i];
     for (int i = threadIdx.x; i < n * 64; i += BLOCK) s_dw[i] = 0ull;
     for (int i = threadIdx.x; i < n_slots * 64; i += BLOCK) s_ct[i] = 0u;
     if (n_slots > 0) for (int i = threadIdx.x; i < n * n; i += BLOCK) s_slot[i] = p.pair_slot[i];
@@ -569,7 +571,7 @@ __global__ __launch_bounds__(SMALL ? WT_BRANCH_BLOCK_SMALL : WT_BLOCK) void wt_b
   const int tile = blockIdx.x % p.n_tiles;
   const int grp = (blockIdx.x / p.n_tiles) * (BLOCK / 64) + wave;
   const bool active = grp < p.n_groups;              // wave-uniform; every wave reaches the barrier at the end
-  const double* __restrict__ Brows = SMALL ? s_B2 : p.B2;
+  const double* __restrict__ Brows = B2L ? s_B2 : p.B2;
   uint8_t* s_ms = s_ms_all + wave * 64 * 64 + lane;
   const uint32_t rep = (uint32_t)(p.replica_offset + tile * 64 + lane);
   const bool valid = tile * 64 + lane < p.n_rep;
@@ -901,17 +903,22 @@ hipError_t launch_wtiles_sweep(const WtParams& p, const std::vector<int32_t>& up
   {
     const bool small = p.n_states <= 32;
     const size_t lds = small ? sizeof(double) * (size_t)p.n_states * p.ldt + sizeof(unsigned long long) * (size_t)p.n_states * 64 +
-                                   sizeof(uint32_t) * (size_t)p.n_slots * 64 + sizeof(int16_t) * (size_t)p.n_states * p.n_states + 16 : 0;
+                                   sizeof(uint32_t) * (size_t)p.n_slots * 64 + sizeof(int16_t) * (size_t)p.n_states * p.n_states + 16
+                             : sizeof(double) * (size_t)p.n_states * p.ldt;
     // n <= 32: eight waves share the workgroup's LDS tables (B rows, dwell and count accumulators: 26 KB at 20 states) -- 58 KB per
     // workgroup, two per CU, four waves per SIMD where four-wave workgroups (43 KB) gave three
     const int wpb = small ? WT_BRANCH_BLOCK_SMALL / 64 : WPB;
     const dim3 g((unsigned)(((int64_t)p.n_groups + wpb - 1) / wpb * p.n_tiles));
+    const bool b2l = !small && p.group >= 4;           // n > 32: B rows in LDS once a wave walks four or more branches
+    const size_t lds_now = small ? lds : (b2l ? lds : 0);
     if (p.ks) {
-      if (small) hipLaunchKernelGGL((wt_branch_kernel<true, true>), g, dim3(WT_BRANCH_BLOCK_SMALL), lds, stream, p, it);
-      else hipLaunchKernelGGL((wt_branch_kernel<true, false>), g, dim3(WT_BLOCK), lds, stream, p, it);
+      if (small) hipLaunchKernelGGL((wt_branch_kernel<true, true, true>), g, dim3(WT_BRANCH_BLOCK_SMALL), lds_now, stream, p, it);
+      else if (b2l) hipLaunchKernelGGL((wt_branch_kernel<true, false, true>), g, dim3(WT_BLOCK), lds_now, stream, p, it);
+      else hipLaunchKernelGGL((wt_branch_kernel<true, false, false>), g, dim3(WT_BLOCK), lds_now, stream, p, it);
     } else {
-      if (small) hipLaunchKernelGGL((wt_branch_kernel<false, true>), g, dim3(WT_BRANCH_BLOCK_SMALL), lds, stream, p, it);
-      else hipLaunchKernelGGL((wt_branch_kernel<false, false>), g, dim3(WT_BLOCK), lds, stream, p, it);
+      if (small) hipLaunchKernelGGL((wt_branch_kernel<false, true, true>), g, dim3(WT_BRANCH_BLOCK_SMALL), lds_now, stream, p, it);
+      else if (b2l) hipLaunchKernelGGL((wt_branch_kernel<false, false, true>), g, dim3(WT_BLOCK), lds_now, stream, p, it);
+      else hipLaunchKernelGGL((wt_branch_kernel<false, false, false>), g, dim3(WT_BLOCK), lds_now, stream, p, it);
     }
   }
   mark(3);

@@ -341,6 +341,27 @@ def test_wide_tiles_pruning_kernels_agree(n, form):
         _same(got[r], want, n, "tiles")
 
 
+def test_wide_tiles_branch_kernel_with_B_rows_in_lds_beyond_32_states():
+    """Beyond 32 states the branch kernel of the lane-per-replica mapping stages the rows of B in LDS once a wave walks four or more
+    branches (tiles x branches >= 4 x 65 536): 40 states on a 3 000-tip tree with 45 tiles, replicas of three tiles against the oracle."""
+    n = 40
+    Q = synth.dense_Q(n, 0.01, 0.04, seed=404)
+    Omega = 1.25 * float(np.max(np.abs(np.diag(Q))))
+    pid = np.full(n, 1.0 / n)
+    z = synth.make_tree(3000, Q, Omega, 4040, pid, init_segments=2)
+    nen, nodelist, root = _orders(z)
+    N, S, seed = 4, 2880, 909
+    eng = _lib.Engine(z, Q, pid, Omega, N, variant=_lib.PHM_MCMC_BIGTREE, seed=seed, n_replicas=S, mapping="tiles")
+    eng.run(N); eng.sync()
+    got = eng.stats(0, N)
+    eng.close()
+    for r in (0, 64 + 17, S - 1):
+        want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(n) + Q / Omega, Omega, nen, nodelist, root, N, variant=O.BIGTREE, seed=seed, replica=r)
+        assert rc == 0
+        _same(got[r], want, n, "tiles")
+    np.testing.assert_allclose(got[:, :, :n].sum(2), z["edge.length"].sum(), rtol=1e-11)
+
+
 @pytest.mark.parametrize("n,band", [(9, 1), (33, 1), (64, 1), (16, 2), (48, 7)])
 @pytest.mark.parametrize("fn,variant", [("sumstatMCMC", O.PLAIN), ("SPARSEsumstatMCMC", O.SPARSE)])
 def test_wide_branch_mapping_sparse_rows_match_oracle(n, band, fn, variant):
