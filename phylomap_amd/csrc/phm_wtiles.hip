@@ -910,6 +910,12 @@ hipError_t launch_wtiles_sweep(const WtParams& p, const std::vector<int32_t>& up
     const int wpb = small ? WT_BRANCH_BLOCK_SMALL / 64 : WPB;
     const dim3 g((unsigned)(((int64_t)p.n_groups + wpb - 1) / wpb * p.n_tiles));
     const bool b2l = !small && p.group >= 4;           // n > 32: B rows in LDS once a wave walks four or more branches
+    static bool attr_set = false;
+    if (!attr_set) {      // n = 32 with 96 countable pairs: 51 KB dynamic + 35 KB static per eight-wave workgroup, beyond the default 64 KB
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wt_branch_kernel<true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wt_branch_kernel<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+      attr_set = true;
+    }
     const size_t lds_now = small ? lds : (b2l ? lds : 0);
     if (p.ks) {
       if (small) hipLaunchKernelGGL((wt_branch_kernel<true, true, true>), g, dim3(WT_BRANCH_BLOCK_SMALL), lds_now, stream, p, it);

@@ -341,6 +341,30 @@ def test_wide_tiles_pruning_kernels_agree(n, form):
         _same(got[r], want, n, "tiles")
 
 
+@pytest.mark.parametrize("n,band", [(32, 1), (24, 2), (32, 31)])
+def test_wide_tiles_branch_kernel_lds_budget_at_the_top_of_the_small_range(n, band):
+    """n <= 32: an eight-wave workgroup of the branch kernel keeps the rows of B, the dwell table and (for a banded B with at most 96
+    possible transitions) the transition counters in LDS -- up to 86 KB at 32 states, beyond the default 64 KB per workgroup;
+    a dense B (992 possible transitions) counts in global memory instead."""
+    rs = np.random.default_rng(n * 10 + band)
+    Q = np.zeros((n, n))
+    for i in range(n):
+        for j in range(max(0, i - band), min(n, i + band + 1)):
+            if i != j:
+                Q[i, j] = rs.uniform(0.02, 0.08)
+    np.fill_diagonal(Q, -Q.sum(1))
+    Omega = 1.25 * float(np.max(np.abs(np.diag(Q))))
+    pid = np.full(n, 1.0 / n)
+    z = synth.make_tree(12, Q, Omega, 800 + n + band, pid, init_segments=(n if band < n - 1 else 2))      # a banded B reaches state j from i in |i - j| / band steps
+    nen, nodelist, root = _orders(z)
+    N, S, seed = 6, 70, 55
+    got = api.sumstatMCMC_bigtree(z, Q, pid, Omega, N, seed=seed, n_replicas=S, mapping="tiles")
+    for r in (0, 63, 64, S - 1):
+        want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(n) + Q / Omega, Omega, nen, nodelist, root, N, variant=O.BIGTREE, seed=seed, replica=r)
+        assert rc == 0
+        _same(got[r], want, n, "tiles")
+
+
 def test_wide_tiles_branch_kernel_with_B_rows_in_lds_beyond_32_states():
     """Beyond 32 states the branch kernel of the lane-per-replica mapping stages the rows of B in LDS once a wave walks four or more
     branches (tiles x branches >= 4 x 65 536): 40 states on a 3 000-tip tree with 45 tiles, replicas of three tiles against the oracle."""
