@@ -13,7 +13,7 @@
  *  - matrices follow R's layout (COLUMN-major): Q, B, lefts, rights, d, edge, and the result;
  *  - every call returns a phm_status; phm_last_error() gives a thread-local message
  *    (the reference throws through BEGIN_RCPP/END_RCPP, src/RcppExports.cpp:35,53);
- *  - randomness: Philox4x32-10 keyed by phm_options.seed, counter (block, entity, iteration,
+ *  - randomness: Philox4x32-7 keyed by phm_options.seed, counter (block, entity, iteration,
  *    replica), draw d = word d & 3 of block d >> 2 mapped to (x + 0.5) 2^-32; the Rcpp shim draws the seed from R's stream inside its RNGScope
  *    (src/RcppExports.cpp:38) so set.seed() still controls results;
  *  - there is NO CPU fallback: without a usable HIP device every compute call returns
@@ -28,7 +28,8 @@
 extern "C" {
 #endif
 
-#define PHM_VERSION 100
+#define PHM_VERSION 200     /* 200: phm_options carries named fields (mapping, storage, ...) instead of reserved[6];
+                                   phm_info.recoveries */
 
 typedef enum phm_status {
   PHM_OK = 0,
@@ -56,8 +57,12 @@ typedef enum phm_variant {
                                  l01, l10, rkappas, lkappas, gammas (recordQks :1789-1798), root state (0-based).
                                  The per-iteration Gibbs/MH updates of Q (:1862-1866) run in phm_maketreelistMCMCks. */
   ,
-  PHM_MCMC_BF = 4             /* tree sweep of maketreelistMCMCbf (treesamplebf :1169-1179): two states, tips observed, n x n counts
-                                 incl. self pairs, layout time0,time1,n00,n01,n10,n11,l01,l10,root_state (R/sumstatMCMCbf.R:33) */
+  PHM_MCMC_BF = 4             /* tree sweep of maketreelistMCMCbf (treesamplebf :1169-1179): tips observed, n x n counts incl. self
+                                 pairs (shortenerbf :1010-1014), row-normalised pruning (:1085); n-generic in the reference.  Result:
+                                 N x (n + n*n + 3): dwell, counts (row-major from,to), Q[0,1], Q[1,0], root state -- at n = 2 the
+                                 reference's time0,time1,n00,n01,n10,n11,l01,l10,root_state (R/sumstatMCMCbf.R:33; its column 8 is
+                                 hard-wired at :1129, which is n + n*n + 2 for two states).  The rate updates (two states only)
+                                 run in phm_maketreelistMCMCbf */
   ,
   PHM_MCMC_MT = 5             /* tree sweep of maketreelistMCMCmt (treesamplemtNS :2157-2165): the bf sweep with the UN-normalised
                                  pruning makePLrcppmt :1938-1950; two states */
@@ -88,6 +93,16 @@ typedef struct phm_model {
   int32_t variant;             /* phm_variant */
 } phm_model;
 
+/* how a sweep is laid over the lanes (phm_options.mapping).  n <= 4: REPLICAS = one lane per replica, one wave per 64-replica
+ * tile walks the tree (largest replica counts); BRANCHES = one lane per branch of one chain (a handful of chains, large trees);
+ * TILES = one wave per (64-replica tile, branch) (10^2 .. 10^5 replicas).  5..64 states: REPLICAS = one wave per 64-replica
+ * tile, replicas in turn, lanes = states (phm_wide.hip; lists of trees); BRANCHES = one wave per (replica, branch), lanes =
+ * states (a handful of chains); TILES = one lane per replica, one wave per (tile, item), pruning on the matrix cores or over
+ * the non-zeros of a sparse B (the default beyond 8 replicas at 20 states, always at 61: the measured crossover).
+ * phm_maketreelistEXP: AUTO / TILES = one wave per (tile of 64 samples, branch); REPLICAS = one wave per tile of 64 samples
+ * walks the tree (dwell sums then add in the reference's order). */
+typedef enum phm_mapping { PHM_MAP_AUTO = 0, PHM_MAP_REPLICAS = 1, PHM_MAP_BRANCHES = 2, PHM_MAP_TILES = 3 } phm_mapping;
+
 typedef struct phm_options {
   uint64_t seed;               /* Philox key */
   int32_t n_replicas;          /* S: independent chains / sites run side by side (>=1; 0 -> 1) */
@@ -97,37 +112,33 @@ typedef struct phm_options {
   int32_t device;              /* HIP device ordinal; -1 = current device */
   int32_t iters_per_launch;    /* MCMC iterations fused into one kernel launch; 0 -> default */
   double  cap_tail;            /* dwell capacity: the 1+Poisson(Omega*t_b) quantile at this tail, per branch; 0 -> 1e-3 for the
-                                  sequential streams of mapping 1, 1e-14 for the fixed slots of mappings 2 and 3.  An overflow is
-                                  recovered (reserved[5]) */
-  int32_t reserved[6];         /* [0]: dwell-stream storage of the replica mapping, 0 = automatic, 1 = one ring per tile (half the
-                                       HBM), 2 = two buffers (5 % faster sweep for n <= 4)
-                                  [1]: mapping of a sweep onto the lanes (one tree), 0 = automatic by replica count; for n <= 4:
-                                       1 = one lane per replica, one wave per 64-replica tile walks the tree (largest replica counts),
-                                       2 = one lane per branch of one chain (a handful of chains, large trees),
-                                       3 = one wave per (64-replica tile, branch) (10^2 .. 10^5 replicas);
-                                       Same draws and counts in every mapping; dwell sums differ in the last bits between
-                                       1 and 2/3 (summation order).  cap_tail defaults to 1e-12 for 2 and 3 (fixed slots).
-                                       5..64 states: 1 = one wave per 64-replica tile, replicas in turn, lanes = states (phm_wide.hip),
-                                       2 = one wave per (replica, branch), lanes = states (a handful of chains),
-                                       3 = one lane per replica, one wave per (tile, item), pruning on the matrix cores (the default
-                                       beyond 8 replicas at 20 states, always at 61 states: the measured crossover with 2);
-                                       bits 8-9 (measurement aid, mapping 3): form of the pruning kernel, 0 = by tile count,
-                                       1 = one wave per (node, tile), 2 = one workgroup / wave per 16-replica block (same bits)
-                                       phm_maketreelistEXP: 0 or 3 = one wave per (tile of 64 samples, branch) (the default), 1 = one
-                                       wave per tile of 64 samples walks the tree (dwell sums then add in the reference's order)
-                                  [2]: 1 = record HIP events between the phases of a sweep (phm_engine_phase_ms)
-                                  [3]: phm_maketreelistEXP: 1 = divide every internal partial-likelihood row by its sum in the
-                                       pruning pass.  The reference's makePLexp (src/phylomap.cpp:2899-2906) does not rescale, so
-                                       sumstatEXP underflows (PHM_ERR_ZERO_PROB) beyond a few hundred tips; node draws do not
-                                       depend on a row's scale, so this is the same sampler in exact arithmetic.
-                                       phm_maketreelistMCMC / phm_SPARSEmaketreelistMCMC: 1 = the same for their pruning pass (what
-                                       makePLrcpp_bigtree :525 does; the plain and the SPARSE driver underflow on trees of thousands of
-                                       tips, man/sumstatMCMC_bigtree.Rd:17)
-                                  [4]: internal (capacity recovery): log2 of the multiplier applied to the provisioned capacities
-                                  [5]: 1 = no capacity recovery: a sweep that outgrows its slots fails with PHM_ERR_CAPACITY.  Default
-                                       (0): the engine is rebuilt with doubled slots and the iterations run so far are replayed --
-                                       bit-identical, every random number being addressed by (replica, iteration, entity) -- so a
-                                       run cannot abort where the reference's std::list (src/phylomap.cpp:18-21) would grow */
+                                  sequential streams of PHM_MAP_REPLICAS, 1e-9 for the fixed slots of PHM_MAP_BRANCHES / PHM_MAP_TILES
+                                  (an overflow is recovered unless no_recovery is set) */
+  int32_t mapping;             /* phm_mapping: how a sweep is laid over the lanes (one tree); PHM_MAP_AUTO = by replica count.
+                                  Same draws and counts in every mapping; dwell sums differ in the last bits between
+                                  PHM_MAP_REPLICAS and the other two (summation order). */
+  int32_t storage;             /* dwell-stream storage of PHM_MAP_REPLICAS: 0 = automatic, 1 = one ring per tile (half the HBM),
+                                  2 = two buffers (5 % faster sweep for n <= 4) */
+  int32_t pruning_form;        /* measurement / test aid, 5..64 states with PHM_MAP_TILES: form of the pruning kernel, 0 = by tile
+                                  count, 1 = one wave per (node, tile), 2 = one workgroup / wave per 16-replica block (same bits) */
+  int32_t phase_timing;        /* 1 = record HIP events between the phases of a sweep (phm_engine_phase_ms) */
+  int32_t rescale_pruning;     /* phm_maketreelistEXP: 1 = divide every internal partial-likelihood row by its sum in the pruning
+                                  pass.  The reference's makePLexp (src/phylomap.cpp:2899-2906) does not rescale, so sumstatEXP
+                                  underflows (PHM_ERR_ZERO_PROB) beyond a few hundred tips; node draws do not depend on a row's
+                                  scale, so this is the same sampler in exact arithmetic.
+                                  phm_maketreelistMCMC / phm_SPARSEmaketreelistMCMC: 1 = the same for their pruning pass (what
+                                  makePLrcpp_bigtree :525 does; the plain and the SPARSE driver underflow on trees of thousands
+                                  of tips, man/sumstatMCMC_bigtree.Rd:17) */
+  int32_t no_recovery;         /* 1 = a sweep that outgrows its slots fails with PHM_ERR_CAPACITY.  Default (0): the engine is
+                                  rebuilt with doubled slots and the iterations run so far are replayed -- bit-identical, every
+                                  random number being addressed by (replica, iteration, entity) -- so a run cannot abort where
+                                  the reference's std::list (src/phylomap.cpp:18-21) would grow */
+  int32_t sparse_chains;       /* 5..64 states with PHM_MAP_TILES: 0 = automatic (by the fill of the chain matrix), 1 = pruning
+                                  chains and forward draws over the non-zeros of B only (SPARSEmakePLrcpp :490-501,
+                                  SPARSEresamplebranchstates :218-261), 2 = dense (matrix cores).  Same bits either way: a
+                                  skipped term is an exact zero */
+  int32_t capacity_boost_log2; /* internal (capacity recovery): log2 of the multiplier applied to the provisioned capacities */
+  int32_t reserved[3];         /* must be 0 */
 } phm_options;
 
 typedef struct phm_info {
@@ -140,12 +151,19 @@ typedef struct phm_info {
   double  last_run_ms;         /* HIP-event time of the last phm_engine_run (all its launches) */
   int32_t last_run_launches;
   int32_t iters_done;
+  int32_t recoveries;          /* capacity recoveries (rebuild + replay) this handle has gone through; a timed region asserts 0 */
+  int32_t mapping;             /* the phm_mapping in force (the automatic choice resolved) */
+  int32_t sparse_chains;       /* 1 when the sweep runs over the non-zeros of B only */
+  int32_t reserved;
 } phm_info;
 
 typedef struct phm_engine phm_engine;
 
 /* ---- library ---- */
 int32_t     phm_version(void);
+/* sizeof of the plain structs of this header as the library was built (which: 0 phm_options, 1 phm_info, 2 phm_tree,
+ * 3 phm_model; anything else: -1) -- lets a foreign-function binding (ctypes, cgo, .C) check its mirror of the layout */
+int32_t     phm_struct_size(int32_t which);
 int32_t     phm_device_count(void);
 const char* phm_last_error(void);
 const char* phm_status_string(int32_t status);
@@ -172,6 +190,13 @@ int32_t phm_SPARSEmaketreelistMCMC(   /* src/phylomap.cpp:822, src/RcppExports.c
     const phm_options* opt, double* out);
 /* Tree sweep of sumstatMCMCks with Q held fixed (see PHM_MCMC_KS); out: N x (n + n*n + 2 + 3k + 1) column-major. */
 int32_t phm_maketreelistMCMCks_sweep( /* src/phylomap.cpp:1802 minus the Q updates of :1862-1866 */
+    const phm_tree* x, int32_t n_states, const double* Q, const double* pid, const double* B, double Omega,
+    const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
+    const phm_options* opt, double* out);
+/* Tree sweep of sumstatMCMCbf with Q held fixed (see PHM_MCMC_BF), ANY n: tips observed, all consecutive pairs counted
+ * (the "n + n^2" layout of shortenerbf); out: N x (n + n*n + 3) column-major: dwell, counts (row-major from,to), Q[0,1], Q[1,0],
+ * root state (0-based). */
+int32_t phm_maketreelistMCMCbf_sweep( /* treesamplebf src/phylomap.cpp:1169-1179 inside the N-loop of :1295-1301, minus the updates */
     const phm_tree* x, int32_t n_states, const double* Q, const double* pid, const double* B, double Omega,
     const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
     const phm_options* opt, double* out);
@@ -287,7 +312,7 @@ int32_t phm_engine_set_model(phm_engine* e, const double* Q);
 int32_t phm_engine_dump(phm_engine* e, int32_t replica, int32_t* seg_count, double* seg_dwell, int32_t seg_cap,
                         int32_t* node_states, double* PL);
 int32_t phm_engine_info(phm_engine* e, phm_info* info);
-/* measurement aid (phm_options.reserved[2] = 1, (tile, item) mappings): HIP-event milliseconds of the last phm_engine_run, summed over
+/* measurement aid (phm_options.phase_timing = 1, (tile, item) mappings): HIP-event milliseconds of the last phm_engine_run, summed over
  * its sweeps, for the four phases of a sweep: pruning levels (makePLrcpp*), root + node draws (sampleinternalnodes*), the branch
  * kernel (sampleabranch + updatedwelltimes), the statistics reductions.  Valid after phm_engine_sync. */
 int32_t phm_engine_phase_ms(phm_engine* e, double* out4);

@@ -935,7 +935,11 @@ static int mcmc_driver(const orc_tree* x, int n, const double* Q_cm, const doubl
   const int32_t* edge2 = x->edge + E; const int32_t* edge1 = x->edge;
   const int ks = (variant == ORC_MCMC_KS) ? 1 : (variant == ORC_MCMC_BF) ? 2 : 0;   /* 1: ks sweep, 2: bf sweep */
   if (ks == 1 && (n & 1)) return ORC_ERR_BAD_INPUT;           /* hidden-rates structure: n = 2k+2 (:1820) */
-  if (ks == 2 && n != 2) return ORC_ERR_BAD_INPUT;            /* recordQ / updatel01 hard-wire two states (:1181-1185) */
+  /* The bf SWEEP (treesamplebf :1169-1179, sampleinternalnodesMCMCbf :1091-1163, sampleabranchbf :1031-1074, shortenerbf
+   * :997-1028) is written for any n; two states are hard-wired around it only: the N x 9 matrix (:1293), root column 8 (:1129)
+   * and updatel01 / updatel10 (:1187-1253).  With Q held fixed (prior == NULL) any n is taken: the root state goes to column
+   * n + n*n + 2, which is the reference's 8 at n = 2. */
+  if (ks == 2 && n != 2 && prior) return ORC_ERR_BAD_INPUT;
   if (prior && (!ks || (ks == 1 && n < 4) || n > 64)) return ORC_ERR_BAD_INPUT;
   const int kk = (ks == 1) ? n / 2 - 1 : 0;
   int cols = ks ? n + n * n + 2 + 3 * kk + 1 + (dic ? 1 : 0) : n + n * (n - 1);

@@ -46,8 +46,9 @@ extern "C" {
                                  shortenerbf counts :1010-1014, recordQks :1789-1798, root state :1350-1352;
                                  the Gibbs/MH updates of Q (:1862-1866) are NOT run.  out: N x (n+n*n+2+3k+1) */
 
-#define ORC_MCMC_BF       4   /* tree sweep of maketreelistMCMCbf src/phylomap.cpp:1258-1305 (two states, tips observed,
-                                 shortenerbf counts, columns l01 l10 root); out: N x 9 */
+#define ORC_MCMC_BF       4   /* tree sweep of maketreelistMCMCbf src/phylomap.cpp:1258-1305 (tips observed, shortenerbf counts,
+                                 columns l01 l10 root); out: N x (n + n*n + 3) -- N x 9 at the reference's two states; any n
+                                 with Q held fixed (the sweep :1169-1179 is n-generic), n = 2 with the rate updates */
 #define ORC_MCMC_MT       5   /* maketreelistMCMCmt   src/phylomap.cpp:2267-2365: list of trees, two states, Q updated */
 #define ORC_MCMC_KSMT     6   /* maketreelistMCMCksmt src/phylomap.cpp:2722-2844: list of trees, hidden rates */
 #define ORC_FORCE_NORMALISE 32 /* OR-ed into PLAIN / SPARSE: rows of the pruning pass divided by their sum (:525), not in the reference */

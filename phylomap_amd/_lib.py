@@ -16,9 +16,9 @@ STATUS = {0: "PHM_OK", 1: "PHM_ERR_BAD_INPUT", 2: "PHM_ERR_UNSUPPORTED", 3: "PHM
 PHM_MCMC, PHM_MCMC_BIGTREE, PHM_MCMC_SPARSE, PHM_MCMC_KS, PHM_MCMC_BF, PHM_MCMC_MT, PHM_MCMC_KSMT = 0, 1, 2, 3, 4, 5, 6
 
 EXPORTS = [
-    "phm_version", "phm_device_count", "phm_last_error", "phm_status_string",
+    "phm_version", "phm_struct_size", "phm_device_count", "phm_last_error", "phm_status_string",
     "phm_maketreelistMCMC", "phm_maketreelistMCMC_bigtree", "phm_SPARSEmaketreelistMCMC", "phm_maketreelistEXP",
-    "phm_maketreelistMCMCks_sweep", "phm_maketreelistMCMCbf", "phm_maketreelistMCMCks", "phm_maketreelistMCMC2sDICt", "phm_maketreelistMCMCksDICt", "phm_engine_set_model", "phm_qupdate_apply",
+    "phm_maketreelistMCMCks_sweep", "phm_maketreelistMCMCbf_sweep", "phm_maketreelistMCMCbf", "phm_maketreelistMCMCks", "phm_maketreelistMCMC2sDICt", "phm_maketreelistMCMCksDICt", "phm_engine_set_model", "phm_qupdate_apply",
     "phm_expm_eigen", "phm_expm_eigen_mfma", "phm_expm_pade", "phm_expm_pade_mfma",
     "phm_engine_create", "phm_engine_run", "phm_engine_sync", "phm_engine_read_stats", "phm_engine_dump",
     "phm_engine_info", "phm_engine_destroy", "phm_engine_reduced_stats_device",
@@ -49,7 +49,10 @@ class Model(C.Structure):
 class Options(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("n_replicas", C.c_int32), ("replica_offset", C.c_int32),
                 ("reduce", C.c_int32), ("tips_per_replica", C.c_int32), ("device", C.c_int32),
-                ("iters_per_launch", C.c_int32), ("cap_tail", C.c_double), ("reserved", C.c_int32 * 6)]
+                ("iters_per_launch", C.c_int32), ("cap_tail", C.c_double), ("mapping", C.c_int32), ("storage", C.c_int32),
+                ("pruning_form", C.c_int32), ("phase_timing", C.c_int32), ("rescale_pruning", C.c_int32),
+                ("no_recovery", C.c_int32), ("sparse_chains", C.c_int32), ("capacity_boost_log2", C.c_int32),
+                ("reserved", C.c_int32 * 3)]
 
 
 class Info(C.Structure):
@@ -57,7 +60,8 @@ class Info(C.Structure):
                 ("n_replicas_padded", C.c_int32), ("n_cols", C.c_int32), ("max_iters", C.c_int32),
                 ("device_bytes", C.c_int64), ("rows_per_replica", C.c_int64), ("seg_read", C.c_int64),
                 ("seg_written", C.c_int64), ("last_run_ms", C.c_double), ("last_run_launches", C.c_int32),
-                ("iters_done", C.c_int32)]
+                ("iters_done", C.c_int32), ("recoveries", C.c_int32), ("mapping", C.c_int32), ("sparse_chains", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 def _p(a, t):
@@ -104,6 +108,7 @@ def load():
         L.phm_maketreelistMCMC_bigtree.argtypes = mc
         L.phm_SPARSEmaketreelistMCMC.argtypes = mc
         L.phm_maketreelistMCMCks_sweep.argtypes = mc
+        L.phm_maketreelistMCMCbf_sweep.argtypes = mc
         mcq = mc[:10] + [C.POINTER(C.c_double), C.c_int32] + mc[10:]
         L.phm_maketreelistMCMCbf.argtypes = mcq
         L.phm_maketreelistMCMCks.argtypes = mcq
@@ -129,6 +134,10 @@ def load():
                                          C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.phm_expm_pade.argtypes = [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32, C.c_int32,
                                     C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        for which, mirror in enumerate((Options, Info, Tree, Model)):      # the ctypes mirrors must match the C layout
+            if L.phm_struct_size(which) != C.sizeof(mirror):
+                raise RuntimeError(f"{LIB_PATH}: {mirror.__name__} is {L.phm_struct_size(which)} bytes in the library, "
+                                   f"{C.sizeof(mirror)} in phylomap_amd/_lib.py (stale build? run make)")
         _lib = L
     return _lib
 
@@ -191,18 +200,21 @@ MAPPING = {"auto": 0, "replicas": 1, "branches": 2, "tiles": 3}
 
 def make_options(seed=0, n_replicas=1, replica_offset=0, reduce=False, tips_per_replica=False, device=-1,
                  iters_per_launch=0, cap_tail=0.0, storage=0, mapping="auto", phase_timing=False, rescale=False, recover=True,
-                 pruning_form=0):
+                 pruning_form=0, sparse_chains=0):
     """``mapping``: how a sweep is laid over the lanes -- "replicas" (one lane per chain: the throughput layout for many
     replicas), "branches" (one lane per branch, n <= 4; one wave per (replica, branch) for 5..64 states: few chains on a large
-    tree), "tiles" (lanes = replicas, one wave per tile of 64 replicas and branch: 10^2 .. 10^5 replicas) or "auto"."""
+    tree), "tiles" (lanes = replicas, one wave per tile of 64 replicas and branch: 10^2 .. 10^5 replicas) or "auto".
+    ``sparse_chains``: 5..64 states, "tiles": 0 automatic, 1 chains over the non-zeros of B only, 2 dense (matrix cores)."""
     o = Options()
     o.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
     o.n_replicas, o.replica_offset, o.reduce = int(n_replicas), int(replica_offset), int(bool(reduce))
-    o.reserved[0] = int(storage)          # 0 automatic, 1 ring, 2 two buffers
-    o.reserved[1] = (MAPPING[mapping] if isinstance(mapping, str) else int(mapping)) | (int(pruning_form) & 3) << 8      # pruning_form: 5..64 states, tiles: 1 a wave per (node, tile), 2 16-replica blocks, 0 by tile count
-    o.reserved[2] = int(bool(phase_timing))
-    o.reserved[3] = int(bool(rescale))      # sumstatEXP: rescaled pruning pass
-    o.reserved[5] = 0 if recover else 1     # capacity recovery (rebuild with doubled slots + replay)
+    o.storage = int(storage)          # 0 automatic, 1 ring, 2 two buffers
+    o.mapping = MAPPING[mapping] if isinstance(mapping, str) else int(mapping)
+    o.pruning_form = int(pruning_form) & 3      # 5..64 states, tiles: 1 a wave per (node, tile), 2 16-replica blocks, 0 by tile count
+    o.phase_timing = int(bool(phase_timing))
+    o.rescale_pruning = int(bool(rescale))      # sumstatEXP / sumstatMCMC / SPARSEsumstatMCMC: rescaled pruning pass
+    o.no_recovery = 0 if recover else 1         # capacity recovery (rebuild with doubled slots + replay)
+    o.sparse_chains = int(sparse_chains)
     o.tips_per_replica, o.device, o.iters_per_launch, o.cap_tail = int(bool(tips_per_replica)), int(device), int(iters_per_launch), float(cap_tail)
     return o
 
@@ -236,7 +248,7 @@ class Engine:
         if int(variant) in (PHM_MCMC_KS, PHM_MCMC_KSMT):
             self.cols = self.n + self.n * self.n + 2 + 3 * (self.n // 2 - 1) + 1
         if int(variant) in (PHM_MCMC_BF, PHM_MCMC_MT):
-            self.cols = 9
+            self.cols = self.n + self.n * self.n + 3
         self.S = max(1, int(self.opt.n_replicas)) * n_trees      # tree-major: replica j * n_replicas + c
         self.reduce = bool(self.opt.reduce)
 

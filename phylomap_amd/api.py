@@ -39,6 +39,8 @@ def _mcmc(fn_name, z, Q, pid, Omega, N, sites=None, **opt):
     cols = n + n * (n - 1)
     if fn_name == "phm_maketreelistMCMCks_sweep":
         cols = n + n * n + 2 + 3 * (n // 2 - 1) + 1                         # man/sumstatMCMCks.Rd:19
+    if fn_name == "phm_maketreelistMCMCbf_sweep":
+        cols = n + n * n + 3                                                  # dwell, n x n counts, Q[0,1], Q[1,0], root state
     single = bool(o.reduce) or S == 1
     out = np.zeros((N, cols), order="F") if single else np.zeros((S, cols, N))
     st = getattr(L, fn_name)(C.byref(ft.c), n, _lib._p(Q, C.c_double), _lib._p(pid, C.c_double),
@@ -69,6 +71,14 @@ def sumstatMCMCks_sweep(z, Q, pid, Omega, N, **opt):
     n x n transition counters including self pairs, result layout of man/sumstatMCMCks.Rd:19.  ``sumstatMCMCks`` below
     adds the per-iteration Gibbs/MH updates of Q (src/phylomap.cpp:1862-1866) and is the drop-in for the R function."""
     return _mcmc("phm_maketreelistMCMCks_sweep", z, Q, pid, Omega, N, **opt)
+
+
+def sumstatMCMCbf_sweep(z, Q, pid, Omega, N, **opt):
+    """The tree sweep of ``sumstatMCMCbf`` (treesamplebf, src/phylomap.cpp:1169-1179) with Q held FIXED, for ANY number of
+    states: tips observed, row-normalised pruning, every consecutive pair of segment states counted -- self pairs, i.e.
+    virtual jumps, included (shortenerbf :1010-1014) -- into n x n counters.  Columns: n dwell sums, n*n counts (row-major
+    from, to), Q[0,1], Q[1,0], root state (0-based); at n = 2 that is the layout of R/sumstatMCMCbf.R:33."""
+    return _mcmc("phm_maketreelistMCMCbf_sweep", z, Q, pid, Omega, N, **opt)
 
 
 def _qupdate(fn_name, z, Q, pid, Omega, N, prior, cols, **opt):

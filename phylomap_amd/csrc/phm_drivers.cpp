@@ -39,6 +39,11 @@ int32_t phm_maketreelistMCMCks_sweep(const phm_tree* x, int32_t n, const double*
                                      const phm_options* opt, double* out) {
   return run_mcmc_oneshot(PHM_MCMC_KS, x, n, Q, pid, B, Omega, nen, nodelist, root, N, opt, out);
 }
+int32_t phm_maketreelistMCMCbf_sweep(const phm_tree* x, int32_t n, const double* Q, const double* pid, const double* B,
+                                     double Omega, const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
+                                     const phm_options* opt, double* out) {
+  return run_mcmc_oneshot(PHM_MCMC_BF, x, n, Q, pid, B, Omega, nen, nodelist, root, N, opt, out);
+}
 int32_t phm_SPARSEmaketreelistMCMC(const phm_tree* x, int32_t n, const double* Q, const double* pid, const double* B,
                                    double Omega, const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
                                    const phm_options* opt, double* out) {
@@ -67,6 +72,7 @@ static int32_t run_qupdate(int variant, bool dic, const phm_tree* x, int32_t n, 
   if (N < 1) return fail(PHM_ERR_BAD_INPUT, "N must be >= 1");
   const int need = (variant == PHM_MCMC_BF) ? 4 : 6;
   if (n_prior < need) return fail(PHM_ERR_BAD_INPUT, variant == PHM_MCMC_BF ? "the two-state drivers need prior = c(a01, b01, a10, b10)" : "the hidden-rates drivers need prior = c(a_l, b_l, a_k, b_k, a_g, b_g)");
+  if (variant == PHM_MCMC_BF && n != 2) return fail(PHM_ERR_BAD_INPUT, "sumstatMCMCbf / sumstatMCMC2sDICt are two-state models (9 hard-wired columns and the two-rate updates, src/phylomap.cpp:1129, :1181-1253, :1293); the sweep alone takes any n: phm_maketreelistMCMCbf_sweep");
   if (variant == PHM_MCMC_KS && (n < 4 || (n & 1))) return fail(PHM_ERR_BAD_INPUT, "sumstatMCMCks needs n = 2k+2 states with k >= 1 (src/phylomap.cpp:1820; updateksl01 reads rkappas(0))");
   if (dic && (!x || !x->edge_length || !nen)) return fail(PHM_ERR_BAD_INPUT, "the DIC drivers need x$edge.length and nen (src/phylomap.cpp:3223, :3158)");
   phm_options o;

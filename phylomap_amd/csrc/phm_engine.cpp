@@ -24,6 +24,16 @@ constexpr int TILES_AUTO_MAX_REPLICAS = 262144;
 // interpolated linearly in n.
 inline int wbranch_auto_max_replicas(int n) { return std::max(0, std::min(8, 8 - (n - 20) / 5)); }
 
+// Tail at which the fixed slots of the branch-parallel mappings are provisioned, per (replica, branch, sweep).  A slot that
+// overflows costs a rebuild with doubled slots and a replay (recover_capacity), so the tail is set from the number of draws
+// the engine is created for: at most 0.05 expected recoveries over S x E x max_iters draws, and never looser than 1e-9 (the
+// quantile of 1 + Poisson(Omega t_b) moves by one segment per factor ~6 at Omega t_b = 4, so short runs get ~20 % smaller
+// slots than the 1e-14 of round 2 and the full-length C3 run keeps about what it had).
+inline double default_slot_tail(int64_t S, int64_t E, int64_t max_iters) {
+  const double draws = (double)std::max<int64_t>(S, 1) * (double)std::max<int64_t>(E, 1) * (double)std::max<int64_t>(max_iters, 1);
+  return std::max(1e-16, std::min(1e-9, 0.05 / draws));
+}
+
 bool ks_layout(int v) { return v == PHM_MCMC_KS || v == PHM_MCMC_BF || v == PHM_MCMC_MT || v == PHM_MCMC_KSMT; }   // n x n counts, root column
 bool hidden_rates(int v) { return v == PHM_MCMC_KS || v == PHM_MCMC_KSMT; }                                         // parity tip masks
 bool normalised_variant(int v) { return v == PHM_MCMC_BIGTREE || v == PHM_MCMC_KS || v == PHM_MCMC_BF; }           // makePLnormalized :1085
@@ -279,8 +289,8 @@ int32_t narrow_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
   const phm::Schedule& s = e->sched;
   const int E = s.n_edge, T = s.n_tips, Nn = s.n_node, n = e->n, S = e->S;
   // One slot per branch: 1 + Poisson(Omega t_b) segments in stationarity, provisioned far into the tail because a slot
-  // has no neighbour to borrow from (default 1e-14 per branch and sweep; an overflow is recovered by rebuilding with doubled slots); longer caller-supplied paths get m0 on top.
-  const double tail = o.cap_tail > 0.0 ? o.cap_tail : 1e-14;
+  // has no neighbour to borrow from (default_slot_tail; an overflow is recovered by rebuilding with doubled slots); longer caller-supplied paths get m0 on top.
+  const double tail = o.cap_tail > 0.0 ? o.cap_tail : default_slot_tail(S, E, max_iters);
   e->nw_off.assign(E + 1, 0);
   std::vector<int32_t> cap(E);
   int max_cap = 0;
@@ -432,8 +442,8 @@ int32_t tiles_setup(phm_engine* e, const phm_tree* x, const phm_model* model, co
   const phm::Schedule& s = e->sched;
   const int E = s.n_edge, T = s.n_tips, Nn = s.n_node, n = e->n, tiles = e->tiles;
   // One slot of rows per branch; a row holds the 64 replicas of the tile, so the slot must take the LARGEST of 64 segment
-  // counts: provisioned at 1e-14 per replica, branch and sweep (1 + Poisson(Omega t_b), plus the caller's initial length).
-  const double tail = o.cap_tail > 0.0 ? o.cap_tail : 1e-14;
+  // counts: provisioned at default_slot_tail per replica, branch and sweep (1 + Poisson(Omega t_b), plus the caller's initial length).
+  const double tail = o.cap_tail > 0.0 ? o.cap_tail : default_slot_tail(e->S, E, max_iters);
   e->tl_slot.assign(E + 1, 0);
   std::vector<int32_t> cap(E);
   int max_cap = 0;
@@ -537,7 +547,7 @@ int32_t tiles_setup(phm_engine* e, const phm_tree* x, const phm_model* model, co
 int32_t wtiles_setup(phm_engine* e, const phm_tree* x, const phm_model* model, const phm_options& o, int32_t max_iters) {
   const phm::Schedule& s = e->sched;
   const int E = s.n_edge, T = s.n_tips, Nn = s.n_node, n = e->n, tiles = e->tiles;
-  const double tail = o.cap_tail > 0.0 ? o.cap_tail : 1e-14;
+  const double tail = o.cap_tail > 0.0 ? o.cap_tail : default_slot_tail(e->S, E, max_iters);
   e->tl_slot.assign(E + 1, 0);
   std::vector<int32_t> cap(E);
   int max_cap = 0;
@@ -583,7 +593,12 @@ int32_t wtiles_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
   const size_t cnt_bytes = sizeof(uint32_t) * (size_t)tiles * n * n * 64;
   size_t free_b = 0, total_b = 0;
   HIPCHK(hipMemGetInfo(&free_b, &total_b));
-  const size_t need = 2 * dw_bytes + pl_bytes + cnt_bytes + stats_bytes + sizeof(double) * 3 * tab + (size_t)tiles * (5 * (size_t)E + Nn + 8 * (size_t)n) * 64;
+  const int nblk_need = (n + 7) / 8, ldb_need = (nblk_need + 1) & ~1;
+  const size_t tot_bytes = sizeof(double) * (size_t)e->nw_klong * n * n * ldb_need;                     // blkL: running sums of the forward draws
+  const size_t acc_bytes = sizeof(unsigned long long) * (size_t)tiles * (n + 1) * 64;                   // dwfx + segacc
+  const size_t red_bytes = e->reduce ? sizeof(double) * (size_t)max_iters * e->dcols : 0;
+  const size_t need = 2 * dw_bytes + pl_bytes + cnt_bytes + stats_bytes + tot_bytes + acc_bytes + red_bytes + sizeof(double) * 3 * tab +
+                      (size_t)tiles * (5 * (size_t)E + Nn + 8 * (size_t)n) * 64;
   if (need + (64u << 20) > free_b) {
     char buf[256];
     std::snprintf(buf, sizeof buf, "engine needs %.2f GiB of HBM, %.2f GiB free (reduce n_replicas or max_iters)", need / 1073741824.0, free_b / 1073741824.0);
@@ -613,7 +628,7 @@ int32_t wtiles_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
   HIPCHK(e->d_err.alloc(sizeof(uint32_t))); HIPCHK(e->d_seg.alloc(sizeof(unsigned long long)));
   if (e->reduce) HIPCHK(e->d_red.alloc(sizeof(double) * (size_t)max_iters * e->dcols));
   e->bytes = (int64_t)(2 * dw_bytes + pl_bytes + cnt_bytes + e->d_stats.bytes + e->d_red.bytes + e->d_mcount.bytes + e->d_tl_estate.bytes +
-                       e->d_nstate.bytes + e->d_wt_dwfx.bytes + sizeof(double) * 3 * tab);
+                       e->d_nstate.bytes + e->d_wt_dwfx.bytes + e->d_wt_segacc.bytes + e->d_wt_totL.bytes + sizeof(double) * 3 * tab);
   HIPCHK(hipMemcpy(e->d_up.p, s.up.data(), e->d_up.bytes, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(e->d_down.p, s.down.data(), e->d_down.bytes, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(e->d_nw_border.p, border.data(), e->d_nw_border.bytes, hipMemcpyHostToDevice));
@@ -646,7 +661,7 @@ int32_t wtiles_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
   // branches per wave of the branch kernel: one while waves are scarce, up to 8 once there are 65 536 of them anyway
   p.group = (int32_t)std::max<int64_t>(1, std::min<int64_t>(8, (int64_t)tiles * E / 65536));
   p.n_groups = (E + p.group - 1) / p.group;
-  p.up_form = (o.reserved[1] >> 8) & 3;
+  p.up_form = o.pruning_form & 3; p.sparse = 0;
   p.seed_lo = (uint32_t)(o.seed & 0xFFFFFFFFull); p.seed_hi = (uint32_t)(o.seed >> 32);
   p.rows = rows;
   {   // dwell accumulators: 64-bit fixed point, a replica's column never exceeds the tree length
@@ -675,6 +690,8 @@ phm_engine* live(phm_engine* e) {
   while (e && e->fwd) e = e->fwd;
   return e;
 }
+// a handle whose capacity recovery failed has no device state left (recover_capacity)
+inline int32_t dead_engine() { return fail(PHM_ERR_CAPACITY, "the engine outgrew its dwell capacity and could not be rebuilt; destroy it and create a new one (larger cap_tail margin, fewer replicas)"); }
 
 std::shared_ptr<SavedInput> save_input(const phm_tree* trees, int32_t n_trees, const phm_model* model, const phm_options& o, int32_t max_iters) {
   auto sv = std::make_shared<SavedInput>();
@@ -711,6 +728,16 @@ std::shared_ptr<SavedInput> save_input(const phm_tree* trees, int32_t n_trees, c
 extern "C" {
 
 int32_t phm_version(void) { return PHM_VERSION; }
+
+int32_t phm_struct_size(int32_t which) {
+  switch (which) {
+    case 0: return (int32_t)sizeof(phm_options);
+    case 1: return (int32_t)sizeof(phm_info);
+    case 2: return (int32_t)sizeof(phm_tree);
+    case 3: return (int32_t)sizeof(phm_model);
+    default: return -1;
+  }
+}
 
 int32_t phm_device_count(void) {
   int n = 0;
@@ -758,7 +785,12 @@ int32_t phm_engine_create_multi(const phm_tree* trees, int32_t n_trees, const ph
   if (!model->Q || !model->pid) return fail(PHM_ERR_BAD_INPUT, "model: Q/pid missing");
   if (model->variant < PHM_MCMC || model->variant > PHM_MCMC_KSMT) return fail(PHM_ERR_BAD_INPUT, "unknown variant");
   if (hidden_rates(model->variant) && (n & 1)) return fail(PHM_ERR_BAD_INPUT, "sumstatMCMCks needs a hidden-rates Q of even size n = 2k+2 (src/phylomap.cpp:1820)");
-  if ((model->variant == PHM_MCMC_BF || model->variant == PHM_MCMC_MT) && n != 2) return fail(PHM_ERR_BAD_INPUT, "sumstatMCMCbf / sumstatMCMCmt are two-state models (hard-wired columns, src/phylomap.cpp:1181-1185, :2169-2173)");
+  // The bf SWEEP (treesamplebf :1169-1179: sampleinternalnodesMCMCbf :1091-1163, sampleabranchbf :1031-1074, shortenerbf :997-1028)
+  // is written for any n; what hard-wires two states is around it: the 9-column matrix and root column 8 of the driver
+  // (:1129, :1293) and the rate updates (:1181-1253) -- those restrictions live in phm_maketreelistMCMCbf / 2sDICt.  Here PHM_MCMC_BF
+  // with n states gives n dwell sums, n x n counts incl. self pairs, Q[0,1], Q[1,0] and the root state in column n + n*n + 2
+  // (= 8 at n = 2).  The multi-tree sweep keeps n = 2 (recordQmtNS :2169-2173 writes columns 6 and 7).
+  if (model->variant == PHM_MCMC_MT && n != 2) return fail(PHM_ERR_BAD_INPUT, "sumstatMCMCmt is a two-state model (hard-wired columns, src/phylomap.cpp:2169-2173)");
   if (n_trees > 1 && (o.reduce || o.tips_per_replica)) return fail(PHM_ERR_UNSUPPORTED, "a list of trees takes neither reduce nor tips_per_replica");
   if (max_iters < 1) return fail(PHM_ERR_BAD_INPUT, "max_iters must be >= 1");
   if (!(model->Omega > 0.0) || !std::isfinite(model->Omega)) return fail(PHM_ERR_BAD_INPUT, "Omega must be positive");
@@ -798,12 +830,12 @@ int32_t phm_engine_create_multi(const phm_tree* trees, int32_t n_trees, const ph
   e->max_iters = max_iters; e->reduce = o.reduce ? 1 : 0;
   e->ipl = o.iters_per_launch > 0 ? o.iters_per_launch : 8;
   e->tips_per_replica = o.tips_per_replica != 0 || n_trees > 1;      // a list of trees: tip data per tile
-  e->phase_timing = o.reserved[2] != 0;
-  // reserved[3] != 0 with a fixed-Q MCMC variant: the pruning pass of sumstatMCMC / SPARSEsumstatMCMC rescaled like _bigtree's (:525)
-  e->normalise = normalised_variant(e->variant) || (o.reserved[3] != 0 && (e->variant == PHM_MCMC || e->variant == PHM_MCMC_SPARSE));
-  e->cap_boost = 1 << std::max(0, std::min(10, (int)o.reserved[4]));      // internal: set by the capacity recovery
-  e->recover = o.reserved[5] == 0;
-  e->saved = save_input(trees, n_trees, model, o, max_iters);
+  e->phase_timing = o.phase_timing != 0;
+  // rescale_pruning with a fixed-Q MCMC variant: the pruning pass of sumstatMCMC / SPARSEsumstatMCMC rescaled like _bigtree's (:525)
+  e->normalise = normalised_variant(e->variant) || (o.rescale_pruning != 0 && (e->variant == PHM_MCMC || e->variant == PHM_MCMC_SPARSE));
+  e->cap_boost = 1 << std::max(0, std::min(10, (int)o.capacity_boost_log2));      // internal: set by the capacity recovery
+  e->recover = o.no_recovery == 0;
+  if (e->recover) e->saved = save_input(trees, n_trees, model, o, max_iters);      // the replay needs the caller's inputs; nothing is kept otherwise
 
   std::string serr;
   e->scheds.resize(n_trees);
@@ -816,11 +848,11 @@ int32_t phm_engine_create_multi(const phm_tree* trees, int32_t n_trees, const ph
   HIPCHK(hipGetDevice(&e->device));
   const int E = s.n_edge, T = s.n_tips;
 
-  // Mapping of the sweep onto lanes (reserved[1]: 0 automatic, 1 one lane per replica, 2 one lane per branch): with few
+  // Mapping of the sweep onto lanes (phm_options.mapping): with few
   // chains the replica mapping would leave all but a handful of lanes idle and walk the tree sequentially.
   const bool small_n = !e->wide && n_trees == 1;
-  const int map_req = o.reserved[1] & 0xff;      // bits 8-9: form of the wide-state pruning kernel (measurement / tests)
-  const bool auto_map = map_req == 0 && o.reserved[0] == 0;      // a ring / two-buffer request names the replica layout
+  const int map_req = o.mapping;
+  const bool auto_map = map_req == PHM_MAP_AUTO && o.storage == 0;      // a ring / two-buffer request names the replica layout
   if ((map_req == 2 || map_req == 3) && n_trees != 1) return fail(PHM_ERR_UNSUPPORTED, "the branch-parallel mappings take a single tree");
   if (e->wide) {      // 5..64 states: lane = replica, wave per (tile, item) (phm_wtiles.hip); a handful of chains: wave per (replica, branch)
     e->tiled = n_trees == 1 && (map_req == 3 || (auto_map && e->S > wbranch_auto_max_replicas(n)));
@@ -940,10 +972,10 @@ int32_t phm_engine_create_multi(const phm_tree* trees, int32_t n_trees, const ph
                                                      : sizeof(double) * (size_t)max_iters * e->dcols * e->S_pad;
   const size_t dw_bytes = sizeof(double) * (size_t)e->tiles * rows * 64;
   // Two buffers save two VALU operations per dwell access (about 5 % of the n <= 4 sweep) and cost twice the HBM:
-  // used when they take less than a third of the free memory, unless the caller asks (reserved[0]: 1 ring, 2 two buffers).
+  // used when they take less than a third of the free memory, unless the caller asks (phm_options.storage: 1 ring, 2 two buffers).
   size_t free_b = 0, total_b = 0;
   HIPCHK(hipMemGetInfo(&free_b, &total_b));
-  e->ring = e->wide || n_trees > 1 || o.reserved[0] == 1 || (o.reserved[0] != 2 && 2 * dw_bytes > free_b / 3);
+  e->ring = e->wide || n_trees > 1 || o.storage == 1 || (o.storage != 2 && 2 * dw_bytes > free_b / 3);
   size_t need = (e->ring ? 1 : 2) * dw_bytes + stats_bytes + sizeof(double) * (size_t)e->tiles * s.n_node * n * 64 +
                 (size_t)e->tiles * (s.n_node + 2 * (size_t)E) * 64 + e->tips_host.size();
   if (need + (64u << 20) > free_b) {
@@ -1042,6 +1074,7 @@ int32_t phm_engine_create_multi(const phm_tree* trees, int32_t n_trees, const ph
 int32_t phm_engine_run(phm_engine* e, int32_t n_iters, void* hip_stream) {
   e = live(e);
   if (!e) return fail(PHM_ERR_STATE, "engine is NULL");
+  if (e->dead) return dead_engine();
   if (n_iters < 0 || e->iters_done + n_iters > e->max_iters) return fail(PHM_ERR_STATE, "iteration range exceeds max_iters");
   HIPCHK(hipSetDevice(e->device));
   hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
@@ -1107,30 +1140,38 @@ static int32_t recover_capacity(phm_engine* e) {
   int boost_log2 = 0;
   while ((1 << boost_log2) < e->cap_boost) ++boost_log2;
   if (boost_log2 >= 8) return fail(PHM_ERR_CAPACITY, "a branch outgrew its dwell capacity after 8 doublings of the slots");
+  // The chain state of this engine is past an overflow and of no further use; its buffers go first because the doubled slots
+  // of the replacement rarely fit beside them.  From here on the handle is either forwarded to a working replacement or DEAD:
+  // every entry point refuses a dead engine (PHM_ERR_CAPACITY) instead of launching on freed memory.
   e->release_device();
+  e->dead = true;
   phm_options o = sv->opt;
-  o.reserved[4] = boost_log2 + 1;
+  o.capacity_boost_log2 = boost_log2 + 1;
   phm_engine* r = nullptr;
   const std::vector<std::pair<int32_t, std::vector<double>>> hist = sv->model_hist;      // the replay appends its own copy
   int32_t st = phm_engine_create_multi(sv->flat.data(), (int32_t)sv->flat.size(), &sv->model, &o, sv->max_iters, &r);
   if (st) return (st == PHM_ERR_OOM) ? fail(PHM_ERR_CAPACITY, "a branch outgrew its dwell capacity and larger slots do not fit in HBM: " + g_phm_err) : st;
   r->recoveries = e->recoveries + 1;
-  e->fwd = r;
   size_t h = 0;
   for (int it = 0; it < T && !st;) {
-    while (h < hist.size() && hist[h].first <= it) { st = phm_engine_set_model(r, hist[h].second.data()); ++h; if (st) return st; }
+    while (!st && h < hist.size() && hist[h].first <= it) { st = phm_engine_set_model(r, hist[h].second.data()); ++h; }
+    if (st) break;
     const int next = (h < hist.size()) ? std::min(T, hist[h].first) : T;
     st = phm_engine_run(r, next - it, stream);
     it = next;
   }
   while (!st && h < hist.size()) { st = phm_engine_set_model(r, hist[h].second.data()); ++h; }
-  if (st) return st;
-  return phm_engine_sync(r);          // may recover again (the replacement forwards in turn)
+  if (!st) st = phm_engine_sync(r);   // may recover again (the replacement forwards in turn; it ends up dead itself if that fails)
+  if (st) { const std::string msg = g_phm_err; delete r; return fail(st, "capacity recovery failed, the engine is no longer usable: " + msg); }
+  e->fwd = r;
+  e->dead = false;
+  return PHM_OK;
 }
 
 int32_t phm_engine_sync(phm_engine* e) {
   e = live(e);
   if (!e) return fail(PHM_ERR_STATE, "engine is NULL");
+  if (e->dead) return dead_engine();
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipStreamSynchronize(e->last_stream));
   if (e->timing_pending) {
@@ -1157,6 +1198,7 @@ int32_t phm_engine_sync(phm_engine* e) {
 int32_t phm_engine_read_stats(phm_engine* e, int32_t iter0, int32_t n, double* out) {
   e = live(e);
   if (!e || !out) return fail(PHM_ERR_STATE, "engine/out is NULL");
+  if (e->dead) return dead_engine();
   if (iter0 < 0 || n < 0 || iter0 + n > e->iters_done) return fail(PHM_ERR_STATE, "statistics requested for iterations that have not run");
   if (n == 0) return PHM_OK;
   HIPCHK(hipSetDevice(e->device));
@@ -1197,6 +1239,7 @@ int32_t phm_engine_dump(phm_engine* e, int32_t replica, int32_t* seg_count, doub
                         int32_t* node_states, double* PL) {
   e = live(e);
   if (!e) return fail(PHM_ERR_STATE, "engine is NULL");
+  if (e->dead) return dead_engine();
   if (replica < 0 || replica >= e->S) return fail(PHM_ERR_BAD_INPUT, "replica out of range");
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipStreamSynchronize(e->last_stream));
@@ -1283,12 +1326,16 @@ int32_t phm_engine_dump(phm_engine* e, int32_t replica, int32_t* seg_count, doub
 int32_t phm_engine_info(phm_engine* e, phm_info* info) {
   e = live(e);
   if (!e || !info) return fail(PHM_ERR_STATE, "engine/info is NULL");
+  if (e->dead) return dead_engine();
   std::memset(info, 0, sizeof(*info));
   info->n_states = e->n; info->n_edge = e->sched.n_edge; info->n_replicas = e->S; info->n_replicas_padded = e->S_pad;
   info->n_cols = e->cols; info->max_iters = e->max_iters; info->device_bytes = e->bytes;
   info->rows_per_replica = e->rows;
   info->seg_read = (int64_t)e->seg_total; info->seg_written = 0;
   info->last_run_ms = e->last_ms; info->last_run_launches = e->last_launches; info->iters_done = e->iters_done;
+  info->recoveries = e->recoveries;
+  info->mapping = e->narrow ? PHM_MAP_BRANCHES : e->tiled ? PHM_MAP_TILES : PHM_MAP_REPLICAS;
+  info->sparse_chains = (e->tiled && e->wide) ? e->pwt.sparse : 0;
   return PHM_OK;
 }
 
@@ -1297,7 +1344,8 @@ void phm_engine_destroy(phm_engine* e) { delete e; }      // deletes the chain o
 int32_t phm_engine_phase_ms(phm_engine* e, double* out4) {
   e = live(e);
   if (!e || !out4) return fail(PHM_ERR_STATE, "engine/out is NULL");
-  if (!e->phase_timing || !e->tiled) return fail(PHM_ERR_STATE, "phase timing needs phm_options.reserved[2] = 1 and a (tile, item) mapping");
+  if (e->dead) return dead_engine();
+  if (!e->phase_timing || !e->tiled) return fail(PHM_ERR_STATE, "phase timing needs phm_options.phase_timing = 1 and a (tile, item) mapping");
   for (int i = 0; i < 4; ++i) out4[i] = e->phase_ms[i];
   return PHM_OK;
 }
@@ -1312,6 +1360,7 @@ extern "C" int32_t phm_engine_reduced_stats_device(phm_engine* e, int32_t iter0,
                                                    void** out_dev) {
   e = live(e);
   if (!e || !out_dev) return fail(PHM_ERR_STATE, "engine/out is NULL");
+  if (e->dead) return dead_engine();
   if (!e->reduce) return fail(PHM_ERR_STATE, "engine was not created with reduce = 1");
   if (iter0 < 0 || n < 1 || iter0 + n > e->iters_done) return fail(PHM_ERR_STATE, "statistics requested for iterations that have not run");
   HIPCHK(hipSetDevice(e->device));
@@ -1330,6 +1379,7 @@ extern "C" int32_t phm_engine_reduced_stats_device(phm_engine* e, int32_t iter0,
 extern "C" int32_t phm_engine_time_pruning(phm_engine* e, int32_t n_iters, void* hip_stream, double* ms_out) {
   e = live(e);
   if (!e || !ms_out) return fail(PHM_ERR_STATE, "engine/ms_out is NULL");
+  if (e->dead) return dead_engine();
   const bool wt = e->wide && e->tiled;
   if (!wt && (e->wide || e->narrow || e->tiled || e->n_trees > 1)) return fail(PHM_ERR_UNSUPPORTED, "pruning-only timing is implemented for the replica mapping with n_states <= 4 and the lane-per-replica mapping of 5..64 states");
   if (n_iters < 1) return fail(PHM_ERR_BAD_INPUT, "n_iters must be >= 1");
@@ -1358,6 +1408,7 @@ extern "C" int32_t phm_engine_time_pruning(phm_engine* e, int32_t n_iters, void*
 extern "C" int32_t phm_engine_set_model(phm_engine* e, const double* Q) {
   e = live(e);
   if (!e || !Q) return fail(PHM_ERR_STATE, "engine/Q is NULL");
+  if (e->dead) return dead_engine();
   if (e->saved) e->saved->model_hist.emplace_back(e->iters_done, std::vector<double>(Q, Q + (size_t)e->n * e->n));
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipStreamSynchronize(e->last_stream));

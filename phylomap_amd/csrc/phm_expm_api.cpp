@@ -206,17 +206,17 @@ int32_t phm_maketreelistEXP(const phm_tree* x, int32_t n, const double* Q, const
     HIPCHK(duord.alloc(sizeof(int32_t) * uorder.size()));
     HIPCHK(hipMemcpy(duord.p, uorder.data(), duord.bytes, hipMemcpyHostToDevice));
     HIPCHK(phm::launch_exp_pl_levels(n, T, dup.as<phm::UpStep>(), duord.as<int32_t>(), ulevel, dP.as<double>(), dPL.as<double>(),
-                                     o.reserved[3] != 0, nullptr));
+                                     o.rescale_pruning != 0, nullptr));
     HIPCHK(hipDeviceSynchronize());      // duord goes out of scope
   }
   hipEvent_t ev0 = nullptr, ev1 = nullptr;      // time of the sampling kernel alone (phm_last_kernel_ms)
   HIPCHK(hipEventCreate(&ev0)); HIPCHK(hipEventCreate(&ev1));
   HIPCHK(hipEventRecord(ev0, nullptr));
 
-  // Mapping (phm_options.reserved[1]): 1 = one wave per tile of 64 samples walks the tree (exp_sample_kernel / exp_wide_kernel);
+  // Mapping (phm_options.mapping): 1 = one wave per tile of 64 samples walks the tree (exp_sample_kernel / exp_wide_kernel);
   // 3 = one wave per (tile, branch) (exp_tiles_*); 0 = automatic: the (tile, branch) mapping unless there are so many samples
   // that the tiles alone fill the chip.
-  const bool use_tiles = o.reserved[1] == 3 || (o.reserved[1] == 0 && tiles < EXP_TILES_AUTO_MAX_TILES);
+  const bool use_tiles = o.mapping == PHM_MAP_TILES || (o.mapping == PHM_MAP_AUTO && tiles < EXP_TILES_AUTO_MAX_TILES);
   if (use_tiles) {
     // edges with an internal child, grouped by depth (parents' states are drawn a level earlier)
     std::vector<int32_t> depth(s.n_node, 0), order, level_off;

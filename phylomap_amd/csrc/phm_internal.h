@@ -181,8 +181,9 @@ struct phm_engine {
   std::shared_ptr<SavedInput> saved;
   phm_engine* fwd = nullptr;                       // set after a capacity recovery: every entry point continues on the rebuilt engine
   int cap_boost = 1;                               // multiplier of the provisioned slot / stream capacities (doubles per recovery)
-  bool recover = true;                             // phm_options.reserved[5] = 1 switches the recovery off (overflow -> PHM_ERR_CAPACITY)
+  bool recover = true;                             // phm_options.no_recovery = 1 switches the recovery off (overflow -> PHM_ERR_CAPACITY)
   int recoveries = 0;
+  bool dead = false;                               // a capacity recovery failed: no device state left, every entry point refuses
   int n = 0, cols = 0, dcols = 0, variant = 0;   // cols: result columns; dcols: columns kept on the device
   std::vector<double> qparams;                     // bf/ks: l01, l10, rkappas, lkappas, gammas of the CURRENT Q (recordQks :1789-1798)
   std::vector<std::vector<double>> qhist;          // ... as recorded at the start of every iteration that has run
@@ -190,7 +191,7 @@ struct phm_engine {
   std::vector<double> hB2, hBc, hscale, hpid;      // current model, row-major
   int S = 0, S_pad = 0, tiles = 0, max_iters = 0, iters_done = 0, ipl = 0;
   int reduce = 0, device = 0;
-  bool normalise = false;               // rows of the pruning pass divided by their sum (the variant's own rule, or phm_options.reserved[3])
+  bool normalise = false;               // rows of the pruning pass divided by their sum (the variant's own rule, or phm_options.rescale_pruning)
   phm::Schedule sched;                 // tree 0 (every tree of a list has the same tip / edge counts)
   std::vector<phm::Schedule> scheds;   // one per tree
   int n_trees = 1, S_tree = 0, tpt = 0;   // list of trees: S_tree chains per tree on tpt tiles each; S = n_trees * S_tree
@@ -233,7 +234,7 @@ struct phm_engine {
   // 5..64 states with `tiled` set: one lane per replica, wave per (tile, item), pruning on the matrix cores (phm_wtiles.hip)
   phm::WtParams pwt;
   DevBuf d_wt_dwfx, d_wt_segacc, d_wt_B2, d_wt_totL, d_wt_pair_slot, d_wt_slot_col;
-  bool phase_timing = false;                       // phm_options.reserved[2]: HIP events between the phases of a (tile, item) sweep
+  bool phase_timing = false;                       // phm_options.phase_timing: HIP events between the phases of a (tile, item) sweep
   std::vector<hipEvent_t> phase_ev;                // 5 per iteration of the last run
   int phase_iters = 0;
   double phase_ms[4] = {0.0, 0.0, 0.0, 0.0};       // pruning levels, node draws, branch kernel, reductions (sums over the last run)

@@ -48,6 +48,7 @@ struct WtParams {
   int32_t normalise, tips_per_replica, ks, tip_masks, reduce, n_cols;
   int32_t klong;                             // rows of the chain tables
   int32_t group, n_groups;                   // branches walked by one wave of the branch kernel; ceil(n_edge / group)
+  int32_t sparse;                            // 1: chains and forward draws over the non-zeros of the chain matrix (ELLPACK tables below)
   int32_t up_form;                           // pruning kernel: 0 chosen by tile count, 1 a wave per (node, tile), 2 split into 16-replica blocks
   uint32_t seed_lo, seed_hi;
   int64_t rows;                              // rows of one tile in one dwell buffer (sum of the slot sizes)

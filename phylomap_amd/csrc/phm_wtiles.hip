@@ -1,9 +1,27 @@
 // phm_wtiles.hip -- 5..64 states, one lane per replica, a wavefront per (tile of 64 replicas, item); see phm_wtiles.h.
 #include "phm_wtiles.h"
 
+#include <mutex>
+#include <utility>
+
 namespace phm {
 
 namespace {
+
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to the function object of the CURRENT device: remembered per
+// (function, device) under a mutex (one process may drive several GPUs from several threads), errors handed back.
+hipError_t allow_dynamic_lds(const void* fn, int bytes) {
+  static std::mutex mu;
+  static std::vector<std::pair<const void*, int>> done;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> guard(mu);
+  for (const auto& d : done) if (d.first == fn && d.second == dev) return hipSuccess;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) done.emplace_back(fn, dev);
+  return e;
+}
 
 using d4_t = __attribute__((ext_vector_type(4))) double;
 
@@ -836,13 +854,12 @@ __global__ __launch_bounds__(WT_BLOCK) void wt_stats_kernel(WtParams p, int it, 
 }
 
 template <int MT>
-void launch_up_levels(const WtParams& p, const std::vector<int32_t>& up_off, hipStream_t stream) {
+hipError_t launch_up_levels(const WtParams& p, const std::vector<int32_t>& up_off, hipStream_t stream) {
   const size_t lds = sizeof(double) * (size_t)(WT_BLOCK / 64) * p.n_states * 64;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wt_up_kernel<MT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)(sizeof(double) * (size_t)(WT_BLOCK / 64) * 16 * MT * 64));      // the largest n of this MT
-    attr_set = true;
+  {
+    const hipError_t ae = allow_dynamic_lds(reinterpret_cast<const void*>(wt_up_kernel<MT>),
+                                            (int)(sizeof(double) * (size_t)(WT_BLOCK / 64) * 16 * MT * 64));      // the largest n of this MT
+    if (ae != hipSuccess) return ae;
   }
   // Measured crossovers (profiles/r02_probe_few_tiles.log): the row-split workgroups win below about 64 tiles at 20 states and
   // below about 512 tiles at 61 states; the sorted blocks of the per-tile kernel beyond.
@@ -866,17 +883,19 @@ void launch_up_levels(const WtParams& p, const std::vector<int32_t>& up_off, hip
       hipLaunchKernelGGL(wt_up_kernel<MT>, dim3(grid), dim3(WT_BLOCK), lds, stream, p, up_off[l], up_off[l + 1]);
     }
   }
+  return hipSuccess;
 }
 
 }  // namespace
 
 hipError_t launch_wtiles_up(const WtParams& p, const std::vector<int32_t>& up_off, hipStream_t stream) {
   const int mt = (p.n_states + 15) / 16;
-  if (mt == 1) launch_up_levels<1>(p, up_off, stream);
-  else if (mt == 2) launch_up_levels<2>(p, up_off, stream);
-  else if (mt == 3) launch_up_levels<3>(p, up_off, stream);
-  else launch_up_levels<4>(p, up_off, stream);
-  return hipGetLastError();
+  hipError_t e;
+  if (mt == 1) e = launch_up_levels<1>(p, up_off, stream);
+  else if (mt == 2) e = launch_up_levels<2>(p, up_off, stream);
+  else if (mt == 3) e = launch_up_levels<3>(p, up_off, stream);
+  else e = launch_up_levels<4>(p, up_off, stream);
+  return e != hipSuccess ? e : hipGetLastError();
 }
 
 hipError_t launch_wtiles_sweep(const WtParams& p, const std::vector<int32_t>& up_off,
@@ -910,11 +929,10 @@ hipError_t launch_wtiles_sweep(const WtParams& p, const std::vector<int32_t>& up
     const int wpb = small ? WT_BRANCH_BLOCK_SMALL / 64 : WPB;
     const dim3 g((unsigned)(((int64_t)p.n_groups + wpb - 1) / wpb * p.n_tiles));
     const bool b2l = !small && p.group >= 4;           // n > 32: B rows in LDS once a wave walks four or more branches
-    static bool attr_set = false;
-    if (!attr_set) {      // n = 32 with 96 countable pairs: 51 KB dynamic + 35 KB static per eight-wave workgroup, beyond the default 64 KB
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wt_branch_kernel<true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wt_branch_kernel<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-      attr_set = true;
+    if (small) {      // n = 32 with 96 countable pairs: 51 KB dynamic + 35 KB static per eight-wave workgroup, beyond the default 64 KB
+      const hipError_t ae = p.ks ? allow_dynamic_lds(reinterpret_cast<const void*>(wt_branch_kernel<true, true, true>), 64 * 1024)
+                                 : allow_dynamic_lds(reinterpret_cast<const void*>(wt_branch_kernel<false, true, true>), 64 * 1024);
+      if (ae != hipSuccess) return ae;
     }
     const size_t lds_now = small ? lds : (b2l ? lds : 0);
     if (p.ks) {

@@ -133,7 +133,7 @@ def maketreelistMCMC(z, Q, pid, B, Omega, nen, nodelist, root, N, variant=PLAIN,
     if variant & ~FORCE_NORMALISE == KS:
         cols = n + n * n + 2 + 3 * (n // 2 - 1) + 1
     if variant & ~FORCE_NORMALISE == BF:
-        cols = 9
+        cols = n + n * n + 3
     if dic:
         cols += 1
     out = np.zeros((N, cols), order="F")

@@ -229,10 +229,11 @@ def sumstatMCMC(z, Q, pid, Omega, N, nen, nodelist, root, seed, replica, variant
     dw = [[float(x) for x in z["maps"][b]] for b in range(E)]
     st = [[int(x) - 1 for x in z["mapnames"][b]] for b in range(E)]                              # :29
     PL = [[0.0] * n for _ in range(2 * T - 1)]
-    ks = variant == "ks"                                   # treesampleks :1422-1432 with Q fixed (maketreelistMCMCks :1802-1872)
-    kk = n // 2 - 1
+    hid = variant == "ks"                                  # treesampleks :1422-1432 with Q fixed (maketreelistMCMCks :1802-1872)
+    ks = hid or variant == "bf"                            # bf: treesamplebf :1169-1179 -- the n x n counting layout with observed tips
+    kk = n // 2 - 1 if hid else 0
     for i in range(T):
-        if not ks:
+        if not hid:
             PL[i][int(z["states"][i]) - 1] = 1.0                                                # :914
         else:                                                                                   # :1838-1845
             for j in range(1 if int(z["states"][i]) % 2 == 0 else 0, n, 2):
@@ -274,7 +275,8 @@ def sumstatMCMC(z, Q, pid, Omega, N, nen, nodelist, root, seed, replica, variant
                 v = matTvec(Bc, v)
             rm[node - 1] = sample([v[c] * PL[node - 1][c] for c in range(n)], rng.u(it, ENT_NODE | (node - 1), 0))
         if ks:
-            out[it][cols - 1] = float(rm[root - 1])                                             # :1350-1352
+            out[it][cols - 1] = float(rm[root - 1])                                             # :1350-1352 / :1129
+        if hid:
             for b in range(E):                                                                  # :1384-1397
                 if e2[b] <= T:
                     ps = rm[e1[b] - 1]

@@ -125,6 +125,71 @@ def test_c4_dense_61_states_500_tips(mapping):
     _run_config(4, _lib.PHM_MCMC_BIGTREE, O.BIGTREE, mapping, S, 8, 4242, False, dump_replica=S - 1)
 
 
+def _check_ks_rows(got, want, n):
+    """n dwell sums (1e-10), n x n counts incl. self pairs (exact), parameter columns and root state (exact)"""
+    assert got.shape == want.shape
+    np.testing.assert_array_equal(got[:, n:], want[:, n:])
+    np.testing.assert_allclose(got[:, :n], want[:, :n], rtol=1e-10, atol=0)
+
+
+@pytest.mark.parametrize("mapping,S", [("replicas", 70), ("branches", 66), ("tiles", 128), ("tiles", 8512)])
+def test_c4_61_states_in_the_n_plus_n2_counting_layout(mapping, S):
+    """C4 as SURVEY section 8 scopes it: the `ks layout` = n dwell sums + n x n counts with self pairs (shortenerbf,
+    src/phylomap.cpp:997-1028; sampleabranchbf :1031-1074; treesamplebf :1169-1179) on the dense 61-state Q -- odd n, so
+    observed tips (the bf sweep; the hidden-rates masks need even n).  8 512 replicas = 133 tiles: the branch kernel's
+    KS template with grouped branches and 61 x 61 counters per lane."""
+    z, Q, pid, Omega, nen, nodelist, root = _config(4)
+    n, N, seed = 61, (3 if S > 1000 else 6), 6100 + S
+    got = api.sumstatMCMCbf_sweep(z, Q, pid, Omega, N, seed=seed, n_replicas=S, mapping=mapping)
+    assert got.shape == (S, N, n + n * n + 3)
+    for r in sorted({0, 17, min(63, S - 1), min(S // 2 + 50, S - 1), S - 1}):
+        want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(n) + Q / Omega, Omega, nen, nodelist, root, N, variant=O.BF, seed=seed, replica=r)
+        assert rc == 0
+        _check_ks_rows(got[r], want, n)
+    np.testing.assert_allclose(got[:, :, :n].sum(2), z["edge.length"].sum(), rtol=1e-11)
+    cnt = got[:, :, n:n + n * n]
+    assert np.all(cnt == np.round(cnt)) and cnt.sum() > 0
+    if S <= 128:      # summed over replicas on the device = the sum of the per-replica rows
+        red = api.sumstatMCMCbf_sweep(z, Q, pid, Omega, N, seed=seed, n_replicas=S, mapping=mapping, reduce=True)
+        np.testing.assert_array_equal(red[:, n:n + n * n], got.sum(0)[:, n:n + n * n])
+        np.testing.assert_allclose(red[:, :n], got.sum(0)[:, :n], rtol=1e-12)
+
+
+def _hidden_rates_62():
+    """62 states = 31 rate regimes of a binary trait (make2sQ, R/sourceme.R:229-246) on the C4 tree; only the trait is observed"""
+    if "hr62" not in _CACHE:
+        k = 30
+        rk = 0.02 + 0.01 * (np.arange(k) % 5)
+        lk = 0.03 + 0.01 * (np.arange(k) % 3)
+        gam = 0.5 + 0.25 * (np.arange(k) % 7)
+        Q = synth.make2sQ(0.05, 0.08, rk, lk, gam)
+        n = Q.shape[0]
+        Omega = 1.25 * float(np.max(np.abs(np.diag(Q))))
+        pid = np.full(n, 1.0 / n)
+        z = synth.make_tree(500, Q, Omega, 0x5EED0004, pid)
+        z["states"] = ((z["states"] - 1) % 2 + 1).astype(np.int32)
+        for b, (p_, c_) in enumerate(z["edge"]):
+            if c_ <= 500:
+                z["mapnames"][b][-1] = z["states"][c_ - 1]
+        _CACHE["hr62"] = (z, Q, pid, Omega, treeorder.pruningwiseedgeorder(z), treeorder.makenodelist(z), treeorder.myreorder(z))
+    return _CACHE["hr62"]
+
+
+@pytest.mark.parametrize("mapping,S", [("replicas", 70), ("branches", 66), ("tiles", 128), ("tiles", 8512)])
+def test_hidden_rates_62_states_500_tips_ks_sweep(mapping, S):
+    """sumstatMCMCks' tree sweep (src/phylomap.cpp:1422-1432) at the size C4 names: n = 2k+2 = 62, parity tip masks
+    (:1838-1845), tips re-sampled (:1384-1397), n x n counts, recordQks columns (2 + 3k = 92), root state."""
+    z, Q, pid, Omega, nen, nodelist, root = _hidden_rates_62()
+    n, k, N, seed = 62, 30, (3 if S > 1000 else 6), 6200 + S
+    got = api.sumstatMCMCks_sweep(z, Q, pid, Omega, N, seed=seed, n_replicas=S, mapping=mapping)
+    assert got.shape == (S, N, n + n * n + 2 + 3 * k + 1)
+    for r in sorted({0, 17, min(63, S - 1), min(S // 2 + 50, S - 1), S - 1}):
+        want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(n) + Q / Omega, Omega, nen, nodelist, root, N, variant=O.KS, seed=seed, replica=r)
+        assert rc == 0
+        _check_ks_rows(got[r], want, n)
+    np.testing.assert_allclose(got[:, :, :n].sum(2), z["edge.length"].sum(), rtol=1e-11)
+
+
 @pytest.mark.parametrize("mapping", WIDE_MAPPINGS)
 def test_c5_sparse_20_states_5000_tips(mapping):
     """C5: tridiagonal 20-state Q on a 5 000-tip tree.  SPARSEsumstatMCMC has no rescaling (src/phylomap.cpp:490-501), so at

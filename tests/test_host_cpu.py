@@ -148,6 +148,7 @@ def test_rate_matrix_updates_product_equals_oracle(n, mt):
 
 
 def test_cabi_exports_every_declared_symbol():
+    import ctypes as C
     hdr = open(os.path.join(ROOT, "include", "phylomap_hip.h")).read()
     declared = sorted(set(re.findall(r"\b(phm_[A-Za-z0-9_]+)\s*\(", hdr)))
     assert len(declared) >= 17
@@ -155,7 +156,8 @@ def test_cabi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), f"{name} declared in include/phylomap_hip.h but not exported"
     assert sorted(_lib.EXPORTS) == declared
-    assert L.phm_version() == 100
+    assert L.phm_version() == 200
+    assert [L.phm_struct_size(i) for i in range(5)] == [C.sizeof(_lib.Options), C.sizeof(_lib.Info), C.sizeof(_lib.Tree), C.sizeof(_lib.Model), -1]
     assert L.phm_status_string(6).decode() == "branch capacity exceeded"
 
 

@@ -247,6 +247,39 @@ def test_ks_sweep_oracle_equals_python_restatement(n):
         assert rc == 0
 
 
+@pytest.mark.parametrize("n", [2, 3, 5, 7])
+def test_bf_sweep_oracle_equals_python_restatement_for_any_state_count(n):
+    """treesamplebf (src/phylomap.cpp:1169-1179) is n-generic: observed tips, n x n counts incl. self pairs (shortenerbf
+    :1010-1014), row-normalised pruning (:1085); only the driver's 9 columns and the rate updates are two-state."""
+    Q = {2: synth.config_Q(1), 3: np.array([[-.3, .2, .1], [.05, -.15, .1], [.2, .2, -.4]]),
+         5: synth.dense_Q(5, 0.02, 0.08, seed=5), 7: synth.dense_Q(7, 0.02, 0.08, seed=7)}[n]
+    Omega = 1.25 * float(np.max(np.abs(np.diag(Q))))
+    pid = np.full(n, 1.0 / n)
+    z = synth.make_tree(9, Q, Omega, 660 + n)
+    nen, nodelist, root = _orders(z)
+    N, seed, rep = 5, 13, 1
+    got, rc = O.maketreelistMCMC(z, Q, pid, np.eye(n) + Q / Omega, Omega, nen, nodelist, root, N, variant=O.BF, seed=seed, replica=rep)
+    assert rc == 0 and got.shape == (N, n + n * n + 3)
+    want = np.array(pyref.sumstatMCMC(z, Q.tolist(), pid.tolist(), Omega, N, [int(v) for v in nen], [int(v) for v in nodelist],
+                                      root, seed, rep, "bf"))
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_allclose(got[:, :n].sum(1), z["edge.length"].sum(), rtol=1e-12)
+    cnt = got[:, n:n + n * n].reshape(N, n, n)
+    # every consecutive pair of segments is counted once: segments - branches, summed over the tree
+    big, rc = O.maketreelistMCMC(z, Q, pid, np.eye(n) + Q / Omega, Omega, nen, nodelist, root, N, variant=O.BIGTREE, seed=seed, replica=rep)
+    assert rc == 0
+    # the bf sweep draws what the _bigtree sweep draws (same pruning, same streams): its off-diagonal counts are _bigtree's
+    off = np.array([[cnt[i][a][c] for a in range(n) for c in range(n) if a != c] for i in range(N)])
+    np.testing.assert_array_equal(off, big[:, n:])
+    np.testing.assert_array_equal(got[:, :n], big[:, :n])
+    assert np.all(got[:, n + n * n] == Q[0, 1]) and np.all(got[:, n + n * n + 1] == Q[1, 0])
+    assert np.all((got[:, -1] >= 0) & (got[:, -1] < n))
+    # the rate-updating driver stays two-state
+    if n != 2:
+        _, rc = O.maketreelistMCMC(z, Q, pid, np.eye(n) + Q / Omega, Omega, nen, nodelist, root, 2, variant=O.BF, prior=[1, 1, 1, 1])
+        assert rc & O.ERR_BAD_INPUT
+
+
 def test_dic_loglikelihood_against_scipy():
     """The log p(y|Q) column of the DIC drivers (src/phylomap.cpp:3239-3251): Pade expm + scaled pruning vs scipy."""
     from scipy.linalg import expm
