@@ -133,10 +133,11 @@ typedef struct phm_options {
                                   rebuilt with doubled slots and the iterations run so far are replayed -- bit-identical, every
                                   random number being addressed by (replica, iteration, entity) -- so a run cannot abort where
                                   the reference's std::list (src/phylomap.cpp:18-21) would grow */
-  int32_t sparse_chains;       /* 5..64 states with PHM_MAP_TILES: 0 = automatic (by the fill of the chain matrix), 1 = pruning
-                                  chains and forward draws over the non-zeros of B only (SPARSEmakePLrcpp :490-501,
-                                  SPARSEresamplebranchstates :218-261), 2 = dense (matrix cores).  Same bits either way: a
-                                  skipped term is an exact zero */
+  int32_t sparse_chains;       /* 5..64 states with PHM_MAP_TILES: pruning chains and forward draws over the non-zeros of a BANDED B only
+                                  (what SPARSEmakePLrcpp :490-501 / SPARSEresamplebranchstates :218-261 get from sp_mat).  0 =
+                                  automatic: used when n <= 32 and B has a half-bandwidth of 1 (tridiagonal) or 2 (make2sQ hidden
+                                  rates); 1 = required (PHM_ERR_UNSUPPORTED otherwise); 2 = never (chains on the matrix cores).
+                                  Same bits either way: a skipped term is an exact zero */
   int32_t capacity_boost_log2; /* internal (capacity recovery): log2 of the multiplier applied to the provisioned capacities */
   int32_t reserved[3];         /* must be 0 */
 } phm_options;
@@ -153,7 +154,7 @@ typedef struct phm_info {
   int32_t iters_done;
   int32_t recoveries;          /* capacity recoveries (rebuild + replay) this handle has gone through; a timed region asserts 0 */
   int32_t mapping;             /* the phm_mapping in force (the automatic choice resolved) */
-  int32_t sparse_chains;       /* 1 when the sweep runs over the non-zeros of B only */
+  int32_t sparse_chains;       /* bit 0: pruning chains run over the band of the chain matrix; bit 1: forward draws over the band of B */
   int32_t reserved;
 } phm_info;
 

@@ -157,6 +157,34 @@ int32_t upload_model(phm_engine* e) {
     }
     HIPCHK(hipMemcpy(e->d_Bc.p, e->hBc.data(), sizeof(double) * n * n, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(e->d_scale.p, e->hscale.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+    {   // Banded matrices (SPARSEmakePLrcpp :490-501 and SPARSEresamplebranchstates :218-261 exploit sp_mat; here: the band).
+        // Decided per model: a rate update of the Q-updating drivers may widen or narrow the band between sweeps.
+      auto half_bandwidth = [&](const std::vector<double>& M) {
+        int hb = 0;
+        for (int i = 0; i < n; ++i)
+          for (int j = 0; j < n; ++j) if (M[(size_t)i * n + j] != 0.0) hb = std::max(hb, std::abs(i - j));
+        return hb;
+      };
+      auto usable = [&](int hb) { return e->sparse_req != 2 && n <= phm::WT_BAND_NMAX && hb >= 1 && hb <= phm::WT_BAND_MAX && 2 * hb + 1 < n; };
+      const int hbc = half_bandwidth(e->hBc), hb2 = half_bandwidth(e->hB2);
+      e->pwt.band_up = usable(hbc) ? hbc : 0;
+      e->pwt.band_draw = usable(hb2) ? hb2 : 0;
+      if (e->sparse_req == 1 && (!e->pwt.band_up || !e->pwt.band_draw))
+        return fail(PHM_ERR_UNSUPPORTED, "sparse_chains = 1: the band kernels take n <= 32 states and a half-bandwidth of B of at most 2");
+      std::memset(&e->wt_band, 0, sizeof e->wt_band);
+      if (e->pwt.band_up) {
+        const int hb = e->pwt.band_up, w = 2 * hb + 1;
+        for (int i = 0; i < n; ++i)
+          for (int d = 0; d < w; ++d) { const int j = i + d - hb; if (j >= 0 && j < n) e->wt_band.c[i * w + d] = e->hBc[(size_t)i * n + j]; }
+      }
+      std::vector<double> b2band((size_t)n * (2 * phm::WT_BAND_MAX + 1), 0.0);
+      if (e->pwt.band_draw) {
+        const int hb = e->pwt.band_draw, w = 2 * hb + 1;
+        for (int i = 0; i < n; ++i)
+          for (int d = 0; d < w; ++d) { const int j = i + d - hb; if (j >= 0 && j < n) b2band[(size_t)i * w + d] = e->hB2[(size_t)i * n + j]; }
+      }
+      HIPCHK(hipMemcpy(e->d_wt_B2band.p, b2band.data(), sizeof(double) * b2band.size(), hipMemcpyHostToDevice));
+    }
     return PHM_OK;
   }
   if (e->narrow || e->tiled) {      // tables long enough for every possible segment count, read from global memory / L2
@@ -610,6 +638,7 @@ int32_t wtiles_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
   HIPCHK(e->d_nw_colL.alloc(sizeof(double) * tab)); HIPCHK(e->d_nw_rowL.alloc(sizeof(double) * tab));
   HIPCHK(e->d_nw_maskL.alloc(sizeof(double) * (size_t)e->nw_klong * 2 * ldt));
   HIPCHK(e->d_wt_B2.alloc(sizeof(double) * (size_t)n * ldt)); HIPCHK(e->d_Bc.alloc(sizeof(double) * n * n));
+  HIPCHK(e->d_wt_B2band.alloc(sizeof(double) * (size_t)n * (2 * phm::WT_BAND_MAX + 1)));
   const int nblk = (n + 7) / 8, ldb = (nblk + 1) & ~1;
   HIPCHK(e->d_wt_totL.alloc(sizeof(double) * (size_t)e->nw_klong * n * n * ldb));
   HIPCHK(e->d_wt_pair_slot.alloc(sizeof(int16_t) * (size_t)n * n)); HIPCHK(e->d_wt_slot_col.alloc(sizeof(int32_t) * phm::WT_MAX_SLOTS));
@@ -661,7 +690,8 @@ int32_t wtiles_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
   // branches per wave of the branch kernel: one while waves are scarce, up to 8 once there are 65 536 of them anyway
   p.group = (int32_t)std::max<int64_t>(1, std::min<int64_t>(8, (int64_t)tiles * E / 65536));
   p.n_groups = (E + p.group - 1) / p.group;
-  p.up_form = o.pruning_form & 3; p.sparse = 0;
+  p.up_form = o.pruning_form & 3; p.band_up = 0; p.band_draw = 0; p.B2band = e->d_wt_B2band.as<double>();
+  e->sparse_req = o.sparse_chains;
   p.seed_lo = (uint32_t)(o.seed & 0xFFFFFFFFull); p.seed_hi = (uint32_t)(o.seed >> 32);
   p.rows = rows;
   {   // dwell accumulators: 64-bit fixed point, a replica's column never exceeds the tree length
@@ -1105,7 +1135,7 @@ int32_t phm_engine_run(phm_engine* e, int32_t n_iters, void* hip_stream) {
       if (e->n == 2) le = phm::launch_tiles_sweep<2>(e->t2, e->nw_up_off, e->nw_down_off, it, stream, pev);
       if (e->n == 3) le = phm::launch_tiles_sweep<3>(e->t3, e->nw_up_off, e->nw_down_off, it, stream, pev);
       if (e->n == 4) le = phm::launch_tiles_sweep<4>(e->t4, e->nw_up_off, e->nw_down_off, it, stream, pev);
-      if (e->wide) le = phm::launch_wtiles_sweep(e->pwt, e->nw_up_off, e->nw_down_off, it, stream, pev);
+      if (e->wide) le = phm::launch_wtiles_sweep(e->pwt, e->wt_band, e->nw_up_off, e->nw_down_off, it, stream, pev);
       launches += (int)(e->nw_up_off.size() + e->nw_down_off.size()) + 2;
     }
     HIPCHK(le);
@@ -1335,7 +1365,7 @@ int32_t phm_engine_info(phm_engine* e, phm_info* info) {
   info->last_run_ms = e->last_ms; info->last_run_launches = e->last_launches; info->iters_done = e->iters_done;
   info->recoveries = e->recoveries;
   info->mapping = e->narrow ? PHM_MAP_BRANCHES : e->tiled ? PHM_MAP_TILES : PHM_MAP_REPLICAS;
-  info->sparse_chains = (e->tiled && e->wide) ? e->pwt.sparse : 0;
+  info->sparse_chains = (e->tiled && e->wide) ? (e->pwt.band_up > 0) + 2 * (e->pwt.band_draw > 0) : 0;
   return PHM_OK;
 }
 
@@ -1387,7 +1417,7 @@ extern "C" int32_t phm_engine_time_pruning(phm_engine* e, int32_t n_iters, void*
   hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
   HIPCHK(hipEventRecord(e->ev0, stream));
   hipError_t le = hipSuccess;
-  if (wt) for (int i = 0; i < n_iters && le == hipSuccess; ++i) le = phm::launch_wtiles_up(e->pwt, e->nw_up_off, stream);
+  if (wt) for (int i = 0; i < n_iters && le == hipSuccess; ++i) le = phm::launch_wtiles_up(e->pwt, e->wt_band, e->nw_up_off, stream);
   // iteration index = iters_done keeps the dwell ping-pong parity; nothing but PL is written
   if (!wt && e->n == 2) { auto p = e->p2; p.prune_only = 1; for (int i = 0; i < n_iters && le == hipSuccess; ++i) le = phm::launch_mcmc<2>(p, e->iters_done, 1, stream); }
   if (e->n == 3) { auto p = e->p3; p.prune_only = 1; for (int i = 0; i < n_iters && le == hipSuccess; ++i) le = phm::launch_mcmc<3>(p, e->iters_done, 1, stream); }

@@ -39,7 +39,14 @@ constexpr int WT_BLOCK = 256;
 #define WT_BRANCH_BLOCK_SMALL 512
 #endif
 constexpr int WT_FEW_TILES = 112;       // n <= 16: below this many tiles the pruning pass runs a wave per 16-replica block (latency) instead of per tile (throughput)
+constexpr int WT_BAND_MAX = 2;          // largest half-bandwidth served by the band kernels (tridiagonal: 1; make2sQ hidden rates: 2)
+constexpr int WT_BAND_NMAX = 32;        // ... up to this many states (the vectors of a chain live in registers)
 constexpr int WT_MAX_SLOTS = 96;        // possible transitions (non-zero entries of B) up to which the branch kernel counts in LDS
+
+// the band of the chain matrix as kernel-argument constants (scalar loads): c[i * (2 hb + 1) + d] = Bc[i][i + d - hb]
+struct WtBand {
+  double c[WT_BAND_NMAX * (2 * WT_BAND_MAX + 1)];
+};
 
 struct WtParams {
   int32_t n_states, ldt;                     // ldt: row stride of the tables (n rounded up to even: 16-byte rows)
@@ -48,12 +55,15 @@ struct WtParams {
   int32_t normalise, tips_per_replica, ks, tip_masks, reduce, n_cols;
   int32_t klong;                             // rows of the chain tables
   int32_t group, n_groups;                   // branches walked by one wave of the branch kernel; ceil(n_edge / group)
-  int32_t sparse;                            // 1: chains and forward draws over the non-zeros of the chain matrix (ELLPACK tables below)
+  int32_t band_up;                           // > 0: the chain matrix is banded with this half-bandwidth (<= WT_BAND_MAX, n <= WT_BAND_NMAX): pruning
+                                             //   chains as per-lane FMAs over the band (wt_up_band_kernel) instead of the matrix cores
+  int32_t band_draw;                         // > 0: the rows of the dense B are banded likewise: a forward draw walks the band of its row only
   int32_t up_form;                           // pruning kernel: 0 chosen by tile count, 1 a wave per (node, tile), 2 split into 16-replica blocks
   uint32_t seed_lo, seed_hi;
   int64_t rows;                              // rows of one tile in one dwell buffer (sum of the slot sizes)
   double fx_scale, fx_inv;                   // fixed-point scale of the dwell accumulators and its inverse (powers of two)
   const double* B2;                          // [n][ldt] dense B, rows of the forward draws
+  const double* B2band;                      // [n][2 band_draw + 1]: B2[s][s - band_draw .. s + band_draw] (0 outside the matrix)
   const double* Bc;                          // [n][n] chain matrix (B, or thresholded B for SPARSE), row-major
   const double* scale;                       // [n] 1/(Omega+q_ss)
   const double* pid;                         // [n]
@@ -88,9 +98,9 @@ struct WtParams {
 };
 
 // phase_ev: optional 5 events, as in launch_tiles_sweep
-hipError_t launch_wtiles_sweep(const WtParams& p, const std::vector<int32_t>& up_off,
+hipError_t launch_wtiles_sweep(const WtParams& p, const WtBand& band, const std::vector<int32_t>& up_off,
                                const std::vector<int32_t>& down_off, int it, hipStream_t stream, hipEvent_t* phase_ev = nullptr);
 // the pruning (up) sweep alone, for bench.py's roofline block
-hipError_t launch_wtiles_up(const WtParams& p, const std::vector<int32_t>& up_off, hipStream_t stream);
+hipError_t launch_wtiles_up(const WtParams& p, const WtBand& band, const std::vector<int32_t>& up_off, hipStream_t stream);
 
 }  // namespace phm

@@ -246,6 +246,92 @@ __global__ __launch_bounds__(WT_BLOCK) void wt_up_kernel(WtParams p, int begin, 
   if (err) atomicOr(p.err, err);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Pruning through a BANDED chain matrix (tridiagonal amino-acid-style or count-valued Q: half-bandwidth 1; the hidden-rates
+// Q of make2sQ: 2) -- what SPARSEmakePLrcpp / spmmmmvFORpl (src/phylomap.cpp:490-501, :451-457) exploit through sp_mat.
+// One LANE per replica, a wave per (node, tile): the lane keeps its child vector in registers and applies
+//   y_i = fma(Bc[i][j], x_j, acc),  j = i - HB .. i + HB ascending, from +0
+// in place.  The dense specification adds, in the same order, terms whose coefficient is an exact zero: fma(0, x_j, acc) =
+// acc for the finite non-negative x of a partial likelihood, so the two give the same bits (and so do in-band zeros, which
+// are multiplied).  The coefficients are kernel-argument constants (scalar loads).  A lane stops after its own m - 1 steps
+// (exec mask), the wave runs to its longest chain.  At 20 states a chain step is 58 FMAs per replica where the matrix-core
+// kernel issues 40 padded 16 x 16 x 4 MFMAs per 64 replicas = 16x the flops, and on this chip vector and matrix FP64 peak
+// are the same number.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NP, int HB>
+__global__ __launch_bounds__(WT_BLOCK) void wt_up_band_kernel(WtParams p, WtBand bd, int begin, int end) {
+  constexpr int W = 2 * HB + 1;
+  const int lane = threadIdx.x & 63;
+  const int n_lvl = end - begin;
+  const int64_t item = (int64_t)blockIdx.x * (WT_BLOCK / 64) + (threadIdx.x >> 6);
+  if (item >= (int64_t)n_lvl * p.n_tiles) return;
+  const int n = p.n_states, ldt = p.ldt;
+  const int tile = (int)(item % p.n_tiles), li = (int)(item / p.n_tiles);
+  const UpStep st = p.up[p.up_order[begin + li]];
+  double* __restrict__ PLt = p.PL + (size_t)tile * p.n_node * n * 64;
+  const uint16_t* __restrict__ mct = p.mcount + (size_t)tile * p.n_edge * 64;
+  const uint8_t* __restrict__ tips_t = p.tips_per_replica ? p.tips + (size_t)tile * p.n_tips * 64 : p.tips;
+  uint32_t err = 0;
+  double R[2][NP];
+#pragma unroll
+  for (int ch = 0; ch < 2; ++ch) {                     // ch 0: "first" = child[1] (:508); ch 1: "second" = child[0] (:509)
+    const int child = st.child[1 - ch], edge = st.edge[1 - ch];
+    int k = (int)mct[edge * 64 + lane] - 1;
+    if (child < 0) {                                   // tip: a row of the chain table (the chain run from a unit vector / the parity mask)
+      const int tip = ~child;
+      const int ts = p.tips_per_replica ? tips_t[tip * 64 + lane] : p.tips[tip];
+      if (k >= p.klong) { err |= DERR_CAPACITY; k = p.klong - 1; }
+      const double2* __restrict__ src = reinterpret_cast<const double2*>(p.tip_masks ? p.maskL + ((size_t)k * 2 + (ts & 1)) * ldt : p.colL + ((size_t)k * n + ts) * ldt);
+#pragma unroll
+      for (int i = 0; i < NP; i += 2) {                // rows are 16-byte aligned and padded to an even length with zeros
+        double2 v = {0.0, 0.0};
+        if (i < n) v = src[i >> 1];
+        R[ch][i] = v.x; R[ch][i + 1] = v.y;
+      }
+    } else {
+      double (&x)[NP] = R[ch];
+#pragma unroll
+      for (int i = 0; i < NP; ++i) x[i] = (i < n) ? PLt[((size_t)child * n + i) * 64 + lane] : 0.0;
+      const int kmax = wave_max_count(k);
+      for (int step = 1; step <= kmax; ++step) {
+        if (step <= k) {                               // x <- Bc x for the lanes still inside their chain
+          double prev[HB];
+#pragma unroll
+          for (int d = 0; d < HB; ++d) prev[d] = 0.0;
+#pragma unroll
+          for (int i = 0; i < NP; ++i) {
+            double acc = 0.0;
+#pragma unroll
+            for (int d = 0; d < HB; ++d) if (i - HB + d >= 0) acc = __builtin_fma(bd.c[i * W + d], prev[d], acc);
+            acc = __builtin_fma(bd.c[i * W + HB], x[i], acc);
+#pragma unroll
+            for (int d = 1; d <= HB; ++d) if (i + d < NP) acc = __builtin_fma(bd.c[i * W + HB + d], x[i + d], acc);
+#pragma unroll
+            for (int d = 0; d + 1 < HB; ++d) prev[d] = prev[d + 1];
+            prev[HB - 1] = x[i];
+            x[i] = acc;
+          }
+        }
+      }
+    }
+  }
+  double P[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) P[i] = R[0][i] * R[1][i];                      // :510
+  if (p.normalise) {                                                          // :525; four interleaved partial sums
+    double t[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < NP; ++i) t[i & 3] += P[i];
+    const double tt = (t[0] + t[1]) + (t[2] + t[3]);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) P[i] = P[i] / tt;
+  }
+#pragma unroll
+  for (int i = 0; i < NP; ++i)
+    if (i < n) PLt[((size_t)st.parent * n + i) * 64 + lane] = P[i];
+  if (err) atomicOr(p.err, err);
+}
+
 // The same pruning step for FEW tiles: a wave per (node, tile, 16-replica block), blocks in replica order, no LDS.  With one
 // tile a height level of the kernel above is a single wave working through four blocks and two children (C4: 168 us per level,
 // 84 % of a 4.6 ms sweep); here the four blocks run on four waves.  With many tiles the sorted blocks of the kernel above win
@@ -557,7 +643,10 @@ __global__ __launch_bounds__(WT_BLOCK) void wt_down_kernel(WtParams p, int it, i
 // (64-bit fixed point, ds_add_u64) that is handed to the tile's accumulators once, as coalesced rows -- a scattered atomic
 // leaves L2 as a 64-byte request of its own, and at one per merged segment they were a quarter of the kernel's HBM traffic
 // on C5 (profiles/r02_pmc_C5_summary.json).  Larger n: B rows through L1/L2 (30 KB of LDS would halve the occupancy).
-template <bool KS, bool SMALL, bool B2L>
+// BAND > 0 (with SMALL): the rows of B are banded with this half-bandwidth (SPARSEresamplebranchstates :218-261 walks the
+// non-zeros of a row of the sparse matrix): a forward draw multiplies and adds the 2 BAND + 1 in-band terms only -- every
+// other term of the probability vector is an exact +0, so total, running sums and the state drawn keep their bits.
+template <bool KS, bool SMALL, bool B2L, int BAND>
 __global__ __launch_bounds__(SMALL ? WT_BRANCH_BLOCK_SMALL : WT_BLOCK) void wt_branch_kernel(WtParams p, int it) {
   constexpr int BLOCK = SMALL ? WT_BRANCH_BLOCK_SMALL : WT_BLOCK;
   extern __shared__ __align__(16) unsigned char s_dyn[];            // SMALL: [n][ldt] rows of B, then [n][64] dwell sums (u64)
@@ -579,7 +668,8 @@ __global__ __launch_bounds__(SMALL ? WT_BRANCH_BLOCK_SMALL : WT_BLOCK) void wt_b
   if ((int)threadIdx.x < n) s_scale[threadIdx.x] = p.scale[threadIdx.x];
   // B2L: the rows of B in LDS (always for n <= 32; beyond, 30 KB at 61 states, when a workgroup walks enough branches to pay for
   // staging them -- a third of a draw's per-lane table reads: C4 branch kernel 20.8 -> 18.3-19.8 ms at 65 536 replicas)
-  if (B2L) for (int i = threadIdx.x; i < n * ldt; i += BLOCK) s_B2[i] = p.B2[i];
+  if (BAND > 0) { for (int i = threadIdx.x; i < n * (2 * BAND + 1); i += BLOCK) s_B2[i] = p.B2band[i]; }      // the band of B instead of its rows
+  else if (B2L) for (int i = threadIdx.x; i < n * ldt; i += BLOCK) s_B2[i] = p.B2[i];
   if (SMALL) {
     for (int i = threadIdx.x; i < n * 64; i += BLOCK) s_dw[i] = 0ull;
     for (int i = threadIdx.x; i < n_slots * 64; i += BLOCK) s_ct[i] = 0u;
@@ -632,6 +722,32 @@ __global__ __launch_bounds__(SMALL ? WT_BRANCH_BLOCK_SMALL : WT_BLOCK) void wt_b
   auto draw_state_w = [&](int i, int sprev, uint32_t word) -> int {
     int kk = m - i - 1;
     if (kk >= p.klong) { err |= DERR_CAPACITY; kk = p.klong - 1; }
+    if (BAND > 0) {
+      constexpr int W = 2 * BAND + 1;
+      const double* __restrict__ beta = p.colL + ((size_t)kk * n + cs) * ldt;
+      const double* __restrict__ bb = s_B2 + sprev * W;
+      double pr[W];
+#pragma unroll
+      for (int d = 0; d < W; ++d) {
+        const int c = sprev + d - BAND;
+        pr[d] = (c >= 0 && c < n) ? bb[d] * beta[c] : 0.0;
+      }
+      double total = pr[0];                                                      // 0 + .. + 0 + pr_0 = pr_0 exactly
+#pragma unroll
+      for (int d = 1; d < W; ++d) total += pr[d];
+      if (!(total > 0.0) || isinf(total)) err |= DERR_ZERO_PROB;
+      const double thr = u01(word) * total;
+      // states below the band: running sum +0, passed unless the threshold itself is 0; states above it: running sum = total >= thr
+      int idx = (thr <= 0.0) ? 0 : max(sprev - BAND, 0);
+      double cum = 0.0;
+#pragma unroll
+      for (int d = 0; d < W; ++d) {
+        const int c = sprev + d - BAND;
+        cum += pr[d];
+        idx += (c >= 0 && c < n - 1 && !(thr <= cum)) ? 1 : 0;
+      }
+      return idx;
+    }
     // The running sums of the probability vector p_c = B[s_prev][c] (B^kk e_end)[c] are a function of (kk, s_prev, end) alone.
     // The host has formed them with the sampler's own unfused left-to-right additions and keeps every eighth one (blkL: the sum
     // after states 7, 15, ..., and the total): the lane finds the block of eight states its threshold falls into from that one
@@ -888,7 +1004,30 @@ hipError_t launch_up_levels(const WtParams& p, const std::vector<int32_t>& up_of
 
 }  // namespace
 
-hipError_t launch_wtiles_up(const WtParams& p, const std::vector<int32_t>& up_off, hipStream_t stream) {
+template <int NP, int HB>
+void launch_up_band(const WtParams& p, const WtBand& band, const std::vector<int32_t>& up_off, hipStream_t stream) {
+  for (size_t l = 0; l + 1 < up_off.size(); ++l) {
+    const int cnt = up_off[l + 1] - up_off[l];
+    if (cnt <= 0) continue;
+    const int64_t items = (int64_t)cnt * p.n_tiles;        // a wave per (node, tile)
+    hipLaunchKernelGGL((wt_up_band_kernel<NP, HB>), dim3((unsigned)((items + 3) / 4)), dim3(WT_BLOCK), 0, stream, p, band, up_off[l], up_off[l + 1]);
+  }
+}
+
+hipError_t launch_wtiles_up(const WtParams& p, const WtBand& band, const std::vector<int32_t>& up_off, hipStream_t stream) {
+  if (p.band_up > 0) {                                  // banded chain matrix: per-lane FMAs over the band
+    const int np = (p.n_states + 3) / 4;               // vectors padded to a multiple of four states
+#define PHM_BAND_CASE(NPQ)                                                                          \
+    case NPQ: if (p.band_up == 1) launch_up_band<4 * NPQ, 1>(p, band, up_off, stream);            \
+              else launch_up_band<4 * NPQ, 2>(p, band, up_off, stream);                            \
+              break;
+    switch (np) {
+      PHM_BAND_CASE(2) PHM_BAND_CASE(3) PHM_BAND_CASE(4) PHM_BAND_CASE(5) PHM_BAND_CASE(6) PHM_BAND_CASE(7) PHM_BAND_CASE(8)
+      default: return hipErrorInvalidValue;
+    }
+#undef PHM_BAND_CASE
+    return hipGetLastError();
+  }
   const int mt = (p.n_states + 15) / 16;
   hipError_t e;
   if (mt == 1) e = launch_up_levels<1>(p, up_off, stream);
@@ -898,13 +1037,13 @@ hipError_t launch_wtiles_up(const WtParams& p, const std::vector<int32_t>& up_of
   return e != hipSuccess ? e : hipGetLastError();
 }
 
-hipError_t launch_wtiles_sweep(const WtParams& p, const std::vector<int32_t>& up_off,
+hipError_t launch_wtiles_sweep(const WtParams& p, const WtBand& band, const std::vector<int32_t>& up_off,
                                const std::vector<int32_t>& down_off, int it, hipStream_t stream, hipEvent_t* phase_ev) {
   constexpr int WPB = WT_BLOCK / 64;
   auto blocks = [&](int64_t items) { return dim3((unsigned)((items + WPB - 1) / WPB)); };
   auto mark = [&](int i) { if (phase_ev) (void)hipEventRecord(phase_ev[i], stream); };
   mark(0);
-  hipError_t e = launch_wtiles_up(p, up_off, stream);
+  hipError_t e = launch_wtiles_up(p, band, up_off, stream);
   if (e != hipSuccess) return e;
   mark(1);
   hipLaunchKernelGGL(wt_root_kernel, blocks(p.n_tiles), dim3(WT_BLOCK), 0, stream, p, it);
@@ -930,20 +1069,28 @@ hipError_t launch_wtiles_sweep(const WtParams& p, const std::vector<int32_t>& up
     const dim3 g((unsigned)(((int64_t)p.n_groups + wpb - 1) / wpb * p.n_tiles));
     const bool b2l = !small && p.group >= 4;           // n > 32: B rows in LDS once a wave walks four or more branches
     if (small) {      // n = 32 with 96 countable pairs: 51 KB dynamic + 35 KB static per eight-wave workgroup, beyond the default 64 KB
-      const hipError_t ae = p.ks ? allow_dynamic_lds(reinterpret_cast<const void*>(wt_branch_kernel<true, true, true>), 64 * 1024)
-                                 : allow_dynamic_lds(reinterpret_cast<const void*>(wt_branch_kernel<false, true, true>), 64 * 1024);
+      const void* fn = p.ks ? (p.band_draw == 1 ? (const void*)wt_branch_kernel<true, true, true, 1> : p.band_draw == 2 ? (const void*)wt_branch_kernel<true, true, true, 2> : (const void*)wt_branch_kernel<true, true, true, 0>)
+                            : (p.band_draw == 1 ? (const void*)wt_branch_kernel<false, true, true, 1> : p.band_draw == 2 ? (const void*)wt_branch_kernel<false, true, true, 2> : (const void*)wt_branch_kernel<false, true, true, 0>);
+      const hipError_t ae = allow_dynamic_lds(fn, 64 * 1024);
       if (ae != hipSuccess) return ae;
     }
     const size_t lds_now = small ? lds : (b2l ? lds : 0);
+    const int band = small ? p.band_draw : 0;
+#define PHM_BRANCH(KSV, SM, BL, BD) hipLaunchKernelGGL((wt_branch_kernel<KSV, SM, BL, BD>), g, dim3(SM ? WT_BRANCH_BLOCK_SMALL : WT_BLOCK), lds_now, stream, p, it)
     if (p.ks) {
-      if (small) hipLaunchKernelGGL((wt_branch_kernel<true, true, true>), g, dim3(WT_BRANCH_BLOCK_SMALL), lds_now, stream, p, it);
-      else if (b2l) hipLaunchKernelGGL((wt_branch_kernel<true, false, true>), g, dim3(WT_BLOCK), lds_now, stream, p, it);
-      else hipLaunchKernelGGL((wt_branch_kernel<true, false, false>), g, dim3(WT_BLOCK), lds_now, stream, p, it);
+      if (small && band == 1) PHM_BRANCH(true, true, true, 1);
+      else if (small && band == 2) PHM_BRANCH(true, true, true, 2);
+      else if (small) PHM_BRANCH(true, true, true, 0);
+      else if (b2l) PHM_BRANCH(true, false, true, 0);
+      else PHM_BRANCH(true, false, false, 0);
     } else {
-      if (small) hipLaunchKernelGGL((wt_branch_kernel<false, true, true>), g, dim3(WT_BRANCH_BLOCK_SMALL), lds_now, stream, p, it);
-      else if (b2l) hipLaunchKernelGGL((wt_branch_kernel<false, false, true>), g, dim3(WT_BLOCK), lds_now, stream, p, it);
-      else hipLaunchKernelGGL((wt_branch_kernel<false, false, false>), g, dim3(WT_BLOCK), lds_now, stream, p, it);
+      if (small && band == 1) PHM_BRANCH(false, true, true, 1);
+      else if (small && band == 2) PHM_BRANCH(false, true, true, 2);
+      else if (small) PHM_BRANCH(false, true, true, 0);
+      else if (b2l) PHM_BRANCH(false, false, true, 0);
+      else PHM_BRANCH(false, false, false, 0);
     }
+#undef PHM_BRANCH
   }
   mark(3);
   const int ncnt = p.ks ? p.n_states * p.n_states : p.n_states * (p.n_states - 1);

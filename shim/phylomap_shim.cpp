@@ -7,6 +7,7 @@
 // phylomap package with  PKG_CPPFLAGS=-I<repo>/include  PKG_LIBS=-L<repo>/phylomap_amd -lphylomap_hip.
 #include <Rcpp.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "phylomap_hip.h"
@@ -58,22 +59,68 @@ struct FlatTree {
   }
 };
 
-// Called inside the RNGScope (src/RcppExports.cpp:38): two draws from R's stream seed Philox, so
-// set.seed() keeps controlling the result.  options(phylomap.hip.replicas=, phylomap.hip.device=) are optional.
-phm_options options_from_R() {
-  phm_options o = {};
+// What the R session asks of the device beyond the reference's arguments.  All optional:
+//   options(phylomap.hip.replicas = S)   S independent chains on the same data (default 1 = the reference's semantics exactly)
+//   x$sites = S x length(x$states) matrix of 1-based tip states: S sites of an alignment on the same tree, one chain each
+//   options(phylomap.hip.reduce = FALSE) return list of S matrices instead of their sum
+//   options(phylomap.hip.device = d)     HIP device ordinal
+// With S > 1 the default result is the N x cols matrix of statistics SUMMED over the chains / sites (what a likelihood over
+// sites needs, and the form in which 10^4 chains cost one row each); a single chain on a big tree uses one lane per branch, from a
+// few hundred chains on the lanes are the chains -- the throughput mapping is reached from R this way.
+struct HipRequest {
+  phm_options o;
+  int S = 1;
+  bool summed = true;
+  std::vector<int32_t> site_states;            // S * n_tips, replica-major (phm_tree.states with tips_per_replica)
+};
+
+// Called inside the RNGScope (src/RcppExports.cpp:38): two draws from R's stream seed Philox, so set.seed() keeps
+// controlling the result.
+HipRequest request_from_R(List x, int n_tips) {
+  HipRequest rq;
+  phm_options& o = rq.o;
+  o = phm_options();
   uint64_t hi = (uint64_t)(unif_rand() * 4294967296.0), lo = (uint64_t)(unif_rand() * 4294967296.0);
   o.seed = (hi << 32) | lo;
-  o.n_replicas = 1;
-  o.device = -1;
   Environment base("package:base");
   Function getOption = base["getOption"];
   o.device = as<int>(getOption("phylomap.hip.device", -1));
-  return o;
+  rq.S = as<int>(getOption("phylomap.hip.replicas", 1));
+  rq.summed = as<bool>(getOption("phylomap.hip.reduce", true));
+  if (x.containsElementNamed("sites")) {
+    IntegerMatrix sites = as<IntegerMatrix>(x["sites"]);             // REALSXP matrices are coerced, as x$states is
+    if (sites.ncol() != n_tips) stop("x$sites must have one column per tip (%d), it has %d", n_tips, sites.ncol());
+    rq.S = sites.nrow();
+    rq.site_states.resize((size_t)rq.S * n_tips);
+    for (int s = 0; s < rq.S; ++s)
+      for (int t = 0; t < n_tips; ++t) rq.site_states[(size_t)s * n_tips + t] = sites.begin()[s + (size_t)rq.S * t];   // column-major
+    o.tips_per_replica = 1;
+  }
+  if (rq.S < 1) stop("phylomap.hip.replicas must be >= 1");
+  o.n_replicas = rq.S;
+  o.reduce = (rq.S > 1 && rq.summed) ? 1 : 0;
+  return rq;
 }
 
 void check(int32_t st) {
   if (st != PHM_OK) stop("phylomap_hip: %s: %s", phm_status_string(st), phm_last_error());   // END_RCPP turns it into an R error
+}
+
+// N x cols matrix (one chain, or the sum over chains), or a list of S such matrices
+SEXP wrap_result(const std::vector<double>& buf, int N, int cols, const HipRequest& rq) {
+  const bool single = rq.S == 1 || rq.summed;
+  if (single) {
+    NumericMatrix out(N, cols);
+    std::copy(buf.begin(), buf.begin() + (size_t)N * cols, out.begin());
+    return out;
+  }
+  List res(rq.S);
+  for (int s = 0; s < rq.S; ++s) {
+    NumericMatrix m(N, cols);
+    std::copy(buf.begin() + (size_t)s * N * cols, buf.begin() + (size_t)(s + 1) * N * cols, m.begin());
+    res[s] = m;
+  }
+  return res;
 }
 
 typedef int32_t (*mcmc_fn)(const phm_tree*, int32_t, const double*, const double*, const double*, double,
@@ -82,17 +129,19 @@ typedef int32_t (*mcmc_fn)(const phm_tree*, int32_t, const double*, const double
 SEXP run_mcmc(mcmc_fn fn, SEXP xSEXP, SEXP QSEXP, SEXP pidSEXP, SEXP BSEXP, SEXP OmegaSEXP, SEXP nenSEXP,
               SEXP nodelistSEXP, SEXP rootSEXP, SEXP NSEXP) {
   RNGScope scope;
-  FlatTree ft(as<List>(xSEXP));
+  List x = as<List>(xSEXP);
+  FlatTree ft(x);
   NumericMatrix Q(QSEXP), B(BSEXP);
   NumericVector pid(pidSEXP);
   IntegerVector nen(nenSEXP), nodelist(nodelistSEXP);
-  const int n = Q.nrow(), N = as<int>(NSEXP);
-  NumericMatrix out(N, n + n * (n - 1));                            // :926
-  phm_options o = options_from_R();
-  const phm_tree t = ft.view();
+  const int n = Q.nrow(), N = as<int>(NSEXP), cols = n + n * (n - 1);  // :926
+  HipRequest rq = request_from_R(x, (int)ft.states.size());
+  phm_tree t = ft.view();
+  if (!rq.site_states.empty()) t.states = rq.site_states.data();
+  std::vector<double> buf((size_t)N * cols * ((rq.S == 1 || rq.summed) ? 1 : rq.S));
   check(fn(&t, n, Q.begin(), pid.begin(), B.begin(), as<double>(OmegaSEXP), nen.begin(), nodelist.begin(),
-           as<int>(rootSEXP), N, &o, out.begin()));
-  return out;
+           as<int>(rootSEXP), N, &rq.o, buf.data()));
+  return wrap_result(buf, N, cols, rq);
 }
 
 }  // namespace
@@ -126,17 +175,20 @@ typedef int32_t (*qupd_fn)(const phm_tree*, int32_t, const double*, const double
 static SEXP run_qupdate(qupd_fn fn, int cols_extra_k, int dic, SEXP xSEXP, SEXP QSEXP, SEXP pidSEXP, SEXP BSEXP, SEXP OmegaSEXP,
                         SEXP nenSEXP, SEXP nodelistSEXP, SEXP rootSEXP, SEXP NSEXP, SEXP priorSEXP) {
   RNGScope scope;
-  FlatTree ft(as<List>(xSEXP));
+  List x = as<List>(xSEXP);
+  FlatTree ft(x);
   NumericMatrix Q(QSEXP), B(BSEXP);
   NumericVector pid(pidSEXP), prior(priorSEXP);
   IntegerVector nen(nenSEXP), nodelist(nodelistSEXP);
   const int n = Q.nrow(), N = as<int>(NSEXP);
   const int k = cols_extra_k ? n / 2 - 1 : 0;
   NumericMatrix out(N, n + n * n + 2 + 3 * k + 1 + dic);            // :1293 (bf), :1857 (ks), :3230 / :3372 (DIC)
-  phm_options o = options_from_R();
-  const phm_tree t = ft.view();
+  // S > 1 (options / x$sites): the chains are sites sharing one Q; the updates see, and `out` holds, the statistics summed over them
+  HipRequest rq = request_from_R(x, (int)ft.states.size());
+  phm_tree t = ft.view();
+  if (!rq.site_states.empty()) t.states = rq.site_states.data();
   check(fn(&t, n, Q.begin(), pid.begin(), B.begin(), as<double>(OmegaSEXP), nen.begin(), nodelist.begin(),
-           as<int>(rootSEXP), N, prior.begin(), (int32_t)prior.size(), &o, out.begin()));
+           as<int>(rootSEXP), N, prior.begin(), (int32_t)prior.size(), &rq.o, out.begin()));
   return out;
 }
 
@@ -188,7 +240,9 @@ static SEXP run_qupdate_mt(mt_fn fn, int hidden, SEXP xSEXP, SEXP QSEXP, SEXP pi
   const int n = Q.nrow(), N = as<int>(NSEXP);
   const int k = hidden ? n / 2 - 1 : 0;
   NumericMatrix out(N, n + n * n + 2 + 3 * k + 1);                  // :2338 (mt), :2815 (ksmt); last column tree_number
-  phm_options o = options_from_R();
+  HipRequest rq = request_from_R(List(), 0);                        // lists of trees: one chain per tree (R/sumstatMCMCmt.R)
+  phm_options o = rq.o;
+  o.n_replicas = 1; o.reduce = 0; o.tips_per_replica = 0;
   check(fn(trees.data(), (int32_t)trees.size(), n, Q.begin(), pid.begin(), B.begin(), as<double>(OmegaSEXP), nen_m.begin(),
            nodelist_m.begin(), roots.begin(), N, prior.begin(), (int32_t)prior.size(), &o, out.begin()));
   return out;
@@ -218,7 +272,9 @@ RcppExport SEXP phylomap_maketreelistEXP(SEXP xSEXP, SEXP QSEXP, SEXP pidSEXP, S
   IntegerVector nen(nenSEXP), nodelist(nodelistSEXP);
   const int n = Q.nrow(), N = as<int>(NSEXP);
   NumericMatrix out(N, n + n * (n - 1));                            // :3031
-  phm_options o = options_from_R();
+  HipRequest rq = request_from_R(List(), 0);                        // samples are i.i.d.: N is the replica axis already
+  phm_options o = rq.o;
+  o.n_replicas = 1; o.reduce = 0; o.tips_per_replica = 0;
   const phm_tree t = ft.view();
   check(phm_maketreelistEXP(&t, n, Q.begin(), pid.begin(), nen.begin(), nodelist.begin(), as<int>(rootSEXP), N,
                             lefts.begin(), rights.begin(), d.begin(), &o, out.begin()));

@@ -33,12 +33,13 @@ struct NumericMatrix : MatBase<double> { using MatBase<double>::MatBase; };
 struct IntegerMatrix : MatBase<int> { using MatBase<int>::MatBase; };
 
 struct List;
-struct Proxy { operator SEXP() const; template <typename T> operator T() const; };
+struct Proxy { operator SEXP() const; template <typename T> operator T() const; template <typename T> Proxy& operator=(const T&); };
 struct NamedArg { template <typename T> NamedArg operator=(const T&) const; };
 NamedArg Named(const char*);
 struct List {
   List(); List(SEXP); List(const Proxy&);
   Proxy operator[](const char*) const; Proxy operator[](int) const;
+  List(int);
   long size() const; bool containsElementNamed(const char*) const;
   template <typename... A> static List create(A...);
   operator SEXP() const;

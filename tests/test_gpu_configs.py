@@ -209,6 +209,35 @@ def test_c5_sparse_20_states_5000_tips(mapping):
     _run_config(5, _lib.PHM_MCMC_SPARSE, O.SPARSE | O.FORCE_NORMALISE, mapping, 70, 8, 6161, False, dump_replica=69, rescale=True)
 
 
+@pytest.mark.parametrize("S", [200, 7232])
+def test_c5_band_kernels_equal_the_dense_kernels_bit_for_bit(S):
+    """C5's B is tridiagonal: the lane-per-replica mapping then prunes with per-lane FMAs over the band (wt_up_band_kernel) and
+    draws forward states over the band of a row -- the use SPARSEmakePLrcpp / SPARSEresamplebranchstates make of sp_mat
+    (src/phylomap.cpp:490-501, :218-261).  A skipped term is an exact zero, so everything must equal the dense kernels
+    (matrix cores + running-sum tables) to the last bit: statistics, partial likelihoods, node states, paths."""
+    z, Q, pid, Omega, nen, nodelist, root = _config(5)
+    n, N, seed = 20, 5, 5500 + S
+    res = {}
+    for sc in (1, 2):
+        eng = _lib.Engine(z, Q, pid, Omega, N, variant=_lib.PHM_MCMC_BIGTREE, seed=seed, n_replicas=S, mapping="tiles", sparse_chains=sc)
+        eng.run(N); eng.sync()
+        assert eng.info().sparse_chains == (3 if sc == 1 else 0)
+        res[sc] = (eng.stats(0, N), eng.dump(S - 1))
+        eng.close()
+    np.testing.assert_array_equal(res[1][0], res[2][0])
+    for key in ("seg_count", "node_states", "PL", "seg_dwell"):
+        np.testing.assert_array_equal(res[1][1][key], res[2][1][key])
+    for r in (0, S - 1):
+        want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(n) + Q / Omega, Omega, nen, nodelist, root, N, variant=O.BIGTREE, seed=seed, replica=r)
+        assert rc == 0
+        _check_rows(res[1][0][r], want, n, False)
+    # a dense matrix has no band to offer
+    z4, Q4, pid4, Om4 = _config(4)[:4]
+    with pytest.raises(_lib.PhmError) as e:
+        _lib.Engine(z4, Q4, pid4, Om4, 1, variant=_lib.PHM_MCMC_BIGTREE, n_replicas=64, mapping="tiles", sparse_chains=1)
+    assert e.value.status == 2
+
+
 @pytest.mark.parametrize("mapping", WIDE_MAPPINGS)
 def test_c5_sparse_variant_on_the_largest_tree_it_survives(mapping):
     """the SPARSE driver proper (thresholded chain matrix, dense forward rows, no rescaling) on a 200-tip tree"""
