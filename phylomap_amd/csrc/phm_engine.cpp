@@ -625,7 +625,7 @@ int32_t wtiles_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
   const size_t tot_bytes = sizeof(double) * (size_t)e->nw_klong * n * n * ldb_need;                     // blkL: running sums of the forward draws
   const size_t acc_bytes = sizeof(unsigned long long) * (size_t)tiles * (n + 1) * 64;                   // dwfx + segacc
   const size_t red_bytes = e->reduce ? sizeof(double) * (size_t)max_iters * e->dcols : 0;
-  const size_t need = 2 * dw_bytes + pl_bytes + cnt_bytes + stats_bytes + tot_bytes + acc_bytes + red_bytes + sizeof(double) * 3 * tab +
+  const size_t need = 2 * dw_bytes + dw_bytes / 8 + pl_bytes + cnt_bytes + stats_bytes + tot_bytes + acc_bytes + red_bytes + sizeof(double) * 3 * tab +
                       (size_t)tiles * (5 * (size_t)E + Nn + 8 * (size_t)n) * 64;
   if (need + (64u << 20) > free_b) {
     char buf[256];
@@ -648,15 +648,22 @@ int32_t wtiles_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
   HIPCHK(e->d_mcount.alloc(sizeof(uint16_t) * (size_t)tiles * E * 64));
   HIPCHK(e->d_dw0.alloc(dw_bytes)); HIPCHK(e->d_dw1.alloc(dw_bytes));
   HIPCHK(e->d_tl_estate.alloc(sizeof(uint16_t) * (size_t)tiles * E * 64));
+  HIPCHK(e->d_wt_mstate.alloc((size_t)tiles * rows * 64));
   HIPCHK(e->d_PL.alloc(pl_bytes));
   HIPCHK(e->d_nstate.alloc((size_t)tiles * Nn * 64));
   HIPCHK(e->d_tl_cnt.alloc(cnt_bytes));
   HIPCHK(e->d_wt_dwfx.alloc(sizeof(unsigned long long) * (size_t)tiles * n * 64));
   HIPCHK(e->d_wt_segacc.alloc(sizeof(unsigned long long) * (size_t)tiles * 64));
+  if (e->reduce) {      // statistics summed over replicas: per-tile totals the branch kernel adds to directly (phm_wtiles.hip)
+    HIPCHK(e->d_wt_dwfx_tile.alloc(sizeof(unsigned long long) * (size_t)tiles * n * 16));
+    HIPCHK(e->d_wt_cnt_tile.alloc(sizeof(uint32_t) * (size_t)tiles * n * n));
+    HIPCHK(hipMemset(e->d_wt_dwfx_tile.p, 0, e->d_wt_dwfx_tile.bytes));
+    HIPCHK(hipMemset(e->d_wt_cnt_tile.p, 0, e->d_wt_cnt_tile.bytes));
+  }
   HIPCHK(e->d_stats.alloc(stats_bytes));
   HIPCHK(e->d_err.alloc(sizeof(uint32_t))); HIPCHK(e->d_seg.alloc(sizeof(unsigned long long)));
   if (e->reduce) HIPCHK(e->d_red.alloc(sizeof(double) * (size_t)max_iters * e->dcols));
-  e->bytes = (int64_t)(2 * dw_bytes + pl_bytes + cnt_bytes + e->d_stats.bytes + e->d_red.bytes + e->d_mcount.bytes + e->d_tl_estate.bytes +
+  e->bytes = (int64_t)(2 * dw_bytes + e->d_wt_mstate.bytes + pl_bytes + cnt_bytes + e->d_stats.bytes + e->d_red.bytes + e->d_mcount.bytes + e->d_tl_estate.bytes +
                        e->d_nstate.bytes + e->d_wt_dwfx.bytes + e->d_wt_segacc.bytes + e->d_wt_totL.bytes + sizeof(double) * 3 * tab);
   HIPCHK(hipMemcpy(e->d_up.p, s.up.data(), e->d_up.bytes, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(e->d_down.p, s.down.data(), e->d_down.bytes, hipMemcpyHostToDevice));
@@ -697,7 +704,7 @@ int32_t wtiles_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
   {   // dwell accumulators: 64-bit fixed point, a replica's column never exceeds the tree length
     int ex = 0;
     (void)std::frexp(std::max(tree_len, 1.0), &ex);       // tree_len < 2^ex
-    p.fx_scale = std::ldexp(1.0, 61 - ex); p.fx_inv = std::ldexp(1.0, ex - 61);
+    p.fx_scale = std::ldexp(1.0, 60 - ex); p.fx_inv = std::ldexp(1.0, ex - 60);      // four lanes' sums share an accumulator in the reduced output: < 2^62
   }
   p.B2 = e->d_wt_B2.as<double>(); p.Bc = e->d_Bc.as<double>(); p.scale = e->d_scale.as<double>(); p.pid = e->d_pid.as<double>();
   p.up = e->d_up.as<phm::UpStep>(); p.down = e->d_down.as<phm::DownStep>();
@@ -709,8 +716,11 @@ int32_t wtiles_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
   p.tips = e->d_tips.as<uint8_t>(); p.mcount = e->d_mcount.as<uint16_t>();
   p.dw[0] = e->d_dw0.as<double>(); p.dw[1] = e->d_dw1.as<double>();
   p.estate = e->d_tl_estate.as<uint16_t>(); p.PL = e->d_PL.as<double>(); p.nstate = e->d_nstate.as<uint8_t>();
+  p.mstate = e->d_wt_mstate.as<uint8_t>();
   p.dwfx = e->d_wt_dwfx.as<unsigned long long>(); p.cnt = e->d_tl_cnt.as<uint32_t>();
   p.segacc = e->d_wt_segacc.as<unsigned long long>();
+  p.dwfx_tile = e->reduce ? e->d_wt_dwfx_tile.as<unsigned long long>() : nullptr;
+  p.cnt_tile = e->reduce ? e->d_wt_cnt_tile.as<uint32_t>() : nullptr;
   p.stats = e->d_stats.as<double>(); p.err = e->d_err.as<uint32_t>(); p.segcnt = e->d_seg.as<unsigned long long>();
   return PHM_OK;
 }

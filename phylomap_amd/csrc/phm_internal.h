@@ -233,7 +233,7 @@ struct phm_engine {
   phm::TileParams<4> t4;
   // 5..64 states with `tiled` set: one lane per replica, wave per (tile, item), pruning on the matrix cores (phm_wtiles.hip)
   phm::WtParams pwt;
-  DevBuf d_wt_dwfx, d_wt_segacc, d_wt_B2, d_wt_totL, d_wt_pair_slot, d_wt_slot_col, d_wt_B2band;
+  DevBuf d_wt_dwfx, d_wt_segacc, d_wt_B2, d_wt_totL, d_wt_pair_slot, d_wt_slot_col, d_wt_B2band, d_wt_mstate, d_wt_dwfx_tile, d_wt_cnt_tile;
   phm::WtBand wt_band;                            // band of the chain matrix (kernel-argument constants of wt_up_band_kernel)
   int sparse_req = 0;                              // phm_options.sparse_chains
   bool phase_timing = false;                       // phm_options.phase_timing: HIP events between the phases of a (tile, item) sweep
@@ -254,7 +254,7 @@ struct phm_engine {
                      &d_nw_up_order, &d_nw_down_order, &d_nw_border, &d_nw_off, &d_nw_colL, &d_nw_rowL, &d_nw_maskL, &d_nw_mcount,
                      &d_nw_dwA, &d_nw_dwB, &d_nw_mstate, &d_nw_mlen, &d_nw_estate, &d_nw_part, &d_nw_rowbuf, &d_ell_col, &d_ell_val,
                      &d_ell2_col, &d_ell2_val, &d_wb_cnt, &d_tl_slot, &d_tl_pdw, &d_tl_pchunk, &d_tl_cnt, &d_tl_estate, &d_tl_pseg,
-                     &d_tl_segprev, &d_wt_dwfx, &d_wt_segacc, &d_wt_B2, &d_wt_totL, &d_wt_pair_slot, &d_wt_slot_col, &d_wt_B2band};
+                     &d_tl_segprev, &d_wt_dwfx, &d_wt_segacc, &d_wt_B2, &d_wt_totL, &d_wt_pair_slot, &d_wt_slot_col, &d_wt_B2band, &d_wt_mstate, &d_wt_dwfx_tile, &d_wt_cnt_tile};
     for (DevBuf* b : all) b->reset();
   }
   ~phm_engine() {

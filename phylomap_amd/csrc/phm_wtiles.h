@@ -86,11 +86,14 @@ struct WtParams {
   const uint8_t* tips;                       // [n_tips] or [tile][n_tips][64]
   uint16_t* mcount;                          // [tile][n_edge][64]
   double* dw[2];                             // [tile][rows][64]; sweep `it` reads dw[it & 1], writes the other
+  uint8_t* mstate;                           // [tile][rows][64] states of the merged segments of a branch between the two passes of the branch kernel
   uint16_t* estate;                          // [tile][n_edge][64]: parent-side state | child-side state << 8
   double* PL;                                // [tile][n_node][n][64]
   uint8_t* nstate;                           // [tile][n_node][64]
   unsigned long long* dwfx;                  // [tile][n][64] dwell sums of the sweep, fixed point
   uint32_t* cnt;                             // [tile][n*n][64] transition counters of the sweep
+  unsigned long long* dwfx_tile;             // reduced output: [tile][n][16] dwell sums over the lanes of a tile (n > 32; entry lane & 15: four lanes each), fixed point; else NULL
+  uint32_t* cnt_tile;                        // reduced output: [tile][n*n] transition counts summed over the lanes of a tile; else NULL
   unsigned long long* segacc;                // [tile][64] segments read + written by the valid replicas (spread over 64 slots)
   double* stats;                             // engine layout: reduce ? [iter][tile][cols] : [iter][cols][n_rep_pad]
   uint32_t* err;

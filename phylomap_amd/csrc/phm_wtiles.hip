@@ -4,6 +4,11 @@
 #include <mutex>
 #include <utility>
 
+#ifndef PHM_BAND_PREFETCH
+#define PHM_BAND_PREFETCH 0
+#endif
+
+
 namespace phm {
 
 namespace {
@@ -635,9 +640,31 @@ __global__ __launch_bounds__(WT_BLOCK) void wt_down_kernel(WtParams p, int it, i
   if (err) atomicOr(p.err, err);
 }
 
+// Dynamic LDS of the branch kernel, in this order (offsets in bytes, every piece 16-byte aligned):
+//   b2   : rows of B [n][ldt] (SMALL, or B2L), or its band [n][2 BAND + 1]
+//   dw   : SMALL: dwell sums of the workgroup [n][64] u64
+//   ct   : SMALL with few possible transitions: counts [n_slots][64] u32;  slot: pair -> slot [n*n] i16
+//   dwt  : reduced output, not SMALL: dwell sums of the workgroup summed over lanes, [n][16] u64 (lane & 15 spreads the atomics)
+//   pc   : reduced output, no slots: transition counts of the workgroup summed over lanes, [ncnt] u32
+struct BranchLds { uint32_t b2, dw, ct, slot, dwt, pc, total; };
+__host__ __device__ inline BranchLds branch_lds(int n, int ldt, int n_slots, bool small, bool b2l, int band, bool red, bool ks) {
+  auto up16 = [](uint32_t v) { return (v + 15u) & ~15u; };
+  BranchLds L;
+  uint32_t o = 0;
+  L.b2 = o; o += up16(8u * (band > 0 ? (uint32_t)n * (2 * band + 1) : (small || b2l) ? (uint32_t)n * ldt : 0u));
+  L.dw = o; o += small ? 8u * n * 64 : 0u;
+  L.ct = o; o += small ? up16(4u * n_slots * 64) : 0u;
+  L.slot = o; o += (small && n_slots > 0) ? up16(2u * n * n) : 0u;
+  const bool red_dw = red && !small, red_pc = red && n_slots == 0;
+  L.dwt = o; o += red_dw ? 8u * n * 16 : 0u;
+  L.pc = o; o += red_pc ? up16(4u * (ks ? n * n : n * (n - 1))) : 0u;
+  L.total = o;
+  return L;
+}
+
 // One branch for the 64 replicas of a tile: resamplebranchstates :264-308, shortener :44-73 (shortenerbf :997-1030),
 // virtual jumps sampleabranch :391-410, dwell sums updatedwelltimes :745-757.  The two-flat-pass scheme of phm_tiles.hip;
-// the states of the merged segments live in LDS (a byte per segment and lane), transition counts go straight to the tile's
+// the states of the merged segments go through a byte row per dwell row in global memory, transition counts go straight to the tile's
 // counters (integer atomics: exact in any order).  The four waves of a workgroup walk four groups of branches of the SAME
 // tile.  SMALL (n <= 32): the rows of B sit in LDS and the dwell sums of the workgroup are collected in one LDS table
 // (64-bit fixed point, ds_add_u64) that is handed to the tile's accumulators once, as coalesced rows -- a scattered atomic
@@ -650,20 +677,29 @@ template <bool KS, bool SMALL, bool B2L, int BAND>
 __global__ __launch_bounds__(SMALL ? WT_BRANCH_BLOCK_SMALL : WT_BLOCK) void wt_branch_kernel(WtParams p, int it) {
   constexpr int BLOCK = SMALL ? WT_BRANCH_BLOCK_SMALL : WT_BLOCK;
   extern __shared__ __align__(16) unsigned char s_dyn[];            // SMALL: [n][ldt] rows of B, then [n][64] dwell sums (u64)
-  __shared__ uint8_t s_ms_all[(BLOCK / 64) * 64 * 64];           // [wave][segment][lane]
   __shared__ double s_scale[64];
   __shared__ __align__(16) double s_ltab[2 * PHM_LOGTAB_N];        // (1/c_j, log c_j) of the exponential variates (neglog_u32)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t lane8 = (uint32_t)lane * 8u;
   const int n = p.n_states, ldt = p.ldt;
-  double* s_B2 = reinterpret_cast<double*>(s_dyn);
-  unsigned long long* s_dw = reinterpret_cast<unsigned long long*>(s_dyn + sizeof(double) * (size_t)n * ldt);
+  const int n_slots = SMALL ? p.n_slots : 0;
+  // reduced output (statistics summed over replicas, the form 10^4 sites are asked in): what is summed anyway is summed here --
+  // the workgroup's counts per transition and, for n > 32, its dwell sums per state collect in LDS and reach the tile's totals
+  // as a few coalesced atomics at the end.  Per replica they are one scattered global atomic per segment (the counters of a tile,
+  // n^2 x 64 x 4 B = 0.95 MB at 61 states, do not stay in L2): half of the C4 branch kernel (profiles/r03_probe_branch_ablation.log).
+  const bool red = p.cnt_tile != nullptr;
+  const bool red_dw = red && !SMALL, red_pc = red && n_slots == 0;
+  const int ncnt = KS ? n * n : n * (n - 1);
+  const BranchLds L = branch_lds(n, ldt, n_slots, SMALL, B2L, BAND, red, KS);
+  double* s_B2 = reinterpret_cast<double*>(s_dyn + L.b2);
+  unsigned long long* s_dw = reinterpret_cast<unsigned long long*>(s_dyn + L.dw);
   // SMALL with a sparse B (at most WT_MAX_SLOTS possible transitions, e.g. a banded rate matrix): the workgroup's transition
   // counts too are collected in LDS, one 32-bit counter per (possible pair, lane), and handed over as coalesced rows
-  uint32_t* s_ct = reinterpret_cast<uint32_t*>(s_dw + (size_t)n * 64);           // [n_slots][64]
-  int16_t* s_slot = reinterpret_cast<int16_t*>(s_ct + (size_t)p.n_slots * 64);   // [n*n] pair -> slot, -1: none
-  const int n_slots = SMALL ? p.n_slots : 0;
+  uint32_t* s_ct = reinterpret_cast<uint32_t*>(s_dyn + L.ct);                    // [n_slots][64]
+  int16_t* s_slot = reinterpret_cast<int16_t*>(s_dyn + L.slot);                  // [n*n] pair -> slot, -1: none
+  unsigned long long* s_dwt = reinterpret_cast<unsigned long long*>(s_dyn + L.dwt);   // [n][16]
+  uint32_t* s_pc = reinterpret_cast<uint32_t*>(s_dyn + L.pc);                    // [ncnt]
   for (int i = threadIdx.x; i < 2 * PHM_LOGTAB_N; i += BLOCK) s_ltab[i] = logtab_entry(i);
   if ((int)threadIdx.x < n) s_scale[threadIdx.x] = p.scale[threadIdx.x];
   // B2L: the rows of B in LDS (always for n <= 32; beyond, 30 KB at 61 states, when a workgroup walks enough branches to pay for
@@ -675,12 +711,13 @@ __global__ __launch_bounds__(SMALL ? WT_BRANCH_BLOCK_SMALL : WT_BLOCK) void wt_b
     for (int i = threadIdx.x; i < n_slots * 64; i += BLOCK) s_ct[i] = 0u;
     if (n_slots > 0) for (int i = threadIdx.x; i < n * n; i += BLOCK) s_slot[i] = p.pair_slot[i];
   }
+  if (red_dw) for (int i = threadIdx.x; i < n * 16; i += BLOCK) s_dwt[i] = 0ull;
+  if (red_pc) for (int i = threadIdx.x; i < ncnt; i += BLOCK) s_pc[i] = 0u;
   __syncthreads();
   const int tile = blockIdx.x % p.n_tiles;
   const int grp = (blockIdx.x / p.n_tiles) * (BLOCK / 64) + wave;
   const bool active = grp < p.n_groups;              // wave-uniform; every wave reaches the barrier at the end
   const double* __restrict__ Brows = B2L ? s_B2 : p.B2;
-  uint8_t* s_ms = s_ms_all + wave * 64 * 64 + lane;
   const uint32_t rep = (uint32_t)(p.replica_offset + tile * 64 + lane);
   const bool valid = tile * 64 + lane < p.n_rep;
   uint16_t* __restrict__ mct = p.mcount + (size_t)tile * p.n_edge * 64;
@@ -690,14 +727,18 @@ __global__ __launch_bounds__(SMALL ? WT_BRANCH_BLOCK_SMALL : WT_BLOCK) void wt_b
   uint32_t segs = 0;
   auto add_dwell = [&](int s, double len) {                                    // updatedwelltimes :752, per merged segment
     const unsigned long long v = (unsigned long long)__double2ll_rn(len * p.fx_scale);
-    if (SMALL) atomicAdd(s_dw + s * 64 + lane, v); else atomicAdd(gdw + s * 64 + lane, v);
+    if (SMALL) atomicAdd(s_dw + s * 64 + lane, v);
+    else if (red_dw) { if (valid) atomicAdd(s_dwt + s * 16 + (lane & 15), v); }
+    else atomicAdd(gdw + s * 64 + lane, v);
   };
   auto count = [&](int a, int c) {                                             // shortener :65-66 / shortenerbf :1010-1014
     if (n_slots > 0) {
       const int sl = s_slot[a * n + c];
       if (sl >= 0) { atomicAdd(s_ct + sl * 64 + lane, 1u); return; }
     }
-    atomicAdd(gc + (KS ? a * n + c : a * (n - 1) + (c > a ? c - 1 : c)) * 64, 1u);
+    const int col = KS ? a * n + c : a * (n - 1) + (c > a ? c - 1 : c);
+    if (red_pc) { if (valid) atomicAdd(s_pc + col, 1u); }
+    else atomicAdd(gc + col * 64, 1u);
   };
   if (active) {
   const int q1 = min((grp + 1) * p.group, p.n_edge);
@@ -711,6 +752,11 @@ __global__ __launch_bounds__(SMALL ? WT_BRANCH_BLOCK_SMALL : WT_BLOCK) void wt_b
   double* __restrict__ in = p.dw[it & 1] + ((size_t)tile * p.rows + roff) * 64;
   double* __restrict__ out = p.dw[(it & 1) ^ 1] + ((size_t)tile * p.rows + roff) * 64;
   auto IN = [&](int k) -> double& { return at(in, (uint32_t)k * 512u + lane8); };
+  // states of the merged segments, a byte per (row, lane) beside the dwell rows: pass A writes, pass B reads one step ahead.
+  // (They sat in LDS, 4 KB per wave: with them in global memory -- 64-byte coalesced rows, L2-resident between the passes -- an
+  // eight-wave workgroup needs 29 KB instead of 61 KB at 20 states and the SIMDs hold eight waves instead of four.)
+  uint8_t* __restrict__ msrow = p.mstate + ((size_t)tile * p.rows + roff) * 64 + lane;
+  auto MS = [&](int k) -> uint8_t& { return msrow[(uint32_t)k * 64u]; };
 
   Stream su, se;
   su.open(ENT_BSTATE | (uint32_t)b, (uint32_t)it, rep, p.seed_lo, p.seed_hi);
@@ -797,12 +843,59 @@ __global__ __launch_bounds__(SMALL ? WT_BRANCH_BLOCK_SMALL : WT_BLOCK) void wt_b
     return idx;
   };
 
+  // Banded B, pass A: the entries of B^kk e_end a draw needs sit around the state drawn one step earlier -- a load whose address
+  // hangs on the previous draw, i.e. an L2 round trip inside the dependent chain of the branch.  A band move changes the state by
+  // at most BAND, so the 4 BAND + 1 entries around the state BEFORE the previous draw cover whatever that draw returns: they are
+  // requested a whole step ahead (window `win` around `wbase`) and the draw picks its 2 BAND + 1 out of them.
+  constexpr int WW = 4 * (BAND > 0 ? BAND : 1) + 1;
+  auto load_window = [&](int i, int centre, double (&win)[WW]) {                // entries centre - 2 BAND .. centre + 2 BAND of row (m - i - 1, end)
+    int kk = m - i - 1;
+    if (kk >= p.klong) kk = p.klong - 1;                                         // (flagged by the draw itself)
+    const double* __restrict__ beta = p.colL + ((size_t)kk * n + cs) * ldt;
+#pragma unroll
+    for (int t = 0; t < WW; ++t) win[t] = beta[min(max(centre + t - 2 * BAND, 0), n - 1)];
+  };
+  auto draw_state_win = [&](int i, int sprev, uint32_t word, const double (&win)[WW], int wbase) -> int {
+    constexpr int W = 2 * BAND + 1;
+    const int delta = sprev - wbase;
+    if (delta < -BAND || delta > BAND) return draw_state_w(i, sprev, word);     // not reachable by band moves; kept for safety
+    if (m - i - 1 >= p.klong) err |= DERR_CAPACITY;
+    const double* __restrict__ bb = s_B2 + sprev * W;
+    double pr[W];
+#pragma unroll
+    for (int d = 0; d < W; ++d) {
+      double v = win[d + BAND];
+#pragma unroll
+      for (int dd = -BAND; dd <= BAND; ++dd) v = (delta == dd) ? win[d + dd + BAND] : v;
+      const int c = sprev + d - BAND;
+      pr[d] = (c >= 0 && c < n) ? bb[d] * v : 0.0;
+    }
+    double total = pr[0];
+#pragma unroll
+    for (int d = 1; d < W; ++d) total += pr[d];
+    if (!(total > 0.0) || isinf(total)) err |= DERR_ZERO_PROB;
+    const double thr = u01(word) * total;
+    int idx = (thr <= 0.0) ? 0 : max(sprev - BAND, 0);
+    double cum = 0.0;
+#pragma unroll
+    for (int d = 0; d < W; ++d) {
+      const int c = sprev + d - BAND;
+      cum += pr[d];
+      idx += (c >= 0 && c < n - 1 && !(thr <= cum)) ? 1 : 0;
+    }
+    return idx;
+  };
+
   if (mmax <= 64) {
     // Pass A: one old segment per step for every lane; merged segments written back in place over the consumed rows.
     int w = 0;
     int cur_s = (m == 1) ? cs : ps;            // updatenodestates :469-472 (m==1: child wins)
+    const int s_first = cur_s;                 // state of the first merged segment
     double cur_len = IN(0);
     double dnext = (m > 1) ? IN(1) : 0.0;
+    double win[WW];
+    int wbase = cur_s;
+    if (BAND > 0 && PHM_BAND_PREFETCH) { if (1 < m - 1) load_window(1, cur_s, win); }
     for (int i0 = 1; i0 < mmax; i0 += 4) {
       uint32_t wd[4] = {0u, 0u, 0u, 0u};
       if (i0 < mmax - 1)                       // some lane still draws in this group (draws exist for i < m - 1)
@@ -811,30 +904,41 @@ __global__ __launch_bounds__(SMALL ? WT_BRANCH_BLOCK_SMALL : WT_BLOCK) void wt_b
       for (int qq = 0; qq < 4; ++qq) {
         const int i = i0 + qq;
         if (i < m) {
-          const int si = (i == m - 1) ? cs : draw_state_w(i, cur_s, wd[qq]);
+          int si;
+          if (BAND > 0 && PHM_BAND_PREFETCH) {
+            double nwin[WW];
+            if (i + 1 < m - 1) load_window(i + 1, cur_s, nwin);              // for the draw of the next step, around the state before this one
+            si = (i == m - 1) ? cs : draw_state_win(i, cur_s, wd[qq], win, wbase);
+#pragma unroll
+            for (int t = 0; t < WW; ++t) win[t] = nwin[t];
+            wbase = cur_s;
+          } else {
+            si = (i == m - 1) ? cs : draw_state_w(i, cur_s, wd[qq]);
+          }
           const double di = dnext;
           if (i + 1 < m) dnext = IN(i + 1);
           if (KS) count(cur_s, si);
           if (si == cur_s) cur_len = cur_len + di;                           // shortener :54
           else {
             IN(w) = cur_len;
-            s_ms[w * 64] = (uint8_t)cur_s;
+            MS(w) = (uint8_t)cur_s;
             if (!KS) count(cur_s, si);
             ++w; cur_s = si; cur_len = di;
           }
         }
       }
     }
-    s_ms[w * 64] = (uint8_t)cur_s;
+    MS(w) = (uint8_t)cur_s;
     const int nmerged = w + 1;
     const double len0 = (w == 0) ? cur_len : IN(0);
     if (w > 0) IN(w) = cur_len;
 
     // Pass B: one new piece per step for every lane (virtual jumps :391-410).
     int j = 0;
-    int s = s_ms[0];
+    int s = s_first;
     double len = len0;
     double lnext = (nmerged > 1) ? ((w == 1) ? cur_len : IN(1)) : 0.0;
+    int snext = (nmerged > 1) ? ((w == 1) ? cur_s : (int)MS(1)) : 0;
     double tot = 0.0, scale = s_scale[s];
     bool stuck = false, done = false;
     for (uint32_t t0 = 0; __any(!done); t0 += 4) {
@@ -858,9 +962,8 @@ __global__ __launch_bounds__(SMALL ? WT_BRANCH_BLOCK_SMALL : WT_BLOCK) void wt_b
           ++j;
           if (j >= nmerged) done = true;
           else {
-            len = lnext;
-            if (j + 1 < nmerged) lnext = IN(j + 1);
-            s = s_ms[j * 64];
+            len = lnext; s = snext;
+            if (j + 1 < nmerged) { lnext = IN(j + 1); snext = MS(j + 1); }
             scale = s_scale[s]; tot = 0.0;
           }
         }
@@ -917,8 +1020,18 @@ __global__ __launch_bounds__(SMALL ? WT_BRANCH_BLOCK_SMALL : WT_BLOCK) void wt_b
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) segs += __shfl_xor(segs, off, 64);
   if (lane == 0 && active) atomicAdd(p.segacc + (size_t)tile * 64 + (grp & 63), (unsigned long long)segs);
+  if (SMALL || red) __syncthreads();
+  if (red_dw)
+    for (int i = threadIdx.x; i < n * 16; i += BLOCK) {
+      const unsigned long long v = s_dwt[i];
+      if (v) atomicAdd(p.dwfx_tile + (size_t)tile * n * 16 + i, v);
+    }
+  if (red_pc)
+    for (int i = threadIdx.x; i < ncnt; i += BLOCK) {
+      const uint32_t v = s_pc[i];
+      if (v) atomicAdd(p.cnt_tile + (size_t)tile * n * n + i, v);
+    }
   if (SMALL) {                                       // the workgroup's dwell sums -> the tile's accumulators, row by row
-    __syncthreads();
     for (int i = threadIdx.x; i < n * 64; i += BLOCK) {
       const unsigned long long v = s_dw[i];
       if (v) atomicAdd(gdw + i, v);
@@ -948,13 +1061,25 @@ __global__ __launch_bounds__(WT_BLOCK) void wt_stats_kernel(WtParams p, int it, 
   const int c1 = min(dcols, (chunk + 1) * 64);
   for (int c = chunk * 64; c < c1; ++c) {
     double v;
-    if (c < n) { v = (double)(long long)gdw[c * 64] * p.fx_inv; gdw[c * 64] = 0ull; }
-    else if (c < n + ncnt) { v = (double)gc[(c - n) * 64]; gc[(c - n) * 64] = 0u; }
-    else v = (double)p.nstate[((size_t)tile * p.n_node + p.root) * 64 + lane];   // :1350-1352
+    // reduced output: the branch kernel has summed part of the statistics over the lanes already (dwfx_tile: sixteen partial
+    // sums per state, each over four lanes' worth of a tile -- 64-bit fixed point below 2^62; cnt_tile: exact counts); the
+    // per-lane accumulators it then leaves untouched are not read
+    const bool tile_dw = p.cnt_tile != nullptr && n > 32, tile_pc = p.cnt_tile != nullptr && p.n_slots == 0;
+    if (c < n) {
+      if (tile_dw) {
+        unsigned long long* td = p.dwfx_tile + ((size_t)tile * n + c) * 16;
+        v = 0.0;
+        if (lane < 16) { v = (double)(long long)td[lane] * p.fx_inv; td[lane] = 0ull; }
+      } else { v = (double)(long long)gdw[c * 64] * p.fx_inv; gdw[c * 64] = 0ull; v = (valid || !p.reduce) ? v : 0.0; }
+    } else if (c < n + ncnt) {
+      uint32_t k = 0;
+      if (!tile_pc) { k = gc[(c - n) * 64]; gc[(c - n) * 64] = 0u; }
+      v = (valid || !p.reduce) ? (double)k : 0.0;
+    } else v = (valid || !p.reduce) ? (double)p.nstate[((size_t)tile * p.n_node + p.root) * 64 + lane] : 0.0;   // :1350-1352
     if (p.reduce) {
-      v = valid ? v : 0.0;
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane == 0 && tile_pc && c >= n && c < n + ncnt) { v += (double)p.cnt_tile[(size_t)tile * n * n + (c - n)]; p.cnt_tile[(size_t)tile * n * n + (c - n)] = 0u; }
       if (lane == 0) p.stats[((size_t)it * p.n_tiles + tile) * p.n_cols + c] = v;
     } else {
       p.stats[((size_t)it * p.n_cols + c) * p.n_rep_pad + rep_local] = v;
@@ -1060,21 +1185,21 @@ hipError_t launch_wtiles_sweep(const WtParams& p, const WtBand& band, const std:
   mark(2);
   {
     const bool small = p.n_states <= 32;
-    const size_t lds = small ? sizeof(double) * (size_t)p.n_states * p.ldt + sizeof(unsigned long long) * (size_t)p.n_states * 64 +
-                                   sizeof(uint32_t) * (size_t)p.n_slots * 64 + sizeof(int16_t) * (size_t)p.n_states * p.n_states + 16
-                             : sizeof(double) * (size_t)p.n_states * p.ldt;
-    // n <= 32: eight waves share the workgroup's LDS tables (B rows, dwell and count accumulators: 26 KB at 20 states) -- 58 KB per
-    // workgroup, two per CU, four waves per SIMD where four-wave workgroups (43 KB) gave three
+    const bool red = p.cnt_tile != nullptr;
+    // n <= 32: eight waves share the workgroup's LDS tables (B rows, dwell and count accumulators: 26 KB at 20 states)
     const int wpb = small ? WT_BRANCH_BLOCK_SMALL / 64 : WPB;
     const dim3 g((unsigned)(((int64_t)p.n_groups + wpb - 1) / wpb * p.n_tiles));
     const bool b2l = !small && p.group >= 4;           // n > 32: B rows in LDS once a wave walks four or more branches
-    if (small) {      // n = 32 with 96 countable pairs: 51 KB dynamic + 35 KB static per eight-wave workgroup, beyond the default 64 KB
-      const void* fn = p.ks ? (p.band_draw == 1 ? (const void*)wt_branch_kernel<true, true, true, 1> : p.band_draw == 2 ? (const void*)wt_branch_kernel<true, true, true, 2> : (const void*)wt_branch_kernel<true, true, true, 0>)
-                            : (p.band_draw == 1 ? (const void*)wt_branch_kernel<false, true, true, 1> : p.band_draw == 2 ? (const void*)wt_branch_kernel<false, true, true, 2> : (const void*)wt_branch_kernel<false, true, true, 0>);
-      const hipError_t ae = allow_dynamic_lds(fn, 64 * 1024);
+    const BranchLds L = branch_lds(p.n_states, p.ldt, small ? p.n_slots : 0, small, b2l, small ? p.band_draw : 0, red, p.ks != 0);
+    const size_t lds_now = L.total;
+    {      // beyond the default 64 KB of dynamic LDS: n = 32 with 96 countable pairs; 61 states with the rows of B and the reduced counters
+      const void* fn = p.ks ? (small ? (p.band_draw == 1 ? (const void*)wt_branch_kernel<true, true, true, 1> : p.band_draw == 2 ? (const void*)wt_branch_kernel<true, true, true, 2> : (const void*)wt_branch_kernel<true, true, true, 0>)
+                                     : (b2l ? (const void*)wt_branch_kernel<true, false, true, 0> : (const void*)wt_branch_kernel<true, false, false, 0>))
+                            : (small ? (p.band_draw == 1 ? (const void*)wt_branch_kernel<false, true, true, 1> : p.band_draw == 2 ? (const void*)wt_branch_kernel<false, true, true, 2> : (const void*)wt_branch_kernel<false, true, true, 0>)
+                                     : (b2l ? (const void*)wt_branch_kernel<false, false, true, 0> : (const void*)wt_branch_kernel<false, false, false, 0>));
+      const hipError_t ae = allow_dynamic_lds(fn, 96 * 1024);
       if (ae != hipSuccess) return ae;
     }
-    const size_t lds_now = small ? lds : (b2l ? lds : 0);
     const int band = small ? p.band_draw : 0;
 #define PHM_BRANCH(KSV, SM, BL, BD) hipLaunchKernelGGL((wt_branch_kernel<KSV, SM, BL, BD>), g, dim3(SM ? WT_BRANCH_BLOCK_SMALL : WT_BLOCK), lds_now, stream, p, it)
     if (p.ks) {
