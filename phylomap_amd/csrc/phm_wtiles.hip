@@ -4,9 +4,6 @@
 #include <mutex>
 #include <utility>
 
-#ifndef PHM_BAND_PREFETCH
-#define PHM_BAND_PREFETCH 0
-#endif
 
 
 namespace phm {
@@ -843,49 +840,6 @@ __global__ __launch_bounds__(SMALL ? WT_BRANCH_BLOCK_SMALL : WT_BLOCK) void wt_b
     return idx;
   };
 
-  // Banded B, pass A: the entries of B^kk e_end a draw needs sit around the state drawn one step earlier -- a load whose address
-  // hangs on the previous draw, i.e. an L2 round trip inside the dependent chain of the branch.  A band move changes the state by
-  // at most BAND, so the 4 BAND + 1 entries around the state BEFORE the previous draw cover whatever that draw returns: they are
-  // requested a whole step ahead (window `win` around `wbase`) and the draw picks its 2 BAND + 1 out of them.
-  constexpr int WW = 4 * (BAND > 0 ? BAND : 1) + 1;
-  auto load_window = [&](int i, int centre, double (&win)[WW]) {                // entries centre - 2 BAND .. centre + 2 BAND of row (m - i - 1, end)
-    int kk = m - i - 1;
-    if (kk >= p.klong) kk = p.klong - 1;                                         // (flagged by the draw itself)
-    const double* __restrict__ beta = p.colL + ((size_t)kk * n + cs) * ldt;
-#pragma unroll
-    for (int t = 0; t < WW; ++t) win[t] = beta[min(max(centre + t - 2 * BAND, 0), n - 1)];
-  };
-  auto draw_state_win = [&](int i, int sprev, uint32_t word, const double (&win)[WW], int wbase) -> int {
-    constexpr int W = 2 * BAND + 1;
-    const int delta = sprev - wbase;
-    if (delta < -BAND || delta > BAND) return draw_state_w(i, sprev, word);     // not reachable by band moves; kept for safety
-    if (m - i - 1 >= p.klong) err |= DERR_CAPACITY;
-    const double* __restrict__ bb = s_B2 + sprev * W;
-    double pr[W];
-#pragma unroll
-    for (int d = 0; d < W; ++d) {
-      double v = win[d + BAND];
-#pragma unroll
-      for (int dd = -BAND; dd <= BAND; ++dd) v = (delta == dd) ? win[d + dd + BAND] : v;
-      const int c = sprev + d - BAND;
-      pr[d] = (c >= 0 && c < n) ? bb[d] * v : 0.0;
-    }
-    double total = pr[0];
-#pragma unroll
-    for (int d = 1; d < W; ++d) total += pr[d];
-    if (!(total > 0.0) || isinf(total)) err |= DERR_ZERO_PROB;
-    const double thr = u01(word) * total;
-    int idx = (thr <= 0.0) ? 0 : max(sprev - BAND, 0);
-    double cum = 0.0;
-#pragma unroll
-    for (int d = 0; d < W; ++d) {
-      const int c = sprev + d - BAND;
-      cum += pr[d];
-      idx += (c >= 0 && c < n - 1 && !(thr <= cum)) ? 1 : 0;
-    }
-    return idx;
-  };
-
   if (mmax <= 64) {
     // Pass A: one old segment per step for every lane; merged segments written back in place over the consumed rows.
     int w = 0;
@@ -893,9 +847,6 @@ __global__ __launch_bounds__(SMALL ? WT_BRANCH_BLOCK_SMALL : WT_BLOCK) void wt_b
     const int s_first = cur_s;                 // state of the first merged segment
     double cur_len = IN(0);
     double dnext = (m > 1) ? IN(1) : 0.0;
-    double win[WW];
-    int wbase = cur_s;
-    if (BAND > 0 && PHM_BAND_PREFETCH) { if (1 < m - 1) load_window(1, cur_s, win); }
     for (int i0 = 1; i0 < mmax; i0 += 4) {
       uint32_t wd[4] = {0u, 0u, 0u, 0u};
       if (i0 < mmax - 1)                       // some lane still draws in this group (draws exist for i < m - 1)
@@ -904,17 +855,7 @@ __global__ __launch_bounds__(SMALL ? WT_BRANCH_BLOCK_SMALL : WT_BLOCK) void wt_b
       for (int qq = 0; qq < 4; ++qq) {
         const int i = i0 + qq;
         if (i < m) {
-          int si;
-          if (BAND > 0 && PHM_BAND_PREFETCH) {
-            double nwin[WW];
-            if (i + 1 < m - 1) load_window(i + 1, cur_s, nwin);              // for the draw of the next step, around the state before this one
-            si = (i == m - 1) ? cs : draw_state_win(i, cur_s, wd[qq], win, wbase);
-#pragma unroll
-            for (int t = 0; t < WW; ++t) win[t] = nwin[t];
-            wbase = cur_s;
-          } else {
-            si = (i == m - 1) ? cs : draw_state_w(i, cur_s, wd[qq]);
-          }
+          const int si = (i == m - 1) ? cs : draw_state_w(i, cur_s, wd[qq]);
           const double di = dnext;
           if (i + 1 < m) dnext = IN(i + 1);
           if (KS) count(cur_s, si);
