@@ -7,14 +7,17 @@ sufficient statistics) over every replica resident on the GPU.
 
 Workload at N = 1 (and, replica-sharded, at N > 1): BASELINE.json configs[2] = C3, the configuration the north-star target
 is quoted on -- sumstatMCMC_bigtree, 4-state Q = make2sQ(.1,.1,.2,.2,10), 10 000-tip synthetic tree
-(src/phylomap.cpp:942-986).  It fits one GPU (16 384 replicas = 151 GiB with one wave per (tile of 64 replicas, branch)).
+(src/phylomap.cpp:942-986).  It fits one GPU (16 384 replicas with one wave per (tile of 64 replicas, branch)).
 Replicas (independent chains / sites) are sharded across ranks with no data-path collective; the only exchange is one
 RCCL all-reduce of the K x cols statistics at the end.  Inputs are resident in HBM before the timed region starts.
+`--scaling weak` (default): every rank runs the same number of replicas, rank 0's choice broadcast to all;
+`--scaling strong`: the replicas one GPU holds are split over the ranks.
 
-The same JSON line carries, at N = 1, one block per other BASELINE configuration (C2 streaming layout, C4 dense
-61 states, C5 sparse 20 states, sumstatEXP on C1 and on a 1 000-tip tree), each with its own roofline figures measured
-with HIP events inside the library, the batched expm rates, and the CPU oracle timed on this box's host cores
-(1 core, 1 core with the reference's O(E) edge search, all cores).
+`roofline` is SURVEY.md 8(d)'s whole-sweep figure, E * S * B_alg / (time of all kernels of one sweep), with one block per
+kernel of the sweep nested under it (`kernels`; `dominant_kernel` names the largest).  The same JSON line carries, at N = 1,
+the rate of ONE chain on the headline configuration (what the R call gets), one block per other BASELINE configuration
+(C2 streaming layout, C4 dense 61 states in the n + n^2 counting layout, C5 sparse 20 states, sumstatEXP on C1 and on a
+1 000-tip tree), the batched expm rates, and the CPU oracle timed on this box's host cores.
 """
 import argparse
 import json
@@ -29,7 +32,8 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (about 6.3 TB/s achievable)
 MEASURED_TRIAD_GBS = 5751.9   # tools/device_peaks/device_peaks.hip on an MI355X of this pool (read-only 6382, copy 4956 GB/s; FP64 vector 65.5 TFLOP/s)
-MFMA_F64_PEAK_TFLOPS = 78.6   # MI355X_MICROARCH.md: dense FP64 matrix peak
+MFMA_F64_PEAK_TFLOPS = 78.6   # MI355X_MICROARCH.md: dense FP64 matrix peak (= the vector FP64 peak on this chip)
+N_SIMD, NOMINAL_GHZ, VALU_CLOCKS = 1024, 2.4, 4.9   # 256 CUs x 4 SIMDs; a back-to-back wave64 VALU instruction issues in 4.7-5.4 nominal clocks (profiles/r01_valu_rates.log)
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -84,9 +88,21 @@ def cpu_baseline(cfg, target_s=3.0, all_cores=False):
 
 
 def load_traffic():
-    """HBM bytes per launch from the rocprofv3 --pmc passes (tools/summarise_pmc.py -> profiles/r02_traffic.json)."""
-    f = os.path.join(ROOT, "profiles", "r02_traffic.json")
+    """HBM bytes per unit and per kernel from this round's rocprofv3 --pmc passes (tools/pmc_target.py -> tools/pmc_summary.py
+    -> profiles/r03_traffic.json); bench.py scales them to its own launch sizes."""
+    f = os.path.join(ROOT, "profiles", "r03_traffic.json")
     return json.load(open(f)) if os.path.exists(f) else {}
+
+
+def kernel_traffic(entry, *needles):
+    """(bytes per unit, VALU instructions per sweep, kernel names) summed over the kernels of a traffic entry whose name holds a needle"""
+    tot, valu, names = 0.0, 0.0, []
+    for k, e in (entry or {}).get("kernels", {}).items():
+        if any(nd in k for nd in needles):
+            tot += e.get("hbm_bytes_per_unit", 0.0)
+            valu += e.get("SQ_INSTS_VALU", 0.0)
+            names.append(k)
+    return (tot if names else None), (valu if names else None), names
 
 
 def main():
@@ -94,7 +110,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--replicas", type=int, default=0, help="replicas per GPU (0: sized from free HBM)")
+    ap.add_argument("--burnin", type=int, default=12, help="untimed sweeps before the warm-up: the chain leaves its initial paths (two half-length segments per "
+                    "branch, n on C5), whose sweeps cost less (more) than stationary ones; SURVEY 8(d) discards the first 10 %% of a run likewise")
+    ap.add_argument("--replicas", type=int, default=0, help="replicas per GPU (weak) / in total (strong); 0: sized from rank 0's free HBM")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--config", type=int, default=3, help="BASELINE configuration of the headline line (3 = C3, the north-star's; 2 = C2)")
     ap.add_argument("--ipl", type=int, default=8, help="sweeps fused per kernel launch (replica mapping)")
     ap.add_argument("--storage", type=int, default=2, help="replica mapping, dwell streams: 2 = two buffers (fastest), 1 = one ring (half the HBM)")
@@ -136,6 +155,7 @@ def main():
     parallel.init_process_group(backend, device_index=local_rank)
     stream = torch.cuda.current_stream().cuda_stream
     traffic = load_traffic()
+    dist_dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
 
     def barrier():
         torch.cuda.synchronize()
@@ -143,25 +163,28 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def sized_replicas(z, Q, pid, Omega, mapping, cap, frac=0.80, storage=0):
+    def sized_replicas(z, Q, pid, Omega, mapping, cap, frac=0.80, storage=0, variant=_lib.PHM_MCMC_BIGTREE, max_iters=1):
         """replicas that fit `frac` of the free HBM, in whole groups of tiles, at most `cap`"""
         free_b, _ = torch.cuda.mem_get_info()
-        probe = _lib.Engine(z, Q, pid, Omega, 1, variant=_lib.PHM_MCMC_BIGTREE, seed=1, n_replicas=64, reduce=True,
-                            device=local_rank, storage=storage, mapping=mapping)
+        # the slots of the (tile, item) mappings are provisioned from the run length (S x E x sweeps draws): the probe tile gets the tail of the full job
+        tail = max(1e-16, min(1e-9, 0.05 / (float(cap) * z["edge"].shape[0] * max_iters))) if mapping == "tiles" else 0.0
+        probe = _lib.Engine(z, Q, pid, Omega, max_iters, variant=variant, seed=1, n_replicas=64, reduce=True,
+                            device=local_rank, storage=storage, mapping=mapping, cap_tail=tail)
         per_tile = probe.info().device_bytes
         probe.close()
         S = int(min(cap, (frac * free_b) // per_tile * 64))
         return max(64, S // 1024 * 1024 if S >= 1024 else S // 64 * 64)
 
-    def measure(cfg, mapping, S, K, W, seed, ipl=8, storage=0, collective=False, offset=0):
-        """K timed sweeps of configuration `cfg` after W warm-up sweeps; returns (block, wall seconds, engine statistics)."""
+    def measure(cfg, mapping, S, K, W, seed, ipl=8, storage=0, collective=False, offset=0, variant=_lib.PHM_MCMC_BIGTREE, tkey=None):
+        """K timed sweeps of configuration `cfg` after args.burnin + W untimed sweeps; returns (block, wall seconds)."""
+        W = W + args.burnin
         z, Q, pid, Omega = synth.config_problem(cfg)
         n, E = Q.shape[0], z["edge"].shape[0]
-        cols = n + n * (n - 1)
         tiled = mapping == "tiles"
-        eng = _lib.Engine(z, Q, pid, Omega, K + W, variant=_lib.PHM_MCMC_BIGTREE, seed=seed, n_replicas=S, replica_offset=offset,
+        eng = _lib.Engine(z, Q, pid, Omega, K + W, variant=variant, seed=seed, n_replicas=S, replica_offset=offset,
                           reduce=True, device=local_rank, iters_per_launch=ipl, storage=storage, mapping=mapping,
                           phase_timing=tiled)
+        cols = eng.cols
         eng.run(W, stream)
         eng.sync()
         seg0 = eng.info().seg_read
@@ -188,83 +211,121 @@ def main():
         dt = time.perf_counter() - t0
 
         info = eng.info()
+        assert info.recoveries == 0, "a capacity recovery (rebuild + replay) happened inside the timed region"
         units = E * S * K                                    # branch x replica paths sampled by this rank
         seg = (info.seg_read - seg0) / units                 # measured mean (m_b + m'_b)
         b_alg = 16 * n + 12 * seg + 26                       # algorithmic bytes per branch x replica x sweep
         kernel_s = info.last_run_ms / 1e3
         stats = eng.stats(W, K)
-        # sanity: dwell row sums = S x tree length; the matrix handed to RCCL is the same matrix (x world)
+        # sanity: dwell row sums = S x tree length; the matrix handed to RCCL is the same matrix (summed over ranks)
         assert np.allclose(stats[:, :n].sum(1), S * z["edge.length"].sum(), rtol=1e-9)
-        if total is not None:
-            assert np.allclose(total[:, :n].sum(1), world * S * z["edge.length"].sum(), rtol=1e-9)
-            if world == 1:
-                assert np.array_equal(total, stats)
-        tkey = f"C{cfg}"
-        tr = traffic.get(tkey, {})
-        blk = {"workload": f"C{cfg}", "n_states": n, "n_tips": int(z["states"].size), "branches": E, "replicas": S, "mapping": mapping,
+        if total is not None and world == 1:
+            assert np.array_equal(total, stats)
+        tr = traffic.get(tkey or f"C{cfg}", {})
+        per = E * S                                          # units of one sweep
+        blk = {"workload": tkey or f"C{cfg}", "n_states": n, "n_tips": int(z["states"].size), "branches": E, "replicas": S, "mapping": mapping,
                "ms_per_sweep": dt / K * 1e3, "realisations_per_s": units / dt, "hbm_gib_resident": info.device_bytes / 2 ** 30,
-               "mean_segments_read_plus_written": seg}
-        sweep = {"bound": "hbm", "alg_bytes_per_unit": b_alg, "achieved": units * b_alg / kernel_s / 1e9, "peak": HBM_PEAK_GBS,
-                 "unit": "GB/s", "frac": units * b_alg / kernel_s / 1e9 / HBM_PEAK_GBS, "kernel_ms_per_sweep": info.last_run_ms / K,
-                 "launches_per_sweep": info.last_run_launches / K, "frac_of_measured_triad": units * b_alg / kernel_s / 1e9 / MEASURED_TRIAD_GBS}
-        if tr.get("all_kernels_bytes_per_unit"):
-            sweep["traffic"] = tr["all_kernels_bytes_per_unit"] * E * S      # every kernel of one sweep, HBM bytes from the PMC passes
+               "replicas_per_gib": S / (info.device_bytes / 2 ** 30), "mean_segments_read_plus_written": seg}
+        sweep = {"bound": "hbm", "definition": "SURVEY 8(d): E * S * B_alg / (HIP-event time of all kernels of one sweep), B_alg = 16 n + 12 mean(m + m') + 26",
+                 "alg_bytes_per_unit": b_alg, "units_per_launch": per, "launches": K, "avg_launch_ms": info.last_run_ms / K,
+                 "achieved": units * b_alg / kernel_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": units * b_alg / kernel_s / 1e9 / HBM_PEAK_GBS, "kernel_launches_per_sweep": info.last_run_launches / K,
+                 "frac_of_measured_triad": units * b_alg / kernel_s / 1e9 / MEASURED_TRIAD_GBS,
+                 "traffic": (tr["all_kernels_bytes_per_unit"] * per) if tr.get("all_kernels_bytes_per_unit") else None,
+                 "traffic_source": tr.get("source")}
         if tiled:
             up_ms, down_ms, br_ms, st_ms = [v / K for v in eng.phase_ms()]
-            per = E * S                                      # units per launch of the branch kernel = one sweep
-            br_bytes = 12 * seg + 8                          # the branch step's share of B_alg
-            branch = {"bound": "hbm", "kernel": ("tiles_branch_kernel<4, false>" if n <= 4 else "wt_branch_kernel<false>"),
-                      "achieved": per * br_bytes / (br_ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                      "frac": per * br_bytes / (br_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
-                      "traffic": (tr["branch_kernel_bytes_per_unit"] * per) if tr.get("branch_kernel_bytes_per_unit") else None,
-                      "launches": K, "avg_launch_ms": br_ms, "alg_bytes_per_unit": br_bytes, "units_per_launch": per}
-            n_int = E // 2 - 1                               # branches whose child is an internal node
-            prune = {"bound": "hbm", "kernel": ("tiles_up_kernel<4>" if n <= 4 else f"wt_up_kernel<{(n + 15) // 16}>") + " (all height levels of one sweep)",
-                     "alg_bytes_per_unit": 12 * n + 12, "ms_per_sweep": up_ms,
-                     "achieved": per * (12 * n + 12) / (up_ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": per * (12 * n + 12) / (up_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
-                     "traffic": (tr["up_kernels_bytes_per_unit"] * per) if tr.get("up_kernels_bytes_per_unit") else None}
-            if prune["traffic"]:      # what the pruning levels actually move (tip rows come from u8 states + tables, not from HBM)
-                prune["counter_traffic_frac"] = prune["traffic"] / (up_ms / 1e3) / 1e9 / HBM_PEAK_GBS
-            if n > 4:                                        # 5..64 states: the pruning chains run on the matrix cores
-                mbar = seg / 2.0
-                flops = 2.0 * n * n * max(mbar - 1.0, 0.0) * n_int * S      # 2 n^2 (m - 1) per internal-child branch
+
+            def kblock(needles, ms, alg_bytes, what):
+                bpu, valu, names = kernel_traffic(tr, *needles)
+                e = {"kernel": ", ".join(names) if names else "/".join(needles), "what": what, "bound": "hbm", "alg_bytes_per_unit": alg_bytes,
+                     "units_per_launch": per, "launches": K, "avg_launch_ms": ms,
+                     "achieved": per * alg_bytes / (ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": per * alg_bytes / (ms / 1e3) / 1e9 / HBM_PEAK_GBS, "traffic": (bpu * per) if bpu else None}
+                if bpu:
+                    e["counter_traffic_frac"] = bpu * per / (ms / 1e3) / 1e9 / HBM_PEAK_GBS
+                if valu:      # VALU issue: instructions of the PMC run, scaled to this run's units, at the measured issue rate
+                    scale = per / tr["units_per_sweep_in_pmc_run"]
+                    e["valu_issue_frac"] = valu * scale * VALU_CLOCKS / (N_SIMD * NOMINAL_GHZ * 1e9 * ms / 1e3)
+                return e
+            branch = kblock(("_branch_kernel",), br_ms, 12 * seg + 8, "resamplebranchstates + shortener + virtual jumps + dwell sums (src/phylomap.cpp:264-413, :44-73, :745-757); one launch per sweep")
+            prune = kblock(("_up_",), up_ms, 12 * n + 12, "makePLrcpp* (src/phylomap.cpp:503-529), all height levels of one sweep")
+            draws = kblock(("_down_kernel", "_root_kernel"), down_ms, 4 * n + 6, "sampleinternalnodes* + updatenodestates (src/phylomap.cpp:618-657, :460-475), all depth levels")
+            red = kblock(("_stats_kernel", "_chunk_kernel"), st_ms, 0.0, "statistics rows (fixed-order reductions)")
+            if n > 4 and eng.info().sparse_chains & 1 == 0:   # 5..64 states, dense B: the pruning chains run on the matrix cores
+                n_int = E // 2 - 1                           # branches whose child is an internal node
+                flops = 2.0 * n * n * max(seg / 2.0 - 1.0, 0.0) * n_int * S      # 2 n^2 (m - 1) per internal-child branch
                 prune["mfma"] = {"bound": "mfma", "achieved": flops / (up_ms / 1e3) / 1e12, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                 "frac": flops / (up_ms / 1e3) / 1e12 / MFMA_F64_PEAK_TFLOPS,
-                                 "alg_flops_per_sweep": flops, "note": "algorithmic flops 2 n^2 (mean m - 1) per internal-child branch; the "
-                                 "kernel issues max-over-16-replicas steps of 64-padded tiles"}
+                                 "frac": flops / (up_ms / 1e3) / 1e12 / MFMA_F64_PEAK_TFLOPS, "alg_flops_per_sweep": flops,
+                                 "note": "algorithmic flops 2 n^2 (mean m - 1) per internal-child branch; the kernel issues max-over-16-replicas steps of 64-padded tiles"}
+            kernels = {"branch": branch, "pruning": prune, "node_draws": draws, "reductions": red}
+            dom = max(("branch", "pruning", "node_draws"), key=lambda k: kernels[k]["avg_launch_ms"])
             blk["phases_ms_per_sweep"] = {"pruning_levels": up_ms, "node_draws": down_ms, "branch_kernel": br_ms, "reductions": st_ms}
-            blk["roofline"] = dict(branch, sweep=sweep)
+            blk["roofline"] = dict(sweep, dominant_kernel=dict(kernels[dom], phase=dom), kernels=kernels)
             blk["pruning_sweep"] = prune
         else:
-            per = E * S * ipl
-            blk["roofline"] = dict(sweep, kernel=f"mcmc_sweep_kernel<{n}>",
-                                   traffic=(tr["sweep_kernel_bytes_per_unit"] * per) if tr.get("sweep_kernel_bytes_per_unit") else None,
+            per_l = E * S * ipl
+            bpu, valu, names = kernel_traffic(tr, "mcmc_sweep_kernel")
+            blk["roofline"] = dict(sweep, kernel=f"mcmc_sweep_kernel<{n}> (the whole sweep fused, {ipl} sweeps per launch)",
                                    launches=info.last_run_launches, avg_launch_ms=info.last_run_ms / max(1, info.last_run_launches),
-                                   units_per_launch=per, measured_triad_peak=MEASURED_TRIAD_GBS)
+                                   units_per_launch=per_l, measured_triad_peak=MEASURED_TRIAD_GBS)
+            if valu:
+                blk["roofline"]["valu_issue_frac"] = valu * (per / tr["units_per_sweep_in_pmc_run"]) * VALU_CLOCKS / (N_SIMD * NOMINAL_GHZ * 1e9 * info.last_run_ms / K / 1e3)
             if n <= 4 and mapping == "replicas":
                 prune_ms = eng.time_pruning(8, stream) / 8.0
                 blk["pruning_sweep"] = {"kernel": f"mcmc_sweep_kernel<{n}> (up sweep only)", "ms_per_sweep": prune_ms,
                                         "alg_bytes_per_unit": 12 * n + 12, "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "achieved": E * S * (12 * n + 12) / (prune_ms / 1e3) / 1e9,
-                                        "frac": E * S * (12 * n + 12) / (prune_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
-                                        "traffic": (tr["pruning_bytes_per_unit"] * E * S) if tr.get("pruning_bytes_per_unit") else None}
-                if blk["pruning_sweep"]["traffic"]:
-                    blk["pruning_sweep"]["counter_traffic_frac"] = blk["pruning_sweep"]["traffic"] / (prune_ms / 1e3) / 1e9 / HBM_PEAK_GBS
+                                        "frac": E * S * (12 * n + 12) / (prune_ms / 1e3) / 1e9 / HBM_PEAK_GBS}
         eng.close()
         return blk, dt
+
+    def one_chain(cfg, sweeps):
+        """the reference's own calling pattern: ONE chain (every R/sumstat*.R call), on the mapping the library picks for it"""
+        z, Q, pid, Om = synth.config_problem(cfg)
+        E = z["edge"].shape[0]
+        one = _lib.Engine(z, Q, pid, Om, sweeps + 4, variant=_lib.PHM_MCMC_BIGTREE, seed=1, n_replicas=1, device=local_rank)
+        one.run(4); one.sync()
+        t1 = time.perf_counter(); one.run(sweeps); one.sync(); d1 = time.perf_counter() - t1
+        mp = {1: "one lane per replica", 2: "one lane per branch (n <= 4) / one wave per (replica, branch)", 3: "one lane per replica, wave per (tile, item)"}[one.info().mapping]
+        one.close()
+        return {"workload": f"C{cfg}, ONE chain: what the R call sumstatMCMC_bigtree(z, Q, pid, Omega, N) gets (R/sumstatMCMC_bigtree.R:21-29)",
+                "mapping": mp, "ms_per_sweep": d1 / sweeps * 1e3, "realisations_per_s": E * sweeps / d1}
 
     # ---- headline ------------------------------------------------------------------------------------------------
     K, W = args.steps, args.warmup
     cfg = args.config
     mapping = args.mapping or ("replicas" if cfg == 2 else "tiles")
     zc, Qc, pidc, Omc = synth.config_problem(cfg)
-    S = args.replicas
-    if S <= 0:
+    sto = args.storage if mapping == "replicas" else 0
+    S_req = args.replicas
+    if S_req <= 0:
         cap = {2: 393216, 3: 16384, 4: 65536, 5: 16384}.get(cfg, 16384)
-        S = sized_replicas(zc, Qc, pidc, Omc, mapping, cap, storage=args.storage if mapping == "replicas" else 0)
-    head, dt = measure(cfg, mapping, S, K, W, 0x5EED0000 + cfg, ipl=args.ipl, storage=args.storage if mapping == "replicas" else 0,
-                       collective=(world > 1 or args.force_collective), offset=parallel.weak_shard(S, rank)[0])
+        S_req = sized_replicas(zc, Qc, pidc, Omc, mapping, cap, storage=sto, max_iters=K + W + args.burnin)
+    if world > 1:      # one decision for the whole job: rank 0's (ranks sizing from their own free HBM could disagree)
+        t = torch.tensor([S_req], dtype=torch.int64, device=dist_dev)
+        dist.broadcast(t, src=0)
+        S_req = int(t.item())
+    if args.scaling == "strong":
+        offset, S = parallel.split_replicas(S_req, world, rank)
+        S_total = S_req
+    else:
+        offset, S = parallel.weak_shard(S_req, rank)
+        S_total = S_req * world
+    if world > 1:      # fail loudly if the ranks do not tile [0, S_total) exactly
+        mine = torch.tensor([offset, S], dtype=torch.int64, device=dist_dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        spans = sorted((int(a[0]), int(a[1])) for a in allr)
+        pos = 0
+        for o_, s_ in spans:
+            if o_ != pos or s_ < 1:
+                raise SystemExit(f"bench.py: ranks disagree on the replica sharding: {spans} does not tile [0, {S_total})")
+            pos += s_
+        if pos != S_total:
+            raise SystemExit(f"bench.py: ranks disagree on the replica sharding: {spans} does not tile [0, {S_total})")
+    head, dt = measure(cfg, mapping, S, K, W, 0x5EED0000 + cfg, ipl=args.ipl, storage=sto,
+                       collective=(world > 1 or args.force_collective), offset=offset)
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -277,47 +338,54 @@ def main():
                  5: "C5: sparse 20-state sweep (row-normalised PL)"}
         out = {
             "metric": "stochastic-map realisations/sec (branches x sites sampled/s)",
-            "value": E * S * K * world / dt, "unit": "branch-site realisations/s",
+            "value": E * S_total * K / dt, "unit": "branch-site realisations/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{names.get(cfg, f'C{cfg}')}, {n}-state Q, {head['n_tips']}-tip synthetic tree, Omega*mean(t_b)=4",
-                       "n_states": n, "n_tips": head["n_tips"], "branches": E, "replicas_per_gpu": S,
+                       "n_states": n, "n_tips": head["n_tips"], "branches": E, "replicas_total": S_total, "replicas_rank0": S,
                        "mapping": {"tiles": "one wave per (tile of 64 replicas, branch)", "replicas": "one lane per replica, one wave per tile walks the tree"}.get(mapping, mapping),
-                       "parallelism": f"replica-sharded x{world}, one RCCL all-reduce of the statistics"},
+                       "parallelism": f"replica-sharded x{world} ({args.scaling}), one RCCL all-reduce of the statistics"},
             "roofline": head["roofline"],
             "phases_ms_per_sweep": head.get("phases_ms_per_sweep"),
             "pruning_sweep": head.get("pruning_sweep"),
             "hbm_bytes_resident": int(head["hbm_gib_resident"] * 2 ** 30),
+            "replicas_per_gib": head["replicas_per_gib"],
         }
         if cfg in cpu:
             out["cpu_baseline"] = cpu[cfg]
             out["speedup_vs_cpu_1core"] = out["value"] / cpu[cfg]["value"]
             out["speedup_vs_cpu_1core_faithful"] = out["value"] / cpu[cfg]["faithful_value"]
             out["speedup_vs_cpu_all_cores"] = out["value"] / cpu[cfg]["all_cores"]["value"]
+    if rank == 0 and world == 1:
+        sc = one_chain(cfg, 100)
+        if cfg in cpu:
+            sc["speedup_vs_cpu_1core"] = sc["realisations_per_s"] / cpu[cfg]["value"]
+            sc["speedup_vs_cpu_1core_faithful"] = sc["realisations_per_s"] / cpu[cfg]["faithful_value"]
+        out["single_chain"] = sc
 
     # ---- the other BASELINE configurations, one block each (N = 1 only) -----------------------------------------------
     if rank == 0 and world == 1 and not args.no_extras:
         blocks = {}
-        plan = [(2, "replicas", 393216, 16, 8, 2), (4, "tiles", 65536, 6, 6, 0), (5, "tiles", 16384, 6, 8, 0)]
+        # (cfg, mapping, cap, K, W, storage, variant, key): C4 in the n + n^2 counting layout (shortenerbf: self pairs counted) SURVEY 8 scopes it in
+        plan = [(2, "replicas", 393216, 16, 8, 2, _lib.PHM_MCMC_BIGTREE, "C2"), (4, "tiles", 65536, 6, 6, 0, _lib.PHM_MCMC_BF, "C4bf"),
+                (5, "tiles", 16384, 6, 8, 0, _lib.PHM_MCMC_BIGTREE, "C5")]
         if cfg == 2:
-            plan[0] = (3, "tiles", 16384, 12, 6, 0)
-        for c, mp, capS, k, w, sto in plan:
+            plan[0] = (3, "tiles", 16384, 12, 6, 0, _lib.PHM_MCMC_BIGTREE, "C3")
+        for c, mp, capS, k, w, sto_c, var, key in plan:
             z, Q, pid, Om = synth.config_problem(c)
-            Sx = sized_replicas(z, Q, pid, Om, mp, capS, frac=0.80, storage=sto)
-            blk, _ = measure(c, mp, Sx, k, w, 0x5EED0000 + c, ipl=8, storage=sto)
+            Sx = sized_replicas(z, Q, pid, Om, mp, capS, frac=0.80, storage=sto_c, variant=var, max_iters=k + w + args.burnin)
+            blk, _ = measure(c, mp, Sx, k, w, 0x5EED0000 + c, ipl=8, storage=sto_c, variant=var, tkey=key)
+            if var == _lib.PHM_MCMC_BF:
+                blk["layout"] = "n dwell sums + n x n counts incl. self pairs (shortenerbf, src/phylomap.cpp:997-1028) + root state"
             if c in cpu:
                 blk["cpu_baseline"] = cpu[c]
                 blk["speedup_vs_cpu_1core"] = blk["realisations_per_s"] / cpu[c]["value"]
-            blocks[f"C{c}"] = blk
+            blocks[key] = blk
         # the reference's own calling pattern -- ONE chain -- and an alignment-sized job, on the C2 tree
+        blocks["C2_single_chain"] = one_chain(2, 100)
         z, Q, pid, Om = synth.config_problem(2)
         E2 = z["edge"].shape[0]
-        one = _lib.Engine(z, Q, pid, Om, 104, variant=_lib.PHM_MCMC_BIGTREE, seed=1, n_replicas=1, device=local_rank, mapping="branches")
-        one.run(4); one.sync()
-        t1 = time.perf_counter(); one.run(100); one.sync(); d1 = time.perf_counter() - t1
-        one.close()
-        blocks["C2_single_chain"] = {"mapping": "one lane per branch", "ms_per_sweep": d1 / 100 * 1e3, "realisations_per_s": E2 * 100 / d1}
         mid = _lib.Engine(z, Q, pid, Om, 44, variant=_lib.PHM_MCMC_BIGTREE, seed=1, n_replicas=4096, reduce=True, device=local_rank, mapping="tiles")
         mid.run(4); mid.sync()
         t1 = time.perf_counter(); mid.run(40); mid.sync(); d1 = time.perf_counter() - t1
@@ -340,14 +408,19 @@ def main():
             t1 = time.perf_counter()
             api.sumstatEXP(z, Q, pid, 1000, seed=3, rescale=resc, device=local_rank)      # the sample count R users call it with
             call_1000 = time.perf_counter() - t1
+            tr = traffic.get(key, {})
+            bpu, valu, knames = kernel_traffic(tr, "exp_tiles_", "exp_sample", "exp_wide")
+            rl = {"bound": "valu", "kernel": ", ".join(knames) if knames else "exp_tiles_branch_kernel (+ root, node levels, finish)", "launches": 1, "avg_launch_ms": kms,
+                  "alg_bytes_per_unit": alg, "units_per_launch": E * N, "achieved": E * N * alg / (kms / 1e3) / 1e9,
+                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": E * N * alg / (kms / 1e3) / 1e9 / HBM_PEAK_GBS,
+                  "traffic": (bpu * E * N) if bpu else None, "traffic_source": tr.get("source")}
+            if valu:      # the bound claimed: VALU issue = instructions (PMC run, scaled by units) x measured issue clocks / kernel time
+                rl["valu_issue_frac"] = valu * (E * N / tr["units_per_sweep_in_pmc_run"]) * VALU_CLOCKS / (N_SIMD * NOMINAL_GHZ * 1e9 * kms / 1e3)
+                rl["note"] = ("VALU-issue bound: SQ_INSTS_VALU of the sampler's kernels x 4.9 nominal clocks / (1 024 SIMDs x 2.4 GHz) over the kernel time; "
+                              "the 300-row B^k e_j table and P(t_b) stay in L2, HBM sees the statistics and the jump-time scratch only")
             blocks[key] = {"workload": f"sumstatEXP, {n}-state Q, {z['states'].size}-tip tree, N = {N} i.i.d. samples" + (", rescaled pruning pass" if resc else ""),
                            "mapping": "one wave per (tile of 64 samples, branch)", "whole_call_ms_at_N_1000": call_1000 * 1e3,
-                           "realisations_per_s": E * N / (kms / 1e3), "realisations_per_s_incl_setup_and_copies": E * N / wall,
-                           "roofline": {"bound": "hbm", "kernel": "exp_tiles_branch_kernel (+ root, node levels, finish)", "launches": 1, "avg_launch_ms": kms,
-                                        "alg_bytes_per_unit": alg, "units_per_launch": E * N, "achieved": E * N * alg / (kms / 1e3) / 1e9,
-                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": E * N * alg / (kms / 1e3) / 1e9 / HBM_PEAK_GBS,
-                                        "traffic": traffic.get(key, {}).get("sample_kernel_bytes_per_launch"),
-                                        "note": "latency / VALU bound: the 300-row B^k e_j table and P(t_b) are L2-resident; avg_launch_ms = all kernels of the sampler"}}
+                           "realisations_per_s": E * N / (kms / 1e3), "realisations_per_s_incl_setup_and_copies": E * N / wall, "roofline": rl}
         out["configs"] = blocks
 
         # secondary metric of BASELINE.json: expm(Q t)/s (batched transition matrices, kernel time)
