@@ -233,6 +233,59 @@ static int sample_cat_R(const double* p, int n, double u, int* err) {
   for (jj = 0; jj < n - 1; ++jj) { cum += pr[jj]; if (u <= cum) break; }
   return perm[jj];
 }
+/* Rf_dpois(k, lambda, 0) as newunifSample calls it (src/phylomap.cpp:107,128): R's saddle-point dpois_raw (nmath/dpois.c,
+ * Loader 2000) with stirlerr (nmath/stirlerr.c) and bd0 (nmath/bd0.c), restated from the published sources as they stood up to
+ * R 4.0.x.  R >= 4.1 evaluates the deviance part through ebd0() (a 128-entry table of logarithms, not restated): the two differ
+ * in the last ulps, which moves a jump count only when the uniform falls within ~1e-16 of a partial sum.  UNVERIFIED here
+ * (no R); checked against exp(-lambda) lambda^k / k! in 50-digit arithmetic to <= 4 ulp (tests/test_oracle_cpu.py). */
+static double r_stirlerr(double n) {
+  static const double sferr_halves[31] = {
+    0.0, 0.1534264097200273452913848, 0.0810614667953272582196702, 0.0548141210519176538961390, 0.0413406959554092940938221,
+    0.03316287351993628748511048, 0.02767792568499833914878929, 0.02374616365629749597132920, 0.02079067210376509311152277,
+    0.01848845053267318523077934, 0.01664469118982119216319487, 0.01513497322191737887351255, 0.01387612882307074799874573,
+    0.01281046524292022692424986, 0.01189670994589177009505572, 0.01110455975820691732662991, 0.010411265261972096497478567,
+    0.009799416126158803298389475, 0.009255462182712732917728637, 0.008768700134139385462952823, 0.008330563433362871256469318,
+    0.007934114564314020547248100, 0.007573675487951840794972024, 0.007244554301320383179543912, 0.006942840107209529865664152,
+    0.006665247032707682442354394, 0.006408994188004207068439631, 0.006171712263039457647532867, 0.005951370112758847735624416,
+    0.005746216513010115682023589, 0.005554733551962801371038690 };
+  const double S0 = 0.083333333333333333333, S1 = 0.00277777777777777777778, S2 = 0.00079365079365079365079365,
+               S3 = 0.000595238095238095238095238, S4 = 0.0008417508417508417508417508;
+  if (n <= 15.0) {
+    double nn = n + n;
+    if (nn == (int)nn) return sferr_halves[(int)nn];
+    return lgamma(n + 1.) - (n + 0.5) * log(n) + n - 0.918938533204672741780329736406;      /* M_LN_SQRT_2PI */
+  }
+  double nn = n * n;
+  if (n > 500) return (S0 - S1 / nn) / n;
+  if (n > 80) return (S0 - (S1 - S2 / nn) / nn) / n;
+  if (n > 35) return (S0 - (S1 - (S2 - S3 / nn) / nn) / nn) / n;
+  return (S0 - (S1 - (S2 - (S3 - S4 / nn) / nn) / nn) / nn) / n;
+}
+static double r_bd0(double x, double np) {
+  if (fabs(x - np) < 0.1 * (x + np)) {
+    double v = (x - np) / (x + np);
+    double s = (x - np) * v;
+    if (fabs(s) < 2.2250738585072014e-308) return s;
+    double ej = 2 * x * v;
+    v = v * v;
+    for (int j = 1; j < 1000; j++) {
+      ej *= v;
+      double s1 = s + ej / ((j << 1) + 1);
+      if (s1 == s) return s1;
+      s = s1;
+    }
+  }
+  return x * log(x / np) + np - x;
+}
+static double r_dpois(double x, double lambda) {
+  if (lambda == 0) return (x == 0) ? 1. : 0.;
+  if (x < 0) return 0.;
+  if (x <= lambda * 2.2250738585072014e-308) return exp(-lambda);
+  if (lambda < x * 2.2250738585072014e-308) return exp(-lambda + x * log(lambda) - lgamma(x + 1));
+  return exp(-r_stirlerr(x) - r_bd0(x, lambda)) / sqrt(6.283185307179586476925286766559 * x);   /* R_D_fexp(M_2PI x, .) */
+}
+double orc_r_dpois(double x, double lambda) { return r_dpois(x, lambda); }
+
 int orc_rstream_selftest(uint32_t seed, int n_unif, int n_exp, double* unif_out, double* exp_out) {   /* set.seed; runif(n_unif); rexp(n_exp) */
   r_set_seed(seed);
   for (int i = 0; i < n_unif; ++i) unif_out[i] = r_unif_rand();
@@ -1273,9 +1326,9 @@ static void sampleinternalnodesEXP(const int32_t* edge1, const int32_t* edge2, c
   for (int i = 0; i < 2 * T - 1; ++i) rm[i] = rm[i] + 1;
 }
 
-/* dpois(k; lam) by the recurrence p_0 = exp(-lam), p_k = p_{k-1}*lam/k.  The reference calls R's
- * Rf_dpois (saddle-point dpois_raw, src/phylomap.cpp:107,128) which is not under /root/reference;
- * the two agree to a few ulp.  */
+/* dpois(k; lam) by the recurrence p_0 = exp(-lam), p_k = p_{k-1}*lam/k (Philox mode; the HIP kernels do the same).  The
+ * reference calls R's Rf_dpois (saddle-point dpois_raw, src/phylomap.cpp:107,128), which is not under /root/reference: R-stream
+ * mode uses its restatement r_dpois; the two agree to a few ulp.  */
 
 /* newunifSample, src/phylomap.cpp:93-208.  Returns 1 when the 300-jump cap was hit (:120-125). */
 static int newunifSample(int startState, int endState, double elapsedTime, double transProb, Branch* out,
@@ -1287,7 +1340,7 @@ static int newunifSample(int startState, int endState, double elapsedTime, doubl
   bpws[endState] = 1.0;                                                      /* :100 */
   double rU = draw_u(rc, (uint32_t)iteration, ent, dr++);                    /* :103 */
   double lam = poissonRate * elapsedTime;
-  double pk = orc_exp(-lam);                                                 /* dpois(0) */
+  double pk = g_rstream ? r_dpois(0.0, lam) : orc_exp(-lam);                 /* dpois(0) */
   double cum = 0.0;
   if (startState == endState) cum = pk / transProb;                          /* :107 */
   int notExceed = !(cum > rU);
@@ -1296,7 +1349,7 @@ static int newunifSample(int startState, int endState, double elapsedTime, doubl
     numJumps++;
     if (numJumps > 300) return 1;                                            /* :120 */
     matvec(B2, bpws + (size_t)(numJumps - 1) * n, bpws + (size_t)numJumps * n, n);   /* :127 */
-    pk = pk * lam / (double)numJumps;
+    pk = g_rstream ? r_dpois((double)numJumps, lam) : pk * lam / (double)numJumps;
     double nextProb = pk * bpws[(size_t)numJumps * n + startState] / transProb;      /* :128 */
     cum += nextProb;
     if (cum > rU) notExceed = 0;
@@ -1357,8 +1410,11 @@ int orc_maketreelistEXP(const orc_tree* x, int n, const double* Q_cm, const doub
   int cols = n + n * (n - 1);
   size_t nn = (size_t)n * n;
   rngctx rc = { rng, 0, 0 };
-  if (rng->mode == 2) return ORC_ERR_BAD_INPUT;       /* R-stream mode: Rf_dpois (saddle-point) is not restated */
-  g_rstream = 0;
+  /* R-stream mode: set.seed(seed_lo), then unif_rand consumed in the reference's order -- per iteration the root and the nodes of
+   * nodelist through RcppArmadillo::sample (:2934, :2956), then per branch in edge order rU (:103), the jump times runif(k) (:147,
+   * :151) and one runif per interior state (:159, sampleOnce: no sort); Rf_dpois by r_dpois */
+  g_rstream = (rng->mode == 2);
+  if (g_rstream) r_set_seed(rng->seed_lo);
 
   double* L = (double*)malloc(sizeof(double) * nn * 3);
   double *R = L + nn, *B2 = L + 2 * nn;
@@ -1414,6 +1470,7 @@ int orc_maketreelistEXP(const orc_tree* x, int n, const double* Q_cm, const doub
       updatedwelltimes(it, &brs[i], out, N);
     }
   }
+  g_rstream = 0;
   fill_dump(dump, brs, E, rm, 2 * T - 1, PL, pl_len);
   for (int i = 0; i < E; ++i) { free(brs[i].d); free(brs[i].s); }
   free(tmp.d); free(tmp.s); free(dom); free(times); free(bpws); free(eoc); free(rm); free(w); free(PL); free(P);

@@ -56,7 +56,8 @@ extern "C" {
 /* RNG: mode 0 = counter-based Philox4x32-7 streams (the mode the GPU matches bit for bit);
  *      mode 1 = scripted tapes consumed in the reference's draw order (for hand KATs);
  *      mode 2 = "R stream": set.seed(seed_lo) + unif_rand / exp_rand / sorted RcppArmadillo::sample consumed sequentially
- *               in the reference's order (fixed-Q MCMC variants only).  UNVERIFIED: no R here; see tools/r_parity/. */
+ *               in the reference's order (the fixed-Q MCMC variants and sumstatEXP, whose Rf_dpois is restated as dpois_raw with
+ *               stirlerr / bd0).  UNVERIFIED: no R here; see tools/r_parity/. */
 typedef struct orc_rng {
   int32_t  mode;
   uint32_t seed_lo, seed_hi;   /* Philox key */
@@ -99,6 +100,7 @@ double orc_neglog_u32(uint32_t k);   /* -log((k + 0.5) 2^-32), table-based, ~1 u
 double orc_stream_u(uint32_t seed_lo, uint32_t seed_hi, uint32_t replica, uint32_t iter,
                     uint32_t entity, uint32_t draw);
 
+double orc_r_dpois(double x, double lambda);   /* R's dpois_raw (stirlerr + bd0, R <= 4.0.x), what R-stream mode puts in place of the recurrence */
 int orc_rstream_selftest(uint32_t seed, int n_unif, int n_exp, double* unif_out, double* exp_out);   /* set.seed(seed); runif(n_unif); rexp(n_exp) */
 
 /* ---- per-function entry points for known-answer tests ---- */

@@ -181,7 +181,7 @@ def maketreelistMCMCmt(treelist, Q, pid, B, Omega, nen_m, nodelist_m, roots, N, 
 
 
 def maketreelistEXP(z, Q, pid, nen, nodelist, root, N, lefts, rights, d, seed=1, replica=0,
-                    faithful_search=False, recompute=False, tape_u=None, dump=False, rescale=False):
+                    faithful_search=False, recompute=False, tape_u=None, dump=False, rescale=False, rstream=False):
     Q = np.asarray(Q, dtype=np.float64)
     n = Q.shape[0]
     ft = FlatTree(z)
@@ -192,7 +192,7 @@ def maketreelistEXP(z, Q, pid, nen, nodelist, root, N, lefts, rights, d, seed=1,
     nodelist = np.ascontiguousarray(nodelist, dtype=np.int32)
     cols = n + n * (n - 1)
     out = np.zeros((N, cols), order="F")
-    rng, keep = make_rng(seed, replica, tape_u, None)
+    rng, keep = make_rng(seed, replica, tape_u, None, rstream)
     db = DumpBuf(ft, n) if dump else None
     rc = lib().orc_maketreelistEXP(C.byref(ft.c), n, _ptr(Qc, C.c_double), _ptr(pid, C.c_double),
                                    _ptr(nen, C.c_int32), _ptr(nodelist, C.c_int32), int(root), int(N),

@@ -108,6 +108,45 @@ def test_r_stream_mode_runs_the_same_sampler():
     np.testing.assert_array_equal(a, a2)
 
 
+def test_r_dpois_restatement_and_exp_r_stream_mode():
+    """Rf_dpois (src/phylomap.cpp:107,128) restated as R's saddle-point dpois_raw (stirlerr + bd0): against
+    exp(-lam) lam^k / k! in exact rational / 50-digit arithmetic, and sumstatEXP in R-stream mode (set.seed + unif_rand in the
+    reference's draw order, dpois_raw) as a second realisation of the same sampler."""
+    import ctypes as C
+    import math
+    import mpmath
+    mpmath.mp.dps = 50
+    L = O.lib()
+    L.orc_r_dpois.restype = C.c_double
+    L.orc_r_dpois.argtypes = [C.c_double, C.c_double]
+    worst = 0.0
+    for lam in (0.01, 0.3, 1.0, 2.5, 4.0, 7.75, 19.0, 33.3, 60.0):
+        for k in (0, 1, 2, 3, 5, 8, 13, 15, 16, 21, 34, 36, 55, 81, 150, 300):
+            want = mpmath.exp(-mpmath.mpf(lam)) * mpmath.mpf(lam) ** k / mpmath.factorial(k)
+            got = L.orc_r_dpois(float(k), lam)
+            if want < 1e-300:
+                continue
+            ulp = abs(mpmath.mpf(got) - want) / (mpmath.mpf(2) ** (mpmath.floor(mpmath.log(want, 2)) - 52))
+            # dpois_raw = exp(-stirlerr - bd0) / sqrt(2 pi k): a few ulp near the mode, and the rounding of the exponent's argument
+            # (relative error ~ |log p| eps) far out in the tails -- a wrong table entry or coefficient would show as 1e3 .. 1e12 ulp
+            # (and bd0's x log(x / lambda) + lambda - x cancels when |x - lambda| > 0.1 (x + lambda): the weakness R 4.1's ebd0 removed)
+            worst = max(worst, float(ulp) / (8.0 + 4.0 * (abs(float(mpmath.log(want))) + (k * abs(math.log(k / lam)) if k else 0.0))))
+    assert worst <= 1.0, worst
+    assert L.orc_r_dpois(0.0, 0.0) == 1.0 and L.orc_r_dpois(3.0, 0.0) == 0.0 and L.orc_r_dpois(0.0, 2.0) == math.exp(-2.0)
+    z, Q, pid, Omega = synth.config_problem(1, n_tips=30)
+    nen, nodelist, root = _orders(z)
+    lefts, rights, d = api.eigen_decompose(Q)
+    a, rc = O.maketreelistEXP(z, Q, pid, nen, nodelist, root, 600, lefts, rights, d, seed=11, rstream=True)
+    assert rc == 0
+    np.testing.assert_allclose(a[:, :2].sum(1), z["edge.length"].sum(), rtol=1e-12)
+    b, rc = O.maketreelistEXP(z, Q, pid, nen, nodelist, root, 600, lefts, rights, d, seed=11)
+    assert rc == 0
+    ja, jb = a[:, 2:].sum(1), b[:, 2:].sum(1)
+    assert abs(ja.mean() - jb.mean()) < 5 * np.hypot(ja.std(), jb.std()) / np.sqrt(600)
+    a2, _ = O.maketreelistEXP(z, Q, pid, nen, nodelist, root, 600, lefts, rights, d, seed=11, rstream=True)
+    np.testing.assert_array_equal(a, a2)
+
+
 # ---- per-function known answers (hand-derived) ---------------------------------------------------------
 def test_shortener_merges_and_counts():
     # states 0,0,2,2,1,0 with n=3: merged 0(1.5) 2(3.0) 1(4.0) 0(8.0); transitions 0->2, 2->1, 1->0
@@ -597,3 +636,46 @@ def test_exponential_variates_are_exponential():
     assert stats.kstest(u, "uniform").pvalue > 1e-3
     np.testing.assert_allclose(e, -np.log(u), rtol=1e-13)                  # the variate IS -log of the same draw's uniform
     assert abs(e.mean() - 1.0) < 0.02 and abs(e.var() - 1.0) < 0.05
+
+
+def test_r_parity_procedure_file_plumbing(tmp_path):
+    """tools/r_parity/: export_case.py -> (Rscript run_reference.R, needs R) -> compare.py.  Without R the files the R script
+    would write are produced by the oracle's own R-stream mode, which checks every file format and the comparison itself
+    (all four drivers incl. sumstatEXP must then report EXACT); it pins nothing about R."""
+    import subprocess
+    import sys
+    root_dir = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = str(tmp_path / "case")
+    subprocess.run([sys.executable, os.path.join(root_dir, "tools", "r_parity", "export_case.py"), d], check=True, capture_output=True)
+    edge = np.loadtxt(os.path.join(d, "edge.csv"), delimiter=",", dtype=np.int32)
+    states = np.loadtxt(os.path.join(d, "states.csv"), dtype=np.int32)
+    Q = np.loadtxt(os.path.join(d, "Q.csv"), delimiter=",")
+    pid = np.loadtxt(os.path.join(d, "pid.csv"))
+    maps, names = [], []
+    for line in open(os.path.join(d, "maps.csv")):
+        a, b = line.strip().split(";")
+        maps.append(np.array([float(v) for v in a.split()]))
+        names.append(np.array([int(v) for v in b.split()], dtype=np.int32))
+    z = {"edge": edge, "Nnode": states.size - 1, "edge.length": np.loadtxt(os.path.join(d, "edge_length.csv")), "states": states,
+         "maps": maps, "mapnames": names}
+    nen, nodelist, root = _orders(z)
+    np.savetxt(os.path.join(d, "nen.csv"), nen, fmt="%d")
+    np.savetxt(os.path.join(d, "nodelist.csv"), nodelist, fmt="%d")
+    np.savetxt(os.path.join(d, "root.csv"), [root], fmt="%d")
+    par = np.genfromtxt(os.path.join(d, "params.csv"), delimiter=",", names=True)
+    Omega, N, seed, n = float(par["Omega"]), int(par["N"]), int(par["seed"]), Q.shape[0]
+    for name, var in (("sumstatMCMC", O.PLAIN), ("sumstatMCMC_bigtree", O.BIGTREE), ("SPARSEsumstatMCMC", O.SPARSE)):
+        got, rc = O.maketreelistMCMC(z, Q, pid, np.eye(n) + Q / Omega, Omega, nen, nodelist, root, N, variant=var, seed=seed, rstream=True)
+        assert rc == 0
+        np.savetxt(os.path.join(d, name + ".csv"), got, delimiter=",", fmt="%.17g")
+    lefts, rights, dd = api.eigen_decompose(Q)
+    for nm, a in (("lefts", lefts), ("rights", rights), ("dd", dd)):
+        np.savetxt(os.path.join(d, nm + ".csv"), a, delimiter=",", fmt="%.17g")
+    got, rc = O.maketreelistEXP(z, Q, pid, nen, nodelist, root, N, lefts, rights, dd, seed=seed, rstream=True, recompute=True)
+    assert rc == 0
+    np.savetxt(os.path.join(d, "sumstatEXP.csv"), got, delimiter=",", fmt="%.17g")
+    r = subprocess.run([sys.executable, os.path.join(root_dir, "tools", "r_parity", "compare.py"), d], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("EXACT") == 4 and "sumstatEXP" in r.stdout
+    rs = open(os.path.join(root_dir, "tools", "r_parity", "run_reference.R")).read()
+    assert "sumstatEXP(z, Q, pid, par$N)" in rs and "eigen(Q)" in rs

@@ -35,4 +35,17 @@ for name, var in (("sumstatMCMC", O.PLAIN), ("sumstatMCMC_bigtree", O.BIGTREE), 
     dwell = np.allclose(got[:, :n], want[:, :n], rtol=1e-10, atol=0)
     print(f"{name}: rc={rc} counts {'EXACT' if counts else 'DIFFER'}, dwell {'within 1e-10' if dwell else 'DIFFER'}")
     ok = ok and counts and dwell and rc == 0
+# sumstatEXP: set.seed + unif_rand in the order of treesampleEXP / newunifSample (src/phylomap.cpp:2977-2996, :93-208), the
+# sorted RcppArmadillo::sample for the node states, sampleOnce for the interior states, Rf_dpois as dpois_raw (R <= 4.0.x;
+# R >= 4.1 evaluates it through ebd0: last-ulp differences that move a jump count only when a uniform lands within ~1e-16
+# of a partial sum)
+if os.path.exists(os.path.join(d, "sumstatEXP.csv")):
+    want = np.loadtxt(os.path.join(d, "sumstatEXP.csv"), delimiter=",")
+    lefts, rights, dd = (np.loadtxt(os.path.join(d, f + ".csv"), delimiter=",") for f in ("lefts", "rights", "dd"))
+    got, rc = O.maketreelistEXP(z, Q, pid, nen, nodelist, root, N, lefts, rights, dd, seed=seed, rstream=True, recompute=True)
+    counts = np.array_equal(got[:, n:], want[:, n:])
+    dwell = np.allclose(got[:, :n], want[:, :n], rtol=1e-10, atol=0)
+    rv = open(os.path.join(d, "R_version.txt")).read().strip() if os.path.exists(os.path.join(d, "R_version.txt")) else "?"
+    print(f"sumstatEXP (R {rv}): rc={rc} counts {'EXACT' if counts else 'DIFFER'}, dwell {'within 1e-10' if dwell else 'DIFFER'}")
+    ok = ok and counts and dwell and rc == 0
 sys.exit(0 if ok else 1)

@@ -30,4 +30,13 @@ for (v in c("sumstatMCMC", "sumstatMCMC_bigtree", "SPARSEsumstatMCMC")) {
   ss <- do.call(v, list(z, Q, pid, par$Omega, par$N))
   write.table(format(ss, digits = 17), file.path(d, paste0(v, ".csv")), sep = ",", row.names = FALSE, col.names = FALSE, quote = FALSE)
 }
+# sumstatEXP (R/sumstatEXP.R:19-31): the eigen-decomposition R computes is written out too, so that the oracle exponentiates
+# with R's own lefts / rights / d (LAPACK's eigenvector scaling differs from numpy's in the last bits)
+uer <- eigen(Q); lefts <- uer$vectors; rights <- solve(lefts); dd <- diag(uer$values)
+for (nm in c("lefts", "rights", "dd")) write.table(format(get(nm), digits = 17), file.path(d, paste0(nm, ".csv")), sep = ",", row.names = FALSE, col.names = FALSE, quote = FALSE)
+z$edge.length <- el
+set.seed(par$seed)
+ss <- sumstatEXP(z, Q, pid, par$N)
+write.table(format(ss, digits = 17), file.path(d, "sumstatEXP.csv"), sep = ",", row.names = FALSE, col.names = FALSE, quote = FALSE)
+writeLines(paste(R.version$major, R.version$minor, sep = "."), file.path(d, "R_version.txt"))   # dpois_raw changed in R 4.1 (ebd0)
 cat("done\n")
