@@ -69,7 +69,7 @@ def test_c1_sumstatEXP_100_tips():
     """C1: simulate_2_state_tree-shaped problem, ~100 tips, sumstatEXP (src/phylomap.cpp:3001-3051)."""
     z, Q, pid, Omega, nen, nodelist, root = _config(1)
     lefts, rights, d = api.eigen_decompose(Q)
-    N = 256
+    N = 1000                                        # SURVEY 8(d): C1 runs N = 1 000 samples
     got = api.sumstatEXP(z, Q, pid, N, seed=11)
     want, rc = O.maketreelistEXP(z, Q, pid, nen, nodelist, root, N, lefts, rights, d, seed=11)
     assert rc == 0 and got.shape == (N, 4)

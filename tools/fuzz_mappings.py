@@ -18,7 +18,12 @@ def run(seed, n_cases):
     for case in range(n_cases):
         n = int(rs.choice([2, 3, 4, 4, 5, 6, 8, 12, 17, 20, 33, 48, 61]))      # 1 .. 4 row blocks of the matrix-core pruning kernels
         Q = synth.dense_Q(n, 0.02, 0.3, seed=int(rs.integers(1 << 30)))
-        if rs.random() < 0.3:                                    # some exactly-zero rates (sparse threshold path)
+        band = int(rs.choice([0, 0, 1, 2])) if n >= 5 else 0      # round 3: tridiagonal / pentadiagonal rate matrices (band kernels, n <= 32)
+        if band:
+            idx = np.arange(n)
+            Q[np.abs(idx[:, None] - idx[None, :]) > band] = 0.0
+            np.fill_diagonal(Q, 0.0); np.fill_diagonal(Q, -Q.sum(1))
+        elif rs.random() < 0.3:                                    # some exactly-zero rates (sparse threshold path)
             mask = rs.random((n, n)) < 0.3
             np.fill_diagonal(mask, False)
             Q[mask] = 0.0
@@ -36,7 +41,9 @@ def run(seed, n_cases):
                      mapnames=[z["mapnames"][i] for i in perm])
         nen, nodelist, root = treeorder.pruningwiseedgeorder(z), treeorder.makenodelist(z), treeorder.myreorder(z)
         fn, var = VAR[int(rs.integers(3))]
-        if n % 2 == 0 and rs.random() < 0.4:                     # hidden-rates sweep: only the parity of a tip state is observed
+        if rs.random() < 0.25:                                   # round 3: the n + n^2 counting layout with observed tips, any n
+            fn, var = "sumstatMCMCbf_sweep", O.BF
+        elif n % 2 == 0 and rs.random() < 0.4:                     # hidden-rates sweep: only the parity of a tip state is observed
             fn, var = "sumstatMCMCks_sweep", O.KS
             z = dict(z, states=((z["states"] - 1) % 2 + 1).astype(np.int32), mapnames=[m.copy() for m in z["mapnames"]])
             T = len(z["states"])
@@ -49,8 +56,9 @@ def run(seed, n_cases):
         wants = [O.maketreelistMCMC(z, Q, pid, B, Omega, nen, nodelist, root, N, variant=var, seed=seed, replica=r) for r in reps]
         for mapping in ["replicas", "branches", "tiles"]:
             form = int(rs.integers(3)) if mapping == "tiles" else 0      # pruning kernel of the 5..64-state tile mapping
+            sc = int(rs.choice([0, 0, 2])) if mapping == "tiles" else 0  # band kernels where the matrix offers a band / dense kernels
             try:
-                got = getattr(api, fn)(z, Q, pid, Omega, N, seed=seed, n_replicas=S, mapping=mapping, pruning_form=form)
+                got = getattr(api, fn)(z, Q, pid, Omega, N, seed=seed, n_replicas=S, mapping=mapping, pruning_form=form, sparse_chains=sc)
                 if S == 1:
                     got = got[None]
                 err = None
@@ -62,7 +70,7 @@ def run(seed, n_cases):
                 elif err is not None:
                     ok = False
                 else:
-                    ncnt = n * n if var == O.KS else n * (n - 1)
+                    ncnt = n * n if var in (O.KS, O.BF) else n * (n - 1)
                     ok = (np.array_equal(got[r][:, n:n + ncnt], want[:, n:n + ncnt]) and np.allclose(got[r][:, :n], want[:, :n], rtol=1e-10, atol=0)
                           and np.allclose(got[r][:, n + ncnt:], want[:, n + ncnt:], rtol=1e-12, atol=0, equal_nan=True))
                 if not ok:
@@ -70,7 +78,7 @@ def run(seed, n_cases):
                     if got is not None and rc == 0:
                         d = np.argwhere(~np.isclose(got[r], want, rtol=1e-10, atol=0, equal_nan=True))
                         print("   differing (row, col):", d[:6].tolist(), "got", [got[r][tuple(x)] for x in d[:3]], "want", [want[tuple(x)] for x in d[:3]])
-                    print(f"MISMATCH case {case}: n={n} tips={tips} S={S} N={N} {fn} mapping={mapping} form={form} replica={r} oracle_rc={rc} err={err}")
+                    print(f"MISMATCH case {case}: n={n} band={band} tips={tips} S={S} N={N} {fn} mapping={mapping} form={form} sparse_chains={sc} replica={r} oracle_rc={rc} err={err}")
     return bad
 
 
