@@ -39,8 +39,9 @@ typedef enum phm_status {
   PHM_ERR_OOM = 4,            /* device memory */
   PHM_ERR_ZERO_PROB = 5,      /* all-zero / non-finite probability vector (RcppArmadillo::sample throws) */
   PHM_ERR_CAPACITY = 6,       /* a sweep outgrew its dwell capacity and could not be recovered (recovery switched off, larger slots
-                                 do not fit in HBM, or the 128-segment scratch of the state-per-lane tile kernel, mapping 1 with
-                                 n > 4); std::list in the reference is unbounded */
+                                 do not fit in HBM, or the 128-segment scratch of the state-per-lane tile kernel, PHM_MAP_REPLICAS with
+                                 n > 4); std::list in the reference is unbounded.  After a FAILED recovery the handle has no device
+                                 state left: every later call on it returns this status until it is destroyed */
   PHM_ERR_UNIF_CAP = 7,       /* newunifSample needed > 300 jumps (src/phylomap.cpp:120-125) */
   PHM_ERR_STATE = 8           /* API misuse (engine not created, iteration range, ...) */
 } phm_status;

@@ -613,6 +613,8 @@ int32_t wtiles_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
   }
 
   const int ldt = (n + 1) & ~1;
+  if ((uint64_t)e->nw_klong * n * ldt * sizeof(double) >= (1ull << 32))      // the kernels address a chain table with 32-bit byte offsets
+    return fail(PHM_ERR_UNSUPPORTED, "branch too long for the lane-per-replica mapping: a chain table would exceed 4 GB");
   const size_t stats_bytes = e->reduce ? sizeof(double) * (size_t)max_iters * tiles * e->dcols
                                        : sizeof(double) * (size_t)max_iters * e->dcols * e->S_pad;
   const size_t dw_bytes = sizeof(double) * (size_t)tiles * rows * 64;
@@ -696,6 +698,7 @@ int32_t wtiles_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
   p.klong = e->nw_klong;
   // branches per wave of the branch kernel: one while waves are scarce, up to 8 once there are 65 536 of them anyway
   p.group = (int32_t)std::max<int64_t>(1, std::min<int64_t>(8, (int64_t)tiles * E / 65536));
+  if (const char* g = std::getenv("PHM_WT_GROUP")) p.group = std::max(1, std::atoi(g));      // measurement aid
   p.n_groups = (E + p.group - 1) / p.group;
   p.up_form = o.pruning_form & 3; p.band_up = 0; p.band_draw = 0; p.B2band = e->d_wt_B2band.as<double>();
   e->sparse_req = o.sparse_chains;
@@ -1190,6 +1193,10 @@ static int32_t recover_capacity(phm_engine* e) {
   phm_engine* r = nullptr;
   const std::vector<std::pair<int32_t, std::vector<double>>> hist = sv->model_hist;      // the replay appends its own copy
   int32_t st = phm_engine_create_multi(sv->flat.data(), (int32_t)sv->flat.size(), &sv->model, &o, sv->max_iters, &r);
+  if (!st && std::getenv("PHM_TEST_RECOVERY_FAILS")) {      // test aid: a replacement that "does not fit" (tests/test_gpu_parity.py)
+    delete r; r = nullptr;
+    st = fail(PHM_ERR_OOM, "PHM_TEST_RECOVERY_FAILS is set");
+  }
   if (st) return (st == PHM_ERR_OOM) ? fail(PHM_ERR_CAPACITY, "a branch outgrew its dwell capacity and larger slots do not fit in HBM: " + g_phm_err) : st;
   r->recoveries = e->recoveries + 1;
   size_t h = 0;

@@ -767,14 +767,22 @@ __global__ __launch_bounds__(SMALL ? WT_BRANCH_BLOCK_SMALL : WT_BLOCK) void wt_b
     if (kk >= p.klong) { err |= DERR_CAPACITY; kk = p.klong - 1; }
     if (BAND > 0) {
       constexpr int W = 2 * BAND + 1;
-      const double* __restrict__ beta = p.colL + ((size_t)kk * n + cs) * ldt;
+      // The 2 BAND + 1 table entries are loaded UNCONDITIONALLY from clamped columns and issued together (one wait for all of
+      // them: as per-term `if (in range) load` the compiler emitted a branch and a full wait per term -- three serial L2 round
+      // trips per draw); a term outside the matrix has a zero band coefficient (the host's table), so its product is an exact
+      // +0 whatever was loaded.  32-bit byte offsets from a scalar base (the tables are far below 4 GB: checked on the host).
+      const uint32_t row = (uint32_t)((kk * n + cs) * ldt);
       const double* __restrict__ bb = s_B2 + sprev * W;
-      double pr[W];
+      double bt[W], bv[W];
 #pragma unroll
       for (int d = 0; d < W; ++d) {
-        const int c = sprev + d - BAND;
-        pr[d] = (c >= 0 && c < n) ? bb[d] * beta[c] : 0.0;
+        const int cc = min(max(sprev + d - BAND, 0), n - 1);
+        bt[d] = at(p.colL, (row + (uint32_t)cc) * 8u);
+        bv[d] = bb[d];
       }
+      double pr[W];
+#pragma unroll
+      for (int d = 0; d < W; ++d) pr[d] = bv[d] * bt[d];
       double total = pr[0];                                                      // 0 + .. + 0 + pr_0 = pr_0 exactly
 #pragma unroll
       for (int d = 1; d < W; ++d) total += pr[d];

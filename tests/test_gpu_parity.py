@@ -883,6 +883,28 @@ def test_capacity_overflow_is_recovered_like_an_unbounded_list(mapping):
     np.testing.assert_array_equal(ok[0][:, 4:], got[0][:5, 4:])
 
 
+def test_failed_capacity_recovery_leaves_a_dead_handle_not_freed_memory(monkeypatch):
+    """the recovery frees the engine's buffers before the replacement exists.  When the replacement cannot be built
+    (here: PHM_TEST_RECOVERY_FAILS; in the field: doubled slots that do not fit) the handle must refuse every further call
+    instead of sweeping on freed HBM."""
+    z, Q, pid, Omega = _problem(4, 40, 3)
+    Om = 6.0 * Omega
+    monkeypatch.setenv("PHM_TEST_RECOVERY_FAILS", "1")
+    eng = _lib.Engine(z, Q, pid, Om, 30, variant=_lib.PHM_MCMC_BIGTREE, seed=1, n_replicas=70, mapping="tiles", cap_tail=0.9)
+    eng.run(12)
+    with pytest.raises(_lib.PhmError) as e:
+        eng.sync()                               # overflow -> recovery -> the replacement "does not fit"
+    assert e.value.status == 6
+    for call in (lambda: eng.run(1), eng.sync, lambda: eng.stats(0, 1), lambda: eng.dump(0), lambda: eng.set_model(Q), eng.info):
+        with pytest.raises(_lib.PhmError) as e:
+            call()
+        assert e.value.status == 6 and "could not be rebuilt" in str(e.value)
+    eng.close()                                  # destroying a dead handle is fine
+    monkeypatch.delenv("PHM_TEST_RECOVERY_FAILS")
+    ok = api.sumstatMCMC_bigtree(z, Q, pid, Om, 5, seed=1, n_replicas=70, mapping="tiles", cap_tail=0.9)      # and the library is unharmed
+    assert ok.shape == (70, 5, 16)
+
+
 def test_capacity_recovery_replays_the_rate_updates():
     """sumstatMCMCbf changes Q after every sweep: a recovery has to replay the model changes at their iterations."""
     z, Q, pid, Omega = _problem(2, 30, 21)
