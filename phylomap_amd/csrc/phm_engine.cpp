@@ -1456,7 +1456,15 @@ extern "C" int32_t phm_engine_set_model(phm_engine* e, const double* Q) {
   e = live(e);
   if (!e || !Q) return fail(PHM_ERR_STATE, "engine/Q is NULL");
   if (e->dead) return dead_engine();
-  if (e->saved) e->saved->model_hist.emplace_back(e->iters_done, std::vector<double>(Q, Q + (size_t)e->n * e->n));
+  if (e->saved) {
+    // the replay of a capacity recovery needs every model the chain has run under; kept while that history stays small
+    // (256 MB of host memory: 10^4 iterations at 58 states), dropped -- and the recovery with it -- beyond
+    auto& hist = e->saved->model_hist;
+    if (!hist.empty() && hist.back().first == e->iters_done) hist.pop_back();      // two updates before the same sweep: the later one counts
+    const size_t entry = sizeof(double) * (size_t)e->n * e->n;
+    if ((hist.size() + 1) * entry > (256u << 20)) { e->saved.reset(); e->recover = false; }
+    else hist.emplace_back(e->iters_done, std::vector<double>(Q, Q + (size_t)e->n * e->n));
+  }
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipStreamSynchronize(e->last_stream));
   std::vector<double> B2, Bc, scale, qp;
