@@ -255,3 +255,10 @@ def test_shim_type_checks_against_a_mock_of_the_rcpp_surface():
     rfile = open(os.path.join(root, "shim", "R", "phylomap_tree_orders.R")).read()
     for name in ("pruningwiseedgeorder", "makenodelist", "myreorder"):
         assert re.search(rf"^{name} <- function\(x\)", rfile, re.M)
+    # the replica axis from R: the option names the shim reads are the ones the R helper file and INTEGRATION.md use
+    shim = open(src).read()
+    helper = open(os.path.join(root, "shim", "R", "phylomap_hip_options.R")).read()
+    integ = open(os.path.join(root, "INTEGRATION.md")).read()
+    for opt in ("phylomap.hip.replicas", "phylomap.hip.reduce", "phylomap.hip.device"):
+        assert f'"{opt}"' in shim and opt in helper and opt in integ
+    assert 'containsElementNamed("sites")' in shim and "z$sites <- sites" in helper
