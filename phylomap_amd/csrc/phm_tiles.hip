@@ -215,6 +215,10 @@ __global__ __launch_bounds__(TILES_BLOCK, KS ? 7 : 8) void tiles_branch_kernel(T
     uint64_t pk0 = 0, pk1 = 0;
     int w = 0;
     int cur_s = (m == 1) ? cs : ps;            // updatenodestates :469-472 (m==1: child wins)
+    // The first two and the last merged segment stay in registers (first_len, second_len, cur_len); only the ones between them
+    // pass through the slot's rows -- with at most three merged segments on a branch (the common case) pass B reads nothing back
+    // (they all went through the rows: 17.2 -> 15.9 ms with two of them in registers, profiles/r03_probe_branch_ablation.log).
+    double first_len = 0.0, second_len = 0.0;
     double cur_len = IN(0);
     double dnext = (m > 1) ? IN(1) : 0.0;
     // Four steps per Philox block of the state stream (the step index is wave-uniform: draw i - 1 is a fixed word of it).
@@ -232,7 +236,7 @@ __global__ __launch_bounds__(TILES_BLOCK, KS ? 7 : 8) void tiles_branch_kernel(T
         if (KS) s_cnt[(cur_s * NS + si) * 64 + lane] = (uint16_t)(s_cnt[(cur_s * NS + si) * 64 + lane] + 1u);               // shortenerbf :1010-1014
         if (si == cur_s) cur_len = cur_len + di;                           // shortener :54
         else {
-          IN(w) = cur_len;
+          if (w == 0) first_len = cur_len; else if (w == 1) second_len = cur_len; else IN(w) = cur_len;
           if (w < 32) pk0 |= (uint64_t)cur_s << (2 * w); else pk1 |= (uint64_t)cur_s << (2 * (w - 32));
           if (!KS) s_cnt[(cur_s * (NS - 1) + (si > cur_s ? si - 1 : si)) * 64 + lane] = (uint16_t)(s_cnt[(cur_s * (NS - 1) + (si > cur_s ? si - 1 : si)) * 64 + lane] + 1u);   // shortener :65-66
           ++w; cur_s = si; cur_len = di;
@@ -242,14 +246,13 @@ __global__ __launch_bounds__(TILES_BLOCK, KS ? 7 : 8) void tiles_branch_kernel(T
     }
     if (w < 32) pk0 |= (uint64_t)cur_s << (2 * w); else pk1 |= (uint64_t)cur_s << (2 * (w - 32));
     const int nmerged = w + 1;
-    const double len0 = (w == 0) ? cur_len : IN(0);
-    if (w > 0) IN(w) = cur_len;
+    const double len0 = (w == 0) ? cur_len : first_len;
 
     // Pass B: one new piece per step for every lane (virtual jumps :391-410, dwell sums :745-757).
     int j = 0;
     int s = (int)(pk0 & 3u);
     double len = len0;
-    double lnext = (nmerged > 1) ? ((w == 1) ? cur_len : IN(1)) : 0.0;
+    double lnext = (nmerged > 1) ? ((w == 1) ? cur_len : second_len) : 0.0;
     double tot = 0.0, scale = s_scale[s], acc = s_dw[s * 64 + lane];
     bool stuck = false, done = false;
     // Four steps per Philox block of the exponential stream: a lane draws one variate per piece until it meets a zero-length
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(TILES_BLOCK, KS ? 7 : 8) void tiles_branch_kernel(T
           if (j >= nmerged) done = true;
           else {
             len = lnext;
-            if (j + 1 < nmerged) lnext = IN(j + 1);
+            if (j + 1 < w) lnext = IN(j + 1); else lnext = cur_len;          // the last merged segment never left its register
             s = (int)(((j < 32) ? (pk0 >> (2 * j)) : (pk1 >> (2 * (j - 32)))) & 3u);
             scale = s_scale[s]; tot = 0.0; acc = s_dw[s * 64 + lane];
           }

@@ -853,6 +853,10 @@ __global__ __launch_bounds__(SMALL ? WT_BRANCH_BLOCK_SMALL : WT_BLOCK) void wt_b
     int w = 0;
     int cur_s = (m == 1) ? cs : ps;            // updatenodestates :469-472 (m==1: child wins)
     const int s_first = cur_s;                 // state of the first merged segment
+    // the first two and the last merged segment (length and state) stay in registers; only the ones between them pass through the
+    // slot's rows and the byte rows beside them: with at most three merged segments on a branch pass B reads nothing back
+    double first_len = 0.0, second_len = 0.0;
+    int second_s = 0;
     double cur_len = IN(0);
     double dnext = (m > 1) ? IN(1) : 0.0;
     for (int i0 = 1; i0 < mmax; i0 += 4) {
@@ -869,25 +873,24 @@ __global__ __launch_bounds__(SMALL ? WT_BRANCH_BLOCK_SMALL : WT_BLOCK) void wt_b
           if (KS) count(cur_s, si);
           if (si == cur_s) cur_len = cur_len + di;                           // shortener :54
           else {
-            IN(w) = cur_len;
-            MS(w) = (uint8_t)cur_s;
+            if (w == 0) first_len = cur_len;
+            else if (w == 1) { second_len = cur_len; second_s = cur_s; }
+            else { IN(w) = cur_len; MS(w) = (uint8_t)cur_s; }
             if (!KS) count(cur_s, si);
             ++w; cur_s = si; cur_len = di;
           }
         }
       }
     }
-    MS(w) = (uint8_t)cur_s;
     const int nmerged = w + 1;
-    const double len0 = (w == 0) ? cur_len : IN(0);
-    if (w > 0) IN(w) = cur_len;
+    const double len0 = (w == 0) ? cur_len : first_len;
 
     // Pass B: one new piece per step for every lane (virtual jumps :391-410).
     int j = 0;
     int s = s_first;
     double len = len0;
-    double lnext = (nmerged > 1) ? ((w == 1) ? cur_len : IN(1)) : 0.0;
-    int snext = (nmerged > 1) ? ((w == 1) ? cur_s : (int)MS(1)) : 0;
+    double lnext = (nmerged > 1) ? ((w == 1) ? cur_len : second_len) : 0.0;
+    int snext = (nmerged > 1) ? ((w == 1) ? cur_s : second_s) : 0;
     double tot = 0.0, scale = s_scale[s];
     bool stuck = false, done = false;
     for (uint32_t t0 = 0; __any(!done); t0 += 4) {
@@ -912,7 +915,7 @@ __global__ __launch_bounds__(SMALL ? WT_BRANCH_BLOCK_SMALL : WT_BLOCK) void wt_b
           if (j >= nmerged) done = true;
           else {
             len = lnext; s = snext;
-            if (j + 1 < nmerged) { lnext = IN(j + 1); snext = MS(j + 1); }
+            if (j + 1 < w) { lnext = IN(j + 1); snext = MS(j + 1); } else { lnext = cur_len; snext = cur_s; }      // the last one never left its registers
             scale = s_scale[s]; tot = 0.0;
           }
         }
