@@ -248,6 +248,8 @@ __device__ __forceinline__ void sweep_body(const McmcParams<NS>& p, int iter0, i
         uint64_t pk0 = 0, pk1 = 0;
         int w = 0;
         int cur_s = (m == 1) ? cs : ps;            // updatenodestates :469-472 (m==1: child wins)
+        // the first two and the last merged segment stay in registers; only the ones between them pass through the stream's rows
+        double first_len = 0.0, second_len = 0.0;
         double cur_len = IN(roff);
         double dnext = (m > 1) ? IN(roff + 1) : 0.0;
         // Four steps per Philox block of the state stream: the step index is wave-uniform here, so the block is computed
@@ -266,7 +268,7 @@ __device__ __forceinline__ void sweep_body(const McmcParams<NS>& p, int iter0, i
             if (KS) s_cnt[(cur_s * NS + si) * 64 + lane] += 1u;               // shortenerbf :1010-1014
             if (si == cur_s) cur_len = cur_len + di;                           // shortener :54
             else {
-              IN(roff + w) = cur_len;
+              if (w == 0) first_len = cur_len; else if (w == 1) second_len = cur_len; else IN(roff + w) = cur_len;
               if (w < 32) pk0 |= (uint64_t)cur_s << (2 * w); else pk1 |= (uint64_t)cur_s << (2 * (w - 32));
               if (!KS) {
                 int col = cur_s * (NS - 1) + (si > cur_s ? si - 1 : si);       // shortener :65-66
@@ -279,14 +281,13 @@ __device__ __forceinline__ void sweep_body(const McmcParams<NS>& p, int iter0, i
         }
         if (w < 32) pk0 |= (uint64_t)cur_s << (2 * w); else pk1 |= (uint64_t)cur_s << (2 * (w - 32));
         const int nmerged = w + 1;
-        const double len0 = (w == 0) ? cur_len : IN(roff);
-        if (w > 0) IN(roff + w) = cur_len;
+        const double len0 = (w == 0) ? cur_len : first_len;
 
         // Pass B: one new piece per step for every lane (virtual jumps :391-410, dwell sums :745-757).
         int j = 0;
         int s = (int)(pk0 & 3u);
         double len = len0;
-        double lnext = (nmerged > 1) ? ((w == 1) ? cur_len : IN(roff + 1)) : 0.0;
+        double lnext = (nmerged > 1) ? ((w == 1) ? cur_len : second_len) : 0.0;
         double tot = 0.0, scale = s_scale[s], acc = s_dw[s * 64 + lane];
         bool stuck = false, done = false;
         // Four steps per Philox block of the exponential stream.  A lane emits one piece per step and draws one variate for
@@ -315,7 +316,7 @@ __device__ __forceinline__ void sweep_body(const McmcParams<NS>& p, int iter0, i
               if (j >= nmerged) done = true;
               else {
                 len = lnext;
-                if (j + 1 < nmerged) lnext = IN(roff + j + 1);
+                if (j + 1 < w) lnext = IN(roff + j + 1); else lnext = cur_len;      // the last merged segment never left its register
                 s = (int)(((j < 32) ? (pk0 >> (2 * j)) : (pk1 >> (2 * (j - 32)))) & 3u);
                 scale = s_scale[s]; tot = 0.0; acc = s_dw[s * 64 + lane];
               }
