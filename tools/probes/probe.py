@@ -1,6 +1,6 @@
 """Throughput probe for the MCMC engine (not part of the product): python tools/probe.py S iters ipl [config] [mapping]"""
 import sys, time, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from phylomap_amd import _lib, synth
 

@@ -1,6 +1,6 @@
 """sumstatEXP throughput by sample count and mapping: python tools/probe_exp.py [cfg]"""
 import sys, time, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from phylomap_amd import _lib, api, synth
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 2

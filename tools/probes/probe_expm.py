@@ -1,6 +1,6 @@
 """expm throughput probe: python tools/probe_expm.py n n_t"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from phylomap_amd import api, synth
 n = int(sys.argv[1]); nt = int(sys.argv[2])

@@ -1,6 +1,6 @@
 """ms per sweep and per phase (pruning, node draws, branch kernel, reductions) of a (tile, item) mapping: python tools/probe_phases.py cfg S [iters [sparse_chains]]"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from phylomap_amd import _lib, synth
 cfg = int(sys.argv[1]); S = int(sys.argv[2]); N = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 sparse = int(sys.argv[4]) if len(sys.argv) > 4 else 0      # phm_options.sparse_chains: 0 auto, 1 band kernels required, 2 dense

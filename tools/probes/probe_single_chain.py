@@ -1,6 +1,6 @@
 """One chain on the C2 tree with the branch mapping: wall time per sweep (run under rocprofv3 --kernel-trace to see launches)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from phylomap_amd import _lib, synth
 z, Q, pid, Om = synth.config_problem(2)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 400

@@ -1,6 +1,6 @@
 """ms per sweep of the 5..64-state mappings at small replica counts (tunes the automatic choice): python tools/probe_small_S.py cfg"""
 import sys, time, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from phylomap_amd import _lib, synth
 cfg = int(sys.argv[1])
 z, Q, pid, Om = synth.config_problem(cfg)

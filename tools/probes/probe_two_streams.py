@@ -1,7 +1,7 @@
 """Do two half-size engines on two HIP streams overlap (tree passes of one under the branch kernel of the other)?
 python tools/probe_two_streams.py cfg S_total"""
 import sys, time, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from phylomap_amd import _lib, synth
 cfg, S = int(sys.argv[1]), int(sys.argv[2])
