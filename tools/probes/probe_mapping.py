@@ -1,5 +1,5 @@
 import sys, time, numpy as np
-sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))))
 from phylomap_amd import _lib, synth
 z,Q,pid,Om=synth.config_problem(2)
 for mapping,S in (("branches",1),("replicas",1),("branches",16),("branches",64),("tiles",64),("branches",256),("tiles",256),("replicas",256),("branches",1024),("tiles",1024),("replicas",1024),("branches",4096),("tiles",4096),("replicas",4096),("tiles",16384),("replicas",16384),("tiles",65536),("replicas",65536),("tiles",131072),("replicas",131072),("replicas",196608),("replicas",327680),("replicas",393216),("branches",32),("tiles",32)):

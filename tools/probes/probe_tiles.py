@@ -1,6 +1,6 @@
 """Per-kernel split of the wave-per-(tile, branch) mapping at one replica count (run under rocprofv3 --kernel-trace)."""
 import sys, time, numpy as np
-sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))))
 from phylomap_amd import _lib, synth
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 mapping = sys.argv[2] if len(sys.argv) > 2 else "tiles"
