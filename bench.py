@@ -363,6 +363,17 @@ def main():
             sc["speedup_vs_cpu_1core"] = sc["realisations_per_s"] / cpu[cfg]["value"]
             sc["speedup_vs_cpu_1core_faithful"] = sc["realisations_per_s"] / cpu[cfg]["faithful_value"]
         out["single_chain"] = sc
+        # the drop-in's own shape: ONE reference-shaped call (host buffers in, host matrix out) with the replica axis switched on --
+        # upload, engine set-up, N sweeps, reduction, download all inside the clock; never part of `value`
+        if not args.no_extras:
+            Nc, Sc = 500, 4096
+            t1 = time.perf_counter()
+            ss = api.sumstatMCMC_bigtree(zc, Qc, pidc, Omc, Nc, seed=1, n_replicas=Sc, reduce=True, device=local_rank)
+            wall = time.perf_counter() - t1
+            assert ss.shape == (Nc, head["n_states"] + head["n_states"] * (head["n_states"] - 1))
+            out["one_shot_call"] = {"workload": f"C{cfg}: one phm_maketreelistMCMC_bigtree call, {Sc} chains summed, N = {Nc} sweeps, host buffers in / host matrix out "
+                                                f"(upload, engine set-up, sweeps, reduction, download inside the clock)",
+                                    "wall_s": wall, "realisations_per_s_incl_setup_and_copies": head["branches"] * Sc * Nc / wall}
 
     # ---- the other BASELINE configurations, one block each (N = 1 only) -----------------------------------------------
     if rank == 0 and world == 1 and not args.no_extras:
