@@ -260,8 +260,7 @@ void fill_narrow_params(phm_engine* e, phm::NarrowParams<NS>& p, const phm_optio
   p.total_cap = e->nw_total_cap;
   for (int i = 0; i < NS * NS; ++i) { p.B2[i] = e->hB2[i]; p.Bc[i] = e->hBc[i]; }
   for (int i = 0; i < NS; ++i) { p.scale[i] = e->hscale[i]; p.pid[i] = e->hpid[i]; }
-  p.up = e->d_up.as<phm::UpStep>(); p.down = e->d_down.as<phm::DownStep>();
-  p.up_order = e->d_nw_up_order.as<int32_t>(); p.down_order = e->d_nw_down_order.as<int32_t>();
+  p.up_lv = e->d_nw_up_lv.as<phm::UpStep>(); p.down_lv = e->d_nw_down_lv.as<phm::DownStep>();
   p.up_off = e->d_nw_up_off.as<int32_t>(); p.down_off = e->d_nw_down_off.as<int32_t>();
   p.branch_order = e->d_nw_border.as<int32_t>(); p.off = e->d_nw_off.as<int64_t>();
   p.colL = e->d_nw_colL.as<double>(); p.rowL = e->d_nw_rowL.as<double>(); p.maskL = e->d_nw_maskL.as<double>();
@@ -270,6 +269,7 @@ void fill_narrow_params(phm_engine* e, phm::NarrowParams<NS>& p, const phm_optio
   p.mstate = e->d_nw_mstate.as<uint8_t>(); p.mlen = e->d_nw_mlen.as<double>(); p.estate = e->d_nw_estate.as<uint8_t>();
   p.PL = e->d_PL.as<double>(); p.nstate = e->d_nstate.as<uint8_t>(); p.part = e->d_nw_part.as<double>();
   p.rowbuf = e->d_nw_rowbuf.as<double>(); p.stats = e->d_stats.as<double>();
+  p.dmap = e->d_nw_dmap.as<uint16_t>();
   p.err = e->d_err.as<uint32_t>(); p.segcnt = e->d_seg.as<unsigned long long>();
 }
 
@@ -307,6 +307,15 @@ int32_t build_level_orders(phm_engine* e) {
   HIPCHK(e->d_nw_up_order.alloc(sizeof(int32_t) * Nn)); HIPCHK(e->d_nw_down_order.alloc(sizeof(int32_t) * E));
   HIPCHK(hipMemcpy(e->d_nw_up_order.p, up_order.data(), e->d_nw_up_order.bytes, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(e->d_nw_down_order.p, down_order.data(), e->d_nw_down_order.bytes, hipMemcpyHostToDevice));
+  {   // the steps themselves in level order (phm_narrow.hip reads them without the indirection)
+    std::vector<phm::UpStep> up_lv(Nn);
+    std::vector<phm::DownStep> down_lv(E);
+    for (int i = 0; i < Nn; ++i) up_lv[i] = s.up[up_order[i]];
+    for (int i = 0; i < E; ++i) down_lv[i] = s.down[down_order[i]];
+    HIPCHK(e->d_nw_up_lv.alloc(sizeof(phm::UpStep) * Nn)); HIPCHK(e->d_nw_down_lv.alloc(sizeof(phm::DownStep) * E));
+    HIPCHK(hipMemcpy(e->d_nw_up_lv.p, up_lv.data(), e->d_nw_up_lv.bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_nw_down_lv.p, down_lv.data(), e->d_nw_down_lv.bytes, hipMemcpyHostToDevice));
+  }
   HIPCHK(e->d_nw_up_off.alloc(sizeof(int32_t) * e->nw_up_off.size())); HIPCHK(e->d_nw_down_off.alloc(sizeof(int32_t) * e->nw_down_off.size()));
   HIPCHK(hipMemcpy(e->d_nw_up_off.p, e->nw_up_off.data(), e->d_nw_up_off.bytes, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(e->d_nw_down_off.p, e->nw_down_off.data(), e->d_nw_down_off.bytes, hipMemcpyHostToDevice));
@@ -375,6 +384,7 @@ int32_t narrow_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
   HIPCHK(e->d_nstate.alloc((size_t)S * Nn));
   HIPCHK(e->d_nw_part.alloc(sizeof(double) * (size_t)S * E * part_cols));
   HIPCHK(e->d_nw_rowbuf.alloc(sizeof(double) * (size_t)S * e->dcols));
+  if (!e->wide) HIPCHK(e->d_nw_dmap.alloc(sizeof(uint16_t) * (size_t)S * E));
   HIPCHK(e->d_stats.alloc(stats_bytes));
   HIPCHK(e->d_err.alloc(sizeof(uint32_t))); HIPCHK(e->d_seg.alloc(sizeof(unsigned long long)));
   if (e->reduce) HIPCHK(e->d_red.alloc(sizeof(double) * (size_t)max_iters * e->dcols));

@@ -37,12 +37,10 @@ struct NarrowParams {
   uint32_t seed_lo, seed_hi;
   int64_t total_cap;                         // doubles per replica in one dwell buffer
   double B2[NS * NS], Bc[NS * NS], scale[NS], pid[NS];
-  const UpStep* up;                          // [n_node]
-  const DownStep* down;                      // [n_edge]
-  const int32_t* up_order;                   // positions into up[], grouped by height level
-  const int32_t* down_order;                 // positions into down[], grouped by depth level
-  const int32_t* up_off;                     // level boundaries into up_order (device copy of the host array)
-  const int32_t* down_off;                   // level boundaries into down_order
+  const UpStep* up_lv;                       // [n_node] pruning steps grouped by height level (children strictly below their parent)
+  const DownStep* down_lv;                   // [n_edge] sampling steps grouped by depth level
+  const int32_t* up_off;                     // level boundaries into up_lv (device copy of the host array)
+  const int32_t* down_off;                   // level boundaries into down_lv
   const int32_t* branch_order;               // edge rows, largest capacity first
   const int64_t* off;                        // [n_edge + 1] CSR offsets of the branch slots
   const double* colL;                        // [klong][NS][NS]  (Bc^k e_j)[r]
@@ -56,6 +54,7 @@ struct NarrowParams {
   uint8_t* estate;                           // [replica][n_edge][2] end states (parent side, child side) of every edge
   double* PL;                                // [replica][n_node][NS]
   uint8_t* nstate;                           // [replica][n_node]
+  uint16_t* dmap;                            // [replica][n_edge] transition map of every edge (sampling sweep), level order
   double* part;                              // [replica][n_edge][NS + NS*NS + 1] per-branch dwell sums, counts, segments touched
   double* rowbuf;                            // [replica][n_cols] statistics row of the sweep
   double* stats;                             // engine layout: reduce ? [iter][tile][cols] : [iter][cols][n_rep_pad]

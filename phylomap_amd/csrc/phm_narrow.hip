@@ -3,40 +3,69 @@
 // streams addressed by (replica, iteration, node | branch), the same deterministic log.
 #include "phm_narrow.h"
 
+#include <algorithm>
+
 namespace phm {
 
 namespace {
 
-// B^k applied to a child's partial-likelihood vector (mmmmvFORpl, src/phylomap.cpp:446-450).  Tips: the chain started from a
-// one-hot row (or, ks, from a parity mask :1838-1845) is a table row; internal children: the chain itself.
+// Loads in these steps are UNCONDITIONAL (a lane that does not need a value reads a valid neighbouring address and drops it): a
+// load under a lane condition is compiled to a branch with a full s_waitcnt behind it, one serial round trip per condition.
+
+// level boundaries and other wave-uniform read-only words: through the scalar cache
+typedef const int32_t __attribute__((address_space(4))) * const_i32_ptr;
+__device__ __forceinline__ int32_t uniform_word(const int32_t* a, int i) { return ((const_i32_ptr)(uintptr_t)a)[i]; }
+
+// What a pruning step reads that no other step of the sweep writes: chain lengths of its two edges, states of its tip children.
+struct UpOps { int k[2], tip[2]; };
+
 template <int NS>
-__device__ __forceinline__ void child_vec(const NarrowParams<NS>& p, const double* __restrict__ PLr,
-                                          const uint8_t* __restrict__ tips, int child, int k, double (&v)[NS], uint32_t& err) {
-  if (child < 0) {
-    const int st = tips[~child];
-    if (k >= p.klong) { err |= DERR_CAPACITY; k = p.klong - 1; }
-    const double* src = (p.ks && p.tip_masks) ? p.maskL + ((size_t)k * 2 + (st & 1)) * NS : p.colL + ((size_t)k * NS + st) * NS;
+__device__ __forceinline__ UpOps up_operands(const NarrowParams<NS>& p, int r, const UpStep& st) {
+  const int32_t* __restrict__ mc = p.mcount + (size_t)r * p.n_edge;
+  const uint8_t* __restrict__ tips = p.tips_per_replica ? p.tips + (size_t)r * p.n_tips : p.tips;
+  UpOps o;
 #pragma unroll
-    for (int c = 0; c < NS; ++c) v[c] = src[c];
-  } else {
+  for (int c = 0; c < 2; ++c) {
+    o.k[c] = mc[st.edge[c]] - 1;
+    o.tip[c] = (int)tips[st.child[c] < 0 ? ~st.child[c] : 0];
+  }
+  return o;
+}
+
+// one internal node of one chain: PL[parent] = (B^(ma-1) PL[a]) (.) (B^(mb-1) PL[b])   (mmmmvFORpl, src/phylomap.cpp:446-450,
+// :508-510).  Tip child: the chain started from a one-hot row (or, ks, from a parity mask :1838-1845) is a table row;
+// internal child: the chain itself.  `store` = 0: computed and dropped (a lane beyond the end of its level).
+template <int NS>
+__device__ __forceinline__ void up_load(const NarrowParams<NS>& p, int r, const UpStep& st, const UpOps& o, double (&v)[2][NS],
+                                        int (&steps)[2], uint32_t& err) {
+  const double* PLr = p.PL + (size_t)r * p.n_node * NS;
 #pragma unroll
-    for (int c = 0; c < NS; ++c) v[c] = PLr[child * NS + c];
-    for (int i = 0; i < k; ++i) matvec_u<NS>(p.Bc, v);
+  for (int c = 0; c < 2; ++c) {
+    const int child = st.child[c];
+    int k = o.k[c];
+    const double* src;
+    if (child < 0) {
+      if (k >= p.klong) { err |= DERR_CAPACITY; k = p.klong - 1; }
+      src = (p.ks && p.tip_masks) ? p.maskL + ((size_t)k * 2 + (o.tip[c] & 1)) * NS : p.colL + ((size_t)k * NS + o.tip[c]) * NS;
+      steps[c] = 0;
+    } else {
+      src = PLr + (size_t)child * NS;
+      steps[c] = k;
+    }
+#pragma unroll
+    for (int q = 0; q < NS; ++q) v[c][q] = src[q];
   }
 }
 
-// one internal node of one chain: PL[parent] = (B^(ma-1) PL[a]) (.) (B^(mb-1) PL[b])
 template <int NS>
-__device__ __forceinline__ void up_node(const NarrowParams<NS>& p, int r, int idx, uint32_t& err) {
-  const UpStep st = p.up[p.up_order[idx]];
-  const int32_t* __restrict__ mc = p.mcount + (size_t)r * p.n_edge;
+__device__ __forceinline__ void up_finish(const NarrowParams<NS>& p, int r, const UpStep& st, double (&v)[2][NS], const int (&steps)[2],
+                                          bool store) {
   double* PLr = p.PL + (size_t)r * p.n_node * NS;
-  const uint8_t* __restrict__ tips = p.tips_per_replica ? p.tips + (size_t)r * p.n_tips : p.tips;
-  double x[NS], y[NS];
-  child_vec<NS>(p, PLr, tips, st.child[1], mc[st.edge[1]] - 1, x, err);        // "first"  (:508)
-  child_vec<NS>(p, PLr, tips, st.child[0], mc[st.edge[0]] - 1, y, err);        // "second" (:509)
+  for (int i = 0; i < steps[1]; ++i) matvec_u<NS>(p.Bc, v[1]);                 // "first"  (:508)
+  for (int i = 0; i < steps[0]; ++i) matvec_u<NS>(p.Bc, v[0]);                 // "second" (:509)
+  double x[NS];
 #pragma unroll
-  for (int c = 0; c < NS; ++c) x[c] = x[c] * y[c];                             // :510
+  for (int c = 0; c < NS; ++c) x[c] = v[1][c] * v[0][c];                       // :510
   if (p.normalise) {                                                           // :525
     double s = x[0];
 #pragma unroll
@@ -44,8 +73,24 @@ __device__ __forceinline__ void up_node(const NarrowParams<NS>& p, int r, int id
 #pragma unroll
     for (int c = 0; c < NS; ++c) x[c] = x[c] / s;
   }
+  if (store) {
 #pragma unroll
-  for (int c = 0; c < NS; ++c) PLr[st.parent * NS + c] = x[c];
+    for (int c = 0; c < NS; ++c) PLr[st.parent * NS + c] = x[c];
+  }
+}
+
+template <int NS>
+__device__ __forceinline__ void up_node(const NarrowParams<NS>& p, int r, const UpStep& st, const UpOps& o, bool store, uint32_t& err) {
+  double v[2][NS];
+  int steps[2];
+  up_load<NS>(p, r, st, o, v, steps, err);
+  up_finish<NS>(p, r, st, v, steps, store);
+}
+
+template <int NS>
+__device__ __forceinline__ void up_node(const NarrowParams<NS>& p, int r, int idx, uint32_t& err) {
+  const UpStep st = p.up_lv[idx];
+  up_node<NS>(p, r, st, up_operands<NS>(p, r, st), true, err);
 }
 
 template <int NS>
@@ -68,73 +113,153 @@ __device__ __forceinline__ void root_node(const NarrowParams<NS>& p, int r, int 
   p.nstate[(size_t)r * p.n_node + p.root] = (uint8_t)sample_cat<NS>(pr, u, err);   // :627
 }
 
-// child ~ e_ps^T B^(m-1) (.) PL[child]   (Tvmmp :431-436, :651); ks: tips too, against their parity mask (:1384-1397)
+// Sampling sweep: child ~ e_ps^T B^(m-1) (.) PL[child]   (Tvmmp :431-436, :651); ks: tips too, against their parity mask
+// (:1384-1397).  Everything in that draw except the parent's state ps is known once the pruning sweep is done -- PL[child], the
+// chain length, the node's uniform -- and ps has NS possible values.  So the sweep is split:
+//   narrow_downmap_kernel   every edge of every chain side by side, the whole device wide: the draw is carried out for EACH
+//                           possible parent state; the NS outcomes (2 bits each + "probabilities were all zero") are one 16-bit
+//                           word per edge, the edge's transition map;
+//   narrow_downwalk_kernel  one workgroup per chain walks the levels root to tips: state[child] = map[edge][state[parent]],
+//                           a table look-up per edge and an LDS barrier per level -- no arithmetic on the critical path.
+// The outcome for the parent state that materialises is exactly the draw of the reference's sweep: same operands, same order.
 template <int NS>
-__device__ __forceinline__ void down_edge(const NarrowParams<NS>& p, int r, int it, int idx, uint32_t& err) {
-  const DownStep ds = p.down[p.down_order[idx]];
-  const int b = ds.edge;
-  const int m = p.mcount[(size_t)r * p.n_edge + b];
-  uint8_t* __restrict__ nst = p.nstate + (size_t)r * p.n_node;
+__global__ __launch_bounds__(NARROW_BLOCK) void narrow_downmap_kernel(NarrowParams<NS> p, int it) {
+  const int idx = blockIdx.x * NARROW_BLOCK + threadIdx.x;
+  const int r = blockIdx.y;
+  if (idx >= p.n_edge) return;
+  const DownStep ds = p.down_lv[idx];
   const uint8_t* __restrict__ tips = p.tips_per_replica ? p.tips + (size_t)r * p.n_tips : p.tips;
-  const int ps = nst[ds.parent];
-  int cs;
-  if (ds.child >= 0 || (p.ks && p.tip_masks)) {
-    int kk = m - 1;
-    if (kk >= p.klong) { err |= DERR_CAPACITY; kk = p.klong - 1; }
-    const double* src = p.rowL + ((size_t)kk * NS + ps) * NS;
-    double w[NS];
-    uint32_t node_id;
-    if (ds.child >= 0) {
-      const double* __restrict__ PLc = p.PL + ((size_t)r * p.n_node + ds.child) * NS;
-#pragma unroll
-      for (int c = 0; c < NS; ++c) w[c] = src[c] * PLc[c];
-      node_id = (uint32_t)(ds.child + p.n_tips);
-    } else {
-      const int tip = ~ds.child;
-      const int par = tips[tip] & 1;
-#pragma unroll
-      for (int c = 0; c < NS; ++c) w[c] = src[c] * (((c & 1) == par) ? 1.0 : 0.0);
-      node_id = (uint32_t)tip;
-    }
-    const double u = stream_u(p.seed_lo, p.seed_hi, (uint32_t)(p.replica_offset + r), (uint32_t)it, ENT_NODE | node_id, 0);
-    cs = sample_cat<NS>(w, u, err);                                            // :655
-    if (ds.child >= 0) nst[ds.child] = (uint8_t)cs;
-  } else {
-    cs = tips[~ds.child];                                                      // :612
-  }
-  uint8_t* es = p.estate + ((size_t)r * p.n_edge + b) * 2;
-  es[0] = (uint8_t)ps; es[1] = (uint8_t)cs;                                    // updatenodestates :460-475
-}
-
-template <int NS>
-__global__ __launch_bounds__(NARROW_BLOCK) void narrow_down_kernel(NarrowParams<NS> p, int it, int begin, int end) {
-  const int idx = begin + blockIdx.x * NARROW_BLOCK + threadIdx.x;
-  if (idx >= end) return;
+  const bool internal = ds.child >= 0;
+  const int tip_state = (int)tips[internal ? 0 : ~ds.child];
+  const bool draws = internal || (p.ks && p.tip_masks);
+  int kk = p.mcount[(size_t)r * p.n_edge + ds.edge] - 1;
   uint32_t err = 0;
-  down_edge<NS>(p, blockIdx.y, it, idx, err);
+  if (kk >= p.klong) { if (draws) err |= DERR_CAPACITY; kk = p.klong - 1; }
+  const double* __restrict__ PLc = p.PL + ((size_t)r * p.n_node + (internal ? ds.child : 0)) * NS;
+  const double* __restrict__ rows = p.rowL + (size_t)(draws ? kk : 0) * NS * NS;
+  const int par = tip_state & 1;
+  double wgt[NS];
+#pragma unroll
+  for (int c = 0; c < NS; ++c) {
+    const double pl = PLc[c];
+    wgt[c] = internal ? pl : (((c & 1) == par) ? 1.0 : 0.0);
+  }
+  const uint32_t node_id = internal ? (uint32_t)(ds.child + p.n_tips) : (uint32_t)~ds.child;
+  const double u = stream_u(p.seed_lo, p.seed_hi, (uint32_t)(p.replica_offset + r), (uint32_t)it, ENT_NODE | node_id, 0);
+  uint32_t code = 0;
+#pragma unroll
+  for (int q = 0; q < NS; ++q) {
+    double w[NS];
+#pragma unroll
+    for (int c = 0; c < NS; ++c) w[c] = rows[q * NS + c] * wgt[c];
+    uint32_t e2 = 0;
+    const int drawn = sample_cat<NS>(w, u, e2);                                // :655
+    const uint32_t out = draws ? ((uint32_t)drawn | (e2 ? 4u : 0u)) : (uint32_t)tip_state;   // :612
+    code |= out << (4 * q);
+  }
+  p.dmap[(size_t)r * p.n_edge + idx] = (uint16_t)code;
   if (err) atomicOr(p.err, err);
 }
 
-// The levels near the root hold a handful of nodes each; one workgroup per chain walks them in a single launch -- the top
-// of the pruning sweep, the root draw, the first levels of the sampling sweep -- with a WORKGROUP-scope fence and a barrier
-// between levels: producer and consumer are waves of one workgroup on one CU, and a device-scope fence would write back and
-// invalidate the XCD's L2 at every level (the kernel boundary publishes the results to the other kernels).
-constexpr int NARROW_MID_BLOCK = 256;
-template <int NS>
-__global__ __launch_bounds__(NARROW_MID_BLOCK) void narrow_mid_kernel(NarrowParams<NS> p, int it, int up_first, int up_levels,
-                                                                      int down_levels) {
+constexpr int NARROW_WALK_BLOCK = 1024;
+constexpr int NARROW_LDS_NODES = 60 * 1024;        // node states of one chain kept in LDS during the walk (1 byte each)
+
+// LDS-only release / barrier / acquire: the waves wait for their LDS traffic, not for the global stores in flight
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// Root draw, then the walk.  The node states of the chain live in LDS (LDSN; trees of up to NARROW_LDS_NODES internal nodes,
+// otherwise in the global array behind workgroup-scope fences); the global copies (node states, end states of every edge:
+// updatenodestates :460-475) are written behind, nobody in this kernel waits for them.  The records of level l + 1 are
+// requested while level l is looked up.
+template <int NS, bool LDSN>
+__global__ __launch_bounds__(NARROW_WALK_BLOCK) void narrow_downwalk_kernel(NarrowParams<NS> p, int it, int n_levels) {
+  extern __shared__ uint8_t s_nst[];
   const int r = blockIdx.x;
+  const int tid = threadIdx.x;
   uint32_t err = 0;
-  for (int l = up_first; l < up_levels; ++l) {
-    for (int idx = p.up_off[l] + threadIdx.x; idx < p.up_off[l + 1]; idx += NARROW_MID_BLOCK) up_node<NS>(p, r, idx, err);
-    __threadfence_block();
-    __syncthreads();
+  uint8_t* __restrict__ nst = p.nstate + (size_t)r * p.n_node;
+  uint8_t* __restrict__ est = p.estate + (size_t)r * p.n_edge * 2;
+  const uint16_t* __restrict__ dmap = p.dmap + (size_t)r * p.n_edge;
+  // first records before the root draw: they do not depend on it
+  int lo = uniform_word(p.down_off, 0), hi = uniform_word(p.down_off, 1);
+  int at = min(lo + tid, p.n_edge - 1);
+  DownStep ds = p.down_lv[at];
+  uint32_t code = dmap[at];
+  if (tid == 0) {
+    root_node<NS>(p, r, it, err);
+    if (LDSN) s_nst[p.root] = nst[p.root];
   }
-  if (threadIdx.x == 0) root_node<NS>(p, r, it, err);
-  __threadfence_block();
-  __syncthreads();
-  for (int l = 0; l < down_levels; ++l) {
-    for (int idx = p.down_off[l] + threadIdx.x; idx < p.down_off[l + 1]; idx += NARROW_MID_BLOCK) down_edge<NS>(p, r, it, idx, err);
+  if (LDSN) lds_barrier();
+  else { __threadfence_block(); __syncthreads(); }
+  for (int l = 0; l < n_levels; ++l) {
+    const int lo_n = hi, hi_n = (l + 1 < n_levels) ? uniform_word(p.down_off, l + 2) : hi;
+    const int at_n = min(lo_n + tid, p.n_edge - 1);
+    const DownStep ds_n = p.down_lv[at_n];
+    const uint32_t code_n = dmap[at_n];
+    for (int idx = lo + tid; idx < hi; idx += NARROW_WALK_BLOCK) {
+      if (idx != lo + tid) { ds = p.down_lv[idx]; code = dmap[idx]; }
+      const int ps = LDSN ? s_nst[ds.parent] : nst[ds.parent];
+      const uint32_t out = code >> (4 * ps);
+      const int cs = (int)(out & 3u);
+      if (out & 4u) err |= DERR_ZERO_PROB;
+      if (ds.child >= 0) {
+        if (LDSN) s_nst[ds.child] = (uint8_t)cs;
+        nst[ds.child] = (uint8_t)cs;
+      }
+      est[ds.edge * 2] = (uint8_t)ps; est[ds.edge * 2 + 1] = (uint8_t)cs;
+    }
+    if (LDSN) lds_barrier();
+    else { __threadfence_block(); __syncthreads(); }
+    lo = lo_n; hi = hi_n; ds = ds_n; code = code_n;
+  }
+  if (err) atomicOr(p.err, err);
+}
+
+// Narrow pruning levels: one workgroup per chain walks a RUN of consecutive levels in a single launch, with a WORKGROUP-scope
+// fence and a barrier between levels: producer and consumer are waves of one workgroup on one CU, and a device-scope fence
+// would write back and invalidate the XCD's L2 at every level (the kernel boundary publishes the results to the other
+// kernels).  A level costs a launch (5-8 us on an otherwise empty device) when it is launched by itself and 2-3 us inside this
+// kernel, so every level of up to NARROW_FUSE_WIDTH items goes here; only wider levels get their own grid.
+// The kernel is software-pipelined over the levels: while level l is computed, the operands of level l + 1 that no step of the
+// sweep writes (chain lengths, tip data) are on their way, and the step records of level l + 2 behind them.  Loads are
+// unconditional; a wavefront takes part in a level only if one of the levels in its pipeline has an item for it (near the root
+// one wavefront works and the others wait at the barrier); the stage registers of a wavefront that sat out are stale but valid
+// addresses, and whether a lane HAS an item is recomputed from the level boundaries every time, never carried.
+constexpr int NARROW_MID_BLOCK = 1024;
+constexpr int NARROW_FUSE_WIDTH = NARROW_MID_BLOCK;
+template <int NS>
+__global__ __launch_bounds__(NARROW_MID_BLOCK) void narrow_mid_kernel(NarrowParams<NS> p, int up_lo, int up_hi) {
+  const int r = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int wave_base = tid & ~63;
+  uint32_t err = 0;
+  auto lo_of = [&](int l) { return uniform_word(p.up_off, min(l, up_hi - 1)); };
+  auto hi_of = [&](int l) { return l < up_hi ? uniform_word(p.up_off, l + 1) : lo_of(l); };      // empty beyond the run
+  auto fetch = [&](int l, UpStep& st) {
+    const int lo = lo_of(l), hi = hi_of(l);
+    st = p.up_lv[max(min(lo + tid, hi - 1), 0)];
+  };
+  UpStep stA, stB;
+  fetch(up_lo, stA); fetch(up_lo + 1, stB);
+  UpOps opA = up_operands<NS>(p, r, stA);
+  for (int l = up_lo; l < up_hi; ++l) {
+    const int w0 = hi_of(l) - lo_of(l), w1 = hi_of(l + 1) - lo_of(l + 1), w2 = hi_of(l + 2) - lo_of(l + 2);
+    if (wave_base < max(w0, max(w1, w2))) {
+      double v[2][NS];                               // the loads this level waits for go out first, the look-ahead behind them
+      int steps[2];
+      up_load<NS>(p, r, stA, opA, v, steps, err);
+      UpStep stC;
+      fetch(l + 2, stC);
+      const UpOps opB = up_operands<NS>(p, r, stB);
+      up_finish<NS>(p, r, stA, v, steps, tid < w0);
+      const int hi = hi_of(l);
+      for (int idx = lo_of(l) + tid + NARROW_MID_BLOCK; idx < hi; idx += NARROW_MID_BLOCK) up_node<NS>(p, r, idx, err);
+      stA = stB; opA = opB; stB = stC;
+    }
     __threadfence_block();
     __syncthreads();
   }
@@ -142,22 +267,14 @@ __global__ __launch_bounds__(NARROW_MID_BLOCK) void narrow_mid_kernel(NarrowPara
 }
 
 // One branch of one chain: resamplebranchstates :264-308, shortener :44-73 (shortenerbf :997-1030), virtual jumps
-// sampleabranch :391-410, dwell sums updatedwelltimes :745-757.
+// sampleabranch :391-410, dwell sums updatedwelltimes :745-757.  The lane's dwell sums and transition counts collect in its own
+// LDS columns (s_dw, s_cnt); returns the segments read + written.
 template <int NS>
-__global__ __launch_bounds__(NARROW_BLOCK) void narrow_branch_kernel(NarrowParams<NS> p, int it) {
-  __shared__ double s_dw[NS * NARROW_BLOCK];
-  __shared__ uint32_t s_cnt[NS * NS * NARROW_BLOCK];
-  __shared__ __align__(16) double s_ltab[2 * PHM_LOGTAB_N];        // (1/c_j, log c_j) of the exponential variates (neglog_u32)
-  const int lane = threadIdx.x;
-  const int idx = blockIdx.x * NARROW_BLOCK + lane;
-  const int r = blockIdx.y;
-  for (int i = lane; i < 2 * PHM_LOGTAB_N; i += NARROW_BLOCK) s_ltab[i] = logtab_entry(i);
-  __syncthreads();
-  if (idx >= p.n_edge) return;
+__device__ __forceinline__ int narrow_branch_lane(const NarrowParams<NS>& p, int it, int idx, int r, int lane, double* s_dw,
+                                                  uint32_t* s_cnt, const double* s_ltab, uint32_t& err) {
   const int b = p.branch_order[idx];
   const uint32_t rep = (uint32_t)(p.replica_offset + r);
   const bool KS = p.ks != 0;
-  const int ncnt = KS ? NS * NS : NS * (NS - 1);
   int32_t* __restrict__ mc = p.mcount + (size_t)r * p.n_edge;
   const int m = mc[b];
   const uint8_t* es = p.estate + ((size_t)r * p.n_edge + b) * 2;
@@ -168,11 +285,6 @@ __global__ __launch_bounds__(NARROW_BLOCK) void narrow_branch_kernel(NarrowParam
   double* __restrict__ out = p.dw[(it & 1) ^ 1] + (size_t)r * p.total_cap + o;
   double* __restrict__ ml = p.mlen + (size_t)r * p.total_cap + o;
   uint8_t* __restrict__ ms = p.mstate + (size_t)r * p.total_cap + o;
-  uint32_t err = 0;
-#pragma unroll
-  for (int c = 0; c < NS; ++c) s_dw[c * NARROW_BLOCK + lane] = 0.0;
-  for (int c = 0; c < NS * NS; ++c) s_cnt[c * NARROW_BLOCK + lane] = 0u;
-
   Stream su, se;
   su.open(ENT_BSTATE | (uint32_t)b, (uint32_t)it, rep, p.seed_lo, p.seed_hi);
   se.open(ENT_BEXP | (uint32_t)b, (uint32_t)it, rep, p.seed_lo, p.seed_hi);
@@ -254,28 +366,69 @@ __global__ __launch_bounds__(NARROW_BLOCK) void narrow_branch_kernel(NarrowParam
   if (mnew > cap) mnew = cap;
   mc[b] = mnew;
 
-  double* part = p.part + ((size_t)r * p.n_edge + b) * (NS + NS * NS + 1);
-#pragma unroll
-  for (int c = 0; c < NS; ++c) part[c] = s_dw[c * NARROW_BLOCK + lane];
-  for (int c = 0; c < ncnt; ++c) part[NS + c] = (double)s_cnt[c * NARROW_BLOCK + lane];
-  part[NS + NS * NS] = (double)(m + mnew);           // segments read + written (one global counter would serialise every lane)
-  if (err) atomicOr(p.err, err);
+  return m + mnew;
 }
 
-// Statistics row of one chain: every column is the sum of the per-branch values, added in a fixed order (thread t takes
-// branches t, t+256, ... in edge order, then a fixed tree over the 256 partial sums) -> identical from run to run.
-// One workgroup per (chain, column): the columns of a row are reduced side by side (blockIdx.y), not one after the other.
+// One wavefront per workgroup, one branch per lane.  The per-lane sums are added over the wavefront in a fixed shuffle tree and
+// ONE row per wavefront goes to `part` (n + n^2 + 1 values: dwell sums, counts, segments touched): the statistics kernel adds
+// E / 64 rows per chain, not E.
 template <int NS>
-__global__ __launch_bounds__(256) void narrow_stats_kernel(NarrowParams<NS> p) {
+__global__ __launch_bounds__(NARROW_BLOCK) void narrow_branch_kernel(NarrowParams<NS> p, int it) {
+  static_assert(NARROW_BLOCK == 64, "the reduction below is one wavefront wide");
+  __shared__ double s_dw[NS * NARROW_BLOCK];
+  __shared__ uint32_t s_cnt[NS * NS * NARROW_BLOCK];
+  __shared__ __align__(16) double s_ltab[2 * PHM_LOGTAB_N];        // (1/c_j, log c_j) of the exponential variates (neglog_u32)
+  const int lane = threadIdx.x;
+  const int idx = blockIdx.x * NARROW_BLOCK + lane;
+  const int r = blockIdx.y;
+  for (int i = lane; i < 2 * PHM_LOGTAB_N; i += NARROW_BLOCK) s_ltab[i] = logtab_entry(i);
+#pragma unroll
+  for (int c = 0; c < NS; ++c) s_dw[c * NARROW_BLOCK + lane] = 0.0;
+  for (int c = 0; c < NS * NS; ++c) s_cnt[c * NARROW_BLOCK + lane] = 0u;
+  __syncthreads();
+  uint32_t err = 0;
+  int segs = 0;
+  if (idx < p.n_edge) segs = narrow_branch_lane<NS>(p, it, idx, r, lane, s_dw, s_cnt, s_ltab, err);
+  if (err) atomicOr(p.err, err);
+
+  const int ncnt = p.ks ? NS * NS : NS * (NS - 1);
+  constexpr int PC = NS + NS * NS + 1;
+  double* part = p.part + ((size_t)r * gridDim.x + blockIdx.x) * PC;
+#pragma unroll
+  for (int c = 0; c < NS; ++c) {
+    double v = s_dw[c * NARROW_BLOCK + lane];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = v + __shfl_xor(v, d);
+    if (lane == 0) part[c] = v;
+  }
+  for (int c = 0; c < ncnt; ++c) {
+    uint32_t v = s_cnt[c * NARROW_BLOCK + lane];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    if (lane == 0) part[NS + c] = (double)v;
+  }
+  {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) segs += __shfl_xor(segs, d);
+    if (lane == 0) part[PC - 1] = (double)segs;      // segments read + written (one global counter would serialise every lane)
+  }
+}
+
+// Statistics row of one chain: every column is the sum of the per-wavefront rows of the branch kernel, added in a fixed order
+// (thread t takes rows t, t+256, ... then a fixed tree over the 256 partial sums) -> identical from run to run.
+// One workgroup per (chain, column): the columns of a row are reduced side by side (blockIdx.y), not one after the other.
+// Without the reduction over replicas the value goes straight into the engine's statistics layout ([iter][cols][n_rep_pad]).
+template <int NS>
+__global__ __launch_bounds__(256) void narrow_stats_kernel(NarrowParams<NS> p, int it, int n_rows) {
   __shared__ double red[256];
   const int r = blockIdx.x;
   const int c = blockIdx.y;                          // 0 .. NS + ncnt; the last one adds the segment counts (column pc - 1)
   const int ncnt = p.ks ? NS * NS : NS * (NS - 1);
   const int pc = NS + NS * NS + 1;
-  const double* part = p.part + (size_t)r * p.n_edge * pc;
+  const double* part = p.part + (size_t)r * n_rows * pc;
   const int src_c = (c == NS + ncnt) ? pc - 1 : c;
   double s = 0.0;
-  for (int e = threadIdx.x; e < p.n_edge; e += 256) s += part[(size_t)e * pc + src_c];
+  for (int e = threadIdx.x; e < n_rows; e += 256) s += part[(size_t)e * pc + src_c];
   red[threadIdx.x] = s;
   __syncthreads();
   for (int half = 128; half >= 1; half >>= 1) {
@@ -283,28 +436,29 @@ __global__ __launch_bounds__(256) void narrow_stats_kernel(NarrowParams<NS> p) {
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    if (c < NS + ncnt) p.rowbuf[(size_t)r * p.n_cols + c] = red[0];
-    else atomicAdd(p.segcnt, (unsigned long long)red[0]);
-    if (p.ks && c == 0)                                                        // root state, 0-based (:1350-1352)
-      p.rowbuf[(size_t)r * p.n_cols + NS + ncnt] = (double)p.nstate[(size_t)r * p.n_node + p.root];
+    if (c < NS + ncnt) {
+      if (p.reduce) p.rowbuf[(size_t)r * p.n_cols + c] = red[0];
+      else p.stats[((size_t)it * p.n_cols + c) * p.n_rep_pad + r] = red[0];
+    } else {
+      atomicAdd(p.segcnt, (unsigned long long)red[0]);
+    }
+    if (p.ks && c == 0) {                                                      // root state, 0-based (:1350-1352)
+      const double rs = (double)p.nstate[(size_t)r * p.n_node + p.root];
+      if (p.reduce) p.rowbuf[(size_t)r * p.n_cols + NS + ncnt] = rs;
+      else p.stats[((size_t)it * p.n_cols + NS + ncnt) * p.n_rep_pad + r] = rs;
+    }
   }
 }
 
-// rows -> the engine's statistics layout (per replica, or summed over each 64-replica tile in replica order)
+// rows of the chains of one 64-replica tile summed in replica order -> the engine's reduced statistics layout
 template <int NS>
 __global__ void narrow_emit_kernel(NarrowParams<NS> p, int it) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (!p.reduce) {
-    if (gid >= p.n_rep * p.n_cols) return;
-    const int r = gid / p.n_cols, c = gid % p.n_cols;
-    p.stats[((size_t)it * p.n_cols + c) * p.n_rep_pad + r] = p.rowbuf[(size_t)r * p.n_cols + c];
-  } else {
-    if (gid >= p.n_tiles * p.n_cols) return;
-    const int tile = gid / p.n_cols, c = gid % p.n_cols;
-    double s = 0.0;
-    for (int r = tile * 64; r < tile * 64 + 64 && r < p.n_rep; ++r) s += p.rowbuf[(size_t)r * p.n_cols + c];
-    p.stats[((size_t)it * p.n_tiles + tile) * p.n_cols + c] = s;
-  }
+  if (gid >= p.n_tiles * p.n_cols) return;
+  const int tile = gid / p.n_cols, c = gid % p.n_cols;
+  double s = 0.0;
+  for (int r = tile * 64; r < tile * 64 + 64 && r < p.n_rep; ++r) s += p.rowbuf[(size_t)r * p.n_cols + c];
+  p.stats[((size_t)it * p.n_tiles + tile) * p.n_cols + c] = s;
 }
 
 }  // namespace
@@ -313,29 +467,38 @@ template <int NS>
 hipError_t launch_narrow_sweep(const NarrowParams<NS>& p, const std::vector<int32_t>& up_off,
                                const std::vector<int32_t>& down_off, int it, hipStream_t stream) {
   const unsigned S = (unsigned)p.n_rep;
-  // big levels: one launch each; the small levels around the root: one launch for all of them
+  // pruning levels, tips side first: runs of consecutive narrow levels share one launch of narrow_mid_kernel, a wide level
+  // gets its own grid; then the sampling sweep: transition maps of all edges, root draw + walk
   const int UL = (int)up_off.size() - 1, DL = (int)down_off.size() - 1;
-  int up_first = UL, down_levels = 0;
-  while (up_first > 0 && up_off[up_first] - up_off[up_first - 1] <= NARROW_MID_BLOCK) --up_first;
-  while (down_levels < DL && down_off[down_levels + 1] - down_off[down_levels] <= NARROW_MID_BLOCK) ++down_levels;
-  for (int l = 0; l < up_first; ++l) {
-    const int n = up_off[l + 1] - up_off[l];
-    if (n <= 0) continue;
+  auto width = [&](int t) { return up_off[t + 1] - up_off[t]; };
+  for (int t = 0; t < UL;) {
+    if (width(t) <= NARROW_FUSE_WIDTH) {
+      int t1 = t;
+      while (t1 < UL && width(t1) <= NARROW_FUSE_WIDTH) ++t1;
+      hipLaunchKernelGGL(narrow_mid_kernel<NS>, dim3(S), dim3(NARROW_MID_BLOCK), 0, stream, p, t, t1);
+      t = t1;
+      continue;
+    }
+    const int n = width(t);
     hipLaunchKernelGGL(narrow_up_kernel<NS>, dim3((n + NARROW_BLOCK - 1) / NARROW_BLOCK, S), dim3(NARROW_BLOCK), 0, stream, p,
-                       up_off[l], up_off[l + 1]);
+                       up_off[t], up_off[t + 1]);
+    ++t;
   }
-  hipLaunchKernelGGL(narrow_mid_kernel<NS>, dim3(S), dim3(NARROW_MID_BLOCK), 0, stream, p, it, up_first, UL, down_levels);
-  for (int l = down_levels; l < DL; ++l) {
-    const int n = down_off[l + 1] - down_off[l];
-    if (n <= 0) continue;
-    hipLaunchKernelGGL(narrow_down_kernel<NS>, dim3((n + NARROW_BLOCK - 1) / NARROW_BLOCK, S), dim3(NARROW_BLOCK), 0, stream, p,
-                       it, down_off[l], down_off[l + 1]);
+  hipLaunchKernelGGL(narrow_downmap_kernel<NS>, dim3((p.n_edge + NARROW_BLOCK - 1) / NARROW_BLOCK, S), dim3(NARROW_BLOCK), 0, stream,
+                     p, it);
+  if (p.n_node <= NARROW_LDS_NODES)
+    hipLaunchKernelGGL((narrow_downwalk_kernel<NS, true>), dim3(S), dim3(NARROW_WALK_BLOCK), (size_t)((p.n_node + 15) & ~15), stream, p,
+                       it, DL);
+  else
+    hipLaunchKernelGGL((narrow_downwalk_kernel<NS, false>), dim3(S), dim3(NARROW_WALK_BLOCK), 0, stream, p, it, DL);
+  const unsigned n_waves = (unsigned)((p.n_edge + NARROW_BLOCK - 1) / NARROW_BLOCK);
+  hipLaunchKernelGGL(narrow_branch_kernel<NS>, dim3(n_waves, S), dim3(NARROW_BLOCK), 0, stream, p, it);
+  hipLaunchKernelGGL(narrow_stats_kernel<NS>, dim3(S, NS + (p.ks ? NS * NS : NS * (NS - 1)) + 1), dim3(256), 0, stream, p, it,
+                     (int)n_waves);
+  if (p.reduce) {
+    const int items = p.n_tiles * p.n_cols;
+    hipLaunchKernelGGL(narrow_emit_kernel<NS>, dim3((items + 255) / 256), dim3(256), 0, stream, p, it);
   }
-  hipLaunchKernelGGL(narrow_branch_kernel<NS>, dim3((p.n_edge + NARROW_BLOCK - 1) / NARROW_BLOCK, S), dim3(NARROW_BLOCK), 0,
-                     stream, p, it);
-  hipLaunchKernelGGL(narrow_stats_kernel<NS>, dim3(S, NS + (p.ks ? NS * NS : NS * (NS - 1)) + 1), dim3(256), 0, stream, p);
-  const int items = (p.reduce ? p.n_tiles : p.n_rep) * p.n_cols;
-  hipLaunchKernelGGL(narrow_emit_kernel<NS>, dim3((items + 255) / 256), dim3(256), 0, stream, p, it);
   return hipGetLastError();
 }
 
