@@ -260,8 +260,9 @@ void fill_narrow_params(phm_engine* e, phm::NarrowParams<NS>& p, const phm_optio
   p.total_cap = e->nw_total_cap;
   for (int i = 0; i < NS * NS; ++i) { p.B2[i] = e->hB2[i]; p.Bc[i] = e->hBc[i]; }
   for (int i = 0; i < NS; ++i) { p.scale[i] = e->hscale[i]; p.pid[i] = e->hpid[i]; }
-  p.up_lv = e->d_nw_up_lv.as<phm::UpStep>(); p.down_lv = e->d_nw_down_lv.as<phm::DownStep>();
-  p.up_off = e->d_nw_up_off.as<int32_t>(); p.down_off = e->d_nw_down_off.as<int32_t>();
+  p.cl_nodes = e->d_nw_cl_nodes.as<phm::ClusterNode>(); p.cl_item_off = e->d_nw_cl_item_off.as<int32_t>();
+  p.cl_lvl_ptr = e->d_nw_cl_lvl_ptr.as<int32_t>(); p.cl_lvl_off = e->d_nw_cl_lvl_off.as<int32_t>();
+  p.down_lv = e->d_nw_down_lv.as<phm::DownStep>(); p.down_off = e->d_nw_down_off.as<int32_t>();
   p.branch_order = e->d_nw_border.as<int32_t>(); p.off = e->d_nw_off.as<int64_t>();
   p.colL = e->d_nw_colL.as<double>(); p.rowL = e->d_nw_rowL.as<double>(); p.maskL = e->d_nw_maskL.as<double>();
   p.tips = e->d_tips.as<uint8_t>();
@@ -307,13 +308,10 @@ int32_t build_level_orders(phm_engine* e) {
   HIPCHK(e->d_nw_up_order.alloc(sizeof(int32_t) * Nn)); HIPCHK(e->d_nw_down_order.alloc(sizeof(int32_t) * E));
   HIPCHK(hipMemcpy(e->d_nw_up_order.p, up_order.data(), e->d_nw_up_order.bytes, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(e->d_nw_down_order.p, down_order.data(), e->d_nw_down_order.bytes, hipMemcpyHostToDevice));
-  {   // the steps themselves in level order (phm_narrow.hip reads them without the indirection)
-    std::vector<phm::UpStep> up_lv(Nn);
+  {   // the sampling steps themselves in level order (phm_narrow.hip reads them without the indirection)
     std::vector<phm::DownStep> down_lv(E);
-    for (int i = 0; i < Nn; ++i) up_lv[i] = s.up[up_order[i]];
     for (int i = 0; i < E; ++i) down_lv[i] = s.down[down_order[i]];
-    HIPCHK(e->d_nw_up_lv.alloc(sizeof(phm::UpStep) * Nn)); HIPCHK(e->d_nw_down_lv.alloc(sizeof(phm::DownStep) * E));
-    HIPCHK(hipMemcpy(e->d_nw_up_lv.p, up_lv.data(), e->d_nw_up_lv.bytes, hipMemcpyHostToDevice));
+    HIPCHK(e->d_nw_down_lv.alloc(sizeof(phm::DownStep) * E));
     HIPCHK(hipMemcpy(e->d_nw_down_lv.p, down_lv.data(), e->d_nw_down_lv.bytes, hipMemcpyHostToDevice));
   }
   HIPCHK(e->d_nw_up_off.alloc(sizeof(int32_t) * e->nw_up_off.size())); HIPCHK(e->d_nw_down_off.alloc(sizeof(int32_t) * e->nw_down_off.size()));
@@ -384,7 +382,20 @@ int32_t narrow_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
   HIPCHK(e->d_nstate.alloc((size_t)S * Nn));
   HIPCHK(e->d_nw_part.alloc(sizeof(double) * (size_t)S * E * part_cols));
   HIPCHK(e->d_nw_rowbuf.alloc(sizeof(double) * (size_t)S * e->dcols));
-  if (!e->wide) HIPCHK(e->d_nw_dmap.alloc(sizeof(uint16_t) * (size_t)S * E));
+  if (!e->wide) {
+    HIPCHK(e->d_nw_dmap.alloc(sizeof(uint16_t) * (size_t)S * E));
+    phm::ClusterPlan plan;                           // pruning sweep of phm_narrow.hip: subtrees in tiers
+    phm::build_cluster_plan(s, phm::NARROW_CLUSTER_NODES, plan);
+    e->nw_tier_off = plan.tier_off;
+    HIPCHK(e->d_nw_cl_nodes.alloc(sizeof(phm::ClusterNode) * plan.nodes.size()));
+    HIPCHK(e->d_nw_cl_item_off.alloc(sizeof(int32_t) * plan.item_off.size()));
+    HIPCHK(e->d_nw_cl_lvl_ptr.alloc(sizeof(int32_t) * plan.lvl_ptr.size()));
+    HIPCHK(e->d_nw_cl_lvl_off.alloc(sizeof(int32_t) * plan.lvl_off.size()));
+    HIPCHK(hipMemcpy(e->d_nw_cl_nodes.p, plan.nodes.data(), e->d_nw_cl_nodes.bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_nw_cl_item_off.p, plan.item_off.data(), e->d_nw_cl_item_off.bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_nw_cl_lvl_ptr.p, plan.lvl_ptr.data(), e->d_nw_cl_lvl_ptr.bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_nw_cl_lvl_off.p, plan.lvl_off.data(), e->d_nw_cl_lvl_off.bytes, hipMemcpyHostToDevice));
+  }
   HIPCHK(e->d_stats.alloc(stats_bytes));
   HIPCHK(e->d_err.alloc(sizeof(uint32_t))); HIPCHK(e->d_seg.alloc(sizeof(unsigned long long)));
   if (e->reduce) HIPCHK(e->d_red.alloc(sizeof(double) * (size_t)max_iters * e->dcols));
@@ -1137,9 +1148,9 @@ int32_t phm_engine_run(phm_engine* e, int32_t n_iters, void* hip_stream) {
     hipError_t le = hipSuccess;
     for (int i = 0; i < n_iters && le == hipSuccess; ++i) {
       const int it = e->iters_done + i;
-      if (e->n == 2) le = phm::launch_narrow_sweep<2>(e->n2, e->nw_up_off, e->nw_down_off, it, stream);
-      if (e->n == 3) le = phm::launch_narrow_sweep<3>(e->n3, e->nw_up_off, e->nw_down_off, it, stream);
-      if (e->n == 4) le = phm::launch_narrow_sweep<4>(e->n4, e->nw_up_off, e->nw_down_off, it, stream);
+      if (e->n == 2) le = phm::launch_narrow_sweep<2>(e->n2, e->nw_tier_off, e->nw_down_off, it, stream);
+      if (e->n == 3) le = phm::launch_narrow_sweep<3>(e->n3, e->nw_tier_off, e->nw_down_off, it, stream);
+      if (e->n == 4) le = phm::launch_narrow_sweep<4>(e->n4, e->nw_tier_off, e->nw_down_off, it, stream);
       if (e->wide) le = phm::launch_wbranch_sweep(e->pwb, e->nw_up_off, e->nw_down_off, it, stream);
       launches += (int)(e->nw_up_off.size() + e->nw_down_off.size()) + 2;
     }

@@ -26,6 +26,8 @@
 
 namespace phm {
 
+constexpr int NARROW_CLUSTER_NODES = 256;   // internal nodes per pruning cluster (their vectors: 8 KB of LDS at 4 states)
+constexpr int NARROW_CLUSTER_BLOCK = 512;   // eight lanes per node, 64 nodes per pass
 constexpr int NARROW_BLOCK = 64;      // one wavefront per workgroup: latency-bound work spread over as many CUs as possible
 
 template <int NS>
@@ -37,9 +39,11 @@ struct NarrowParams {
   uint32_t seed_lo, seed_hi;
   int64_t total_cap;                         // doubles per replica in one dwell buffer
   double B2[NS * NS], Bc[NS * NS], scale[NS], pid[NS];
-  const UpStep* up_lv;                       // [n_node] pruning steps grouped by height level (children strictly below their parent)
+  const ClusterNode* cl_nodes;               // pruning sweep: clusters of <= NARROW_CLUSTER_NODES nodes, tier by tier (phm_sched.h)
+  const int32_t* cl_item_off;                // [n_clusters + 1] into cl_nodes
+  const int32_t* cl_lvl_ptr;                 // [n_clusters + 1] into cl_lvl_off
+  const int32_t* cl_lvl_off;                 // per cluster: boundaries of its height levels (positions in cl_nodes)
   const DownStep* down_lv;                   // [n_edge] sampling steps grouped by depth level
-  const int32_t* up_off;                     // level boundaries into up_lv (device copy of the host array)
   const int32_t* down_off;                   // level boundaries into down_lv
   const int32_t* branch_order;               // edge rows, largest capacity first
   const int64_t* off;                        // [n_edge + 1] CSR offsets of the branch slots
@@ -62,9 +66,9 @@ struct NarrowParams {
   unsigned long long* segcnt;
 };
 
-// one full sweep (iteration index `it`) enqueued on `stream`; level boundaries are host arrays (L+1 entries each)
+// one full sweep (iteration index `it`) enqueued on `stream`; tier boundaries (clusters) and depth-level boundaries are host arrays
 template <int NS>
-hipError_t launch_narrow_sweep(const NarrowParams<NS>& p, const std::vector<int32_t>& up_off,
+hipError_t launch_narrow_sweep(const NarrowParams<NS>& p, const std::vector<int32_t>& tier_off,
                                const std::vector<int32_t>& down_off, int it, hipStream_t stream);
 
 }  // namespace phm

@@ -9,96 +9,115 @@ namespace phm {
 
 namespace {
 
-// Loads in these steps are UNCONDITIONAL (a lane that does not need a value reads a valid neighbouring address and drops it): a
-// load under a lane condition is compiled to a branch with a full s_waitcnt behind it, one serial round trip per condition.
-
 // level boundaries and other wave-uniform read-only words: through the scalar cache
 typedef const int32_t __attribute__((address_space(4))) * const_i32_ptr;
 __device__ __forceinline__ int32_t uniform_word(const int32_t* a, int i) { return ((const_i32_ptr)(uintptr_t)a)[i]; }
 
-// What a pruning step reads that no other step of the sweep writes: chain lengths of its two edges, states of its tip children.
-struct UpOps { int k[2], tip[2]; };
+// LDS-only release / barrier / acquire: the waves wait for their LDS traffic, not for the global stores in flight
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 
+// element J of the quad's four lanes, to all four (DPP quad_perm: no LDS traffic)
+template <int J>
+__device__ __forceinline__ double quad_bcast(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_mov_dpp(lo, J * 0x55, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, J * 0x55, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+
+// Pruning sweep, PL[parent] = (B^(ma-1) PL[a]) (.) (B^(mb-1) PL[b])   (mmmmvFORpl src/phylomap.cpp:446-450, :508-510, :525).
+// What bounds one chain on a big tree is the LATENCY of the longest root-to-tip line of dependent steps, so the sweep is laid
+// out for latency:
+//  * clusters (phm_sched.h ClusterPlan): one workgroup per subtree of <= NARROW_CLUSTER_NODES internal nodes walks ITS height
+//    levels with the vectors of its nodes in LDS and an LDS-only barrier per level; all clusters of a tier in one launch, the
+//    next tier (the subtrees of what is left above) in the next: 2 launches for 10 000 tips instead of one per height level;
+//  * eight lanes per node: a quad per child, lane q of the quad holds component q of the child's vector and computes row q of
+//    every chain step -- (((M_q0 x_0 + M_q1 x_1) + M_q2 x_2) + M_q3 x_3), the reference's order -- with the other three
+//    components read across the quad by DPP: a chain step is 7 dependent f64 operations instead of 28 per lane;
+//  * a tip child's chain is a table row (started from a one-hot row or, ks, a parity mask :1838-1845); the records, chain
+//    lengths and tip data of the next level are requested before the barrier of this one.  Loads are unconditional (a load under
+//    a lane condition is compiled to a branch with a full s_waitcnt behind it): a lane without an item reads a valid
+//    neighbouring address and drops the value.
+// The vectors also go to the global PL array (the transition maps of the sampling sweep and the clusters above read them);
+// nobody in the kernel waits for those stores.
 template <int NS>
-__device__ __forceinline__ UpOps up_operands(const NarrowParams<NS>& p, int r, const UpStep& st) {
+__global__ __launch_bounds__(NARROW_CLUSTER_BLOCK) void narrow_cluster_kernel(NarrowParams<NS> p, int first_cluster) {
+  __shared__ double s_pl[NARROW_CLUSTER_NODES * NS];
+  constexpr int G = NARROW_CLUSTER_BLOCK / 8;        // nodes per pass
+  const int cl = first_cluster + blockIdx.x;
+  const int r = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int g = tid >> 3, c = (tid >> 2) & 1, q = min(tid & 3, NS - 1);
+  const bool lane_on = (tid & 3) < NS;
+  uint32_t err = 0;
+  const int item0 = uniform_word(p.cl_item_off, cl);
+  const int lv0 = uniform_word(p.cl_lvl_ptr, cl), lv1 = uniform_word(p.cl_lvl_ptr, cl + 1) - 1;      // levels lv0 .. lv1 - 1
+  const int item_last = uniform_word(p.cl_item_off, cl + 1) - 1;
   const int32_t* __restrict__ mc = p.mcount + (size_t)r * p.n_edge;
   const uint8_t* __restrict__ tips = p.tips_per_replica ? p.tips + (size_t)r * p.n_tips : p.tips;
-  UpOps o;
+  double* __restrict__ PLr = p.PL + (size_t)r * p.n_node * NS;
+  double mrow[NS];
 #pragma unroll
-  for (int c = 0; c < 2; ++c) {
-    o.k[c] = mc[st.edge[c]] - 1;
-    o.tip[c] = (int)tips[st.child[c] < 0 ? ~st.child[c] : 0];
-  }
-  return o;
-}
+  for (int j = 0; j < NS; ++j) mrow[j] = p.Bc[q * NS + j];
 
-// one internal node of one chain: PL[parent] = (B^(ma-1) PL[a]) (.) (B^(mb-1) PL[b])   (mmmmvFORpl, src/phylomap.cpp:446-450,
-// :508-510).  Tip child: the chain started from a one-hot row (or, ks, from a parity mask :1838-1845) is a table row;
-// internal child: the chain itself.  `store` = 0: computed and dropped (a lane beyond the end of its level).
-template <int NS>
-__device__ __forceinline__ void up_load(const NarrowParams<NS>& p, int r, const UpStep& st, const UpOps& o, double (&v)[2][NS],
-                                        int (&steps)[2], uint32_t& err) {
-  const double* PLr = p.PL + (size_t)r * p.n_node * NS;
-#pragma unroll
-  for (int c = 0; c < 2; ++c) {
-    const int child = st.child[c];
-    int k = o.k[c];
-    const double* src;
-    if (child < 0) {
-      if (k >= p.klong) { err |= DERR_CAPACITY; k = p.klong - 1; }
-      src = (p.ks && p.tip_masks) ? p.maskL + ((size_t)k * 2 + (o.tip[c] & 1)) * NS : p.colL + ((size_t)k * NS + o.tip[c]) * NS;
-      steps[c] = 0;
-    } else {
-      src = PLr + (size_t)child * NS;
-      steps[c] = k;
+  struct Ops { int parent, child, slot, k, tip; };
+  auto fetch = [&](int item) {
+    const ClusterNode nd = p.cl_nodes[min(item, item_last)];
+    Ops o;
+    o.parent = nd.parent;
+    o.child = c ? nd.child[1] : nd.child[0];
+    o.slot = c ? nd.slot[1] : nd.slot[0];
+    o.k = mc[c ? nd.edge[1] : nd.edge[0]] - 1;
+    o.tip = (int)tips[o.child < 0 ? ~o.child : 0];
+    return o;
+  };
+  int lo = uniform_word(p.cl_lvl_off, lv0);
+  Ops nxt = fetch(lo + g);
+  for (int lv = lv0; lv < lv1; ++lv) {
+    const int hi = uniform_word(p.cl_lvl_off, lv + 1);
+    for (int base = lo; base < hi; base += G) {
+      const int item = base + g;
+      const Ops o = (base == lo) ? nxt : fetch(item);
+      // the child's vector: LDS (same cluster), table row (tip), global (a cluster of an earlier tier)
+      int k = o.k;
+      const bool tipc = o.child < 0;
+      if (tipc && k >= p.klong) { if (item < hi) err |= DERR_CAPACITY; k = p.klong - 1; }
+      const double* src = tipc ? ((p.ks && p.tip_masks) ? p.maskL + ((size_t)k * 2 + (o.tip & 1)) * NS + q
+                                                        : p.colL + ((size_t)k * NS + o.tip) * NS + q)
+                               : PLr + (size_t)o.child * NS + q;
+      const double from_mem = *src;
+      const double from_lds = s_pl[max(o.slot, 0) * NS + q];
+      double v = (o.slot >= 0) ? from_lds : from_mem;
+      const int steps = (tipc || item >= hi) ? 0 : k;
+      if (base == lo && lv + 1 < lv1) nxt = fetch(hi + g);                     // next level's operands, behind this level's loads
+      for (int i = 0; i < steps; ++i) {                                        // uniform over the quad
+        double acc = mrow[0] * quad_bcast<0>(v);
+        if (NS > 1) acc += mrow[NS > 1 ? 1 : 0] * quad_bcast<1>(v);
+        if (NS > 2) acc += mrow[NS > 2 ? 2 : 0] * quad_bcast<2>(v);
+        if (NS > 3) acc += mrow[NS > 3 ? 3 : 0] * quad_bcast<3>(v);
+        v = acc;
+      }
+      const double other = __shfl_xor(v, 4);                                   // the sibling quad's component q
+      double x = c ? v * other : other * v;                                    // "first" (child[1]) times "second" (:510)
+      if (p.normalise) {                                                       // :525
+        double sum = quad_bcast<0>(x);
+        if (NS > 1) sum += quad_bcast<1>(x);
+        if (NS > 2) sum += quad_bcast<2>(x);
+        if (NS > 3) sum += quad_bcast<3>(x);
+        x = x / sum;
+      }
+      if (item < hi && c == 0 && lane_on) {
+        s_pl[(item - item0) * NS + q] = x;
+        PLr[(size_t)o.parent * NS + q] = x;
+      }
     }
-#pragma unroll
-    for (int q = 0; q < NS; ++q) v[c][q] = src[q];
+    lds_barrier();
+    lo = hi;
   }
-}
-
-template <int NS>
-__device__ __forceinline__ void up_finish(const NarrowParams<NS>& p, int r, const UpStep& st, double (&v)[2][NS], const int (&steps)[2],
-                                          bool store) {
-  double* PLr = p.PL + (size_t)r * p.n_node * NS;
-  for (int i = 0; i < steps[1]; ++i) matvec_u<NS>(p.Bc, v[1]);                 // "first"  (:508)
-  for (int i = 0; i < steps[0]; ++i) matvec_u<NS>(p.Bc, v[0]);                 // "second" (:509)
-  double x[NS];
-#pragma unroll
-  for (int c = 0; c < NS; ++c) x[c] = v[1][c] * v[0][c];                       // :510
-  if (p.normalise) {                                                           // :525
-    double s = x[0];
-#pragma unroll
-    for (int c = 1; c < NS; ++c) s += x[c];
-#pragma unroll
-    for (int c = 0; c < NS; ++c) x[c] = x[c] / s;
-  }
-  if (store) {
-#pragma unroll
-    for (int c = 0; c < NS; ++c) PLr[st.parent * NS + c] = x[c];
-  }
-}
-
-template <int NS>
-__device__ __forceinline__ void up_node(const NarrowParams<NS>& p, int r, const UpStep& st, const UpOps& o, bool store, uint32_t& err) {
-  double v[2][NS];
-  int steps[2];
-  up_load<NS>(p, r, st, o, v, steps, err);
-  up_finish<NS>(p, r, st, v, steps, store);
-}
-
-template <int NS>
-__device__ __forceinline__ void up_node(const NarrowParams<NS>& p, int r, int idx, uint32_t& err) {
-  const UpStep st = p.up_lv[idx];
-  up_node<NS>(p, r, st, up_operands<NS>(p, r, st), true, err);
-}
-
-template <int NS>
-__global__ __launch_bounds__(NARROW_BLOCK) void narrow_up_kernel(NarrowParams<NS> p, int begin, int end) {
-  const int idx = begin + blockIdx.x * NARROW_BLOCK + threadIdx.x;
-  if (idx >= end) return;
-  uint32_t err = 0;
-  up_node<NS>(p, blockIdx.y, idx, err);
   if (err) atomicOr(p.err, err);
 }
 
@@ -164,13 +183,6 @@ __global__ __launch_bounds__(NARROW_BLOCK) void narrow_downmap_kernel(NarrowPara
 constexpr int NARROW_WALK_BLOCK = 1024;
 constexpr int NARROW_LDS_NODES = 60 * 1024;        // node states of one chain kept in LDS during the walk (1 byte each)
 
-// LDS-only release / barrier / acquire: the waves wait for their LDS traffic, not for the global stores in flight
-__device__ __forceinline__ void lds_barrier() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
-
 // Root draw, then the walk.  The node states of the chain live in LDS (LDSN; trees of up to NARROW_LDS_NODES internal nodes,
 // otherwise in the global array behind workgroup-scope fences); the global copies (node states, end states of every edge:
 // updatenodestates :460-475) are written behind, nobody in this kernel waits for them.  The records of level l + 1 are
@@ -215,53 +227,6 @@ __global__ __launch_bounds__(NARROW_WALK_BLOCK) void narrow_downwalk_kernel(Narr
     if (LDSN) lds_barrier();
     else { __threadfence_block(); __syncthreads(); }
     lo = lo_n; hi = hi_n; ds = ds_n; code = code_n;
-  }
-  if (err) atomicOr(p.err, err);
-}
-
-// Narrow pruning levels: one workgroup per chain walks a RUN of consecutive levels in a single launch, with a WORKGROUP-scope
-// fence and a barrier between levels: producer and consumer are waves of one workgroup on one CU, and a device-scope fence
-// would write back and invalidate the XCD's L2 at every level (the kernel boundary publishes the results to the other
-// kernels).  A level costs a launch (5-8 us on an otherwise empty device) when it is launched by itself and 2-3 us inside this
-// kernel, so every level of up to NARROW_FUSE_WIDTH items goes here; only wider levels get their own grid.
-// The kernel is software-pipelined over the levels: while level l is computed, the operands of level l + 1 that no step of the
-// sweep writes (chain lengths, tip data) are on their way, and the step records of level l + 2 behind them.  Loads are
-// unconditional; a wavefront takes part in a level only if one of the levels in its pipeline has an item for it (near the root
-// one wavefront works and the others wait at the barrier); the stage registers of a wavefront that sat out are stale but valid
-// addresses, and whether a lane HAS an item is recomputed from the level boundaries every time, never carried.
-constexpr int NARROW_MID_BLOCK = 1024;
-constexpr int NARROW_FUSE_WIDTH = NARROW_MID_BLOCK;
-template <int NS>
-__global__ __launch_bounds__(NARROW_MID_BLOCK) void narrow_mid_kernel(NarrowParams<NS> p, int up_lo, int up_hi) {
-  const int r = blockIdx.x;
-  const int tid = threadIdx.x;
-  const int wave_base = tid & ~63;
-  uint32_t err = 0;
-  auto lo_of = [&](int l) { return uniform_word(p.up_off, min(l, up_hi - 1)); };
-  auto hi_of = [&](int l) { return l < up_hi ? uniform_word(p.up_off, l + 1) : lo_of(l); };      // empty beyond the run
-  auto fetch = [&](int l, UpStep& st) {
-    const int lo = lo_of(l), hi = hi_of(l);
-    st = p.up_lv[max(min(lo + tid, hi - 1), 0)];
-  };
-  UpStep stA, stB;
-  fetch(up_lo, stA); fetch(up_lo + 1, stB);
-  UpOps opA = up_operands<NS>(p, r, stA);
-  for (int l = up_lo; l < up_hi; ++l) {
-    const int w0 = hi_of(l) - lo_of(l), w1 = hi_of(l + 1) - lo_of(l + 1), w2 = hi_of(l + 2) - lo_of(l + 2);
-    if (wave_base < max(w0, max(w1, w2))) {
-      double v[2][NS];                               // the loads this level waits for go out first, the look-ahead behind them
-      int steps[2];
-      up_load<NS>(p, r, stA, opA, v, steps, err);
-      UpStep stC;
-      fetch(l + 2, stC);
-      const UpOps opB = up_operands<NS>(p, r, stB);
-      up_finish<NS>(p, r, stA, v, steps, tid < w0);
-      const int hi = hi_of(l);
-      for (int idx = lo_of(l) + tid + NARROW_MID_BLOCK; idx < hi; idx += NARROW_MID_BLOCK) up_node<NS>(p, r, idx, err);
-      stA = stB; opA = opB; stB = stC;
-    }
-    __threadfence_block();
-    __syncthreads();
   }
   if (err) atomicOr(p.err, err);
 }
@@ -464,26 +429,14 @@ __global__ void narrow_emit_kernel(NarrowParams<NS> p, int it) {
 }  // namespace
 
 template <int NS>
-hipError_t launch_narrow_sweep(const NarrowParams<NS>& p, const std::vector<int32_t>& up_off,
+hipError_t launch_narrow_sweep(const NarrowParams<NS>& p, const std::vector<int32_t>& tier_off,
                                const std::vector<int32_t>& down_off, int it, hipStream_t stream) {
   const unsigned S = (unsigned)p.n_rep;
-  // pruning levels, tips side first: runs of consecutive narrow levels share one launch of narrow_mid_kernel, a wide level
-  // gets its own grid; then the sampling sweep: transition maps of all edges, root draw + walk
-  const int UL = (int)up_off.size() - 1, DL = (int)down_off.size() - 1;
-  auto width = [&](int t) { return up_off[t + 1] - up_off[t]; };
-  for (int t = 0; t < UL;) {
-    if (width(t) <= NARROW_FUSE_WIDTH) {
-      int t1 = t;
-      while (t1 < UL && width(t1) <= NARROW_FUSE_WIDTH) ++t1;
-      hipLaunchKernelGGL(narrow_mid_kernel<NS>, dim3(S), dim3(NARROW_MID_BLOCK), 0, stream, p, t, t1);
-      t = t1;
-      continue;
-    }
-    const int n = width(t);
-    hipLaunchKernelGGL(narrow_up_kernel<NS>, dim3((n + NARROW_BLOCK - 1) / NARROW_BLOCK, S), dim3(NARROW_BLOCK), 0, stream, p,
-                       up_off[t], up_off[t + 1]);
-    ++t;
-  }
+  // pruning sweep: one launch per tier of clusters; then the sampling sweep: transition maps of all edges, root draw + walk
+  const int DL = (int)down_off.size() - 1;
+  for (size_t t = 0; t + 1 < tier_off.size(); ++t)
+    hipLaunchKernelGGL(narrow_cluster_kernel<NS>, dim3((unsigned)(tier_off[t + 1] - tier_off[t]), S), dim3(NARROW_CLUSTER_BLOCK), 0,
+                       stream, p, tier_off[t]);
   hipLaunchKernelGGL(narrow_downmap_kernel<NS>, dim3((p.n_edge + NARROW_BLOCK - 1) / NARROW_BLOCK, S), dim3(NARROW_BLOCK), 0, stream,
                      p, it);
   if (p.n_node <= NARROW_LDS_NODES)

@@ -197,4 +197,82 @@ int32_t poisson_capacity(double lambda, double tail) {
   return (int32_t)cap;
 }
 
+void build_cluster_plan(const Schedule& s, int32_t max_nodes, ClusterPlan& plan) {
+  const int Nn = s.n_node;
+  plan = ClusterPlan();
+  // s.up lists children before parents: one pass gives heights and the parent of every internal node
+  std::vector<int32_t> height(Nn, 0), parent(Nn, -1), step_of(Nn, -1);
+  for (int k = 0; k < Nn; ++k) {
+    const UpStep& u = s.up[k];
+    step_of[u.parent] = k;
+    int h = 0;
+    for (int c = 0; c < 2; ++c)
+      if (u.child[c] >= 0) { h = std::max(h, height[u.child[c]] + 1); parent[u.child[c]] = u.parent; }
+    height[u.parent] = h;
+  }
+  std::vector<int32_t> cluster_of(Nn, -1), rsize(Nn, 0);
+  std::vector<std::vector<int32_t>> members;             // per cluster: internal indices
+  std::vector<int32_t> croot;                            // per cluster: its root node
+  plan.tier_off.push_back(0);
+  int assigned = 0;
+  while (assigned < Nn) {
+    // sizes of the not-yet-assigned part of every subtree (children before parents)
+    for (int k = 0; k < Nn; ++k) {
+      const UpStep& u = s.up[k];
+      if (cluster_of[u.parent] >= 0) { rsize[u.parent] = 0; continue; }
+      int sz = 1;
+      for (int c = 0; c < 2; ++c) if (u.child[c] >= 0) sz += rsize[u.child[c]];
+      rsize[u.parent] = sz;
+    }
+    const int first = (int)members.size();
+    // parents before children: a node joins its parent's cluster of this tier, or starts one when its subtree fits
+    for (int k = Nn - 1; k >= 0; --k) {
+      const int v = s.up[k].parent;
+      if (cluster_of[v] >= 0) continue;
+      const int pv = parent[v];
+      if (pv >= 0 && cluster_of[pv] >= first) { cluster_of[v] = cluster_of[pv]; members[cluster_of[v]].push_back(v); ++assigned; continue; }
+      if (rsize[v] <= max_nodes) {
+        cluster_of[v] = (int)members.size();
+        members.emplace_back(1, v);
+        croot.push_back(v);
+        ++assigned;
+      }
+    }
+    // big clusters first: they bound the duration of the tier's launch
+    std::vector<int32_t> order((int)members.size() - first);
+    for (size_t i = 0; i < order.size(); ++i) order[i] = first + (int)i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return members[a].size() > members[b].size(); });
+    std::vector<std::vector<int32_t>> sorted_m;
+    for (int c : order) sorted_m.push_back(std::move(members[c]));
+    for (size_t i = 0; i < order.size(); ++i) {
+      members[first + i] = std::move(sorted_m[i]);
+      for (int v : members[first + i]) cluster_of[v] = first + (int)i;
+    }
+    plan.tier_off.push_back((int)members.size());
+  }
+  std::vector<int32_t> pos(Nn, -1);
+  plan.item_off.push_back(0);
+  plan.lvl_ptr.push_back(0);
+  for (size_t c = 0; c < members.size(); ++c) {
+    std::vector<int32_t>& m = members[c];
+    std::stable_sort(m.begin(), m.end(), [&](int a, int b) { return height[a] < height[b]; });
+    const int base = (int)plan.nodes.size();
+    for (size_t i = 0; i < m.size(); ++i) pos[m[i]] = (int)i;
+    for (size_t i = 0; i < m.size(); ++i) {
+      const UpStep& u = s.up[step_of[m[i]]];
+      ClusterNode nd;
+      nd.parent = u.parent; nd.pad = 0;
+      for (int k = 0; k < 2; ++k) {
+        nd.child[k] = u.child[k]; nd.edge[k] = u.edge[k];
+        nd.slot[k] = (u.child[k] >= 0 && cluster_of[u.child[k]] == (int)c) ? pos[u.child[k]] : -1;
+      }
+      if (i == 0 || height[m[i]] != height[m[i - 1]]) plan.lvl_off.push_back(base + (int)i);
+      plan.nodes.push_back(nd);
+    }
+    plan.lvl_off.push_back(base + (int)m.size());
+    plan.item_off.push_back((int)plan.nodes.size());
+    plan.lvl_ptr.push_back((int)plan.lvl_off.size());
+  }
+}
+
 }  // namespace phm

@@ -24,6 +24,30 @@ struct DownStep {      // one branch of the pre-order (root-to-tips) sweep
   int32_t pad;
 };
 
+// Pruning sweep of the one-chain mapping (phm_narrow.hip): the internal nodes cut into CLUSTERS -- maximal subtrees of at most
+// `max_nodes` not-yet-assigned nodes -- in TIERS: tier 0 holds the bottom subtrees, tier 1 the maximal subtrees of what is left,
+// ... (two tiers for a 10 000-tip tree at 256 nodes per cluster).  Clusters of one tier are independent (one workgroup each, one
+// launch per tier); inside a cluster the nodes are ordered by height and a child of the same cluster is addressed by its position
+// in the cluster (its partial-likelihood vector stays in LDS).
+struct ClusterNode {
+  int32_t parent;      // internal index
+  int32_t child[2];    // >= 0: internal index; < 0: ~tip
+  int32_t edge[2];     // edge rows (0-based)
+  int32_t slot[2];     // child in the same cluster: its position in the cluster; else -1
+  int32_t pad;
+};
+
+struct ClusterPlan {
+  std::vector<ClusterNode> nodes;       // all clusters, tier by tier; inside a cluster by height
+  std::vector<int32_t> item_off;        // [n_clusters + 1] into nodes
+  std::vector<int32_t> lvl_ptr;         // [n_clusters + 1] into lvl_off
+  std::vector<int32_t> lvl_off;         // per cluster: boundaries of its height levels (absolute positions in nodes), levels + 1 entries
+  std::vector<int32_t> tier_off;        // [n_tiers + 1] into the cluster list
+};
+
+struct Schedule;
+void build_cluster_plan(const Schedule& s, int32_t max_nodes, ClusterPlan& plan);
+
 struct Schedule {
   int32_t n_tips = 0, n_node = 0, n_edge = 0;
   int32_t root = 0;                 // internal index of the root
