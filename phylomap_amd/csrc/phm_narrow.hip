@@ -232,150 +232,164 @@ __global__ __launch_bounds__(NARROW_WALK_BLOCK) void narrow_downwalk_kernel(Narr
 }
 
 // One branch of one chain: resamplebranchstates :264-308, shortener :44-73 (shortenerbf :997-1030), virtual jumps
-// sampleabranch :391-410, dwell sums updatedwelltimes :745-757.  The lane's dwell sums and transition counts collect in its own
-// LDS columns (s_dw, s_cnt); returns the segments read + written.
-template <int NS>
-__device__ __forceinline__ int narrow_branch_lane(const NarrowParams<NS>& p, int it, int idx, int r, int lane, double* s_dw,
-                                                  uint32_t* s_cnt, const double* s_ltab, uint32_t& err) {
-  const int b = p.branch_order[idx];
-  const uint32_t rep = (uint32_t)(p.replica_offset + r);
-  const bool KS = p.ks != 0;
-  int32_t* __restrict__ mc = p.mcount + (size_t)r * p.n_edge;
-  const int m = mc[b];
-  const uint8_t* es = p.estate + ((size_t)r * p.n_edge + b) * 2;
-  const int ps = es[0], cs = es[1];
-  const int64_t o = p.off[b];
-  const int cap = (int)(p.off[b + 1] - o);
-  const double* __restrict__ in = p.dw[it & 1] + (size_t)r * p.total_cap + o;
-  double* __restrict__ out = p.dw[(it & 1) ^ 1] + (size_t)r * p.total_cap + o;
-  double* __restrict__ ml = p.mlen + (size_t)r * p.total_cap + o;
-  uint8_t* __restrict__ ms = p.mstate + (size_t)r * p.total_cap + o;
-  Stream su, se;
-  su.open(ENT_BSTATE | (uint32_t)b, (uint32_t)it, rep, p.seed_lo, p.seed_hi);
-  se.open(ENT_BEXP | (uint32_t)b, (uint32_t)it, rep, p.seed_lo, p.seed_hi);
-
-  // pass A: states of the interior change points, s_i ~ B[s_{i-1},:] (.) B^(m-i-1) e_end (:290, :301-304); equal
-  // neighbours merged (:54), merged lengths and states written to the scratch slots.  The input lengths and the table
-  // rows do not depend on the states drawn so far, so they are fetched eight steps at a time ahead of the dependent chain.
-  constexpr int CH = 8;
-  int w = 0;
-  int cur_s = (m == 1) ? cs : ps;                    // updatenodestates :469-472 (m == 1: the child end wins)
-  double cur_len = in[0];
-  for (int i0 = 1; i0 < m; i0 += CH) {
-    double dbuf[CH], bbuf[CH][NS];
-#pragma unroll
-    for (int q = 0; q < CH; ++q) {
-      const int i = i0 + q;
-      dbuf[q] = (i < m) ? in[i] : 0.0;
-      int kk = m - i - 1;
-      if (kk >= p.klong) { err |= DERR_CAPACITY; kk = p.klong - 1; }
-      const double* beta = p.colL + ((size_t)(kk > 0 ? kk : 0) * NS + cs) * NS;
-#pragma unroll
-      for (int c = 0; c < NS; ++c) bbuf[q][c] = (i < m - 1) ? beta[c] : 0.0;
-    }
-#pragma unroll
-    for (int q = 0; q < CH; ++q) {
-      const int i = i0 + q;
-      if (i < m) {
-        int si;
-        if (i == m - 1) si = cs;
-        else {
-          double pr[NS];
-#pragma unroll
-          for (int c = 0; c < NS; ++c) pr[c] = p.B2[cur_s * NS + c] * bbuf[q][c];
-          si = sample_cat<NS>(pr, su.draw((uint32_t)(i - 1)), err);
-        }
-        const double di = dbuf[q];
-        if (KS) s_cnt[(cur_s * NS + si) * NARROW_BLOCK + lane] += 1u;            // shortenerbf :1010-1014
-        if (si == cur_s) cur_len = cur_len + di;
-        else {
-          ml[w] = cur_len; ms[w] = (uint8_t)cur_s;
-          if (!KS) s_cnt[(cur_s * (NS - 1) + (si > cur_s ? si - 1 : si)) * NARROW_BLOCK + lane] += 1u;   // shortener :65-66
-          ++w; cur_s = si; cur_len = di;
-        }
-      }
-    }
-  }
-  ml[w] = cur_len; ms[w] = (uint8_t)cur_s;
-  const int nmerged = w + 1;
-
-  // pass B: virtual jumps, gaps ~ Exp(Omega + q_ss) until each merged segment is used up (:391-410); a segment that is not
-  // positive leaves itself and everything after it untouched (the reference's iterators stop advancing, :397, :405-406)
-  int mnew = 0;
-  uint32_t edraw = 0;
-  bool stuck = false;
-  for (int j = 0; j < nmerged; ++j) {
-    const int s = ms[j];
-    const double len = ml[j];
-    double acc = s_dw[s * NARROW_BLOCK + lane];
-    if (stuck || !(0.0 < len)) {
-      stuck = true;
-      if (mnew < cap) out[mnew] = len; else err |= DERR_CAPACITY;
-      acc += len;
-      ++mnew;
-    } else {
-      const double scale = p.scale[s];
-      double tot = 0.0;
-      while (tot < len) {
-        const double rl = scale * neglog_u32(se.draw_word(edraw++), s_ltab);      // :398
-        double piece;
-        if ((tot + rl) < len) { piece = rl; tot += rl; }
-        else { piece = len - tot; tot = len; }
-        if (mnew < cap) out[mnew] = piece; else err |= DERR_CAPACITY;
-        acc += piece;                                                          // updatedwelltimes :752
-        ++mnew;
-      }
-    }
-    s_dw[s * NARROW_BLOCK + lane] = acc;
-  }
-  if (mnew > cap) mnew = cap;
-  mc[b] = mnew;
-
-  return m + mnew;
-}
-
-// One wavefront per workgroup, one branch per lane.  The per-lane sums are added over the wavefront in a fixed shuffle tree and
-// ONE row per wavefront goes to `part` (n + n^2 + 1 values: dwell sums, counts, segments touched): the statistics kernel adds
-// E / 64 rows per chain, not E.
+// sampleabranch :391-410, dwell sums updatedwelltimes :745-757 -- EIGHT LANES PER BRANCH.
+// The step is a short sequential state machine (previous state -> next state, running lengths, consumption of exponential gaps)
+// fed by expensive values that do NOT depend on the state: the uniforms and backward vectors of the interior change points, the
+// exponential variates.  The eight lanes compute those eight at a time --
+//   * a TRANSITION MAP per interior change point: the draw s_i ~ B[s_{i-1},:] (.) B^(m-i-1) e_end (:290, :301-304) carried out
+//     for each of the NS possible previous states (2 bits + "all-zero" flag each), beside the old segment's length;
+//   * eight standard exponential variates of the branch's stream (:398);
+// -- and exchange them through LDS; then all eight walk the state machine redundantly (same inputs, same results, one of them
+// stores): merged segments (:54) are completed and cut by virtual jumps on the fly, so there is no merged-segment scratch.
+// A wave takes 8 branches and runs as long as its longest one needs batches, not segments: one chain on 20 000 branches has
+// far more SIMDs than waves, and the latency of the longest wave is what the sweep waits for.
 template <int NS>
 __global__ __launch_bounds__(NARROW_BLOCK) void narrow_branch_kernel(NarrowParams<NS> p, int it) {
-  static_assert(NARROW_BLOCK == 64, "the reduction below is one wavefront wide");
-  __shared__ double s_dw[NS * NARROW_BLOCK];
-  __shared__ uint32_t s_cnt[NS * NS * NARROW_BLOCK];
+  static_assert(NARROW_BLOCK == 64, "one wavefront per workgroup");
+  constexpr int L = 8, GROUPS = NARROW_BLOCK / L;
+  __shared__ uint32_t s_cnt[NS * NS * GROUPS];
+  __shared__ double s_xlen[NARROW_BLOCK];            // exchange: lengths of eight old segments per group,
+  __shared__ uint32_t s_xmap[NARROW_BLOCK];          //           their transition maps,
+  __shared__ double s_xe[NARROW_BLOCK];              //           eight exponential variates per group
   __shared__ __align__(16) double s_ltab[2 * PHM_LOGTAB_N];        // (1/c_j, log c_j) of the exponential variates (neglog_u32)
   const int lane = threadIdx.x;
-  const int idx = blockIdx.x * NARROW_BLOCK + lane;
+  const int grp = lane / L, j = lane % L, gbase = grp * L;
   const int r = blockIdx.y;
   for (int i = lane; i < 2 * PHM_LOGTAB_N; i += NARROW_BLOCK) s_ltab[i] = logtab_entry(i);
-#pragma unroll
-  for (int c = 0; c < NS; ++c) s_dw[c * NARROW_BLOCK + lane] = 0.0;
-  for (int c = 0; c < NS * NS; ++c) s_cnt[c * NARROW_BLOCK + lane] = 0u;
+  for (int i = lane; i < NS * NS * GROUPS; i += NARROW_BLOCK) s_cnt[i] = 0u;
   __syncthreads();
+  const int idx = blockIdx.x * GROUPS + grp;
+  const bool KS = p.ks != 0;
   uint32_t err = 0;
   int segs = 0;
-  if (idx < p.n_edge) segs = narrow_branch_lane<NS>(p, it, idx, r, lane, s_dw, s_cnt, s_ltab, err);
+  double acc[NS];
+#pragma unroll
+  for (int c = 0; c < NS; ++c) acc[c] = 0.0;
+
+  if (idx < p.n_edge) {
+    const int b = p.branch_order[idx];
+    const uint32_t rep = (uint32_t)(p.replica_offset + r);
+    int32_t* __restrict__ mc = p.mcount + (size_t)r * p.n_edge;
+    const int m = mc[b];
+    const uint8_t* es = p.estate + ((size_t)r * p.n_edge + b) * 2;
+    const int ps = es[0], cs = es[1];
+    const int64_t o = p.off[b];
+    const int cap = (int)(p.off[b + 1] - o);
+    const double* __restrict__ in = p.dw[it & 1] + (size_t)r * p.total_cap + o;
+    double* __restrict__ out = p.dw[(it & 1) ^ 1] + (size_t)r * p.total_cap + o;
+    const uint32_t ent_s = ENT_BSTATE | (uint32_t)b, ent_e = ENT_BEXP | (uint32_t)b;
+
+    int cur_s = (m == 1) ? cs : ps;                  // updatenodestates :469-472 (m == 1: the child end wins)
+    double cur_len = in[0];
+    int mnew = 0;
+    uint32_t edraw = 0, ehave = 0;                   // exponential variates consumed / computed so far
+    bool stuck = false;
+    for (int i = 1; i <= m; ++i) {
+      int si = -1;                                   // i == m: past the last old segment, the running one is complete
+      double li = 0.0;
+      if (i < m) {
+        if (((i - 1) & (L - 1)) == 0) {              // a new batch of eight old segments: lane j takes segment i + j
+          const int ii = i + j;
+          const int iic = min(ii, m - 1);
+          const double len = in[iic];
+          int kk = m - iic - 1;
+          if (kk >= p.klong) { if (ii < m - 1) err |= DERR_CAPACITY; kk = p.klong - 1; }
+          const double* beta = p.colL + ((size_t)kk * NS + cs) * NS;
+          double bv[NS];
+#pragma unroll
+          for (int c = 0; c < NS; ++c) bv[c] = beta[c];
+          const double u = u01(stream_word(p.seed_lo, p.seed_hi, rep, (uint32_t)it, ent_s, (uint32_t)max(iic - 1, 0)));
+          uint32_t code = 0;
+#pragma unroll
+          for (int q = 0; q < NS; ++q) {
+            double pr[NS];
+#pragma unroll
+            for (int c = 0; c < NS; ++c) pr[c] = p.B2[q * NS + c] * bv[c];
+            uint32_t e2 = 0;
+            const int sq = sample_cat<NS>(pr, u, e2);
+            code |= ((uint32_t)sq | (e2 ? 4u : 0u)) << (4 * q);
+          }
+          if (iic == m - 1) code = (uint32_t)cs * 0x1111u;                     // the last segment ends in the child's state
+          s_xlen[lane] = len; s_xmap[lane] = code;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+        }
+        const int at = gbase + ((i - 1) & (L - 1));
+        li = s_xlen[at];
+        const uint32_t out_i = s_xmap[at] >> (4 * cur_s);
+        si = (int)(out_i & 3u);
+        if (out_i & 4u) err |= DERR_ZERO_PROB;
+        if (KS && j == 0) s_cnt[(cur_s * NS + si) * GROUPS + grp] += 1u;       // shortenerbf :1010-1014
+        if (si == cur_s) { cur_len = cur_len + li; continue; }                  // :54
+        if (!KS && j == 0) s_cnt[(cur_s * (NS - 1) + (si > cur_s ? si - 1 : si)) * GROUPS + grp] += 1u;   // shortener :65-66
+      }
+      // the merged segment (cur_s, cur_len) is complete: virtual jumps, gaps ~ Exp(Omega + q_ss) until it is used up (:391-410);
+      // a segment that is not positive leaves itself and everything after it untouched (the reference's iterators stop
+      // advancing, :397, :405-406)
+      {
+        const int sg = cur_s;
+        const double len = cur_len;
+        double add = 0.0;
+        if (stuck || !(0.0 < len)) {
+          stuck = true;
+          if (mnew < cap) { if (j == 0) out[mnew] = len; } else err |= DERR_CAPACITY;
+          add = len;
+          ++mnew;
+        } else {
+          double scale = p.scale[0];
+#pragma unroll
+          for (int c = 1; c < NS; ++c) scale = (sg == c) ? p.scale[c] : scale;
+          double tot = 0.0;
+          while (tot < len) {
+            if (edraw == ehave) {                    // the next eight variates of the branch's stream, one per lane
+              s_xe[lane] = neglog_u32(stream_word(p.seed_lo, p.seed_hi, rep, (uint32_t)it, ent_e, ehave + (uint32_t)j), s_ltab);
+              ehave += L;
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+              __builtin_amdgcn_wave_barrier();
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+            }
+            const double rl = scale * s_xe[gbase + (int)(edraw & (L - 1))];    // :398
+            ++edraw;
+            double piece;
+            if ((tot + rl) < len) { piece = rl; tot += rl; }
+            else { piece = len - tot; tot = len; }
+            if (mnew < cap) { if (j == 0) out[mnew] = piece; } else err |= DERR_CAPACITY;
+            add += piece;
+            ++mnew;
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < NS; ++c) acc[c] += (sg == c) ? add : 0.0;          // updatedwelltimes :752
+      }
+      cur_s = si; cur_len = li;
+    }
+    if (mnew > cap) mnew = cap;
+    if (j == 0) mc[b] = mnew;
+    segs = m + mnew;
+  }
   if (err) atomicOr(p.err, err);
 
-  const int ncnt = p.ks ? NS * NS : NS * (NS - 1);
+  // one row per wavefront: the eight branches' sums, added in a fixed tree (every lane of a group holds the group's values)
+  const int ncnt = KS ? NS * NS : NS * (NS - 1);
   constexpr int PC = NS + NS * NS + 1;
   double* part = p.part + ((size_t)r * gridDim.x + blockIdx.x) * PC;
 #pragma unroll
   for (int c = 0; c < NS; ++c) {
-    double v = s_dw[c * NARROW_BLOCK + lane];
+    double v = acc[c];
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = v + __shfl_xor(v, d);
+    for (int d = L; d < NARROW_BLOCK; d <<= 1) v = v + __shfl_xor(v, d);
     if (lane == 0) part[c] = v;
   }
-  for (int c = 0; c < ncnt; ++c) {
-    uint32_t v = s_cnt[c * NARROW_BLOCK + lane];
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-    if (lane == 0) part[NS + c] = (double)v;
-  }
-  {
+  for (int d = L; d < NARROW_BLOCK; d <<= 1) segs += __shfl_xor(segs, d);
+  if (lane == 0) part[PC - 1] = (double)segs;        // segments read + written (one global counter would serialise every lane)
+  __syncthreads();
+  if (lane < ncnt) {
+    uint32_t v = 0;
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) segs += __shfl_xor(segs, d);
-    if (lane == 0) part[PC - 1] = (double)segs;      // segments read + written (one global counter would serialise every lane)
+    for (int g2 = 0; g2 < GROUPS; ++g2) v += s_cnt[lane * GROUPS + g2];
+    part[NS + lane] = (double)v;
   }
 }
 
@@ -444,7 +458,7 @@ hipError_t launch_narrow_sweep(const NarrowParams<NS>& p, const std::vector<int3
                        it, DL);
   else
     hipLaunchKernelGGL((narrow_downwalk_kernel<NS, false>), dim3(S), dim3(NARROW_WALK_BLOCK), 0, stream, p, it, DL);
-  const unsigned n_waves = (unsigned)((p.n_edge + NARROW_BLOCK - 1) / NARROW_BLOCK);
+  const unsigned n_waves = (unsigned)((p.n_edge + 7) / 8);          // eight branches per wavefront
   hipLaunchKernelGGL(narrow_branch_kernel<NS>, dim3(n_waves, S), dim3(NARROW_BLOCK), 0, stream, p, it);
   hipLaunchKernelGGL(narrow_stats_kernel<NS>, dim3(S, NS + (p.ks ? NS * NS : NS * (NS - 1)) + 1), dim3(256), 0, stream, p, it,
                      (int)n_waves);
