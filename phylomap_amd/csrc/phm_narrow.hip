@@ -45,18 +45,32 @@ __device__ __forceinline__ double quad_bcast(double x) {
 // The vectors also go to the global PL array (the transition maps of the sampling sweep and the clusters above read them);
 // nobody in the kernel waits for those stores.
 template <int NS>
-__global__ __launch_bounds__(NARROW_CLUSTER_BLOCK) void narrow_cluster_kernel(NarrowParams<NS> p, int first_cluster) {
-  __shared__ double s_pl[NARROW_CLUSTER_NODES * NS];
+__global__ __launch_bounds__(NARROW_CLUSTER_BLOCK) void narrow_cluster_kernel(NarrowParams<NS> p, int first_cluster, int it) {
   constexpr int G = NARROW_CLUSTER_BLOCK / 8;        // nodes per pass
+  constexpr int PASSES = NARROW_CLUSTER_NODES / G;
+  __shared__ double s_pl[NARROW_CLUSTER_NODES * NS];           // vectors computed in this cluster
+  __shared__ double s_v0[NARROW_CLUSTER_NODES * 2 * NS];       // start vectors that come from outside: table rows, clusters below
+  __shared__ int32_t s_steps[NARROW_CLUSTER_NODES * 2];        // chain steps of (node, child): m - 1, 0 for a tip
+  __shared__ int32_t s_slot[NARROW_CLUSTER_NODES * 2];         // child of the same cluster: its position; else -1
+  __shared__ int32_t s_parent[NARROW_CLUSTER_NODES];
   const int cl = first_cluster + blockIdx.x;
   const int r = blockIdx.y;
   const int tid = threadIdx.x;
   const int g = tid >> 3, c = (tid >> 2) & 1, q = min(tid & 3, NS - 1);
   const bool lane_on = (tid & 3) < NS;
   uint32_t err = 0;
+#ifdef PHM_DEBUG_LEVEL_CLOCK
+  __shared__ unsigned long long s_clk[96];
+  __shared__ int s_mx[96];
+  int n_clk = 0;
+#define PHM_CLK(X) do { if (tid == 0 && n_clk < 96) { s_mx[n_clk] = (X); s_clk[n_clk++] = wall_clock64(); } } while (0)
+  PHM_CLK(0);
+#else
+#define PHM_CLK(X) do {} while (0)
+#endif
   const int item0 = uniform_word(p.cl_item_off, cl);
+  const int n_items = uniform_word(p.cl_item_off, cl + 1) - item0;
   const int lv0 = uniform_word(p.cl_lvl_ptr, cl), lv1 = uniform_word(p.cl_lvl_ptr, cl + 1) - 1;      // levels lv0 .. lv1 - 1
-  const int item_last = uniform_word(p.cl_item_off, cl + 1) - 1;
   const int32_t* __restrict__ mc = p.mcount + (size_t)r * p.n_edge;
   const uint8_t* __restrict__ tips = p.tips_per_replica ? p.tips + (size_t)r * p.n_tips : p.tips;
   double* __restrict__ PLr = p.PL + (size_t)r * p.n_node * NS;
@@ -64,36 +78,62 @@ __global__ __launch_bounds__(NARROW_CLUSTER_BLOCK) void narrow_cluster_kernel(Na
 #pragma unroll
   for (int j = 0; j < NS; ++j) mrow[j] = p.Bc[q * NS + j];
 
-  struct Ops { int parent, child, slot, k, tip; };
-  auto fetch = [&](int item) {
-    const ClusterNode nd = p.cl_nodes[min(item, item_last)];
-    Ops o;
-    o.parent = nd.parent;
-    o.child = c ? nd.child[1] : nd.child[0];
-    o.slot = c ? nd.slot[1] : nd.slot[0];
-    o.k = mc[c ? nd.edge[1] : nd.edge[0]] - 1;
-    o.tip = (int)tips[o.child < 0 ? ~o.child : 0];
-    return o;
-  };
-  int lo = uniform_word(p.cl_lvl_off, lv0);
-  Ops nxt = fetch(lo + g);
+  // Everything the cluster reads from memory, once, all passes side by side (three dependent round trips in total): records,
+  // then chain lengths and tip data, then the start vectors of the children that are not in the cluster.  The level loop below
+  // touches LDS only.
+  {
+    int child[PASSES], slot[PASSES], edge[PASSES], parent[PASSES], k[PASSES], tip[PASSES];
+    double v0[PASSES];
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+      const ClusterNode nd = p.cl_nodes[item0 + min(ps * G + g, n_items - 1)];
+      parent[ps] = nd.parent;
+      child[ps] = c ? nd.child[1] : nd.child[0];
+      slot[ps] = c ? nd.slot[1] : nd.slot[0];
+      edge[ps] = c ? nd.edge[1] : nd.edge[0];
+    }
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+      k[ps] = mc[edge[ps]] - 1;
+      tip[ps] = (int)tips[child[ps] < 0 ? ~child[ps] : 0];
+    }
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+      const bool tipc = child[ps] < 0;
+      int kk = k[ps];
+      if (tipc && kk >= p.klong) { if (ps * G + g < n_items) err |= DERR_CAPACITY; kk = p.klong - 1; }
+      const double* src = tipc ? ((p.ks && p.tip_masks) ? p.maskL + ((size_t)kk * 2 + (tip[ps] & 1)) * NS + q
+                                                        : p.colL + ((size_t)kk * NS + tip[ps]) * NS + q)
+                               : PLr + (size_t)child[ps] * NS + q;
+      v0[ps] = *src;                                 // a child of this cluster: a stale value, never used
+    }
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+      const int local = ps * G + g;
+      if (local < n_items) {
+        if (lane_on) s_v0[(local * 2 + c) * NS + q] = v0[ps];
+        if ((tid & 3) == 0) {
+          s_steps[local * 2 + c] = child[ps] < 0 ? 0 : k[ps];
+          s_slot[local * 2 + c] = slot[ps];
+          if (c == 0) s_parent[local] = parent[ps];
+        }
+      }
+    }
+  }
+  lds_barrier();
+  PHM_CLK(n_items);
+
+  int lo = uniform_word(p.cl_lvl_off, lv0) - item0;
   for (int lv = lv0; lv < lv1; ++lv) {
-    const int hi = uniform_word(p.cl_lvl_off, lv + 1);
+    const int hi = uniform_word(p.cl_lvl_off, lv + 1) - item0;
     for (int base = lo; base < hi; base += G) {
-      const int item = base + g;
-      const Ops o = (base == lo) ? nxt : fetch(item);
-      // the child's vector: LDS (same cluster), table row (tip), global (a cluster of an earlier tier)
-      int k = o.k;
-      const bool tipc = o.child < 0;
-      if (tipc && k >= p.klong) { if (item < hi) err |= DERR_CAPACITY; k = p.klong - 1; }
-      const double* src = tipc ? ((p.ks && p.tip_masks) ? p.maskL + ((size_t)k * 2 + (o.tip & 1)) * NS + q
-                                                        : p.colL + ((size_t)k * NS + o.tip) * NS + q)
-                               : PLr + (size_t)o.child * NS + q;
-      const double from_mem = *src;
-      const double from_lds = s_pl[max(o.slot, 0) * NS + q];
-      double v = (o.slot >= 0) ? from_lds : from_mem;
-      const int steps = (tipc || item >= hi) ? 0 : k;
-      if (base == lo && lv + 1 < lv1) nxt = fetch(hi + g);                     // next level's operands, behind this level's loads
+      const int local = min(base + g, hi - 1);
+      const bool live = base + g < hi;
+      const int slot = s_slot[local * 2 + c];
+      const int steps = live ? s_steps[local * 2 + c] : 0;
+      const double outside = s_v0[(local * 2 + c) * NS + q];
+      const double inside = s_pl[max(slot, 0) * NS + q];
+      double v = (slot >= 0) ? inside : outside;
       for (int i = 0; i < steps; ++i) {                                        // uniform over the quad
         double acc = mrow[0] * quad_bcast<0>(v);
         if (NS > 1) acc += mrow[NS > 1 ? 1 : 0] * quad_bcast<1>(v);
@@ -110,15 +150,24 @@ __global__ __launch_bounds__(NARROW_CLUSTER_BLOCK) void narrow_cluster_kernel(Na
         if (NS > 3) sum += quad_bcast<3>(x);
         x = x / sum;
       }
-      if (item < hi && c == 0 && lane_on) {
-        s_pl[(item - item0) * NS + q] = x;
-        PLr[(size_t)o.parent * NS + q] = x;
+      if (live && c == 0 && lane_on) {
+        s_pl[local * NS + q] = x;
+        PLr[(size_t)s_parent[local] * NS + q] = x;
       }
     }
     lds_barrier();
+    PHM_CLK(hi - lo);
     lo = hi;
   }
   if (err) atomicOr(p.err, err);
+#ifdef PHM_DEBUG_LEVEL_CLOCK
+  if (tid == 0 && r == 0 && blockIdx.x == 0 && it == 30) {
+    printf("clusterclock first %d items %d:", first_cluster, n_items);
+    for (int i = 1; i < n_clk; ++i) printf(" %d(%d)", (int)(s_clk[i] - s_clk[i - 1]), s_mx[i]);
+    printf("\n");
+  }
+#endif
+#undef PHM_CLK
 }
 
 template <int NS>
@@ -185,50 +234,83 @@ constexpr int NARROW_LDS_NODES = 60 * 1024;        // node states of one chain k
 
 // Root draw, then the walk.  The node states of the chain live in LDS (LDSN; trees of up to NARROW_LDS_NODES internal nodes,
 // otherwise in the global array behind workgroup-scope fences); the global copies (node states, end states of every edge:
-// updatenodestates :460-475) are written behind, nobody in this kernel waits for them.  The records of level l + 1 are
-// requested while level l is looked up.
+// updatenodestates :460-475) are written behind, nobody in this kernel waits for them.  A level of the walk is far shorter than
+// a memory round trip, so a lane requests its record of level l + 4 when it has used the one of level l (a ring of four).
 template <int NS, bool LDSN>
 __global__ __launch_bounds__(NARROW_WALK_BLOCK) void narrow_downwalk_kernel(NarrowParams<NS> p, int it, int n_levels) {
   extern __shared__ uint8_t s_nst[];
+  constexpr int RING = 4;
   const int r = blockIdx.x;
   const int tid = threadIdx.x;
   uint32_t err = 0;
   uint8_t* __restrict__ nst = p.nstate + (size_t)r * p.n_node;
   uint8_t* __restrict__ est = p.estate + (size_t)r * p.n_edge * 2;
   const uint16_t* __restrict__ dmap = p.dmap + (size_t)r * p.n_edge;
+  auto level_lo = [&](int l) { return uniform_word(p.down_off, min(l, n_levels)); };
+#ifdef PHM_DEBUG_LEVEL_CLOCK
+  __shared__ unsigned long long s_clk[96];
+  int n_clk = 0;
+#define PHM_CLK() do { if (tid == 0 && n_clk < 96) s_clk[n_clk++] = wall_clock64(); } while (0)
+  PHM_CLK();
+#else
+#define PHM_CLK() do {} while (0)
+#endif
+  DownStep ring_ds[RING];
+  uint32_t ring_code[RING];
   // first records before the root draw: they do not depend on it
-  int lo = uniform_word(p.down_off, 0), hi = uniform_word(p.down_off, 1);
-  int at = min(lo + tid, p.n_edge - 1);
-  DownStep ds = p.down_lv[at];
-  uint32_t code = dmap[at];
+#pragma unroll
+  for (int k = 0; k < RING; ++k) {
+    const int at = min(level_lo(k) + tid, p.n_edge - 1);
+    ring_ds[k] = p.down_lv[at];
+    ring_code[k] = dmap[at];
+  }
   if (tid == 0) {
     root_node<NS>(p, r, it, err);
     if (LDSN) s_nst[p.root] = nst[p.root];
   }
   if (LDSN) lds_barrier();
   else { __threadfence_block(); __syncthreads(); }
-  for (int l = 0; l < n_levels; ++l) {
-    const int lo_n = hi, hi_n = (l + 1 < n_levels) ? uniform_word(p.down_off, l + 2) : hi;
-    const int at_n = min(lo_n + tid, p.n_edge - 1);
-    const DownStep ds_n = p.down_lv[at_n];
-    const uint32_t code_n = dmap[at_n];
-    for (int idx = lo + tid; idx < hi; idx += NARROW_WALK_BLOCK) {
-      if (idx != lo + tid) { ds = p.down_lv[idx]; code = dmap[idx]; }
-      const int ps = LDSN ? s_nst[ds.parent] : nst[ds.parent];
-      const uint32_t out = code >> (4 * ps);
-      const int cs = (int)(out & 3u);
-      if (out & 4u) err |= DERR_ZERO_PROB;
-      if (ds.child >= 0) {
-        if (LDSN) s_nst[ds.child] = (uint8_t)cs;
-        nst[ds.child] = (uint8_t)cs;
+  PHM_CLK();
+  for (int l0 = 0; l0 < n_levels; l0 += RING) {
+#pragma unroll
+    for (int k = 0; k < RING; ++k) {
+      const int l = l0 + k;
+      if (l < n_levels) {
+        const int lo = level_lo(l), hi = level_lo(l + 1);
+        DownStep ds = ring_ds[k];
+        uint32_t code = ring_code[k];
+        {
+          const int at = min(level_lo(l + RING) + tid, p.n_edge - 1);
+          ring_ds[k] = p.down_lv[at];
+          ring_code[k] = dmap[at];
+        }
+        for (int idx = lo + tid; idx < hi; idx += NARROW_WALK_BLOCK) {
+          if (idx != lo + tid) { ds = p.down_lv[idx]; code = dmap[idx]; }
+          const int ps = LDSN ? s_nst[ds.parent] : nst[ds.parent];
+          const uint32_t out = code >> (4 * ps);
+          const int cs = (int)(out & 3u);
+          if (out & 4u) err |= DERR_ZERO_PROB;
+          if (ds.child >= 0) {
+            if (LDSN) s_nst[ds.child] = (uint8_t)cs;
+            nst[ds.child] = (uint8_t)cs;
+          }
+          est[ds.edge * 2] = (uint8_t)ps; est[ds.edge * 2 + 1] = (uint8_t)cs;
+        }
+        if (LDSN) lds_barrier();
+        else { __threadfence_block(); __syncthreads(); }
+        PHM_CLK();
       }
-      est[ds.edge * 2] = (uint8_t)ps; est[ds.edge * 2 + 1] = (uint8_t)cs;
     }
-    if (LDSN) lds_barrier();
-    else { __threadfence_block(); __syncthreads(); }
-    lo = lo_n; hi = hi_n; ds = ds_n; code = code_n;
   }
   if (err) atomicOr(p.err, err);
+#ifdef PHM_DEBUG_LEVEL_CLOCK
+  if (tid == 0 && r == 0 && it == 30) {
+    printf("walkclock:");
+    for (int i = 1; i < n_clk; ++i) printf(" %d", (int)(s_clk[i] - s_clk[i - 1]));
+    printf("\n");
+  }
+#endif
+#undef PHM_CLK
 }
 
 // One branch of one chain: resamplebranchstates :264-308, shortener :44-73 (shortenerbf :997-1030), virtual jumps
@@ -258,7 +340,10 @@ __global__ __launch_bounds__(NARROW_BLOCK) void narrow_branch_kernel(NarrowParam
   for (int i = lane; i < 2 * PHM_LOGTAB_N; i += NARROW_BLOCK) s_ltab[i] = logtab_entry(i);
   for (int i = lane; i < NS * NS * GROUPS; i += NARROW_BLOCK) s_cnt[i] = 0u;
   __syncthreads();
-  const int idx = blockIdx.x * GROUPS + grp;
+  // branch_order lists the branches longest first; group g of wave k takes position g * n_waves + k: every wave gets one of
+  // the longest branches and seven progressively shorter ones, so the expensive batch code (executed once per group, the
+  // groups reach it at different moments) adds up to about the same in every wave instead of eight-fold in the first
+  const int idx = grp * (int)gridDim.x + (int)blockIdx.x;
   const bool KS = p.ks != 0;
   uint32_t err = 0;
   int segs = 0;
@@ -450,7 +535,7 @@ hipError_t launch_narrow_sweep(const NarrowParams<NS>& p, const std::vector<int3
   const int DL = (int)down_off.size() - 1;
   for (size_t t = 0; t + 1 < tier_off.size(); ++t)
     hipLaunchKernelGGL(narrow_cluster_kernel<NS>, dim3((unsigned)(tier_off[t + 1] - tier_off[t]), S), dim3(NARROW_CLUSTER_BLOCK), 0,
-                       stream, p, tier_off[t]);
+                       stream, p, tier_off[t], it);
   hipLaunchKernelGGL(narrow_downmap_kernel<NS>, dim3((p.n_edge + NARROW_BLOCK - 1) / NARROW_BLOCK, S), dim3(NARROW_BLOCK), 0, stream,
                      p, it);
   if (p.n_node <= NARROW_LDS_NODES)
