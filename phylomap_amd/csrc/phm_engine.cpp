@@ -8,14 +8,27 @@
 
 namespace {
 
-// Automatic choice of the mapping (measured on C2, profiles/r01_probe_mapping.log; ms per sweep):
+// Automatic choice of the mapping (n <= 4).  Round 1 on C2 (profiles/r01_probe_mapping.log; ms per sweep):
 //   chains                  1     32     64    256   1024   4096   16384   65536   131072   196608   327680   393216
 //   lane = branch         0.17   0.22   0.25   0.62   2.4    9.3
 //   wave = tile x branch         0.32   0.32   0.36   0.48   1.0     3.0    10.0     19.3    (28.5 at 182 GiB; 262 144: 37.5)
 //   lane = replica        19.0                 21.4   25.8   26.7    26.7    28.2     34.4     39.0     48.6     53.2
-// One lane per branch for a handful of chains; one wave per (tile, branch) as long as its slots fit in HBM; the replica
+// One lane group per branch for a handful of chains; one wave per (tile, branch) as long as its slots fit in HBM; the replica
 // mapping (a single wave per tile, compact sequential streams) for the largest replica counts.
-constexpr int NARROW_AUTO_MAX_REPLICAS = 95;
+// Round 3 (latency-shaped one-chain kernels, profiles/r03_probe_crossover.log): the branch mapping costs
+// 0.04 + 0.002 x levels + 5.2e-7 x S x E ms per sweep, the (tile, branch) mapping 0.008 x levels + 2.6e-5 x E while its tiles
+// do not fill the device (C1 / C2 / C3: 0.16 / 0.33 / 0.84 ms up to ~512 chains) -> the branch mapping up to
+//   S* = (0.008 levels + 2.6e-5 E - 0.02) / (5.2e-7 E)      (C3: 72 chains, measured crossover 64..96; C2: 208, measured 256..384;
+//                                                             C1: 1 020, measured > 1 024)
+inline int narrow_auto_max_replicas(const phm::Schedule& s) {
+  std::vector<int32_t> depth(s.n_node, 0);
+  int levels = 1;
+  for (const phm::DownStep& d : s.down)              // parents before children
+    if (d.child >= 0) { depth[d.child] = depth[d.parent] + 1; levels = std::max(levels, depth[d.child] + 1); }
+  const double E = (double)s.n_edge;
+  const double cap = (0.008 * levels + 2.6e-5 * E - 0.02) / (5.2e-7 * E);
+  return (int)std::max(16.0, std::min(4096.0, cap));
+}
 constexpr int TILES_AUTO_MAX_REPLICAS = 262144;
 // 5..64 states: a wave per (replica, branch) (phm_wbranch.hip) exposes S x E waves whatever S is; the lane-per-replica mapping
 // (phm_wtiles.hip) needs whole tiles of 64 replicas and pays a fixed serial cost per tree level (one tile: 1.25 ms per sweep on
@@ -922,7 +935,7 @@ int32_t phm_engine_create_multi(const phm_tree* trees, int32_t n_trees, const ph
     e->tiled = n_trees == 1 && (map_req == 3 || (auto_map && e->S > wbranch_auto_max_replicas(n)));
     e->narrow = n_trees == 1 && !e->tiled && (map_req == 2 || auto_map);
   } else {
-    e->narrow = small_n && (map_req == 2 || (auto_map && e->S <= NARROW_AUTO_MAX_REPLICAS));
+    e->narrow = small_n && (map_req == 2 || (auto_map && e->S <= narrow_auto_max_replicas(s)));
     e->tiled = small_n && !e->narrow && (map_req == 3 || (auto_map && e->S <= TILES_AUTO_MAX_REPLICAS));
   }
   if (e->narrow && e->S > 65535) {      // the replica index is the grid's y dimension in these kernels

@@ -28,6 +28,10 @@ namespace phm {
 
 constexpr int NARROW_CLUSTER_NODES = 256;   // internal nodes per pruning cluster (their vectors: 8 KB of LDS at 4 states)
 constexpr int NARROW_CLUSTER_BLOCK = 512;   // eight lanes per node, 64 nodes per pass
+#ifndef PHM_NARROW_BRANCH_LANES
+#define PHM_NARROW_BRANCH_LANES 8
+#endif
+constexpr int NARROW_BRANCH_LANES = PHM_NARROW_BRANCH_LANES;   // lanes that share one branch in narrow_branch_kernel
 constexpr int NARROW_BLOCK = 64;      // one wavefront per workgroup: latency-bound work spread over as many CUs as possible
 
 template <int NS>

@@ -229,7 +229,10 @@ __global__ __launch_bounds__(NARROW_BLOCK) void narrow_downmap_kernel(NarrowPara
   if (err) atomicOr(p.err, err);
 }
 
-constexpr int NARROW_WALK_BLOCK = 1024;
+#ifndef PHM_NARROW_WALK_BLOCK
+#define PHM_NARROW_WALK_BLOCK 1024
+#endif
+constexpr int NARROW_WALK_BLOCK = PHM_NARROW_WALK_BLOCK;
 constexpr int NARROW_LDS_NODES = 60 * 1024;        // node states of one chain kept in LDS during the walk (1 byte each)
 
 // Root draw, then the walk.  The node states of the chain live in LDS (LDSN; trees of up to NARROW_LDS_NODES internal nodes,
@@ -255,15 +258,24 @@ __global__ __launch_bounds__(NARROW_WALK_BLOCK) void narrow_downwalk_kernel(Narr
 #else
 #define PHM_CLK() do {} while (0)
 #endif
+  // level boundaries of the next eight levels in scalar registers, refilled four at a time one round ahead of their use
+  int off[2 * RING + 1], off_next[RING];
+#pragma unroll
+  for (int k = 0; k <= 2 * RING; ++k) off[k] = level_lo(k);
+  // a lane's first record of a level (item lo + tid), requested four levels ahead -- by the waves that have one: near the root a
+  // level holds a handful of edges, and sixteen waves issuing loads nobody uses cost more than the level itself
+  const int wave_base = tid & ~63;
   DownStep ring_ds[RING];
   uint32_t ring_code[RING];
-  // first records before the root draw: they do not depend on it
+  auto request = [&](int k, int lo_l, int hi_l) {
+    if (wave_base < hi_l - lo_l) {
+      const int at = min(lo_l + tid, p.n_edge - 1);
+      ring_ds[k] = p.down_lv[at];
+      ring_code[k] = dmap[at];
+    }
+  };
 #pragma unroll
-  for (int k = 0; k < RING; ++k) {
-    const int at = min(level_lo(k) + tid, p.n_edge - 1);
-    ring_ds[k] = p.down_lv[at];
-    ring_code[k] = dmap[at];
-  }
+  for (int k = 0; k < RING; ++k) { ring_ds[k] = DownStep{0, 0, 0, 0}; ring_code[k] = 0u; request(k, off[k], off[k + 1]); }      // before the root draw
   if (tid == 0) {
     root_node<NS>(p, r, it, err);
     if (LDSN) s_nst[p.root] = nst[p.root];
@@ -273,17 +285,15 @@ __global__ __launch_bounds__(NARROW_WALK_BLOCK) void narrow_downwalk_kernel(Narr
   PHM_CLK();
   for (int l0 = 0; l0 < n_levels; l0 += RING) {
 #pragma unroll
+    for (int k = 0; k < RING; ++k) off_next[k] = level_lo(l0 + 2 * RING + 1 + k);
+#pragma unroll
     for (int k = 0; k < RING; ++k) {
       const int l = l0 + k;
       if (l < n_levels) {
-        const int lo = level_lo(l), hi = level_lo(l + 1);
+        const int lo = off[k], hi = off[k + 1];
         DownStep ds = ring_ds[k];
         uint32_t code = ring_code[k];
-        {
-          const int at = min(level_lo(l + RING) + tid, p.n_edge - 1);
-          ring_ds[k] = p.down_lv[at];
-          ring_code[k] = dmap[at];
-        }
+        request(k, off[k + RING], off[k + RING + 1]);
         for (int idx = lo + tid; idx < hi; idx += NARROW_WALK_BLOCK) {
           if (idx != lo + tid) { ds = p.down_lv[idx]; code = dmap[idx]; }
           const int ps = LDSN ? s_nst[ds.parent] : nst[ds.parent];
@@ -301,6 +311,10 @@ __global__ __launch_bounds__(NARROW_WALK_BLOCK) void narrow_downwalk_kernel(Narr
         PHM_CLK();
       }
     }
+#pragma unroll
+    for (int k = 0; k <= RING; ++k) off[k] = off[k + RING];
+#pragma unroll
+    for (int k = 0; k < RING; ++k) off[RING + 1 + k] = off_next[k];
   }
   if (err) atomicOr(p.err, err);
 #ifdef PHM_DEBUG_LEVEL_CLOCK
@@ -328,7 +342,7 @@ __global__ __launch_bounds__(NARROW_WALK_BLOCK) void narrow_downwalk_kernel(Narr
 template <int NS>
 __global__ __launch_bounds__(NARROW_BLOCK) void narrow_branch_kernel(NarrowParams<NS> p, int it) {
   static_assert(NARROW_BLOCK == 64, "one wavefront per workgroup");
-  constexpr int L = 8, GROUPS = NARROW_BLOCK / L;
+  constexpr int L = NARROW_BRANCH_LANES, GROUPS = NARROW_BLOCK / L;
   __shared__ uint32_t s_cnt[NS * NS * GROUPS];
   __shared__ double s_xlen[NARROW_BLOCK];            // exchange: lengths of eight old segments per group,
   __shared__ uint32_t s_xmap[NARROW_BLOCK];          //           their transition maps,
@@ -543,7 +557,8 @@ hipError_t launch_narrow_sweep(const NarrowParams<NS>& p, const std::vector<int3
                        it, DL);
   else
     hipLaunchKernelGGL((narrow_downwalk_kernel<NS, false>), dim3(S), dim3(NARROW_WALK_BLOCK), 0, stream, p, it, DL);
-  const unsigned n_waves = (unsigned)((p.n_edge + 7) / 8);          // eight branches per wavefront
+  constexpr int per_wave = NARROW_BLOCK / NARROW_BRANCH_LANES;
+  const unsigned n_waves = (unsigned)((p.n_edge + per_wave - 1) / per_wave);
   hipLaunchKernelGGL(narrow_branch_kernel<NS>, dim3(n_waves, S), dim3(NARROW_BLOCK), 0, stream, p, it);
   hipLaunchKernelGGL(narrow_stats_kernel<NS>, dim3(S, NS + (p.ks ? NS * NS : NS * (NS - 1)) + 1), dim3(256), 0, stream, p, it,
                      (int)n_waves);
