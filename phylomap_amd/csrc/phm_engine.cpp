@@ -275,7 +275,8 @@ void fill_narrow_params(phm_engine* e, phm::NarrowParams<NS>& p, const phm_optio
   for (int i = 0; i < NS; ++i) { p.scale[i] = e->hscale[i]; p.pid[i] = e->hpid[i]; }
   p.cl_nodes = e->d_nw_cl_nodes.as<phm::ClusterNode>(); p.cl_item_off = e->d_nw_cl_item_off.as<int32_t>();
   p.cl_lvl_ptr = e->d_nw_cl_lvl_ptr.as<int32_t>(); p.cl_lvl_off = e->d_nw_cl_lvl_off.as<int32_t>();
-  p.down_lv = e->d_nw_down_lv.as<phm::DownStep>(); p.down_off = e->d_nw_down_off.as<int32_t>();
+  p.down_lv = e->d_nw_down_lv.as<phm::DownStep>(); p.walk_off = e->d_nw_walk_off.as<int32_t>();
+  p.edge_parent = e->d_nw_edge_parent.as<int32_t>(); p.dmap_edge = e->d_nw_dmap_edge.as<uint16_t>();
   p.branch_order = e->d_nw_border.as<int32_t>(); p.off = e->d_nw_off.as<int64_t>();
   p.colL = e->d_nw_colL.as<double>(); p.rowL = e->d_nw_rowL.as<double>(); p.maskL = e->d_nw_maskL.as<double>();
   p.tips = e->d_tips.as<uint8_t>();
@@ -321,11 +322,26 @@ int32_t build_level_orders(phm_engine* e) {
   HIPCHK(e->d_nw_up_order.alloc(sizeof(int32_t) * Nn)); HIPCHK(e->d_nw_down_order.alloc(sizeof(int32_t) * E));
   HIPCHK(hipMemcpy(e->d_nw_up_order.p, up_order.data(), e->d_nw_up_order.bytes, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(e->d_nw_down_order.p, down_order.data(), e->d_nw_down_order.bytes, hipMemcpyHostToDevice));
-  {   // the sampling steps themselves in level order (phm_narrow.hip reads them without the indirection)
-    std::vector<phm::DownStep> down_lv(E);
-    for (int i = 0; i < E; ++i) down_lv[i] = s.down[down_order[i]];
+  if (!e->wide) {
+    // phm_narrow.hip: the sampling steps themselves (no indirection).  Edges that lead to an INTERNAL node first, grouped by depth
+    // level -- the walk propagates states only along those --, then the tip edges; boundaries of the first part in nw_walk_off
+    std::vector<phm::DownStep> walk_lv;
+    walk_lv.reserve(E);
+    e->nw_walk_off.assign(1, 0);
+    for (int l = 0; l + 1 < (int)e->nw_down_off.size(); ++l) {
+      for (int i = e->nw_down_off[l]; i < e->nw_down_off[l + 1]; ++i)
+        if (s.down[down_order[i]].child >= 0) walk_lv.push_back(s.down[down_order[i]]);
+      if ((int)walk_lv.size() > e->nw_walk_off.back()) e->nw_walk_off.push_back((int)walk_lv.size());
+    }
+    for (int i = 0; i < E; ++i) if (s.down[down_order[i]].child < 0) walk_lv.push_back(s.down[down_order[i]]);
+    std::vector<int32_t> edge_parent(E);
+    for (int i = 0; i < E; ++i) edge_parent[s.down[i].edge] = s.down[i].parent;
     HIPCHK(e->d_nw_down_lv.alloc(sizeof(phm::DownStep) * E));
-    HIPCHK(hipMemcpy(e->d_nw_down_lv.p, down_lv.data(), e->d_nw_down_lv.bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_nw_down_lv.p, walk_lv.data(), e->d_nw_down_lv.bytes, hipMemcpyHostToDevice));
+    HIPCHK(e->d_nw_walk_off.alloc(sizeof(int32_t) * e->nw_walk_off.size()));
+    HIPCHK(hipMemcpy(e->d_nw_walk_off.p, e->nw_walk_off.data(), e->d_nw_walk_off.bytes, hipMemcpyHostToDevice));
+    HIPCHK(e->d_nw_edge_parent.alloc(sizeof(int32_t) * E));
+    HIPCHK(hipMemcpy(e->d_nw_edge_parent.p, edge_parent.data(), e->d_nw_edge_parent.bytes, hipMemcpyHostToDevice));
   }
   HIPCHK(e->d_nw_up_off.alloc(sizeof(int32_t) * e->nw_up_off.size())); HIPCHK(e->d_nw_down_off.alloc(sizeof(int32_t) * e->nw_down_off.size()));
   HIPCHK(hipMemcpy(e->d_nw_up_off.p, e->nw_up_off.data(), e->d_nw_up_off.bytes, hipMemcpyHostToDevice));
@@ -397,6 +413,7 @@ int32_t narrow_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
   HIPCHK(e->d_nw_rowbuf.alloc(sizeof(double) * (size_t)S * e->dcols));
   if (!e->wide) {
     HIPCHK(e->d_nw_dmap.alloc(sizeof(uint16_t) * (size_t)S * E));
+    HIPCHK(e->d_nw_dmap_edge.alloc(sizeof(uint16_t) * (size_t)S * E));
     phm::ClusterPlan plan;                           // pruning sweep of phm_narrow.hip: subtrees in tiers
     phm::build_cluster_plan(s, phm::NARROW_CLUSTER_NODES, plan);
     e->nw_tier_off = plan.tier_off;
@@ -1161,9 +1178,9 @@ int32_t phm_engine_run(phm_engine* e, int32_t n_iters, void* hip_stream) {
     hipError_t le = hipSuccess;
     for (int i = 0; i < n_iters && le == hipSuccess; ++i) {
       const int it = e->iters_done + i;
-      if (e->n == 2) le = phm::launch_narrow_sweep<2>(e->n2, e->nw_tier_off, e->nw_down_off, it, stream);
-      if (e->n == 3) le = phm::launch_narrow_sweep<3>(e->n3, e->nw_tier_off, e->nw_down_off, it, stream);
-      if (e->n == 4) le = phm::launch_narrow_sweep<4>(e->n4, e->nw_tier_off, e->nw_down_off, it, stream);
+      if (e->n == 2) le = phm::launch_narrow_sweep<2>(e->n2, e->nw_tier_off, e->nw_walk_off, it, stream);
+      if (e->n == 3) le = phm::launch_narrow_sweep<3>(e->n3, e->nw_tier_off, e->nw_walk_off, it, stream);
+      if (e->n == 4) le = phm::launch_narrow_sweep<4>(e->n4, e->nw_tier_off, e->nw_walk_off, it, stream);
       if (e->wide) le = phm::launch_wbranch_sweep(e->pwb, e->nw_up_off, e->nw_down_off, it, stream);
       launches += (int)(e->nw_up_off.size() + e->nw_down_off.size()) + 2;
     }

@@ -214,13 +214,14 @@ struct phm_engine {
   DevBuf d_B2, d_Bc, d_scale, d_pid;
   // branch-parallel mapping for few chains on a large tree (phm_narrow.hip)
   bool narrow = false;
+  std::vector<int32_t> nw_walk_off;                // depth-level boundaries of the internal-child edges (walk of phm_narrow.hip)
   std::vector<int32_t> nw_tier_off;                // cluster tiers of the one-chain pruning sweep (phm_sched.h ClusterPlan)
   std::vector<int32_t> nw_up_off, nw_down_off;     // level boundaries into up_order / down_order
   std::vector<int64_t> nw_off;                     // CSR offsets of the branch slots
   int nw_klong = 0;
   int64_t nw_total_cap = 0;
   DevBuf d_nw_up_off, d_nw_down_off, d_nw_up_order, d_nw_down_order, d_nw_border, d_nw_off, d_nw_colL, d_nw_rowL, d_nw_maskL, d_nw_mcount, d_nw_dwA, d_nw_dwB,
-      d_nw_mstate, d_nw_mlen, d_nw_estate, d_nw_part, d_nw_rowbuf, d_nw_down_lv, d_nw_dmap, d_nw_cl_nodes, d_nw_cl_item_off, d_nw_cl_lvl_ptr, d_nw_cl_lvl_off, d_ell_col, d_ell_val, d_ell2_col, d_ell2_val;
+      d_nw_mstate, d_nw_mlen, d_nw_estate, d_nw_part, d_nw_rowbuf, d_nw_down_lv, d_nw_dmap, d_nw_dmap_edge, d_nw_walk_off, d_nw_edge_parent, d_nw_cl_nodes, d_nw_cl_item_off, d_nw_cl_lvl_ptr, d_nw_cl_lvl_off, d_ell_col, d_ell_val, d_ell2_col, d_ell2_val;
   DevBuf d_wb_cnt;
   phm::WideBranchParams pwb;                  // n > 4 with `narrow` set: one wave per (replica, branch) (phm_wbranch.hip)
   phm::NarrowParams<2> n2;
@@ -254,7 +255,7 @@ struct phm_engine {
     DevBuf* all[] = {&d_roots, &d_mask, &d_up, &d_down, &d_col, &d_row, &d_tips, &d_mcount, &d_dw0, &d_dw1, &d_cursor, &d_PL, &d_nstate,
                      &d_stats, &d_err, &d_seg, &d_red, &d_red_out, &d_B2, &d_Bc, &d_scale, &d_pid, &d_nw_up_off, &d_nw_down_off,
                      &d_nw_up_order, &d_nw_down_order, &d_nw_border, &d_nw_off, &d_nw_colL, &d_nw_rowL, &d_nw_maskL, &d_nw_mcount,
-                     &d_nw_dwA, &d_nw_dwB, &d_nw_mstate, &d_nw_mlen, &d_nw_estate, &d_nw_part, &d_nw_rowbuf, &d_nw_down_lv, &d_nw_dmap, &d_nw_cl_nodes, &d_nw_cl_item_off, &d_nw_cl_lvl_ptr, &d_nw_cl_lvl_off, &d_ell_col, &d_ell_val,
+                     &d_nw_dwA, &d_nw_dwB, &d_nw_mstate, &d_nw_mlen, &d_nw_estate, &d_nw_part, &d_nw_rowbuf, &d_nw_down_lv, &d_nw_dmap, &d_nw_dmap_edge, &d_nw_walk_off, &d_nw_edge_parent, &d_nw_cl_nodes, &d_nw_cl_item_off, &d_nw_cl_lvl_ptr, &d_nw_cl_lvl_off, &d_ell_col, &d_ell_val,
                      &d_ell2_col, &d_ell2_val, &d_wb_cnt, &d_tl_slot, &d_tl_pdw, &d_tl_pchunk, &d_tl_cnt, &d_tl_estate, &d_tl_pseg,
                      &d_tl_segprev, &d_wt_dwfx, &d_wt_segacc, &d_wt_B2, &d_wt_totL, &d_wt_pair_slot, &d_wt_slot_col, &d_wt_B2band, &d_wt_mstate, &d_wt_dwfx_tile, &d_wt_cnt_tile};
     for (DevBuf* b : all) b->reset();

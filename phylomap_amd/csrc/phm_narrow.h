@@ -47,8 +47,9 @@ struct NarrowParams {
   const int32_t* cl_item_off;                // [n_clusters + 1] into cl_nodes
   const int32_t* cl_lvl_ptr;                 // [n_clusters + 1] into cl_lvl_off
   const int32_t* cl_lvl_off;                 // per cluster: boundaries of its height levels (positions in cl_nodes)
-  const DownStep* down_lv;                   // [n_edge] sampling steps grouped by depth level
-  const int32_t* down_off;                   // level boundaries into down_lv
+  const DownStep* down_lv;                   // [n_edge] sampling steps: edges to internal nodes grouped by depth level, then the tip edges
+  const int32_t* walk_off;                   // depth-level boundaries of the first part
+  const int32_t* edge_parent;                // [n_edge] internal index of the parent node of every edge row
   const int32_t* branch_order;               // edge rows, largest capacity first
   const int64_t* off;                        // [n_edge + 1] CSR offsets of the branch slots
   const double* colL;                        // [klong][NS][NS]  (Bc^k e_j)[r]
@@ -62,7 +63,8 @@ struct NarrowParams {
   uint8_t* estate;                           // [replica][n_edge][2] end states (parent side, child side) of every edge
   double* PL;                                // [replica][n_node][NS]
   uint8_t* nstate;                           // [replica][n_node]
-  uint16_t* dmap;                            // [replica][n_edge] transition map of every edge (sampling sweep), level order
+  uint16_t* dmap;                            // [replica][n_edge] transition map of every edge (sampling sweep), down_lv order
+  uint16_t* dmap_edge;                       // the same maps by edge row (branch kernel: end states of its edge)
   double* part;                              // [replica][n_edge][NS + NS*NS + 1] per-branch dwell sums, counts, segments touched
   double* rowbuf;                            // [replica][n_cols] statistics row of the sweep
   double* stats;                             // engine layout: reduce ? [iter][tile][cols] : [iter][cols][n_rep_pad]
@@ -73,6 +75,6 @@ struct NarrowParams {
 // one full sweep (iteration index `it`) enqueued on `stream`; tier boundaries (clusters) and depth-level boundaries are host arrays
 template <int NS>
 hipError_t launch_narrow_sweep(const NarrowParams<NS>& p, const std::vector<int32_t>& tier_off,
-                               const std::vector<int32_t>& down_off, int it, hipStream_t stream);
+                               const std::vector<int32_t>& walk_off, int it, hipStream_t stream);
 
 }  // namespace phm

@@ -188,7 +188,10 @@ __device__ __forceinline__ void root_node(const NarrowParams<NS>& p, int r, int 
 //                           possible parent state; the NS outcomes (2 bits each + "probabilities were all zero") are one 16-bit
 //                           word per edge, the edge's transition map;
 //   narrow_downwalk_kernel  one workgroup per chain walks the levels root to tips: state[child] = map[edge][state[parent]],
-//                           a table look-up per edge and an LDS barrier per level -- no arithmetic on the critical path.
+//                           a table look-up per edge and an LDS barrier per level -- no arithmetic on the critical path; only
+//                           the edges that lead to an internal node take part (nothing hangs below a tip);
+//   narrow_branch_kernel    reads the end states of its edge (updatenodestates :460-475) off the edge's map and the parent's
+//                           state, tip edges included.
 // The outcome for the parent state that materialises is exactly the draw of the reference's sweep: same operands, same order.
 template <int NS>
 __global__ __launch_bounds__(NARROW_BLOCK) void narrow_downmap_kernel(NarrowParams<NS> p, int it) {
@@ -226,6 +229,7 @@ __global__ __launch_bounds__(NARROW_BLOCK) void narrow_downmap_kernel(NarrowPara
     code |= out << (4 * q);
   }
   p.dmap[(size_t)r * p.n_edge + idx] = (uint16_t)code;
+  p.dmap_edge[(size_t)r * p.n_edge + ds.edge] = (uint16_t)code;
   if (err) atomicOr(p.err, err);
 }
 
@@ -235,36 +239,26 @@ __global__ __launch_bounds__(NARROW_BLOCK) void narrow_downmap_kernel(NarrowPara
 constexpr int NARROW_WALK_BLOCK = PHM_NARROW_WALK_BLOCK;
 constexpr int NARROW_LDS_NODES = 60 * 1024;        // node states of one chain kept in LDS during the walk (1 byte each)
 
-// Root draw, then the walk.  The node states of the chain live in LDS (LDSN; trees of up to NARROW_LDS_NODES internal nodes,
-// otherwise in the global array behind workgroup-scope fences); the global copies (node states, end states of every edge:
-// updatenodestates :460-475) are written behind, nobody in this kernel waits for them.  A level of the walk is far shorter than
-// a memory round trip, so a lane requests its record of level l + 4 when it has used the one of level l (a ring of four).
+// Root draw, then the walk over the edges that lead to internal nodes.  The node states of the chain live in LDS (LDSN; trees
+// of up to NARROW_LDS_NODES internal nodes) and go to the global array in one coalesced pass at the end; larger trees walk the
+// global array behind workgroup-scope fences.  A level of the walk is far shorter than a memory round trip, so a lane requests
+// its record of level l + 4 when it has used the one of level l (a ring of four) -- if its wave has one: near the root a level
+// holds a handful of edges, and sixteen waves issuing loads nobody uses cost more than the level itself.
 template <int NS, bool LDSN>
 __global__ __launch_bounds__(NARROW_WALK_BLOCK) void narrow_downwalk_kernel(NarrowParams<NS> p, int it, int n_levels) {
   extern __shared__ uint8_t s_nst[];
   constexpr int RING = 4;
   const int r = blockIdx.x;
   const int tid = threadIdx.x;
+  const int wave_base = tid & ~63;
   uint32_t err = 0;
   uint8_t* __restrict__ nst = p.nstate + (size_t)r * p.n_node;
-  uint8_t* __restrict__ est = p.estate + (size_t)r * p.n_edge * 2;
   const uint16_t* __restrict__ dmap = p.dmap + (size_t)r * p.n_edge;
-  auto level_lo = [&](int l) { return uniform_word(p.down_off, min(l, n_levels)); };
-#ifdef PHM_DEBUG_LEVEL_CLOCK
-  __shared__ unsigned long long s_clk[96];
-  int n_clk = 0;
-#define PHM_CLK() do { if (tid == 0 && n_clk < 96) s_clk[n_clk++] = wall_clock64(); } while (0)
-  PHM_CLK();
-#else
-#define PHM_CLK() do {} while (0)
-#endif
+  auto level_lo = [&](int l) { return uniform_word(p.walk_off, min(l, n_levels)); };
   // level boundaries of the next eight levels in scalar registers, refilled four at a time one round ahead of their use
   int off[2 * RING + 1], off_next[RING];
 #pragma unroll
   for (int k = 0; k <= 2 * RING; ++k) off[k] = level_lo(k);
-  // a lane's first record of a level (item lo + tid), requested four levels ahead -- by the waves that have one: near the root a
-  // level holds a handful of edges, and sixteen waves issuing loads nobody uses cost more than the level itself
-  const int wave_base = tid & ~63;
   DownStep ring_ds[RING];
   uint32_t ring_code[RING];
   auto request = [&](int k, int lo_l, int hi_l) {
@@ -282,7 +276,6 @@ __global__ __launch_bounds__(NARROW_WALK_BLOCK) void narrow_downwalk_kernel(Narr
   }
   if (LDSN) lds_barrier();
   else { __threadfence_block(); __syncthreads(); }
-  PHM_CLK();
   for (int l0 = 0; l0 < n_levels; l0 += RING) {
 #pragma unroll
     for (int k = 0; k < RING; ++k) off_next[k] = level_lo(l0 + 2 * RING + 1 + k);
@@ -298,17 +291,12 @@ __global__ __launch_bounds__(NARROW_WALK_BLOCK) void narrow_downwalk_kernel(Narr
           if (idx != lo + tid) { ds = p.down_lv[idx]; code = dmap[idx]; }
           const int ps = LDSN ? s_nst[ds.parent] : nst[ds.parent];
           const uint32_t out = code >> (4 * ps);
-          const int cs = (int)(out & 3u);
           if (out & 4u) err |= DERR_ZERO_PROB;
-          if (ds.child >= 0) {
-            if (LDSN) s_nst[ds.child] = (uint8_t)cs;
-            nst[ds.child] = (uint8_t)cs;
-          }
-          est[ds.edge * 2] = (uint8_t)ps; est[ds.edge * 2 + 1] = (uint8_t)cs;
+          if (LDSN) s_nst[ds.child] = (uint8_t)(out & 3u);
+          else nst[ds.child] = (uint8_t)(out & 3u);
         }
         if (LDSN) lds_barrier();
         else { __threadfence_block(); __syncthreads(); }
-        PHM_CLK();
       }
     }
 #pragma unroll
@@ -316,15 +304,10 @@ __global__ __launch_bounds__(NARROW_WALK_BLOCK) void narrow_downwalk_kernel(Narr
 #pragma unroll
     for (int k = 0; k < RING; ++k) off[RING + 1 + k] = off_next[k];
   }
-  if (err) atomicOr(p.err, err);
-#ifdef PHM_DEBUG_LEVEL_CLOCK
-  if (tid == 0 && r == 0 && it == 30) {
-    printf("walkclock:");
-    for (int i = 1; i < n_clk; ++i) printf(" %d", (int)(s_clk[i] - s_clk[i - 1]));
-    printf("\n");
+  if (LDSN) {                                        // the states of the sweep, for the branch kernel and the statistics
+    for (int i = tid; i < p.n_node; i += NARROW_WALK_BLOCK) nst[i] = s_nst[i];
   }
-#endif
-#undef PHM_CLK
+  if (err) atomicOr(p.err, err);
 }
 
 // One branch of one chain: resamplebranchstates :264-308, shortener :44-73 (shortenerbf :997-1030), virtual jumps
@@ -370,8 +353,10 @@ __global__ __launch_bounds__(NARROW_BLOCK) void narrow_branch_kernel(NarrowParam
     const uint32_t rep = (uint32_t)(p.replica_offset + r);
     int32_t* __restrict__ mc = p.mcount + (size_t)r * p.n_edge;
     const int m = mc[b];
-    const uint8_t* es = p.estate + ((size_t)r * p.n_edge + b) * 2;
-    const int ps = es[0], cs = es[1];
+    const int ps = p.nstate[(size_t)r * p.n_node + p.edge_parent[b]];          // updatenodestates :460-475: the edge's end states
+    const uint32_t ends = (uint32_t)p.dmap_edge[(size_t)r * p.n_edge + b] >> (4 * ps);
+    const int cs = (int)(ends & 3u);
+    if (ends & 4u) err |= DERR_ZERO_PROB;
     const int64_t o = p.off[b];
     const int cap = (int)(p.off[b + 1] - o);
     const double* __restrict__ in = p.dw[it & 1] + (size_t)r * p.total_cap + o;
@@ -543,10 +528,10 @@ __global__ void narrow_emit_kernel(NarrowParams<NS> p, int it) {
 
 template <int NS>
 hipError_t launch_narrow_sweep(const NarrowParams<NS>& p, const std::vector<int32_t>& tier_off,
-                               const std::vector<int32_t>& down_off, int it, hipStream_t stream) {
+                               const std::vector<int32_t>& walk_off, int it, hipStream_t stream) {
   const unsigned S = (unsigned)p.n_rep;
   // pruning sweep: one launch per tier of clusters; then the sampling sweep: transition maps of all edges, root draw + walk
-  const int DL = (int)down_off.size() - 1;
+  const int DL = (int)walk_off.size() - 1;
   for (size_t t = 0; t + 1 < tier_off.size(); ++t)
     hipLaunchKernelGGL(narrow_cluster_kernel<NS>, dim3((unsigned)(tier_off[t + 1] - tier_off[t]), S), dim3(NARROW_CLUSTER_BLOCK), 0,
                        stream, p, tier_off[t], it);
