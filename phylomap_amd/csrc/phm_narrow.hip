@@ -311,102 +311,221 @@ __global__ __launch_bounds__(NARROW_WALK_BLOCK) void narrow_downwalk_kernel(Narr
 }
 
 // One branch of one chain: resamplebranchstates :264-308, shortener :44-73 (shortenerbf :997-1030), virtual jumps
-// sampleabranch :391-410, dwell sums updatedwelltimes :745-757 -- EIGHT LANES PER BRANCH.
+// sampleabranch :391-410, dwell sums updatedwelltimes :745-757 -- EIGHT LANES PER BRANCH, eight branches per wave.
 // The step is a short sequential state machine (previous state -> next state, running lengths, consumption of exponential gaps)
-// fed by expensive values that do NOT depend on the state: the uniforms and backward vectors of the interior change points, the
-// exponential variates.  The eight lanes compute those eight at a time --
+// fed by expensive values that do NOT depend on the state:
 //   * a TRANSITION MAP per interior change point: the draw s_i ~ B[s_{i-1},:] (.) B^(m-i-1) e_end (:290, :301-304) carried out
 //     for each of the NS possible previous states (2 bits + "all-zero" flag each), beside the old segment's length;
-//   * eight standard exponential variates of the branch's stream (:398);
-// -- and exchange them through LDS; then all eight walk the state machine redundantly (same inputs, same results, one of them
-// stores): merged segments (:54) are completed and cut by virtual jumps on the fly, so there is no merged-segment scratch.
-// A wave takes 8 branches and runs as long as its longest one needs batches, not segments: one chain on 20 000 branches has
-// far more SIMDs than waves, and the latency of the longest wave is what the sweep waits for.
+//   * the standard exponential variates of the branch's stream (:398).
+// Those are computed WAVE-WIDE first: the interior change points of the wave's eight branches are numbered consecutively and
+// taken 64 at a time (two passes for a typical wave), likewise a first allotment of m + 8 variates per branch; then the eight
+// lanes of a branch walk its state machine redundantly (same inputs, same results, one of them stores), reading maps, lengths
+// and variates from LDS.  Merged segments (:54) are completed and cut by virtual jumps on the fly: no merged-segment scratch.
+// What does not fit the wave's LDS windows (NARROW_MAP_WINDOW entries, NARROW_EXP_WINDOW variates: very long branches) and
+// variates beyond the allotment are computed eight at a time by the branch's own lanes.
+// branch_order lists the branches longest first; group g of wave k takes position g * n_waves + k: one of the longest branches
+// and seven progressively shorter ones in every wave.  One chain on 20 000 branches has far more SIMDs than waves: the latency
+// of the slowest wave is what the sweep waits for.
+#ifndef PHM_NARROW_MAP_WINDOW
+#define PHM_NARROW_MAP_WINDOW 192
+#endif
+#ifndef PHM_NARROW_EXP_WINDOW
+#define PHM_NARROW_EXP_WINDOW 256
+#endif
+constexpr int NARROW_MAP_WINDOW = PHM_NARROW_MAP_WINDOW, NARROW_EXP_WINDOW = PHM_NARROW_EXP_WINDOW;
+
+constexpr int NARROW_OUT_STAGE = 32;
 template <int NS>
-__global__ __launch_bounds__(NARROW_BLOCK) void narrow_branch_kernel(NarrowParams<NS> p, int it) {
-  static_assert(NARROW_BLOCK == 64, "one wavefront per workgroup");
-  constexpr int L = NARROW_BRANCH_LANES, GROUPS = NARROW_BLOCK / L;
-  __shared__ uint32_t s_cnt[NS * NS * GROUPS];
-  __shared__ double s_xlen[NARROW_BLOCK];            // exchange: lengths of eight old segments per group,
-  __shared__ uint32_t s_xmap[NARROW_BLOCK];          //           their transition maps,
-  __shared__ double s_xe[NARROW_BLOCK];              //           eight exponential variates per group
-  __shared__ __align__(16) double s_ltab[2 * PHM_LOGTAB_N];        // (1/c_j, log c_j) of the exponential variates (neglog_u32)
+struct BranchLds {
+  static constexpr int MAXG = 8;
+  uint32_t cnt[NS * NS * MAXG];
+  double wlen[NARROW_MAP_WINDOW];                    // wave-wide: lengths of the old segments 1 .. m - 1 of every branch,
+  uint16_t wmap[NARROW_MAP_WINDOW];                  //            their transition maps,
+  double we[NARROW_EXP_WINDOW];                      //            the first variates of every branch
+  double xlen[NARROW_BLOCK];                         // per branch, L at a time: what lies beyond the windows
+  uint32_t xmap[NARROW_BLOCK];
+  double xe[NARROW_BLOCK];
+  double out[MAXG * NARROW_OUT_STAGE];               // new segment lengths of a branch, written out 32 at a time by its lanes
+  int32_t gm[MAXG], gcs[MAXG], gb[MAXG];
+  long long goff[MAXG];
+  alignas(16) double ltab[2 * PHM_LOGTAB_N];         // (1/c_j, log c_j) of the exponential variates (neglog_u32)
+};
+
+// L lanes per branch, 64 / L branches in the wave; the wave's group g takes sorted position first + g * stride
+template <int NS, int L>
+__device__ __forceinline__ void narrow_branch_body(const NarrowParams<NS>& p, int it, int first, int stride, BranchLds<NS>& sh) {
+  constexpr int GROUPS = NARROW_BLOCK / L, OUTW = NARROW_OUT_STAGE;
+  uint32_t* s_cnt = sh.cnt;
+  double* s_wlen = sh.wlen; uint16_t* s_wmap = sh.wmap; double* s_we = sh.we;
+  double* s_xlen = sh.xlen; uint32_t* s_xmap = sh.xmap; double* s_xe = sh.xe; double* s_out = sh.out;
+  int32_t* s_gm = sh.gm; int32_t* s_gcs = sh.gcs; int32_t* s_gb = sh.gb; long long* s_goff = sh.goff;
+  double* s_ltab = sh.ltab;
   const int lane = threadIdx.x;
   const int grp = lane / L, j = lane % L, gbase = grp * L;
   const int r = blockIdx.y;
+#ifdef PHM_DEBUG_LEVEL_CLOCK
+  unsigned long long tk[6];
+  tk[0] = wall_clock64();
+#define PHM_TK(K) tk[K] = wall_clock64()
+#else
+#define PHM_TK(K) do {} while (0)
+#endif
   for (int i = lane; i < 2 * PHM_LOGTAB_N; i += NARROW_BLOCK) s_ltab[i] = logtab_entry(i);
   for (int i = lane; i < NS * NS * GROUPS; i += NARROW_BLOCK) s_cnt[i] = 0u;
-  __syncthreads();
-  // branch_order lists the branches longest first; group g of wave k takes position g * n_waves + k: every wave gets one of
-  // the longest branches and seven progressively shorter ones, so the expensive batch code (executed once per group, the
-  // groups reach it at different moments) adds up to about the same in every wave instead of eight-fold in the first
-  const int idx = grp * (int)gridDim.x + (int)blockIdx.x;
+  const int idx = first + grp * stride;
+  const bool have = idx < p.n_edge;
   const bool KS = p.ks != 0;
   uint32_t err = 0;
-  int segs = 0;
   double acc[NS];
 #pragma unroll
   for (int c = 0; c < NS; ++c) acc[c] = 0.0;
 
-  if (idx < p.n_edge) {
-    const int b = p.branch_order[idx];
-    const uint32_t rep = (uint32_t)(p.replica_offset + r);
-    int32_t* __restrict__ mc = p.mcount + (size_t)r * p.n_edge;
-    const int m = mc[b];
-    const int ps = p.nstate[(size_t)r * p.n_node + p.edge_parent[b]];          // updatenodestates :460-475: the edge's end states
-    const uint32_t ends = (uint32_t)p.dmap_edge[(size_t)r * p.n_edge + b] >> (4 * ps);
-    const int cs = (int)(ends & 3u);
-    if (ends & 4u) err |= DERR_ZERO_PROB;
-    const int64_t o = p.off[b];
-    const int cap = (int)(p.off[b + 1] - o);
-    const double* __restrict__ in = p.dw[it & 1] + (size_t)r * p.total_cap + o;
-    double* __restrict__ out = p.dw[(it & 1) ^ 1] + (size_t)r * p.total_cap + o;
-    const uint32_t ent_s = ENT_BSTATE | (uint32_t)b, ent_e = ENT_BEXP | (uint32_t)b;
+  const int b = p.branch_order[have ? idx : 0];
+  const uint32_t rep = (uint32_t)(p.replica_offset + r);
+  int32_t* __restrict__ mc = p.mcount + (size_t)r * p.n_edge;
+  const int m = have ? mc[b] : 1;
+  const int ps = p.nstate[(size_t)r * p.n_node + p.edge_parent[b]];            // updatenodestates :460-475: the edge's end states
+  const uint32_t ends = (uint32_t)p.dmap_edge[(size_t)r * p.n_edge + b] >> (4 * ps);
+  const int cs = (int)(ends & 3u);
+  if (have && (ends & 4u)) err |= DERR_ZERO_PROB;
+  const int64_t o = p.off[b];
+  const int cap = (int)(p.off[b + 1] - o);
+  const double* __restrict__ dw_in = p.dw[it & 1] + (size_t)r * p.total_cap;
+  const double* __restrict__ in = dw_in + o;
+  double* __restrict__ out = p.dw[(it & 1) ^ 1] + (size_t)r * p.total_cap + o;
+  const uint32_t ent_s = ENT_BSTATE | (uint32_t)b, ent_e = ENT_BEXP | (uint32_t)b;
+  if (j == 0) { s_gm[grp] = m; s_gcs[grp] = cs; s_gb[grp] = b; s_goff[grp] = (long long)o; }
+  __syncthreads();
+  PHM_TK(1);
 
+  // windows: branch g owns map entries [wb[g], wb[g] + m_g - 1) and variates [eb[g], eb[g] + m_g + 8), cut at the window ends
+  int wb[GROUPS + 1], eb[GROUPS + 1];
+  wb[0] = 0; eb[0] = 0;
+#pragma unroll
+  for (int g = 0; g < GROUPS; ++g) {
+    const int mg = s_gm[g];
+    wb[g + 1] = min(wb[g] + (mg - 1), NARROW_MAP_WINDOW);
+    eb[g + 1] = min(eb[g] + (mg + 8), NARROW_EXP_WINDOW);
+  }
+  int my_wb = 0, my_eb = 0, pre = 0, epre = 0;       // this branch's window positions and sizes
+#pragma unroll
+  for (int g = 0; g < GROUPS; ++g)
+    if (g == grp) { my_wb = wb[g]; pre = wb[g + 1] - wb[g]; my_eb = eb[g]; epre = eb[g + 1] - eb[g]; }
+  for (int e0 = 0; e0 < wb[GROUPS]; e0 += NARROW_BLOCK) {      // transition maps, 64 change points at a time
+    const int e = min(e0 + lane, wb[GROUPS] - 1);
+    int g = 0;
+#pragma unroll
+    for (int k = 1; k < GROUPS; ++k) g += (e >= wb[k]) ? 1 : 0;
+    int wbg = 0;
+#pragma unroll
+    for (int k = 1; k < GROUPS; ++k) wbg = (g == k) ? wb[k] : wbg;
+    const int gm = s_gm[g], gcs = s_gcs[g];
+    const int i = e - wbg + 1;                       // old segment 1 .. gm - 1 of branch g
+    const double seglen = dw_in[s_goff[g] + i];
+    int kk = gm - i - 1;
+    if (kk >= p.klong) { if (i < gm - 1) err |= DERR_CAPACITY; kk = p.klong - 1; }
+    const double* beta = p.colL + ((size_t)kk * NS + gcs) * NS;
+    double bv[NS];
+#pragma unroll
+    for (int c = 0; c < NS; ++c) bv[c] = beta[c];
+    const double u = u01(stream_word(p.seed_lo, p.seed_hi, rep, (uint32_t)it, ENT_BSTATE | (uint32_t)s_gb[g], (uint32_t)(i - 1)));
+    uint32_t code = 0;
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+      double pr[NS];
+#pragma unroll
+      for (int c = 0; c < NS; ++c) pr[c] = p.B2[q * NS + c] * bv[c];
+      uint32_t e2 = 0;
+      const int sq = sample_cat<NS>(pr, u, e2);
+      code |= ((uint32_t)sq | (e2 ? 4u : 0u)) << (4 * q);
+    }
+    if (i == gm - 1) code = (uint32_t)gcs * 0x1111u;                           // the last segment ends in the child's state
+    s_wlen[e] = seglen; s_wmap[e] = (uint16_t)code;
+  }
+  PHM_TK(2);
+  for (int e0 = 0; e0 < eb[GROUPS]; e0 += NARROW_BLOCK) {      // exponential variates, 64 at a time
+    const int e = min(e0 + lane, eb[GROUPS] - 1);
+    int g = 0;
+#pragma unroll
+    for (int k = 1; k < GROUPS; ++k) g += (e >= eb[k]) ? 1 : 0;
+    int ebg = 0;
+#pragma unroll
+    for (int k = 1; k < GROUPS; ++k) ebg = (g == k) ? eb[k] : ebg;
+    s_we[e] = neglog_u32(stream_word(p.seed_lo, p.seed_hi, rep, (uint32_t)it, ENT_BEXP | (uint32_t)s_gb[g], (uint32_t)(e - ebg)), s_ltab);
+  }
+  __syncthreads();
+  PHM_TK(3);
+
+  int segs = 0;
+  if (have) {
     int cur_s = (m == 1) ? cs : ps;                  // updatenodestates :469-472 (m == 1: the child end wins)
     double cur_len = in[0];
-    int mnew = 0;
-    uint32_t edraw = 0, ehave = 0;                   // exponential variates consumed / computed so far
+    int mnew = 0, flushed = 0;
+    auto emit = [&](double piece) {                  // one more new segment (all eight lanes alike)
+      if (mnew < cap) {
+        s_out[grp * OUTW + (mnew - flushed)] = piece;
+        if (mnew - flushed == OUTW - 1) {
+#pragma unroll
+          for (int t = 0; t < OUTW; t += L) if (L <= OUTW || t + j < OUTW) out[flushed + t + j] = s_out[grp * OUTW + t + j];
+          flushed += OUTW;
+        }
+      } else {
+        err |= DERR_CAPACITY;
+      }
+      ++mnew;
+    };
+    uint32_t edraw = 0, ehave = (uint32_t)epre;      // exponential variates consumed / available so far
     bool stuck = false;
+    // the next window entries ride in registers: an iteration of the walk is a few dependent operations, an LDS read in the
+    // middle of it would double it
+    double pf_len = s_wlen[my_wb], pf_e = s_we[my_eb];
+    uint32_t pf_map = s_wmap[my_wb];
     for (int i = 1; i <= m; ++i) {
       int si = -1;                                   // i == m: past the last old segment, the running one is complete
       double li = 0.0;
       if (i < m) {
-        if (((i - 1) & (L - 1)) == 0) {              // a new batch of eight old segments: lane j takes segment i + j
-          const int ii = i + j;
-          const int iic = min(ii, m - 1);
-          const double len = in[iic];
-          int kk = m - iic - 1;
-          if (kk >= p.klong) { if (ii < m - 1) err |= DERR_CAPACITY; kk = p.klong - 1; }
-          const double* beta = p.colL + ((size_t)kk * NS + cs) * NS;
-          double bv[NS];
+        uint32_t map_i;
+        if (i - 1 < pre) {
+          li = pf_len; map_i = pf_map;
+          const int nx = my_wb + min(i, pre - 1);
+          pf_len = s_wlen[nx]; pf_map = s_wmap[nx];
+        } else {
+          const int past = i - 1 - pre;              // beyond the wave's window: eight old segments at a time, lane j takes i + j
+          if ((past & (L - 1)) == 0) {
+            const int ii = i + j;
+            const int iic = min(ii, m - 1);
+            const double len = in[iic];
+            int kk = m - iic - 1;
+            if (kk >= p.klong) { if (ii < m - 1) err |= DERR_CAPACITY; kk = p.klong - 1; }
+            const double* beta = p.colL + ((size_t)kk * NS + cs) * NS;
+            double bv[NS];
 #pragma unroll
-          for (int c = 0; c < NS; ++c) bv[c] = beta[c];
-          const double u = u01(stream_word(p.seed_lo, p.seed_hi, rep, (uint32_t)it, ent_s, (uint32_t)max(iic - 1, 0)));
-          uint32_t code = 0;
+            for (int c = 0; c < NS; ++c) bv[c] = beta[c];
+            const double u = u01(stream_word(p.seed_lo, p.seed_hi, rep, (uint32_t)it, ent_s, (uint32_t)max(iic - 1, 0)));
+            uint32_t code = 0;
 #pragma unroll
-          for (int q = 0; q < NS; ++q) {
-            double pr[NS];
+            for (int q = 0; q < NS; ++q) {
+              double pr[NS];
 #pragma unroll
-            for (int c = 0; c < NS; ++c) pr[c] = p.B2[q * NS + c] * bv[c];
-            uint32_t e2 = 0;
-            const int sq = sample_cat<NS>(pr, u, e2);
-            code |= ((uint32_t)sq | (e2 ? 4u : 0u)) << (4 * q);
+              for (int c = 0; c < NS; ++c) pr[c] = p.B2[q * NS + c] * bv[c];
+              uint32_t e2 = 0;
+              const int sq = sample_cat<NS>(pr, u, e2);
+              code |= ((uint32_t)sq | (e2 ? 4u : 0u)) << (4 * q);
+            }
+            if (iic == m - 1) code = (uint32_t)cs * 0x1111u;
+            s_xlen[lane] = len; s_xmap[lane] = code;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
           }
-          if (iic == m - 1) code = (uint32_t)cs * 0x1111u;                     // the last segment ends in the child's state
-          s_xlen[lane] = len; s_xmap[lane] = code;
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
-          __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+          li = s_xlen[gbase + (past & (L - 1))]; map_i = s_xmap[gbase + (past & (L - 1))];
         }
-        const int at = gbase + ((i - 1) & (L - 1));
-        li = s_xlen[at];
-        const uint32_t out_i = s_xmap[at] >> (4 * cur_s);
+        const uint32_t out_i = map_i >> (4 * cur_s);
         si = (int)(out_i & 3u);
         if (out_i & 4u) err |= DERR_ZERO_PROB;
-        if (KS && j == 0) s_cnt[(cur_s * NS + si) * GROUPS + grp] += 1u;       // shortenerbf :1010-1014
+        if (KS && j == 0) atomicAdd(&s_cnt[(cur_s * NS + si) * GROUPS + grp], 1u);      // shortenerbf :1010-1014
         if (si == cur_s) { cur_len = cur_len + li; continue; }                  // :54
-        if (!KS && j == 0) s_cnt[(cur_s * (NS - 1) + (si > cur_s ? si - 1 : si)) * GROUPS + grp] += 1u;   // shortener :65-66
+        if (!KS && j == 0) atomicAdd(&s_cnt[(cur_s * (NS - 1) + (si > cur_s ? si - 1 : si)) * GROUPS + grp], 1u);   // shortener :65-66
       }
       // the merged segment (cur_s, cur_len) is complete: virtual jumps, gaps ~ Exp(Omega + q_ss) until it is used up (:391-410);
       // a segment that is not positive leaves itself and everything after it untouched (the reference's iterators stop
@@ -417,30 +536,35 @@ __global__ __launch_bounds__(NARROW_BLOCK) void narrow_branch_kernel(NarrowParam
         double add = 0.0;
         if (stuck || !(0.0 < len)) {
           stuck = true;
-          if (mnew < cap) { if (j == 0) out[mnew] = len; } else err |= DERR_CAPACITY;
+          emit(len);
           add = len;
-          ++mnew;
         } else {
           double scale = p.scale[0];
 #pragma unroll
           for (int c = 1; c < NS; ++c) scale = (sg == c) ? p.scale[c] : scale;
           double tot = 0.0;
           while (tot < len) {
-            if (edraw == ehave) {                    // the next eight variates of the branch's stream, one per lane
-              s_xe[lane] = neglog_u32(stream_word(p.seed_lo, p.seed_hi, rep, (uint32_t)it, ent_e, ehave + (uint32_t)j), s_ltab);
-              ehave += L;
-              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
-              __builtin_amdgcn_wave_barrier();
-              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+            double ev;
+            if (edraw < (uint32_t)epre) {
+              ev = pf_e;
+              pf_e = s_we[my_eb + min((int)edraw + 1, epre - 1)];
+            } else {
+              if (edraw == ehave) {                  // beyond the allotment: the next eight variates of the stream, one per lane
+                s_xe[lane] = neglog_u32(stream_word(p.seed_lo, p.seed_hi, rep, (uint32_t)it, ent_e, ehave + (uint32_t)j), s_ltab);
+                ehave += L;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+              }
+              ev = s_xe[gbase + (int)((edraw - (uint32_t)epre) & (L - 1))];
             }
-            const double rl = scale * s_xe[gbase + (int)(edraw & (L - 1))];    // :398
+            const double rl = scale * ev;                                      // :398
             ++edraw;
             double piece;
             if ((tot + rl) < len) { piece = rl; tot += rl; }
             else { piece = len - tot; tot = len; }
-            if (mnew < cap) { if (j == 0) out[mnew] = piece; } else err |= DERR_CAPACITY;
+            emit(piece);
             add += piece;
-            ++mnew;
           }
         }
 #pragma unroll
@@ -449,9 +573,17 @@ __global__ __launch_bounds__(NARROW_BLOCK) void narrow_branch_kernel(NarrowParam
       cur_s = si; cur_len = li;
     }
     if (mnew > cap) mnew = cap;
+    for (int t = j; t < mnew - flushed; t += L) out[flushed + t] = s_out[grp * OUTW + t];
     if (j == 0) mc[b] = mnew;
     segs = m + mnew;
   }
+  PHM_TK(4);
+#ifdef PHM_DEBUG_LEVEL_CLOCK
+  if (it == 30 && r == 0 && (blockIdx.x == 0 || blockIdx.x == 7 || blockIdx.x == 1200 || blockIdx.x == gridDim.x - 1) && j == 0)
+    printf("branchclock block %d grp %d m %d: loads %d maps %d exps %d walk %d ticks (windows %d %d) start %llu\n", (int)blockIdx.x, grp, m,
+           (int)(tk[1] - tk[0]), (int)(tk[2] - tk[1]), (int)(tk[3] - tk[2]), (int)(tk[4] - tk[3]), wb[GROUPS], eb[GROUPS], tk[0]);
+#endif
+#undef PHM_TK
   if (err) atomicOr(p.err, err);
 
   // one row per wavefront: the eight branches' sums, added in a fixed tree (every lane of a group holds the group's values)
@@ -475,6 +607,18 @@ __global__ __launch_bounds__(NARROW_BLOCK) void narrow_branch_kernel(NarrowParam
     for (int g2 = 0; g2 < GROUPS; ++g2) v += s_cnt[lane * GROUPS + g2];
     part[NS + lane] = (double)v;
   }
+}
+
+// The longest branches set the duration of the kernel: the first n_long (sorted order) get a wave each -- one control flow, the
+// walk at its shortest --, the others go eight to a wave: group g of wave k takes position n_long + g * n_waves8 + k, one of
+// the longer branches and seven progressively shorter ones in every wave.
+template <int NS>
+__global__ __launch_bounds__(NARROW_BLOCK) void narrow_branch_kernel(NarrowParams<NS> p, int it, int n_long) {
+  static_assert(NARROW_BLOCK == 64, "one wavefront per workgroup");
+  __shared__ BranchLds<NS> sh;
+  const int k = (int)blockIdx.x;
+  if (k < n_long) narrow_branch_body<NS, 64>(p, it, k, 0, sh);
+  else narrow_branch_body<NS, 8>(p, it, n_long + (k - n_long), (int)gridDim.x - n_long, sh);
 }
 
 // Statistics row of one chain: every column is the sum of the per-wavefront rows of the branch kernel, added in a fixed order
@@ -542,9 +686,9 @@ hipError_t launch_narrow_sweep(const NarrowParams<NS>& p, const std::vector<int3
                        it, DL);
   else
     hipLaunchKernelGGL((narrow_downwalk_kernel<NS, false>), dim3(S), dim3(NARROW_WALK_BLOCK), 0, stream, p, it, DL);
-  constexpr int per_wave = NARROW_BLOCK / NARROW_BRANCH_LANES;
-  const unsigned n_waves = (unsigned)((p.n_edge + per_wave - 1) / per_wave);
-  hipLaunchKernelGGL(narrow_branch_kernel<NS>, dim3(n_waves, S), dim3(NARROW_BLOCK), 0, stream, p, it);
+  const int n_long = std::min(p.n_edge / 16, 128);
+  const unsigned n_waves = (unsigned)(n_long + (p.n_edge - n_long + 7) / 8);
+  hipLaunchKernelGGL(narrow_branch_kernel<NS>, dim3(n_waves, S), dim3(NARROW_BLOCK), 0, stream, p, it, n_long);
   hipLaunchKernelGGL(narrow_stats_kernel<NS>, dim3(S, NS + (p.ks ? NS * NS : NS * (NS - 1)) + 1), dim3(256), 0, stream, p, it,
                      (int)n_waves);
   if (p.reduce) {
