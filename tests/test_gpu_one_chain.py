@@ -1,0 +1,116 @@
+"""The one-chain mapping (phm_narrow.hip: what a plain R call gets) on the tree shapes its latency-shaped kernels special-case:
+subtree clusters in several tiers, a walk with hundreds of levels, node states beyond the LDS copy, windows of the branch kernel.
+Counts bit-exact against the CPU oracle, dwell sums within 1e-10 (src/phylomap.cpp:775-785 one sweep; :503-529, :591-663, :264-413)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from phylomap_amd import _lib, api, synth, treeorder
+
+pytestmark = pytest.mark.gpu
+
+
+def _orders(z):
+    return treeorder.pruningwiseedgeorder(z), treeorder.makenodelist(z), treeorder.myreorder(z)
+
+
+def _tree_from_edges(edge, lens, Q, pid, seed, init_segments=2):
+    """The tail of synth.make_tree for a hand-made topology (cladewise edge rows, tips 1..T, root T + 1)."""
+    T = edge.shape[0] // 2 + 1
+    states = np.asarray(synth.simulate_tips(edge, lens, Q, pid, seed), dtype=np.int32)
+    maps, mapnames = [], []
+    node_states = np.ones((edge.shape[0], 2), dtype=np.int32)
+    for r in range(edge.shape[0]):
+        child = int(edge[r, 1])
+        end = int(states[child - 1]) if child <= T else 1
+        maps.append(np.full(init_segments, lens[r] / init_segments))
+        mapnames.append(np.array([1] * (init_segments - 1) + [end], dtype=np.int32))
+        node_states[r, 1] = end
+    return {"edge": edge, "Nnode": T - 1, "edge.length": lens, "states": states, "maps": maps, "mapnames": mapnames,
+            "node.states": node_states}
+
+
+def _ladder(T, mean_len, seed):
+    """Caterpillar: internal node k hangs tip k and internal node k + 1; the last one hangs two tips.  Depth T - 1."""
+    rs = np.random.default_rng(seed)
+    edges = []
+    for k in range(T - 1):
+        node = T + 1 + k
+        edges.append((node, k + 1))                                  # a tip
+        edges.append((node, node + 1) if k < T - 2 else (node, T))   # the next rung / the last tip
+    edge = np.asarray(edges, dtype=np.int32)
+    # cladewise: a node's rows follow the row that leads to it -- here they already do (tip row, then the rung and its subtree)
+    return edge, rs.exponential(mean_len, size=edge.shape[0])
+
+
+def _same(got, want, n, ks=False):
+    ncnt = n * n if ks else n * (n - 1)
+    np.testing.assert_array_equal(got[..., n:n + ncnt], want[..., n:n + ncnt])
+    np.testing.assert_allclose(got[..., :n], want[..., :n], rtol=1e-10, atol=0)
+    np.testing.assert_array_equal(got[..., n + ncnt:], want[..., n + ncnt:])
+
+
+@pytest.mark.parametrize("fn,variant", [("sumstatMCMC_bigtree", O.BIGTREE), ("sumstatMCMCks_sweep", O.KS)])
+def test_ladder_tree_many_cluster_tiers_and_a_walk_of_699_levels(fn, variant):
+    """700 tips in a caterpillar: three tiers of subtree clusters (256 + 256 + 187 nodes, each a 256-level chain), 699 walk levels
+    of one edge each, and the ks sweep's re-sampled tips on every rung."""
+    Q = synth.config_Q(2)
+    Omega = 1.25 * float(np.max(np.abs(np.diag(Q))))
+    pid = np.full(4, 0.25)
+    edge, lens = _ladder(700, 1.0 / Omega, 5)
+    z = _tree_from_edges(edge, lens, Q, pid, seed=9)
+    if variant == O.KS:                              # only the parity of a tip state is observed
+        z = dict(z, states=((z["states"] - 1) % 2 + 1).astype(np.int32))
+        for b, (p_, c_) in enumerate(edge):
+            if c_ <= 700:
+                z["mapnames"][b][-1] = z["states"][c_ - 1]
+    nen, nodelist, root = _orders(z)
+    S, N = 3, 6
+    got = getattr(api, fn)(z, Q, pid, Omega, N, seed=77, n_replicas=S, mapping="branches")
+    for r in range(S):
+        want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(4) + Q / Omega, Omega, nen, nodelist, root, N, variant=variant, seed=77, replica=r)
+        assert rc == 0
+        _same(got[r], want, 4, ks=variant == O.KS)
+
+
+def test_one_chain_on_70000_tips_node_states_beyond_the_lds_copy():
+    """69 999 internal nodes: the walk keeps the node states in the global array (the LDS copy holds 61 440), the pruning sweep
+    has three tiers; three sweeps of one chain against the oracle, and the tree-length invariant."""
+    z, Q, pid, Omega = synth.config_problem(3, n_tips=70000)
+    nen, nodelist, root = _orders(z)
+    N = 3
+    eng = _lib.Engine(z, Q, pid, Omega, N, variant=_lib.PHM_MCMC_BIGTREE, seed=4, n_replicas=1, mapping="branches")
+    eng.run(N); eng.sync()
+    info = eng.info()
+    assert info.mapping == _lib.MAPPING["branches"] and info.recoveries == 0
+    got = eng.stats(0, N)[0]
+    eng.close()
+    want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(4) + Q / Omega, Omega, nen, nodelist, root, N, variant=O.BIGTREE, seed=4, replica=0)
+    assert rc == 0
+    _same(got, want, 4)
+    np.testing.assert_allclose(got[:, :4].sum(1), float(z["edge.length"].sum()), rtol=1e-11)
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_long_paths_beyond_the_branch_kernel_windows_two_and_three_states(n):
+    """300 segments per branch on 40 tips: every wave of the branch kernel overflows its map window (192 change points) and its
+    variate window (256), for 2 and 3 states (a quad of the pruning kernel then has idle lanes)."""
+    Q = {2: synth.config_Q(1), 3: np.array([[-.3, .2, .1], [.05, -.15, .1], [.2, .2, -.4]])}[n]
+    Omega = 1.25 * float(np.max(np.abs(np.diag(Q))))
+    pid = np.full(n, 1.0 / n)
+    z = synth.make_tree(40, Q, Omega, 31, pid, init_segments=300)
+    nen, nodelist, root = _orders(z)
+    got = api.sumstatMCMC(z, Q, pid, Omega, 5, seed=3, n_replicas=2, mapping="branches")
+    for r in range(2):
+        want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(n) + Q / Omega, Omega, nen, nodelist, root, 5, seed=3, replica=r)
+        assert rc == 0
+        _same(got[r], want, n)
+
+
+def test_automatic_mapping_follows_tree_size():
+    """profiles/r03_probe_crossover.log: the branch mapping up to ~70 chains on 10 000 tips, ~200 on 1 000 tips, ~1 000 on 100."""
+    for cfg, S, want in [(3, 64, "branches"), (3, 96, "tiles"), (2, 128, "branches"), (2, 512, "tiles"), (1, 512, "branches")]:
+        z, Q, pid, Omega = synth.config_problem(cfg)
+        eng = _lib.Engine(z, Q, pid, Omega, 2, variant=_lib.PHM_MCMC_BIGTREE, seed=1, n_replicas=S)
+        assert eng.info().mapping == _lib.MAPPING[want], (cfg, S)
+        eng.close()
