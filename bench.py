@@ -284,13 +284,18 @@ def main():
         """the reference's own calling pattern: ONE chain (every R/sumstat*.R call), on the mapping the library picks for it"""
         z, Q, pid, Om = synth.config_problem(cfg)
         E = z["edge"].shape[0]
-        one = _lib.Engine(z, Q, pid, Om, sweeps + 4, variant=_lib.PHM_MCMC_BIGTREE, seed=1, n_replicas=1, device=local_rank)
-        one.run(4); one.sync()
-        t1 = time.perf_counter(); one.run(sweeps); one.sync(); d1 = time.perf_counter() - t1
-        mp = {1: "one lane per replica", 2: "one lane per branch (n <= 4) / one wave per (replica, branch)", 3: "one lane per replica, wave per (tile, item)"}[one.info().mapping]
-        one.close()
+        res = {}
+        for S1 in (1, 8):                                 # 8: a handful of chains on the same mapping (options(phylomap.hip.replicas = 8))
+            one = _lib.Engine(z, Q, pid, Om, sweeps + 40, variant=_lib.PHM_MCMC_BIGTREE, seed=1, n_replicas=S1, device=local_rank)
+            one.run(40); one.sync()                       # the paths reach their stationary length (two segments per branch at the start)
+            t1 = time.perf_counter(); one.run(sweeps); one.sync(); d1 = time.perf_counter() - t1
+            mp = {1: "one lane per replica", 2: "branch mapping: subtree clusters (8 lanes per node), transition maps + walk, 8 lanes per branch (n <= 4) / "
+                                                "one wave per (replica, branch) (n > 4)", 3: "one lane per replica, wave per (tile, item)"}[one.info().mapping]
+            one.close()
+            res[S1] = (mp, d1 / sweeps * 1e3, S1 * E * sweeps / d1)
         return {"workload": f"C{cfg}, ONE chain: what the R call sumstatMCMC_bigtree(z, Q, pid, Omega, N) gets (R/sumstatMCMC_bigtree.R:21-29)",
-                "mapping": mp, "ms_per_sweep": d1 / sweeps * 1e3, "realisations_per_s": E * sweeps / d1}
+                "mapping": res[1][0], "ms_per_sweep": res[1][1], "realisations_per_s": res[1][2],
+                "eight_chains": {"ms_per_sweep": res[8][1], "realisations_per_s": res[8][2]}}
 
     # ---- headline ------------------------------------------------------------------------------------------------
     K, W = args.steps, args.warmup
@@ -358,7 +363,7 @@ def main():
             out["speedup_vs_cpu_1core_faithful"] = out["value"] / cpu[cfg]["faithful_value"]
             out["speedup_vs_cpu_all_cores"] = out["value"] / cpu[cfg]["all_cores"]["value"]
     if rank == 0 and world == 1:
-        sc = one_chain(cfg, 100)
+        sc = one_chain(cfg, 400)
         if cfg in cpu:
             sc["speedup_vs_cpu_1core"] = sc["realisations_per_s"] / cpu[cfg]["value"]
             sc["speedup_vs_cpu_1core_faithful"] = sc["realisations_per_s"] / cpu[cfg]["faithful_value"]
@@ -394,7 +399,7 @@ def main():
                 blk["speedup_vs_cpu_1core"] = blk["realisations_per_s"] / cpu[c]["value"]
             blocks[key] = blk
         # the reference's own calling pattern -- ONE chain -- and an alignment-sized job, on the C2 tree
-        blocks["C2_single_chain"] = one_chain(2, 100)
+        blocks["C2_single_chain"] = one_chain(2, 400)
         z, Q, pid, Om = synth.config_problem(2)
         E2 = z["edge"].shape[0]
         mid = _lib.Engine(z, Q, pid, Om, 44, variant=_lib.PHM_MCMC_BIGTREE, seed=1, n_replicas=4096, reduce=True, device=local_rank, mapping="tiles")

@@ -281,7 +281,6 @@ void fill_narrow_params(phm_engine* e, phm::NarrowParams<NS>& p, const phm_optio
   p.colL = e->d_nw_colL.as<double>(); p.rowL = e->d_nw_rowL.as<double>(); p.maskL = e->d_nw_maskL.as<double>();
   p.tips = e->d_tips.as<uint8_t>();
   p.mcount = e->d_nw_mcount.as<int32_t>(); p.dw[0] = e->d_nw_dwA.as<double>(); p.dw[1] = e->d_nw_dwB.as<double>();
-  p.mstate = e->d_nw_mstate.as<uint8_t>(); p.mlen = e->d_nw_mlen.as<double>(); p.estate = e->d_nw_estate.as<uint8_t>();
   p.PL = e->d_PL.as<double>(); p.nstate = e->d_nstate.as<uint8_t>(); p.part = e->d_nw_part.as<double>();
   p.rowbuf = e->d_nw_rowbuf.as<double>(); p.stats = e->d_stats.as<double>();
   p.dmap = e->d_nw_dmap.as<uint16_t>();
@@ -390,7 +389,8 @@ int32_t narrow_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
   size_t free_b = 0, total_b = 0;
   HIPCHK(hipMemGetInfo(&free_b, &total_b));
   const size_t part_cols = e->wide ? (size_t)n + 1 : (size_t)n + n * n + 1;      // n > 4: counters go through atomics, not per branch
-  const size_t need = 3 * dw_bytes + (size_t)S * e->nw_total_cap + stats_bytes + sizeof(double) * (3 * tab + (size_t)S * E * part_cols + (e->wide ? 2 * (size_t)S * e->dcols : 0));
+  const size_t n_dw = e->wide ? 3 : 2;             // n <= 4: the branch kernel needs no merged-segment scratch (phm_narrow.hip)
+  const size_t need = n_dw * dw_bytes + (e->wide ? (size_t)S * e->nw_total_cap : 0) + stats_bytes + sizeof(double) * (3 * tab + (size_t)S * E * part_cols + (e->wide ? 2 * (size_t)S * e->dcols : 0));
   if (need + (64u << 20) > free_b) {
     char buf[256];
     std::snprintf(buf, sizeof buf, "engine needs %.2f GiB of HBM, %.2f GiB free (reduce n_replicas or max_iters)", need / 1073741824.0, free_b / 1073741824.0);
@@ -404,9 +404,11 @@ int32_t narrow_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
   HIPCHK(e->d_tips.alloc(e->tips_host.size()));
   HIPCHK(e->d_nw_mcount.alloc(sizeof(int32_t) * (size_t)S * E));
   HIPCHK(e->d_nw_dwA.alloc(dw_bytes)); HIPCHK(e->d_nw_dwB.alloc(dw_bytes));
-  HIPCHK(e->d_nw_mstate.alloc((size_t)S * e->nw_total_cap));
-  HIPCHK(e->d_nw_mlen.alloc(dw_bytes));
-  HIPCHK(e->d_nw_estate.alloc((size_t)S * E * 2));
+  if (e->wide) {
+    HIPCHK(e->d_nw_mstate.alloc((size_t)S * e->nw_total_cap));
+    HIPCHK(e->d_nw_mlen.alloc(dw_bytes));
+    HIPCHK(e->d_nw_estate.alloc((size_t)S * E * 2));
+  }
   HIPCHK(e->d_PL.alloc(sizeof(double) * (size_t)S * Nn * n));
   HIPCHK(e->d_nstate.alloc((size_t)S * Nn));
   HIPCHK(e->d_nw_part.alloc(sizeof(double) * (size_t)S * E * part_cols));
@@ -429,7 +431,7 @@ int32_t narrow_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
   HIPCHK(e->d_stats.alloc(stats_bytes));
   HIPCHK(e->d_err.alloc(sizeof(uint32_t))); HIPCHK(e->d_seg.alloc(sizeof(unsigned long long)));
   if (e->reduce) HIPCHK(e->d_red.alloc(sizeof(double) * (size_t)max_iters * e->dcols));
-  e->bytes = (int64_t)(3 * dw_bytes + e->d_nw_mstate.bytes + e->d_nw_part.bytes + e->d_PL.bytes + e->d_stats.bytes + e->d_red.bytes +
+  e->bytes = (int64_t)(n_dw * dw_bytes + e->d_nw_mstate.bytes + e->d_nw_part.bytes + e->d_PL.bytes + e->d_stats.bytes + e->d_red.bytes +
                        sizeof(double) * 3 * tab + e->d_nw_mcount.bytes);
   HIPCHK(hipMemcpy(e->d_up.p, s.up.data(), e->d_up.bytes, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(e->d_down.p, s.down.data(), e->d_down.bytes, hipMemcpyHostToDevice));

@@ -58,9 +58,6 @@ struct NarrowParams {
   const uint8_t* tips;                       // [n_tips] or [replica][n_tips], 0-based
   int32_t* mcount;                           // [replica][n_edge]
   double* dw[2];                             // [replica][total_cap] each; sweep `it` reads dw[it & 1], writes the other
-  double* mlen;                              // [replica][total_cap] lengths of the merged segments (scratch of one sweep)
-  uint8_t* mstate;                           // [replica][total_cap] ... and their states
-  uint8_t* estate;                           // [replica][n_edge][2] end states (parent side, child side) of every edge
   double* PL;                                // [replica][n_node][NS]
   uint8_t* nstate;                           // [replica][n_node]
   uint16_t* dmap;                            // [replica][n_edge] transition map of every edge (sampling sweep), down_lv order
