@@ -254,30 +254,32 @@ __global__ __launch_bounds__(WB_BLOCK) void wb_branch_kernel(WideBranchParams p,
   if (err) atomicOr(p.err, err);
 }
 
-// Statistics row of one replica: dwell columns = sums of the per-branch values in edge order (thread c owns column c and
-// adds the branches one after the other: a fixed order, identical from run to run).  The [edge][column] block of a replica
-// is streamed through LDS in chunks of 64 edges, so every cache line is read once and coalesced; counters are copied out
-// of the atomic buffer (and cleared), (ks) the root state appended.
-constexpr int WB_STATS_CHUNK = 64;
+// Statistics row of one replica.  Dwell columns = sums of the per-branch values, one workgroup per (replica, column): thread t
+// adds branches t, t + 256, ... then a fixed tree over the 256 partial sums -- a fixed order, identical from run to run, and the
+// n + 1 columns of a row reduced side by side (one workgroup streaming the whole [edge][column] block took 0.36 ms per sweep for
+// one chain on C5: 40 % of the sweep).  Counters are copied out of the atomic buffer (and cleared) by the same workgroups, a
+// slice each; (ks) the root state appended.
 __global__ __launch_bounds__(256) void wb_stats_kernel(WideBranchParams p) {
-  extern __shared__ double s_chunk[];               // [WB_STATS_CHUNK][n + 1]
-  const int r = blockIdx.x, n = p.n_states, tid = threadIdx.x;
+  __shared__ double red[256];
+  const int r = blockIdx.x, c = blockIdx.y, n = p.n_states, tid = threadIdx.x;
   const int ncnt = p.count_self ? n * n : n * (n - 1);
   const int pc = n + 1;                             // column n: segments read + written
   const double* __restrict__ part = p.part + (size_t)r * p.n_edge * pc;
   double acc = 0.0;
-  for (int e0 = 0; e0 < p.n_edge; e0 += WB_STATS_CHUNK) {
-    const int ne = min(WB_STATS_CHUNK, p.n_edge - e0);
-    for (int i = tid; i < ne * pc; i += 256) s_chunk[i] = part[(size_t)e0 * pc + i];
-    __syncthreads();
-    if (tid < pc) for (int k = 0; k < ne; ++k) acc += s_chunk[k * pc + tid];
+  for (int e = tid; e < p.n_edge; e += 256) acc += part[(size_t)e * pc + c];
+  red[tid] = acc;
+  __syncthreads();
+  for (int half = 128; half >= 1; half >>= 1) {
+    if (tid < half) red[tid] = red[tid] + red[tid + half];
     __syncthreads();
   }
-  if (tid < n) p.rowbuf[(size_t)r * p.n_cols + tid] = acc;
-  else if (tid == n) atomicAdd(p.segcnt, (unsigned long long)acc);
+  if (tid == 0) {
+    if (c < n) p.rowbuf[(size_t)r * p.n_cols + c] = red[0];
+    else atomicAdd(p.segcnt, (unsigned long long)red[0]);
+  }
   double* cnt = p.cnt + (size_t)r * p.n_cols + n;
-  for (int k = tid; k < ncnt; k += 256) { p.rowbuf[(size_t)r * p.n_cols + n + k] = cnt[k]; cnt[k] = 0.0; }
-  if (p.ks && tid == 0)                                                        // root state, 0-based (:1350-1352)
+  for (int k = c * 256 + tid; k < ncnt; k += 256 * pc) { p.rowbuf[(size_t)r * p.n_cols + n + k] = cnt[k]; cnt[k] = 0.0; }
+  if (p.ks && tid == 0 && c == 0)                                              // root state, 0-based (:1350-1352)
     p.rowbuf[(size_t)r * p.n_cols + n + ncnt] = (double)p.nstate[(size_t)r * p.n_node + p.root];
 }
 
@@ -319,7 +321,7 @@ hipError_t launch_wbranch_sweep(const WideBranchParams& p, const std::vector<int
     if (cnt > 0) hipLaunchKernelGGL(wb_down_kernel, dim3((cnt + WPB - 1) / WPB, S), dim3(WB_BLOCK), 0, stream, p, it, down_off[l], down_off[l + 1]);
   }
   hipLaunchKernelGGL(wb_branch_kernel, dim3((p.n_edge + WPB - 1) / WPB, S), dim3(WB_BLOCK), (size_t)p.n_states * p.ell2_w * 12, stream, p, it);
-  hipLaunchKernelGGL(wb_stats_kernel, dim3(S), dim3(256), sizeof(double) * WB_STATS_CHUNK * (p.n_states + 1), stream, p);
+  hipLaunchKernelGGL(wb_stats_kernel, dim3(S, (unsigned)(p.n_states + 1)), dim3(256), 0, stream, p);
   const int64_t items = (int64_t)(p.reduce ? p.n_tiles : p.n_rep) * p.n_cols;
   hipLaunchKernelGGL(wb_emit_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, p, it);
   return hipGetLastError();
