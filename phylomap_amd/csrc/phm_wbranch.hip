@@ -52,12 +52,17 @@ __global__ __launch_bounds__(WB_BLOCK) void wb_up_kernel(WideBranchParams p, int
   } else {
     l = stage_model(p, smem);              // ends with a barrier
   }
+  // TWO waves per node, one per child: the two chains B^(m-1) PL[child] are the longest dependent line of a level (up to
+  // ~15 steps of n fused multiply-adds each) and do not depend on one another; the "second" child's wave hands its vector
+  // over through LDS and the "first" child's wave finishes the node.
+  __shared__ double s_second[WB_BLOCK / 128][64];
   const int n = p.n_states, lane = threadIdx.x & 63;
-  const int idx = begin + blockIdx.x * (WB_BLOCK / 64) + (threadIdx.x >> 6);
+  const int wave = threadIdx.x >> 6, slot = wave >> 1, which = 1 - (wave & 1);      // even wave: child[1] ("first"), odd wave: child[0]
+  const int idx = begin + blockIdx.x * (WB_BLOCK / 128) + slot;
   const int r = blockIdx.y;
-  if (idx >= end) return;                         // whole waves only; no barrier below this line
+  const bool live = idx < end;
   const int c = lane < n ? lane : n - 1;
-  const UpStep st = p.up[p.up_order[idx]];
+  const UpStep st = p.up[p.up_order[live ? idx : begin]];
   const int32_t* __restrict__ mc = p.mcount + (size_t)r * p.n_edge;
   double* PLr = p.PL + (size_t)r * p.n_node * n;
   const uint8_t* __restrict__ tips = p.tips_per_replica ? p.tips + (size_t)r * p.n_tips : p.tips;
@@ -74,12 +79,16 @@ __global__ __launch_bounds__(WB_BLOCK) void wb_up_kernel(WideBranchParams p, int
     else for (int i = 0; i < k; ++i) v = coop_matvec(l.Bc, v, n, l.ldn, c);
     return v;
   };
-  double x = child_vec(st.child[1], mc[st.edge[1]] - 1);        // "first"  (:508)
-  const double y = child_vec(st.child[0], mc[st.edge[0]] - 1);  // "second" (:509)
-  x = x * y;                                                    // :510
-  if (p.normalise) x = x / coop_sum(x, n);                      // :525
-  if (lane < n) PLr[(size_t)st.parent * n + lane] = x;
-  if (err) atomicOr(p.err, err);
+  double x = 0.0;
+  if (live) x = child_vec(st.child[which], mc[st.edge[which]] - 1);       // which = 1: "first" (:508), 0: "second" (:509)
+  if (which == 0) s_second[slot][lane] = x;
+  __syncthreads();
+  if (live && which == 1) {
+    x = x * s_second[slot][lane];                               // :510
+    if (p.normalise) x = x / coop_sum(x, n);                    // :525
+    if (lane < n) PLr[(size_t)st.parent * n + lane] = x;
+  }
+  if (live && err) atomicOr(p.err, err);
 }
 
 __global__ __launch_bounds__(WB_BLOCK) void wb_root_kernel(WideBranchParams p, int it) {
@@ -313,7 +322,7 @@ hipError_t launch_wbranch_sweep(const WideBranchParams& p, const std::vector<int
   }
   for (size_t l = 0; l + 1 < up_off.size(); ++l) {
     const int cnt = up_off[l + 1] - up_off[l];
-    if (cnt > 0) hipLaunchKernelGGL(wb_up_kernel, dim3((cnt + WPB - 1) / WPB, S), dim3(WB_BLOCK), p.ell_w > 0 ? (size_t)p.n_states * p.ell_w * 12 : lds, stream, p, up_off[l], up_off[l + 1]);
+    if (cnt > 0) hipLaunchKernelGGL(wb_up_kernel, dim3((cnt + WPB / 2 - 1) / (WPB / 2), S), dim3(WB_BLOCK), p.ell_w > 0 ? (size_t)p.n_states * p.ell_w * 12 : lds, stream, p, up_off[l], up_off[l + 1]);
   }
   hipLaunchKernelGGL(wb_root_kernel, dim3((S + WPB - 1) / WPB), dim3(WB_BLOCK), 0, stream, p, it);
   for (size_t l = 0; l + 1 < down_off.size(); ++l) {
