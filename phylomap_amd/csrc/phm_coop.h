@@ -28,9 +28,26 @@ __device__ __forceinline__ int wave_max_w(int v) {
 // y <- M y with lanes over rows: M row-major in LDS with an ODD row stride ldn, so the 64 lanes reading M[c][j]
 // (stride ldn doubles) fall on distinct banks, and the transposed access M[q][c] is contiguous anyway
 __device__ __forceinline__ double coop_matvec(const double* __restrict__ M, double v, int n, int ldn, int c) {
+  // The chain is one dependent FMA per term; what must not sit between two of them is the LDS latency of the matrix entry
+  // (a read + s_waitcnt per term is ~100 cycles against ~10 for readlane + FMA).  Eight entries of the row are requested while
+  // the previous eight are consumed; the order of the terms (j ascending, fused) is unchanged.
   const double* row = M + c * ldn;
   double acc = 0.0;
-  for (int j = 0; j < n; ++j) acc = __builtin_fma(row[j], readlane_f64(v, j), acc);
+  double cur[8], nxt[8];
+  const int n8 = n & ~7;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) cur[t] = row[min(t, n - 1)];
+  for (int j = 0; j < n8; j += 8) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) nxt[t] = row[min(j + 8 + t, n - 1)];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc = __builtin_fma(cur[t], readlane_f64(v, j + t), acc);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) cur[t] = nxt[t];
+  }
+#pragma unroll
+  for (int t = 0; t < 7; ++t)
+    if (n8 + t < n) acc = __builtin_fma(cur[t], readlane_f64(v, n8 + t), acc);
   return acc;
 }
 
