@@ -51,6 +51,36 @@ __device__ __forceinline__ double coop_matvec(const double* __restrict__ M, doub
   return acc;
 }
 
+// The same product with the vector passed through LDS as well (svec: 64 doubles of the calling wave, 16-byte aligned): v_readlane
+// into an SGPR pair and its hazards cost ~3x the FMA they feed; a same-address LDS read is a broadcast and rides in the same
+// batches of eight as the matrix entries.  Same terms, same order.
+__device__ __forceinline__ double coop_matvec_lds(const double* __restrict__ M, double* __restrict__ svec, double v, int n, int ldn,
+                                                  int c, int lane) {
+  const double* row = M + c * ldn;
+  svec[lane] = v;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+  double acc = 0.0;
+  double cur[8], nxt[8], vc[8], vn[8];
+  const int n8 = n & ~7;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) { cur[t] = row[min(t, n - 1)]; vc[t] = svec[t]; }
+  for (int j = 0; j < n8; j += 8) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { nxt[t] = row[min(j + 8 + t, n - 1)]; vn[t] = svec[(j + 8 + t) & 63]; }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc = __builtin_fma(cur[t], vc[t], acc);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { cur[t] = nxt[t]; vc[t] = vn[t]; }
+  }
+#pragma unroll
+  for (int t = 0; t < 7; ++t)
+    if (n8 + t < n) acc = __builtin_fma(cur[t], vc[t], acc);
+  __builtin_amdgcn_wave_barrier();                   // every lane has read the vector before the next product overwrites it
+  return acc;
+}
+
 // the same product for a matrix with at most w non-zeros per row, kept in ELLPACK form (columns ascending; padding entries
 // have value 0): lane c gathers v[col] of its own non-zeros.  Skipping the exact zeros of a row leaves its fused chain
 // unchanged bit for bit -- fma(0, x, acc) = acc for finite x.

@@ -56,6 +56,7 @@ __global__ __launch_bounds__(WB_BLOCK) void wb_up_kernel(WideBranchParams p, int
   // ~15 steps of n fused multiply-adds each) and do not depend on one another; the "second" child's wave hands its vector
   // over through LDS and the "first" child's wave finishes the node.
   __shared__ double s_second[WB_BLOCK / 128][64];
+  __shared__ __align__(16) double s_vec[WB_BLOCK / 64][64];        // the chain vector of each wave (coop_matvec_lds)
   const int n = p.n_states, lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6, slot = wave >> 1, which = 1 - (wave & 1);      // even wave: child[1] ("first"), odd wave: child[0]
   const int idx = begin + blockIdx.x * (WB_BLOCK / 128) + slot;
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(WB_BLOCK) void wb_up_kernel(WideBranchParams p, int
     }
     double v = PLr[(size_t)child * n + c];
     if (ell_w > 0) for (int i = 0; i < k; ++i) v = coop_matvec_ell(s_ecol, s_eval, v, ell_w, c);
-    else for (int i = 0; i < k; ++i) v = coop_matvec(l.Bc, v, n, l.ldn, c);
+    else for (int i = 0; i < k; ++i) v = coop_matvec_lds(l.Bc, s_vec[wave], v, n, l.ldn, c, lane);
     return v;
   };
   double x = 0.0;
