@@ -1180,11 +1180,17 @@ int32_t phm_engine_run(phm_engine* e, int32_t n_iters, void* hip_stream) {
     hipError_t le = hipSuccess;
     for (int i = 0; i < n_iters && le == hipSuccess; ++i) {
       const int it = e->iters_done + i;
-      if (e->n == 2) le = phm::launch_narrow_sweep<2>(e->n2, e->nw_tier_off, e->nw_walk_off, it, stream);
-      if (e->n == 3) le = phm::launch_narrow_sweep<3>(e->n3, e->nw_tier_off, e->nw_walk_off, it, stream);
-      if (e->n == 4) le = phm::launch_narrow_sweep<4>(e->n4, e->nw_tier_off, e->nw_walk_off, it, stream);
+      if (e->n == 2) le = phm::launch_narrow_sweep<2>(e->n2, e->nw_tier_off, e->nw_walk_off, it, stream, i > 0);
+      if (e->n == 3) le = phm::launch_narrow_sweep<3>(e->n3, e->nw_tier_off, e->nw_walk_off, it, stream, i > 0);
+      if (e->n == 4) le = phm::launch_narrow_sweep<4>(e->n4, e->nw_tier_off, e->nw_walk_off, it, stream, i > 0);
       if (e->wide) le = phm::launch_wbranch_sweep(e->pwb, e->nw_up_off, e->nw_down_off, it, stream);
       launches += (int)(e->nw_up_off.size() + e->nw_down_off.size()) + 2;
+    }
+    if (n_iters > 0 && le == hipSuccess && !e->wide) {       // the last sweep's statistics (phm_narrow.hip defers them by one launch)
+      const int it = e->iters_done + n_iters - 1;
+      if (e->n == 2) le = phm::launch_narrow_stats<2>(e->n2, it, stream);
+      if (e->n == 3) le = phm::launch_narrow_stats<3>(e->n3, it, stream);
+      if (e->n == 4) le = phm::launch_narrow_stats<4>(e->n4, it, stream);
     }
     HIPCHK(le);
   }

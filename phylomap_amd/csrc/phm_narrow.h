@@ -72,6 +72,9 @@ struct NarrowParams {
 // one full sweep (iteration index `it`) enqueued on `stream`; tier boundaries (clusters) and depth-level boundaries are host arrays
 template <int NS>
 hipError_t launch_narrow_sweep(const NarrowParams<NS>& p, const std::vector<int32_t>& tier_off,
-                               const std::vector<int32_t>& walk_off, int it, hipStream_t stream);
+                               const std::vector<int32_t>& walk_off, int it, hipStream_t stream, bool stats_pending);
+// statistics of the last sweep of a call (the others are added up in the first launch of the sweep that follows)
+template <int NS>
+hipError_t launch_narrow_stats(const NarrowParams<NS>& p, int it, hipStream_t stream);
 
 }  // namespace phm

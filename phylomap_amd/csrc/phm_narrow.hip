@@ -20,6 +20,9 @@ __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+template <int NS>
+__device__ __forceinline__ void narrow_stats_body(const NarrowParams<NS>& p, int it, int n_rows, int r, int c, double* red);
+
 // element J of the quad's four lanes, to all four (DPP quad_perm: no LDS traffic)
 template <int J>
 __device__ __forceinline__ double quad_bcast(double x) {
@@ -45,7 +48,15 @@ __device__ __forceinline__ double quad_bcast(double x) {
 // The vectors also go to the global PL array (the transition maps of the sampling sweep and the clusters above read them);
 // nobody in the kernel waits for those stores.
 template <int NS>
-__global__ __launch_bounds__(NARROW_CLUSTER_BLOCK) void narrow_cluster_kernel(NarrowParams<NS> p, int first_cluster, int it) {
+__global__ __launch_bounds__(NARROW_CLUSTER_BLOCK) void narrow_cluster_kernel(NarrowParams<NS> p, int first_cluster, int n_clusters, int it, int stats_rows) {
+  // Blocks beyond the tier's clusters (first tier of a sweep, stats_rows > 0): the statistics row of the PREVIOUS sweep, one
+  // column each -- a launch of its own costs the sweep ~6 us of ramp-up for ~1 us of work, here it rides along for free.
+  // (The previous sweep's per-wavefront rows and node states are untouched until this sweep's later kernels.)
+  if ((int)blockIdx.x >= n_clusters) {
+    __shared__ double red[NARROW_CLUSTER_BLOCK];
+    narrow_stats_body<NS>(p, it - 1, stats_rows, blockIdx.y, (int)blockIdx.x - n_clusters, red);
+    return;
+  }
   constexpr int G = NARROW_CLUSTER_BLOCK / 8;        // nodes per pass
   constexpr int PASSES = NARROW_CLUSTER_NODES / G;
   __shared__ double s_pl[NARROW_CLUSTER_NODES * NS];           // vectors computed in this cluster
@@ -626,19 +637,17 @@ __global__ __launch_bounds__(NARROW_BLOCK) void narrow_branch_kernel(NarrowParam
 // One workgroup per (chain, column): the columns of a row are reduced side by side (blockIdx.y), not one after the other.
 // Without the reduction over replicas the value goes straight into the engine's statistics layout ([iter][cols][n_rep_pad]).
 template <int NS>
-__global__ __launch_bounds__(256) void narrow_stats_kernel(NarrowParams<NS> p, int it, int n_rows) {
-  __shared__ double red[256];
-  const int r = blockIdx.x;
-  const int c = blockIdx.y;                          // 0 .. NS + ncnt; the last one adds the segment counts (column pc - 1)
-  const int ncnt = p.ks ? NS * NS : NS * (NS - 1);
+__device__ __forceinline__ void narrow_stats_body(const NarrowParams<NS>& p, int it, int n_rows, int r, int c, double* red) {
+  const int nt = (int)blockDim.x;                    // 256 or 512 threads
+  const int ncnt = p.ks ? NS * NS : NS * (NS - 1);   // c = 0 .. NS + ncnt; the last one adds the segment counts (column pc - 1)
   const int pc = NS + NS * NS + 1;
   const double* part = p.part + (size_t)r * n_rows * pc;
   const int src_c = (c == NS + ncnt) ? pc - 1 : c;
   double s = 0.0;
-  for (int e = threadIdx.x; e < n_rows; e += 256) s += part[(size_t)e * pc + src_c];
+  for (int e = threadIdx.x; e < n_rows; e += nt) s += part[(size_t)e * pc + src_c];
   red[threadIdx.x] = s;
   __syncthreads();
-  for (int half = 128; half >= 1; half >>= 1) {
+  for (int half = nt / 2; half >= 1; half >>= 1) {
     if ((int)threadIdx.x < half) red[threadIdx.x] = red[threadIdx.x] + red[threadIdx.x + half];
     __syncthreads();
   }
@@ -657,6 +666,12 @@ __global__ __launch_bounds__(256) void narrow_stats_kernel(NarrowParams<NS> p, i
   }
 }
 
+template <int NS>
+__global__ __launch_bounds__(256) void narrow_stats_kernel(NarrowParams<NS> p, int it, int n_rows) {
+  __shared__ double red[256];
+  narrow_stats_body<NS>(p, it, n_rows, blockIdx.x, blockIdx.y, red);
+}
+
 // rows of the chains of one 64-replica tile summed in replica order -> the engine's reduced statistics layout
 template <int NS>
 __global__ void narrow_emit_kernel(NarrowParams<NS> p, int it) {
@@ -671,14 +686,27 @@ __global__ void narrow_emit_kernel(NarrowParams<NS> p, int it) {
 }  // namespace
 
 template <int NS>
+static unsigned narrow_branch_waves(const NarrowParams<NS>& p, int& n_long) {
+  n_long = std::min(p.n_edge / 16, 128);
+  return (unsigned)(n_long + (p.n_edge - n_long + 7) / 8);
+}
+
+template <int NS>
 hipError_t launch_narrow_sweep(const NarrowParams<NS>& p, const std::vector<int32_t>& tier_off,
-                               const std::vector<int32_t>& walk_off, int it, hipStream_t stream) {
+                               const std::vector<int32_t>& walk_off, int it, hipStream_t stream, bool stats_pending) {
   const unsigned S = (unsigned)p.n_rep;
-  // pruning sweep: one launch per tier of clusters; then the sampling sweep: transition maps of all edges, root draw + walk
+  int n_long = 0;
+  const unsigned n_waves = narrow_branch_waves<NS>(p, n_long);
+  const unsigned stat_cols = (unsigned)(NS + (p.ks ? NS * NS : NS * (NS - 1)) + 1);
+  // pruning sweep: one launch per tier of clusters (the first one also carries the previous sweep's statistics, if they are
+  // still to be added up); then the sampling sweep: transition maps of all edges, root draw + walk; branch paths
   const int DL = (int)walk_off.size() - 1;
-  for (size_t t = 0; t + 1 < tier_off.size(); ++t)
-    hipLaunchKernelGGL(narrow_cluster_kernel<NS>, dim3((unsigned)(tier_off[t + 1] - tier_off[t]), S), dim3(NARROW_CLUSTER_BLOCK), 0,
-                       stream, p, tier_off[t], it);
+  for (size_t t = 0; t + 1 < tier_off.size(); ++t) {
+    const unsigned ncl = (unsigned)(tier_off[t + 1] - tier_off[t]);
+    const bool carry = t == 0 && stats_pending;
+    hipLaunchKernelGGL(narrow_cluster_kernel<NS>, dim3(ncl + (carry ? stat_cols : 0u), S), dim3(NARROW_CLUSTER_BLOCK), 0, stream, p,
+                       tier_off[t], (int)ncl, it, carry ? (int)n_waves : 0);
+  }
   hipLaunchKernelGGL(narrow_downmap_kernel<NS>, dim3((p.n_edge + NARROW_BLOCK - 1) / NARROW_BLOCK, S), dim3(NARROW_BLOCK), 0, stream,
                      p, it);
   if (p.n_node <= NARROW_LDS_NODES)
@@ -686,20 +714,31 @@ hipError_t launch_narrow_sweep(const NarrowParams<NS>& p, const std::vector<int3
                        it, DL);
   else
     hipLaunchKernelGGL((narrow_downwalk_kernel<NS, false>), dim3(S), dim3(NARROW_WALK_BLOCK), 0, stream, p, it, DL);
-  const int n_long = std::min(p.n_edge / 16, 128);
-  const unsigned n_waves = (unsigned)(n_long + (p.n_edge - n_long + 7) / 8);
   hipLaunchKernelGGL(narrow_branch_kernel<NS>, dim3(n_waves, S), dim3(NARROW_BLOCK), 0, stream, p, it, n_long);
-  hipLaunchKernelGGL(narrow_stats_kernel<NS>, dim3(S, NS + (p.ks ? NS * NS : NS * (NS - 1)) + 1), dim3(256), 0, stream, p, it,
-                     (int)n_waves);
-  if (p.reduce) {
+  if (p.reduce) {                                    // summed over replicas: the row is needed by the tile sums right away
+    hipLaunchKernelGGL(narrow_stats_kernel<NS>, dim3(S, stat_cols), dim3(256), 0, stream, p, it, (int)n_waves);
     const int items = p.n_tiles * p.n_cols;
     hipLaunchKernelGGL(narrow_emit_kernel<NS>, dim3((items + 255) / 256), dim3(256), 0, stream, p, it);
   }
   return hipGetLastError();
 }
 
-template hipError_t launch_narrow_sweep<2>(const NarrowParams<2>&, const std::vector<int32_t>&, const std::vector<int32_t>&, int, hipStream_t);
-template hipError_t launch_narrow_sweep<3>(const NarrowParams<3>&, const std::vector<int32_t>&, const std::vector<int32_t>&, int, hipStream_t);
-template hipError_t launch_narrow_sweep<4>(const NarrowParams<4>&, const std::vector<int32_t>&, const std::vector<int32_t>&, int, hipStream_t);
+// statistics of sweep `it` when no further sweep follows in this call (launch_narrow_sweep leaves them to the next sweep's first launch)
+template <int NS>
+hipError_t launch_narrow_stats(const NarrowParams<NS>& p, int it, hipStream_t stream) {
+  if (p.reduce) return hipSuccess;
+  int n_long = 0;
+  const unsigned n_waves = narrow_branch_waves<NS>(p, n_long);
+  hipLaunchKernelGGL(narrow_stats_kernel<NS>, dim3((unsigned)p.n_rep, (unsigned)(NS + (p.ks ? NS * NS : NS * (NS - 1)) + 1)), dim3(256), 0,
+                     stream, p, it, (int)n_waves);
+  return hipGetLastError();
+}
+
+template hipError_t launch_narrow_sweep<2>(const NarrowParams<2>&, const std::vector<int32_t>&, const std::vector<int32_t>&, int, hipStream_t, bool);
+template hipError_t launch_narrow_stats<2>(const NarrowParams<2>&, int, hipStream_t);
+template hipError_t launch_narrow_sweep<3>(const NarrowParams<3>&, const std::vector<int32_t>&, const std::vector<int32_t>&, int, hipStream_t, bool);
+template hipError_t launch_narrow_stats<3>(const NarrowParams<3>&, int, hipStream_t);
+template hipError_t launch_narrow_sweep<4>(const NarrowParams<4>&, const std::vector<int32_t>&, const std::vector<int32_t>&, int, hipStream_t, bool);
+template hipError_t launch_narrow_stats<4>(const NarrowParams<4>&, int, hipStream_t);
 
 }  // namespace phm
