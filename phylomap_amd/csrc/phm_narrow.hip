@@ -32,6 +32,16 @@ __device__ __forceinline__ double quad_bcast(double x) {
   return __hiloint2double(hi, lo);
 }
 
+// the value held four lanes away: lanes 0-3 and 4-7 of every group of eight swap (DPP row shifts by four, bank-masked)
+__device__ __forceinline__ double swap_quads(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  int tl = __builtin_amdgcn_update_dpp(lo, lo, 0x104, 0xf, 0x5, false);       // row_shl:4 -> banks 0 and 2 read lane + 4
+  int th = __builtin_amdgcn_update_dpp(hi, hi, 0x104, 0xf, 0x5, false);
+  tl = __builtin_amdgcn_update_dpp(tl, lo, 0x114, 0xf, 0xa, false);           // row_shr:4 -> banks 1 and 3 read lane - 4
+  th = __builtin_amdgcn_update_dpp(th, hi, 0x114, 0xf, 0xa, false);
+  return __hiloint2double(th, tl);
+}
+
 // Pruning sweep, PL[parent] = (B^(ma-1) PL[a]) (.) (B^(mb-1) PL[b])   (mmmmvFORpl src/phylomap.cpp:446-450, :508-510, :525).
 // What bounds one chain on a big tree is the LATENCY of the longest root-to-tip line of dependent steps, so the sweep is laid
 // out for latency:
@@ -152,7 +162,7 @@ __global__ __launch_bounds__(NARROW_CLUSTER_BLOCK) void narrow_cluster_kernel(Na
         if (NS > 3) acc += mrow[NS > 3 ? 3 : 0] * quad_bcast<3>(v);
         v = acc;
       }
-      const double other = __shfl_xor(v, 4);                                   // the sibling quad's component q
+      const double other = swap_quads(v);                                      // the sibling quad's component q
       double x = c ? v * other : other * v;                                    // "first" (child[1]) times "second" (:510)
       if (p.normalise) {                                                       // :525
         double sum = quad_bcast<0>(x);
