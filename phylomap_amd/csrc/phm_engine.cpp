@@ -478,6 +478,7 @@ int32_t narrow_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
     p.ell2_w = 0; p.ell2_col = e->d_ell2_col.as<int32_t>(); p.ell2_val = e->d_ell2_val.as<double>();
     p.up = e->d_up.as<phm::UpStep>(); p.down = e->d_down.as<phm::DownStep>();
     p.up_order = e->d_nw_up_order.as<int32_t>(); p.down_order = e->d_nw_down_order.as<int32_t>();
+    p.up_off = e->d_nw_up_off.as<int32_t>(); p.down_off = e->d_nw_down_off.as<int32_t>();
     p.branch_order = e->d_nw_border.as<int32_t>(); p.off = e->d_nw_off.as<int64_t>();
     p.colL = e->d_nw_colL.as<double>(); p.rowL = e->d_nw_rowL.as<double>(); p.maskL = e->d_nw_maskL.as<double>();
     p.tips = e->d_tips.as<uint8_t>(); p.mcount = e->d_nw_mcount.as<int32_t>();

@@ -51,6 +51,8 @@ struct WideBranchParams {
   const DownStep* down;
   const int32_t* up_order;
   const int32_t* down_order;
+  const int32_t* up_off;                     // level boundaries into up_order / down_order (device copies of the host arrays)
+  const int32_t* down_off;
   const int32_t* branch_order;
   const int64_t* off;                        // [n_edge + 1] CSR offsets of the branch slots
   const double* colL;                        // [klong][n][n]  (Bc^k e_j)[r]

@@ -23,14 +23,14 @@ struct Lds {
 };
 
 // stage the model matrices (odd row stride: conflict-free row and column access); ends with a barrier
-__device__ __forceinline__ Lds stage_model(const WideBranchParams& p, unsigned char* smem) {
+__device__ __forceinline__ Lds stage_model(const WideBranchParams& p, unsigned char* smem, int bs = WB_BLOCK) {
   const int n = p.n_states;
   Lds l;
   l.ldn = n | 1;
   l.Bc = reinterpret_cast<double*>(smem);
   l.B2 = p.sparse ? l.Bc + n * l.ldn : l.Bc;
   l.scale = l.Bc + (p.sparse ? 2 : 1) * n * l.ldn;
-  for (int i = threadIdx.x; i < n * n; i += WB_BLOCK) {
+  for (int i = threadIdx.x; i < n * n; i += bs) {
     const int r = i / n, cc = i - r * n;
     l.Bc[r * l.ldn + cc] = p.Bc[i];
     if (p.sparse) l.B2[r * l.ldn + cc] = p.B2[i];
@@ -40,34 +40,28 @@ __device__ __forceinline__ Lds stage_model(const WideBranchParams& p, unsigned c
   return l;
 }
 
-__global__ __launch_bounds__(WB_BLOCK) void wb_up_kernel(WideBranchParams p, int begin, int end) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  const int ell_w = p.ell_w;                 // sparse chain matrix: only its ELLPACK rows are staged; else the dense matrix
-  double* s_eval = reinterpret_cast<double*>(smem);
-  int32_t* s_ecol = reinterpret_cast<int32_t*>(s_eval + p.n_states * ell_w);
-  Lds l = {nullptr, nullptr, nullptr, 0};
-  if (ell_w > 0) {
-    for (int i = threadIdx.x; i < p.n_states * ell_w; i += WB_BLOCK) { s_ecol[i] = p.ell_col[i]; s_eval[i] = p.ell_val[i]; }
-    __syncthreads();
-  } else {
-    l = stage_model(p, smem);              // ends with a barrier
-  }
-  // TWO waves per node, one per child: the two chains B^(m-1) PL[child] are the longest dependent line of a level (up to
-  // ~15 steps of n fused multiply-adds each) and do not depend on one another; the "second" child's wave hands its vector
-  // over through LDS and the "first" child's wave finishes the node.
-  __shared__ double s_second[WB_BLOCK / 128][64];
-  __shared__ __align__(16) double s_vec[WB_BLOCK / 64][64];        // the chain vector of each wave (coop_matvec_lds)
-  const int n = p.n_states, lane = threadIdx.x & 63;
+// One height level of the pruning sweep for the waves of a workgroup of BS threads: TWO waves per node, one per child -- the two
+// chains B^(m-1) PL[child] are the longest dependent line of a level (up to ~15 steps of n fused multiply-adds each) and do not
+// depend on one another; the "second" child's wave hands its vector over through LDS and the "first" child's wave finishes the
+// node.  `first` = position of the workgroup's first node in the level order.  Contains one barrier (all waves reach it).
+struct UpLds {
+  const int32_t* ecol; const double* eval;   // ELLPACK rows of a sparse chain matrix (ell_w > 0), else the dense model in `l`
+  Lds l;
+  double (*second)[64];                      // [BS / 128][64]
+  double (*vec)[64];                         // [BS / 64][64] the chain vector of each wave (coop_matvec_lds)
+};
+
+template <int BS>
+__device__ __forceinline__ void wb_up_level(const WideBranchParams& p, const UpLds& sh, int first, int end, int r, uint32_t& err) {
+  const int n = p.n_states, lane = threadIdx.x & 63, ell_w = p.ell_w;
   const int wave = threadIdx.x >> 6, slot = wave >> 1, which = 1 - (wave & 1);      // even wave: child[1] ("first"), odd wave: child[0]
-  const int idx = begin + blockIdx.x * (WB_BLOCK / 128) + slot;
-  const int r = blockIdx.y;
+  const int idx = first + slot;
   const bool live = idx < end;
   const int c = lane < n ? lane : n - 1;
-  const UpStep st = p.up[p.up_order[live ? idx : begin]];
+  const UpStep st = p.up[p.up_order[live ? idx : first]];
   const int32_t* __restrict__ mc = p.mcount + (size_t)r * p.n_edge;
   double* PLr = p.PL + (size_t)r * p.n_node * n;
   const uint8_t* __restrict__ tips = p.tips_per_replica ? p.tips + (size_t)r * p.n_tips : p.tips;
-  uint32_t err = 0;
   // B^k applied to a child's partial-likelihood vector (mmmmvFORpl :446-450); tips: a row of the chain table
   auto child_vec = [&](int child, int k) -> double {
     if (child < 0) {
@@ -76,20 +70,64 @@ __global__ __launch_bounds__(WB_BLOCK) void wb_up_kernel(WideBranchParams p, int
       return p.tip_masks ? p.maskL[((size_t)k * 2 + (ts & 1)) * n + c] : p.colL[((size_t)k * n + ts) * n + c];
     }
     double v = PLr[(size_t)child * n + c];
-    if (ell_w > 0) for (int i = 0; i < k; ++i) v = coop_matvec_ell(s_ecol, s_eval, v, ell_w, c);
-    else for (int i = 0; i < k; ++i) v = coop_matvec_lds(l.Bc, s_vec[wave], v, n, l.ldn, c, lane);
+    if (ell_w > 0) for (int i = 0; i < k; ++i) v = coop_matvec_ell(sh.ecol, sh.eval, v, ell_w, c);
+    else for (int i = 0; i < k; ++i) v = coop_matvec_lds(sh.l.Bc, sh.vec[wave], v, n, sh.l.ldn, c, lane);
     return v;
   };
   double x = 0.0;
   if (live) x = child_vec(st.child[which], mc[st.edge[which]] - 1);       // which = 1: "first" (:508), 0: "second" (:509)
-  if (which == 0) s_second[slot][lane] = x;
+  if (which == 0) sh.second[slot][lane] = x;
   __syncthreads();
   if (live && which == 1) {
-    x = x * s_second[slot][lane];                               // :510
+    x = x * sh.second[slot][lane];                              // :510
     if (p.normalise) x = x / coop_sum(x, n);                    // :525
     if (lane < n) PLr[(size_t)st.parent * n + lane] = x;
   }
-  if (live && err) atomicOr(p.err, err);
+}
+
+template <int BS>
+__device__ __forceinline__ UpLds wb_up_stage(const WideBranchParams& p, unsigned char* smem, double (*second)[64], double (*vec)[64]) {
+  UpLds sh;
+  const int ell_w = p.ell_w;                 // sparse chain matrix: only its ELLPACK rows are staged; else the dense matrix
+  double* s_eval = reinterpret_cast<double*>(smem);
+  int32_t* s_ecol = reinterpret_cast<int32_t*>(s_eval + p.n_states * ell_w);
+  sh.l = {nullptr, nullptr, nullptr, 0};
+  if (ell_w > 0) {
+    for (int i = threadIdx.x; i < p.n_states * ell_w; i += BS) { s_ecol[i] = p.ell_col[i]; s_eval[i] = p.ell_val[i]; }
+    __syncthreads();
+  } else {
+    sh.l = stage_model(p, smem, BS);       // ends with a barrier
+  }
+  sh.ecol = s_ecol; sh.eval = s_eval; sh.second = second; sh.vec = vec;
+  return sh;
+}
+
+__global__ __launch_bounds__(WB_BLOCK) void wb_up_kernel(WideBranchParams p, int begin, int end) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ double s_second[WB_BLOCK / 128][64];
+  __shared__ __align__(16) double s_vec[WB_BLOCK / 64][64];
+  const UpLds sh = wb_up_stage<WB_BLOCK>(p, smem, s_second, s_vec);
+  uint32_t err = 0;
+  wb_up_level<WB_BLOCK>(p, sh, begin + blockIdx.x * (WB_BLOCK / 128), end, blockIdx.y, err);
+  if (err) atomicOr(p.err, err);
+}
+
+// A RUN of consecutive narrow height levels (<= WB_RUN_BLOCK / 128 nodes each) in one launch: one workgroup per chain stages the
+// model once and walks the levels with a workgroup-scope fence and a barrier in between -- near the root a level is a handful of
+// nodes, and a launch of its own (ramp-up + staging 30 KB of B at 61 states) costs more than its chains.
+constexpr int WB_RUN_BLOCK = 1024;
+__global__ __launch_bounds__(WB_RUN_BLOCK) void wb_up_run_kernel(WideBranchParams p, int l0, int l1) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ double s_second[WB_RUN_BLOCK / 128][64];
+  __shared__ __align__(16) double s_vec[WB_RUN_BLOCK / 64][64];
+  const UpLds sh = wb_up_stage<WB_RUN_BLOCK>(p, smem, s_second, s_vec);
+  uint32_t err = 0;
+  for (int l = l0; l < l1; ++l) {
+    wb_up_level<WB_RUN_BLOCK>(p, sh, p.up_off[l], p.up_off[l + 1], blockIdx.x, err);
+    __threadfence_block();
+    __syncthreads();
+  }
+  if (err) atomicOr(p.err, err);
 }
 
 __global__ __launch_bounds__(WB_BLOCK) void wb_root_kernel(WideBranchParams p, int it) {
@@ -321,9 +359,24 @@ hipError_t launch_wbranch_sweep(const WideBranchParams& p, const std::vector<int
     hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(wb_up_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e1 != hipSuccess) return e1;
   }
-  for (size_t l = 0; l + 1 < up_off.size(); ++l) {
+  const size_t up_lds = p.ell_w > 0 ? (size_t)p.n_states * p.ell_w * 12 : lds;
+  if (lds > 48 * 1024) {
+    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(wb_up_run_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e1 != hipSuccess) return e1;
+  }
+  const int UL = (int)up_off.size() - 1;
+  auto narrow = [&](int l) { return up_off[l + 1] - up_off[l] <= WB_RUN_BLOCK / 128; };
+  for (int l = 0; l < UL;) {
+    if (narrow(l) && l + 1 < UL && narrow(l + 1)) {              // at least two narrow levels in a row: one launch for the run
+      int l1 = l;
+      while (l1 < UL && narrow(l1)) ++l1;
+      hipLaunchKernelGGL(wb_up_run_kernel, dim3(S), dim3(WB_RUN_BLOCK), up_lds, stream, p, l, l1);
+      l = l1;
+      continue;
+    }
     const int cnt = up_off[l + 1] - up_off[l];
-    if (cnt > 0) hipLaunchKernelGGL(wb_up_kernel, dim3((cnt + WPB / 2 - 1) / (WPB / 2), S), dim3(WB_BLOCK), p.ell_w > 0 ? (size_t)p.n_states * p.ell_w * 12 : lds, stream, p, up_off[l], up_off[l + 1]);
+    if (cnt > 0) hipLaunchKernelGGL(wb_up_kernel, dim3((cnt + WPB / 2 - 1) / (WPB / 2), S), dim3(WB_BLOCK), up_lds, stream, p, up_off[l], up_off[l + 1]);
+    ++l;
   }
   hipLaunchKernelGGL(wb_root_kernel, dim3((S + WPB - 1) / WPB), dim3(WB_BLOCK), 0, stream, p, it);
   for (size_t l = 0; l + 1 < down_off.size(); ++l) {
