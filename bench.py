@@ -400,6 +400,11 @@ def main():
             blocks[key] = blk
         # the reference's own calling pattern -- ONE chain -- and an alignment-sized job, on the C2 tree
         blocks["C2_single_chain"] = one_chain(2, 400)
+        blocks["C4_single_chain"] = one_chain(4, 60)      # 61 / 20 states: one wave per (replica, branch), state per lane (phm_wbranch.hip)
+        blocks["C5_single_chain"] = one_chain(5, 100)
+        for key, c in (("C2_single_chain", 2), ("C4_single_chain", 4), ("C5_single_chain", 5)):
+            if c in cpu:
+                blocks[key]["speedup_vs_cpu_1core"] = blocks[key]["realisations_per_s"] / cpu[c]["value"]
         z, Q, pid, Om = synth.config_problem(2)
         E2 = z["edge"].shape[0]
         mid = _lib.Engine(z, Q, pid, Om, 44, variant=_lib.PHM_MCMC_BIGTREE, seed=1, n_replicas=4096, reduce=True, device=local_rank, mapping="tiles")
