@@ -201,9 +201,18 @@ int32_t upload_model(phm_engine* e) {
     return PHM_OK;
   }
   if (e->narrow || e->tiled) {      // tables long enough for every possible segment count, read from global memory / L2
-    HIPCHK(hipMemcpy(e->d_nw_colL.p, col.data(), sizeof(double) * col.size(), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(e->d_nw_rowL.p, row.data(), sizeof(double) * row.size(), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(e->d_nw_maskL.p, maskpow.data(), sizeof(double) * maskpow.size(), hipMemcpyHostToDevice));
+    // through page-locked staging (the rate-updating drivers come here after every sweep: three pageable hipMemcpy calls were
+    // ~50 us of a 190 us iteration)
+    const size_t nc = col.size(), nr = row.size(), nm = maskpow.size();
+    HIPCHK(e->pin_up.reserve(sizeof(double) * (nc + nr + nm)));
+    double* stage = e->pin_up.as<double>();
+    std::memcpy(stage, col.data(), sizeof(double) * nc);
+    std::memcpy(stage + nc, row.data(), sizeof(double) * nr);
+    std::memcpy(stage + nc + nr, maskpow.data(), sizeof(double) * nm);
+    HIPCHK(hipMemcpyAsync(e->d_nw_colL.p, stage, sizeof(double) * nc, hipMemcpyHostToDevice, e->last_stream));
+    HIPCHK(hipMemcpyAsync(e->d_nw_rowL.p, stage + nc, sizeof(double) * nr, hipMemcpyHostToDevice, e->last_stream));
+    HIPCHK(hipMemcpyAsync(e->d_nw_maskL.p, stage + nc + nr, sizeof(double) * nm, hipMemcpyHostToDevice, e->last_stream));
+    HIPCHK(hipStreamSynchronize(e->last_stream));      // one wait for the three: the next sweep may be enqueued on another stream
     if (e->wide) {      // 5..64 states: the model matrices live in global memory
       HIPCHK(hipMemcpy(e->d_B2.p, e->hB2.data(), sizeof(double) * n * n, hipMemcpyHostToDevice));
       HIPCHK(hipMemcpy(e->d_Bc.p, e->hBc.data(), sizeof(double) * n * n, hipMemcpyHostToDevice));
@@ -1331,8 +1340,19 @@ int32_t phm_engine_read_stats(phm_engine* e, int32_t iter0, int32_t n, double* o
       for (int c = 0; c < dcols; ++c) out[(size_t)out_col(c) * n + i] = h[(size_t)i * dcols + c];
     fill_params(out);
   } else {
-    std::vector<double> h((size_t)n * dcols * e->S_pad);
-    HIPCHK(hipMemcpy(h.data(), e->d_stats.as<double>() + (size_t)iter0 * dcols * e->S_pad, sizeof(double) * h.size(), hipMemcpyDeviceToHost));
+    const size_t hn = (size_t)n * dcols * e->S_pad;
+    std::vector<double> hv;
+    const double* h;
+    if (sizeof(double) * hn <= (1u << 20)) {           // a row or a few: page-locked staging, one asynchronous copy
+      HIPCHK(e->pin_down.reserve(sizeof(double) * hn));
+      HIPCHK(hipMemcpyAsync(e->pin_down.p, e->d_stats.as<double>() + (size_t)iter0 * dcols * e->S_pad, sizeof(double) * hn, hipMemcpyDeviceToHost, e->last_stream));
+      HIPCHK(hipStreamSynchronize(e->last_stream));
+      h = e->pin_down.as<double>();
+    } else {
+      hv.resize(hn);
+      HIPCHK(hipMemcpy(hv.data(), e->d_stats.as<double>() + (size_t)iter0 * dcols * e->S_pad, sizeof(double) * hn, hipMemcpyDeviceToHost));
+      h = hv.data();
+    }
     for (int r = 0; r < e->S; ++r) {
       for (int c = 0; c < dcols; ++c)
         for (int i = 0; i < n; ++i) out[((size_t)r * cols + out_col(c)) * n + i] = h[((size_t)i * dcols + c) * e->S_pad + e->pad_index(r)];

@@ -58,6 +58,25 @@ struct DevBuf {
   template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// page-locked host staging (async copies of a few KB between sweeps: a pageable hipMemcpy costs a synchronous ~15-30 us each)
+struct PinnedBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  PinnedBuf() = default;
+  PinnedBuf(const PinnedBuf&) = delete;
+  PinnedBuf& operator=(const PinnedBuf&) = delete;
+  ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+  hipError_t reserve(size_t n) {
+    if (n <= bytes) return hipSuccess;
+    if (p) (void)hipHostFree(p);
+    p = nullptr; bytes = 0;
+    hipError_t e = hipHostMalloc(&p, n, hipHostMallocDefault);
+    if (e == hipSuccess) bytes = n; else p = nullptr;
+    return e;
+  }
+  template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
 inline int32_t select_device(int32_t device) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(PHM_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
@@ -245,6 +264,7 @@ struct phm_engine {
   double phase_ms[4] = {0.0, 0.0, 0.0, 0.0};       // pruning levels, node draws, branch kernel, reductions (sums over the last run)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipStream_t last_stream = nullptr;
+  PinnedBuf pin_up, pin_down;                      // staging of the model tables (host -> device) and of small statistics reads
   bool timing_pending = false;
   double last_ms = 0.0;
   int last_launches = 0;
