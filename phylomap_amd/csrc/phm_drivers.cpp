@@ -2,6 +2,9 @@
 // fixed-Q drivers, the Q-updating drivers (bf / ks / DIC) and the multi-tree drivers (mt / ksmt); host-side glue only.
 #include "phm_internal.h"
 
+#include <chrono>
+#include <cstdio>
+
 extern "C" {
 
 // ---- reference-shaped one-shot drivers -------------------------------------------------------------
@@ -141,10 +144,19 @@ static int32_t run_qupdate(int variant, bool dic, const phm_tree* x, int32_t n, 
   }
 
   std::vector<double> Qw(Q, Q + nn), Qr, row(ecols);
+  // PHM_QTIMING=1 (measurement aid): mean host time of the phases of an iteration, printed once at the end
+  const bool qtiming = std::getenv("PHM_QTIMING") != nullptr;
+  double t_run = 0, t_sync = 0, t_read = 0, t_upd = 0, t_set = 0;
+  auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   for (int i = 0; i < N && !st; ++i) {
+    const double t0 = qtiming ? now() : 0;
     st = phm_engine_run(e, 1, nullptr);
+    const double t1 = qtiming ? now() : 0;
     if (!st) st = phm_engine_sync(e);
+    const double t2 = qtiming ? now() : 0;
     if (!st) st = phm_engine_read_stats(e, i, 1, row.data());
+    const double t3 = qtiming ? now() : 0;
+    t_run += t1 - t0; t_sync += t2 - t1; t_read += t3 - t2;
     if (st) break;
     if (dic) {                                        // :3239-3251 / :3379-3391, with the Q that drove this sweep
       cm_to_rm(Qw.data(), n, Qr);
@@ -157,10 +169,16 @@ static int32_t run_qupdate(int variant, bool dic, const phm_tree* x, int32_t n, 
                                        dlogs.as<double>(), dpid.as<double>(), root - 1, dll.as<double>(), nullptr));
       HIPCHK(hipMemcpy(&loglik[i], dll.p, sizeof(double), hipMemcpyDeviceToHost));
     }
+    const double t4 = qtiming ? now() : 0;
     if (variant == PHM_MCMC_BF) phm::bf_updates(Qw.data(), Omega, prior, row.data(), o.seed, (uint32_t)i);
     else phm::ks_updates(Qw.data(), n, Omega, prior, row.data(), o.seed, (uint32_t)i);
+    const double t5 = qtiming ? now() : 0;
     if (i + 1 < N) st = phm_engine_set_model(e, Qw.data());
+    t_upd += t5 - t4; t_set += (qtiming ? now() : 0) - t5;
   }
+  if (qtiming)
+    std::fprintf(stderr, "phm qtiming (us per iteration): launch %.1f  wait for the sweep %.1f  read row %.1f  rate updates %.1f  new model %.1f\n",
+                 t_run / N, t_sync / N, t_read / N, t_upd / N, t_set / N);
   if (st) return st;
   if (!dic) return phm_engine_read_stats(e, 0, N, out);
   std::vector<double> tmp((size_t)N * ecols);

@@ -212,7 +212,7 @@ int32_t upload_model(phm_engine* e) {
     HIPCHK(hipMemcpyAsync(e->d_nw_colL.p, stage, sizeof(double) * nc, hipMemcpyHostToDevice, e->last_stream));
     HIPCHK(hipMemcpyAsync(e->d_nw_rowL.p, stage + nc, sizeof(double) * nr, hipMemcpyHostToDevice, e->last_stream));
     HIPCHK(hipMemcpyAsync(e->d_nw_maskL.p, stage + nc + nr, sizeof(double) * nm, hipMemcpyHostToDevice, e->last_stream));
-    HIPCHK(hipStreamSynchronize(e->last_stream));      // one wait for the three: the next sweep may be enqueued on another stream
+    HIPCHK(wait_stream(e->last_stream));               // one wait for the three: the next sweep may be enqueued on another stream
     if (e->wide) {      // 5..64 states: the model matrices live in global memory
       HIPCHK(hipMemcpy(e->d_B2.p, e->hB2.data(), sizeof(double) * n * n, hipMemcpyHostToDevice));
       HIPCHK(hipMemcpy(e->d_Bc.p, e->hBc.data(), sizeof(double) * n * n, hipMemcpyHostToDevice));
@@ -294,6 +294,11 @@ void fill_narrow_params(phm_engine* e, phm::NarrowParams<NS>& p, const phm_optio
   p.rowbuf = e->d_nw_rowbuf.as<double>(); p.stats = e->d_stats.as<double>();
   p.dmap = e->d_nw_dmap.as<uint16_t>();
   p.err = e->d_err.as<uint32_t>(); p.segcnt = e->d_seg.as<unsigned long long>();
+  p.host_row = nullptr;
+  if (e->S == 1 && !e->reduce && e->pin_row.reserve(sizeof(double) * (e->dcols + 2)) == hipSuccess) {
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, e->pin_row.p, 0) == hipSuccess) p.host_row = reinterpret_cast<double*>(dp);
+  }
 }
 
 // Level schedules shared by the branch-parallel mappings: positions of up[] grouped by HEIGHT (children strictly below their
@@ -1236,6 +1241,8 @@ int32_t phm_engine_run(phm_engine* e, int32_t n_iters, void* hip_stream) {
   HIPCHK(hipEventRecord(e->ev1, stream));
   for (int i = 0; i < n_iters; ++i) e->qhist.push_back(e->qparams);      // recordQ / recordQks at the start of each sweep
   e->iters_done += n_iters;
+  e->epi_iter = (e->narrow && !e->wide && n_iters > 0 && ((e->n == 2 && e->n2.host_row) || (e->n == 3 && e->n3.host_row) || (e->n == 4 && e->n4.host_row)))
+                    ? e->iters_done - 1 : -1;
   e->last_stream = stream;
   e->timing_pending = true;
   e->last_launches = launches;
@@ -1289,7 +1296,7 @@ int32_t phm_engine_sync(phm_engine* e) {
   if (!e) return fail(PHM_ERR_STATE, "engine is NULL");
   if (e->dead) return dead_engine();
   HIPCHK(hipSetDevice(e->device));
-  HIPCHK(hipStreamSynchronize(e->last_stream));
+  HIPCHK(wait_stream(e->last_stream));
   if (e->timing_pending) {
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
@@ -1303,9 +1310,22 @@ int32_t phm_engine_sync(phm_engine* e) {
         e->phase_ms[ph] += pm;
       }
   }
+  if (e->epi_iter == e->iters_done - 1 && e->epi_iter >= 0) {      // one chain: the statistics kernel left both words in host memory
+    const double* hr = e->pin_row.as<double>();
+    const uint32_t derr = (uint32_t)hr[e->dcols + 1];
+    e->seg_total = (unsigned long long)hr[e->dcols];
+    if ((derr & phm::DERR_CAPACITY) && !(derr & ~phm::DERR_CAPACITY) && e->recover && e->saved) return recover_capacity(e);
+    return device_status(derr);
+  }
+  // error word and segment counter: two asynchronous copies into page-locked memory and ONE (polling) wait -- two pageable
+  // hipMemcpy calls were ~40 us of every iteration of the rate-updating drivers
+  HIPCHK(e->pin_status.reserve(16));
+  HIPCHK(hipMemcpyAsync(e->pin_status.p, e->d_err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, e->last_stream));
+  HIPCHK(hipMemcpyAsync(e->pin_status.as<unsigned char>() + 8, e->d_seg.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, e->last_stream));
+  HIPCHK(wait_stream(e->last_stream));
   uint32_t derr = 0;
-  HIPCHK(hipMemcpy(&derr, e->d_err.p, sizeof derr, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(&e->seg_total, e->d_seg.p, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  std::memcpy(&derr, e->pin_status.p, sizeof derr);
+  std::memcpy(&e->seg_total, e->pin_status.as<unsigned char>() + 8, sizeof(unsigned long long));
   if ((derr & phm::DERR_CAPACITY) && !(derr & ~phm::DERR_CAPACITY) && e->recover && e->saved && !(e->wide && !e->narrow && !e->tiled))
     return recover_capacity(e);      // (the state-per-lane tile kernel of phm_wide.hip has a fixed 128-segment scratch: not recoverable)
   return device_status(derr);
@@ -1318,7 +1338,7 @@ int32_t phm_engine_read_stats(phm_engine* e, int32_t iter0, int32_t n, double* o
   if (iter0 < 0 || n < 0 || iter0 + n > e->iters_done) return fail(PHM_ERR_STATE, "statistics requested for iterations that have not run");
   if (n == 0) return PHM_OK;
   HIPCHK(hipSetDevice(e->device));
-  HIPCHK(hipStreamSynchronize(e->last_stream));
+  HIPCHK(wait_stream(e->last_stream));
   const int cols = e->cols, dcols = e->dcols;
   // device column -> result column: identical except for ks, whose parameter columns (recordQks) sit between the
   // counters and the root state and are constants of the fixed Q
@@ -1343,10 +1363,14 @@ int32_t phm_engine_read_stats(phm_engine* e, int32_t iter0, int32_t n, double* o
     const size_t hn = (size_t)n * dcols * e->S_pad;
     std::vector<double> hv;
     const double* h;
-    if (sizeof(double) * hn <= (1u << 20)) {           // a row or a few: page-locked staging, one asynchronous copy
+    if (n == 1 && iter0 == e->epi_iter && e->S == 1) {   // the row the statistics kernel wrote to host memory
+      hv.assign(hn, 0.0);
+      for (int c = 0; c < dcols; ++c) hv[(size_t)c * e->S_pad + e->pad_index(0)] = e->pin_row.as<double>()[c];
+      h = hv.data();
+    } else if (sizeof(double) * hn <= (1u << 20)) {    // a row or a few: page-locked staging, one asynchronous copy
       HIPCHK(e->pin_down.reserve(sizeof(double) * hn));
       HIPCHK(hipMemcpyAsync(e->pin_down.p, e->d_stats.as<double>() + (size_t)iter0 * dcols * e->S_pad, sizeof(double) * hn, hipMemcpyDeviceToHost, e->last_stream));
-      HIPCHK(hipStreamSynchronize(e->last_stream));
+      HIPCHK(wait_stream(e->last_stream));
       h = e->pin_down.as<double>();
     } else {
       hv.resize(hn);
@@ -1546,7 +1570,7 @@ extern "C" int32_t phm_engine_set_model(phm_engine* e, const double* Q) {
     else hist.emplace_back(e->iters_done, std::vector<double>(Q, Q + (size_t)e->n * e->n));
   }
   HIPCHK(hipSetDevice(e->device));
-  HIPCHK(hipStreamSynchronize(e->last_stream));
+  HIPCHK(wait_stream(e->last_stream));
   std::vector<double> B2, Bc, scale, qp;
   int32_t st = compute_model(e->variant, e->n, Q, nullptr, e->Omega, B2, Bc, scale, qp);
   if (st) return st;

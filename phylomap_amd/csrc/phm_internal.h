@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -76,6 +77,19 @@ struct PinnedBuf {
   }
   template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
 };
+
+// Wait for a stream the way a loop of short sweeps needs it: hipStreamSynchronize sleeps on an interrupt and wakes 20-50 us after
+// the work is done (more than half a one-chain sweep); polling the stream for the first half millisecond returns within
+// microseconds, and anything longer falls through to the sleeping wait.
+inline hipError_t wait_stream(hipStream_t s) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t q = hipStreamQuery(s);
+    if (q == hipSuccess) return hipSuccess;
+    if (q != hipErrorNotReady) return q;
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(500)) return hipStreamSynchronize(s);
+  }
+}
 
 inline int32_t select_device(int32_t device) {
   int n = 0;
@@ -264,7 +278,9 @@ struct phm_engine {
   double phase_ms[4] = {0.0, 0.0, 0.0, 0.0};       // pruning levels, node draws, branch kernel, reductions (sums over the last run)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipStream_t last_stream = nullptr;
-  PinnedBuf pin_up, pin_down;                      // staging of the model tables (host -> device) and of small statistics reads
+  PinnedBuf pin_up, pin_down, pin_status, pin_row;
+  int epi_iter = -1;                               // iteration whose statistics row / status words sit in pin_row (one-chain engines)
+                      // staging of the model tables (host -> device) and of small statistics reads
   bool timing_pending = false;
   double last_ms = 0.0;
   int last_launches = 0;

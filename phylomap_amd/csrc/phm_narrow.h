@@ -67,6 +67,9 @@ struct NarrowParams {
   double* stats;                             // engine layout: reduce ? [iter][tile][cols] : [iter][cols][n_rep_pad]
   uint32_t* err;
   unsigned long long* segcnt;
+  double* host_row;                          // page-locked host memory (or null): the statistics kernel of a ONE-chain engine leaves the
+                                             // row, the error word and the segment counter there too -- n_cols + 2 doubles; a loop that
+                                             // reads one row per sweep (the rate-updating drivers) then needs no device-to-host copy
 };
 
 // one full sweep (iteration index `it`) enqueued on `stream`; tier boundaries (clusters) and depth-level boundaries are host arrays

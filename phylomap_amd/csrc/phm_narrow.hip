@@ -662,16 +662,23 @@ __device__ __forceinline__ void narrow_stats_body(const NarrowParams<NS>& p, int
     __syncthreads();
   }
   if (threadIdx.x == 0) {
+    double* host = (p.host_row && r == 0 && !p.reduce) ? p.host_row : nullptr;
     if (c < NS + ncnt) {
       if (p.reduce) p.rowbuf[(size_t)r * p.n_cols + c] = red[0];
       else p.stats[((size_t)it * p.n_cols + c) * p.n_rep_pad + r] = red[0];
+      if (host) host[c] = red[0];
     } else {
-      atomicAdd(p.segcnt, (unsigned long long)red[0]);
+      const unsigned long long before = atomicAdd(p.segcnt, (unsigned long long)red[0]);
+      if (host) {                                    // the status words of the sweep (no kernel of the sweep is still running)
+        host[p.n_cols] = (double)(before + (unsigned long long)red[0]);
+        host[p.n_cols + 1] = (double)*p.err;
+      }
     }
     if (p.ks && c == 0) {                                                      // root state, 0-based (:1350-1352)
       const double rs = (double)p.nstate[(size_t)r * p.n_node + p.root];
       if (p.reduce) p.rowbuf[(size_t)r * p.n_cols + NS + ncnt] = rs;
       else p.stats[((size_t)it * p.n_cols + NS + ncnt) * p.n_rep_pad + r] = rs;
+      if (host) host[NS + ncnt] = rs;
     }
   }
 }
