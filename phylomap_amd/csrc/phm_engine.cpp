@@ -209,9 +209,13 @@ int32_t upload_model(phm_engine* e) {
     std::memcpy(stage, col.data(), sizeof(double) * nc);
     std::memcpy(stage + nc, row.data(), sizeof(double) * nr);
     std::memcpy(stage + nc + nr, maskpow.data(), sizeof(double) * nm);
-    HIPCHK(hipMemcpyAsync(e->d_nw_colL.p, stage, sizeof(double) * nc, hipMemcpyHostToDevice, e->last_stream));
-    HIPCHK(hipMemcpyAsync(e->d_nw_rowL.p, stage + nc, sizeof(double) * nr, hipMemcpyHostToDevice, e->last_stream));
-    HIPCHK(hipMemcpyAsync(e->d_nw_maskL.p, stage + nc + nr, sizeof(double) * nm, hipMemcpyHostToDevice, e->last_stream));
+    if (e->narrow && !e->wide) {                       // phm_narrow.hip: one block, one copy
+      HIPCHK(hipMemcpyAsync(e->d_nw_colL.p, stage, sizeof(double) * (nc + nr + nm), hipMemcpyHostToDevice, e->last_stream));
+    } else {
+      HIPCHK(hipMemcpyAsync(e->d_nw_colL.p, stage, sizeof(double) * nc, hipMemcpyHostToDevice, e->last_stream));
+      HIPCHK(hipMemcpyAsync(e->d_nw_rowL.p, stage + nc, sizeof(double) * nr, hipMemcpyHostToDevice, e->last_stream));
+      HIPCHK(hipMemcpyAsync(e->d_nw_maskL.p, stage + nc + nr, sizeof(double) * nm, hipMemcpyHostToDevice, e->last_stream));
+    }
     HIPCHK(wait_stream(e->last_stream));               // one wait for the three: the next sweep may be enqueued on another stream
     if (e->wide) {      // 5..64 states: the model matrices live in global memory
       HIPCHK(hipMemcpy(e->d_B2.p, e->hB2.data(), sizeof(double) * n * n, hipMemcpyHostToDevice));
@@ -287,7 +291,10 @@ void fill_narrow_params(phm_engine* e, phm::NarrowParams<NS>& p, const phm_optio
   p.down_lv = e->d_nw_down_lv.as<phm::DownStep>(); p.walk_off = e->d_nw_walk_off.as<int32_t>();
   p.edge_parent = e->d_nw_edge_parent.as<int32_t>(); p.dmap_edge = e->d_nw_dmap_edge.as<uint16_t>();
   p.branch_order = e->d_nw_border.as<int32_t>(); p.off = e->d_nw_off.as<int64_t>();
-  p.colL = e->d_nw_colL.as<double>(); p.rowL = e->d_nw_rowL.as<double>(); p.maskL = e->d_nw_maskL.as<double>();
+  {
+    const size_t tab = (size_t)e->nw_klong * NS * NS;      // one block: colL | rowL | maskL (narrow_setup)
+    p.colL = e->d_nw_colL.as<double>(); p.rowL = p.colL + tab; p.maskL = p.colL + 2 * tab;
+  }
   p.tips = e->d_tips.as<uint8_t>();
   p.mcount = e->d_nw_mcount.as<int32_t>(); p.dw[0] = e->d_nw_dwA.as<double>(); p.dw[1] = e->d_nw_dwB.as<double>();
   p.PL = e->d_PL.as<double>(); p.nstate = e->d_nstate.as<uint8_t>(); p.part = e->d_nw_part.as<double>();
@@ -413,8 +420,12 @@ int32_t narrow_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
   HIPCHK(e->d_up.alloc(sizeof(phm::UpStep) * Nn)); HIPCHK(e->d_down.alloc(sizeof(phm::DownStep) * E));
   { int32_t lst = build_level_orders(e); if (lst) return lst; }
   HIPCHK(e->d_nw_border.alloc(sizeof(int32_t) * E)); HIPCHK(e->d_nw_off.alloc(sizeof(int64_t) * (E + 1)));
-  HIPCHK(e->d_nw_colL.alloc(sizeof(double) * tab)); HIPCHK(e->d_nw_rowL.alloc(sizeof(double) * tab));
-  HIPCHK(e->d_nw_maskL.alloc(sizeof(double) * (size_t)e->nw_klong * 2 * n));
+  if (e->wide) {
+    HIPCHK(e->d_nw_colL.alloc(sizeof(double) * tab)); HIPCHK(e->d_nw_rowL.alloc(sizeof(double) * tab));
+    HIPCHK(e->d_nw_maskL.alloc(sizeof(double) * (size_t)e->nw_klong * 2 * n));
+  } else {      // n <= 4: the three tables in one block (colL | rowL | maskL): a model update is ONE host-to-device copy
+    HIPCHK(e->d_nw_colL.alloc(sizeof(double) * (2 * tab + (size_t)e->nw_klong * 2 * n)));
+  }
   HIPCHK(e->d_tips.alloc(e->tips_host.size()));
   HIPCHK(e->d_nw_mcount.alloc(sizeof(int32_t) * (size_t)S * E));
   HIPCHK(e->d_nw_dwA.alloc(dw_bytes)); HIPCHK(e->d_nw_dwB.alloc(dw_bytes));
