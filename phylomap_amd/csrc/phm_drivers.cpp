@@ -101,6 +101,8 @@ static int32_t run_qupdate(int variant, bool dic, const phm_tree* x, int32_t n, 
   // DIC: device state of the per-iteration log-likelihood (expmat(Q t_b) for every branch, then pruning in nen order)
   DevBuf dQ, dt, ds, dwork, dP, dPL0, dPL, dpid, dup, dll, derr, dorder, dlogs;
   std::vector<double> loglik;
+  PinnedBuf pin_dic, pin_ll;                        // staging of (Q, squarings); log p(y|Q) of every iteration, written by the device
+  double* ll_dev = nullptr;
   std::vector<int32_t> ll_level_off;
   std::vector<int32_t> sq(E);
   if (dic) {
@@ -141,6 +143,11 @@ static int32_t run_qupdate(int variant, bool dic, const phm_tree* x, int32_t n, 
     HIPCHK(hipMemcpy(dup.p, upn.data(), dup.bytes, hipMemcpyHostToDevice));
     HIPCHK(hipMemset(derr.p, 0, sizeof(uint32_t)));
     loglik.resize(N);
+    HIPCHK(pin_dic.reserve(sizeof(double) * nn + sizeof(int32_t) * E));
+    HIPCHK(pin_ll.reserve(sizeof(double) * N));
+    void* dp = nullptr;
+    HIPCHK(hipHostGetDevicePointer(&dp, pin_ll.p, 0));
+    ll_dev = reinterpret_cast<double*>(dp);
   }
 
   std::vector<double> Qw(Q, Q + nn), Qr, row(ecols);
@@ -159,15 +166,19 @@ static int32_t run_qupdate(int variant, bool dic, const phm_tree* x, int32_t n, 
     t_run += t1 - t0; t_sync += t2 - t1; t_read += t3 - t2;
     if (st) break;
     if (dic) {                                        // :3239-3251 / :3379-3391, with the Q that drove this sweep
+      // nothing here waits: Q and the squarings go up from page-locked staging, log p(y|Q) of iteration i lands in slot i of a
+      // page-locked array; the wait of the next model update (same stream) covers the kernels before the staging is reused
       cm_to_rm(Qw.data(), n, Qr);
-      for (int b = 0; b < E; ++b) sq[b] = pade_squarings(Qr.data(), n, x->edge_length[b]);
-      HIPCHK(hipMemcpy(dQ.p, Qr.data(), dQ.bytes, hipMemcpyHostToDevice));
-      HIPCHK(hipMemcpy(ds.p, sq.data(), ds.bytes, hipMemcpyHostToDevice));
+      double* stQ = pin_dic.as<double>();
+      int32_t* stS = reinterpret_cast<int32_t*>(stQ + nn);
+      std::memcpy(stQ, Qr.data(), sizeof(double) * nn);
+      for (int b = 0; b < E; ++b) stS[b] = pade_squarings(Qr.data(), n, x->edge_length[b]);
+      HIPCHK(hipMemcpyAsync(dQ.p, stQ, dQ.bytes, hipMemcpyHostToDevice, nullptr));
+      HIPCHK(hipMemcpyAsync(ds.p, stS, ds.bytes, hipMemcpyHostToDevice, nullptr));
       HIPCHK(hipMemcpyAsync(dPL.p, dPL0.p, dPL.bytes, hipMemcpyDeviceToDevice, nullptr));
       HIPCHK(phm::launch_expm_pade(n, dQ.as<double>(), dt.as<double>(), ds.as<int32_t>(), E, dwork.as<double>(), dP.as<double>(), derr.as<uint32_t>(), nullptr));
       HIPCHK(phm::launch_exp_pl_loglik(n, Nn, T, dup.as<phm::UpStep>(), dorder.as<int32_t>(), ll_level_off, dP.as<double>(), dPL.as<double>(),
-                                       dlogs.as<double>(), dpid.as<double>(), root - 1, dll.as<double>(), nullptr));
-      HIPCHK(hipMemcpy(&loglik[i], dll.p, sizeof(double), hipMemcpyDeviceToHost));
+                                       dlogs.as<double>(), dpid.as<double>(), root - 1, ll_dev + i, nullptr));
     }
     const double t4 = qtiming ? now() : 0;
     if (variant == PHM_MCMC_BF) phm::bf_updates(Qw.data(), Omega, prior, row.data(), o.seed, (uint32_t)i);
@@ -181,6 +192,8 @@ static int32_t run_qupdate(int variant, bool dic, const phm_tree* x, int32_t n, 
                  t_run / N, t_sync / N, t_read / N, t_upd / N, t_set / N);
   if (st) return st;
   if (!dic) return phm_engine_read_stats(e, 0, N, out);
+  HIPCHK(hipStreamSynchronize(nullptr));
+  std::memcpy(loglik.data(), pin_ll.p, sizeof(double) * N);
   std::vector<double> tmp((size_t)N * ecols);
   st = phm_engine_read_stats(e, 0, N, tmp.data());
   if (st) return st;

@@ -17,6 +17,7 @@ for b, (p_, c_) in enumerate(z4["edge"]):
         z4["mapnames"][b][-1] = z4["states"][c_ - 1]
 for name, fn, args in (("sumstatMCMCbf  (2 states)", api.sumstatMCMCbf, (z2, Q2, pid2, 10.0, N, [.55, 1, .56, 1.01])),
                        ("sumstatMCMCks  (4 states)", api.sumstatMCMCks, (z4, Q4, pid4, 10.0, N, [1, 10, 2, 10, 20, 2])),
+                       ("sumstatMCMC2sDICt (2 states, + log p(y|Q) by matrix exponentials every iteration)", api.sumstatMCMC2sDICt, (z2, Q2, pid2, 10.0, N, [.55, 1, .56, 1.01])),
                        ("sumstatMCMC_bigtree fixed Q (2 states)", api.sumstatMCMC_bigtree, (z2, Q2, pid2, 10.0, N))):
     fn(*args[:4], 20, *args[5:], seed=1)
     t = time.time(); out = fn(*args, seed=2); dt = time.time() - t
