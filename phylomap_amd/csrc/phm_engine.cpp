@@ -484,6 +484,10 @@ int32_t narrow_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
   if (n == 4) fill_narrow_params<4>(e, e->n4, o);
   if (e->wide) {      // 5..64 states: one wave per (replica, branch), lanes = states (phm_wbranch.hip)
     HIPCHK(e->d_wb_cnt.alloc(sizeof(double) * (size_t)S * e->dcols));
+    // transition maps of the sampling sweep (n bytes per edge and chain) up to 32 states -- a map costs n draws of n terms: one chain
+    // on C5 (20 states) 0.40 -> 0.37 ms per sweep, on C4 (61 states) 0.78 -> 0.82 -- and while they stay small beside the paths;
+    // otherwise one launch per depth level
+    if (n <= 32 && (size_t)S * s.n_edge * n <= (256u << 20)) HIPCHK(e->d_nw_dmap.alloc((size_t)S * s.n_edge * n));
     HIPCHK(hipMemset(e->d_wb_cnt.p, 0, e->d_wb_cnt.bytes));
     HIPCHK(e->d_B2.alloc(sizeof(double) * n * n)); HIPCHK(e->d_Bc.alloc(sizeof(double) * n * n));
     HIPCHK(e->d_ell_col.alloc(sizeof(int32_t) * n * phm::WB_ELL_MAX)); HIPCHK(e->d_ell_val.alloc(sizeof(double) * n * phm::WB_ELL_MAX));
@@ -511,6 +515,7 @@ int32_t narrow_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
     p.mstate = e->d_nw_mstate.as<uint8_t>(); p.estate = e->d_nw_estate.as<uint8_t>();
     p.PL = e->d_PL.as<double>(); p.nstate = e->d_nstate.as<uint8_t>(); p.part = e->d_nw_part.as<double>();
     p.cnt = e->d_wb_cnt.as<double>(); p.rowbuf = e->d_nw_rowbuf.as<double>(); p.stats = e->d_stats.as<double>();
+    p.dmap = e->d_nw_dmap.as<uint8_t>();
     p.err = e->d_err.as<uint32_t>(); p.segcnt = e->d_seg.as<unsigned long long>();
   }
   return PHM_OK;

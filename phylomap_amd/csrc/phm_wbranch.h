@@ -66,6 +66,7 @@ struct WideBranchParams {
   uint8_t* estate;                           // [replica][n_edge][2]
   double* PL;                                // [replica][n_node][n]
   uint8_t* nstate;                           // [replica][n_node]
+  uint8_t* dmap;                             // [replica][n_edge (depth-level order)][n] transition maps of the sampling sweep; null: level launches
   double* part;                              // [replica][n_edge][n + 1] per-branch dwell sums, segments touched
   double* cnt;                               // [replica][n_cols] transition counters of the sweep (f64 atomics on integers)
   double* rowbuf;                            // [replica][n_cols]

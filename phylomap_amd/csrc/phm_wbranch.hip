@@ -183,6 +183,82 @@ __global__ __launch_bounds__(WB_BLOCK) void wb_down_kernel(WideBranchParams p, i
   if (err) atomicOr(p.err, err);
 }
 
+// The sampling sweep in two steps, as in phm_narrow.hip: the draw child ~ e_ps^T B^(m-1) (.) PL[child] depends on the sweep only
+// through the parent's state ps, so wb_downmap_kernel (a wave per (replica, edge), all edges side by side) carries it out for
+// EACH of the n possible ps -- one byte per candidate: the drawn state, bit 7 = "probabilities all zero" -- and wb_walk_kernel (one
+// workgroup per chain) walks the depth levels with state[child] = map[edge][state[parent]], node states in LDS, one byte
+// gathered per edge and level.  Same operands, same order as wb_down_kernel for the ps that materialises.
+__global__ __launch_bounds__(WB_BLOCK) void wb_downmap_kernel(WideBranchParams p, int it) {
+  const int n = p.n_states, lane = threadIdx.x & 63;
+  const int idx = blockIdx.x * (WB_BLOCK / 64) + (threadIdx.x >> 6);          // position in depth-level order
+  const int r = blockIdx.y;
+  if (idx >= p.n_edge) return;
+  const int c = lane < n ? lane : n - 1;
+  const DownStep ds = p.down[p.down_order[idx]];
+  const uint8_t* __restrict__ tips = p.tips_per_replica ? p.tips + (size_t)r * p.n_tips : p.tips;
+  uint8_t* __restrict__ map = p.dmap + ((size_t)r * p.n_edge + idx) * n;
+  uint32_t err = 0;
+  if (ds.child >= 0 || p.tip_masks) {
+    int kk = p.mcount[(size_t)r * p.n_edge + ds.edge] - 1;
+    if (kk >= p.klong) { err |= DERR_CAPACITY; kk = p.klong - 1; }
+    double wgt;
+    uint32_t node_id;
+    if (ds.child >= 0) {
+      wgt = p.PL[((size_t)r * p.n_node + ds.child) * n + c];
+      node_id = (uint32_t)(ds.child + p.n_tips);
+    } else {
+      const int par = tips[~ds.child] & 1;
+      wgt = ((c & 1) == par) ? 1.0 : 0.0;
+      node_id = (uint32_t)(~ds.child);
+    }
+    const double u = stream_u(p.seed_lo, p.seed_hi, (uint32_t)(p.replica_offset + r), (uint32_t)it, ENT_NODE | node_id, 0);
+    const double* __restrict__ rows = p.rowL + (size_t)kk * n * n;
+    int mine = 0;
+    for (int q = 0; q < n; ++q) {
+      const double w = (lane < n) ? rows[(size_t)q * n + c] * wgt : 0.0;
+      uint32_t e2 = 0;
+      const int cs = coop_sample(w, u, n, lane, e2);                           // :655
+      if (lane == q) mine = cs | (e2 ? 0x80 : 0);
+    }
+    if (lane < n) map[lane] = (uint8_t)mine;
+  } else {
+    if (lane < n) map[lane] = tips[~ds.child];                                 // :612
+  }
+  if (err) atomicOr(p.err, err);
+}
+
+constexpr int WB_WALK_BLOCK = 1024;
+__global__ __launch_bounds__(WB_WALK_BLOCK) void wb_walk_kernel(WideBranchParams p, int n_levels, int use_lds) {
+  extern __shared__ uint8_t s_nst[];
+  const int n = p.n_states, tid = threadIdx.x, r = blockIdx.x;
+  uint8_t* __restrict__ nst = p.nstate + (size_t)r * p.n_node;
+  uint8_t* __restrict__ est = p.estate + (size_t)r * p.n_edge * 2;
+  const uint8_t* __restrict__ map = p.dmap + (size_t)r * p.n_edge * n;
+  uint32_t err = 0;
+  if (use_lds) {
+    if (tid == 0) s_nst[p.root] = nst[p.root];                                 // the root draw (wb_root_kernel)
+    __syncthreads();
+  }
+  for (int l = 0; l < n_levels; ++l) {
+    const int lo = p.down_off[l], hi = p.down_off[l + 1];
+    for (int idx = lo + tid; idx < hi; idx += WB_WALK_BLOCK) {
+      const DownStep ds = p.down[p.down_order[idx]];
+      const int ps = use_lds ? s_nst[ds.parent] : nst[ds.parent];
+      const int out = map[(size_t)idx * n + ps];
+      const int cs = out & 0x7f;
+      if (out & 0x80) err |= DERR_ZERO_PROB;
+      if (ds.child >= 0) {
+        if (use_lds) s_nst[ds.child] = (uint8_t)cs;
+        nst[ds.child] = (uint8_t)cs;
+      }
+      est[ds.edge * 2] = (uint8_t)ps; est[ds.edge * 2 + 1] = (uint8_t)cs;     // updatenodestates :460-475
+    }
+    if (!use_lds) __threadfence_block();
+    __syncthreads();
+  }
+  if (err) atomicOr(p.err, err);
+}
+
 // One branch of one replica: resamplebranchstates :264-308, shortener :44-73 (shortenerbf :997-1030), virtual jumps
 // sampleabranch :391-410, dwell sums updatedwelltimes :745-757.
 __global__ __launch_bounds__(WB_BLOCK) void wb_branch_kernel(WideBranchParams p, int it) {
@@ -379,9 +455,16 @@ hipError_t launch_wbranch_sweep(const WideBranchParams& p, const std::vector<int
     ++l;
   }
   hipLaunchKernelGGL(wb_root_kernel, dim3((S + WPB - 1) / WPB), dim3(WB_BLOCK), 0, stream, p, it);
-  for (size_t l = 0; l + 1 < down_off.size(); ++l) {
-    const int cnt = down_off[l + 1] - down_off[l];
-    if (cnt > 0) hipLaunchKernelGGL(wb_down_kernel, dim3((cnt + WPB - 1) / WPB, S), dim3(WB_BLOCK), 0, stream, p, it, down_off[l], down_off[l + 1]);
+  if (p.dmap) {      // transition maps of all edges, then one workgroup per chain walks the levels
+    hipLaunchKernelGGL(wb_downmap_kernel, dim3((p.n_edge + WPB - 1) / WPB, S), dim3(WB_BLOCK), 0, stream, p, it);
+    const int use_lds = p.n_node <= 60 * 1024;
+    hipLaunchKernelGGL(wb_walk_kernel, dim3(S), dim3(WB_WALK_BLOCK), use_lds ? (size_t)((p.n_node + 15) & ~15) : 0, stream, p,
+                       (int)down_off.size() - 1, use_lds);
+  } else {
+    for (size_t l = 0; l + 1 < down_off.size(); ++l) {
+      const int cnt = down_off[l + 1] - down_off[l];
+      if (cnt > 0) hipLaunchKernelGGL(wb_down_kernel, dim3((cnt + WPB - 1) / WPB, S), dim3(WB_BLOCK), 0, stream, p, it, down_off[l], down_off[l + 1]);
+    }
   }
   hipLaunchKernelGGL(wb_branch_kernel, dim3((p.n_edge + WPB - 1) / WPB, S), dim3(WB_BLOCK), (size_t)p.n_states * p.ell2_w * 12, stream, p, it);
   hipLaunchKernelGGL(wb_stats_kernel, dim3(S, (unsigned)(p.n_states + 1)), dim3(256), 0, stream, p);
