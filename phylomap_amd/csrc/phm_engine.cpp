@@ -31,11 +31,11 @@ inline int narrow_auto_max_replicas(const phm::Schedule& s) {
 }
 constexpr int TILES_AUTO_MAX_REPLICAS = 262144;
 // 5..64 states: a wave per (replica, branch) (phm_wbranch.hip) exposes S x E waves whatever S is; the lane-per-replica mapping
-// (phm_wtiles.hip) needs whole tiles of 64 replicas and pays a fixed serial cost per tree level (one tile: 1.25 ms per sweep on
-// C4, 1.06 ms on C5, with the pruning products of a 16-replica block split over a wave per row block).  Measured crossover
-// (profiles/r02_probe_small_S_C{4,5}.log): 8 replicas at 20 states, none at 61 states (1.28 ms for one chain there) --
-// interpolated linearly in n.
-inline int wbranch_auto_max_replicas(int n) { return std::max(0, std::min(8, 8 - (n - 20) / 5)); }
+// (phm_wtiles.hip) needs whole tiles of 64 replicas and pays a fixed serial cost per tree level (one tile: 1.04 ms per sweep on
+// C4, 0.81 ms on C5).  Round 3 (two waves per node, LDS-fed chains, transition maps, per-column statistics) moved the crossover
+// (profiles/r03_probe_small_S_C{4,5}.log): C4 (1 000 branches) 0.76 ms at one chain, + 9 us per further chain -> ~30 chains;
+// C5 (10 000 branches) 0.38 ms, + 60 us per chain -> ~7 chains.  The slope follows the branch count: 50 000 / E chains, at most 32.
+inline int wbranch_auto_max_replicas(int n_edge) { return std::max(1, std::min(32, 50000 / std::max(1, n_edge))); }
 
 // Tail at which the fixed slots of the branch-parallel mappings are provisioned, per (replica, branch, sweep).  A slot that
 // overflows costs a rebuild with doubled slots and a replay (recover_capacity), so the tail is set from the number of draws
@@ -982,7 +982,7 @@ int32_t phm_engine_create_multi(const phm_tree* trees, int32_t n_trees, const ph
   const bool auto_map = map_req == PHM_MAP_AUTO && o.storage == 0;      // a ring / two-buffer request names the replica layout
   if ((map_req == 2 || map_req == 3) && n_trees != 1) return fail(PHM_ERR_UNSUPPORTED, "the branch-parallel mappings take a single tree");
   if (e->wide) {      // 5..64 states: lane = replica, wave per (tile, item) (phm_wtiles.hip); a handful of chains: wave per (replica, branch)
-    e->tiled = n_trees == 1 && (map_req == 3 || (auto_map && e->S > wbranch_auto_max_replicas(n)));
+    e->tiled = n_trees == 1 && (map_req == 3 || (auto_map && e->S > wbranch_auto_max_replicas(E)));
     e->narrow = n_trees == 1 && !e->tiled && (map_req == 2 || auto_map);
   } else {
     e->narrow = small_n && (map_req == 2 || (auto_map && e->S <= narrow_auto_max_replicas(s)));
