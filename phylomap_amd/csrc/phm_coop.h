@@ -81,6 +81,30 @@ __device__ __forceinline__ double coop_matvec_lds(const double* __restrict__ M, 
   return acc;
 }
 
+// The same product with the lane's matrix row already in REGISTERS (brow[j] = M[c][j], zero beyond n): a kernel that applies the
+// same matrix many times (the chains of a pruning level) loads its row once; a step is then 32 broadcast reads of the vector
+// (two entries each) and the FMA chain.  Same terms, same order; the zero entries beyond n add fma(0, x, acc) = acc.
+__device__ __forceinline__ double coop_matvec_regs(const double (&brow)[64], double* __restrict__ svec, double v, int n, int lane) {
+  svec[lane] = (lane < n) ? v : 0.0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+  const double2* sv2 = reinterpret_cast<const double2*>(svec);
+  double acc = 0.0;
+#pragma unroll
+  for (int j = 0; j < 64; j += 8) {
+    if (j < n) {                                     // wave-uniform: whole batches of eight beyond n are skipped
+      const double2 a = sv2[j / 2], b = sv2[j / 2 + 1], cc = sv2[j / 2 + 2], d = sv2[j / 2 + 3];
+      acc = __builtin_fma(brow[j], a.x, acc);     acc = __builtin_fma(brow[j + 1], a.y, acc);
+      acc = __builtin_fma(brow[j + 2], b.x, acc); acc = __builtin_fma(brow[j + 3], b.y, acc);
+      acc = __builtin_fma(brow[j + 4], cc.x, acc); acc = __builtin_fma(brow[j + 5], cc.y, acc);
+      acc = __builtin_fma(brow[j + 6], d.x, acc); acc = __builtin_fma(brow[j + 7], d.y, acc);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();                   // every lane has read the vector before the next product overwrites it
+  return acc;
+}
+
 // the same product for a matrix with at most w non-zeros per row, kept in ELLPACK form (columns ascending; padding entries
 // have value 0): lane c gathers v[col] of its own non-zeros.  Skipping the exact zeros of a row leaves its fused chain
 // unchanged bit for bit -- fma(0, x, acc) = acc for finite x.

@@ -52,7 +52,8 @@ struct UpLds {
 };
 
 template <int BS>
-__device__ __forceinline__ void wb_up_level(const WideBranchParams& p, const UpLds& sh, int first, int end, int r, uint32_t& err) {
+__device__ __forceinline__ void wb_up_level(const WideBranchParams& p, const UpLds& sh, const double (&brow)[64], int first, int end, int r,
+                                            uint32_t& err) {
   const int n = p.n_states, lane = threadIdx.x & 63, ell_w = p.ell_w;
   const int wave = threadIdx.x >> 6, slot = wave >> 1, which = 1 - (wave & 1);      // even wave: child[1] ("first"), odd wave: child[0]
   const int idx = first + slot;
@@ -71,7 +72,7 @@ __device__ __forceinline__ void wb_up_level(const WideBranchParams& p, const UpL
     }
     double v = PLr[(size_t)child * n + c];
     if (ell_w > 0) for (int i = 0; i < k; ++i) v = coop_matvec_ell(sh.ecol, sh.eval, v, ell_w, c);
-    else for (int i = 0; i < k; ++i) v = coop_matvec_lds(sh.l.Bc, sh.vec[wave], v, n, sh.l.ldn, c, lane);
+    else for (int i = 0; i < k; ++i) v = coop_matvec_regs(brow, sh.vec[wave], v, n, lane);
     return v;
   };
   double x = 0.0;
@@ -102,28 +103,46 @@ __device__ __forceinline__ UpLds wb_up_stage(const WideBranchParams& p, unsigned
   return sh;
 }
 
+// the lane's row of the dense chain matrix, in registers for the whole kernel (coop_matvec_regs); zeros beyond n / for ELLPACK
+__device__ __forceinline__ void wb_load_row(const WideBranchParams& p, const UpLds& sh, double (&brow)[64]) {
+  const int n = p.n_states, lane = threadIdx.x & 63;
+  const int c = lane < n ? lane : n - 1;
+#pragma unroll
+  for (int j = 0; j < 64; ++j) brow[j] = (p.ell_w == 0 && j < n) ? sh.l.Bc[c * sh.l.ldn + j] : 0.0;
+}
+
 __global__ __launch_bounds__(WB_BLOCK) void wb_up_kernel(WideBranchParams p, int begin, int end) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ double s_second[WB_BLOCK / 128][64];
   __shared__ __align__(16) double s_vec[WB_BLOCK / 64][64];
   const UpLds sh = wb_up_stage<WB_BLOCK>(p, smem, s_second, s_vec);
+  double brow[64];
+  wb_load_row(p, sh, brow);
   uint32_t err = 0;
-  wb_up_level<WB_BLOCK>(p, sh, begin + blockIdx.x * (WB_BLOCK / 128), end, blockIdx.y, err);
+  wb_up_level<WB_BLOCK>(p, sh, brow, begin + blockIdx.x * (WB_BLOCK / 128), end, blockIdx.y, err);
   if (err) atomicOr(p.err, err);
 }
 
-// A RUN of consecutive narrow height levels (<= WB_RUN_BLOCK / 128 nodes each) in one launch: one workgroup per chain stages the
+// A RUN of consecutive narrow height levels (at most four or eight nodes each) in one launch: one workgroup per chain stages the
 // model once and walks the levels with a workgroup-scope fence and a barrier in between -- near the root a level is a handful of
 // nodes, and a launch of its own (ramp-up + staging 30 KB of B at 61 states) costs more than its chains.
-constexpr int WB_RUN_BLOCK = 1024;
-__global__ __launch_bounds__(WB_RUN_BLOCK) void wb_up_run_kernel(WideBranchParams p, int l0, int l1) {
+// The dense chain matrix keeps a row per lane in registers (128 VGPRs: 512-lane workgroups, four nodes per level); an ELLPACK
+// matrix does not (1 024 lanes, eight nodes per level).
+template <int BS, bool DENSE>
+__global__ __launch_bounds__(BS) void wb_up_run_kernel(WideBranchParams p, int l0, int l1) {
   extern __shared__ __align__(16) unsigned char smem[];
-  __shared__ double s_second[WB_RUN_BLOCK / 128][64];
-  __shared__ __align__(16) double s_vec[WB_RUN_BLOCK / 64][64];
-  const UpLds sh = wb_up_stage<WB_RUN_BLOCK>(p, smem, s_second, s_vec);
+  __shared__ double s_second[BS / 128][64];
+  __shared__ __align__(16) double s_vec[BS / 64][64];
+  const UpLds sh = wb_up_stage<BS>(p, smem, s_second, s_vec);
+  double brow[64];
+  if (DENSE) wb_load_row(p, sh, brow);
+  else {
+#pragma unroll
+    for (int j = 0; j < 64; ++j) brow[j] = 0.0;
+  }
   uint32_t err = 0;
   for (int l = l0; l < l1; ++l) {
-    wb_up_level<WB_RUN_BLOCK>(p, sh, p.up_off[l], p.up_off[l + 1], blockIdx.x, err);
+    wb_up_level<BS>(p, sh, brow, p.up_off[l], p.up_off[l + 1], blockIdx.x, err);
     __threadfence_block();
     __syncthreads();
   }
@@ -436,17 +455,20 @@ hipError_t launch_wbranch_sweep(const WideBranchParams& p, const std::vector<int
     if (e1 != hipSuccess) return e1;
   }
   const size_t up_lds = p.ell_w > 0 ? (size_t)p.n_states * p.ell_w * 12 : lds;
+  const bool dense = p.ell_w == 0;
+  const int run_block = dense ? 512 : 1024;
   if (lds > 48 * 1024) {
-    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(wb_up_run_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(wb_up_run_kernel<512, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e1 != hipSuccess) return e1;
   }
   const int UL = (int)up_off.size() - 1;
-  auto narrow = [&](int l) { return up_off[l + 1] - up_off[l] <= WB_RUN_BLOCK / 128; };
+  auto narrow = [&](int l) { return up_off[l + 1] - up_off[l] <= run_block / 128; };
   for (int l = 0; l < UL;) {
     if (narrow(l) && l + 1 < UL && narrow(l + 1)) {              // at least two narrow levels in a row: one launch for the run
       int l1 = l;
       while (l1 < UL && narrow(l1)) ++l1;
-      hipLaunchKernelGGL(wb_up_run_kernel, dim3(S), dim3(WB_RUN_BLOCK), up_lds, stream, p, l, l1);
+      if (dense) hipLaunchKernelGGL((wb_up_run_kernel<512, true>), dim3(S), dim3(512), up_lds, stream, p, l, l1);
+      else hipLaunchKernelGGL((wb_up_run_kernel<1024, false>), dim3(S), dim3(1024), up_lds, stream, p, l, l1);
       l = l1;
       continue;
     }
