@@ -484,10 +484,9 @@ int32_t narrow_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
   if (n == 4) fill_narrow_params<4>(e, e->n4, o);
   if (e->wide) {      // 5..64 states: one wave per (replica, branch), lanes = states (phm_wbranch.hip)
     HIPCHK(e->d_wb_cnt.alloc(sizeof(double) * (size_t)S * e->dcols));
-    // transition maps of the sampling sweep (n bytes per edge and chain) up to 32 states -- a map costs n draws of n terms: one chain
-    // on C5 (20 states) 0.40 -> 0.37 ms per sweep, on C4 (61 states) 0.78 -> 0.82 -- and while they stay small beside the paths;
-    // otherwise one launch per depth level
-    if (n <= 32 && (size_t)S * s.n_edge * n <= (256u << 20)) HIPCHK(e->d_nw_dmap.alloc((size_t)S * s.n_edge * n));
+    // transition maps of the sampling sweep (n bytes per edge and chain) while they stay small beside the paths; beyond: one launch
+    // per depth level
+    if ((size_t)S * s.n_edge * n <= (256u << 20)) HIPCHK(e->d_nw_dmap.alloc((size_t)S * s.n_edge * n));
     HIPCHK(hipMemset(e->d_wb_cnt.p, 0, e->d_wb_cnt.bytes));
     HIPCHK(e->d_B2.alloc(sizeof(double) * n * n)); HIPCHK(e->d_Bc.alloc(sizeof(double) * n * n));
     HIPCHK(e->d_ell_col.alloc(sizeof(int32_t) * n * phm::WB_ELL_MAX)); HIPCHK(e->d_ell_val.alloc(sizeof(double) * n * phm::WB_ELL_MAX));

@@ -208,7 +208,8 @@ __global__ __launch_bounds__(WB_BLOCK) void wb_down_kernel(WideBranchParams p, i
 // workgroup per chain) walks the depth levels with state[child] = map[edge][state[parent]], node states in LDS, one byte
 // gathered per edge and level.  Same operands, same order as wb_down_kernel for the ps that materialises.
 __global__ __launch_bounds__(WB_BLOCK) void wb_downmap_kernel(WideBranchParams p, int it) {
-  const int n = p.n_states, lane = threadIdx.x & 63;
+  __shared__ double s_w[WB_BLOCK / 64][64];
+  const int n = p.n_states, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int idx = blockIdx.x * (WB_BLOCK / 64) + (threadIdx.x >> 6);          // position in depth-level order
   const int r = blockIdx.y;
   if (idx >= p.n_edge) return;
@@ -231,15 +232,23 @@ __global__ __launch_bounds__(WB_BLOCK) void wb_downmap_kernel(WideBranchParams p
       node_id = (uint32_t)(~ds.child);
     }
     const double u = stream_u(p.seed_lo, p.seed_hi, (uint32_t)(p.replica_offset + r), (uint32_t)it, ENT_NODE | node_id, 0);
-    const double* __restrict__ rows = p.rowL + (size_t)kk * n * n;
-    int mine = 0;
-    for (int q = 0; q < n; ++q) {
-      const double w = (lane < n) ? rows[(size_t)q * n + c] * wgt : 0.0;
-      uint32_t e2 = 0;
-      const int cs = coop_sample(w, u, n, lane, e2);                           // :655
-      if (lane == q) mine = cs | (e2 ? 0x80 : 0);
-    }
-    if (lane < n) map[lane] = (uint8_t)mine;
+    // lane = CANDIDATE parent state q: the lane walks its own row of (Bc^T)^kk against the weights (broadcast from LDS), once for
+    // the total and once for the count of partial sums below u * total -- the sums coop_sample forms (index order, unfused),
+    // 2 n short steps per wave instead of n draws of n readlane steps each
+    const double* __restrict__ rq = p.rowL + ((size_t)kk * n + c) * n;
+    s_w[wave][lane] = (lane < n) ? wgt : 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+    double run = rq[0] * s_w[wave][0];
+    for (int j = 1; j < n; ++j) run += rq[j] * s_w[wave][j];
+    const bool bad = !(run > 0.0) || isinf(run);
+    const double thr = u * run;
+    double cum = rq[0] * s_w[wave][0];
+    int cnt = (thr <= cum) ? 0 : 1;
+    for (int j = 1; j < n; ++j) { cum += rq[j] * s_w[wave][j]; cnt += (thr <= cum) ? 0 : 1; }
+    const int cs = cnt < n ? cnt : n - 1;
+    if (lane < n) map[lane] = (uint8_t)(cs | (bad ? 0x80 : 0));
   } else {
     if (lane < n) map[lane] = tips[~ds.child];                                 // :612
   }
