@@ -289,7 +289,7 @@ __global__ __launch_bounds__(WB_WALK_BLOCK) void wb_walk_kernel(WideBranchParams
 
 // One branch of one replica: resamplebranchstates :264-308, shortener :44-73 (shortenerbf :997-1030), virtual jumps
 // sampleabranch :391-410, dwell sums updatedwelltimes :745-757.
-__global__ __launch_bounds__(WB_BLOCK) void wb_branch_kernel(WideBranchParams p, int it) {
+__global__ __launch_bounds__(WB_BLOCK) void wb_branch_kernel(WideBranchParams p, int it, int b2_in_lds) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ __align__(16) double s_ltab[2 * PHM_LOGTAB_N];        // (1/c_j, log c_j) of the exponential variates (neglog_u32)
   for (int i = threadIdx.x; i < 2 * PHM_LOGTAB_N; i += WB_BLOCK) s_ltab[i] = logtab_entry(i);
@@ -300,6 +300,14 @@ __global__ __launch_bounds__(WB_BLOCK) void wb_branch_kernel(WideBranchParams p,
   double* s_e2val = reinterpret_cast<double*>(smem);
   int32_t* s_e2col = reinterpret_cast<int32_t*>(s_e2val + p.n_states * w2);
   for (int i = threadIdx.x; i < p.n_states * w2; i += WB_BLOCK) { s_e2col[i] = p.ell2_col[i]; s_e2val[i] = p.ell2_val[i]; }
+  // A handful of chains (b2_in_lds): what the kernel waits for is the LATENCY of its longest branch, and a row of B2 read from L2
+  // after every draw (the row index is the state just drawn) is a dependent round trip per step: the dense matrix is staged then
+  const int ldb = p.n_states | 1;
+  const double* s_B2 = reinterpret_cast<const double*>(smem);
+  if (b2_in_lds && w2 == 0) {
+    double* dst = reinterpret_cast<double*>(smem);
+    for (int i = threadIdx.x; i < p.n_states * p.n_states; i += WB_BLOCK) dst[(i / p.n_states) * ldb + i % p.n_states] = p.B2[i];
+  }
   __syncthreads();
   const int n = p.n_states, lane = threadIdx.x & 63;
   const int idx = blockIdx.x * (WB_BLOCK / 64) + (threadIdx.x >> 6);
@@ -337,14 +345,17 @@ __global__ __launch_bounds__(WB_BLOCK) void wb_branch_kernel(WideBranchParams p,
       if (w2 > 0) {
         // Sparse forward row: lanes are the row's non-zero slots (columns ascending).  The zero entries of the dense vector
         // add +0 to every partial sum, so the draw over the slots picks the same column as the draw over all n states.
+        // the backward vector's row does not depend on the state: one coalesced load, the slot's entry picked across lanes
+        const double beta_c = p.colL[((size_t)kk * n + cs) * n + c];
         const int slot = lane < w2 ? cur_s * w2 + lane : cur_s * w2;
         const int mycol = s_e2col[slot];
-        const double pr = (lane < w2) ? s_e2val[slot] * p.colL[((size_t)kk * n + cs) * n + mycol] : 0.0;
+        const double pr = (lane < w2) ? s_e2val[slot] * __shfl(beta_c, mycol, 64) : 0.0;
         const int t = coop_sample(pr, su.draw((uint32_t)(i - 1)), w2, lane, err);
         si = __builtin_amdgcn_readlane(mycol, t);
       } else {
         const double beta = p.colL[((size_t)kk * n + cs) * n + c];
-        const double pr = (lane < n) ? p.B2[cur_s * n + c] * beta : 0.0;
+        const double b2 = (b2_in_lds) ? s_B2[cur_s * ldb + c] : p.B2[cur_s * n + c];
+        const double pr = (lane < n) ? b2 * beta : 0.0;
         si = coop_sample(pr, su.draw((uint32_t)(i - 1)), n, lane, err);
       }
     }
@@ -497,7 +508,9 @@ hipError_t launch_wbranch_sweep(const WideBranchParams& p, const std::vector<int
       if (cnt > 0) hipLaunchKernelGGL(wb_down_kernel, dim3((cnt + WPB - 1) / WPB, S), dim3(WB_BLOCK), 0, stream, p, it, down_off[l], down_off[l + 1]);
     }
   }
-  hipLaunchKernelGGL(wb_branch_kernel, dim3((p.n_edge + WPB - 1) / WPB, S), dim3(WB_BLOCK), (size_t)p.n_states * p.ell2_w * 12, stream, p, it);
+  const int b2_in_lds = (p.ell2_w == 0 && (int64_t)S * p.n_edge <= 32768) ? 1 : 0;      // a handful of chains: latency of the longest branch
+  const size_t br_lds = b2_in_lds ? sizeof(double) * (size_t)p.n_states * (p.n_states | 1) : (size_t)p.n_states * p.ell2_w * 12;
+  hipLaunchKernelGGL(wb_branch_kernel, dim3((p.n_edge + WPB - 1) / WPB, S), dim3(WB_BLOCK), br_lds, stream, p, it, b2_in_lds);
   hipLaunchKernelGGL(wb_stats_kernel, dim3(S, (unsigned)(p.n_states + 1)), dim3(256), 0, stream, p);
   const int64_t items = (int64_t)(p.reduce ? p.n_tiles : p.n_rep) * p.n_cols;
   hipLaunchKernelGGL(wb_emit_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, p, it);
