@@ -114,3 +114,20 @@ def test_automatic_mapping_follows_tree_size():
         eng = _lib.Engine(z, Q, pid, Omega, 2, variant=_lib.PHM_MCMC_BIGTREE, seed=1, n_replicas=S)
         assert eng.info().mapping == _lib.MAPPING[want], (cfg, S)
         eng.close()
+
+
+def test_one_chain_in_several_run_calls_and_single_row_reads():
+    """run(2), read the last row (served from the row the statistics kernel left in host memory), run(3), read everything: the
+    sweeps of one call hand their statistics to the next sweep's first launch, the last one of a call to a launch of its own."""
+    z, Q, pid, Omega = synth.config_problem(2)
+    nen, nodelist, root = _orders(z)
+    want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(4) + Q / Omega, Omega, nen, nodelist, root, 5, variant=O.BIGTREE, seed=12, replica=0)
+    assert rc == 0
+    eng = _lib.Engine(z, Q, pid, Omega, 5, variant=_lib.PHM_MCMC_BIGTREE, seed=12, n_replicas=1)
+    assert eng.info().mapping == _lib.MAPPING["branches"]
+    eng.run(2); eng.sync()
+    _same(eng.stats(1, 1)[0], want[1:2], 4)
+    eng.run(3); eng.sync()
+    _same(eng.stats(4, 1)[0], want[4:5], 4)
+    _same(eng.stats(0, 5)[0], want, 4)
+    eng.close()
