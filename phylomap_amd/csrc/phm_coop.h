@@ -115,6 +115,55 @@ __device__ __forceinline__ double coop_matvec_ell(const int32_t* __restrict__ ec
   return acc;
 }
 
+// the value of the lane below / above.  gfx950 has no whole-wave DPP shifts (wave_shr / wave_shl ended with gfx9.0): a row shift
+// inside each row of 16 lanes, and the three lanes at a row boundary take their neighbour by v_readlane (uniform lane numbers).
+// The lane at the end of the wave reads 0.
+__device__ __forceinline__ double wave_from_below(double x, int lane) {        // lane c <- lane c - 1
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  int slo = __builtin_amdgcn_update_dpp(0, lo, 0x111, 0xf, 0xf, false);        // row_shr:1
+  int shi = __builtin_amdgcn_update_dpp(0, hi, 0x111, 0xf, 0xf, false);
+#pragma unroll
+  for (int r = 1; r < 4; ++r) {
+    const int blo = __builtin_amdgcn_readlane(lo, 16 * r - 1), bhi = __builtin_amdgcn_readlane(hi, 16 * r - 1);
+    slo = (lane == 16 * r) ? blo : slo; shi = (lane == 16 * r) ? bhi : shi;
+  }
+  return __hiloint2double(shi, slo);
+}
+__device__ __forceinline__ double wave_from_above(double x, int lane) {        // lane c <- lane c + 1
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  int slo = __builtin_amdgcn_update_dpp(0, lo, 0x101, 0xf, 0xf, false);        // row_shl:1
+  int shi = __builtin_amdgcn_update_dpp(0, hi, 0x101, 0xf, 0xf, false);
+#pragma unroll
+  for (int r = 1; r < 4; ++r) {
+    const int blo = __builtin_amdgcn_readlane(lo, 16 * r), bhi = __builtin_amdgcn_readlane(hi, 16 * r);
+    slo = (lane == 16 * r - 1) ? blo : slo; shi = (lane == 16 * r - 1) ? bhi : shi;
+  }
+  return __hiloint2double(shi, slo);
+}
+
+// The ELLPACK product for a BANDED matrix (half-bandwidth HB <= 2: the tutorial's tridiagonal Q): coef[d] = M[c][c + d - HB] (0 where
+// the matrix has no entry), neighbours through DPP row shifts (+ readlane at the row boundaries) instead of ds_bpermute -- a chain step is
+// 2 HB shifts and 2 HB + 1 fused multiply-adds.  Same terms in the same (ascending column) order; a zero coefficient leaves the fused chain unchanged.
+template <int HB>
+__device__ __forceinline__ double coop_matvec_band(const double (&coef)[5], double v, int lane) {
+  double acc = 0.0;
+  if (HB == 2) {
+    const double m1 = wave_from_below(v, lane), p1 = wave_from_above(v, lane);
+    const double m2 = wave_from_below(m1, lane), p2 = wave_from_above(p1, lane);
+    acc = __builtin_fma(coef[0], m2, acc);
+    acc = __builtin_fma(coef[1], m1, acc);
+    acc = __builtin_fma(coef[2], v, acc);
+    acc = __builtin_fma(coef[3], p1, acc);
+    acc = __builtin_fma(coef[4], p2, acc);
+  } else {
+    const double m1 = wave_from_below(v, lane), p1 = wave_from_above(v, lane);
+    acc = __builtin_fma(coef[0], m1, acc);
+    acc = __builtin_fma(coef[1], v, acc);
+    acc = __builtin_fma(coef[2], p1, acc);
+  }
+  return acc;
+}
+
 // first j with u*sum(p) <= p_0+..+p_j (index order); lanes >= n carry p = 0 and never count
 __device__ __forceinline__ int coop_sample(double p, double u, int n, int lane, uint32_t& err) {
   double run = readlane_f64(p, 0);

@@ -244,6 +244,12 @@ int32_t upload_model(phm_engine* e) {
         return PHM_OK;
       };
       { int32_t st = ellpack(e->hBc, e->d_ell_col, e->d_ell_val, e->pwb.ell_w); if (st) return st; }
+      {   // a banded chain matrix (half-bandwidth 1 or 2): neighbours through wave shifts (coop_matvec_band)
+        int hb = 0;
+        for (int i = 0; i < n; ++i)
+          for (int j = 0; j < n; ++j) if (e->hBc[(size_t)i * n + j] != 0.0) hb = std::max(hb, std::abs(i - j));
+        e->pwb.band_hb = (e->pwb.ell_w > 0 && hb >= 1 && hb <= 2 && e->sparse_req != 2) ? hb : 0;
+      }
       { int32_t st = ellpack(e->hB2, e->d_ell2_col, e->d_ell2_val, e->pwb.ell2_w); if (st) return st; }
       return PHM_OK;
     }
@@ -502,7 +508,7 @@ int32_t narrow_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
     p.seed_lo = (uint32_t)(o.seed & 0xFFFFFFFFull); p.seed_hi = (uint32_t)(o.seed >> 32);
     p.total_cap = e->nw_total_cap;
     p.B2 = e->d_B2.as<double>(); p.Bc = e->d_Bc.as<double>(); p.scale = e->d_scale.as<double>(); p.pid = e->d_pid.as<double>();
-    p.ell_w = 0; p.ell_col = e->d_ell_col.as<int32_t>(); p.ell_val = e->d_ell_val.as<double>();
+    p.ell_w = 0; p.band_hb = 0; p.ell_col = e->d_ell_col.as<int32_t>(); p.ell_val = e->d_ell_val.as<double>();
     p.ell2_w = 0; p.ell2_col = e->d_ell2_col.as<int32_t>(); p.ell2_val = e->d_ell2_val.as<double>();
     p.up = e->d_up.as<phm::UpStep>(); p.down = e->d_down.as<phm::DownStep>();
     p.up_order = e->d_nw_up_order.as<int32_t>(); p.down_order = e->d_nw_down_order.as<int32_t>();

@@ -37,6 +37,7 @@ struct WideBranchParams {
   int32_t klong;                             // rows of the chain tables
   int32_t ell_w;                             // > 0: the chain matrix has at most ell_w non-zeros per row (ELLPACK copy below)
   int32_t ell2_w;                            // the same for the dense-step matrix B2 (rows of the forward draws)
+  int32_t band_hb;                           // ell_w > 0 and every non-zero of the chain matrix within |row - col| <= band_hb (1 or 2); else 0
   uint32_t seed_lo, seed_hi;
   int64_t total_cap;                         // doubles per replica in one dwell buffer
   const double* B2;                          // [n][n] dense B, row-major

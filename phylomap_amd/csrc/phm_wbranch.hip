@@ -71,7 +71,9 @@ __device__ __forceinline__ void wb_up_level(const WideBranchParams& p, const UpL
       return p.tip_masks ? p.maskL[((size_t)k * 2 + (ts & 1)) * n + c] : p.colL[((size_t)k * n + ts) * n + c];
     }
     double v = PLr[(size_t)child * n + c];
-    if (ell_w > 0) for (int i = 0; i < k; ++i) v = coop_matvec_ell(sh.ecol, sh.eval, v, ell_w, c);
+    if (p.band_hb == 1) { const double (&cf)[5] = reinterpret_cast<const double (&)[5]>(brow); for (int i = 0; i < k; ++i) v = coop_matvec_band<1>(cf, v, lane); }
+    else if (p.band_hb == 2) { const double (&cf)[5] = reinterpret_cast<const double (&)[5]>(brow); for (int i = 0; i < k; ++i) v = coop_matvec_band<2>(cf, v, lane); }
+    else if (ell_w > 0) for (int i = 0; i < k; ++i) v = coop_matvec_ell(sh.ecol, sh.eval, v, ell_w, c);
     else for (int i = 0; i < k; ++i) v = coop_matvec_regs(brow, sh.vec[wave], v, n, lane);
     return v;
   };
@@ -109,6 +111,14 @@ __device__ __forceinline__ void wb_load_row(const WideBranchParams& p, const UpL
   const int c = lane < n ? lane : n - 1;
 #pragma unroll
   for (int j = 0; j < 64; ++j) brow[j] = (p.ell_w == 0 && j < n) ? sh.l.Bc[c * sh.l.ldn + j] : 0.0;
+  if (p.band_hb > 0) {                             // banded: brow[d] = M[c][c + d - hb] gathered from the lane's ELLPACK row
+    for (int t = 0; t < p.ell_w; ++t) {
+      const int d = sh.ecol[c * p.ell_w + t] - c + p.band_hb;
+      const double val = sh.eval[c * p.ell_w + t];
+#pragma unroll
+      for (int q = 0; q < 5; ++q) brow[q] = (q == d) ? brow[q] + val : brow[q];      // padding entries carry value 0
+    }
+  }
 }
 
 __global__ __launch_bounds__(WB_BLOCK) void wb_up_kernel(WideBranchParams p, int begin, int end) {
@@ -135,7 +145,7 @@ __global__ __launch_bounds__(BS) void wb_up_run_kernel(WideBranchParams p, int l
   __shared__ __align__(16) double s_vec[BS / 64][64];
   const UpLds sh = wb_up_stage<BS>(p, smem, s_second, s_vec);
   double brow[64];
-  if (DENSE) wb_load_row(p, sh, brow);
+  if (DENSE || p.band_hb > 0) wb_load_row(p, sh, brow);
   else {
 #pragma unroll
     for (int j = 0; j < 64; ++j) brow[j] = 0.0;
@@ -289,7 +299,7 @@ __global__ __launch_bounds__(WB_WALK_BLOCK) void wb_walk_kernel(WideBranchParams
 
 // One branch of one replica: resamplebranchstates :264-308, shortener :44-73 (shortenerbf :997-1030), virtual jumps
 // sampleabranch :391-410, dwell sums updatedwelltimes :745-757.
-__global__ __launch_bounds__(WB_BLOCK) void wb_branch_kernel(WideBranchParams p, int it, int b2_in_lds) {
+__global__ __launch_bounds__(WB_BLOCK) void wb_branch_kernel(WideBranchParams p, int it) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ __align__(16) double s_ltab[2 * PHM_LOGTAB_N];        // (1/c_j, log c_j) of the exponential variates (neglog_u32)
   for (int i = threadIdx.x; i < 2 * PHM_LOGTAB_N; i += WB_BLOCK) s_ltab[i] = logtab_entry(i);
@@ -300,14 +310,6 @@ __global__ __launch_bounds__(WB_BLOCK) void wb_branch_kernel(WideBranchParams p,
   double* s_e2val = reinterpret_cast<double*>(smem);
   int32_t* s_e2col = reinterpret_cast<int32_t*>(s_e2val + p.n_states * w2);
   for (int i = threadIdx.x; i < p.n_states * w2; i += WB_BLOCK) { s_e2col[i] = p.ell2_col[i]; s_e2val[i] = p.ell2_val[i]; }
-  // A handful of chains (b2_in_lds): what the kernel waits for is the LATENCY of its longest branch, and a row of B2 read from L2
-  // after every draw (the row index is the state just drawn) is a dependent round trip per step: the dense matrix is staged then
-  const int ldb = p.n_states | 1;
-  const double* s_B2 = reinterpret_cast<const double*>(smem);
-  if (b2_in_lds && w2 == 0) {
-    double* dst = reinterpret_cast<double*>(smem);
-    for (int i = threadIdx.x; i < p.n_states * p.n_states; i += WB_BLOCK) dst[(i / p.n_states) * ldb + i % p.n_states] = p.B2[i];
-  }
   __syncthreads();
   const int n = p.n_states, lane = threadIdx.x & 63;
   const int idx = blockIdx.x * (WB_BLOCK / 64) + (threadIdx.x >> 6);
@@ -345,17 +347,14 @@ __global__ __launch_bounds__(WB_BLOCK) void wb_branch_kernel(WideBranchParams p,
       if (w2 > 0) {
         // Sparse forward row: lanes are the row's non-zero slots (columns ascending).  The zero entries of the dense vector
         // add +0 to every partial sum, so the draw over the slots picks the same column as the draw over all n states.
-        // the backward vector's row does not depend on the state: one coalesced load, the slot's entry picked across lanes
-        const double beta_c = p.colL[((size_t)kk * n + cs) * n + c];
         const int slot = lane < w2 ? cur_s * w2 + lane : cur_s * w2;
         const int mycol = s_e2col[slot];
-        const double pr = (lane < w2) ? s_e2val[slot] * __shfl(beta_c, mycol, 64) : 0.0;
+        const double pr = (lane < w2) ? s_e2val[slot] * p.colL[((size_t)kk * n + cs) * n + mycol] : 0.0;
         const int t = coop_sample(pr, su.draw((uint32_t)(i - 1)), w2, lane, err);
         si = __builtin_amdgcn_readlane(mycol, t);
       } else {
         const double beta = p.colL[((size_t)kk * n + cs) * n + c];
-        const double b2 = (b2_in_lds) ? s_B2[cur_s * ldb + c] : p.B2[cur_s * n + c];
-        const double pr = (lane < n) ? b2 * beta : 0.0;
+        const double pr = (lane < n) ? p.B2[cur_s * n + c] * beta : 0.0;
         si = coop_sample(pr, su.draw((uint32_t)(i - 1)), n, lane, err);
       }
     }
@@ -508,9 +507,7 @@ hipError_t launch_wbranch_sweep(const WideBranchParams& p, const std::vector<int
       if (cnt > 0) hipLaunchKernelGGL(wb_down_kernel, dim3((cnt + WPB - 1) / WPB, S), dim3(WB_BLOCK), 0, stream, p, it, down_off[l], down_off[l + 1]);
     }
   }
-  const int b2_in_lds = (p.ell2_w == 0 && (int64_t)S * p.n_edge <= 32768) ? 1 : 0;      // a handful of chains: latency of the longest branch
-  const size_t br_lds = b2_in_lds ? sizeof(double) * (size_t)p.n_states * (p.n_states | 1) : (size_t)p.n_states * p.ell2_w * 12;
-  hipLaunchKernelGGL(wb_branch_kernel, dim3((p.n_edge + WPB - 1) / WPB, S), dim3(WB_BLOCK), br_lds, stream, p, it, b2_in_lds);
+  hipLaunchKernelGGL(wb_branch_kernel, dim3((p.n_edge + WPB - 1) / WPB, S), dim3(WB_BLOCK), (size_t)p.n_states * p.ell2_w * 12, stream, p, it);
   hipLaunchKernelGGL(wb_stats_kernel, dim3(S, (unsigned)(p.n_states + 1)), dim3(256), 0, stream, p);
   const int64_t items = (int64_t)(p.reduce ? p.n_tiles : p.n_rep) * p.n_cols;
   hipLaunchKernelGGL(wb_emit_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, p, it);
