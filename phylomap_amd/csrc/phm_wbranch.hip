@@ -299,8 +299,12 @@ __global__ __launch_bounds__(WB_WALK_BLOCK) void wb_walk_kernel(WideBranchParams
 
 // One branch of one replica: resamplebranchstates :264-308, shortener :44-73 (shortenerbf :997-1030), virtual jumps
 // sampleabranch :391-410, dwell sums updatedwelltimes :745-757.
-__global__ __launch_bounds__(WB_BLOCK) void wb_branch_kernel(WideBranchParams p, int it) {
+__global__ __launch_bounds__(WB_BLOCK) void wb_branch_kernel(WideBranchParams p, int it, int b2_in_lds) {
   extern __shared__ __align__(16) unsigned char smem[];
+#ifdef PHM_DEBUG_LEVEL_CLOCK
+  const unsigned long long tk0 = wall_clock64();
+  unsigned long long tk1 = 0, tk2 = 0;
+#endif
   __shared__ __align__(16) double s_ltab[2 * PHM_LOGTAB_N];        // (1/c_j, log c_j) of the exponential variates (neglog_u32)
   for (int i = threadIdx.x; i < 2 * PHM_LOGTAB_N; i += WB_BLOCK) s_ltab[i] = logtab_entry(i);
   // This kernel touches one row of the forward-step matrix per draw: it reads that row from global memory (L2) instead of
@@ -310,6 +314,20 @@ __global__ __launch_bounds__(WB_BLOCK) void wb_branch_kernel(WideBranchParams p,
   double* s_e2val = reinterpret_cast<double*>(smem);
   int32_t* s_e2col = reinterpret_cast<int32_t*>(s_e2val + p.n_states * w2);
   for (int i = threadIdx.x; i < p.n_states * w2; i += WB_BLOCK) { s_e2col[i] = p.ell2_col[i]; s_e2val[i] = p.ell2_val[i]; }
+  // A step of this kernel is ~1 us of wave-cooperative arithmetic; a global round trip in it doubles or triples it, and with a
+  // handful of chains the kernel lasts as long as its longest branch.  So: the dense forward-step matrix is staged in LDS when the
+  // chains are few (b2_in_lds; its row index is the state just drawn), the operands that do not depend on the state -- the next
+  // old segment's length, the next backward row -- are requested one step ahead, and the merged segments wait for pass B in LDS
+  // (the first WB_MERGED_LDS of a branch; the rest in the global scratch).
+  constexpr int WB_MERGED_LDS = 192;
+  __shared__ double s_ml[WB_BLOCK / 64][WB_MERGED_LDS];
+  __shared__ uint8_t s_ms[WB_BLOCK / 64][WB_MERGED_LDS];
+  const int ldb = p.n_states | 1;
+  const double* s_B2 = reinterpret_cast<const double*>(smem);
+  if (b2_in_lds && w2 == 0) {
+    double* dst = reinterpret_cast<double*>(smem);
+    for (int i = threadIdx.x; i < p.n_states * p.n_states; i += WB_BLOCK) dst[(i / p.n_states) * ldb + i % p.n_states] = p.B2[i];
+  }
   __syncthreads();
   const int n = p.n_states, lane = threadIdx.x & 63;
   const int idx = blockIdx.x * (WB_BLOCK / 64) + (threadIdx.x >> 6);
@@ -335,40 +353,64 @@ __global__ __launch_bounds__(WB_BLOCK) void wb_branch_kernel(WideBranchParams p,
   su.open(ENT_BSTATE | (uint32_t)b, (uint32_t)it, rep, p.seed_lo, p.seed_hi);
 
   // pass A: interior states s_i ~ B[s_{i-1},:] (.) B^(m-i-1) e_end (:290, :301-304), neighbours merged (:54)
+  const int wv = threadIdx.x >> 6;
+  auto put_merged = [&](int k, double len, int st) {
+    if (k < WB_MERGED_LDS) { s_ml[wv][k] = len; s_ms[wv][k] = (uint8_t)st; }
+    else { ml[k] = len; ms[k] = (uint8_t)st; }
+  };
   int w = 0;
   int cur_s = (m == 1) ? cs : ps;                    // updatenodestates :469-472 (m == 1: the child end wins)
   double cur_len = in[0];
+  // operands of step 1, then always those of the next step while the current one is drawn (clamped addresses, dropped when unused)
+  auto beta_row = [&](int i) {                       // lane c: (Bc^(m-i-1) e_cs)[c]
+    int kk = m - i - 1;
+    if (kk < 0) kk = 0;
+    if (kk >= p.klong) { err |= DERR_CAPACITY; kk = p.klong - 1; }
+    return p.colL[((size_t)kk * n + cs) * n + c];
+  };
+  double d_next = in[min(1, m - 1)];
+  double beta_next = beta_row(1);
+#ifdef PHM_DEBUG_LEVEL_CLOCK
+  if (cur_len >= 0.0) tk1 = wall_clock64();
+#endif
   for (int i = 1; i < m; ++i) {
+    const double di = d_next, beta = beta_next;
+    d_next = in[min(i + 1, m - 1)];
+    beta_next = beta_row(min(i + 1, m - 1));
     int si;
     if (i == m - 1) si = cs;
     else {
-      int kk = m - i - 1;
-      if (kk >= p.klong) { err |= DERR_CAPACITY; kk = p.klong - 1; }
       if (w2 > 0) {
         // Sparse forward row: lanes are the row's non-zero slots (columns ascending).  The zero entries of the dense vector
         // add +0 to every partial sum, so the draw over the slots picks the same column as the draw over all n states.
         const int slot = lane < w2 ? cur_s * w2 + lane : cur_s * w2;
         const int mycol = s_e2col[slot];
-        const double pr = (lane < w2) ? s_e2val[slot] * p.colL[((size_t)kk * n + cs) * n + mycol] : 0.0;
+        const double beta_sel = __shfl(beta, mycol, 64);       // by every lane: a shuffle under a lane condition reads inactive lanes
+        const double pr = (lane < w2) ? s_e2val[slot] * beta_sel : 0.0;
         const int t = coop_sample(pr, su.draw((uint32_t)(i - 1)), w2, lane, err);
         si = __builtin_amdgcn_readlane(mycol, t);
       } else {
-        const double beta = p.colL[((size_t)kk * n + cs) * n + c];
-        const double pr = (lane < n) ? p.B2[cur_s * n + c] * beta : 0.0;
+        const double b2 = b2_in_lds ? s_B2[cur_s * ldb + c] : p.B2[cur_s * n + c];
+        const double pr = (lane < n) ? b2 * beta : 0.0;
         si = coop_sample(pr, su.draw((uint32_t)(i - 1)), n, lane, err);
       }
     }
-    const double di = in[i];
     if (p.count_self && lane == 0) atomicAdd(cnt + cur_s * n + si, 1.0);                    // shortenerbf :1010-1014
     if (si == cur_s) cur_len = cur_len + di;                                                // shortener :54
     else {
-      ml[w] = cur_len; ms[w] = (uint8_t)cur_s;
+      put_merged(w, cur_len, cur_s);
       if (!p.count_self && lane == 0) atomicAdd(cnt + cur_s * (n - 1) + (si > cur_s ? si - 1 : si), 1.0);   // :65-66
       ++w; cur_s = si; cur_len = di;
     }
   }
-  ml[w] = cur_len; ms[w] = (uint8_t)cur_s;
+  put_merged(w, cur_len, cur_s);
   const int nmerged = w + 1;
+#ifdef PHM_DEBUG_LEVEL_CLOCK
+  tk2 = wall_clock64();
+#endif
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 
   // pass B: virtual jumps, gaps ~ Exp(Omega + q_ss) until each merged segment is used up (:391-410); a segment that is not
   // positive leaves itself and everything after it untouched (:397, :405-406).  Lane s carries the dwell sum of state s.
@@ -382,8 +424,8 @@ __global__ __launch_bounds__(WB_BLOCK) void wb_branch_kernel(WideBranchParams p,
   bool have_gen = false;
   bool stuck = false;
   for (int j = 0; j < nmerged; ++j) {
-    const int s = ms[j];
-    const double len = ml[j];
+    const int s = (j < WB_MERGED_LDS) ? (int)s_ms[wv][j] : (int)ms[j];
+    const double len = (j < WB_MERGED_LDS) ? s_ml[wv][j] : ml[j];
     if (stuck || !(0.0 < len)) {
       stuck = true;
       if (mnew < cap) out[mnew] = len; else err |= DERR_CAPACITY;
@@ -410,6 +452,11 @@ __global__ __launch_bounds__(WB_BLOCK) void wb_branch_kernel(WideBranchParams p,
   }
   if (mnew > cap) mnew = cap;
   mc[b] = mnew;
+#ifdef PHM_DEBUG_LEVEL_CLOCK
+  if (it == 30 && r == 0 && lane == 0 && (idx < 4 || idx == 200))
+    printf("wbbranch idx %d m %d mnew %d draws %d: loads %d passA %d passB %d ticks\n", idx, m, mnew, (int)edraw, (int)(tk1 - tk0), (int)(tk2 - tk1),
+           (int)(wall_clock64() - tk2));
+#endif
   double* part = p.part + ((size_t)r * p.n_edge + b) * (n + 1);
   if (lane < n) part[lane] = mine;
   if (lane == 0) part[n] = (double)(m + mnew);
@@ -507,7 +554,9 @@ hipError_t launch_wbranch_sweep(const WideBranchParams& p, const std::vector<int
       if (cnt > 0) hipLaunchKernelGGL(wb_down_kernel, dim3((cnt + WPB - 1) / WPB, S), dim3(WB_BLOCK), 0, stream, p, it, down_off[l], down_off[l + 1]);
     }
   }
-  hipLaunchKernelGGL(wb_branch_kernel, dim3((p.n_edge + WPB - 1) / WPB, S), dim3(WB_BLOCK), (size_t)p.n_states * p.ell2_w * 12, stream, p, it);
+  const int b2_in_lds = (p.ell2_w == 0 && (int64_t)S * p.n_edge <= 32768) ? 1 : 0;      // a handful of chains: latency of the longest branch
+  const size_t br_lds = b2_in_lds ? sizeof(double) * (size_t)p.n_states * (p.n_states | 1) : (size_t)p.n_states * p.ell2_w * 12;
+  hipLaunchKernelGGL(wb_branch_kernel, dim3((p.n_edge + WPB - 1) / WPB, S), dim3(WB_BLOCK), br_lds, stream, p, it, b2_in_lds);
   hipLaunchKernelGGL(wb_stats_kernel, dim3(S, (unsigned)(p.n_states + 1)), dim3(256), 0, stream, p);
   const int64_t items = (int64_t)(p.reduce ? p.n_tiles : p.n_rep) * p.n_cols;
   hipLaunchKernelGGL(wb_emit_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, p, it);
