@@ -26,7 +26,13 @@
 
 namespace phm {
 
-constexpr int NARROW_CLUSTER_NODES = 256;   // internal nodes per pruning cluster (their vectors: 8 KB of LDS at 4 states)
+#ifndef PHM_NARROW_CLUSTER_NODES
+#define PHM_NARROW_CLUSTER_NODES 256
+#endif
+#ifndef PHM_NARROW_LONG
+#define PHM_NARROW_LONG 128
+#endif
+constexpr int NARROW_CLUSTER_NODES = PHM_NARROW_CLUSTER_NODES;   // internal nodes per pruning cluster (their vectors: 8 KB of LDS at 4 states)
 constexpr int NARROW_CLUSTER_BLOCK = 512;   // eight lanes per node, 64 nodes per pass
 #ifndef PHM_NARROW_BRANCH_LANES
 #define PHM_NARROW_BRANCH_LANES 8

@@ -704,7 +704,7 @@ __global__ void narrow_emit_kernel(NarrowParams<NS> p, int it) {
 
 template <int NS>
 static unsigned narrow_branch_waves(const NarrowParams<NS>& p, int& n_long) {
-  n_long = std::min(p.n_edge / 16, 128);
+  n_long = std::min(p.n_edge / 16, PHM_NARROW_LONG);
   return (unsigned)(n_long + (p.n_edge - n_long + 7) / 8);
 }
 
