@@ -1,14 +1,18 @@
-// phm_narrow.h -- the MCMC sweep for FEW chains on a LARGE tree (n <= 4): one lane per BRANCH instead of one lane per
-// replica.  The reference's own workflows run a single chain (every driver's default; e.g. the 3 951-tip squamate analysis,
+// phm_narrow.h -- the MCMC sweep for ONE chain (or a handful) on a LARGE tree (n <= 4): the branch mapping.
+// The reference's own workflows run a single chain (every driver's default; e.g. the 3 951-tip squamate analysis,
 // vignettes/Squamate_DIC_model_selection.Rnw:76-120, 10 000 sweeps of ~880 000 segments each); with one lane per replica
 // such a call would walk the whole tree in ONE lane.  Given the node states the branches of a sweep are conditionally
 // independent (sampleabranch src/phylomap.cpp:370-413 touches one branch), and the random numbers are addressed by
-// (replica, iteration, branch), so the branches can be resampled concurrently with the same results:
-//   up    : one launch per HEIGHT level of the tree, a lane per internal node             makePLrcpp* :503-529
-//   root  : a lane per chain                                                              :618-627
-//   down  : one launch per DEPTH level, a lane per edge: child state + the edge's end states   :640-657, :460-475
-//   branch: a lane per branch (longest first): resample, merge, count, re-insert virtual jumps    :264-413
-//   stats : fixed-order reduction of the per-branch partial sums                          :745-757
+// (replica, iteration, node | branch), so the work of a sweep can be laid out for the LATENCY of its longest dependent line
+// (round 3) with the same results:
+//   pruning : subtree CLUSTERS in tiers (phm_sched.h ClusterPlan), one workgroup per cluster, vectors in LDS, eight lanes
+//             per node (a quad per child, mat-vec rows across the quad by DPP)                 makePLrcpp* :503-529
+//   states  : a TRANSITION MAP per edge (the child's draw for each possible parent state, all edges side by side), then one
+//             workgroup per chain walks the depth levels by table look-up                      :618-657, :460-475, :1384-1397
+//   branches: eight lanes per branch (a wave for each of the longest): transition maps of the interior change points and the
+//             exponential variates wave-wide, then the state machine -- merge, count, virtual jumps -- walked from LDS    :264-413
+//   stats   : one row per wavefront of the branch kernel, added in a fixed order by spare workgroups of the next sweep's first
+//             launch (the last sweep of a call: a launch of its own)                           :745-757
 // Dwell paths live in CSR form (one slot of `cap_b` doubles per branch, two buffers swapped every sweep); the chain powers
 // B^k e_j are read from tables that cover every possible segment count (built on the host with the kernels' arithmetic),
 // so each state draw costs O(1) instead of the O(m) continuation the LDS tables of phm_mcmc.hip need beyond k = 32.
