@@ -6,12 +6,16 @@
 // lanes are still the states, but a wave owns ONE branch of ONE replica: control flow is wave-uniform (scalar registers),
 // only the n-vectors live in the lanes, and S replicas expose S x E waves -- the branches of a sweep are conditionally
 // independent given the node states and every random number is addressed by (replica, iteration, node | branch).
-//   up     : one launch per HEIGHT level, a wave per (node, replica)      makePLrcpp* :503-529
+//   up     : one launch per HEIGHT level (runs of narrow levels near the root: one launch), TWO waves per (node, replica), one
+//            per child chain; dense chain matrix: a row per lane in registers, the vector broadcast from LDS; banded: neighbours
+//            through DPP row shifts; other sparse matrices: ELLPACK rows                  makePLrcpp* :503-529
 //   root   : a wave per replica                                           :618-627
-//   down   : one launch per DEPTH level, a wave per (edge, replica)       :640-657, :460-475
-//   branch : a wave per (branch, replica), longest slots first            :264-413, :44-73, :745-757
-//   stats  : block per replica: fixed-order reduction of the per-branch dwell sums; counters added with f64 atomics
-//            (integers: exact in any order)
+//   down   : a TRANSITION MAP per (edge, replica) -- lane = candidate parent state -- then one workgroup per replica walks the
+//            depth levels by table look-up (round 3; one launch per depth level when the maps would not fit)   :640-657, :460-475
+//   branch : a wave per (branch, replica), longest slots first; state-independent operands a step ahead, merged segments in LDS
+//                                                                          :264-413, :44-73, :745-757
+//   stats  : a workgroup per (replica, column): fixed-order reduction of the per-branch dwell sums; counters added with f64
+//            atomics (integers: exact in any order)
 // Per-replica layout as in phm_narrow.h (CSR dwell slots, two buffers + merge scratch); chain powers from the full-length
 // tables.  Counts bit-identical to the oracle, dwell sums <= 1e-10 relative (added per branch, then reduced).
 #pragma once
