@@ -95,7 +95,7 @@ typedef struct phm_model {
 } phm_model;
 
 /* how a sweep is laid over the lanes (phm_options.mapping).  n <= 4: REPLICAS = one lane per replica, one wave per 64-replica
- * tile walks the tree (largest replica counts); BRANCHES = one lane per branch of one chain (a handful of chains, large trees);
+ * tile walks the tree (largest replica counts); BRANCHES = the sweep of one chain spread over the device for latency (one chain or a handful, large trees);
  * TILES = one wave per (64-replica tile, branch) (10^2 .. 10^5 replicas).  5..64 states: REPLICAS = one wave per 64-replica
  * tile, replicas in turn, lanes = states (phm_wide.hip; lists of trees); BRANCHES = one wave per (replica, branch), lanes =
  * states (a handful of chains); TILES = one lane per replica, one wave per (tile, item), pruning on the matrix cores or over

@@ -202,7 +202,7 @@ def make_options(seed=0, n_replicas=1, replica_offset=0, reduce=False, tips_per_
                  iters_per_launch=0, cap_tail=0.0, storage=0, mapping="auto", phase_timing=False, rescale=False, recover=True,
                  pruning_form=0, sparse_chains=0):
     """``mapping``: how a sweep is laid over the lanes -- "replicas" (one lane per chain: the throughput layout for many
-    replicas), "branches" (one lane per branch, n <= 4; one wave per (replica, branch) for 5..64 states: few chains on a large
+    replicas), "branches" (one chain or a handful in latency form, n <= 4; one wave per (replica, branch) for 5..64 states: few chains on a large
     tree), "tiles" (lanes = replicas, one wave per tile of 64 replicas and branch: 10^2 .. 10^5 replicas) or "auto".
     ``sparse_chains``: 5..64 states, "tiles": 0 automatic, 1 chains over the non-zeros of B only, 2 dense (matrix cores)."""
     o = Options()
