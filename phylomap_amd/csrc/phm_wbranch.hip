@@ -266,17 +266,23 @@ __global__ __launch_bounds__(WB_BLOCK) void wb_downmap_kernel(WideBranchParams p
 }
 
 constexpr int WB_WALK_BLOCK = 1024;
-__global__ __launch_bounds__(WB_WALK_BLOCK) void wb_walk_kernel(WideBranchParams p, int n_levels, int use_lds) {
+__global__ __launch_bounds__(WB_WALK_BLOCK) void wb_walk_kernel(WideBranchParams p, int it, int n_levels, int use_lds) {
   extern __shared__ uint8_t s_nst[];
   const int n = p.n_states, tid = threadIdx.x, r = blockIdx.x;
   uint8_t* __restrict__ nst = p.nstate + (size_t)r * p.n_node;
   uint8_t* __restrict__ est = p.estate + (size_t)r * p.n_edge * 2;
   const uint8_t* __restrict__ map = p.dmap + (size_t)r * p.n_edge * n;
   uint32_t err = 0;
-  if (use_lds) {
-    if (tid == 0) s_nst[p.root] = nst[p.root];                                 // the root draw (wb_root_kernel)
-    __syncthreads();
+  if (tid < 64) {                                    // the root draw (:618-627), by the first wave
+    const int c = tid < n ? tid : n - 1;
+    const double pr = (tid < n) ? p.pid[c] * p.PL[((size_t)r * p.n_node + p.root) * n + c] : 0.0;
+    const double u = stream_u(p.seed_lo, p.seed_hi, (uint32_t)(p.replica_offset + r), (uint32_t)it, ENT_NODE | (uint32_t)(p.root + p.n_tips), 0);
+    const int rs = coop_sample(pr, u, n, tid, err);
+    nst[p.root] = (uint8_t)rs;                       // every lane stores the same value
+    if (use_lds) s_nst[p.root] = (uint8_t)rs;
   }
+  if (!use_lds) __threadfence_block();
+  __syncthreads();
   for (int l = 0; l < n_levels; ++l) {
     const int lo = p.down_off[l], hi = p.down_off[l + 1];
     for (int idx = lo + tid; idx < hi; idx += WB_WALK_BLOCK) {
@@ -468,7 +474,7 @@ __global__ __launch_bounds__(WB_BLOCK) void wb_branch_kernel(WideBranchParams p,
 // n + 1 columns of a row reduced side by side (one workgroup streaming the whole [edge][column] block took 0.36 ms per sweep for
 // one chain on C5: 40 % of the sweep).  Counters are copied out of the atomic buffer (and cleared) by the same workgroups, a
 // slice each; (ks) the root state appended.
-__global__ __launch_bounds__(256) void wb_stats_kernel(WideBranchParams p) {
+__global__ __launch_bounds__(256) void wb_stats_kernel(WideBranchParams p, int it) {
   __shared__ double red[256];
   const int r = blockIdx.x, c = blockIdx.y, n = p.n_states, tid = threadIdx.x;
   const int ncnt = p.count_self ? n * n : n * (n - 1);
@@ -482,14 +488,19 @@ __global__ __launch_bounds__(256) void wb_stats_kernel(WideBranchParams p) {
     if (tid < half) red[tid] = red[tid] + red[tid + half];
     __syncthreads();
   }
+  // without the reduction over replicas the values go straight into the engine's statistics layout ([iter][cols][n_rep_pad])
+  auto put = [&](int col, double v) {
+    if (p.reduce) p.rowbuf[(size_t)r * p.n_cols + col] = v;
+    else p.stats[((size_t)it * p.n_cols + col) * p.n_rep_pad + r] = v;
+  };
   if (tid == 0) {
-    if (c < n) p.rowbuf[(size_t)r * p.n_cols + c] = red[0];
+    if (c < n) put(c, red[0]);
     else atomicAdd(p.segcnt, (unsigned long long)red[0]);
   }
   double* cnt = p.cnt + (size_t)r * p.n_cols + n;
-  for (int k = c * 256 + tid; k < ncnt; k += 256 * pc) { p.rowbuf[(size_t)r * p.n_cols + n + k] = cnt[k]; cnt[k] = 0.0; }
+  for (int k = c * 256 + tid; k < ncnt; k += 256 * pc) { put(n + k, cnt[k]); cnt[k] = 0.0; }
   if (p.ks && tid == 0 && c == 0)                                              // root state, 0-based (:1350-1352)
-    p.rowbuf[(size_t)r * p.n_cols + n + ncnt] = (double)p.nstate[(size_t)r * p.n_node + p.root];
+    put(n + ncnt, (double)p.nstate[(size_t)r * p.n_node + p.root]);
 }
 
 __global__ void wb_emit_kernel(WideBranchParams p, int it) {
@@ -542,13 +553,13 @@ hipError_t launch_wbranch_sweep(const WideBranchParams& p, const std::vector<int
     if (cnt > 0) hipLaunchKernelGGL(wb_up_kernel, dim3((cnt + WPB / 2 - 1) / (WPB / 2), S), dim3(WB_BLOCK), up_lds, stream, p, up_off[l], up_off[l + 1]);
     ++l;
   }
-  hipLaunchKernelGGL(wb_root_kernel, dim3((S + WPB - 1) / WPB), dim3(WB_BLOCK), 0, stream, p, it);
-  if (p.dmap) {      // transition maps of all edges, then one workgroup per chain walks the levels
+  if (p.dmap) {      // transition maps of all edges, then one workgroup per chain draws the root and walks the levels
     hipLaunchKernelGGL(wb_downmap_kernel, dim3((p.n_edge + WPB - 1) / WPB, S), dim3(WB_BLOCK), 0, stream, p, it);
     const int use_lds = p.n_node <= 60 * 1024;
-    hipLaunchKernelGGL(wb_walk_kernel, dim3(S), dim3(WB_WALK_BLOCK), use_lds ? (size_t)((p.n_node + 15) & ~15) : 0, stream, p,
+    hipLaunchKernelGGL(wb_walk_kernel, dim3(S), dim3(WB_WALK_BLOCK), use_lds ? (size_t)((p.n_node + 15) & ~15) : 0, stream, p, it,
                        (int)down_off.size() - 1, use_lds);
   } else {
+    hipLaunchKernelGGL(wb_root_kernel, dim3((S + WPB - 1) / WPB), dim3(WB_BLOCK), 0, stream, p, it);
     for (size_t l = 0; l + 1 < down_off.size(); ++l) {
       const int cnt = down_off[l + 1] - down_off[l];
       if (cnt > 0) hipLaunchKernelGGL(wb_down_kernel, dim3((cnt + WPB - 1) / WPB, S), dim3(WB_BLOCK), 0, stream, p, it, down_off[l], down_off[l + 1]);
@@ -557,9 +568,11 @@ hipError_t launch_wbranch_sweep(const WideBranchParams& p, const std::vector<int
   const int b2_in_lds = (p.ell2_w == 0 && (int64_t)S * p.n_edge <= 32768) ? 1 : 0;      // a handful of chains: latency of the longest branch
   const size_t br_lds = b2_in_lds ? sizeof(double) * (size_t)p.n_states * (p.n_states | 1) : (size_t)p.n_states * p.ell2_w * 12;
   hipLaunchKernelGGL(wb_branch_kernel, dim3((p.n_edge + WPB - 1) / WPB, S), dim3(WB_BLOCK), br_lds, stream, p, it, b2_in_lds);
-  hipLaunchKernelGGL(wb_stats_kernel, dim3(S, (unsigned)(p.n_states + 1)), dim3(256), 0, stream, p);
-  const int64_t items = (int64_t)(p.reduce ? p.n_tiles : p.n_rep) * p.n_cols;
-  hipLaunchKernelGGL(wb_emit_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, p, it);
+  hipLaunchKernelGGL(wb_stats_kernel, dim3(S, (unsigned)(p.n_states + 1)), dim3(256), 0, stream, p, it);
+  if (p.reduce) {
+    const int64_t items = (int64_t)p.n_tiles * p.n_cols;
+    hipLaunchKernelGGL(wb_emit_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, p, it);
+  }
   return hipGetLastError();
 }
 
