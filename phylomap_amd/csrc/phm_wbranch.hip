@@ -328,6 +328,7 @@ __global__ __launch_bounds__(WB_BLOCK) void wb_branch_kernel(WideBranchParams p,
   constexpr int WB_MERGED_LDS = 192;
   __shared__ double s_ml[WB_BLOCK / 64][WB_MERGED_LDS];
   __shared__ uint8_t s_ms[WB_BLOCK / 64][WB_MERGED_LDS];
+  __shared__ uint16_t s_tr[WB_BLOCK / 64][64];       // counter columns of the transitions met since the last flush (n^2 <= 4 096)
   const int ldb = p.n_states | 1;
   const double* s_B2 = reinterpret_cast<const double*>(smem);
   if (b2_in_lds && w2 == 0) {
@@ -363,6 +364,21 @@ __global__ __launch_bounds__(WB_BLOCK) void wb_branch_kernel(WideBranchParams p,
   auto put_merged = [&](int k, double len, int st) {
     if (k < WB_MERGED_LDS) { s_ml[wv][k] = len; s_ms[wv][k] = (uint8_t)st; }
     else { ml[k] = len; ms[k] = (uint8_t)st; }
+  };
+  // Transitions are NOTED in LDS and counted (f64 atomics on integers: exact in any order) 64 at a time: an atomic per step sits
+  // in the same in-order memory queue as the loads the next step waits for, i.e. an L2 round trip per step.
+  int n_tr = 0;
+  auto flush_transitions = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+    if (lane < n_tr) atomicAdd(cnt + s_tr[wv][lane], 1.0);
+    __builtin_amdgcn_wave_barrier();
+    n_tr = 0;
+  };
+  auto note_transition = [&](int col) {
+    s_tr[wv][n_tr] = (uint16_t)col;                  // every lane writes the same value
+    if (++n_tr == 64) flush_transitions();
   };
   int w = 0;
   int cur_s = (m == 1) ? cs : ps;                    // updatenodestates :469-472 (m == 1: the child end wins)
@@ -401,14 +417,15 @@ __global__ __launch_bounds__(WB_BLOCK) void wb_branch_kernel(WideBranchParams p,
         si = coop_sample(pr, su.draw((uint32_t)(i - 1)), n, lane, err);
       }
     }
-    if (p.count_self && lane == 0) atomicAdd(cnt + cur_s * n + si, 1.0);                    // shortenerbf :1010-1014
+    if (p.count_self) note_transition(cur_s * n + si);                                      // shortenerbf :1010-1014
     if (si == cur_s) cur_len = cur_len + di;                                                // shortener :54
     else {
       put_merged(w, cur_len, cur_s);
-      if (!p.count_self && lane == 0) atomicAdd(cnt + cur_s * (n - 1) + (si > cur_s ? si - 1 : si), 1.0);   // :65-66
+      if (!p.count_self) note_transition(cur_s * (n - 1) + (si > cur_s ? si - 1 : si));     // :65-66
       ++w; cur_s = si; cur_len = di;
     }
   }
+  flush_transitions();
   put_merged(w, cur_len, cur_s);
   const int nmerged = w + 1;
 #ifdef PHM_DEBUG_LEVEL_CLOCK
