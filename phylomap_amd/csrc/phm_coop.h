@@ -179,6 +179,36 @@ __device__ __forceinline__ int coop_sample(double p, double u, int n, int lane, 
   return idx < n ? idx : n - 1;
 }
 
+// The same draw with the probabilities passed through LDS (svec: 64 doubles of the calling wave, 16-byte aligned): every lane adds
+// the running sums itself from broadcast reads (eight entries in flight) instead of 2 n v_readlane steps -- the same sums in
+// the same order (entries beyond n are +0 and leave the running sum unchanged); about half the instructions of coop_sample.
+__device__ __forceinline__ int coop_sample_lds(double p, double u, int n, int lane, double* __restrict__ svec, uint32_t& err) {
+  svec[lane] = (lane < n) ? p : 0.0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+  const double2* sv2 = reinterpret_cast<const double2*>(svec);
+  double run = 0.0, mycum = 0.0;
+#pragma unroll
+  for (int j = 0; j < 64; j += 8) {
+    if (j < n) {                                     // wave-uniform
+      const double2 a = sv2[j / 2], b = sv2[j / 2 + 1], c = sv2[j / 2 + 2], d = sv2[j / 2 + 3];
+      const double v[8] = {a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y};
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        run = (j + t == 0) ? v[t] : run + v[t];
+        mycum = (lane == j + t) ? run : mycum;
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();                   // every lane has read the vector before it is overwritten
+  if (!(run > 0.0) || isinf(run)) err |= DERR_ZERO_PROB;
+  const double thr = u * run;
+  const bool fail = (lane < n) && !(thr <= mycum);
+  int idx = (int)__popcll(__ballot(fail));
+  return idx < n ? idx : n - 1;
+}
+
 // normalisation sum of a partial-likelihood row (:525): t_g = x_g + x_{g+4} + ... (ascending), then (t_0 + t_1) + (t_2 + t_3)
 __device__ __forceinline__ double coop_sum(double x, int n) {
   double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;

@@ -328,6 +328,7 @@ __global__ __launch_bounds__(WB_BLOCK) void wb_branch_kernel(WideBranchParams p,
   constexpr int WB_MERGED_LDS = 192;
   __shared__ double s_ml[WB_BLOCK / 64][WB_MERGED_LDS];
   __shared__ uint8_t s_ms[WB_BLOCK / 64][WB_MERGED_LDS];
+  __shared__ __align__(16) double s_pv[WB_BLOCK / 64][64];       // the probability vector of a draw (coop_sample_lds)
   __shared__ uint16_t s_tr[WB_BLOCK / 64][64];       // counter columns of the transitions met since the last flush (n^2 <= 4 096)
   const int ldb = p.n_states | 1;
   const double* s_B2 = reinterpret_cast<const double*>(smem);
@@ -414,7 +415,7 @@ __global__ __launch_bounds__(WB_BLOCK) void wb_branch_kernel(WideBranchParams p,
       } else {
         const double b2 = b2_in_lds ? s_B2[cur_s * ldb + c] : p.B2[cur_s * n + c];
         const double pr = (lane < n) ? b2 * beta : 0.0;
-        si = coop_sample(pr, su.draw((uint32_t)(i - 1)), n, lane, err);
+        si = coop_sample_lds(pr, su.draw((uint32_t)(i - 1)), n, lane, s_pv[wv], err);
       }
     }
     if (p.count_self) note_transition(cur_s * n + si);                                      // shortenerbf :1010-1014
