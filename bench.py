@@ -70,6 +70,7 @@ def cpu_baseline(cfg, target_s=3.0, all_cores=False):
     n_f = max(2, int(min(target_s, 3.0) / (probe_f / 2)))
     dtf = _oracle_run((cfg, n_f, True, 0))
     out = {"value": E * n_it / dt, "unit": "branch-site realisations/s", "cores": 1, "kind": "port",
+           "sample_short": f"C{cfg} tree+Q, 1 chain, {n_it} sweeps",
            "sample": f"same C{cfg} tree and Q, 1 chain, {n_it} sweeps (edge lookup table); with the reference's O(E) edge "
                      f"search per node (src/phylomap.cpp:643): {E * n_f / dtf:.4g}/s over {n_f} sweeps",
            "faithful_value": E * n_f / dtf}
@@ -103,6 +104,82 @@ def kernel_traffic(entry, *needles):
             valu += e.get("SQ_INSTS_VALU", 0.0)
             names.append(k)
     return (tot if names else None), (valu if names else None), names
+
+
+def _r(x, digits=5):
+    """floats to `digits` significant digits (the contract line is read by people and a parser, not re-computed from)"""
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}")
+    if isinstance(x, str):
+        return x[:64]
+    return x
+
+
+def _pick(d, keys):
+    """the scalar (number / short label) entries of `d` named in `keys`, floats rounded"""
+    return {k: _r(d[k]) for k in keys if d and k in d and not isinstance(d[k], (dict, list))}
+
+
+def compact_line(out):
+    """The ONE stdout line of the bench contract, built from the full result `out` (which goes to gpurun_out/bench_detail_n*.json).
+    Numbers only, no prose, < 4 KB (tests/test_host_cpu.py::test_bench_line_is_compact): the round-3 line was 21 KB and the
+    driver could not parse it."""
+    line = {k: _r(out[k]) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                    "vs_baseline", "dtype", "data") if k in out}
+    cfg = out.get("config", {})
+    line["config"] = {k: cfg[k] for k in ("workload", "n_states", "n_tips", "branches", "replicas_total", "max_iters_provisioned", "parallelism") if k in cfg}
+    rk = ("bound", "alg_bytes_per_unit", "units_per_launch", "launches", "avg_launch_ms", "achieved", "peak", "unit", "frac", "traffic")
+    rl = out.get("roofline") or {}
+    line["roofline"] = _pick(rl, rk)
+    if rl.get("dominant_kernel"):
+        line["roofline"]["dominant_kernel"] = _pick(rl["dominant_kernel"], ("kernel",) + rk + ("valu_issue_frac",))
+    ks = rl.get("kernels") or {}
+    if ks:
+        line["roofline"]["phases"] = {ph: _pick(k, ("avg_launch_ms", "alg_bytes_per_unit", "frac")) for ph, k in ks.items() if ph != "reductions"}
+    cb = out.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "faithful_value"))
+        line["cpu_baseline"]["sample"] = cb.get("sample_short", "")
+        if "all_cores" in cb:
+            line["cpu_baseline"]["all_cores"] = _pick(cb["all_cores"], ("value", "cores"))
+        line["speedup_vs_cpu_1core"] = _r(out.get("speedup_vs_cpu_1core"))
+    sc = out.get("single_chain")
+    if sc:
+        line["single_chain"] = {"ms_per_sweep": _r(sc["ms_per_sweep"]), "realisations_per_s": _r(sc["realisations_per_s"]),
+                                "speedup": _r(sc.get("speedup_vs_cpu_1core"))}
+    for k in ("recoveries", "replicas_per_gib", "hbm_bytes_resident"):
+        if k in out:
+            line[k] = _r(out[k])
+    if out.get("stated_length"):
+        line["stated_length"] = {k: _r(v) for k, v in out["stated_length"].items() if not isinstance(v, (dict, list, str))}
+    others = {}
+    for key, blk in (out.get("configs") or {}).items():
+        o = {"value": _r(blk.get("realisations_per_s"), 4), "ms": _r(blk.get("ms_per_sweep"), 4)}
+        brl = blk.get("roofline") or {}
+        if "frac" in brl:
+            o["frac"] = _r(brl["frac"], 3)
+        dk = brl.get("dominant_kernel")
+        if dk:
+            o["dom"] = {"kernel": (dk.get("kernel") or "")[:36], "ms": _r(dk.get("avg_launch_ms"), 4), "frac": _r(dk.get("frac"), 3)}
+        if "replicas" in blk:
+            o["replicas"] = blk["replicas"]
+        others[key] = {k: v for k, v in o.items() if v is not None}
+    if others:
+        line["others"] = others
+    ex = out.get("expm_per_s")
+    if ex:
+        line["expm_per_s"] = {k: _r(v) for k, v in ex.items() if not isinstance(v, (dict, list, str))}
+    line["detail"] = "gpurun_out/bench_detail_n%d.json" % out.get("n_gpus", 1)
+    # hard bound: shed the secondary blocks (they stay in the detail file) before the line can outgrow the parser
+    for shed in ("dom", "others", "expm_per_s", "stated_length"):
+        if len(json.dumps(line)) <= 3800:
+            break
+        if shed == "dom":
+            for o in line.get("others", {}).values():
+                o.pop("dom", None)
+        else:
+            line.pop(shed, None)
+    return line
 
 
 def main():
@@ -472,7 +549,15 @@ def main():
                                   "roofline": {"bound": "mfma", "kernel": "expm_eigen_mfma_kernel", "achieved": 2 * 61 ** 3 * t61.size / (ms_m / 1e3) / 1e12,
                                                "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": 2 * 61 ** 3 * t61.size / (ms_m / 1e3) / 1e12 / MFMA_F64_PEAK_TFLOPS}})
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        # the full detail goes to a FILE (never to stdout / stderr: the driver keeps a few KB of their tail); stdout carries ONE compact line
+        ddir = os.path.join(ROOT, "gpurun_out")
+        try:
+            os.makedirs(ddir, exist_ok=True)
+            with open(os.path.join(ddir, f"bench_detail_n{world}.json"), "w") as f:
+                json.dump(out, f, indent=1)
+        except OSError:
+            pass
+        print(json.dumps(compact_line(out)), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
