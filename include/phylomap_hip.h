@@ -28,8 +28,10 @@
 extern "C" {
 #endif
 
-#define PHM_VERSION 200     /* 200: phm_options carries named fields (mapping, storage, ...) instead of reserved[6];
-                                   phm_info.recoveries */
+#define PHM_VERSION 300     /* 300: phm_options.n_devices / devices[] (replica sharding over the GPUs of a node inside the one-shot
+                                   calls); the measurement / test aids moved out of phm_options into the struct
+                                   phm_debug_options, set by phm_set_debug_options.  200: named option fields instead of reserved[6]; phm_info.recoveries */
+#define PHM_MAX_DEVICES 8   /* GPUs of one node (MI355X: 8 per node over xGMI) */
 
 typedef enum phm_status {
   PHM_OK = 0,
@@ -99,7 +101,7 @@ typedef struct phm_model {
  * TILES = one wave per (64-replica tile, branch) (10^2 .. 10^5 replicas).  5..64 states: REPLICAS = one wave per 64-replica
  * tile, replicas in turn, lanes = states (phm_wide.hip; lists of trees); BRANCHES = one wave per (replica, branch), lanes =
  * states (a handful of chains); TILES = one lane per replica, one wave per (tile, item), pruning on the matrix cores or over
- * the non-zeros of a sparse B (the default beyond 8 replicas at 20 states, always at 61: the measured crossover).
+ * the non-zeros of a sparse B (the default beyond 50 000 / n_edge chains, clamped to 1..32: the measured crossover).
  * phm_maketreelistEXP: AUTO / TILES = one wave per (tile of 64 samples, branch); REPLICAS = one wave per tile of 64 samples
  * walks the tree (dwell sums then add in the reference's order). */
 typedef enum phm_mapping { PHM_MAP_AUTO = 0, PHM_MAP_REPLICAS = 1, PHM_MAP_BRANCHES = 2, PHM_MAP_TILES = 3 } phm_mapping;
@@ -112,17 +114,16 @@ typedef struct phm_options {
   int32_t tips_per_replica;    /* 0: all replicas share x$states; 1: one tip vector per replica (sites) */
   int32_t device;              /* HIP device ordinal; -1 = current device */
   int32_t iters_per_launch;    /* MCMC iterations fused into one kernel launch; 0 -> default */
-  double  cap_tail;            /* dwell capacity: the 1+Poisson(Omega*t_b) quantile at this tail, per branch; 0 -> 1e-3 for the
-                                  sequential streams of PHM_MAP_REPLICAS, 1e-9 for the fixed slots of PHM_MAP_BRANCHES / PHM_MAP_TILES
-                                  (an overflow is recovered unless no_recovery is set) */
+  double  cap_tail;            /* dwell capacity: the 1+Poisson(Omega*t_b) quantile at this tail, per branch.  0 -> automatic: 1e-3 for
+                                  the sequential streams of PHM_MAP_REPLICAS (an overflow there is rare per TILE and recovered); for the
+                                  fixed slots of PHM_MAP_BRANCHES / PHM_MAP_TILES min(1e-9, 0.05 / (S * E * max_iters)), floored at
+                                  1e-16 -- at most 0.05 expected recoveries over the draws the engine is created for, so the HBM
+                                  held per replica grows (slowly: a quantile) with max_iters */
   int32_t mapping;             /* phm_mapping: how a sweep is laid over the lanes (one tree); PHM_MAP_AUTO = by replica count.
                                   Same draws and counts in every mapping; dwell sums differ in the last bits between
                                   PHM_MAP_REPLICAS and the other two (summation order). */
   int32_t storage;             /* dwell-stream storage of PHM_MAP_REPLICAS: 0 = automatic, 1 = one ring per tile (half the HBM),
                                   2 = two buffers (5 % faster sweep for n <= 4) */
-  int32_t pruning_form;        /* measurement / test aid, 5..64 states with PHM_MAP_TILES: form of the pruning kernel, 0 = by tile
-                                  count, 1 = one wave per (node, tile), 2 = one workgroup / wave per 16-replica block (same bits) */
-  int32_t phase_timing;        /* 1 = record HIP events between the phases of a sweep (phm_engine_phase_ms) */
   int32_t rescale_pruning;     /* phm_maketreelistEXP: 1 = divide every internal partial-likelihood row by its sum in the pruning
                                   pass.  The reference's makePLexp (src/phylomap.cpp:2899-2906) does not rescale, so sumstatEXP
                                   underflows (PHM_ERR_ZERO_PROB) beyond a few hundred tips; node draws do not depend on a row's
@@ -134,14 +135,40 @@ typedef struct phm_options {
                                   rebuilt with doubled slots and the iterations run so far are replayed -- bit-identical, every
                                   random number being addressed by (replica, iteration, entity) -- so a run cannot abort where
                                   the reference's std::list (src/phylomap.cpp:18-21) would grow */
-  int32_t sparse_chains;       /* 5..64 states with PHM_MAP_TILES: pruning chains and forward draws over the non-zeros of a BANDED B only
+  int32_t sparse_chains;       /* 5..64 states with PHM_MAP_TILES: pruning chains and forward draws over the NON-ZEROS of B only
                                   (what SPARSEmakePLrcpp :490-501 / SPARSEresamplebranchstates :218-261 get from sp_mat).  0 =
                                   automatic: used when n <= 32 and B has a half-bandwidth of 1 (tridiagonal) or 2 (make2sQ hidden
-                                  rates); 1 = required (PHM_ERR_UNSUPPORTED otherwise); 2 = never (chains on the matrix cores).
+                                  rates), or is sparse enough for the pattern-specialised kernels; 1 = required
+                                  (PHM_ERR_UNSUPPORTED otherwise); 2 = never (chains on the matrix cores).
                                   Same bits either way: a skipped term is an exact zero */
-  int32_t capacity_boost_log2; /* internal (capacity recovery): log2 of the multiplier applied to the provisioned capacities */
+  int32_t n_devices;           /* one-shot calls (phm_maketreelist*): 0 / 1 = one GPU (`device`); 2..PHM_MAX_DEVICES = the
+                                  n_replicas chains / sites (phm_maketreelistEXP: the N samples) are sharded by GLOBAL replica id
+                                  over devices[0 .. n_devices-1], one host thread and one engine per device, no traffic between
+                                  the devices while sampling; with reduce = 1 the per-tile sums are folded in device order (the
+                                  only exchange: N x cols doubles per device).  Every random number is addressed by the global
+                                  replica id, so counts are those of ONE device exactly and dwell sums agree to rounding
+                                  (<= 1e-12; bit-identical on the mappings whose per-tile sums do not depend on the tile count).
+                                  The resident engine (phm_engine_*) is per device: shard with replica_offset there.
+                                  The caller of the reference -- R/sumstatMCMC_bigtree.R:21-29 -> .Call -> one function
+                                  (src/phylomap.cpp:942-986) -- reaches all GPUs of the node through this field */
+  int32_t devices[PHM_MAX_DEVICES]; /* HIP ordinals; an ordinal may repeat (several engines on one GPU: rehearsal on a one-GPU box) */
   int32_t reserved[3];         /* must be 0 */
 } phm_options;
+
+/* Measurement and test aids, kept out of phm_options: set per THREAD by phm_set_debug_options and read by the engines and
+ * one-shot calls that thread creates afterwards (NULL resets to all-zero). */
+typedef struct phm_debug_options {
+  int32_t pruning_form;        /* 5..64 states with PHM_MAP_TILES: form of the pruning kernel, 0 = by tile count, 1 = one wave per
+                                  (node, tile), 2 = one workgroup / wave per 16-replica block (same bits) */
+  int32_t phase_timing;        /* 1 = record HIP events between the phases of a sweep (phm_engine_phase_ms) */
+  int32_t fail_recovery;       /* 1 = every capacity recovery "does not fit" (exercises the dead-handle path) */
+  int32_t branch_group;        /* > 0: branches per wave of the 5..64-state branch kernel (clamped to 1..64); 0 = automatic */
+  int32_t level_groups;        /* (tile, item) mappings, n <= 4: 0 = automatic, 1 = one launch per tree level (no grouped levels) */
+  int32_t q_timing;            /* 1 = the rate-updating drivers print the mean host time of the phases of an iteration to stderr */
+  double  pade_pivot_min;      /* > 0: smallest pivot phm_expm_pade_mfma's unpivoted block elimination accepts (default 1e-3;
+                                  1e300 sends every matrix to the pivoted kernel) */
+  int32_t reserved[4];
+} phm_debug_options;
 
 typedef struct phm_info {
   int32_t n_states, n_edge, n_replicas, n_replicas_padded, n_cols, max_iters;
@@ -164,11 +191,13 @@ typedef struct phm_engine phm_engine;
 /* ---- library ---- */
 int32_t     phm_version(void);
 /* sizeof of the plain structs of this header as the library was built (which: 0 phm_options, 1 phm_info, 2 phm_tree,
- * 3 phm_model; anything else: -1) -- lets a foreign-function binding (ctypes, cgo, .C) check its mirror of the layout */
+ * 3 phm_model, 4 phm_debug_options; anything else: -1) -- lets a foreign-function binding (ctypes, cgo, .C) check its mirror of the layout */
 int32_t     phm_struct_size(int32_t which);
 int32_t     phm_device_count(void);
 const char* phm_last_error(void);
 const char* phm_status_string(int32_t status);
+/* measurement / test aids of this thread -- see the phm_debug_options struct; NULL = defaults */
+int32_t     phm_set_debug_options(const phm_debug_options* dbg);
 /* measurement aid: HIP-event milliseconds of the sampling kernel of this thread's last phm_maketreelistEXP call */
 double      phm_last_kernel_ms(void);
 
@@ -277,7 +306,7 @@ int32_t phm_expm_pade(int32_t n_states, const double* Q, const double* t, int32_
 /* phm_expm_pade with every matrix product on the matrix cores (v_mfma_f64_16x16x4_f64), 16 < n_states <= 64: solve(D, E) by
  * block Gauss-Jordan elimination without row exchanges between the 16 x 16 blocks; a matrix that meets a pivot below 1e-3 there
  * is recomputed by phm_expm_pade's pivoted kernel inside the same call.  Agrees with phm_expm_pade to rounding (<= 2e-13).
- * Test aid: the environment variable PHM_PADE_PIVOT_MIN overrides the 1e-3 (1e300 sends every matrix to the pivoted kernel). */
+ * Test aid: phm_debug_options.pade_pivot_min overrides the 1e-3. */
 int32_t phm_expm_pade_mfma(int32_t n_states, const double* Q, const double* t, int32_t n_t, int32_t device,
                            double* out, double* kernel_ms);
 
@@ -314,7 +343,7 @@ int32_t phm_engine_set_model(phm_engine* e, const double* Q);
 int32_t phm_engine_dump(phm_engine* e, int32_t replica, int32_t* seg_count, double* seg_dwell, int32_t seg_cap,
                         int32_t* node_states, double* PL);
 int32_t phm_engine_info(phm_engine* e, phm_info* info);
-/* measurement aid (phm_options.phase_timing = 1, (tile, item) mappings): HIP-event milliseconds of the last phm_engine_run, summed over
+/* measurement aid (phm_debug_options.phase_timing = 1, (tile, item) mappings): HIP-event milliseconds of the last phm_engine_run, summed over
  * its sweeps, for the four phases of a sweep: pruning levels (makePLrcpp*), root + node draws (sampleinternalnodes*), the branch
  * kernel (sampleabranch + updatedwelltimes), the statistics reductions.  Valid after phm_engine_sync. */
 int32_t phm_engine_phase_ms(phm_engine* e, double* out4);

@@ -24,7 +24,7 @@ EXPORTS = [
     "phm_engine_info", "phm_engine_destroy", "phm_engine_reduced_stats_device",
     "phm_engine_time_pruning", "phm_tree_orders",
     "phm_engine_create_multi", "phm_maketreelistMCMCmt", "phm_maketreelistMCMCksmt", "phm_engine_phase_ms",
-    "phm_last_kernel_ms",
+    "phm_last_kernel_ms", "phm_set_debug_options",
 ]
 
 
@@ -46,13 +46,22 @@ class Model(C.Structure):
                 ("B", C.POINTER(C.c_double)), ("Omega", C.c_double), ("variant", C.c_int32)]
 
 
+PHM_MAX_DEVICES = 8
+
+
 class Options(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("n_replicas", C.c_int32), ("replica_offset", C.c_int32),
                 ("reduce", C.c_int32), ("tips_per_replica", C.c_int32), ("device", C.c_int32),
                 ("iters_per_launch", C.c_int32), ("cap_tail", C.c_double), ("mapping", C.c_int32), ("storage", C.c_int32),
-                ("pruning_form", C.c_int32), ("phase_timing", C.c_int32), ("rescale_pruning", C.c_int32),
-                ("no_recovery", C.c_int32), ("sparse_chains", C.c_int32), ("capacity_boost_log2", C.c_int32),
-                ("reserved", C.c_int32 * 3)]
+                ("rescale_pruning", C.c_int32), ("no_recovery", C.c_int32), ("sparse_chains", C.c_int32),
+                ("n_devices", C.c_int32), ("devices", C.c_int32 * PHM_MAX_DEVICES), ("reserved", C.c_int32 * 3)]
+
+
+class DebugOptions(C.Structure):
+    """phm_debug_options: measurement / test aids, per thread (phm_set_debug_options)."""
+    _fields_ = [("pruning_form", C.c_int32), ("phase_timing", C.c_int32), ("fail_recovery", C.c_int32),
+                ("branch_group", C.c_int32), ("level_groups", C.c_int32), ("q_timing", C.c_int32),
+                ("pade_pivot_min", C.c_double), ("reserved", C.c_int32 * 4)]
 
 
 class Info(C.Structure):
@@ -134,7 +143,8 @@ def load():
                                          C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.phm_expm_pade.argtypes = [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32, C.c_int32,
                                     C.POINTER(C.c_double), C.POINTER(C.c_double)]
-        for which, mirror in enumerate((Options, Info, Tree, Model)):      # the ctypes mirrors must match the C layout
+        L.phm_set_debug_options.argtypes = [C.POINTER(DebugOptions)]
+        for which, mirror in enumerate((Options, Info, Tree, Model, DebugOptions)):      # the ctypes mirrors must match the C layout
             if L.phm_struct_size(which) != C.sizeof(mirror):
                 raise RuntimeError(f"{LIB_PATH}: {mirror.__name__} is {L.phm_struct_size(which)} bytes in the library, "
                                    f"{C.sizeof(mirror)} in phylomap_amd/_lib.py (stale build? run make)")
@@ -198,24 +208,48 @@ def tree_orders(z):
 MAPPING = {"auto": 0, "replicas": 1, "branches": 2, "tiles": 3}
 
 
+def set_debug_options(**kw):
+    """Install this thread's phm_debug_options (measurement / test aids; no arguments = defaults): pruning_form, phase_timing,
+    fail_recovery, branch_group, level_groups, q_timing, pade_pivot_min."""
+    d = DebugOptions()
+    for k, v in kw.items():
+        setattr(d, k, float(v) if k == "pade_pivot_min" else int(v))
+    check(load().phm_set_debug_options(C.byref(d)))
+
+
+_DEBUG_KEYS = ("pruning_form", "phase_timing", "fail_recovery", "branch_group", "level_groups", "q_timing", "pade_pivot_min")
+
+
 def make_options(seed=0, n_replicas=1, replica_offset=0, reduce=False, tips_per_replica=False, device=-1,
-                 iters_per_launch=0, cap_tail=0.0, storage=0, mapping="auto", phase_timing=False, rescale=False, recover=True,
-                 pruning_form=0, sparse_chains=0):
+                 iters_per_launch=0, cap_tail=0.0, storage=0, mapping="auto", rescale=False, recover=True,
+                 sparse_chains=0, devices=None, **debug):
     """``mapping``: how a sweep is laid over the lanes -- "replicas" (one lane per chain: the throughput layout for many
     replicas), "branches" (one chain or a handful in latency form, n <= 4; one wave per (replica, branch) for 5..64 states: few chains on a large
     tree), "tiles" (lanes = replicas, one wave per tile of 64 replicas and branch: 10^2 .. 10^5 replicas) or "auto".
-    ``sparse_chains``: 5..64 states, "tiles": 0 automatic, 1 chains over the non-zeros of B only, 2 dense (matrix cores)."""
+    ``sparse_chains``: 5..64 states, "tiles": 0 automatic, 1 chains over the non-zeros of B only, 2 dense (matrix cores).
+    ``devices``: an int D (GPUs 0..D-1) or a list of HIP ordinals -- the one-shot calls shard the replicas (sumstatEXP: the
+    samples) over them (phm_options.n_devices).  Remaining keywords (``phase_timing``, ``pruning_form``, ...) are
+    phm_debug_options and are installed for this thread as a side effect (defaults when none is given)."""
+    unknown = set(debug) - set(_DEBUG_KEYS)
+    if unknown:
+        raise TypeError(f"unknown option(s) {sorted(unknown)}")
+    set_debug_options(**debug)
     o = Options()
     o.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
     o.n_replicas, o.replica_offset, o.reduce = int(n_replicas), int(replica_offset), int(bool(reduce))
     o.storage = int(storage)          # 0 automatic, 1 ring, 2 two buffers
     o.mapping = MAPPING[mapping] if isinstance(mapping, str) else int(mapping)
-    o.pruning_form = int(pruning_form) & 3      # 5..64 states, tiles: 1 a wave per (node, tile), 2 16-replica blocks, 0 by tile count
-    o.phase_timing = int(bool(phase_timing))
     o.rescale_pruning = int(bool(rescale))      # sumstatEXP / sumstatMCMC / SPARSEsumstatMCMC: rescaled pruning pass
     o.no_recovery = 0 if recover else 1         # capacity recovery (rebuild with doubled slots + replay)
     o.sparse_chains = int(sparse_chains)
     o.tips_per_replica, o.device, o.iters_per_launch, o.cap_tail = int(bool(tips_per_replica)), int(device), int(iters_per_launch), float(cap_tail)
+    if devices is not None:
+        devs = list(range(int(devices))) if np.isscalar(devices) else [int(d) for d in devices]
+        if len(devs) > PHM_MAX_DEVICES:
+            raise ValueError(f"at most {PHM_MAX_DEVICES} devices")
+        o.n_devices = len(devs)
+        for i, d in enumerate(devs):
+            o.devices[i] = d
     return o
 
 

@@ -4,15 +4,130 @@
 
 #include <chrono>
 #include <cstdio>
+#include <thread>
+
+// ---- replica sharding over the GPUs of a node (phm_options.n_devices) ------------------------------------------------------
+// The reference's caller is ONE R function -> .Call -> ONE C++ driver (R/sumstatMCMC_bigtree.R:21-29 -> src/phylomap.cpp:942-986);
+// to reach the other GPUs of the node the sharding has to live below the C-ABI.  Chains are independent given (seed, global
+// replica id), so device d gets a contiguous range of replica ids, runs it on an engine of its own (one host thread per device,
+// nothing crosses between devices while sampling) and the only exchange is the N x cols statistics at the end.
+int32_t phm_plan_shards(const phm_options& o, int64_t units, std::vector<phm_shard>& shards) {
+  shards.clear();
+  const int D = o.n_devices;
+  if (D < 0 || D > PHM_MAX_DEVICES) return fail(PHM_ERR_BAD_INPUT, "n_devices must be in 0..PHM_MAX_DEVICES");
+  if (D <= 1) { shards.push_back({D == 1 ? o.devices[0] : o.device, 0, units}); return PHM_OK; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(PHM_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+  for (int d = 0; d < D; ++d)
+    if (o.devices[d] < 0 || o.devices[d] >= ndev) return fail(PHM_ERR_NO_DEVICE, "phm_options.devices: ordinal out of range");
+  // whole 64-lane tiles per device when there are enough of them (a tile then holds the same replicas as on one device: the
+  // per-tile sums are the one-device ones), single replicas otherwise (a handful of chains: one or a few per GPU)
+  const int64_t grain = units >= (int64_t)64 * D ? 64 : 1;
+  const int64_t blocks = (units + grain - 1) / grain;
+  for (int d = 0; d < D; ++d) {
+    const int64_t b0 = blocks * d / D, b1 = blocks * (d + 1) / D;
+    const int64_t r0 = std::min(units, b0 * grain), r1 = std::min(units, b1 * grain);
+    if (r1 > r0) shards.push_back({o.devices[d], r0, r1 - r0});
+  }
+  return PHM_OK;
+}
+
+namespace {
+
+struct ShardRun {
+  phm_shard sh;
+  phm_engine* e = nullptr;
+  hipStream_t stream = nullptr;
+  int32_t st = PHM_OK;
+  std::string err;
+};
+
+struct ShardSet {      // engines and streams of a sharded call; destroyed on every exit path
+  std::vector<ShardRun> runs;
+  ~ShardSet() {
+    for (ShardRun& r : runs) {
+      if (r.e) phm_engine_destroy(r.e);
+      if (r.stream) { (void)hipSetDevice(r.sh.device); (void)hipStreamDestroy(r.stream); }
+    }
+  }
+  int32_t first_error() const {
+    for (const ShardRun& r : runs) if (r.st) return fail(r.st, "device " + std::to_string(r.sh.device) + ": " + r.err);
+    return PHM_OK;
+  }
+};
+
+// one host thread per shard: engine on the shard's device for its replica range (global ids: replica_offset + first), then
+// `body(run)` -- typically run + sync (+ read).  Worker threads report through ShardRun (phm_last_error is thread-local).
+template <typename Body>
+int32_t run_shards(ShardSet& set, const phm_tree* x, const phm_model& model, const phm_options& base, int32_t max_iters, Body body) {
+  const phm_debug_options dbg = g_phm_debug;
+  auto work = [&](ShardRun& r) {
+    phm_options o = base;
+    o.n_devices = 0; o.device = r.sh.device;
+    o.n_replicas = (int32_t)r.sh.count; o.replica_offset = base.replica_offset + (int32_t)r.sh.first;
+    phm_tree xt = *x;
+    if (base.tips_per_replica) xt.states = x->states + (size_t)r.sh.first * x->n_tips;
+    r.st = phm_engine_create_impl(&xt, 1, &model, &o, dbg, 0, max_iters, &r.e);
+    if (!r.st && hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking) != hipSuccess) r.st = fail(PHM_ERR_NO_DEVICE, "hipStreamCreate failed");
+    if (!r.st) r.st = body(r);
+    if (r.st) r.err = g_phm_err;
+  };
+  std::vector<std::thread> th;
+  for (size_t i = 1; i < set.runs.size(); ++i) th.emplace_back(work, std::ref(set.runs[i]));
+  work(set.runs[0]);
+  for (std::thread& t : th) t.join();
+  return set.first_error();
+}
+
+}  // namespace
 
 extern "C" {
 
 // ---- reference-shaped one-shot drivers -------------------------------------------------------------
+static int32_t run_mcmc_sharded(int variant, const phm_tree* x, int32_t n, const double* Q, const double* pid, const double* B,
+                                double Omega, const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
+                                const phm_options& o, double* out) {
+  phm_model model;
+  model.n_states = n; model.Q = Q; model.pid = pid; model.B = B; model.Omega = Omega; model.variant = variant;
+  if (!x) return fail(PHM_ERR_BAD_INPUT, "tree is NULL");
+  const int S = std::max(1, (int)o.n_replicas);
+  ShardSet set;
+  {
+    std::vector<phm_shard> shards;
+    int32_t st = phm_plan_shards(o, S, shards);
+    if (st) return st;
+    for (const phm_shard& sh : shards) { set.runs.emplace_back(); set.runs.back().sh = sh; }
+  }
+  int cols = 0;
+  bool orders_ok = true;
+  std::string serr;
+  int32_t st = run_shards(set, x, model, o, N, [&](ShardRun& r) -> int32_t {
+    if (&r == &set.runs[0]) {      // the caller's nen / nodelist / root against the tree (host-only check, once)
+      cols = r.e->cols;
+      orders_ok = phm::check_reference_orders(r.e->sched, x->edge, nen, nodelist, root, serr);
+      if (!orders_ok) return fail(PHM_ERR_BAD_INPUT, serr);
+    }
+    int32_t s2 = phm_engine_run(r.e, N, r.stream);
+    if (!s2) s2 = phm_engine_sync(r.e);
+    if (!s2 && !o.reduce) s2 = phm_engine_read_stats(r.e, 0, N, out + (size_t)r.sh.first * N * r.e->cols);
+    return s2;
+  });
+  if (st) return st;
+  if (!o.reduce) return PHM_OK;
+  std::vector<double> acc;                              // the fold of the per-tile sums, device after device
+  for (ShardRun& r : set.runs) { st = phm_engine_fold_reduced(r.e, 0, N, acc); if (st) return st; }
+  return phm_engine_finish_reduced(set.runs[0].e, 0, N, acc, out);
+}
+
 static int32_t run_mcmc_oneshot(int variant, const phm_tree* x, int32_t n, const double* Q, const double* pid,
                                 const double* B, double Omega, const int32_t* nen, const int32_t* nodelist, int32_t root,
                                 int32_t N, const phm_options* opt, double* out) {
   if (!out) return fail(PHM_ERR_BAD_INPUT, "out is NULL");
   if (N < 1) return fail(PHM_ERR_BAD_INPUT, "N must be >= 1");
+  if (opt && opt->n_devices > 1) return run_mcmc_sharded(variant, x, n, Q, pid, B, Omega, nen, nodelist, root, N, *opt, out);
+  if (opt && opt->n_devices < 0) return fail(PHM_ERR_BAD_INPUT, "n_devices must be in 0..PHM_MAX_DEVICES");
+  phm_options one;
+  if (opt && opt->n_devices == 1) { one = *opt; one.device = one.devices[0]; one.n_devices = 0; opt = &one; }
   phm_model model;
   model.n_states = n; model.Q = Q; model.pid = pid; model.B = B; model.Omega = Omega; model.variant = variant;
   phm_engine* e = nullptr;
@@ -68,6 +183,49 @@ extern "C" int32_t phm_tree_orders(int32_t n_tips, int32_t n_edge, const int32_t
 // maketreelistMCMCbf src/phylomap.cpp:1258-1305 (R/sumstatMCMCbf.R) and maketreelistMCMCks :1802-1872 (R/sumstatMCMCks.R).
 // With opt->n_replicas = S > 1 the replicas are sites sharing one Q: the update sees the statistics summed over sites and
 // `out` holds those sums (S = 1 is the reference's semantics exactly).
+// The rate-updating drivers with S > 1 sites sharing Q on several GPUs: every iteration each device sweeps its sites with the
+// current Q, the host adds the devices' (site-summed) rows in device order, draws the new rates from the total and hands the
+// new model to every device.  One row of n + n^2 + 1 doubles per device and iteration is all that moves.
+static int32_t run_qupdate_sharded(int variant, const phm_tree* x, int32_t n, const double* Q, const double* pid, double Omega,
+                                   const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N, const double* prior,
+                                   const phm_model& model, const phm_options& o, double* out) {
+  (void)pid;
+  ShardSet set;
+  {
+    std::vector<phm_shard> shards;
+    int32_t st = phm_plan_shards(o, o.n_replicas, shards);
+    if (st) return st;
+    for (const phm_shard& sh : shards) { set.runs.emplace_back(); set.runs.back().sh = sh; }
+  }
+  std::string serr;
+  int32_t st = run_shards(set, x, model, o, N, [&](ShardRun& r) -> int32_t {
+    if (&r == &set.runs[0] && !phm::check_reference_orders(r.e->sched, x->edge, nen, nodelist, root, serr)) return fail(PHM_ERR_BAD_INPUT, serr);
+    return PHM_OK;
+  });
+  if (st) return st;
+  const int ecols = set.runs[0].e->cols;
+  const size_t nn = (size_t)n * n;
+  std::vector<double> Qw(Q, Q + nn), row(ecols), part(ecols);
+  for (int i = 0; i < N; ++i) {
+    for (ShardRun& r : set.runs) { st = phm_engine_run(r.e, 1, r.stream); if (st) return st; }
+    for (size_t d = 0; d < set.runs.size(); ++d) {
+      ShardRun& r = set.runs[d];
+      st = phm_engine_sync(r.e);
+      if (!st) st = phm_engine_read_stats(r.e, i, 1, d == 0 ? row.data() : part.data());
+      if (st) return st;
+      if (d > 0) {      // dwell sums, counts and the (site-summed) root-state column; the parameter columns are the same on every device
+        for (int c = 0; c < n + (int)nn; ++c) row[c] += part[c];
+        row[ecols - 1] += part[ecols - 1];
+      }
+    }
+    for (int c = 0; c < ecols; ++c) out[(size_t)c * N + i] = row[c];
+    if (variant == PHM_MCMC_BF) phm::bf_updates(Qw.data(), Omega, prior, row.data(), o.seed, (uint32_t)i);
+    else phm::ks_updates(Qw.data(), n, Omega, prior, row.data(), o.seed, (uint32_t)i);
+    if (i + 1 < N) for (ShardRun& r : set.runs) { st = phm_engine_set_model(r.e, Qw.data()); if (st) return st; }
+  }
+  return PHM_OK;
+}
+
 static int32_t run_qupdate(int variant, bool dic, const phm_tree* x, int32_t n, const double* Q, const double* pid,
                            const double* B, double Omega, const int32_t* nen, const int32_t* nodelist, int32_t root, int32_t N,
                            const double* prior, int32_t n_prior, const phm_options* opt_in, double* out) {
@@ -89,6 +247,10 @@ static int32_t run_qupdate(int variant, bool dic, const phm_tree* x, int32_t n, 
   (void)B;     // the reference aliases the caller's B and then overwrites it entry by entry; B = I + Q/Omega throughout
   phm_model model;
   model.n_states = n; model.Q = Q; model.pid = pid; model.B = nullptr; model.Omega = Omega; model.variant = variant;
+  if (o.n_devices < 0 || o.n_devices > PHM_MAX_DEVICES) return fail(PHM_ERR_BAD_INPUT, "n_devices must be in 0..PHM_MAX_DEVICES");
+  if (o.n_devices > 1 && o.n_replicas > 1 && !dic)
+    return run_qupdate_sharded(variant, x, n, Q, pid, Omega, nen, nodelist, root, N, prior, model, o, out);
+  if (o.n_devices >= 1) { o.device = o.devices[0]; o.n_devices = 0; }      // one chain lives on one device
   phm_engine* e = nullptr;
   int32_t st = phm_engine_create(x, &model, &o, N, &e);
   if (st) return st;
@@ -151,8 +313,8 @@ static int32_t run_qupdate(int variant, bool dic, const phm_tree* x, int32_t n, 
   }
 
   std::vector<double> Qw(Q, Q + nn), Qr, row(ecols);
-  // PHM_QTIMING=1 (measurement aid): mean host time of the phases of an iteration, printed once at the end
-  const bool qtiming = std::getenv("PHM_QTIMING") != nullptr;
+  // phm_debug_options.q_timing (measurement aid): mean host time of the phases of an iteration, printed once at the end
+  const bool qtiming = g_phm_debug.q_timing != 0;
   double t_run = 0, t_sync = 0, t_read = 0, t_upd = 0, t_set = 0;
   auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   for (int i = 0; i < N && !st; ++i) {

@@ -787,9 +787,9 @@ int32_t wtiles_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
   p.klong = e->nw_klong;
   // branches per wave of the branch kernel: one while waves are scarce, up to 8 once there are 65 536 of them anyway
   p.group = (int32_t)std::max<int64_t>(1, std::min<int64_t>(8, (int64_t)tiles * E / 65536));
-  if (const char* g = std::getenv("PHM_WT_GROUP")) p.group = std::max(1, std::atoi(g));      // measurement aid
+  if (e->dbg.branch_group > 0) p.group = std::min(64, (int)e->dbg.branch_group);      // measurement aid (phm_debug_options)
   p.n_groups = (E + p.group - 1) / p.group;
-  p.up_form = o.pruning_form & 3; p.band_up = 0; p.band_draw = 0; p.B2band = e->d_wt_B2band.as<double>();
+  p.up_form = e->dbg.pruning_form & 3; p.band_up = 0; p.band_draw = 0; p.B2band = e->d_wt_B2band.as<double>();
   e->sparse_req = o.sparse_chains;
   p.seed_lo = (uint32_t)(o.seed & 0xFFFFFFFFull); p.seed_hi = (uint32_t)(o.seed >> 32);
   p.rows = rows;
@@ -867,8 +867,14 @@ int32_t phm_struct_size(int32_t which) {
     case 1: return (int32_t)sizeof(phm_info);
     case 2: return (int32_t)sizeof(phm_tree);
     case 3: return (int32_t)sizeof(phm_model);
+    case 4: return (int32_t)sizeof(phm_debug_options);
     default: return -1;
   }
+}
+
+int32_t phm_set_debug_options(const phm_debug_options* dbg) {
+  if (dbg) g_phm_debug = *dbg; else g_phm_debug = phm_debug_options{};
+  return PHM_OK;
 }
 
 int32_t phm_device_count(void) {
@@ -901,6 +907,15 @@ int32_t phm_engine_create(const phm_tree* x, const phm_model* model, const phm_o
 
 int32_t phm_engine_create_multi(const phm_tree* trees, int32_t n_trees, const phm_model* model, const phm_options* opt_in,
                                 int32_t max_iters, phm_engine** out) {
+  return phm_engine_create_impl(trees, n_trees, model, opt_in, g_phm_debug, 0, max_iters, out);
+}
+
+}  // extern "C"
+
+// The one constructor behind phm_engine_create / _multi, the multi-device one-shot calls (worker threads pass the CALLER's
+// debug options) and the capacity recovery (boost_log2: log2 of the multiplier applied to the provisioned capacities).
+int32_t phm_engine_create_impl(const phm_tree* trees, int32_t n_trees, const phm_model* model, const phm_options* opt_in,
+                               const phm_debug_options& dbg, int boost_log2, int32_t max_iters, phm_engine** out) {
   if (!out) return fail(PHM_ERR_BAD_INPUT, "out is NULL");
   *out = nullptr;
   if (!trees || !model) return fail(PHM_ERR_BAD_INPUT, "tree/model is NULL");
@@ -962,12 +977,13 @@ int32_t phm_engine_create_multi(const phm_tree* trees, int32_t n_trees, const ph
   e->max_iters = max_iters; e->reduce = o.reduce ? 1 : 0;
   e->ipl = o.iters_per_launch > 0 ? o.iters_per_launch : 8;
   e->tips_per_replica = o.tips_per_replica != 0 || n_trees > 1;      // a list of trees: tip data per tile
-  e->phase_timing = o.phase_timing != 0;
+  e->dbg = dbg;
+  e->phase_timing = dbg.phase_timing != 0;
   // rescale_pruning with a fixed-Q MCMC variant: the pruning pass of sumstatMCMC / SPARSEsumstatMCMC rescaled like _bigtree's (:525)
   e->normalise = normalised_variant(e->variant) || (o.rescale_pruning != 0 && (e->variant == PHM_MCMC || e->variant == PHM_MCMC_SPARSE));
-  e->cap_boost = 1 << std::max(0, std::min(10, (int)o.capacity_boost_log2));      // internal: set by the capacity recovery
+  e->cap_boost = 1 << std::max(0, std::min(10, boost_log2));      // set by the capacity recovery
   e->recover = o.no_recovery == 0;
-  if (e->recover) e->saved = save_input(trees, n_trees, model, o, max_iters);      // the replay needs the caller's inputs; nothing is kept otherwise
+  if (e->recover) { e->saved = save_input(trees, n_trees, model, o, max_iters); e->saved->dbg = dbg; }      // the replay needs the caller's inputs; nothing is kept otherwise
 
   std::string serr;
   e->scheds.resize(n_trees);
@@ -1203,6 +1219,8 @@ int32_t phm_engine_create_multi(const phm_tree* trees, int32_t n_trees, const ph
   return PHM_OK;
 }
 
+extern "C" {
+
 int32_t phm_engine_run(phm_engine* e, int32_t n_iters, void* hip_stream) {
   e = live(e);
   if (!e) return fail(PHM_ERR_STATE, "engine is NULL");
@@ -1286,13 +1304,12 @@ static int32_t recover_capacity(phm_engine* e) {
   e->release_device();
   e->dead = true;
   phm_options o = sv->opt;
-  o.capacity_boost_log2 = boost_log2 + 1;
   phm_engine* r = nullptr;
   const std::vector<std::pair<int32_t, std::vector<double>>> hist = sv->model_hist;      // the replay appends its own copy
-  int32_t st = phm_engine_create_multi(sv->flat.data(), (int32_t)sv->flat.size(), &sv->model, &o, sv->max_iters, &r);
-  if (!st && std::getenv("PHM_TEST_RECOVERY_FAILS")) {      // test aid: a replacement that "does not fit" (tests/test_gpu_parity.py)
+  int32_t st = phm_engine_create_impl(sv->flat.data(), (int32_t)sv->flat.size(), &sv->model, &o, sv->dbg, boost_log2 + 1, sv->max_iters, &r);
+  if (!st && sv->dbg.fail_recovery) {      // test aid: a replacement that "does not fit" (tests/test_gpu_parity.py)
     delete r; r = nullptr;
-    st = fail(PHM_ERR_OOM, "PHM_TEST_RECOVERY_FAILS is set");
+    st = fail(PHM_ERR_OOM, "phm_debug_options.fail_recovery is set");
   }
   if (st) return (st == PHM_ERR_OOM) ? fail(PHM_ERR_CAPACITY, "a branch outgrew its dwell capacity and larger slots do not fit in HBM: " + g_phm_err) : st;
   r->recoveries = e->recoveries + 1;
@@ -1406,6 +1423,55 @@ int32_t phm_engine_read_stats(phm_engine* e, int32_t iter0, int32_t n, double* o
   }
   return PHM_OK;
 }
+
+}  // extern "C"
+
+// Multi-device one-shot calls, reduce = 1: the statistics of iterations [iter0, iter0 + n) summed over this engine's tiles in tile order,
+// CONTINUING from `acc` (n x dcols row-major: the totals of the devices before this one; empty = start from zero) -- the fold of
+// stats_reduce_kernel carried across devices, so whole-tile shards reproduce the one-device sum term by term.  `acc` is replaced.
+int32_t phm_engine_fold_reduced(phm_engine* e, int32_t iter0, int32_t n, std::vector<double>& acc) {
+  e = live(e);
+  if (!e) return fail(PHM_ERR_STATE, "engine is NULL");
+  if (e->dead) return dead_engine();
+  if (!e->reduce) return fail(PHM_ERR_STATE, "engine was not created with reduce = 1");
+  if (iter0 < 0 || n < 1 || iter0 + n > e->iters_done) return fail(PHM_ERR_STATE, "statistics requested for iterations that have not run");
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(wait_stream(e->last_stream));
+  const size_t cnt = (size_t)n * e->dcols;
+  if (!acc.empty() && acc.size() != cnt) return fail(PHM_ERR_STATE, "fold: accumulator size mismatch");
+  const double* init = nullptr;
+  DevBuf dinit;
+  if (!acc.empty()) {
+    HIPCHK(dinit.alloc(sizeof(double) * cnt));
+    HIPCHK(hipMemcpyAsync(dinit.p, acc.data(), sizeof(double) * cnt, hipMemcpyHostToDevice, e->last_stream));
+    init = dinit.as<double>();
+  }
+  HIPCHK(phm::launch_stats_reduce(e->d_stats.as<double>() + (size_t)iter0 * e->tiles * e->dcols, n, e->tiles, e->dcols,
+                                    e->d_red.as<double>() + (size_t)iter0 * e->dcols, e->last_stream, init));
+  acc.resize(cnt);
+  HIPCHK(hipMemcpyAsync(acc.data(), e->d_red.as<double>() + (size_t)iter0 * e->dcols, sizeof(double) * cnt, hipMemcpyDeviceToHost, e->last_stream));
+  HIPCHK(hipStreamSynchronize(e->last_stream));
+  return PHM_OK;
+}
+
+// ... and the result matrix from the finished fold: device columns -> result columns (column-major n x cols), parameter columns of
+// the fixed Q filled in as phm_engine_read_stats does
+int32_t phm_engine_finish_reduced(phm_engine* e, int32_t iter0, int32_t n, const std::vector<double>& acc, double* out) {
+  e = live(e);
+  if (!e || !out) return fail(PHM_ERR_STATE, "engine/out is NULL");
+  const int cols = e->cols, dcols = e->dcols;
+  if (acc.size() != (size_t)n * dcols) return fail(PHM_ERR_STATE, "fold: accumulator size mismatch");
+  for (int i = 0; i < n; ++i)
+    for (int c = 0; c < dcols; ++c) out[(size_t)((dcols != cols && c == dcols - 1) ? cols - 1 : c) * n + i] = acc[(size_t)i * dcols + c];
+  if (dcols != cols)
+    for (int i = 0; i < n; ++i) {
+      const std::vector<double>& qp = e->qhist[iter0 + i];
+      for (size_t q = 0; q < qp.size(); ++q) out[(size_t)(dcols - 1 + q) * n + i] = qp[q];
+    }
+  return PHM_OK;
+}
+
+extern "C" {
 
 int32_t phm_engine_dump(phm_engine* e, int32_t replica, int32_t* seg_count, double* seg_dwell, int32_t seg_cap,
                         int32_t* node_states, double* PL) {

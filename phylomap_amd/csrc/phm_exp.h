@@ -53,6 +53,7 @@ struct ExpParams {
   int32_t n_tips, n_node, n_edge, root;      // root: internal index
   int32_t N;                                 // samples
   int32_t n_tiles;
+  int32_t it0;                               // global index of this call's first sample (multi-device calls split the N samples)
   uint32_t seed_lo, seed_hi, replica;
   double poisson_rate;                       // -min diag(Q), src/phylomap.cpp:3008
   double pid[NS];
@@ -75,6 +76,7 @@ struct ExpWideParams {                         // 5 <= n <= 64: runtime state co
   int32_t n_states;
   int32_t n_tips, n_node, n_edge, root;
   int32_t N, n_tiles;
+  int32_t it0;                                 // global index of the first sample
   uint32_t seed_lo, seed_hi, replica;
   double poisson_rate;
   const double* pid;                           // [n]
@@ -102,6 +104,7 @@ struct ExpTilesParams {
   int32_t n_states;
   int32_t n_tips, n_node, n_edge, root;        // root: internal index
   int32_t N, n_tiles;
+  int32_t it0;                                 // global index of the first sample
   uint32_t seed_lo, seed_hi, replica;
   double poisson_rate;
   double fx_scale, fx_inv;                     // fixed-point scale of the dwell accumulators (powers of two)

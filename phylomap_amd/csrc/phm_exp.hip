@@ -372,7 +372,7 @@ __global__ __launch_bounds__(EXP_BLOCK) void exp_sample_kernel(ExpParams<NS> p) 
     const double* plr = p.PL + (size_t)(p.root + p.n_tips) * NS;
 #pragma unroll
     for (int c = 0; c < NS; ++c) pr[c] = p.pid[c] * plr[c];                   // :2926
-    double u = stream_u(p.seed_lo, p.seed_hi, p.replica, (uint32_t)it, ENT_NODE | (uint32_t)(p.root + p.n_tips), 0);
+    double u = stream_u(p.seed_lo, p.seed_hi, p.replica, (uint32_t)(it + p.it0), ENT_NODE | (uint32_t)(p.root + p.n_tips), 0);
     nst[p.root * 64 + lane] = (uint8_t)sample_cat<NS>(pr, u, err);            // :2934
   }
 
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(EXP_BLOCK) void exp_sample_kernel(ExpParams<NS> p) 
       const double* plc = p.PL + (size_t)(ds.child + p.n_tips) * NS;
 #pragma unroll
       for (int c = 0; c < NS; ++c) pr[c] = Pb[a * NS + c] * plc[c];           // :2953
-      double u = stream_u(p.seed_lo, p.seed_hi, p.replica, (uint32_t)it, ENT_NODE | (uint32_t)(ds.child + p.n_tips), 0);
+      double u = stream_u(p.seed_lo, p.seed_hi, p.replica, (uint32_t)(it + p.it0), ENT_NODE | (uint32_t)(ds.child + p.n_tips), 0);
       e = sample_cat<NS>(pr, u, err);                                         // :2956
       nst[ds.child * 64 + lane] = (uint8_t)e;
     } else {
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(EXP_BLOCK) void exp_sample_kernel(ExpParams<NS> p) 
     const double tb = p.edge_length[b];
     const double transProb = Pb[a * NS + e];
     Stream sr;
-    sr.open(ENT_BUNIF | (uint32_t)b, (uint32_t)it, p.replica, p.seed_lo, p.seed_hi);
+    sr.open(ENT_BUNIF | (uint32_t)b, (uint32_t)(it + p.it0), p.replica, p.seed_lo, p.seed_hi);
     uint32_t dr = 0;
     const double rU = sr.draw(dr++);                                          // :103
     const double lam = p.poisson_rate * tb;
@@ -523,7 +523,7 @@ __global__ __launch_bounds__(EXP_BLOCK) void exp_wide_kernel(ExpWideParams p) {
 
   {
     const double* plr = p.PL + (size_t)(p.root + p.n_tips) * n;
-    double u = stream_u(p.seed_lo, p.seed_hi, p.replica, (uint32_t)it, ENT_NODE | (uint32_t)(p.root + p.n_tips), 0);
+    double u = stream_u(p.seed_lo, p.seed_hi, p.replica, (uint32_t)(it + p.it0), ENT_NODE | (uint32_t)(p.root + p.n_tips), 0);
     nst[p.root * 64 + lane] = (uint8_t)draw_node(p.pid, plr, u);                // :2926-2934
   }
 
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(EXP_BLOCK) void exp_wide_kernel(ExpWideParams p) {
     const double* Pb = p.P + (size_t)b * n * n;
     int e;
     if (ds.child >= 0) {
-      double u = stream_u(p.seed_lo, p.seed_hi, p.replica, (uint32_t)it, ENT_NODE | (uint32_t)(ds.child + p.n_tips), 0);
+      double u = stream_u(p.seed_lo, p.seed_hi, p.replica, (uint32_t)(it + p.it0), ENT_NODE | (uint32_t)(ds.child + p.n_tips), 0);
       e = draw_node(Pb + (size_t)a * n, p.PL + (size_t)(ds.child + p.n_tips) * n, u);   // :2953-2956
       nst[ds.child * 64 + lane] = (uint8_t)e;
     } else {
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(EXP_BLOCK) void exp_wide_kernel(ExpWideParams p) {
     const double tb = p.edge_length[b];
     const double transProb = Pb[(size_t)a * n + e];
     Stream sr;
-    sr.open(ENT_BUNIF | (uint32_t)b, (uint32_t)it, p.replica, p.seed_lo, p.seed_hi);
+    sr.open(ENT_BUNIF | (uint32_t)b, (uint32_t)(it + p.it0), p.replica, p.seed_lo, p.seed_hi);
     uint32_t dr = 0;
     const double rU = sr.draw(dr++);
     const double lam = p.poisson_rate * tb;
@@ -648,7 +648,7 @@ __global__ __launch_bounds__(EXP_BLOCK) void exp_tiles_root_kernel(ExpTilesParam
   if (tile >= p.n_tiles) return;
   const int it = tile * 64 + lane;
   uint32_t err = 0;
-  const double u = stream_u(p.seed_lo, p.seed_hi, p.replica, (uint32_t)it, ENT_NODE | (uint32_t)(p.root + p.n_tips), 0);
+  const double u = stream_u(p.seed_lo, p.seed_hi, p.replica, (uint32_t)(it + p.it0), ENT_NODE | (uint32_t)(p.root + p.n_tips), 0);
   p.nstate[((size_t)tile * p.n_node + p.root) * 64 + lane] =
       (uint8_t)exp_draw_node(p.pid, p.PL + (size_t)(p.root + p.n_tips) * p.n_states, p.n_states, u, err);      // :2926-2934
   if (err && it < p.N) atomicOr(p.err, err);
@@ -666,7 +666,7 @@ __global__ __launch_bounds__(EXP_BLOCK) void exp_tiles_node_kernel(ExpTilesParam
   uint8_t* __restrict__ nst = p.nstate + (size_t)tile * p.n_node * 64;
   const int a = nst[ds.parent * 64 + lane];
   uint32_t err = 0;
-  const double u = stream_u(p.seed_lo, p.seed_hi, p.replica, (uint32_t)it, ENT_NODE | (uint32_t)(ds.child + p.n_tips), 0);
+  const double u = stream_u(p.seed_lo, p.seed_hi, p.replica, (uint32_t)(it + p.it0), ENT_NODE | (uint32_t)(ds.child + p.n_tips), 0);
   const int e = exp_draw_node(p.P + ((size_t)ds.edge * n + a) * n, p.PL + (size_t)(ds.child + p.n_tips) * n, n, u, err);   // :2953-2956
   nst[ds.child * 64 + lane] = (uint8_t)e;
   if (err && it < p.N) atomicOr(p.err, err);
@@ -699,7 +699,7 @@ __global__ __launch_bounds__(EXP_BLOCK) void exp_tiles_branch_kernel(ExpTilesPar
     const double tb = p.edge_length[b];
     const double transProb = Pb[(size_t)a * n + e];
     Stream sr;
-    sr.open(ENT_BUNIF | (uint32_t)b, (uint32_t)it, p.replica, p.seed_lo, p.seed_hi);
+    sr.open(ENT_BUNIF | (uint32_t)b, (uint32_t)(it + p.it0), p.replica, p.seed_lo, p.seed_hi);
     uint32_t dr = 0;
     const double rU = sr.draw(dr++);                                            // :103
     const double lam = p.poisson_rate * tb;

@@ -2,6 +2,8 @@
 // MFMA f64 variants) and the sumstatEXP driver (maketreelistEXP, src/phylomap.cpp:3001-3051).
 #include "phm_internal.h"
 
+#include <thread>
+
 namespace {
 
 struct Timer {
@@ -73,9 +75,8 @@ static int32_t expm_pade_impl(bool mfma, int32_t n, const double* Q, const doubl
   HIPCHK(hipMemcpy(ds.p, sq.data(), ds.bytes, hipMemcpyHostToDevice));
   HIPCHK(hipMemset(derr.p, 0, sizeof(uint32_t)));
   if (mfma) { HIPCHK(dbad.alloc(sizeof(int32_t) * n_t)); HIPCHK(hipMemset(dbad.p, 0, dbad.bytes)); }
-  // smallest pivot the unpivoted block elimination accepts (test aid: PHM_PADE_PIVOT_MIN=1e300 sends every matrix to the pivoted kernel)
-  double piv_min = 1e-3;
-  if (const char* ev = std::getenv("PHM_PADE_PIVOT_MIN")) piv_min = std::atof(ev);
+  // smallest pivot the unpivoted block elimination accepts (test aid: phm_debug_options.pade_pivot_min = 1e300 sends every matrix to the pivoted kernel)
+  const double piv_min = g_phm_debug.pade_pivot_min > 0.0 ? g_phm_debug.pade_pivot_min : 1e-3;
   Timer tm;
   HIPCHK(hipEventCreate(&tm.a)); HIPCHK(hipEventCreate(&tm.b));
   HIPCHK(hipEventRecord(tm.a, nullptr));
@@ -122,9 +123,10 @@ int32_t phm_expm_pade_mfma(int32_t n, const double* Q, const double* t, int32_t 
 
 // maketreelistEXP, src/phylomap.cpp:3001-3051.  P(t_b) and the pruning pass are computed ONCE (the reference
 // recomputes both every iteration although Q never changes, :2980-2981).
-int32_t phm_maketreelistEXP(const phm_tree* x, int32_t n, const double* Q, const double* pid, const int32_t* nen,
-                            const int32_t* nodelist, int32_t root, int32_t N, const double* lefts, const double* rights,
-                            const double* d, const phm_options* opt_in, double* out) {
+// samples [it0, it0 + N) of the call on ONE device (o.device); out: N x cols column-major
+static int32_t exp_oneshot(const phm_tree* x, int32_t n, const double* Q, const double* pid, const int32_t* nen,
+                           const int32_t* nodelist, int32_t root, int32_t N, int32_t it0, const double* lefts, const double* rights,
+                           const double* d, const phm_options* opt_in, double* out) {
   if (!x || !Q || !pid || !lefts || !rights || !d || !out) return fail(PHM_ERR_BAD_INPUT, "phm_maketreelistEXP: NULL argument");
   if (N < 1) return fail(PHM_ERR_BAD_INPUT, "N must be >= 1");
   if (n < 2) return fail(PHM_ERR_BAD_INPUT, "n_states must be >= 2");
@@ -248,7 +250,7 @@ int32_t phm_maketreelistEXP(const phm_tree* x, int32_t n, const double* Q, const
     HIPCHK(hipMemcpy(dpid.p, pid, sizeof(double) * n, hipMemcpyHostToDevice));
     HIPCHK(hipMemset(ddw.p, 0, ddw.bytes)); HIPCHK(hipMemset(dcnt.p, 0, dcnt.bytes));
     phm::ExpTilesParams p;
-    p.n_states = n; p.n_tips = T; p.n_node = s.n_node; p.n_edge = E; p.root = s.root; p.N = N; p.n_tiles = tiles;
+    p.n_states = n; p.n_tips = T; p.n_node = s.n_node; p.n_edge = E; p.root = s.root; p.N = N; p.n_tiles = tiles; p.it0 = it0;
     p.seed_lo = (uint32_t)(o.seed & 0xFFFFFFFFull); p.seed_hi = (uint32_t)(o.seed >> 32); p.replica = (uint32_t)o.replica_offset;
     p.poisson_rate = rate; p.fx_scale = std::ldexp(1.0, 61 - ex); p.fx_inv = std::ldexp(1.0, ex - 61);
     p.pid = dpid.as<double>(); p.down = ddown.as<phm::DownStep>(); p.node_order = dorder.as<int32_t>();
@@ -267,7 +269,7 @@ int32_t phm_maketreelistEXP(const phm_tree* x, int32_t n, const double* Q, const
     return device_status(derrh);
   }
   auto fill = [&](auto& p) {
-    p.n_tips = T; p.n_node = s.n_node; p.n_edge = E; p.root = s.root; p.N = N; p.n_tiles = tiles;
+    p.n_tips = T; p.n_node = s.n_node; p.n_edge = E; p.root = s.root; p.N = N; p.n_tiles = tiles; p.it0 = it0;
     p.seed_lo = (uint32_t)(o.seed & 0xFFFFFFFFull); p.seed_hi = (uint32_t)(o.seed >> 32); p.replica = (uint32_t)o.replica_offset;
     p.poisson_rate = rate;
     for (int i = 0; i < n; ++i) p.pid[i] = pid[i];
@@ -285,7 +287,7 @@ int32_t phm_maketreelistEXP(const phm_tree* x, int32_t n, const double* Q, const
     HIPCHK(hipMemcpy(dpid.p, pid, sizeof(double) * n, hipMemcpyHostToDevice));
     HIPCHK(hipMemset(dout.p, 0, dout.bytes));
     phm::ExpWideParams p;
-    p.n_states = n; p.n_tips = T; p.n_node = s.n_node; p.n_edge = E; p.root = s.root; p.N = N; p.n_tiles = tiles;
+    p.n_states = n; p.n_tips = T; p.n_node = s.n_node; p.n_edge = E; p.root = s.root; p.N = N; p.n_tiles = tiles; p.it0 = it0;
     p.seed_lo = (uint32_t)(o.seed & 0xFFFFFFFFull); p.seed_hi = (uint32_t)(o.seed >> 32); p.replica = (uint32_t)o.replica_offset;
     p.poisson_rate = rate; p.pid = dpid.as<double>();
     p.down = ddown.as<phm::DownStep>(); p.P = dP.as<double>(); p.PL = dPL.as<double>(); p.edge_length = dt.as<double>();
@@ -304,6 +306,51 @@ int32_t phm_maketreelistEXP(const phm_tree* x, int32_t n, const double* Q, const
   uint32_t derrh = 0;
   HIPCHK(hipMemcpy(&derrh, derr.p, sizeof derrh, hipMemcpyDeviceToHost));
   return device_status(derrh);
+}
+
+// The samples are i.i.d. and addressed by their index (src/phylomap.cpp:3045-3048): with phm_options.n_devices > 1 device d draws
+// a contiguous range of the N samples (one host thread per device) -- the matrix is the one-device matrix row for row.
+int32_t phm_maketreelistEXP(const phm_tree* x, int32_t n, const double* Q, const double* pid, const int32_t* nen,
+                            const int32_t* nodelist, int32_t root, int32_t N, const double* lefts, const double* rights,
+                            const double* d, const phm_options* opt_in, double* out) {
+  if (!out) return fail(PHM_ERR_BAD_INPUT, "phm_maketreelistEXP: NULL argument");
+  if (N < 1) return fail(PHM_ERR_BAD_INPUT, "N must be >= 1");
+  phm_options o;
+  std::memset(&o, 0, sizeof(o));
+  o.device = -1;
+  if (opt_in) o = *opt_in;
+  std::vector<phm_shard> shards;
+  int32_t st = phm_plan_shards(o, N, shards);
+  if (st) return st;
+  if (shards.size() == 1) {
+    o.device = shards[0].device; o.n_devices = 0;
+    return exp_oneshot(x, n, Q, pid, nen, nodelist, root, N, 0, lefts, rights, d, &o, out);
+  }
+  const int cols = n + n * (n - 1);
+  struct Run { int32_t st = PHM_OK; std::string err; double ms = 0.0; std::vector<double> buf; };
+  std::vector<Run> runs(shards.size());
+  auto work = [&](size_t i) {
+    phm_options oi = o;
+    oi.device = shards[i].device; oi.n_devices = 0;
+    const int32_t Ni = (int32_t)shards[i].count;
+    runs[i].buf.assign((size_t)Ni * cols, 0.0);
+    runs[i].st = exp_oneshot(x, n, Q, pid, nen, nodelist, root, Ni, (int32_t)shards[i].first, lefts, rights, d, &oi, runs[i].buf.data());
+    if (runs[i].st) runs[i].err = g_phm_err;
+    runs[i].ms = g_phm_last_kernel_ms;
+  };
+  std::vector<std::thread> th;
+  for (size_t i = 1; i < shards.size(); ++i) th.emplace_back(work, i);
+  work(0);
+  for (std::thread& t : th) t.join();
+  double ms = 0.0;
+  for (size_t i = 0; i < shards.size(); ++i) {
+    if (runs[i].st) return fail(runs[i].st, "device " + std::to_string(shards[i].device) + ": " + runs[i].err);
+    ms = std::max(ms, runs[i].ms);
+    const size_t Ni = (size_t)shards[i].count, r0 = (size_t)shards[i].first;
+    for (int c = 0; c < cols; ++c) std::memcpy(out + (size_t)c * N + r0, runs[i].buf.data() + (size_t)c * Ni, sizeof(double) * Ni);
+  }
+  g_phm_last_kernel_ms = ms;      // the devices sample side by side: the longest
+  return PHM_OK;
 }
 
 double phm_last_kernel_ms(void) { return g_phm_last_kernel_ms; }

@@ -28,6 +28,7 @@
 
 inline thread_local std::string g_phm_err;      // phm_last_error()
 inline thread_local double g_phm_last_kernel_ms = 0.0;      // phm_last_kernel_ms()
+inline thread_local phm_debug_options g_phm_debug = {};     // phm_set_debug_options()
 
 inline int32_t fail(int32_t st, const std::string& msg) { g_phm_err = msg; return st; }
 
@@ -206,6 +207,7 @@ struct SavedInput {
   phm_model model;
   std::vector<double> Q, pid, B;
   phm_options opt;
+  phm_debug_options dbg = {};
   int32_t max_iters = 0;
   std::vector<std::pair<int32_t, std::vector<double>>> model_hist;      // (first iteration it applies to, Q column-major): phm_engine_set_model calls
 };
@@ -272,7 +274,8 @@ struct phm_engine {
   DevBuf d_wt_dwfx, d_wt_segacc, d_wt_B2, d_wt_totL, d_wt_pair_slot, d_wt_slot_col, d_wt_B2band, d_wt_mstate, d_wt_dwfx_tile, d_wt_cnt_tile;
   phm::WtBand wt_band;                            // band of the chain matrix (kernel-argument constants of wt_up_band_kernel)
   int sparse_req = 0;                              // phm_options.sparse_chains
-  bool phase_timing = false;                       // phm_options.phase_timing: HIP events between the phases of a (tile, item) sweep
+  phm_debug_options dbg = {};                      // the creating thread's phm_set_debug_options at creation
+  bool phase_timing = false;                       // phm_debug_options.phase_timing: HIP events between the phases of a (tile, item) sweep
   std::vector<hipEvent_t> phase_ev;                // 5 per iteration of the last run
   int phase_iters = 0;
   double phase_ms[4] = {0.0, 0.0, 0.0, 0.0};       // pruning levels, node draws, branch kernel, reductions (sums over the last run)
@@ -303,3 +306,13 @@ struct phm_engine {
     for (hipEvent_t ev : phase_ev) (void)hipEventDestroy(ev);
   }
 };
+
+// the constructor behind phm_engine_create / phm_engine_create_multi (phm_engine.cpp)
+int32_t phm_engine_create_impl(const phm_tree* trees, int32_t n_trees, const phm_model* model, const phm_options* opt_in,
+                               const phm_debug_options& dbg, int boost_log2, int32_t max_iters, phm_engine** out);
+int32_t phm_engine_fold_reduced(phm_engine* e, int32_t iter0, int32_t n, std::vector<double>& acc);
+int32_t phm_engine_finish_reduced(phm_engine* e, int32_t iter0, int32_t n, const std::vector<double>& acc, double* out);
+
+// multi-device one-shot calls (phm_drivers.cpp): contiguous ranges of `units` (replicas / sites / EXP samples) per device
+struct phm_shard { int32_t device; int64_t first, count; };
+int32_t phm_plan_shards(const phm_options& o, int64_t units, std::vector<phm_shard>& shards);

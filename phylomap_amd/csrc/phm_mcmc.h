@@ -56,6 +56,6 @@ hipError_t launch_mcmc_init(int n_edge, int n_tiles, int64_t rows, const DownSte
                             const int32_t* map_off, const double* maps, double* dwell0, uint16_t* mcount,
                             hipStream_t stream);
 hipError_t launch_stats_reduce(const double* partial, int n_iters, int n_tiles, int n_cols, double* out,
-                               hipStream_t stream);
+                               hipStream_t stream, const double* init = nullptr);
 
 }  // namespace phm

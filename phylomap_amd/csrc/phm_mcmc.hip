@@ -451,12 +451,13 @@ __global__ void mcmc_init_kernel(int n_edge, int n_tiles, int64_t rows, const Do
 }
 
 // reduce mode: out[it][col] = sum over tiles of the per-wave partials, fixed order
+// `init` (may be NULL): the fold continues from the totals of the devices before this one (multi-device one-shot calls)
 __global__ void stats_reduce_kernel(const double* __restrict__ partial, int n_iters, int n_tiles, int n_cols,
-                                    double* __restrict__ out) {
+                                    double* __restrict__ out, const double* __restrict__ init) {
   int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n_iters * n_cols) return;
   int it = idx / n_cols, c = idx - it * n_cols;
-  double acc = 0.0;
+  double acc = init ? init[idx] : 0.0;
   for (int t = 0; t < n_tiles; ++t) acc += partial[((size_t)it * n_tiles + t) * n_cols + c];
   out[idx] = acc;
 }
@@ -514,10 +515,10 @@ hipError_t launch_mcmc_init(int n_edge, int n_tiles, int64_t rows, const DownSte
 }
 
 hipError_t launch_stats_reduce(const double* partial, int n_iters, int n_tiles, int n_cols, double* out,
-                               hipStream_t stream) {
+                               hipStream_t stream, const double* init) {
   int total = n_iters * n_cols;
   hipLaunchKernelGGL(stats_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, partial, n_iters, n_tiles,
-                     n_cols, out);
+                     n_cols, out, init);
   return hipGetLastError();
 }
 

@@ -720,7 +720,7 @@ hipError_t launch_narrow_sweep(const NarrowParams<NS>& p, const std::vector<int3
   const int DL = (int)walk_off.size() - 1;
   for (size_t t = 0; t + 1 < tier_off.size(); ++t) {
     const unsigned ncl = (unsigned)(tier_off[t + 1] - tier_off[t]);
-    const bool carry = t == 0 && stats_pending;
+    const bool carry = t == 0 && stats_pending && !p.reduce;   // reduce: the sweep added its own row below (a second pass would count its segments twice)
     hipLaunchKernelGGL(narrow_cluster_kernel<NS>, dim3(ncl + (carry ? stat_cols : 0u), S), dim3(NARROW_CLUSTER_BLOCK), 0, stream, p,
                        tier_off[t], (int)ncl, it, carry ? (int)n_waves : 0);
   }

@@ -64,6 +64,12 @@ struct FlatTree {
 //   x$sites = S x length(x$states) matrix of 1-based tip states: S sites of an alignment on the same tree, one chain each
 //   options(phylomap.hip.reduce = FALSE) return list of S matrices instead of their sum
 //   options(phylomap.hip.device = d)     HIP device ordinal
+//   options(phylomap.hip.devices = D)    D GPUs of the node (0..D-1), or an integer vector of ordinals: the chains / sites
+//                                        (sumstatEXP: the N samples) are sharded over them inside the call (phm_options.n_devices)
+//   options(phylomap.hip.rescale = TRUE) row-rescaled pruning pass for sumstatMCMC / SPARSEsumstatMCMC / sumstatEXP, which
+//                                        underflow in the reference beyond a few hundred / thousand tips (phm_options.rescale_pruning)
+//   options(phylomap.hip.mapping = "auto" | "replicas" | "branches" | "tiles")   how a sweep is laid over the lanes
+//   options(phylomap.hip.cap_tail = p)   tail probability the per-branch path capacity is provisioned for (0 = automatic)
 // With S > 1 the default result is the N x cols matrix of statistics SUMMED over the chains / sites (what a likelihood over
 // sites needs, and the form in which 10^4 chains cost one row each); a single chain on a big tree uses one lane per branch, from a
 // few hundred chains on the lanes are the chains -- the throughput mapping is reached from R this way.
@@ -85,6 +91,29 @@ HipRequest request_from_R(List x, int n_tips) {
   Environment base("package:base");
   Function getOption = base["getOption"];
   o.device = as<int>(getOption("phylomap.hip.device", -1));
+  {
+    IntegerVector devs = as<IntegerVector>(getOption("phylomap.hip.devices", IntegerVector(0)));
+    if (devs.size() == 1 && devs[0] >= 1) {                          // a count: GPUs 0 .. D-1
+      const int D = devs[0];
+      if (D > PHM_MAX_DEVICES) stop("phylomap.hip.devices: at most %d GPUs", (int)PHM_MAX_DEVICES);
+      o.n_devices = D;
+      for (int d = 0; d < D; ++d) o.devices[d] = d;
+    } else if (devs.size() > 1) {                                    // explicit ordinals
+      if (devs.size() > PHM_MAX_DEVICES) stop("phylomap.hip.devices: at most %d GPUs", (int)PHM_MAX_DEVICES);
+      o.n_devices = (int32_t)devs.size();
+      for (int d = 0; d < devs.size(); ++d) o.devices[d] = devs[d];
+    }
+  }
+  o.rescale_pruning = as<bool>(getOption("phylomap.hip.rescale", false)) ? 1 : 0;
+  o.cap_tail = as<double>(getOption("phylomap.hip.cap_tail", 0.0));
+  {
+    std::string mp = as<std::string>(getOption("phylomap.hip.mapping", "auto"));
+    if (mp == "auto") o.mapping = PHM_MAP_AUTO;
+    else if (mp == "replicas") o.mapping = PHM_MAP_REPLICAS;
+    else if (mp == "branches") o.mapping = PHM_MAP_BRANCHES;
+    else if (mp == "tiles") o.mapping = PHM_MAP_TILES;
+    else stop("phylomap.hip.mapping must be \"auto\", \"replicas\", \"branches\" or \"tiles\"");
+  }
   rq.S = as<int>(getOption("phylomap.hip.replicas", 1));
   rq.summed = as<bool>(getOption("phylomap.hip.reduce", true));
   if (x.containsElementNamed("sites")) {

@@ -131,3 +131,23 @@ def test_one_chain_in_several_run_calls_and_single_row_reads():
     _same(eng.stats(4, 1)[0], want[4:5], 4)
     _same(eng.stats(0, 5)[0], want, 4)
     eng.close()
+
+
+def test_segment_counter_of_the_branch_mapping_counts_every_sweep_once():
+    """phm_info.seg_read (the measured m + m' behind bench.py's B_alg) is the same whether the rows are summed over replicas on the
+    device (reduce: every sweep adds its own row) or not (the row is added by the next sweep's first launch), and whether the sweeps
+    come in one call or one by one (the reduce path counted all but the last sweep of a call twice)."""
+    z, Q, pid, Omega = synth.config_problem(2)
+    K, S = 6, 3
+    seen = {}
+    for reduce in (False, True):
+        for step in (K, 1):
+            eng = _lib.Engine(z, Q, pid, Omega, K, variant=_lib.PHM_MCMC_BIGTREE, seed=5, n_replicas=S, reduce=reduce, mapping="branches")
+            for _ in range(K // step):
+                eng.run(step)
+            eng.sync()
+            seen[(reduce, step)] = eng.info().seg_read
+            eng.close()
+    assert len(set(seen.values())) == 1, seen
+    E = z["edge"].shape[0]
+    assert 4 * E * S * K < seen[(True, K)] < 16 * E * S * K          # mean m + m' is about 10 at Omega * mean(t_b) = 4

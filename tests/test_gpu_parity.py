@@ -747,17 +747,20 @@ def test_expm_pade_on_matrix_cores(n):
         np.testing.assert_allclose(P_mfma[b].sum(1), 1.0, atol=1e-12)
 
 
-def test_expm_pade_on_matrix_cores_hands_small_pivots_to_the_pivoted_kernel(monkeypatch):
+def test_expm_pade_on_matrix_cores_hands_small_pivots_to_the_pivoted_kernel():
     """A matrix whose block elimination meets a pivot below the threshold is flagged by the kernel and recomputed by the pivoted
     one: with the threshold raised above every pivot the call returns the exact kernel's matrices bit for bit."""
     Q = synth.dense_Q(61, 0.005, 0.015, seed=61)
     t = np.concatenate([[0.0, 200.0], np.random.default_rng(3).exponential(3.0, 30)])
     P_exact, _ = api.expm_pade(Q, t)
-    monkeypatch.setenv("PHM_PADE_PIVOT_MIN", "1e300")
-    P_fallback, _ = api.expm_pade(Q, t, mfma=True)
-    np.testing.assert_array_equal(P_fallback, P_exact)
-    monkeypatch.setenv("PHM_PADE_PIVOT_MIN", "1.2")      # some matrices (the ones scaled most) go each way
-    P_mixed, _ = api.expm_pade(Q, t, mfma=True)
+    try:
+        _lib.set_debug_options(pade_pivot_min=1e300)
+        P_fallback, _ = api.expm_pade(Q, t, mfma=True)
+        np.testing.assert_array_equal(P_fallback, P_exact)
+        _lib.set_debug_options(pade_pivot_min=1.2)      # some matrices (the ones scaled most) go each way
+        P_mixed, _ = api.expm_pade(Q, t, mfma=True)
+    finally:
+        _lib.set_debug_options()
     np.testing.assert_allclose(P_mixed, P_exact, rtol=0, atol=2e-13)
 
 
@@ -883,14 +886,13 @@ def test_capacity_overflow_is_recovered_like_an_unbounded_list(mapping):
     np.testing.assert_array_equal(ok[0][:, 4:], got[0][:5, 4:])
 
 
-def test_failed_capacity_recovery_leaves_a_dead_handle_not_freed_memory(monkeypatch):
+def test_failed_capacity_recovery_leaves_a_dead_handle_not_freed_memory():
     """the recovery frees the engine's buffers before the replacement exists.  When the replacement cannot be built
-    (here: PHM_TEST_RECOVERY_FAILS; in the field: doubled slots that do not fit) the handle must refuse every further call
+    (here: phm_debug_options.fail_recovery; in the field: doubled slots that do not fit) the handle must refuse every further call
     instead of sweeping on freed HBM."""
     z, Q, pid, Omega = _problem(4, 40, 3)
     Om = 6.0 * Omega
-    monkeypatch.setenv("PHM_TEST_RECOVERY_FAILS", "1")
-    eng = _lib.Engine(z, Q, pid, Om, 30, variant=_lib.PHM_MCMC_BIGTREE, seed=1, n_replicas=70, mapping="tiles", cap_tail=0.9)
+    eng = _lib.Engine(z, Q, pid, Om, 30, variant=_lib.PHM_MCMC_BIGTREE, seed=1, n_replicas=70, mapping="tiles", cap_tail=0.9, fail_recovery=1)
     eng.run(12)
     with pytest.raises(_lib.PhmError) as e:
         eng.sync()                               # overflow -> recovery -> the replacement "does not fit"
@@ -900,7 +902,6 @@ def test_failed_capacity_recovery_leaves_a_dead_handle_not_freed_memory(monkeypa
             call()
         assert e.value.status == 6 and "could not be rebuilt" in str(e.value)
     eng.close()                                  # destroying a dead handle is fine
-    monkeypatch.delenv("PHM_TEST_RECOVERY_FAILS")
     ok = api.sumstatMCMC_bigtree(z, Q, pid, Om, 5, seed=1, n_replicas=70, mapping="tiles", cap_tail=0.9)      # and the library is unharmed
     assert ok.shape == (70, 5, 16)
 

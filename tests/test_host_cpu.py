@@ -156,8 +156,15 @@ def test_cabi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), f"{name} declared in include/phylomap_hip.h but not exported"
     assert sorted(_lib.EXPORTS) == declared
-    assert L.phm_version() == 200
-    assert [L.phm_struct_size(i) for i in range(5)] == [C.sizeof(_lib.Options), C.sizeof(_lib.Info), C.sizeof(_lib.Tree), C.sizeof(_lib.Model), -1]
+    assert L.phm_version() == 300
+    assert [L.phm_struct_size(i) for i in range(6)] == [C.sizeof(_lib.Options), C.sizeof(_lib.Info), C.sizeof(_lib.Tree), C.sizeof(_lib.Model),
+                                                        C.sizeof(_lib.DebugOptions), -1]
+    # the public options struct carries no developer aids and the library reads no environment variable
+    opt_fields = [f[0] for f in _lib.Options._fields_]
+    assert "n_devices" in opt_fields and "devices" in opt_fields
+    assert not {"pruning_form", "phase_timing", "capacity_boost_log2"} & set(opt_fields)
+    for f in os.listdir(os.path.join(ROOT, "phylomap_amd", "csrc")):
+        assert "getenv" not in open(os.path.join(ROOT, "phylomap_amd", "csrc", f)).read(), f
     assert L.phm_status_string(6).decode() == "branch capacity exceeded"
 
 
@@ -259,7 +266,8 @@ def test_shim_type_checks_against_a_mock_of_the_rcpp_surface():
     shim = open(src).read()
     helper = open(os.path.join(root, "shim", "R", "phylomap_hip_options.R")).read()
     integ = open(os.path.join(root, "INTEGRATION.md")).read()
-    for opt in ("phylomap.hip.replicas", "phylomap.hip.reduce", "phylomap.hip.device"):
+    for opt in ("phylomap.hip.replicas", "phylomap.hip.reduce", "phylomap.hip.device", "phylomap.hip.devices", "phylomap.hip.rescale",
+                "phylomap.hip.mapping", "phylomap.hip.cap_tail"):
         assert f'"{opt}"' in shim and opt in helper and opt in integ
     assert 'containsElementNamed("sites")' in shim and "z$sites <- sites" in helper
 
