@@ -9,7 +9,9 @@ OBJDIR  := build/obj
 SRCS    := $(CSRC)/phm_engine.cpp $(CSRC)/phm_drivers.cpp $(CSRC)/phm_expm_api.cpp $(CSRC)/phm_sched.cpp $(CSRC)/phm_qupdate.cpp $(CSRC)/phm_mcmc.hip $(CSRC)/phm_wide.hip $(CSRC)/phm_narrow.hip $(CSRC)/phm_tiles.hip $(CSRC)/phm_wbranch.hip $(CSRC)/phm_wtiles.hip $(CSRC)/phm_exp.hip
 OBJS    := $(patsubst $(CSRC)/%,$(OBJDIR)/%.o,$(SRCS))
 HDRS    := $(wildcard $(CSRC)/*.h) include/phylomap_hip.h
-FLAGS   := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function
+# EXTRA: experiment switches (e.g. make LIB=scratch/libv1.so OBJDIR=build/v1 EXTRA=-DWT_BRANCH_WAVES=8)
+EXTRA   ?=
+FLAGS   := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function $(EXTRA)
 
 all:
 	$(MAKE) -j8 $(LIB)

@@ -38,6 +38,9 @@ constexpr int WT_BLOCK = 256;
 #ifndef WT_BRANCH_BLOCK_SMALL
 #define WT_BRANCH_BLOCK_SMALL 512
 #endif
+#ifndef WT_BRANCH_BLOCK_BIG             // n > 32: waves sharing the workgroup's LDS (rows of B, reduced counters: 55 KB at 61 states). Eight:
+#define WT_BRANCH_BLOCK_BIG 512         // two workgroups = 16 waves per CU, what 110 VGPRs allow (four-wave workgroups: three per CU by LDS, 12.6 -> 8.6 ms on C4)
+#endif
 constexpr int WT_FEW_TILES = 112;       // n <= 16: below this many tiles the pruning pass runs a wave per 16-replica block (latency) instead of per tile (throughput)
 constexpr int WT_BAND_MAX = 2;          // largest half-bandwidth served by the band kernels (tridiagonal: 1; make2sQ hidden rates: 2)
 constexpr int WT_BAND_NMAX = 32;        // ... up to this many states (the vectors of a chain live in registers)

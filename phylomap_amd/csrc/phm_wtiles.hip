@@ -557,15 +557,13 @@ __global__ __launch_bounds__(WT_BLOCK) void wt_root_kernel(WtParams p, int it) {
 }
 
 // child ~ e_ps^T B^(m-1) (.) PL[child]   (Tvmmp :431-436, :651); ks: tips too, against their parity mask (:1384-1397).
-// Two passes over the lane's table row and the child's partial likelihoods, 8 or 16 states per round of loads: the first
-// forms the total, the second walks the running sum (the same products in the same order) and stops once every lane of the
-// wave has its state.  The kernel waits on memory (a lane's row is its own address): keeping the whole probability vector in
-// registers instead (128 of them at 61 states: two waves per SIMD) read every row once but ran 13.7 ms per sweep on C4 at 65 536
-// replicas, three waves 10.9, this form (55 - 130 registers) 6.8; C5: 5.6 -> 4.1 (profiles/r02_probe_few_tiles.log).
+// n <= 32 (wt_down_kernel): two passes over the lane's table row and the child's partial likelihoods, 8 states per round of loads:
+// the first forms the total, the second walks the running sum (the same products in the same order) and stops once every lane of
+// the wave has its state; 55 registers, eight waves per SIMD (C5: 4.1 ms per sweep).  n > 32: wt_down1_kernel below, one pass.
 template <int MT>
 __global__ __launch_bounds__(WT_BLOCK) void wt_down_kernel(WtParams p, int it, int begin, int end) {
   constexpr int NP = 16 * MT;
-  constexpr int CH = MT == 4 ? 32 : MT == 3 ? 16 : 8;   // states per round of loads (measured: 61 states 8.8 / 7.5 / 6.8 ms with 8 / 16 / 32, 20 states 4.1 / 4.4 with 8 / 16)
+  constexpr int CH = 8;                                // states per round of loads (20 states: 4.1 / 4.4 ms per sweep with 8 / 16)
   const int lane = threadIdx.x & 63;
   const int item = blockIdx.x * (WT_BLOCK / 64) + (threadIdx.x >> 6);
   const int n_lvl = end - begin;
@@ -637,6 +635,93 @@ __global__ __launch_bounds__(WT_BLOCK) void wt_down_kernel(WtParams p, int it, i
   if (err) atomicOr(p.err, err);
 }
 
+// The same draw in ONE pass over the child's partial likelihoods and the lane's table row (n > 32, where a two-pass form reads
+// 2 x 31 KB per wave and gathers 2 x 30 sixteen-byte pieces per lane from the row table -- one cache-line look-up per lane and
+// piece: the gathers, not HBM, set its pace).  The running sums cum_c (the sampler's own left-to-right sums: cum_c = cum_{c-1} + p_c
+// from +0) are kept for every state -- states 0 .. 31 in LDS ([state][lane], 16 KB per wave), the rest in registers, so that nothing
+// of the first half occupies registers while the second half's loads are in flight (144 registers: three waves per SIMD, ten per
+// CU by LDS) -- and the state is the number of c <= n - 2 with !(thr <= cum_c): the comparisons of the two-pass walk on the same
+// numbers.  A wave is a workgroup of its own.  C4 at 65 536 replicas: two passes (32 states per round of loads) 6.7 ms per sweep;
+// two passes with the second one confined to the 16-state block the threshold falls into 5.5; one pass with all 122 values in
+// registers (one wave per SIMD) 6.2; this form 4.5 (profiles/r04_probe_c4_variants.log).
+template <int MT>
+__global__ __launch_bounds__(64) void wt_down1_kernel(WtParams p, int it, int begin, int end) {
+  constexpr int NP = 16 * MT;
+  static_assert(MT >= 3, "one-pass node draws: n > 32");
+  extern __shared__ double s_cum[];                    // [32][64]: running sums after states 0 .. 31
+  const int lane = threadIdx.x;
+  const int item = blockIdx.x;
+  const int n_lvl = end - begin;
+  const int n = p.n_states, ldt = p.ldt;
+  const int tile = item / n_lvl;
+  const DownStep ds = p.down[p.down_order[begin + item % n_lvl]];
+  const int b = ds.edge;
+  const double* __restrict__ PLt = p.PL + (size_t)tile * p.n_node * n * 64;
+  uint8_t* __restrict__ nst = p.nstate + (size_t)tile * p.n_node * 64;
+  const uint8_t* __restrict__ tips_t = p.tips_per_replica ? p.tips + (size_t)tile * p.n_tips * 64 : p.tips;
+  const uint32_t rep = (uint32_t)(p.replica_offset + tile * 64 + lane);
+  const int m = p.mcount[((size_t)tile * p.n_edge + b) * 64 + lane];
+  const int ps = nst[ds.parent * 64 + lane];
+  uint32_t err = 0;
+  int cs;
+  if (ds.child >= 0 || p.tip_masks) {
+    int kk = m - 1;
+    if (kk >= p.klong) { err |= DERR_CAPACITY; kk = p.klong - 1; }
+    const double2* __restrict__ src = reinterpret_cast<const double2*>(p.rowL + ((size_t)kk * n + ps) * ldt);
+    uint32_t node_id;
+    const bool internal = ds.child >= 0;
+    const double* __restrict__ PLc = PLt + (size_t)(internal ? ds.child : 0) * n * 64 + lane;
+    int par = 0;
+    if (internal) node_id = (uint32_t)(ds.child + p.n_tips);
+    else { const int tip = ~ds.child; par = (p.tips_per_replica ? tips_t[tip * 64 + lane] : p.tips[tip]) & 1; node_id = (uint32_t)tip; }
+    const double u = stream_u(p.seed_lo, p.seed_hi, rep, (uint32_t)it, ENT_NODE | node_id, 0);
+    // First half (states 0 .. 31): loads, products, running sums -> LDS ([state][lane], 16 KB); second half: the same with the sums
+    // left in registers.  Nothing of the first half stays in registers while the second half's loads are in flight.
+    double cum = 0.0;
+    {
+      double2 r[16];
+      double pl[32];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) r[j] = src[j];                                   // n > 32: all inside the row
+#pragma unroll
+      for (int j = 0; j < 32; ++j) pl[j] = internal ? PLc[(size_t)j * 64] : (((j & 1) == par) ? 1.0 : 0.0);
+#pragma unroll
+      for (int j = 0; j < 32; ++j) {
+        cum += ((j & 1) ? r[j >> 1].y : r[j >> 1].x) * pl[j];
+        s_cum[j * 64 + lane] = cum;
+      }
+    }
+    double hi[NP - 32];
+    {
+      double2 r[(NP - 32) / 2];
+#pragma unroll
+      for (int j = 0; j < (NP - 32) / 2; ++j) { r[j].x = 0.0; r[j].y = 0.0; if (32 + 2 * j < n) r[j] = src[16 + j]; }      // rows are padded to ldt (even) with zeros
+#pragma unroll
+      for (int j = 0; j < NP - 32; ++j) { const int c = 32 + j; hi[j] = internal ? ((c < n) ? PLc[(size_t)c * 64] : 0.0) : (((c & 1) == par) ? 1.0 : 0.0); }
+#pragma unroll
+      for (int j = 0; j < NP - 32; ++j) {
+        const double pr = (32 + j < n) ? ((j & 1) ? r[j >> 1].y : r[j >> 1].x) * hi[j] : 0.0;
+        cum += pr;
+        hi[j] = cum;
+      }
+    }
+    const double total = cum;
+    if (!(total > 0.0) || isinf(total)) err |= DERR_ZERO_PROB;
+    const double thr = u * total;
+    cs = 0;
+#pragma unroll
+    for (int j = 0; j < NP - 32; ++j) cs += (32 + j < n - 1 && !(thr <= hi[j])) ? 1 : 0;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) cs += !(thr <= s_cum[j * 64 + lane]) ? 1 : 0;     // n > 32: states 0 .. 31 are all <= n - 2
+    if (internal) nst[ds.child * 64 + lane] = (uint8_t)cs;                                   // :655
+  } else {
+    const int tip = ~ds.child;
+    cs = p.tips_per_replica ? tips_t[tip * 64 + lane] : p.tips[tip];            // :612
+  }
+  p.estate[((size_t)tile * p.n_edge + b) * 64 + lane] = (uint16_t)(ps | (cs << 8));   // updatenodestates :460-475
+  if (err) atomicOr(p.err, err);
+}
+
 // Dynamic LDS of the branch kernel, in this order (offsets in bytes, every piece 16-byte aligned):
 //   b2   : rows of B [n][ldt] (SMALL, or B2L), or its band [n][2 BAND + 1]
 //   dw   : SMALL: dwell sums of the workgroup [n][64] u64
@@ -671,8 +756,8 @@ __host__ __device__ inline BranchLds branch_lds(int n, int ldt, int n_slots, boo
 // non-zeros of a row of the sparse matrix): a forward draw multiplies and adds the 2 BAND + 1 in-band terms only -- every
 // other term of the probability vector is an exact +0, so total, running sums and the state drawn keep their bits.
 template <bool KS, bool SMALL, bool B2L, int BAND>
-__global__ __launch_bounds__(SMALL ? WT_BRANCH_BLOCK_SMALL : WT_BLOCK) void wt_branch_kernel(WtParams p, int it) {
-  constexpr int BLOCK = SMALL ? WT_BRANCH_BLOCK_SMALL : WT_BLOCK;
+__global__ __launch_bounds__(SMALL ? WT_BRANCH_BLOCK_SMALL : WT_BRANCH_BLOCK_BIG) void wt_branch_kernel(WtParams p, int it) {
+  constexpr int BLOCK = SMALL ? WT_BRANCH_BLOCK_SMALL : WT_BRANCH_BLOCK_BIG;
   extern __shared__ __align__(16) unsigned char s_dyn[];            // SMALL: [n][ldt] rows of B, then [n][64] dwell sums (u64)
   __shared__ double s_scale[64];
   __shared__ __align__(16) double s_ltab[2 * PHM_LOGTAB_N];        // (1/c_j, log c_j) of the exponential variates (neglog_u32)
@@ -859,6 +944,7 @@ __global__ __launch_bounds__(SMALL ? WT_BRANCH_BLOCK_SMALL : WT_BLOCK) void wt_b
     int second_s = 0;
     double cur_len = IN(0);
     double dnext = (m > 1) ? IN(1) : 0.0;
+    double dnext2 = (m > 2) ? IN(2) : 0.0;            // old segments two steps ahead: a step is two dependent table reads long, an HBM read longer
     for (int i0 = 1; i0 < mmax; i0 += 4) {
       uint32_t wd[4] = {0u, 0u, 0u, 0u};
       if (i0 < mmax - 1)                       // some lane still draws in this group (draws exist for i < m - 1)
@@ -869,7 +955,8 @@ __global__ __launch_bounds__(SMALL ? WT_BRANCH_BLOCK_SMALL : WT_BLOCK) void wt_b
         if (i < m) {
           const int si = (i == m - 1) ? cs : draw_state_w(i, cur_s, wd[qq]);
           const double di = dnext;
-          if (i + 1 < m) dnext = IN(i + 1);
+          dnext = dnext2;
+          if (i + 2 < m) dnext2 = IN(i + 2);
           if (KS) count(cur_s, si);
           if (si == cur_s) cur_len = cur_len + di;                           // shortener :54
           else {
@@ -1129,17 +1216,21 @@ hipError_t launch_wtiles_sweep(const WtParams& p, const WtBand& band, const std:
     const int n = down_off[l + 1] - down_off[l];
     if (n <= 0) continue;
     const dim3 g = blocks((int64_t)n * p.n_tiles);
+    if (mt >= 3) {      // n > 32: one pass, a wave per workgroup
+      const dim3 g1((unsigned)((int64_t)n * p.n_tiles));
+      if (mt == 3) hipLaunchKernelGGL(wt_down1_kernel<3>, g1, dim3(64), 32 * 64 * sizeof(double), stream, p, it, down_off[l], down_off[l + 1]);
+      else hipLaunchKernelGGL(wt_down1_kernel<4>, g1, dim3(64), 32 * 64 * sizeof(double), stream, p, it, down_off[l], down_off[l + 1]);
+      continue;
+    }
     if (mt == 1) hipLaunchKernelGGL(wt_down_kernel<1>, g, dim3(WT_BLOCK), 0, stream, p, it, down_off[l], down_off[l + 1]);
-    else if (mt == 2) hipLaunchKernelGGL(wt_down_kernel<2>, g, dim3(WT_BLOCK), 0, stream, p, it, down_off[l], down_off[l + 1]);
-    else if (mt == 3) hipLaunchKernelGGL(wt_down_kernel<3>, g, dim3(WT_BLOCK), 0, stream, p, it, down_off[l], down_off[l + 1]);
-    else hipLaunchKernelGGL(wt_down_kernel<4>, g, dim3(WT_BLOCK), 0, stream, p, it, down_off[l], down_off[l + 1]);
+    else hipLaunchKernelGGL(wt_down_kernel<2>, g, dim3(WT_BLOCK), 0, stream, p, it, down_off[l], down_off[l + 1]);
   }
   mark(2);
   {
     const bool small = p.n_states <= 32;
     const bool red = p.cnt_tile != nullptr;
     // n <= 32: eight waves share the workgroup's LDS tables (B rows, dwell and count accumulators: 26 KB at 20 states)
-    const int wpb = small ? WT_BRANCH_BLOCK_SMALL / 64 : WPB;
+    const int wpb = small ? WT_BRANCH_BLOCK_SMALL / 64 : WT_BRANCH_BLOCK_BIG / 64;
     const dim3 g((unsigned)(((int64_t)p.n_groups + wpb - 1) / wpb * p.n_tiles));
     const bool b2l = !small && p.group >= 4;           // n > 32: B rows in LDS once a wave walks four or more branches
     const BranchLds L = branch_lds(p.n_states, p.ldt, small ? p.n_slots : 0, small, b2l, small ? p.band_draw : 0, red, p.ks != 0);
@@ -1153,7 +1244,7 @@ hipError_t launch_wtiles_sweep(const WtParams& p, const WtBand& band, const std:
       if (ae != hipSuccess) return ae;
     }
     const int band = small ? p.band_draw : 0;
-#define PHM_BRANCH(KSV, SM, BL, BD) hipLaunchKernelGGL((wt_branch_kernel<KSV, SM, BL, BD>), g, dim3(SM ? WT_BRANCH_BLOCK_SMALL : WT_BLOCK), lds_now, stream, p, it)
+#define PHM_BRANCH(KSV, SM, BL, BD) hipLaunchKernelGGL((wt_branch_kernel<KSV, SM, BL, BD>), g, dim3(SM ? WT_BRANCH_BLOCK_SMALL : WT_BRANCH_BLOCK_BIG), lds_now, stream, p, it)
     if (p.ks) {
       if (small && band == 1) PHM_BRANCH(true, true, true, 1);
       else if (small && band == 2) PHM_BRANCH(true, true, true, 2);

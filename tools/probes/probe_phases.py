@@ -1,12 +1,14 @@
-"""ms per sweep and per phase (pruning, node draws, branch kernel, reductions) of a (tile, item) mapping: python tools/probe_phases.py cfg S [iters [sparse_chains]]"""
+"""ms per sweep and per phase (pruning, node draws, branch kernel, reductions) of a (tile, item) mapping:
+python tools/probes/probe_phases.py cfg S [iters [sparse_chains [variant]]]   (variant: bigtree | bf | ks; PHM_LIB selects another build of the library)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from phylomap_amd import _lib, synth
 cfg = int(sys.argv[1]); S = int(sys.argv[2]); N = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 sparse = int(sys.argv[4]) if len(sys.argv) > 4 else 0      # phm_options.sparse_chains: 0 auto, 1 band kernels required, 2 dense
+var = {"bigtree": _lib.PHM_MCMC_BIGTREE, "bf": _lib.PHM_MCMC_BF, "ks": _lib.PHM_MCMC_KS}[sys.argv[5] if len(sys.argv) > 5 else "bigtree"]
 z, Q, pid, Om = synth.config_problem(cfg)
 E = z["edge"].shape[0]
-eng = _lib.Engine(z, Q, pid, Om, N + 10, variant=_lib.PHM_MCMC_BIGTREE, seed=1, n_replicas=S, reduce=True, mapping="tiles", phase_timing=True, sparse_chains=sparse)
+eng = _lib.Engine(z, Q, pid, Om, N + 10, variant=var, seed=1, n_replicas=S, reduce=True, mapping="tiles", phase_timing=True, sparse_chains=sparse)
 eng.run(10); eng.sync()
 i0 = eng.info()
 eng.run(N); eng.sync()
