@@ -672,99 +672,151 @@ __global__ __launch_bounds__(EXP_BLOCK) void exp_tiles_node_kernel(ExpTilesParam
   if (err && it < p.N) atomicOr(p.err, err);
 }
 
-// newunifSample(a, e, t_b, P_b[a,e]) :93-208 for the 64 samples of a tile on one branch; persistent waves over (tile, branch)
-__global__ __launch_bounds__(EXP_BLOCK) void exp_tiles_branch_kernel(ExpTilesParams p) {
+// newunifSample(a, e, t_b, P_b[a,e]) :93-208 for the 64 samples of a tile; persistent waves over (tile, group of `group` consecutive
+// branches in pre-order).
+//  * Jump times (`t * runif(k)` sorted ascending, :147-152): up to EXP_KL per lane sit in LDS ([slot][lane], conflict-free); a lane
+//    with more jumps on a branch uses its wave's scratch rows in global memory (the round-2/3 form for every lane: the insertion
+//    sort was a chain of dependent global reads -- the kernel waited 0.8 of its time and moved 4x its algorithmic bytes).
+//  * NS > 0 (2..4 states, compile-time): the statistics of the group's branches collect in registers (n dwell sums in 64-bit fixed
+//    point, n(n-1) counters) and reach the per-sample accumulators once per group; NS = 0 (runtime n up to 64): one atomic per segment.
+constexpr int EXP_KL = 12;
+
+template <int NS>
+__global__ __launch_bounds__(EXP_BLOCK) void exp_tiles_branch_kernel(ExpTilesParams p, int group) {
+  __shared__ double s_tm[EXP_BLOCK / 64][EXP_KL][64];
   const int lane = threadIdx.x & 63;
-  const int wslot = blockIdx.x * (EXP_BLOCK / 64) + (threadIdx.x >> 6);
-  const int n = p.n_states;
-  const int64_t items = (int64_t)p.n_edge * p.n_tiles;
+  const int wv = threadIdx.x >> 6;
+  const int wslot = blockIdx.x * (EXP_BLOCK / 64) + wv;
+  const int n = NS > 0 ? NS : p.n_states;
+  const int n_groups = (p.n_edge + group - 1) / group;
+  const int64_t items = (int64_t)n_groups * p.n_tiles;
   const size_t npad = (size_t)p.n_tiles * 64;
-  double* __restrict__ tms = p.times + (size_t)wslot * UNIF_CAP * 64;
+  double* __restrict__ gtm = p.times + (size_t)wslot * UNIF_CAP * 64;
+  constexpr int NA = NS > 0 ? NS : 1, NC = NS > 0 ? NS * (NS - 1) : 1;
   uint32_t err = 0;
   for (int64_t item = wslot; item < items; item += (int64_t)gridDim.x * (EXP_BLOCK / 64)) {
     const int tile = (int)(item % p.n_tiles);
-    const DownStep ds = p.down[item / p.n_tiles];
-    const int b = ds.edge;
+    const int q0 = (int)(item / p.n_tiles) * group, q1 = min(q0 + group, p.n_edge);
     const int it = tile * 64 + lane;
     const bool valid = it < p.N;
     const uint8_t* __restrict__ nst = p.nstate + (size_t)tile * p.n_node * 64;
-    const int a = nst[ds.parent * 64 + lane];
-    const int e = ds.child >= 0 ? (int)nst[ds.child * 64 + lane] : (int)p.tips[~ds.child];
-    const double* Pb = p.P + (size_t)b * n * n;
+    unsigned long long acc_dw[NA];
+    uint32_t acc_ct[NC];
+#pragma unroll
+    for (int c = 0; c < NA; ++c) acc_dw[c] = 0ull;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc_ct[c] = 0u;
     auto stat_add = [&](int col, double v) {           // dwell: fixed point, exact in any order
-      if (valid) atomicAdd(p.dwfx + (size_t)col * npad + it, (unsigned long long)__double2ll_rn(v * p.fx_scale));
+      const unsigned long long fx = (unsigned long long)__double2ll_rn(v * p.fx_scale);
+      if (NS > 0) {
+#pragma unroll
+        for (int c = 0; c < NA; ++c) acc_dw[c] += (col == c) ? fx : 0ull;
+      } else if (valid) atomicAdd(p.dwfx + (size_t)col * npad + it, fx);
     };
-    auto count = [&](int from, int to) { if (valid) atomicAdd(p.cnt + (size_t)(from * (n - 1) + (to > from ? to - 1 : to)) * npad + it, 1u); };
-
-    const double tb = p.edge_length[b];
-    const double transProb = Pb[(size_t)a * n + e];
-    Stream sr;
-    sr.open(ENT_BUNIF | (uint32_t)b, (uint32_t)(it + p.it0), p.replica, p.seed_lo, p.seed_hi);
-    uint32_t dr = 0;
-    const double rU = sr.draw(dr++);                                            // :103
-    const double lam = p.poisson_rate * tb;
-    double pk = phm_exp(-lam);
-    double cum = 0.0;
-    if (a == e) cum = pk / transProb;                                           // :107
-    bool notExceed = !(cum > rU);
-    int nj = 0;
-    bool capped = false;
-    while (notExceed) {
-      nj++;
-      if (nj > UNIF_CAP) { capped = true; break; }                              // :120
-      pk = pk * lam / (double)nj;
-      const double nextProb = pk * p.colpow[((size_t)nj * n + e) * n + a] / transProb;   // :127-128
-      cum += nextProb;
-      if (cum > rU) notExceed = false;
-    }
-    if (capped) { if (valid) err |= DERR_UNIF_CAP; continue; }
-    if (nj == 0 || (nj == 1 && a == e)) {                                       // :138
-      stat_add(a, tb - 0.0);
-    } else if (nj == 1) {                                                       // :144
-      const double tj = tb * sr.draw(dr++);
-      stat_add(a, tj - 0.0);
-      stat_add(e, tb - tj);
-      count(a, e);
-    } else {
-      for (int i = 0; i < nj; ++i) {                                            // :151-152 jump times, ascending
-        const double v = tb * sr.draw(dr++);
-        int j = i - 1;
-        while (j >= 0) {
-          const double tj = tms[j * 64 + lane];
-          if (!(tj > v)) break;
-          tms[(j + 1) * 64 + lane] = tj;
-          --j;
-        }
-        tms[(j + 1) * 64 + lane] = v;
+    auto count = [&](int from, int to) {
+      const int col = from * (n - 1) + (to > from ? to - 1 : to);
+      if (NS > 0) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc_ct[c] += (col == c) ? 1u : 0u;
+      } else if (valid) atomicAdd(p.cnt + (size_t)col * npad + it, 1u);
+    };
+    // end states of the first branch of the group; those of the next branch are requested while the current one is sampled
+    DownStep ds = p.down[q0];
+    int a = nst[ds.parent * 64 + lane];
+    int e = ds.child >= 0 ? (int)nst[ds.child * 64 + lane] : (int)p.tips[~ds.child];
+    for (int q = q0; q < q1; ++q) {
+      const int b = ds.edge;
+      const int a_cur = a, e_cur = e;
+      if (q + 1 < q1) {
+        ds = p.down[q + 1];
+        a = nst[ds.parent * 64 + lane];
+        e = ds.child >= 0 ? (int)nst[ds.child * 64 + lane] : (int)p.tips[~ds.child];
       }
-      int prev = a, sprev = a;
-      double tprev = 0.0;
-      for (int i = 1; i <= nj; ++i) {
-        int di = e;
-        if (i < nj) {                                                           // sampleOnce :81-90, :158-160
-          const double* beta = p.colpow + ((size_t)(nj - i) * n + e) * n;
-          const double* row = p.B2 + (size_t)prev * n;
-          double total = row[0] * beta[0];
-          for (int c = 1; c < n; ++c) total += row[c] * beta[c];
-          const double u = sr.draw(dr++);
-          double cw = 0.0;
-          int pick = n;
-          for (int c = 0; c < n; ++c) {
-            cw += (row[c] * beta[c]) / total;
-            if (pick == n && u < cw) pick = c;
+      const double* Pb = p.P + (size_t)b * n * n;
+      const double tb = p.edge_length[b];
+      const double transProb = Pb[(size_t)a_cur * n + e_cur];
+      Stream sr;
+      sr.open(ENT_BUNIF | (uint32_t)b, (uint32_t)(it + p.it0), p.replica, p.seed_lo, p.seed_hi);
+      uint32_t dr = 0;
+      const double rU = sr.draw(dr++);                                            // :103
+      const double lam = p.poisson_rate * tb;
+      double pk = phm_exp(-lam);
+      double cum = 0.0;
+      if (a_cur == e_cur) cum = pk / transProb;                                   // :107
+      bool notExceed = !(cum > rU);
+      int nj = 0;
+      bool capped = false;
+      const double* __restrict__ cp = p.colpow + (size_t)e_cur * n + a_cur;       // (B^k e_e)[a] at cp[k n n]
+      double cnext = cp[(size_t)n * n];
+      while (notExceed) {
+        nj++;
+        if (nj > UNIF_CAP) { capped = true; break; }                              // :120
+        const double ck = cnext;
+        if (nj < UNIF_CAP) cnext = cp[(size_t)(nj + 1) * n * n];                   // the next term's table entry is on its way
+        pk = pk * lam / (double)nj;
+        const double nextProb = pk * ck / transProb;                              // :127-128
+        cum += nextProb;
+        if (cum > rU) notExceed = false;
+      }
+      if (capped) { if (valid) err |= DERR_UNIF_CAP; continue; }
+      if (nj == 0 || (nj == 1 && a_cur == e_cur)) {                               // :138
+        stat_add(a_cur, tb - 0.0);
+      } else if (nj == 1) {                                                       // :144
+        const double tj = tb * sr.draw(dr++);
+        stat_add(a_cur, tj - 0.0);
+        stat_add(e_cur, tb - tj);
+        count(a_cur, e_cur);
+      } else {
+        const bool in_lds = nj <= EXP_KL;
+        double* __restrict__ ltm = &s_tm[wv][0][lane];
+        auto tm_get = [&](int k) -> double { double v; if (in_lds) v = ltm[k * 64]; else v = gtm[k * 64 + lane]; return v; };
+        auto tm_put = [&](int k, double v) { if (in_lds) ltm[k * 64] = v; else gtm[k * 64 + lane] = v; };
+        for (int i = 0; i < nj; ++i) {                                            // :151-152 jump times, ascending
+          const double v = tb * sr.draw(dr++);
+          int j = i - 1;
+          while (j >= 0) {
+            const double tj = tm_get(j);
+            if (!(tj > v)) break;
+            tm_put(j + 1, tj);
+            --j;
           }
-          if (pick == n) { if (valid) err |= DERR_SAMPLEONCE; pick = n - 1; }
-          di = pick;
+          tm_put(j + 1, v);
         }
-        if (prev != di) {                                                       // :168-173 drop virtual jumps
-          const double ti = tms[(i - 1) * 64 + lane];
-          stat_add(sprev, ti - tprev);
-          count(sprev, di);
-          tprev = ti; sprev = di;
+        int prev = a_cur, sprev = a_cur;
+        double tprev = 0.0;
+        for (int i = 1; i <= nj; ++i) {
+          int di = e_cur;
+          if (i < nj) {                                                           // sampleOnce :81-90, :158-160
+            const double* beta = p.colpow + ((size_t)(nj - i) * n + e_cur) * n;
+            const double* row = p.B2 + (size_t)prev * n;
+            double total = row[0] * beta[0];
+            for (int c = 1; c < n; ++c) total += row[c] * beta[c];
+            const double u = sr.draw(dr++);
+            double cw = 0.0;
+            int pick = n;
+            for (int c = 0; c < n; ++c) {
+              cw += (row[c] * beta[c]) / total;
+              if (pick == n && u < cw) pick = c;
+            }
+            if (pick == n) { if (valid) err |= DERR_SAMPLEONCE; pick = n - 1; }
+            di = pick;
+          }
+          if (prev != di) {                                                       // :168-173 drop virtual jumps
+            const double ti = tm_get(i - 1);
+            stat_add(sprev, ti - tprev);
+            count(sprev, di);
+            tprev = ti; sprev = di;
+          }
+          prev = di;
         }
-        prev = di;
+        stat_add(sprev, tb - tprev);
       }
-      stat_add(sprev, tb - tprev);
+    }
+    if (NS > 0 && valid) {
+#pragma unroll
+      for (int c = 0; c < NA; ++c) if (acc_dw[c]) atomicAdd(p.dwfx + (size_t)c * npad + it, acc_dw[c]);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) if (acc_ct[c]) atomicAdd(p.cnt + (size_t)c * npad + it, acc_ct[c]);
     }
   }
   if (err) atomicOr(p.err, err);
@@ -789,7 +841,12 @@ hipError_t launch_exp_tiles(const ExpTilesParams& p, const std::vector<int32_t>&
     const int cnt = level_off[l + 1] - level_off[l];
     if (cnt > 0) hipLaunchKernelGGL(exp_tiles_node_kernel, dim3((unsigned)(((int64_t)cnt * p.n_tiles + W - 1) / W)), dim3(EXP_BLOCK), 0, stream, p, level_off[l], level_off[l + 1]);
   }
-  hipLaunchKernelGGL(exp_tiles_branch_kernel, dim3(branch_blocks), dim3(EXP_BLOCK), 0, stream, p);
+  // branches per wave-item: as many as still leave every SIMD a few waves (an R call with N = 1 000 samples has 16 tiles)
+  const int group = (int)std::max<int64_t>(1, std::min<int64_t>(16, (int64_t)p.n_edge * p.n_tiles / 8192));
+  if (p.n_states == 2) hipLaunchKernelGGL(exp_tiles_branch_kernel<2>, dim3(branch_blocks), dim3(EXP_BLOCK), 0, stream, p, group);
+  else if (p.n_states == 3) hipLaunchKernelGGL(exp_tiles_branch_kernel<3>, dim3(branch_blocks), dim3(EXP_BLOCK), 0, stream, p, group);
+  else if (p.n_states == 4) hipLaunchKernelGGL(exp_tiles_branch_kernel<4>, dim3(branch_blocks), dim3(EXP_BLOCK), 0, stream, p, group);
+  else hipLaunchKernelGGL(exp_tiles_branch_kernel<0>, dim3(branch_blocks), dim3(EXP_BLOCK), 0, stream, p, group);
   const int64_t cells = (int64_t)(p.n_states + p.n_states * (p.n_states - 1)) * p.N;
   hipLaunchKernelGGL(exp_tiles_finish_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, stream, p);
   return hipGetLastError();
