@@ -526,6 +526,13 @@ int32_t narrow_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
   return PHM_OK;
 }
 
+// copies of a tile's transition counters (phm_tiles.h): enough that 512 counter sets exist however few the tiles
+inline int tiles_cnt_copies(int tiles) {
+  int c = 1;
+  while (c < 64 && c * tiles < 512) c *= 2;
+  return c;
+}
+
 // Engine state of the wave-per-(tile, branch) mapping (phm_tiles.hip).
 template <int NS>
 void fill_tile_params(phm_engine* e, phm::TileParams<NS>& p, const phm_options& o) {
@@ -546,11 +553,14 @@ void fill_tile_params(phm_engine* e, phm::TileParams<NS>& p, const phm_options& 
   p.up = e->d_up.as<phm::UpStep>(); p.down = e->d_down.as<phm::DownStep>();
   p.up_order = e->d_nw_up_order.as<int32_t>(); p.down_order = e->d_nw_down_order.as<int32_t>();
   p.branch_order = e->d_nw_border.as<int32_t>(); p.slot = e->d_tl_slot.as<int32_t>();
+  p.cl_nodes = e->d_nw_cl_nodes.as<phm::ClusterNode>();      // NULL unless tiles_setup chose the subtree clusters
+  p.cl_lvl_ptr = e->d_nw_cl_lvl_ptr.as<int32_t>(); p.cl_lvl_off = e->d_nw_cl_lvl_off.as<int32_t>();
   p.colL = e->d_nw_colL.as<double>(); p.rowL = e->d_nw_rowL.as<double>(); p.maskL = e->d_nw_maskL.as<double>();
   p.tips = e->d_tips.as<uint8_t>(); p.mcount = e->d_mcount.as<uint16_t>();
   p.dw[0] = e->d_dw0.as<double>(); p.dw[1] = e->d_dw1.as<double>();
   p.estate = e->d_tl_estate.as<uint8_t>(); p.PL = e->d_PL.as<double>(); p.nstate = e->d_nstate.as<uint8_t>();
   p.pdw = e->d_tl_pdw.as<double>(); p.pchunk = e->d_tl_pchunk.as<double>(); p.cnt = e->d_tl_cnt.as<uint32_t>();
+  p.cnt_copies = tiles_cnt_copies(e->tiles);
   p.pseg = e->d_tl_pseg.as<uint32_t>(); p.segprev = e->d_tl_segprev.as<uint32_t>();
   p.stats = e->d_stats.as<double>(); p.err = e->d_err.as<uint32_t>(); p.segcnt = e->d_seg.as<unsigned long long>();
 }
@@ -623,7 +633,7 @@ int32_t tiles_setup(phm_engine* e, const phm_tree* x, const phm_model* model, co
   HIPCHK(e->d_nstate.alloc((size_t)tiles * Nn * 64));
   HIPCHK(e->d_tl_pdw.alloc(pdw_bytes));
   HIPCHK(e->d_tl_pchunk.alloc(sizeof(double) * (size_t)tiles * n_chunks * n * 64));
-  HIPCHK(e->d_tl_cnt.alloc(sizeof(uint32_t) * (size_t)tiles * n * n * 64));
+  HIPCHK(e->d_tl_cnt.alloc(sizeof(uint32_t) * (size_t)tiles * tiles_cnt_copies(tiles) * n * n * 64));
   HIPCHK(e->d_tl_pseg.alloc(sizeof(uint32_t) * (size_t)tiles * n_chunks * 64)); HIPCHK(e->d_tl_segprev.alloc(sizeof(uint32_t) * tiles));
   HIPCHK(e->d_stats.alloc(stats_bytes));
   HIPCHK(e->d_err.alloc(sizeof(uint32_t))); HIPCHK(e->d_seg.alloc(sizeof(unsigned long long)));
@@ -652,6 +662,21 @@ int32_t tiles_setup(phm_engine* e, const phm_tree* x, const phm_model* model, co
     std::vector<uint32_t> segprev(tiles);
     for (int t = 0; t < tiles; ++t) segprev[t] = (uint32_t)((int64_t)x->map_off[E] * std::min(64, e->S - t * 64));
     HIPCHK(hipMemcpy(e->d_tl_segprev.p, segprev.data(), e->d_tl_segprev.bytes, hipMemcpyHostToDevice));
+  }
+  // few tiles (the sites of an alignment): the two tree passes over clusters cut by height, one launch per tier, instead of one per
+  // level (phm_tiles.h); phm_debug_options.level_groups: 1 = never, 2 = always, 3 = always, clusters cut by subtree size
+  e->nw_tier_off.clear();
+  if (e->dbg.level_groups >= 2 || (e->dbg.level_groups == 0 && (int64_t)tiles * Nn <= phm::TILES_CL_MAX_WORK)) {
+    phm::ClusterPlan plan;
+    if (e->dbg.level_groups == 3) phm::build_cluster_plan(s, phm::TILES_CL_NODES, plan);      // (measured against: subtrees by size)
+    else phm::build_band_plan(s, TILES_CL_BAND, plan);
+    e->nw_tier_off = plan.tier_off;
+    HIPCHK(e->d_nw_cl_nodes.alloc(sizeof(phm::ClusterNode) * plan.nodes.size()));
+    HIPCHK(e->d_nw_cl_lvl_ptr.alloc(sizeof(int32_t) * plan.lvl_ptr.size()));
+    HIPCHK(e->d_nw_cl_lvl_off.alloc(sizeof(int32_t) * plan.lvl_off.size()));
+    HIPCHK(hipMemcpy(e->d_nw_cl_nodes.p, plan.nodes.data(), e->d_nw_cl_nodes.bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_nw_cl_lvl_ptr.p, plan.lvl_ptr.data(), e->d_nw_cl_lvl_ptr.bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_nw_cl_lvl_off.p, plan.lvl_off.data(), e->d_nw_cl_lvl_off.bytes, hipMemcpyHostToDevice));
   }
   if (n == 2) fill_tile_params<2>(e, e->t2, o);
   if (n == 3) fill_tile_params<3>(e, e->t3, o);
@@ -1258,11 +1283,13 @@ int32_t phm_engine_run(phm_engine* e, int32_t n_iters, void* hip_stream) {
     for (int i = 0; i < n_iters && le == hipSuccess; ++i) {
       const int it = e->iters_done + i;
       hipEvent_t* pev = e->phase_timing ? &e->phase_ev[5 * (size_t)i] : nullptr;
-      if (e->n == 2) le = phm::launch_tiles_sweep<2>(e->t2, e->nw_up_off, e->nw_down_off, it, stream, pev);
-      if (e->n == 3) le = phm::launch_tiles_sweep<3>(e->t3, e->nw_up_off, e->nw_down_off, it, stream, pev);
-      if (e->n == 4) le = phm::launch_tiles_sweep<4>(e->t4, e->nw_up_off, e->nw_down_off, it, stream, pev);
+      if (e->n == 2) le = phm::launch_tiles_sweep<2>(e->t2, e->nw_up_off, e->nw_down_off, e->nw_tier_off, it, stream, pev);
+      if (e->n == 3) le = phm::launch_tiles_sweep<3>(e->t3, e->nw_up_off, e->nw_down_off, e->nw_tier_off, it, stream, pev);
+      if (e->n == 4) le = phm::launch_tiles_sweep<4>(e->t4, e->nw_up_off, e->nw_down_off, e->nw_tier_off, it, stream, pev);
       if (e->wide) le = phm::launch_wtiles_sweep(e->pwt, e->wt_band, e->nw_up_off, e->nw_down_off, it, stream, pev);
-      launches += (int)(e->nw_up_off.size() + e->nw_down_off.size()) + 2;
+      const bool clusters = !e->wide && !e->nw_tier_off.empty();
+      launches += clusters ? 2 * ((int)e->nw_tier_off.size() - 1) + 3      // a launch per tier and pass, branch kernel, two reductions
+                           : (int)(e->nw_up_off.size() + e->nw_down_off.size()) + 2;
     }
     HIPCHK(le);
   }

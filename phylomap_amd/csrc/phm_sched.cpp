@@ -275,4 +275,67 @@ void build_cluster_plan(const Schedule& s, int32_t max_nodes, ClusterPlan& plan)
   }
 }
 
+void build_band_plan(const Schedule& s, int32_t band, ClusterPlan& plan) {
+  const int Nn = s.n_node;
+  plan = ClusterPlan();
+  if (band < 1) band = 1;
+  std::vector<int32_t> height(Nn, 0), parent(Nn, -1), step_of(Nn, -1);
+  int max_h = 0;
+  for (int k = 0; k < Nn; ++k) {
+    const UpStep& u = s.up[k];
+    step_of[u.parent] = k;
+    int h = 0;
+    for (int c = 0; c < 2; ++c)
+      if (u.child[c] >= 0) { h = std::max(h, height[u.child[c]] + 1); parent[u.child[c]] = u.parent; }
+    height[u.parent] = h;
+    max_h = std::max(max_h, h);
+  }
+  const int n_tiers = max_h / band + 1;
+  // parents before children: a node joins its parent's cluster when both lie in the same band, else it starts a cluster
+  std::vector<int32_t> cluster_of(Nn, -1);
+  std::vector<std::vector<int32_t>> members;
+  std::vector<int32_t> tier_of_cluster;
+  for (int k = Nn - 1; k >= 0; --k) {
+    const int v = s.up[k].parent, pv = parent[v];
+    if (pv >= 0 && height[pv] / band == height[v] / band) cluster_of[v] = cluster_of[pv];
+    else { cluster_of[v] = (int)members.size(); members.emplace_back(); tier_of_cluster.push_back(height[v] / band); }
+    members[cluster_of[v]].push_back(v);
+  }
+  // clusters tier by tier, big ones first inside a tier
+  std::vector<int32_t> order(members.size());
+  for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+    if (tier_of_cluster[a] != tier_of_cluster[b]) return tier_of_cluster[a] < tier_of_cluster[b];
+    return members[a].size() > members[b].size();
+  });
+  std::vector<int32_t> new_id(members.size());
+  for (size_t i = 0; i < order.size(); ++i) new_id[order[i]] = (int)i;
+  plan.tier_off.assign(n_tiers + 1, 0);
+  for (size_t i = 0; i < order.size(); ++i) plan.tier_off[tier_of_cluster[order[i]] + 1]++;
+  for (int t = 0; t < n_tiers; ++t) plan.tier_off[t + 1] += plan.tier_off[t];
+  std::vector<int32_t> pos(Nn, -1);
+  plan.item_off.push_back(0);
+  plan.lvl_ptr.push_back(0);
+  for (size_t ci = 0; ci < order.size(); ++ci) {
+    std::vector<int32_t>& m = members[order[ci]];
+    std::stable_sort(m.begin(), m.end(), [&](int a, int b) { return height[a] < height[b]; });
+    const int base = (int)plan.nodes.size();
+    for (size_t i = 0; i < m.size(); ++i) pos[m[i]] = (int)i;
+    for (size_t i = 0; i < m.size(); ++i) {
+      const UpStep& u = s.up[step_of[m[i]]];
+      ClusterNode nd;
+      nd.parent = u.parent; nd.pad = 0;
+      for (int k = 0; k < 2; ++k) {
+        nd.child[k] = u.child[k]; nd.edge[k] = u.edge[k];
+        nd.slot[k] = (u.child[k] >= 0 && new_id[cluster_of[u.child[k]]] == (int)ci) ? pos[u.child[k]] : -1;
+      }
+      if (i == 0 || height[m[i]] != height[m[i - 1]]) plan.lvl_off.push_back(base + (int)i);
+      plan.nodes.push_back(nd);
+    }
+    plan.lvl_off.push_back(base + (int)m.size());
+    plan.item_off.push_back((int)plan.nodes.size());
+    plan.lvl_ptr.push_back((int)plan.lvl_off.size());
+  }
+}
+
 }  // namespace phm

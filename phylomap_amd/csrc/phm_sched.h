@@ -47,6 +47,10 @@ struct ClusterPlan {
 
 struct Schedule;
 void build_cluster_plan(const Schedule& s, int32_t max_nodes, ClusterPlan& plan);
+// The same structure cut by HEIGHT: tier k holds the nodes of heights [k band, (k + 1) band), a cluster is a maximal subtree inside
+// its tier (at most 2^band - 1 nodes).  The levels walked one after the other over all tiers then number exactly the height of the
+// tree (subtree clusters by size walk up to the height of a cluster per tier); the last tier is one cluster and holds the root.
+void build_band_plan(const Schedule& s, int32_t band, ClusterPlan& plan);
 
 struct Schedule {
   int32_t n_tips = 0, n_node = 0, n_edge = 0;

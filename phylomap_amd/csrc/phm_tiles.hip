@@ -26,21 +26,16 @@ __device__ __forceinline__ void child_vec(const TileParams<NS>& p, const double*
   }
 }
 
+// PL[parent] = (B^(m1-1) PL[c1]) (.) (B^(m0-1) PL[c0]) (/ sum)  for the 64 replicas of a tile   (:503-529)
 template <int NS>
-__global__ __launch_bounds__(TILES_BLOCK) void tiles_up_kernel(TileParams<NS> p, int begin, int end) {
-  const int lane = threadIdx.x & 63;
-  const int item = blockIdx.x * (TILES_BLOCK / 64) + (threadIdx.x >> 6);
-  const int n_lvl = end - begin;
-  if (item >= n_lvl * p.n_tiles) return;
-  const int tile = item / n_lvl;
-  const UpStep st = p.up[p.up_order[begin + item % n_lvl]];
+__device__ __forceinline__ void up_node(const TileParams<NS>& p, int tile, int parent, int child0, int child1, int edge0, int edge1, int lane,
+                                        uint32_t& err) {
   double* __restrict__ PLt = p.PL + (size_t)tile * p.n_node * NS * 64;
   const uint16_t* __restrict__ mct = p.mcount + (size_t)tile * p.n_edge * 64;
   const uint8_t* __restrict__ tips_t = p.tips_per_replica ? p.tips + (size_t)tile * p.n_tips * 64 : p.tips;
-  uint32_t err = 0;
   double x[NS], y[NS];
-  child_vec<NS>(p, PLt, tips_t, st.child[1], (int)mct[st.edge[1] * 64 + lane] - 1, lane, x, err);   // "first"  (:508)
-  child_vec<NS>(p, PLt, tips_t, st.child[0], (int)mct[st.edge[0] * 64 + lane] - 1, lane, y, err);   // "second" (:509)
+  child_vec<NS>(p, PLt, tips_t, child1, (int)mct[edge1 * 64 + lane] - 1, lane, x, err);   // "first"  (:508)
+  child_vec<NS>(p, PLt, tips_t, child0, (int)mct[edge0 * 64 + lane] - 1, lane, y, err);   // "second" (:509)
 #pragma unroll
   for (int c = 0; c < NS; ++c) x[c] = x[c] * y[c];                             // :510
   if (p.normalise) {                                                           // :525
@@ -51,8 +46,55 @@ __global__ __launch_bounds__(TILES_BLOCK) void tiles_up_kernel(TileParams<NS> p,
     for (int c = 0; c < NS; ++c) x[c] = x[c] / s;
   }
 #pragma unroll
-  for (int c = 0; c < NS; ++c) PLt[(st.parent * NS + c) * 64 + lane] = x[c];
+  for (int c = 0; c < NS; ++c) PLt[(parent * NS + c) * 64 + lane] = x[c];
+}
+
+template <int NS>
+__global__ __launch_bounds__(TILES_BLOCK) void tiles_up_kernel(TileParams<NS> p, int begin, int end) {
+  const int lane = threadIdx.x & 63;
+  const int item = blockIdx.x * (TILES_BLOCK / 64) + (threadIdx.x >> 6);
+  const int n_lvl = end - begin;
+  if (item >= n_lvl * p.n_tiles) return;
+  const int tile = item / n_lvl;
+  const UpStep st = p.up[p.up_order[begin + item % n_lvl]];
+  uint32_t err = 0;
+  up_node<NS>(p, tile, st.parent, st.child[0], st.child[1], st.edge[0], st.edge[1], lane, err);
   if (err) atomicOr(p.err, err);
+}
+
+// The same pass over one TIER of subtree clusters: a workgroup per (cluster, tile) walks the cluster's height levels, its waves
+// sharing the nodes of a level, a workgroup barrier between levels (the waves of a workgroup share their CU's L1: what one wrote
+// before the barrier the others read after it).  Big clusters first.
+template <int NS>
+__global__ __launch_bounds__(TILES_CL_BLOCK) void tiles_up_cluster_kernel(TileParams<NS> p, int cl_begin, int n_cl) {
+  constexpr int W = TILES_CL_BLOCK / 64;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int cl = cl_begin + (int)(blockIdx.x % (unsigned)n_cl);
+  const int tile = (int)(blockIdx.x / (unsigned)n_cl);
+  const int l0 = p.cl_lvl_ptr[cl], l1 = p.cl_lvl_ptr[cl + 1] - 1;
+  uint32_t err = 0;
+  for (int l = l0; l < l1; ++l) {
+    const int i1 = p.cl_lvl_off[l + 1];
+    for (int i = p.cl_lvl_off[l] + wave; i < i1; i += W) {
+      const ClusterNode nd = p.cl_nodes[i];
+      up_node<NS>(p, tile, nd.parent, nd.child[0], nd.child[1], nd.edge[0], nd.edge[1], lane, err);
+    }
+    __syncthreads();
+  }
+  if (err) atomicOr(p.err, err);
+}
+
+// root ~ pid (.) PL[root]   (:618-627)
+template <int NS>
+__device__ __forceinline__ void draw_root(const TileParams<NS>& p, int tile, int it, int lane, uint32_t& err) {
+  const double* __restrict__ PLt = p.PL + (size_t)tile * p.n_node * NS * 64;
+  const uint32_t rep = (uint32_t)(p.replica_offset + tile * 64 + lane);
+  double pr[NS];
+#pragma unroll
+  for (int c = 0; c < NS; ++c) pr[c] = p.pid[c] * PLt[(p.root * NS + c) * 64 + lane];   // :618
+  const double u = stream_u(p.seed_lo, p.seed_hi, rep, (uint32_t)it, ENT_NODE | (uint32_t)(p.root + p.n_tips), 0);
+  p.nstate[((size_t)tile * p.n_node + p.root) * 64 + lane] = (uint8_t)sample_cat<NS>(pr, u, err);   // :627
 }
 
 template <int NS>
@@ -60,18 +102,49 @@ __global__ __launch_bounds__(TILES_BLOCK) void tiles_root_kernel(TileParams<NS> 
   const int lane = threadIdx.x & 63;
   const int tile = blockIdx.x * (TILES_BLOCK / 64) + (threadIdx.x >> 6);
   if (tile >= p.n_tiles) return;
-  const double* __restrict__ PLt = p.PL + (size_t)tile * p.n_node * NS * 64;
-  const uint32_t rep = (uint32_t)(p.replica_offset + tile * 64 + lane);
   uint32_t err = 0;
-  double pr[NS];
-#pragma unroll
-  for (int c = 0; c < NS; ++c) pr[c] = p.pid[c] * PLt[(p.root * NS + c) * 64 + lane];   // :618
-  const double u = stream_u(p.seed_lo, p.seed_hi, rep, (uint32_t)it, ENT_NODE | (uint32_t)(p.root + p.n_tips), 0);
-  p.nstate[((size_t)tile * p.n_node + p.root) * 64 + lane] = (uint8_t)sample_cat<NS>(pr, u, err);   // :627
+  draw_root<NS>(p, tile, it, lane, err);
   if (err) atomicOr(p.err, err);
 }
 
-// child ~ e_ps^T B^(m-1) (.) PL[child]   (Tvmmp :431-436, :651); ks: tips too, against their parity mask (:1384-1397)
+// child ~ e_ps^T B^(m-1) (.) PL[child]   (Tvmmp :431-436, :651); ks: tips too, against their parity mask (:1384-1397);
+// end states of the edge (updatenodestates :460-475)
+template <int NS>
+__device__ __forceinline__ void down_edge(const TileParams<NS>& p, int tile, int it, int b, int parent, int child, int lane, uint32_t& err) {
+  const double* __restrict__ PLt = p.PL + (size_t)tile * p.n_node * NS * 64;
+  uint8_t* __restrict__ nst = p.nstate + (size_t)tile * p.n_node * 64;
+  const uint8_t* __restrict__ tips_t = p.tips_per_replica ? p.tips + (size_t)tile * p.n_tips * 64 : p.tips;
+  const uint32_t rep = (uint32_t)(p.replica_offset + tile * 64 + lane);
+  const int m = p.mcount[((size_t)tile * p.n_edge + b) * 64 + lane];
+  const int ps = nst[parent * 64 + lane];
+  int cs;
+  if (child >= 0 || (p.ks && p.tip_masks)) {
+    int kk = m - 1;
+    if (kk >= p.klong) { err |= DERR_CAPACITY; kk = p.klong - 1; }
+    const double* src = p.rowL + ((size_t)kk * NS + ps) * NS;
+    double w[NS];
+    uint32_t node_id;
+    if (child >= 0) {
+#pragma unroll
+      for (int c = 0; c < NS; ++c) w[c] = src[c] * PLt[(child * NS + c) * 64 + lane];
+      node_id = (uint32_t)(child + p.n_tips);
+    } else {
+      const int tip = ~child;
+      const int par = (p.tips_per_replica ? tips_t[tip * 64 + lane] : p.tips[tip]) & 1;
+#pragma unroll
+      for (int c = 0; c < NS; ++c) w[c] = src[c] * (((c & 1) == par) ? 1.0 : 0.0);
+      node_id = (uint32_t)tip;
+    }
+    const double u = stream_u(p.seed_lo, p.seed_hi, rep, (uint32_t)it, ENT_NODE | node_id, 0);
+    cs = sample_cat<NS>(w, u, err);                                            // :655
+    if (child >= 0) nst[child * 64 + lane] = (uint8_t)cs;
+  } else {
+    const int tip = ~child;
+    cs = p.tips_per_replica ? tips_t[tip * 64 + lane] : p.tips[tip];          // :612
+  }
+  p.estate[((size_t)tile * p.n_edge + b) * 64 + lane] = (uint8_t)(ps | (cs << 4));   // updatenodestates :460-475
+}
+
 template <int NS>
 __global__ __launch_bounds__(TILES_BLOCK) void tiles_down_kernel(TileParams<NS> p, int it, int begin, int end) {
   const int lane = threadIdx.x & 63;
@@ -81,41 +154,34 @@ __global__ __launch_bounds__(TILES_BLOCK) void tiles_down_kernel(TileParams<NS> 
   // persistent waves: kernel arguments and wave set-up once per wave, not once per (edge, tile): 2.28 -> 2.01 ms per sweep on C3 (the pruning
   // kernel above loses by the same change: 3.16 -> 3.7)
   for (int item = blockIdx.x * (TILES_BLOCK / 64) + (threadIdx.x >> 6); item < n_items; item += gridDim.x * (TILES_BLOCK / 64)) {
-  const int tile = item / n_lvl;
-  const DownStep ds = p.down[p.down_order[begin + item % n_lvl]];
-  const int b = ds.edge;
-  const double* __restrict__ PLt = p.PL + (size_t)tile * p.n_node * NS * 64;
-  uint8_t* __restrict__ nst = p.nstate + (size_t)tile * p.n_node * 64;
-  const uint8_t* __restrict__ tips_t = p.tips_per_replica ? p.tips + (size_t)tile * p.n_tips * 64 : p.tips;
-  const uint32_t rep = (uint32_t)(p.replica_offset + tile * 64 + lane);
-  const int m = p.mcount[((size_t)tile * p.n_edge + b) * 64 + lane];
-  const int ps = nst[ds.parent * 64 + lane];
-  int cs;
-  if (ds.child >= 0 || (p.ks && p.tip_masks)) {
-    int kk = m - 1;
-    if (kk >= p.klong) { err |= DERR_CAPACITY; kk = p.klong - 1; }
-    const double* src = p.rowL + ((size_t)kk * NS + ps) * NS;
-    double w[NS];
-    uint32_t node_id;
-    if (ds.child >= 0) {
-#pragma unroll
-      for (int c = 0; c < NS; ++c) w[c] = src[c] * PLt[(ds.child * NS + c) * 64 + lane];
-      node_id = (uint32_t)(ds.child + p.n_tips);
-    } else {
-      const int tip = ~ds.child;
-      const int par = (p.tips_per_replica ? tips_t[tip * 64 + lane] : p.tips[tip]) & 1;
-#pragma unroll
-      for (int c = 0; c < NS; ++c) w[c] = src[c] * (((c & 1) == par) ? 1.0 : 0.0);
-      node_id = (uint32_t)tip;
-    }
-    const double u = stream_u(p.seed_lo, p.seed_hi, rep, (uint32_t)it, ENT_NODE | node_id, 0);
-    cs = sample_cat<NS>(w, u, err);                                            // :655
-    if (ds.child >= 0) nst[ds.child * 64 + lane] = (uint8_t)cs;
-  } else {
-    const int tip = ~ds.child;
-    cs = p.tips_per_replica ? tips_t[tip * 64 + lane] : p.tips[tip];          // :612
+    const DownStep ds = p.down[p.down_order[begin + item % n_lvl]];
+    down_edge<NS>(p, item / n_lvl, it, ds.edge, ds.parent, ds.child, lane, err);
   }
-  p.estate[((size_t)tile * p.n_edge + b) * 64 + lane] = (uint8_t)(ps | (cs << 4));   // updatenodestates :460-475
+  if (err) atomicOr(p.err, err);
+}
+
+// The node draws over one tier of subtree clusters, top level first: a wave per (node of the level, child side) draws the child's
+// state and writes the edge's end states; the tier that holds the root draws it first (with_root).
+template <int NS>
+__global__ __launch_bounds__(TILES_CL_BLOCK) void tiles_down_cluster_kernel(TileParams<NS> p, int it, int cl_begin, int n_cl, int with_root) {
+  constexpr int W = TILES_CL_BLOCK / 64;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int cl = cl_begin + (int)(blockIdx.x % (unsigned)n_cl);
+  const int tile = (int)(blockIdx.x / (unsigned)n_cl);
+  const int l0 = p.cl_lvl_ptr[cl], l1 = p.cl_lvl_ptr[cl + 1] - 1;
+  uint32_t err = 0;
+  if (with_root) {                                   // the last tier is one cluster and its top node is the root
+    if (wave == 0) draw_root<NS>(p, tile, it, lane, err);
+    __syncthreads();
+  }
+  for (int l = l1 - 1; l >= l0; --l) {
+    const int i0 = p.cl_lvl_off[l], cnt = 2 * (p.cl_lvl_off[l + 1] - i0);
+    for (int j = wave; j < cnt; j += W) {
+      const ClusterNode nd = p.cl_nodes[i0 + (j >> 1)];
+      down_edge<NS>(p, tile, it, nd.edge[j & 1], nd.parent, nd.child[j & 1], lane, err);
+    }
+    __syncthreads();
   }
   if (err) atomicOr(p.err, err);
 }
@@ -150,7 +216,7 @@ __global__ __launch_bounds__(TILES_BLOCK, KS ? 7 : 8) void tiles_branch_kernel(T
   uint16_t* s_cnt = s_cnt_all + wave * NCNT * 64;
   const uint32_t rep = (uint32_t)(p.replica_offset + tile * 64 + lane);
   uint16_t* __restrict__ mct = p.mcount + (size_t)tile * p.n_edge * 64;
-  uint32_t* gc = p.cnt + ((size_t)tile * NS * NS) * 64 + lane;
+  uint32_t* gc = p.cnt + (((size_t)tile * p.cnt_copies + (grp & (p.cnt_copies - 1))) * NS * NS) * 64 + lane;
   uint32_t err = 0;
 #pragma unroll
   for (int c = 0; c < NS; ++c) s_dw[c * 64 + lane] = 0.0;
@@ -369,29 +435,74 @@ __global__ __launch_bounds__(TILES_BLOCK) void tiles_chunk_kernel(TileParams<NS>
   p.pseg[((size_t)tile * p.n_chunks + chunk) * 64 + lane] = segs;
 }
 
-// Second stage and the statistics row: a wave per tile.  Columns: n dwell sums, the counters, (ks) the root state.
+// Third stage and the statistics row: a workgroup of TILES_STATS_WAVES waves per tile.  Wave w adds its contiguous share of the
+// chunk sums in chunk order (and its share of the counter copies); wave 0 then adds the waves' partial sums in wave order -- a fixed
+// shape that depends on the number of chunks only, so a run reproduces itself bit for bit -- and writes the row.  (One wave per
+// tile walked all 313 chunk sums of C3 alone: with a handful of tiles the reductions were a quarter of the sweep.)
+// Columns: n dwell sums, the counters, (ks) the root state.
+constexpr int TILES_STATS_WAVES = 8;
+
 template <int NS, bool KS>
-__global__ __launch_bounds__(TILES_BLOCK) void tiles_stats_kernel(TileParams<NS> p, int it) {
+__global__ __launch_bounds__(64 * TILES_STATS_WAVES) void tiles_stats_kernel(TileParams<NS> p, int it) {
   constexpr int NCNT = KS ? NS * NS : NS * (NS - 1);
   constexpr int DCOLS = NS + NCNT + (KS ? 1 : 0);
+  constexpr int SW = TILES_STATS_WAVES;
+  __shared__ double s_dw[SW][NS][64];
+  __shared__ uint32_t s_ct[SW][NCNT][64];
+  __shared__ uint32_t s_sg[SW][64];
   const int lane = threadIdx.x & 63;
-  const int tile = blockIdx.x * (TILES_BLOCK / 64) + (threadIdx.x >> 6);
-  if (tile >= p.n_tiles) return;
+  const int wave = threadIdx.x >> 6;
+  const int tile = blockIdx.x;
   const int rep_local = tile * 64 + lane;
   const bool valid = rep_local < p.n_rep;
+  {
+    const int per = (p.n_chunks + SW - 1) / SW;
+    const int c0 = min(wave * per, p.n_chunks), c1 = min(c0 + per, p.n_chunks);
+    double part[NS];
+#pragma unroll
+    for (int c = 0; c < NS; ++c) part[c] = 0.0;
+    const double* src = p.pchunk + ((size_t)tile * p.n_chunks * NS) * 64 + lane;
+    uint32_t segs = 0;
+    for (int ch = c0; ch < c1; ++ch) {
+#pragma unroll
+      for (int c = 0; c < NS; ++c) part[c] += src[((size_t)ch * NS + c) * 64];
+      segs += p.pseg[((size_t)tile * p.n_chunks + ch) * 64 + lane];
+    }
+#pragma unroll
+    for (int c = 0; c < NS; ++c) s_dw[wave][c][lane] = part[c];
+    s_sg[wave][lane] = segs;
+    uint32_t tot[NCNT];
+#pragma unroll
+    for (int c = 0; c < NCNT; ++c) tot[c] = 0u;
+    for (int k = wave; k < p.cnt_copies; k += SW) {         // integer sums: exact in any order
+      uint32_t* gc = p.cnt + (((size_t)tile * p.cnt_copies + k) * NS * NS) * 64 + lane;
+#pragma unroll
+      for (int c = 0; c < NCNT; ++c) { tot[c] += gc[c * 64]; gc[c * 64] = 0u; }
+    }
+#pragma unroll
+    for (int c = 0; c < NCNT; ++c) s_ct[wave][c][lane] = tot[c];
+  }
+  __syncthreads();
+  if (wave != 0) return;
   double col[DCOLS];
 #pragma unroll
-  for (int c = 0; c < NS; ++c) col[c] = 0.0;
-  const double* src = p.pchunk + ((size_t)tile * p.n_chunks * NS) * 64 + lane;
-  for (int ch = 0; ch < p.n_chunks; ++ch)
+  for (int c = 0; c < NS; ++c) {
+    double v = s_dw[0][c][lane];
 #pragma unroll
-    for (int c = 0; c < NS; ++c) col[c] += src[((size_t)ch * NS + c) * 64];
-  uint32_t* gc = p.cnt + ((size_t)tile * NS * NS) * 64 + lane;
+    for (int w = 1; w < SW; ++w) v += s_dw[w][c][lane];
+    col[c] = v;
+  }
 #pragma unroll
-  for (int c = 0; c < NCNT; ++c) { col[NS + c] = (double)gc[c * 64]; gc[c * 64] = 0u; }
+  for (int c = 0; c < NCNT; ++c) {
+    uint32_t v = 0u;
+#pragma unroll
+    for (int w = 0; w < SW; ++w) v += s_ct[w][c][lane];
+    col[NS + c] = (double)v;
+  }
   {   // segments read (the previous sweep's total) + written (this sweep's), valid replicas only
     uint32_t segs = 0;
-    for (int ch = 0; ch < p.n_chunks; ++ch) segs += p.pseg[((size_t)tile * p.n_chunks + ch) * 64 + lane];
+#pragma unroll
+    for (int w = 0; w < SW; ++w) segs += s_sg[w][lane];
     if (!valid) segs = 0;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) segs += __shfl_xor(segs, off, 64);
@@ -439,35 +550,50 @@ hipError_t launch_tiles_init(int n_edge, int n_tiles, int64_t rows, const int32_
 
 template <int NS>
 hipError_t launch_tiles_sweep(const TileParams<NS>& p, const std::vector<int32_t>& up_off,
-                              const std::vector<int32_t>& down_off, int it, hipStream_t stream, hipEvent_t* phase_ev) {
+                              const std::vector<int32_t>& down_off, const std::vector<int32_t>& tier_off, int it, hipStream_t stream,
+                              hipEvent_t* phase_ev) {
   constexpr int WPB = TILES_BLOCK / 64;
   auto blocks = [&](int64_t items) { return dim3((unsigned)((items + WPB - 1) / WPB)); };
   auto pblocks = [&](int64_t items) { return dim3((unsigned)std::min<int64_t>((items + WPB - 1) / WPB, TILES_PERSISTENT_WGS)); };      // node draws: persistent waves, 8 per SIMD
   auto mark = [&](int i) { if (phase_ev) (void)hipEventRecord(phase_ev[i], stream); };
   mark(0);
-  for (size_t l = 0; l + 1 < up_off.size(); ++l) {
-    const int n = up_off[l + 1] - up_off[l];
-    if (n > 0) hipLaunchKernelGGL(tiles_up_kernel<NS>, blocks((int64_t)n * p.n_tiles), dim3(TILES_BLOCK), 0, stream, p, up_off[l], up_off[l + 1]);
-  }
-  mark(1);
-  hipLaunchKernelGGL(tiles_root_kernel<NS>, blocks(p.n_tiles), dim3(TILES_BLOCK), 0, stream, p, it);
-  for (size_t l = 0; l + 1 < down_off.size(); ++l) {
-    const int n = down_off[l + 1] - down_off[l];
-    if (n > 0) hipLaunchKernelGGL(tiles_down_kernel<NS>, pblocks((int64_t)n * p.n_tiles), dim3(TILES_BLOCK), 0, stream, p, it, down_off[l], down_off[l + 1]);
+  if (p.cl_nodes) {                                  // few tiles: subtree clusters, one launch per tier and pass
+    const int n_tiers = (int)tier_off.size() - 1;
+    for (int t = 0; t < n_tiers; ++t) {
+      const int n_cl = tier_off[t + 1] - tier_off[t];
+      hipLaunchKernelGGL(tiles_up_cluster_kernel<NS>, dim3((unsigned)((int64_t)n_cl * p.n_tiles)), dim3(TILES_CL_BLOCK), 0, stream, p, tier_off[t], n_cl);
+    }
+    mark(1);
+    for (int t = n_tiers - 1; t >= 0; --t) {
+      const int n_cl = tier_off[t + 1] - tier_off[t];
+      hipLaunchKernelGGL(tiles_down_cluster_kernel<NS>, dim3((unsigned)((int64_t)n_cl * p.n_tiles)), dim3(TILES_CL_BLOCK), 0, stream, p, it, tier_off[t], n_cl,
+                         t == n_tiers - 1 ? 1 : 0);
+    }
+  } else {
+    for (size_t l = 0; l + 1 < up_off.size(); ++l) {
+      const int n = up_off[l + 1] - up_off[l];
+      if (n > 0) hipLaunchKernelGGL(tiles_up_kernel<NS>, blocks((int64_t)n * p.n_tiles), dim3(TILES_BLOCK), 0, stream, p, up_off[l], up_off[l + 1]);
+    }
+    mark(1);
+    hipLaunchKernelGGL(tiles_root_kernel<NS>, blocks(p.n_tiles), dim3(TILES_BLOCK), 0, stream, p, it);
+    for (size_t l = 0; l + 1 < down_off.size(); ++l) {
+      const int n = down_off[l + 1] - down_off[l];
+      if (n > 0) hipLaunchKernelGGL(tiles_down_kernel<NS>, pblocks((int64_t)n * p.n_tiles), dim3(TILES_BLOCK), 0, stream, p, it, down_off[l], down_off[l + 1]);
+    }
   }
   mark(2);
   if (p.ks) hipLaunchKernelGGL((tiles_branch_kernel<NS, true>), blocks((int64_t)p.n_groups * p.n_tiles), dim3(TILES_BLOCK), 0, stream, p, it);
   else hipLaunchKernelGGL((tiles_branch_kernel<NS, false>), blocks((int64_t)p.n_groups * p.n_tiles), dim3(TILES_BLOCK), 0, stream, p, it);
   mark(3);
   hipLaunchKernelGGL(tiles_chunk_kernel<NS>, blocks((int64_t)p.n_chunks * p.n_tiles), dim3(TILES_BLOCK), 0, stream, p);
-  if (p.ks) hipLaunchKernelGGL((tiles_stats_kernel<NS, true>), blocks(p.n_tiles), dim3(TILES_BLOCK), 0, stream, p, it);
-  else hipLaunchKernelGGL((tiles_stats_kernel<NS, false>), blocks(p.n_tiles), dim3(TILES_BLOCK), 0, stream, p, it);
+  if (p.ks) hipLaunchKernelGGL((tiles_stats_kernel<NS, true>), dim3(p.n_tiles), dim3(64 * TILES_STATS_WAVES), 0, stream, p, it);
+  else hipLaunchKernelGGL((tiles_stats_kernel<NS, false>), dim3(p.n_tiles), dim3(64 * TILES_STATS_WAVES), 0, stream, p, it);
   mark(4);
   return hipGetLastError();
 }
 
-template hipError_t launch_tiles_sweep<2>(const TileParams<2>&, const std::vector<int32_t>&, const std::vector<int32_t>&, int, hipStream_t, hipEvent_t*);
-template hipError_t launch_tiles_sweep<3>(const TileParams<3>&, const std::vector<int32_t>&, const std::vector<int32_t>&, int, hipStream_t, hipEvent_t*);
-template hipError_t launch_tiles_sweep<4>(const TileParams<4>&, const std::vector<int32_t>&, const std::vector<int32_t>&, int, hipStream_t, hipEvent_t*);
+template hipError_t launch_tiles_sweep<2>(const TileParams<2>&, const std::vector<int32_t>&, const std::vector<int32_t>&, const std::vector<int32_t>&, int, hipStream_t, hipEvent_t*);
+template hipError_t launch_tiles_sweep<3>(const TileParams<3>&, const std::vector<int32_t>&, const std::vector<int32_t>&, const std::vector<int32_t>&, int, hipStream_t, hipEvent_t*);
+template hipError_t launch_tiles_sweep<4>(const TileParams<4>&, const std::vector<int32_t>&, const std::vector<int32_t>&, const std::vector<int32_t>&, int, hipStream_t, hipEvent_t*);
 
 }  // namespace phm
