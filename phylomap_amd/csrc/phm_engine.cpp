@@ -417,7 +417,11 @@ int32_t narrow_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
   HIPCHK(hipMemGetInfo(&free_b, &total_b));
   const size_t part_cols = e->wide ? (size_t)n + 1 : (size_t)n + n * n + 1;      // n > 4: counters go through atomics, not per branch
   const size_t n_dw = e->wide ? 3 : 2;             // n <= 4: the branch kernel needs no merged-segment scratch (phm_narrow.hip)
-  const size_t need = n_dw * dw_bytes + (e->wide ? (size_t)S * e->nw_total_cap : 0) + stats_bytes + sizeof(double) * (3 * tab + (size_t)S * E * part_cols + (e->wide ? 2 * (size_t)S * e->dcols : 0));
+  // transition maps of the sampling sweep: n <= 4 two 16-bit maps per (chain, edge); 5..64 states n bytes per (chain, edge) while that stays below 256 MiB
+  const size_t dmap_bytes = e->wide ? (((size_t)S * E * n <= (256u << 20)) ? (size_t)S * E * n : 0) : 2 * sizeof(uint16_t) * (size_t)S * E;
+  const size_t small_bytes = (size_t)S * (E * (sizeof(int32_t) + 2) + (size_t)Nn * (sizeof(double) * n + 1)) + sizeof(phm::ClusterNode) * (size_t)Nn + 16 * (size_t)E;   // segment counts, end states, PL, node states, schedules
+  const size_t need = n_dw * dw_bytes + (e->wide ? (size_t)S * e->nw_total_cap : 0) + stats_bytes + dmap_bytes + small_bytes +
+                      sizeof(double) * (3 * tab + (size_t)S * E * part_cols + (e->wide ? 2 * (size_t)S * e->dcols : 0));
   if (need + (64u << 20) > free_b) {
     char buf[256];
     std::snprintf(buf, sizeof buf, "engine needs %.2f GiB of HBM, %.2f GiB free (reduce n_replicas or max_iters)", need / 1073741824.0, free_b / 1073741824.0);
@@ -463,7 +467,8 @@ int32_t narrow_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
   HIPCHK(e->d_err.alloc(sizeof(uint32_t))); HIPCHK(e->d_seg.alloc(sizeof(unsigned long long)));
   if (e->reduce) HIPCHK(e->d_red.alloc(sizeof(double) * (size_t)max_iters * e->dcols));
   e->bytes = (int64_t)(n_dw * dw_bytes + e->d_nw_mstate.bytes + e->d_nw_part.bytes + e->d_PL.bytes + e->d_stats.bytes + e->d_red.bytes +
-                       sizeof(double) * 3 * tab + e->d_nw_mcount.bytes);
+                       sizeof(double) * 3 * tab + e->d_nw_mcount.bytes + e->d_nw_dmap.bytes + e->d_nw_dmap_edge.bytes + e->d_nw_cl_nodes.bytes +
+                       (e->wide ? dmap_bytes : 0));
   HIPCHK(hipMemcpy(e->d_up.p, s.up.data(), e->d_up.bytes, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(e->d_down.p, s.down.data(), e->d_down.bytes, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(e->d_nw_border.p, border.data(), e->d_nw_border.bytes, hipMemcpyHostToDevice));

@@ -1235,16 +1235,17 @@ hipError_t launch_wtiles_sweep(const WtParams& p, const WtBand& band, const std:
     const bool b2l = !small && p.group >= 4;           // n > 32: B rows in LDS once a wave walks four or more branches
     const BranchLds L = branch_lds(p.n_states, p.ldt, small ? p.n_slots : 0, small, b2l, small ? p.band_draw : 0, red, p.ks != 0);
     const size_t lds_now = L.total;
-    {      // beyond the default 64 KB of dynamic LDS: n = 32 with 96 countable pairs; 61 states with the rows of B and the reduced counters
-      const void* fn = p.ks ? (small ? (p.band_draw == 1 ? (const void*)wt_branch_kernel<true, true, true, 1> : p.band_draw == 2 ? (const void*)wt_branch_kernel<true, true, true, 2> : (const void*)wt_branch_kernel<true, true, true, 0>)
-                                     : (b2l ? (const void*)wt_branch_kernel<true, false, true, 0> : (const void*)wt_branch_kernel<true, false, false, 0>))
-                            : (small ? (p.band_draw == 1 ? (const void*)wt_branch_kernel<false, true, true, 1> : p.band_draw == 2 ? (const void*)wt_branch_kernel<false, true, true, 2> : (const void*)wt_branch_kernel<false, true, true, 0>)
-                                     : (b2l ? (const void*)wt_branch_kernel<false, false, true, 0> : (const void*)wt_branch_kernel<false, false, false, 0>));
-      const hipError_t ae = allow_dynamic_lds(fn, 96 * 1024);
-      if (ae != hipSuccess) return ae;
-    }
     const int band = small ? p.band_draw : 0;
-#define PHM_BRANCH(KSV, SM, BL, BD) hipLaunchKernelGGL((wt_branch_kernel<KSV, SM, BL, BD>), g, dim3(SM ? WT_BRANCH_BLOCK_SMALL : WT_BRANCH_BLOCK_BIG), lds_now, stream, p, it)
+    // beyond the default 64 KB of dynamic LDS (n = 32 with 96 countable pairs) the kernel variant about to be launched is told so -- once
+    // per (variant, device), and only then: the per-iteration drivers launch a sweep per rate update
+#define PHM_BRANCH(KSV, SM, BL, BD)                                                                                                    \
+    do {                                                                                                                               \
+      if (lds_now > 64 * 1024) {                                                                                                       \
+        const hipError_t ae = allow_dynamic_lds((const void*)wt_branch_kernel<KSV, SM, BL, BD>, 96 * 1024);                            \
+        if (ae != hipSuccess) return ae;                                                                                               \
+      }                                                                                                                                \
+      hipLaunchKernelGGL((wt_branch_kernel<KSV, SM, BL, BD>), g, dim3(SM ? WT_BRANCH_BLOCK_SMALL : WT_BRANCH_BLOCK_BIG), lds_now, stream, p, it); \
+    } while (0)
     if (p.ks) {
       if (small && band == 1) PHM_BRANCH(true, true, true, 1);
       else if (small && band == 2) PHM_BRANCH(true, true, true, 2);
