@@ -6,7 +6,7 @@ ARCH    ?= gfx950
 CSRC    := phylomap_amd/csrc
 LIB     := phylomap_amd/libphylomap_hip.so
 OBJDIR  := build/obj
-SRCS    := $(CSRC)/phm_engine.cpp $(CSRC)/phm_drivers.cpp $(CSRC)/phm_expm_api.cpp $(CSRC)/phm_sched.cpp $(CSRC)/phm_qupdate.cpp $(CSRC)/phm_mcmc.hip $(CSRC)/phm_wide.hip $(CSRC)/phm_narrow.hip $(CSRC)/phm_tiles.hip $(CSRC)/phm_wbranch.hip $(CSRC)/phm_wtiles.hip $(CSRC)/phm_exp.hip
+SRCS    := $(CSRC)/phm_engine.cpp $(CSRC)/phm_drivers.cpp $(CSRC)/phm_expm_api.cpp $(CSRC)/phm_sched.cpp $(CSRC)/phm_qupdate.cpp $(CSRC)/phm_rtc.cpp $(CSRC)/phm_mcmc.hip $(CSRC)/phm_wide.hip $(CSRC)/phm_narrow.hip $(CSRC)/phm_tiles.hip $(CSRC)/phm_wbranch.hip $(CSRC)/phm_wtiles.hip $(CSRC)/phm_exp.hip
 OBJS    := $(patsubst $(CSRC)/%,$(OBJDIR)/%.o,$(SRCS))
 HDRS    := $(wildcard $(CSRC)/*.h) include/phylomap_hip.h
 # EXTRA: experiment switches (e.g. make LIB=scratch/libv1.so OBJDIR=build/v1 EXTRA=-DWT_BRANCH_WAVES=8)
@@ -22,7 +22,7 @@ $(OBJDIR)/%.o: $(CSRC)/% $(HDRS)
 	$(HIPCC) $(FLAGS) -x hip -c -o $@ $<
 
 $(LIB): $(OBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -lhiprtc
 
 oracle:
 	$(MAKE) -C oracle

@@ -252,13 +252,15 @@ def main():
         S = int(min(cap, (frac * free_b) // per_tile * 64))
         return max(64, S // 1024 * 1024 if S >= 1024 else S // 64 * 64)
 
-    def measure(cfg, mapping, S, K, W, seed, ipl=8, storage=0, collective=False, offset=0, variant=_lib.PHM_MCMC_BIGTREE, tkey=None):
-        """K timed sweeps of configuration `cfg` after args.burnin + W untimed sweeps; returns (block, wall seconds)."""
+    def measure(cfg, mapping, S, K, W, seed, ipl=8, storage=0, collective=False, offset=0, variant=_lib.PHM_MCMC_BIGTREE, tkey=None, max_iters=0,
+                problem=None):
+        """K timed sweeps of configuration `cfg` after args.burnin + W untimed sweeps; returns (block, wall seconds).
+        max_iters > K + W: the engine is provisioned for a run of that length (slots, statistics rows), of which K + W sweeps run."""
         W = W + args.burnin
-        z, Q, pid, Omega = synth.config_problem(cfg)
+        z, Q, pid, Omega = problem or synth.config_problem(cfg)
         n, E = Q.shape[0], z["edge"].shape[0]
         tiled = mapping == "tiles"
-        eng = _lib.Engine(z, Q, pid, Omega, K + W, variant=variant, seed=seed, n_replicas=S, replica_offset=offset,
+        eng = _lib.Engine(z, Q, pid, Omega, max(K + W, max_iters), variant=variant, seed=seed, n_replicas=S, replica_offset=offset,
                           reduce=True, device=local_rank, iters_per_launch=ipl, storage=storage, mapping=mapping,
                           phase_timing=tiled)
         cols = eng.cols
@@ -302,7 +304,8 @@ def main():
         per = E * S                                          # units of one sweep
         blk = {"workload": tkey or f"C{cfg}", "n_states": n, "n_tips": int(z["states"].size), "branches": E, "replicas": S, "mapping": mapping,
                "ms_per_sweep": dt / K * 1e3, "realisations_per_s": units / dt, "hbm_gib_resident": info.device_bytes / 2 ** 30,
-               "replicas_per_gib": S / (info.device_bytes / 2 ** 30), "mean_segments_read_plus_written": seg}
+               "replicas_per_gib": S / (info.device_bytes / 2 ** 30), "mean_segments_read_plus_written": seg, "recoveries": int(info.recoveries),
+               "max_iters_provisioned": int(info.max_iters)}
         sweep = {"bound": "hbm", "definition": "SURVEY 8(d): E * S * B_alg / (HIP-event time of all kernels of one sweep), B_alg = 16 n + 12 mean(m + m') + 26",
                  "alg_bytes_per_unit": b_alg, "units_per_launch": per, "launches": K, "avg_launch_ms": info.last_run_ms / K,
                  "achieved": units * b_alg / kernel_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -326,7 +329,7 @@ def main():
                     e["valu_issue_frac"] = valu * scale * VALU_CLOCKS / (N_SIMD * NOMINAL_GHZ * 1e9 * ms / 1e3)
                 return e
             branch = kblock(("_branch_kernel",), br_ms, 12 * seg + 8, "resamplebranchstates + shortener + virtual jumps + dwell sums (src/phylomap.cpp:264-413, :44-73, :745-757); one launch per sweep")
-            prune = kblock(("_up_",), up_ms, 12 * n + 12, "makePLrcpp* (src/phylomap.cpp:503-529), all height levels of one sweep")
+            prune = kblock(("_up_", "sparse_up"), up_ms, 12 * n + 12, "makePLrcpp* (src/phylomap.cpp:503-529), all height levels of one sweep")
             draws = kblock(("_down_kernel", "_root_kernel"), down_ms, 4 * n + 6, "sampleinternalnodes* + updatenodestates (src/phylomap.cpp:618-657, :460-475), all depth levels")
             red = kblock(("_stats_kernel", "_chunk_kernel"), st_ms, 0.0, "statistics rows (fixed-order reductions)")
             if n > 4 and eng.info().sparse_chains & 1 == 0:   # 5..64 states, dense B: the pruning chains run on the matrix cores
@@ -433,12 +436,25 @@ def main():
             "pruning_sweep": head.get("pruning_sweep"),
             "hbm_bytes_resident": int(head["hbm_gib_resident"] * 2 ** 30),
             "replicas_per_gib": head["replicas_per_gib"],
+            "recoveries": head["recoveries"],
         }
+        out["config"]["max_iters_provisioned"] = head["max_iters_provisioned"]
         if cfg in cpu:
             out["cpu_baseline"] = cpu[cfg]
             out["speedup_vs_cpu_1core"] = out["value"] / cpu[cfg]["value"]
             out["speedup_vs_cpu_1core_faithful"] = out["value"] / cpu[cfg]["faithful_value"]
             out["speedup_vs_cpu_all_cores"] = out["value"] / cpu[cfg]["all_cores"]["value"]
+    if rank == 0 and world == 1 and not args.no_extras and cfg == 3:
+        # The headline at the configuration's STATED length (BASELINE configs[2]: 10 000 iterations): an engine provisioned for
+        # max_iters = 10 000 -- slot tail 0.05 / (S E 10 000) per draw, 10 000 statistics rows per tile -- of which the same
+        # burn-in + warm-up + K sweeps run.  Fewer replicas fit per GiB than in the 37-sweep engine above; both are reported.
+        N_stated = 10000
+        S10 = sized_replicas(zc, Qc, pidc, Omc, mapping, 16384, storage=sto, max_iters=N_stated)
+        blk10, _ = measure(cfg, mapping, S10, K, W, 0x5EED0000 + cfg, ipl=args.ipl, storage=sto, max_iters=N_stated)
+        out["stated_length"] = {"max_iters": N_stated, "replicas": S10, "replicas_per_gib": blk10["replicas_per_gib"],
+                                "hbm_gib_resident": blk10["hbm_gib_resident"], "ms_per_sweep": blk10["ms_per_sweep"],
+                                "realisations_per_s": blk10["realisations_per_s"], "roofline_frac": blk10["roofline"]["frac"],
+                                "recoveries": blk10["recoveries"]}
     if rank == 0 and world == 1:
         sc = one_chain(cfg, 400)
         if cfg in cpu:
@@ -465,10 +481,17 @@ def main():
                 (5, "tiles", 16384, 6, 8, 0, _lib.PHM_MCMC_BIGTREE, "C5")]
         if cfg == 2:
             plan[0] = (3, "tiles", 16384, 12, 6, 0, _lib.PHM_MCMC_BIGTREE, "C3")
+        # C5's tree size with an UNSTRUCTURED sparse Q (a degree-6 neighbour graph: BASELINE configs[4] says "amino-acid Q"): pruning in
+        # the kernel generated for the matrix's pattern (phm_rtc.h) instead of on the matrix cores
+        Qn = synth.neighbour_Q(20, 6)
+        Omn = 1.25 * float(np.max(np.abs(np.diag(Qn))))
+        pidn = np.full(20, 0.05)
+        problems = {"C5_unstructured": (synth.make_tree(5000, Qn, Omn, 0x5EED0005, pidn, init_segments=20), Qn, pidn, Omn)}
+        plan.append((5, "tiles", 16384, 6, 8, 0, _lib.PHM_MCMC_BIGTREE, "C5_unstructured"))
         for c, mp, capS, k, w, sto_c, var, key in plan:
-            z, Q, pid, Om = synth.config_problem(c)
+            z, Q, pid, Om = problems.get(key) or synth.config_problem(c)
             Sx = sized_replicas(z, Q, pid, Om, mp, capS, frac=0.80, storage=sto_c, variant=var, max_iters=k + w + args.burnin)
-            blk, _ = measure(c, mp, Sx, k, w, 0x5EED0000 + c, ipl=8, storage=sto_c, variant=var, tkey=key)
+            blk, _ = measure(c, mp, Sx, k, w, 0x5EED0000 + c, ipl=8, storage=sto_c, variant=var, tkey=key, problem=problems.get(key))
             if var == _lib.PHM_MCMC_BF:
                 blk["layout"] = "n dwell sums + n x n counts incl. self pairs (shortenerbf, src/phylomap.cpp:997-1028) + root state"
             if c in cpu:
@@ -489,6 +512,15 @@ def main():
         t1 = time.perf_counter(); mid.run(40); mid.sync(); d1 = time.perf_counter() - t1
         mid.close()
         blocks["C2_4096_sites"] = {"mapping": "one wave per (tile, branch)", "ms_per_sweep": d1 / 40 * 1e3, "realisations_per_s": E2 * 4096 * 40 / d1}
+        for Sm in (256, 1024):                         # an alignment's sites on the 10 000-tip tree: few tiles (tree passes over level clusters)
+            z, Q, pid, Om = synth.config_problem(3)
+            mid = _lib.Engine(z, Q, pid, Om, 52, variant=_lib.PHM_MCMC_BIGTREE, seed=1, n_replicas=Sm, reduce=True, device=local_rank, mapping="tiles")
+            mid.run(12); mid.sync()
+            t1 = time.perf_counter(); mid.run(40); mid.sync(); d1 = time.perf_counter() - t1
+            nl = mid.info().last_run_launches // 40
+            mid.close()
+            blocks[f"C3_{Sm}_sites"] = {"mapping": "one wave per (tile, branch)", "ms_per_sweep": d1 / 40 * 1e3, "launches_per_sweep": nl,
+                                        "realisations_per_s": z["edge"].shape[0] * Sm * 40 / d1}
 
         # sumstatEXP (src/phylomap.cpp:3001-3051): C1 as stated, and the 1 000-tip 4-state tree with the rescaled pruning pass
         L = _lib.load()

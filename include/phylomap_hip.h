@@ -184,7 +184,8 @@ typedef struct phm_info {
   int32_t iters_done;
   int32_t recoveries;          /* capacity recoveries (rebuild + replay) this handle has gone through; a timed region asserts 0 */
   int32_t mapping;             /* the phm_mapping in force (the automatic choice resolved) */
-  int32_t sparse_chains;       /* bit 0: pruning chains run over the band of the chain matrix; bit 1: forward draws over the band of B */
+  int32_t sparse_chains;       /* bit 0: pruning chains run over the non-zeros of the chain matrix; bit 1: forward draws over the band of B;
+                                  bit 2: the pruning kernel was generated for the matrix's pattern (unstructured sparsity, hipRTC) */
   int32_t reserved;
 } phm_info;
 
@@ -284,6 +285,14 @@ int32_t phm_maketreelistEXP(          /* src/phylomap.cpp:3001, src/RcppExports.
  * (column-major, edited in place) given a statistics row: n dwell sums then n*n counts, row-major (from,to). */
 int32_t phm_qupdate_apply(int32_t variant, int32_t n_states, double* Q, double Omega, const double* prior, int32_t n_prior,
                           const double* row, uint64_t seed, uint32_t iter);
+
+/* ---- inspection: the pruning kernel generated for an unstructured sparse chain matrix (no device needed) ----
+ * 5..32 states, PHM_MAP_TILES: when the chain matrix (B, or B thresholded at 1e-7 for SPARSEmaketreelistMCMC, src/phylomap.cpp:801-816)
+ * is at most half full and not banded, its pruning chains run in a kernel generated for the matrix's PATTERN and compiled at model
+ * upload through hipRTC (what SPARSEmakePLrcpp :490-501 gets from sp_mat for any pattern).  This returns that kernel's HIP source for the
+ * non-zero pattern of the n x n column-major matrix M: the number of bytes needed (including the terminator); up to `cap` bytes are
+ * written to `buf` (may be NULL). */
+int32_t phm_sparse_kernel_source(int32_t n_states, const double* M, char* buf, int32_t cap);
 
 /* ---- host-side traversal orders (no device needed) ----
  * O(E) native replacement of the R helper preamble pruningwiseedgeorder / makenodelist / myreorder

@@ -286,6 +286,121 @@ static double r_dpois(double x, double lambda) {
 }
 double orc_r_dpois(double x, double lambda) { return r_dpois(x, lambda); }
 
+/* Rf_rgamma(a, scale) as the rate updates call it (src/phylomap.cpp:1202,1235,1463,1538,1612,1681,1748): R's nmath/rgamma.c --
+ * Ahrens & Dieter GS (1974) for a < 1, GD (1982) for a >= 1 -- with norm_rand() of the default kind INVERSION (two unif_rand()
+ * through qnorm5 = Wichura's AS 241, nmath/qnorm.c) and exp_rand().  Third-party code outside /root/reference, restated from the
+ * published sources and UNVERIFIED against R here (no R): the quantile function is checked against scipy to 1e-15 and the
+ * variates distributionally (tests/test_oracle_cpu.py); tools/r_parity pins them wherever R exists.  R keeps the a-dependent
+ * set-up of GD in static variables keyed by a; recomputing it on every call gives the same values. */
+static double r_qnorm_std(double p) {                                  /* qnorm5(p, 0, 1, lower = TRUE, log = FALSE), 0 < p < 1 */
+  const double q = p - 0.5;
+  double r, val;
+  if (fabs(q) <= 0.425) {                                              /* 0.075 <= p <= 0.925 */
+    r = .180625 - q * q;
+    return q * (((((((r * 2509.0809287301226727 + 33430.575583588128105) * r + 67265.770927008700853) * r + 45921.953931549871457) * r +
+                   13731.693765509461125) * r + 1971.5909503065514427) * r + 133.14166789178437745) * r + 3.387132872796366608) /
+           (((((((r * 5226.495278852545925 + 28729.085735721942674) * r + 39307.89580009271061) * r + 21213.794301586595867) * r +
+               5394.1960214247511077) * r + 687.1870074920579083) * r + 42.313330701600911252) * r + 1.);
+  }
+  r = (q < 0) ? p : 1.0 - p;                                           /* min(p, 1 - p) */
+  r = sqrt(-log(r));
+  if (r <= 5.) {
+    r += -1.6;
+    val = (((((((r * 7.7454501427834140764e-4 + .0227238449892691845833) * r + .24178072517745061177) * r + 1.27045825245236838258) * r +
+              3.64784832476320460504) * r + 5.7694972214606914055) * r + 4.6303378461565452959) * r + 1.42343711074968357734) /
+          (((((((r * 1.05075007164441684324e-9 + 5.475938084995344946e-4) * r + .0151986665636164571966) * r + .14810397642748007459) * r +
+              .68976733498510000455) * r + 1.6763848301838038494) * r + 2.05319162663775882187) * r + 1.);
+  } else {
+    r += -5.;
+    val = (((((((r * 2.01033439929228813265e-7 + 2.71155556874348757815e-5) * r + .0012426609473880784386) * r + .026532189526576123093) * r +
+              .29656057182850489123) * r + 1.7848265399172913358) * r + 5.4637849111641143699) * r + 6.6579046435011037772) /
+          (((((((r * 2.04426310338993978564e-15 + 1.4215117583164458887e-7) * r + 1.8463183175100546818e-5) * r + 7.868691311456132591e-4) * r +
+              .0148753612908506148525) * r + .13692988092273580531) * r + .59983224999778524471) * r + 1.);
+  }
+  return (q < 0.0) ? -val : val;
+}
+static double r_norm_rand(void) {                                      /* snorm.c, INVERSION: unif_rand() alone has too few bits */
+  const double BIG = 134217728;                                        /* 2^27 */
+  double u = r_unif_rand();
+  u = (int)(BIG * u) + r_unif_rand();
+  return r_qnorm_std(u / BIG);
+}
+static double r_rgamma(double a, double scale) {
+  const double sqrt32 = 5.656854, exp_m1 = 0.36787944117144233;
+  const double q1 = 0.04166669, q2 = 0.02083148, q3 = 0.00801191, q4 = 0.00144121, q5 = -7.388e-5, q6 = 2.4511e-4, q7 = 2.424e-4;
+  const double a1 = 0.3333333, a2 = -0.250003, a3 = 0.2000062, a4 = -0.1662921, a5 = 0.1423657, a6 = -0.1367177, a7 = 0.1233795;
+  double e, p, q, r, t, u, v, w, x, ret_val;
+  if (isnan(a) || isnan(scale)) return NAN;
+  if (a <= 0.0 || scale <= 0.0) return (scale == 0. || a == 0.) ? 0. : NAN;
+  if (!isfinite(a) || !isfinite(scale)) return INFINITY;
+  if (a < 1) {                                                         /* GS */
+    e = 1.0 + exp_m1 * a;
+    for (;;) {
+      p = e * r_unif_rand();
+      if (p >= 1.0) {
+        x = -log((e - p) / a);
+        if (r_exp_rand() >= (1.0 - a) * log(x)) break;
+      } else {
+        x = exp(log(p) / a);
+        if (r_exp_rand() >= x) break;
+      }
+    }
+    return scale * x;
+  }
+  /* GD.  Step 1 */
+  const double s2 = a - 0.5, s = sqrt(s2), d = sqrt32 - s * 12;
+  /* Step 2: t = standard normal deviate, x = (s, 1/2)-normal deviate; immediate acceptance */
+  t = r_norm_rand();
+  x = s + 0.5 * t;
+  ret_val = x * x;
+  if (t >= 0) return scale * ret_val;
+  /* Step 3: squeeze acceptance */
+  u = r_unif_rand();
+  if (d * u <= t * t * t) return scale * ret_val;
+  /* Step 4 */
+  r = 1 / a;
+  const double q0 = ((((((q7 * r + q6) * r + q5) * r + q4) * r + q3) * r + q2) * r + q1) * r;
+  double b, si, c;
+  if (a <= 3.686) { b = 0.463 + s + 0.178 * s2; si = 1.235; c = 0.195 / s - 0.079 + 0.16 * s; }
+  else if (a <= 13.022) { b = 1.654 + 0.0076 * s2; si = 1.68 / s + 0.275; c = 0.062 / s + 0.024; }
+  else { b = 1.77; si = 0.75; c = 0.1515 / s; }
+  /* Step 5-7: quotient test */
+  if (x > 0.0) {
+    v = t / (s + s);
+    if (fabs(v) <= 0.25) q = q0 + 0.5 * t * t * ((((((a7 * v + a6) * v + a5) * v + a4) * v + a3) * v + a2) * v + a1) * v;
+    else q = q0 - s * t + 0.25 * t * t + (s2 + s2) * log(1.0 + v);
+    if (log(1.0 - u) <= q) return scale * ret_val;
+  }
+  for (;;) {
+    /* Step 8: e = standard exponential, u = uniform, t = (b, si)-double exponential */
+    e = r_exp_rand();
+    u = r_unif_rand();
+    u = u + u - 1.0;
+    t = (u < 0.0) ? b - si * e : b + si * e;
+    /* Step 9: rejection if t < tau(1) */
+    if (t >= -0.71874483771719) {
+      v = t / (s + s);
+      if (fabs(v) <= 0.25) q = q0 + 0.5 * t * t * ((((((a7 * v + a6) * v + a5) * v + a4) * v + a3) * v + a2) * v + a1) * v;
+      else q = q0 - s * t + 0.25 * t * t + (s2 + s2) * log(1.0 + v);
+      /* Step 11: hat acceptance */
+      if (q > 0.0) {
+        w = expm1(q);
+        if (c * fabs(u) <= w * exp(e - 0.5 * t * t)) break;
+      }
+    }
+  }
+  x = s + 0.5 * t;
+  return scale * x * x;
+}
+double orc_r_qnorm(double p) { return r_qnorm_std(p); }
+/* set.seed(seed); rnorm(n_norm); rgamma(n_gamma, shape, scale = scale) */
+int orc_rstream_gamma_selftest(uint32_t seed, int n_norm, int n_gamma, double shape, double scale, double* norm_out, double* gamma_out) {
+  r_set_seed(seed);
+  for (int i = 0; i < n_norm; ++i) norm_out[i] = r_norm_rand();
+  for (int i = 0; i < n_gamma; ++i) gamma_out[i] = r_rgamma(shape, scale);
+  return 0;
+}
+
 int orc_rstream_selftest(uint32_t seed, int n_unif, int n_exp, double* unif_out, double* exp_out) {   /* set.seed; runif(n_unif); rexp(n_exp) */
   r_set_seed(seed);
   for (int i = 0; i < n_unif; ++i) unif_out[i] = r_unif_rand();
@@ -711,10 +826,12 @@ static void fill_dump(orc_dump* dump, const Branch* brs, int E, const int32_t* r
 typedef struct { rngctx* rc; uint32_t iter; uint32_t ent; uint32_t d; } hstream;
 static double hs_u(hstream* h) {
   orc_rng* r = h->rc->r;
+  if (r->mode == 2) return r_unif_rand();                                 /* R-stream mode: runif(1) of R's own generator, in call order */
   if (r->mode == 1) return draw_u(h->rc, h->iter, h->ent, h->d++);
   return orc_stream_u(r->seed_lo, r->seed_hi, 0xFFFFFFFFu, h->iter, h->ent, h->d++);
 }
 static double hs_rgamma(hstream* h, double a, double scale) {
+  if (h->rc->r->mode == 2) return r_rgamma(a, scale);                     /* R-stream mode: Rf_rgamma itself (restated above) */
   double boost = 1.0;
   if (a < 1.0) { double u = hs_u(h); boost = pow(u, 1.0 / a); a += 1.0; }
   const double d = a - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
@@ -1000,7 +1117,7 @@ static int mcmc_driver(const orc_tree* x, int n, const double* Q_cm, const doubl
   for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) QQ(i, j) = Q_cm[i + (size_t)j * n];
   rngctx rc = { rng, 0, 0 };
   g_rstream = (rng->mode == 2);
-  if (g_rstream) { if (prior) { free(Q); return ORC_ERR_BAD_INPUT; } r_set_seed(rng->seed_lo); }   /* rgamma is not restated */
+  if (g_rstream) r_set_seed(rng->seed_lo);
 
   double* B2 = (double*)malloc(sizeof(double) * n * n);       /* row-major copies */
   double* Bc = (double*)malloc(sizeof(double) * n * n);

@@ -102,6 +102,9 @@ double orc_stream_u(uint32_t seed_lo, uint32_t seed_hi, uint32_t replica, uint32
 
 double orc_r_dpois(double x, double lambda);   /* R's dpois_raw (stirlerr + bd0, R <= 4.0.x), what R-stream mode puts in place of the recurrence */
 int orc_rstream_selftest(uint32_t seed, int n_unif, int n_exp, double* unif_out, double* exp_out);   /* set.seed(seed); runif(n_unif); rexp(n_exp) */
+double orc_r_qnorm(double p);   /* R's qnorm5(p, 0, 1, TRUE, FALSE) (Wichura AS 241), behind norm_rand() of kind INVERSION */
+/* set.seed(seed); rnorm(n_norm); rgamma(n_gamma, shape, scale = scale) -- Rf_rgamma (Ahrens-Dieter GD / GS) as restated for R-stream mode */
+int orc_rstream_gamma_selftest(uint32_t seed, int n_norm, int n_gamma, double shape, double scale, double* norm_out, double* gamma_out);
 
 /* ---- per-function entry points for known-answer tests ---- */
 /* shortener  src/phylomap.cpp:44-73; returns new segment count; stats row gets += counts */

@@ -24,7 +24,7 @@ EXPORTS = [
     "phm_engine_info", "phm_engine_destroy", "phm_engine_reduced_stats_device",
     "phm_engine_time_pruning", "phm_tree_orders",
     "phm_engine_create_multi", "phm_maketreelistMCMCmt", "phm_maketreelistMCMCksmt", "phm_engine_phase_ms",
-    "phm_last_kernel_ms", "phm_set_debug_options",
+    "phm_last_kernel_ms", "phm_set_debug_options", "phm_sparse_kernel_source",
 ]
 
 
@@ -144,6 +144,7 @@ def load():
         L.phm_expm_pade.argtypes = [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32, C.c_int32,
                                     C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.phm_set_debug_options.argtypes = [C.POINTER(DebugOptions)]
+        L.phm_sparse_kernel_source.argtypes = [C.c_int32, C.POINTER(C.c_double), C.c_char_p, C.c_int32]
         for which, mirror in enumerate((Options, Info, Tree, Model, DebugOptions)):      # the ctypes mirrors must match the C layout
             if L.phm_struct_size(which) != C.sizeof(mirror):
                 raise RuntimeError(f"{LIB_PATH}: {mirror.__name__} is {L.phm_struct_size(which)} bytes in the library, "
@@ -203,6 +204,18 @@ def tree_orders(z):
     root = C.c_int32(0)
     check(load().phm_tree_orders(T, E, _p(flat, C.c_int32), _p(nen, C.c_int32), _p(nodelist, C.c_int32), C.byref(root)))
     return nen, nodelist[: int(z["Nnode"]) - 1], int(root.value)
+
+
+def sparse_kernel_source(M):
+    """HIP source of the pruning kernel the library generates for the non-zero pattern of the chain matrix ``M`` (phm_rtc.h)."""
+    Mf = np.asfortranarray(np.asarray(M, dtype=np.float64))
+    L = load()
+    need = L.phm_sparse_kernel_source(Mf.shape[0], _p(Mf, C.c_double), None, 0)
+    if need < 0:
+        check(1)
+    buf = C.create_string_buffer(need)
+    L.phm_sparse_kernel_source(Mf.shape[0], _p(Mf, C.c_double), buf, need)
+    return buf.value.decode()
 
 
 MAPPING = {"auto": 0, "replicas": 1, "branches": 2, "tiles": 3}

@@ -170,6 +170,23 @@ int32_t phm_SPARSEmaketreelistMCMC(const phm_tree* x, int32_t n, const double* Q
 
 }  // extern "C"
 
+// the HIP source of the pruning kernel generated for the non-zero pattern of M (phm_rtc.h); inspection / build checks
+extern "C" int32_t phm_sparse_kernel_source(int32_t n, const double* M, char* buf, int32_t cap) {
+  if (!M || n < 2 || n > phm::RTC_SPARSE_NMAX) return fail(PHM_ERR_BAD_INPUT, "phm_sparse_kernel_source: 2 <= n_states <= 32, M not NULL") ? -1 : -1;
+  std::vector<int32_t> rp(1, 0), cj;
+  for (int i = 0; i < n; ++i) {
+    for (int j = 0; j < n; ++j) if (M[i + (size_t)j * n] != 0.0) cj.push_back(j);
+    rp.push_back((int32_t)cj.size());
+  }
+  const std::string src = phm::rtc_sparse_up_source(n, rp, cj);
+  if (buf && cap > 0) {
+    const size_t k = std::min((size_t)cap - 1, src.size());
+    std::memcpy(buf, src.data(), k);
+    buf[k] = '\0';
+  }
+  return (int32_t)src.size() + 1;
+}
+
 // Native O(E) replacement of pruningwiseedgeorder / makenodelist / myreorder (R/sumstatMCMC.R:1-18); pure host code.
 extern "C" int32_t phm_tree_orders(int32_t n_tips, int32_t n_edge, const int32_t* edge, int32_t* nen, int32_t* nodelist,
                                    int32_t* root) {

@@ -182,8 +182,35 @@ int32_t upload_model(phm_engine* e) {
       const int hbc = half_bandwidth(e->hBc), hb2 = half_bandwidth(e->hB2);
       e->pwt.band_up = usable(hbc) ? hbc : 0;
       e->pwt.band_draw = usable(hb2) ? hb2 : 0;
-      if (e->sparse_req == 1 && (!e->pwt.band_up || !e->pwt.band_draw))
-        return fail(PHM_ERR_UNSUPPORTED, "sparse_chains = 1: the band kernels take n <= 32 states and a half-bandwidth of B of at most 2");
+      // Any other sparse pattern (an amino-acid neighbour structure is not banded): a pruning kernel generated for the pattern of the
+      // chain matrix and compiled now (phm_rtc.h); cached per pattern, so a rate update that keeps the zeros only refreshes the values.
+      e->wt_sparse.kernel = nullptr;
+      if (!e->pwt.band_up && e->sparse_req != 2 && n <= phm::RTC_SPARSE_NMAX) {
+        std::vector<int32_t> rp(1, 0), cj;
+        std::vector<double> cv;
+        for (int i = 0; i < n; ++i) {
+          for (int j = 0; j < n; ++j) if (e->hBc[(size_t)i * n + j] != 0.0) { cj.push_back(j); cv.push_back(e->hBc[(size_t)i * n + j]); }
+          rp.push_back((int32_t)cj.size());
+        }
+        if ((double)cj.size() <= phm::RTC_SPARSE_MAX_FILL * n * n) {
+          std::string rerr;
+          const phm::SparseUpKernel* k = phm::rtc_sparse_up_kernel(n, rp, cj, rerr);
+          if (!k && e->sparse_req == 1) return fail(PHM_ERR_UNSUPPORTED, "sparse_chains = 1: " + rerr);
+          if (k) {
+            if (!e->d_wt_coef.p) HIPCHK(e->d_wt_coef.alloc(sizeof(double) * (size_t)n * n));
+            HIPCHK(hipMemcpy(e->d_wt_coef.p, cv.data(), sizeof(double) * cv.size(), hipMemcpyHostToDevice));
+            phm::RtcUpParams& r = e->wt_sparse.params;
+            const phm::WtParams& w = e->pwt;
+            r.n_states = n; r.ldt = w.ldt; r.n_tips = w.n_tips; r.n_node = w.n_node; r.n_edge = w.n_edge; r.n_tiles = w.n_tiles;
+            r.normalise = w.normalise; r.tips_per_replica = w.tips_per_replica; r.tip_masks = w.tip_masks; r.klong = w.klong;
+            r.up = reinterpret_cast<const phm::RtcUpStep*>(w.up); r.up_order = w.up_order; r.colL = w.colL; r.maskL = w.maskL; r.tips = w.tips;
+            r.mcount = w.mcount; r.PL = w.PL; r.err = w.err; r.coef = e->d_wt_coef.as<double>();
+            e->wt_sparse.kernel = k;
+          }
+        }
+      }
+      if (e->sparse_req == 1 && !e->pwt.band_up && !e->wt_sparse.kernel)
+        return fail(PHM_ERR_UNSUPPORTED, "sparse_chains = 1: the sparse pruning kernels take n <= 32 states and a chain matrix that is banded (half-bandwidth <= 2) or at most half full");
       std::memset(&e->wt_band, 0, sizeof e->wt_band);
       if (e->pwt.band_up) {
         const int hb = e->pwt.band_up, w = 2 * hb + 1;
@@ -1291,7 +1318,7 @@ int32_t phm_engine_run(phm_engine* e, int32_t n_iters, void* hip_stream) {
       if (e->n == 2) le = phm::launch_tiles_sweep<2>(e->t2, e->nw_up_off, e->nw_down_off, e->nw_tier_off, it, stream, pev);
       if (e->n == 3) le = phm::launch_tiles_sweep<3>(e->t3, e->nw_up_off, e->nw_down_off, e->nw_tier_off, it, stream, pev);
       if (e->n == 4) le = phm::launch_tiles_sweep<4>(e->t4, e->nw_up_off, e->nw_down_off, e->nw_tier_off, it, stream, pev);
-      if (e->wide) le = phm::launch_wtiles_sweep(e->pwt, e->wt_band, e->nw_up_off, e->nw_down_off, it, stream, pev);
+      if (e->wide) le = phm::launch_wtiles_sweep(e->pwt, e->wt_band, e->wt_sparse, e->nw_up_off, e->nw_down_off, it, stream, pev);
       const bool clusters = !e->wide && !e->nw_tier_off.empty();
       launches += clusters ? 2 * ((int)e->nw_tier_off.size() - 1) + 3      // a launch per tier and pass, branch kernel, two reductions
                            : (int)(e->nw_up_off.size() + e->nw_down_off.size()) + 2;
@@ -1605,7 +1632,7 @@ int32_t phm_engine_info(phm_engine* e, phm_info* info) {
   info->last_run_ms = e->last_ms; info->last_run_launches = e->last_launches; info->iters_done = e->iters_done;
   info->recoveries = e->recoveries;
   info->mapping = e->narrow ? PHM_MAP_BRANCHES : e->tiled ? PHM_MAP_TILES : PHM_MAP_REPLICAS;
-  info->sparse_chains = (e->tiled && e->wide) ? (e->pwt.band_up > 0) + 2 * (e->pwt.band_draw > 0) : 0;
+  info->sparse_chains = (e->tiled && e->wide) ? (e->pwt.band_up > 0 || e->wt_sparse.kernel != nullptr) + 2 * (e->pwt.band_draw > 0) + 4 * (e->wt_sparse.kernel != nullptr) : 0;
   return PHM_OK;
 }
 
@@ -1657,7 +1684,7 @@ extern "C" int32_t phm_engine_time_pruning(phm_engine* e, int32_t n_iters, void*
   hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
   HIPCHK(hipEventRecord(e->ev0, stream));
   hipError_t le = hipSuccess;
-  if (wt) for (int i = 0; i < n_iters && le == hipSuccess; ++i) le = phm::launch_wtiles_up(e->pwt, e->wt_band, e->nw_up_off, stream);
+  if (wt) for (int i = 0; i < n_iters && le == hipSuccess; ++i) le = phm::launch_wtiles_up(e->pwt, e->wt_band, e->wt_sparse, e->nw_up_off, stream);
   // iteration index = iters_done keeps the dwell ping-pong parity; nothing but PL is written
   if (!wt && e->n == 2) { auto p = e->p2; p.prune_only = 1; for (int i = 0; i < n_iters && le == hipSuccess; ++i) le = phm::launch_mcmc<2>(p, e->iters_done, 1, stream); }
   if (e->n == 3) { auto p = e->p3; p.prune_only = 1; for (int i = 0; i < n_iters && le == hipSuccess; ++i) le = phm::launch_mcmc<3>(p, e->iters_done, 1, stream); }

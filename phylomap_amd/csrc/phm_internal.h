@@ -273,6 +273,8 @@ struct phm_engine {
   phm::WtParams pwt;
   DevBuf d_wt_dwfx, d_wt_segacc, d_wt_B2, d_wt_totL, d_wt_pair_slot, d_wt_slot_col, d_wt_B2band, d_wt_mstate, d_wt_dwfx_tile, d_wt_cnt_tile;
   phm::WtBand wt_band;                            // band of the chain matrix (kernel-argument constants of wt_up_band_kernel)
+  phm::WtSparseUp wt_sparse;                      // pruning kernel generated for the pattern of an unstructured sparse chain matrix (phm_rtc.h)
+  DevBuf d_wt_coef;                               // ... and its coefficients (the non-zeros row by row)
   int sparse_req = 0;                              // phm_options.sparse_chains
   phm_debug_options dbg = {};                      // the creating thread's phm_set_debug_options at creation
   bool phase_timing = false;                       // phm_debug_options.phase_timing: HIP events between the phases of a (tile, item) sweep
@@ -296,7 +298,7 @@ struct phm_engine {
                      &d_nw_up_order, &d_nw_down_order, &d_nw_border, &d_nw_off, &d_nw_colL, &d_nw_rowL, &d_nw_maskL, &d_nw_mcount,
                      &d_nw_dwA, &d_nw_dwB, &d_nw_mstate, &d_nw_mlen, &d_nw_estate, &d_nw_part, &d_nw_rowbuf, &d_nw_down_lv, &d_nw_dmap, &d_nw_dmap_edge, &d_nw_walk_off, &d_nw_edge_parent, &d_nw_cl_nodes, &d_nw_cl_item_off, &d_nw_cl_lvl_ptr, &d_nw_cl_lvl_off, &d_ell_col, &d_ell_val,
                      &d_ell2_col, &d_ell2_val, &d_wb_cnt, &d_tl_slot, &d_tl_pdw, &d_tl_pchunk, &d_tl_cnt, &d_tl_estate, &d_tl_pseg,
-                     &d_tl_segprev, &d_wt_dwfx, &d_wt_segacc, &d_wt_B2, &d_wt_totL, &d_wt_pair_slot, &d_wt_slot_col, &d_wt_B2band, &d_wt_mstate, &d_wt_dwfx_tile, &d_wt_cnt_tile};
+                     &d_tl_segprev, &d_wt_dwfx, &d_wt_segacc, &d_wt_B2, &d_wt_totL, &d_wt_pair_slot, &d_wt_slot_col, &d_wt_B2band, &d_wt_mstate, &d_wt_dwfx_tile, &d_wt_cnt_tile, &d_wt_coef};
     for (DevBuf* b : all) b->reset();
   }
   ~phm_engine() {

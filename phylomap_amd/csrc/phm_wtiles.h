@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "phm_device.h"
+#include "phm_rtc.h"
 #include "phm_sched.h"
 
 namespace phm {
@@ -103,10 +104,16 @@ struct WtParams {
   unsigned long long* segcnt;
 };
 
+// the pruning kernel generated for the pattern of an unstructured sparse chain matrix (phm_rtc.h), or none
+struct WtSparseUp {
+  const SparseUpKernel* kernel = nullptr;
+  RtcUpParams params;
+};
+
 // phase_ev: optional 5 events, as in launch_tiles_sweep
-hipError_t launch_wtiles_sweep(const WtParams& p, const WtBand& band, const std::vector<int32_t>& up_off,
+hipError_t launch_wtiles_sweep(const WtParams& p, const WtBand& band, const WtSparseUp& sparse, const std::vector<int32_t>& up_off,
                                const std::vector<int32_t>& down_off, int it, hipStream_t stream, hipEvent_t* phase_ev = nullptr);
 // the pruning (up) sweep alone, for bench.py's roofline block
-hipError_t launch_wtiles_up(const WtParams& p, const WtBand& band, const std::vector<int32_t>& up_off, hipStream_t stream);
+hipError_t launch_wtiles_up(const WtParams& p, const WtBand& band, const WtSparseUp& sparse, const std::vector<int32_t>& up_off, hipStream_t stream);
 
 }  // namespace phm

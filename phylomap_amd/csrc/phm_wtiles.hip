@@ -1178,7 +1178,8 @@ void launch_up_band(const WtParams& p, const WtBand& band, const std::vector<int
   }
 }
 
-hipError_t launch_wtiles_up(const WtParams& p, const WtBand& band, const std::vector<int32_t>& up_off, hipStream_t stream) {
+hipError_t launch_wtiles_up(const WtParams& p, const WtBand& band, const WtSparseUp& sparse, const std::vector<int32_t>& up_off, hipStream_t stream) {
+  if (sparse.kernel) return launch_sparse_up(*sparse.kernel, sparse.params, up_off, stream);      // unstructured sparse chain matrix: the kernel generated for its pattern
   if (p.band_up > 0) {                                  // banded chain matrix: per-lane FMAs over the band
     const int np = (p.n_states + 3) / 4;               // vectors padded to a multiple of four states
 #define PHM_BAND_CASE(NPQ)                                                                          \
@@ -1201,13 +1202,13 @@ hipError_t launch_wtiles_up(const WtParams& p, const WtBand& band, const std::ve
   return e != hipSuccess ? e : hipGetLastError();
 }
 
-hipError_t launch_wtiles_sweep(const WtParams& p, const WtBand& band, const std::vector<int32_t>& up_off,
+hipError_t launch_wtiles_sweep(const WtParams& p, const WtBand& band, const WtSparseUp& sparse, const std::vector<int32_t>& up_off,
                                const std::vector<int32_t>& down_off, int it, hipStream_t stream, hipEvent_t* phase_ev) {
   constexpr int WPB = WT_BLOCK / 64;
   auto blocks = [&](int64_t items) { return dim3((unsigned)((items + WPB - 1) / WPB)); };
   auto mark = [&](int i) { if (phase_ev) (void)hipEventRecord(phase_ev[i], stream); };
   mark(0);
-  hipError_t e = launch_wtiles_up(p, band, up_off, stream);
+  hipError_t e = launch_wtiles_up(p, band, sparse, up_off, stream);
   if (e != hipSuccess) return e;
   mark(1);
   hipLaunchKernelGGL(wt_root_kernel, blocks(p.n_tiles), dim3(WT_BLOCK), 0, stream, p, it);

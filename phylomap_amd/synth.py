@@ -100,6 +100,25 @@ def tridiagonal_Q(n=20, rate=0.003) -> np.ndarray:
     return Q
 
 
+def neighbour_Q(n=20, degree=6, rate=0.03, seed=0x5EED0005) -> np.ndarray:
+    """An UNSTRUCTURED sparse rate matrix: a symmetric neighbour graph in which every state exchanges with `degree` others (the
+    shape of an amino-acid model restricted to single-nucleotide neighbours: BASELINE configs[4] says "sparse 20-state amino-acid Q").
+    A ring lattice (neighbours at distance 1 .. degree / 2) under a random relabelling of the states, so the matrix is not banded;
+    rates rate * U(0.5, 1.5), symmetric."""
+    rs = PhiloxStream(seed, stream=9)
+    perm = list(range(n))
+    for i in range(n - 1, 0, -1):                        # Fisher-Yates on the generator's stream
+        j = int(rs.uniform() * (i + 1))
+        perm[i], perm[j] = perm[j], perm[i]
+    Q = np.zeros((n, n))
+    for k in range(n):
+        for d in range(1, degree // 2 + 1):
+            a, b = perm[k], perm[(k + d) % n]
+            Q[a, b] = Q[b, a] = rate * (0.5 + rs.uniform())
+    np.fill_diagonal(Q, -Q.sum(axis=1))
+    return Q
+
+
 def dense_Q(n=61, lo=0.005, hi=0.015, seed=0x5EED0004) -> np.ndarray:
     rs = PhiloxStream(seed, stream=7)
     Q = np.zeros((n, n))

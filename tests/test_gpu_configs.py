@@ -238,6 +238,67 @@ def test_c5_band_kernels_equal_the_dense_kernels_bit_for_bit(S):
     assert e.value.status == 2
 
 
+def _neighbour_problem(tips):
+    """C5's tree size with an unstructured sparse Q (degree-6 neighbour graph, not banded)"""
+    Q = synth.neighbour_Q(20, 6)
+    Omega = 1.25 * float(np.max(np.abs(np.diag(Q))))
+    pid = np.full(20, 0.05)
+    z = synth.make_tree(tips, Q, Omega, 0x5EED0005, pid, init_segments=20)
+    return z, Q, pid, Omega, treeorder.pruningwiseedgeorder(z), treeorder.makenodelist(z), treeorder.myreorder(z)
+
+
+@pytest.mark.parametrize("mapping", WIDE_MAPPINGS)
+def test_c5_unstructured_sparse_20_states_5000_tips(mapping):
+    """BASELINE configs[4] says "sparse 20-state amino-acid Q": a neighbour structure, not a band.  SPARSEmakePLrcpp / spmmmmvFORpl
+    (src/phylomap.cpp:490-501, :451-457) walk the non-zeros of ANY sp_mat; here the lane-per-replica mapping prunes with a kernel
+    generated for the pattern of the chain matrix (phm_rtc.h).  5 000 tips, every mapping against the oracle."""
+    z, Q, pid, Omega, nen, nodelist, root = _neighbour_problem(5000)
+    n, N, seed = 20, 4, 909
+    hb = max(abs(i - j) for i in range(n) for j in range(n) if Q[i, j] != 0.0)
+    assert hb > 2 and np.count_nonzero(Q) == n * 7                       # not banded; 6 neighbours + the diagonal
+    S = {"replicas": 66, "branches": 6, "tiles": 130}[mapping]
+    got = api.sumstatMCMC_bigtree(z, Q, pid, Omega, N, seed=seed, n_replicas=S, mapping=mapping)
+    for r in (0, S - 1):
+        want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(n) + Q / Omega, Omega, nen, nodelist, root, N, variant=O.BIGTREE, seed=seed, replica=r)
+        assert rc == 0
+        _check_rows(got[r], want, n, False)
+
+
+@pytest.mark.parametrize("S", [70, 4100])
+def test_c5_unstructured_generated_kernel_equals_the_dense_kernels_bit_for_bit(S):
+    """sparse_chains = 1 (generated kernel required) against 2 (matrix cores): a skipped term is an exact zero, so statistics, partial
+    likelihoods, node states and paths agree to the last bit; the SPARSE driver (thresholded matrix, rescaled) likewise; a rate update
+    that keeps the pattern reuses the kernel; a dense matrix is refused."""
+    z, Q, pid, Omega, nen, nodelist, root = _neighbour_problem(600)
+    n, N, seed = 20, 5, 4400 + S
+    for variant, orc in ((_lib.PHM_MCMC_BIGTREE, O.BIGTREE), (_lib.PHM_MCMC_SPARSE, O.SPARSE | O.FORCE_NORMALISE)):
+        res = {}
+        for sc in (1, 2):
+            eng = _lib.Engine(z, Q, pid, Omega, N, variant=variant, seed=seed, n_replicas=S, mapping="tiles", sparse_chains=sc,
+                              rescale=variant == _lib.PHM_MCMC_SPARSE)
+            eng.run(2); eng.sync()
+            assert eng.info().sparse_chains == (5 if sc == 1 else 0)
+            eng.set_model(Q * 0.9)                       # same zeros, other values: the kernel of the pattern with new coefficients
+            eng.run(N - 2); eng.sync()
+            assert eng.info().sparse_chains == (5 if sc == 1 else 0)
+            res[sc] = (eng.stats(0, N), eng.dump(S - 1))
+            eng.close()
+        np.testing.assert_array_equal(res[1][0], res[2][0])
+        for key in ("seg_count", "node_states", "PL", "seg_dwell"):
+            np.testing.assert_array_equal(res[1][1][key], res[2][1][key])
+        want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(n) + Q / Omega, Omega, nen, nodelist, root, 2, variant=orc, seed=seed, replica=S - 1)
+        assert rc == 0
+        _check_rows(res[1][0][S - 1][:2], want, n, False)
+    # the automatic choice takes the generated kernel too
+    eng = _lib.Engine(z, Q, pid, Omega, 1, variant=_lib.PHM_MCMC_BIGTREE, n_replicas=S, mapping="tiles")
+    assert eng.info().sparse_chains & 4
+    eng.close()
+    z4, Q4, pid4, Om4 = _config(4)[:4]
+    with pytest.raises(_lib.PhmError) as e:
+        _lib.Engine(z4, Q4, pid4, Om4, 1, variant=_lib.PHM_MCMC_BIGTREE, n_replicas=64, mapping="tiles", sparse_chains=1)
+    assert e.value.status == 2
+
+
 @pytest.mark.parametrize("mapping", WIDE_MAPPINGS)
 def test_c5_sparse_variant_on_the_largest_tree_it_survives(mapping):
     """the SPARSE driver proper (thresholded chain matrix, dense forward rows, no rescaling) on a 200-tip tree"""

@@ -315,3 +315,29 @@ def test_bench_line_is_compact():
         assert k in line["roofline"], k
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] == 1
     assert "what" not in text and "prose" not in text
+
+
+def test_generated_sparse_pruning_kernel_compiles_for_gfx950():
+    """The pruning kernel for an unstructured sparse chain matrix is generated at model upload (phm_rtc.cpp) and compiled by hipRTC on
+    the GPU box; here its source is generated for the degree-6 neighbour matrix of tests/test_gpu_configs.py and handed to hipcc
+    (which cross-compiles without a GPU): one fused multiply-add per non-zero, columns ascending inside a row, nothing else."""
+    import shutil
+    import subprocess
+    import tempfile
+    Q = synth.neighbour_Q(20, 6)
+    B = np.eye(20) + Q / (1.25 * np.max(np.abs(np.diag(Q))))
+    src = _lib.sparse_kernel_source(B)
+    assert src.count("__builtin_fma(") == np.count_nonzero(B) == 140
+    for i in range(20):
+        line = [ln for ln in src.splitlines() if f" y[{i}] = a; }}" in ln][0]
+        cols = [int(c) for c in re.findall(r"x\[(\d+)\]", line)]
+        assert cols == sorted(np.nonzero(B[i])[0].tolist())
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    with tempfile.TemporaryDirectory() as d:
+        f = os.path.join(d, "k.hip")
+        open(f, "w").write(src)
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-c", f, "-o", os.path.join(d, "k.o")],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]

@@ -7,6 +7,11 @@ cfg = int(sys.argv[1]); S = int(sys.argv[2]); N = int(sys.argv[3]) if len(sys.ar
 sparse = int(sys.argv[4]) if len(sys.argv) > 4 else 0      # phm_options.sparse_chains: 0 auto, 1 band kernels required, 2 dense
 var = {"bigtree": _lib.PHM_MCMC_BIGTREE, "bf": _lib.PHM_MCMC_BF, "ks": _lib.PHM_MCMC_KS}[sys.argv[5] if len(sys.argv) > 5 else "bigtree"]
 z, Q, pid, Om = synth.config_problem(cfg)
+if os.environ.get("PHM_PROBE_Q") == "neighbour":      # C5's tree size with an UNSTRUCTURED sparse Q (degree-6 neighbour graph: phm_rtc.h)
+    import numpy as np
+    Q = synth.neighbour_Q(Q.shape[0], 6)
+    Om = 1.25 * float(np.max(np.abs(np.diag(Q))))
+    z = synth.make_tree(z["states"].size, Q, Om, 0x5EED0005, pid, init_segments=Q.shape[0])
 E = z["edge"].shape[0]
 eng = _lib.Engine(z, Q, pid, Om, N + 10, variant=var, seed=1, n_replicas=S, reduce=True, mapping="tiles", phase_timing=True, sparse_chains=sparse)
 eng.run(10); eng.sync()
