@@ -315,7 +315,7 @@ static double r_qnorm_std(double p) {                                  /* qnorm5
     val = (((((((r * 2.01033439929228813265e-7 + 2.71155556874348757815e-5) * r + .0012426609473880784386) * r + .026532189526576123093) * r +
               .29656057182850489123) * r + 1.7848265399172913358) * r + 5.4637849111641143699) * r + 6.6579046435011037772) /
           (((((((r * 2.04426310338993978564e-15 + 1.4215117583164458887e-7) * r + 1.8463183175100546818e-5) * r + 7.868691311456132591e-4) * r +
-              .0148753612908506148525) * r + .13692988092273580531) * r + .59983224999778524471) * r + 1.);
+              .0148753612908506148525) * r + .13692988092273580531) * r + .59983220655588793769) * r + 1.);
   }
   return (q < 0.0) ? -val : val;
 }

@@ -679,3 +679,74 @@ def test_r_parity_procedure_file_plumbing(tmp_path):
     assert r.stdout.count("EXACT") == 4 and "sumstatEXP" in r.stdout
     rs = open(os.path.join(root_dir, "tools", "r_parity", "run_reference.R")).read()
     assert "sumstatEXP(z, Q, pid, par$N)" in rs and "eigen(Q)" in rs
+
+
+def test_r_stream_normal_and_gamma_variates():
+    """R-stream mode's Rf_rgamma (Ahrens-Dieter GD / GS with norm_rand by INVERSION, restated from R's published nmath sources; what the
+    rate updates of bf / ks / mt / DIC draw from, src/phylomap.cpp:1202,1235,1463,...).  No R here, so: the quantile function of
+    norm_rand (Wichura's AS 241) against scipy to 1e-15 -- any wrong digit in its 46 coefficients would show at 1e-8 or worse --, the
+    variates against their distributions (Kolmogorov-Smirnov) for shapes on both sides of every branch of the algorithm, and
+    the stream bookkeeping: rnorm(1) consumes exactly two unif_rand()."""
+    import ctypes as C
+    from scipy import stats
+    L = O.lib()
+    L.orc_r_qnorm.restype = C.c_double
+    L.orc_r_qnorm.argtypes = [C.c_double]
+    ps = np.concatenate([np.linspace(1e-6, 1 - 1e-6, 4001), 10.0 ** -np.arange(7, 300, 7.0), [0.075, 0.925, 0.5, 1 - 1e-12]])
+    got = np.array([L.orc_r_qnorm(float(p)) for p in ps])
+    want = stats.norm.ppf(ps)
+    np.testing.assert_allclose(got, want, rtol=2e-15, atol=2e-15)
+
+    def draws(seed, nn, ng, shape=1.0, scale=1.0):
+        a, g = np.zeros(max(nn, 1)), np.zeros(max(ng, 1))
+        L.orc_rstream_gamma_selftest(C.c_uint32(seed), nn, ng, C.c_double(shape), C.c_double(scale),
+                                     a.ctypes.data_as(C.POINTER(C.c_double)), g.ctypes.data_as(C.POINTER(C.c_double)))
+        return a[:nn], g[:ng]
+    # rnorm(1) = qnorm((floor(2^27 u1) + u2) / 2^27) of the first two uniforms of the stream
+    u = np.zeros(2); e = np.zeros(1)
+    L.orc_rstream_selftest(C.c_uint32(42), 2, 0, u.ctypes.data_as(C.POINTER(C.c_double)), e.ctypes.data_as(C.POINTER(C.c_double)))
+    z1 = draws(42, 1, 0)[0][0]
+    assert z1 == L.orc_r_qnorm((np.floor(134217728.0 * u[0]) + u[1]) / 134217728.0)
+    zs = draws(7, 20000, 0)[0]
+    assert stats.kstest(zs, "norm").pvalue > 1e-3 and abs(zs.mean()) < 0.03 and abs(zs.std() - 1) < 0.02
+    for shape, scale in ((0.3, 2.0), (0.95, 1.0), (1.0, 0.5), (2.5, 1.0), (3.686, 1.0), (7.0, 0.1), (13.022, 1.0), (40.0, 0.25), (300.5, 1 / 77.0)):
+        g = draws(11, 0, 20000, shape, scale)[1]
+        assert np.all(g > 0)
+        assert stats.kstest(g, "gamma", args=(shape, 0, scale)).pvalue > 1e-3, (shape, scale)
+
+
+def test_r_stream_mode_drives_the_rate_updating_drivers():
+    """With Rf_rgamma restated, R-stream mode runs sumstatMCMCbf / sumstatMCMCks end to end on R's own stream (tools/r_parity compares
+    them with the package where R exists): deterministic in the seed, dwell rows sum to the tree length, rates stay below Omega,
+    and the posterior means of the rates agree with the Philox-mode runs of the same driver (same sampler, another stream)."""
+    Q2 = np.array([[-0.1, 0.1], [0.1, -0.1]])
+    Omega = 10.0
+    pid = np.array([0.5, 0.5])
+    z = synth.make_tree(40, Q2, 1.0, 0x77, pid)
+    nen, nodelist, root = treeorder.pruningwiseedgeorder(z), treeorder.makenodelist(z), treeorder.myreorder(z)
+    prior = [0.55, 1, 0.56, 1.01]
+    N = 1500
+    means = {True: [], False: []}
+    first = None
+    for rstream in (True, False):
+        for seed in range(1, 7):
+            got, rc = O.maketreelistMCMC(z, Q2, pid, np.eye(2) + Q2 / Omega, Omega, nen, nodelist, root, N, variant=O.BF, seed=seed, prior=prior, rstream=rstream)
+            assert rc == 0
+            np.testing.assert_allclose(got[:, :2].sum(1), z["edge.length"].sum(), rtol=1e-12)
+            assert np.all(got[:, 6:8] > 0) and np.all(got[:, 6:8] < Omega)
+            means[rstream].append(got[300:, 6:8].mean(0))
+            if rstream and seed == 1:
+                first = got
+    again, rc = O.maketreelistMCMC(z, Q2, pid, np.eye(2) + Q2 / Omega, Omega, nen, nodelist, root, N, variant=O.BF, seed=1, prior=prior, rstream=True)
+    np.testing.assert_array_equal(again, first)                     # set.seed(1) reproduces the run
+    # the chain mixes slowly on 40 tips (run means range over 0.2 .. 0.9 in either mode): the two modes agree within that spread
+    mr, mp = np.array(means[True]), np.array(means[False])
+    se = np.sqrt(mr.var(0, ddof=1) / 6 + mp.var(0, ddof=1) / 6)
+    assert np.all(np.abs(mr.mean(0) - mp.mean(0)) < 3.0 * se), (mr.mean(0), mp.mean(0), se)
+    Q4 = synth.make2sQ(.1, .1, .2, .2, 10)
+    z4 = synth.make_tree(30, Q4, 1.0, 0x78, np.full(4, .25))
+    nen, nodelist, root = treeorder.pruningwiseedgeorder(z4), treeorder.makenodelist(z4), treeorder.myreorder(z4)
+    got, rc = O.maketreelistMCMC(z4, Q4, np.full(4, .25), np.eye(4) + Q4 / Omega, Omega, nen, nodelist, root, 50, variant=O.KS, seed=3,
+                                 prior=[1, 10, 2, 10, 20, 2], rstream=True)
+    assert rc == 0
+    np.testing.assert_allclose(got[:, :4].sum(1), z4["edge.length"].sum(), rtol=1e-12)

@@ -48,4 +48,25 @@ if os.path.exists(os.path.join(d, "sumstatEXP.csv")):
     rv = open(os.path.join(d, "R_version.txt")).read().strip() if os.path.exists(os.path.join(d, "R_version.txt")) else "?"
     print(f"sumstatEXP (R {rv}): rc={rc} counts {'EXACT' if counts else 'DIFFER'}, dwell {'within 1e-10' if dwell else 'DIFFER'}")
     ok = ok and counts and dwell and rc == 0
+# the rate-updating drivers: tree sweep + Rf_rgamma (Ahrens-Dieter GD / GS, norm_rand by inversion) + runif on the same stream
+if os.path.exists(os.path.join(d, "sumstatMCMCbf.csv")):
+    parq = np.genfromtxt(os.path.join(d, "params_q.csv"), delimiter=",", names=True)
+    OmQ, NQ, seedQ = float(parq["Omega"]), int(parq["N"]), int(parq["seed"])
+    maps2, names2 = [], []
+    for line in open(os.path.join(d, "maps2.csv")):
+        a, b = line.strip().split(";")
+        maps2.append(np.array([float(v) for v in a.split()]))
+        names2.append(np.array([int(v) for v in b.split()], dtype=np.int32))
+    z2 = dict(z, states=np.loadtxt(os.path.join(d, "states2.csv"), dtype=np.int32), maps=maps2, mapnames=names2)
+    Q2 = np.loadtxt(os.path.join(d, "Q2.csv"), delimiter=",")
+    for name, var, zz, QQ, pp, prior in (("sumstatMCMCbf", O.BF, z2, Q2, np.array([0.5, 0.5]), np.loadtxt(os.path.join(d, "prior_bf.csv"))),
+                                         ("sumstatMCMCks", O.KS, z, Q, pid, np.loadtxt(os.path.join(d, "prior_ks.csv")))):
+        want = np.loadtxt(os.path.join(d, name + ".csv"), delimiter=",")
+        nq = QQ.shape[0]
+        got, rc = O.maketreelistMCMC(zz, QQ, pp, np.eye(nq) + QQ / OmQ, OmQ, nen, nodelist, root, NQ, variant=var, seed=seedQ, prior=prior, rstream=True)
+        got = got[:, :want.shape[1]]
+        counts = np.array_equal(got[:, nq:nq + nq * nq], want[:, nq:nq + nq * nq])
+        rest = np.allclose(np.delete(got, np.s_[nq:nq + nq * nq], axis=1), np.delete(want, np.s_[nq:nq + nq * nq], axis=1), rtol=1e-10, atol=0)
+        print(f"{name}: rc={rc} counts {'EXACT' if counts else 'DIFFER'}, dwell / rates / root state {'within 1e-10' if rest else 'DIFFER'}")
+        ok = ok and counts and rest and rc == 0
 sys.exit(0 if ok else 1)

@@ -23,4 +23,23 @@ with open(os.path.join(out, "maps.csv"), "w") as f:          # one branch per li
         f.write(" ".join("%.17g" % v for v in d) + ";" + " ".join(str(int(v)) for v in s) + "\n")
 with open(os.path.join(out, "params.csv"), "w") as f:
     f.write("Omega,N,seed\n%.17g,%d,%d\n" % (Omega, 25, 101))
+# The rate-updating drivers (Rf_rgamma on R's stream): sumstatMCMCbf on the same tree with two-state data, sumstatMCMCks on the
+# four-state case above; Omega = 10 and the priors of the reference's tutorial (vignettes/phylomap_tutorial.Rnw:204-305)
+Q2 = np.array([[-0.1, 0.1], [0.1, -0.1]])
+st2 = np.asarray(synth.simulate_tips(z["edge"], z["edge.length"], Q2, np.full(2, 0.5), 20260102), dtype=np.int32)      # the same tree, two-state tips
+T = st2.size
+z2 = {"states": st2, "maps": [], "mapnames": []}
+for r in range(z["edge"].shape[0]):                                  # initial paths as R/simulate_2_state_tree.R:19-24: two half-length segments
+    child = int(z["edge"][r, 1])
+    z2["maps"].append(np.full(2, z["edge.length"][r] / 2))
+    z2["mapnames"].append(np.array([1, int(st2[child - 1]) if child <= T else 1], dtype=np.int32))
+np.savetxt(os.path.join(out, "states2.csv"), z2["states"], fmt="%d")
+np.savetxt(os.path.join(out, "Q2.csv"), Q2, fmt="%.17g", delimiter=",")
+with open(os.path.join(out, "maps2.csv"), "w") as f:
+    for d, s in zip(z2["maps"], z2["mapnames"]):
+        f.write(" ".join("%.17g" % v for v in d) + ";" + " ".join(str(int(v)) for v in s) + "\n")
+np.savetxt(os.path.join(out, "prior_bf.csv"), [0.55, 1, 0.56, 1.01], fmt="%.17g")
+np.savetxt(os.path.join(out, "prior_ks.csv"), [1, 10, 2, 10, 20, 2], fmt="%.17g")
+with open(os.path.join(out, "params_q.csv"), "w") as f:
+    f.write("Omega,N,seed\n%.17g,%d,%d\n" % (10.0, 25, 101))
 print("wrote", out)

@@ -38,5 +38,31 @@ z$edge.length <- el
 set.seed(par$seed)
 ss <- sumstatEXP(z, Q, pid, par$N)
 write.table(format(ss, digits = 17), file.path(d, "sumstatEXP.csv"), sep = ",", row.names = FALSE, col.names = FALSE, quote = FALSE)
+# The rate-updating drivers: Rf_rgamma + runif on R's stream after every sweep (src/phylomap.cpp:1299-1300, :1862-1866).  They edit
+# the caller's Q in place (:1212-1217), so each call gets a fresh copy.
+if (file.exists(file.path(d, "params_q.csv"))) {
+  parq <- read.csv(file.path(d, "params_q.csv"))
+  read_maps <- function(f, zz) {
+    lines <- readLines(f); zz$maps <- list(); zz$mapnames <- list()
+    for (i in seq_along(lines)) {
+      p <- strsplit(lines[i], ";")[[1]]
+      dw <- as.numeric(strsplit(p[1], " ")[[1]]); st <- as.integer(strsplit(p[2], " ")[[1]])
+      names(dw) <- st; zz$maps[[i]] <- dw; zz$mapnames[[i]] <- st
+    }
+    zz
+  }
+  z2 <- read_maps(file.path(d, "maps2.csv"), z)
+  z2$states <- scan(file.path(d, "states2.csv"), quiet = TRUE)
+  Q2 <- as.matrix(read.csv(file.path(d, "Q2.csv"), header = FALSE)); dimnames(Q2) <- NULL
+  prior_bf <- scan(file.path(d, "prior_bf.csv"), quiet = TRUE)
+  set.seed(parq$seed)
+  ss <- sumstatMCMCbf(z2, Q2 + 0, c(0.5, 0.5), parq$Omega, parq$N, prior_bf)
+  write.table(format(ss, digits = 17), file.path(d, "sumstatMCMCbf.csv"), sep = ",", row.names = FALSE, col.names = FALSE, quote = FALSE)
+  Q4 <- as.matrix(read.csv(file.path(d, "Q.csv"), header = FALSE)); dimnames(Q4) <- NULL
+  prior_ks <- scan(file.path(d, "prior_ks.csv"), quiet = TRUE)
+  set.seed(parq$seed)
+  ss <- sumstatMCMCks(z, Q4 + 0, pid, parq$Omega, parq$N, prior_ks)
+  write.table(format(ss, digits = 17), file.path(d, "sumstatMCMCks.csv"), sep = ",", row.names = FALSE, col.names = FALSE, quote = FALSE)
+}
 writeLines(paste(R.version$major, R.version$minor, sep = "."), file.path(d, "R_version.txt"))   # dpois_raw changed in R 4.1 (ebd0)
 cat("done\n")
