@@ -90,9 +90,13 @@ def cpu_baseline(cfg, target_s=3.0, all_cores=False):
 
 def load_traffic():
     """HBM bytes per unit and per kernel from this round's rocprofv3 --pmc passes (tools/pmc_target.py -> tools/pmc_summary.py
-    -> profiles/r03_traffic.json); bench.py scales them to its own launch sizes."""
-    f = os.path.join(ROOT, "profiles", "r03_traffic.json")
-    return json.load(open(f)) if os.path.exists(f) else {}
+    -> profiles/r04_traffic.json, entries not re-profiled this round from r03_traffic.json); bench.py scales them to its own launch sizes."""
+    t = {}
+    for rnd in ("r03", "r04"):                     # a configuration re-profiled this round replaces last round's entry
+        f = os.path.join(ROOT, "profiles", f"{rnd}_traffic.json")
+        if os.path.exists(f):
+            t.update(json.load(open(f)))
+    return t
 
 
 def kernel_traffic(entry, *needles):
@@ -124,8 +128,8 @@ def compact_line(out):
     """The ONE stdout line of the bench contract, built from the full result `out` (which goes to gpurun_out/bench_detail_n*.json).
     Numbers only, no prose, < 4 KB (tests/test_host_cpu.py::test_bench_line_is_compact): the round-3 line was 21 KB and the
     driver could not parse it."""
-    line = {k: _r(out[k]) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                                    "vs_baseline", "dtype", "data") if k in out}
+    line = {k: _r(out[k], 9 if k in ("value", "ms_per_step") else 5) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                                                                    "higher_is_better", "scaling", "vs_baseline", "dtype", "data") if k in out}
     cfg = out.get("config", {})
     line["config"] = {k: cfg[k] for k in ("workload", "n_states", "n_tips", "branches", "replicas_total", "max_iters_provisioned", "parallelism") if k in cfg}
     rk = ("bound", "alg_bytes_per_unit", "units_per_launch", "launches", "avg_launch_ms", "achieved", "peak", "unit", "frac", "traffic")

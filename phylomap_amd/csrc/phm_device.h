@@ -30,7 +30,10 @@ constexpr uint32_t ENT_BUNIF  = 3u << 30;
 // ("Crush-resistant"), ten being Random123's default safety margin.  The round function and key schedule are pinned by the
 // published known-answer vectors of both philox4x32-7 and philox4x32-10 (tests/test_oracle_cpu.py); a Philox block is a
 // quarter of the VALU work of a sweep step, so three rounds fewer are 8 % fewer instructions.
-constexpr int PHILOX_ROUNDS = 7;
+#ifndef PHM_EXPERIMENT_PHILOX_ROUNDS      // measurement builds only (docs/EXPERIMENTS.md: what a cheaper generator could buy); never shipped
+#define PHM_EXPERIMENT_PHILOX_ROUNDS 7
+#endif
+constexpr int PHILOX_ROUNDS = PHM_EXPERIMENT_PHILOX_ROUNDS;
 __device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                            uint32_t k0, uint32_t k1, uint32_t (&o)[4]) {
 #pragma unroll

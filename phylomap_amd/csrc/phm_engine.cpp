@@ -26,8 +26,11 @@ inline int narrow_auto_max_replicas(const phm::Schedule& s) {
   for (const phm::DownStep& d : s.down)              // parents before children
     if (d.child >= 0) { depth[d.child] = depth[d.parent] + 1; levels = std::max(levels, depth[d.child] + 1); }
   const double E = (double)s.n_edge;
-  const double cap = (0.008 * levels + 2.6e-5 * E - 0.02) / (5.2e-7 * E);
-  return (int)std::max(16.0, std::min(4096.0, cap));
+  // Round 4 (profiles/r04_probe_crossover.log): with its tree passes over level clusters, counter copies and a workgroup per tile for the
+  // statistics, the (tile, branch) mapping with ONE tile costs 0.03 + 0.0068 levels + 6e-6 E ms per sweep (C1 / C2 / C3: 0.11 / 0.21 / 0.33);
+  // the branch mapping 0.04 + 0.002 levels + 6.5e-7 S E  ->  S* = 454 / 87 / 20 chains (measured crossovers ~500 / ~110 / ~20)
+  const double cap = (0.0048 * levels + 6e-6 * E - 0.01) / (6.5e-7 * E);
+  return (int)std::max(8.0, std::min(4096.0, cap));
 }
 constexpr int TILES_AUTO_MAX_REPLICAS = 262144;
 // 5..64 states: a wave per (replica, branch) (phm_wbranch.hip) exposes S x E waves whatever S is; the lane-per-replica mapping

@@ -108,8 +108,9 @@ def test_long_paths_beyond_the_branch_kernel_windows_two_and_three_states(n):
 
 
 def test_automatic_mapping_follows_tree_size():
-    """profiles/r03_probe_crossover.log: the branch mapping up to ~70 chains on 10 000 tips, ~200 on 1 000 tips, ~1 000 on 100."""
-    for cfg, S, want in [(3, 64, "branches"), (3, 96, "tiles"), (2, 128, "branches"), (2, 512, "tiles"), (1, 512, "branches")]:
+    """profiles/r04_probe_crossover.log: the branch mapping up to ~20 chains on 10 000 tips, ~90 on 1 000 tips, ~450 on 100 (the (tile, branch)
+    mapping with a single tile got 2.5x faster in round 4: level clusters, counter copies)."""
+    for cfg, S, want in [(3, 16, "branches"), (3, 32, "tiles"), (2, 64, "branches"), (2, 128, "tiles"), (1, 256, "branches"), (1, 1024, "tiles")]:
         z, Q, pid, Omega = synth.config_problem(cfg)
         eng = _lib.Engine(z, Q, pid, Omega, 2, variant=_lib.PHM_MCMC_BIGTREE, seed=1, n_replicas=S)
         assert eng.info().mapping == _lib.MAPPING[want], (cfg, S)

@@ -1,6 +1,7 @@
-"""rocprofv3 output of tools/pmc_target.py -> profiles/r03_pmc_<name>_summary.json and one entry of profiles/r03_traffic.json.
+"""rocprofv3 output of tools/pmc_target.py -> <out>/r04_pmc_<name>_summary.json and <out>/r04_traffic_<name>.json (one entry of
+profiles/r04_traffic.json: `python tools/pmc_summary.py --merge profiles` folds the entries into it).
 
-    python tools/pmc_summary.py <name> <units_per_sweep> <warm> <timed> <dir with the passes>
+    python tools/pmc_summary.py <name> <units_per_sweep> <warm> <timed> <dir with the passes> [out dir, default profiles/]
 The directory holds one sub-directory per pass: `trace/` (rocprofv3 --kernel-trace --stats: *_kernel_trace.csv) and `pmc*/`
 (*_counter_collection.csv, one --pmc pass each).  Per kernel (template arguments kept, namespaces dropped) the dispatches are in
 launch order; the last timed / (warm + timed) of them belong to the timed sweeps (every sweep launches the same kernels).
@@ -24,8 +25,24 @@ def short(name):
     return (m.group(1) if m else name).replace(" ", "")
 
 
+ROUND = "r04"
+
+
+def merge(out):
+    tf = os.path.join(out, f"{ROUND}_traffic.json")
+    t = json.load(open(tf)) if os.path.exists(tf) else {}
+    for f in sorted(glob.glob(os.path.join(out, f"{ROUND}_traffic_*.json"))):
+        t.update(json.load(open(f)))
+        os.remove(f)
+    json.dump(t, open(tf, "w"), indent=1)
+    print("merged", sorted(t))
+
+
 def main():
+    if sys.argv[1] == "--merge":
+        return merge(sys.argv[2])
     name, units, warm, timed, d = sys.argv[1], float(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+    out_dir = sys.argv[6] if len(sys.argv) > 6 else os.path.join(ROOT, "profiles")
     frac = timed / float(warm + timed)
     kernels = collections.defaultdict(dict)
     for f in sorted(glob.glob(os.path.join(d, "trace*", "**", "*kernel_trace.csv"), recursive=True)):
@@ -56,14 +73,12 @@ def main():
             total += e["hbm_bytes_per_sweep"]
     out = {"name": name, "units_per_sweep": units, "warm_sweeps": warm, "timed_sweeps": timed, "per": "sweep (counter sums over the timed sweeps / timed)",
            "all_kernels_hbm_bytes_per_unit": total / units, "kernels": {k: kernels[k] for k in sorted(kernels)}}
-    json.dump(out, open(os.path.join(ROOT, "profiles", f"r03_pmc_{name}_summary.json"), "w"), indent=1)
-    tf = os.path.join(ROOT, "profiles", "r03_traffic.json")
-    t = json.load(open(tf)) if os.path.exists(tf) else {}
-    t[name] = {"source": f"profiles/r03_pmc_{name}_summary.json", "units_per_sweep_in_pmc_run": units,
-               "all_kernels_bytes_per_unit": total / units,
-               "kernels": {k: {kk: e[kk] for kk in ("hbm_bytes_per_unit", "launches_per_sweep", "ns_per_sweep", "SQ_INSTS_VALU", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES",
-                                                    "SQ_INSTS_VALU_MFMA_MOPS_F64") if kk in e} for k, e in kernels.items() if "hbm_bytes_per_unit" in e}}
-    json.dump(t, open(tf, "w"), indent=1)
+    json.dump(out, open(os.path.join(out_dir, f"{ROUND}_pmc_{name}_summary.json"), "w"), indent=1)
+    t = {name: {"source": f"profiles/{ROUND}_pmc_{name}_summary.json", "units_per_sweep_in_pmc_run": units,
+                "all_kernels_bytes_per_unit": total / units,
+                "kernels": {k: {kk: e[kk] for kk in ("hbm_bytes_per_unit", "launches_per_sweep", "ns_per_sweep", "SQ_INSTS_VALU", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES",
+                                                     "SQ_INSTS_VALU_MFMA_MOPS_F64") if kk in e} for k, e in kernels.items() if "hbm_bytes_per_unit" in e}}}
+    json.dump(t, open(os.path.join(out_dir, f"{ROUND}_traffic_{name}.json"), "w"), indent=1)
     for k in sorted(kernels, key=lambda k: -kernels[k].get("ns_per_sweep", 0)):
         e = kernels[k]
         print(f"{k[:70]:70s} {e.get('launches_per_sweep', 0):6.1f} launches  {e.get('ns_per_sweep', 0) / 1e6:8.3f} ms  {e.get('hbm_bytes_per_unit', float('nan')):8.1f} B/unit")

@@ -1,5 +1,5 @@
 """The program the rocprofv3 passes of this round run (kernel trace, and one --pmc pass per counter group):
-    python3 tools/pmc_target.py <C2|C3|C4|C4bf|C5|C5dense|EXP_C1|EXP_1000_tips> [replicas | samples]
+    python3 tools/pmc_target.py <C2|C3|C4|C4bf|C5|C5dense|C5_unstructured|EXP_C1|EXP_1000_tips> [replicas | samples]
 W warm-up sweeps, then K timed sweeps of the same engine bench.py measures (same mapping, same options, reduce = 1); prints one JSON
 line with the units (branch x replica) of one sweep.  tools/pmc_summary.py keeps, per kernel, the dispatches of the timed sweeps."""
 import json
@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from phylomap_amd import _lib, api, synth  # noqa: E402
 
 W, K = 14, 3      # the first sweeps start from the initial paths (2 or n segments per branch) and cost less / more than stationary ones
-DEFAULT_S = {"C2": 393216, "C3": 16384, "C4": 65536, "C4bf": 65536, "C5": 16384, "C5dense": 16384}
+DEFAULT_S = {"C2": 393216, "C3": 16384, "C4": 65536, "C4bf": 65536, "C5": 16384, "C5dense": 16384, "C5_unstructured": 16384}
 
 
 def main():
@@ -28,6 +28,11 @@ def main():
     cfg = int(name[1])
     S = int(sys.argv[2]) if len(sys.argv) > 2 else DEFAULT_S[name]
     z, Q, pid, Om = synth.config_problem(cfg)
+    if name == "C5_unstructured":      # C5's size with a degree-6 neighbour graph instead of the band (the kernel generated for the pattern)
+        import numpy as np
+        Q = synth.neighbour_Q(20, 6)
+        Om = 1.25 * float(np.max(np.abs(np.diag(Q))))
+        z = synth.make_tree(5000, Q, Om, 0x5EED0005, pid, init_segments=20)
     variant = _lib.PHM_MCMC_BF if name == "C4bf" else _lib.PHM_MCMC_BIGTREE
     opt = dict(mapping="replicas", storage=2, iters_per_launch=1) if name == "C2" else dict(mapping="tiles")
     if name == "C5dense":
