@@ -722,6 +722,63 @@ __global__ __launch_bounds__(64) void wt_down1_kernel(WtParams p, int it, int be
   if (err) atomicOr(p.err, err);
 }
 
+// ... and for n <= 32 the same one pass with every running sum in registers (NP = n rounded up to a multiple of four): no LDS, a
+// wave per (tile, edge), four waves per workgroup.
+template <int NP>
+__global__ __launch_bounds__(WT_BLOCK) void wt_down1r_kernel(WtParams p, int it, int begin, int end) {
+  const int lane = threadIdx.x & 63;
+  const int item = blockIdx.x * (WT_BLOCK / 64) + (threadIdx.x >> 6);
+  const int n_lvl = end - begin;
+  if (item >= n_lvl * p.n_tiles) return;
+  const int n = p.n_states, ldt = p.ldt;
+  const int tile = item / n_lvl;
+  const DownStep ds = p.down[p.down_order[begin + item % n_lvl]];
+  const int b = ds.edge;
+  const double* __restrict__ PLt = p.PL + (size_t)tile * p.n_node * n * 64;
+  uint8_t* __restrict__ nst = p.nstate + (size_t)tile * p.n_node * 64;
+  const uint8_t* __restrict__ tips_t = p.tips_per_replica ? p.tips + (size_t)tile * p.n_tips * 64 : p.tips;
+  const uint32_t rep = (uint32_t)(p.replica_offset + tile * 64 + lane);
+  const int m = p.mcount[((size_t)tile * p.n_edge + b) * 64 + lane];
+  const int ps = nst[ds.parent * 64 + lane];
+  uint32_t err = 0;
+  int cs;
+  if (ds.child >= 0 || p.tip_masks) {
+    int kk = m - 1;
+    if (kk >= p.klong) { err |= DERR_CAPACITY; kk = p.klong - 1; }
+    const double2* __restrict__ src = reinterpret_cast<const double2*>(p.rowL + ((size_t)kk * n + ps) * ldt);
+    uint32_t node_id;
+    const bool internal = ds.child >= 0;
+    const double* __restrict__ PLc = PLt + (size_t)(internal ? ds.child : 0) * n * 64 + lane;
+    int par = 0;
+    if (internal) node_id = (uint32_t)(ds.child + p.n_tips);
+    else { const int tip = ~ds.child; par = (p.tips_per_replica ? tips_t[tip * 64 + lane] : p.tips[tip]) & 1; node_id = (uint32_t)tip; }
+    const double u = stream_u(p.seed_lo, p.seed_hi, rep, (uint32_t)it, ENT_NODE | node_id, 0);
+    double2 r[NP / 2];
+    double pl[NP];
+#pragma unroll
+    for (int j = 0; j < NP / 2; ++j) { r[j].x = 0.0; r[j].y = 0.0; if (2 * j < n) r[j] = src[j]; }      // rows are padded to ldt (even) with zeros
+#pragma unroll
+    for (int c = 0; c < NP; ++c) pl[c] = internal ? ((c < n) ? PLc[(size_t)c * 64] : 0.0) : (((c & 1) == par) ? 1.0 : 0.0);
+    double cum = 0.0;
+#pragma unroll
+    for (int c = 0; c < NP; ++c) {
+      cum += (c < n) ? ((c & 1) ? r[c >> 1].y : r[c >> 1].x) * pl[c] : 0.0;
+      pl[c] = cum;
+    }
+    if (!(cum > 0.0) || isinf(cum)) err |= DERR_ZERO_PROB;
+    const double thr = u * cum;
+    cs = 0;
+#pragma unroll
+    for (int c = 0; c < NP; ++c) cs += (c < n - 1 && !(thr <= pl[c])) ? 1 : 0;
+    if (internal) nst[ds.child * 64 + lane] = (uint8_t)cs;                                   // :655
+  } else {
+    const int tip = ~ds.child;
+    cs = p.tips_per_replica ? tips_t[tip * 64 + lane] : p.tips[tip];            // :612
+  }
+  p.estate[((size_t)tile * p.n_edge + b) * 64 + lane] = (uint16_t)(ps | (cs << 8));   // updatenodestates :460-475
+  if (err) atomicOr(p.err, err);
+}
+
 // Dynamic LDS of the branch kernel, in this order (offsets in bytes, every piece 16-byte aligned):
 //   b2   : rows of B [n][ldt] (SMALL, or B2L), or its band [n][2 BAND + 1]
 //   dw   : SMALL: dwell sums of the workgroup [n][64] u64
@@ -1223,6 +1280,14 @@ hipError_t launch_wtiles_sweep(const WtParams& p, const WtBand& band, const WtSp
       else hipLaunchKernelGGL(wt_down1_kernel<4>, g1, dim3(64), 32 * 64 * sizeof(double), stream, p, it, down_off[l], down_off[l + 1]);
       continue;
     }
+#ifdef WT_DOWN1R
+    {
+#define PHM_D1R(NPQ) case NPQ: hipLaunchKernelGGL(wt_down1r_kernel<4 * NPQ>, g, dim3(WT_BLOCK), 0, stream, p, it, down_off[l], down_off[l + 1]); break;
+      switch ((p.n_states + 3) / 4) { PHM_D1R(2) PHM_D1R(3) PHM_D1R(4) PHM_D1R(5) PHM_D1R(6) PHM_D1R(7) PHM_D1R(8) default: return hipErrorInvalidValue; }
+#undef PHM_D1R
+      continue;
+    }
+#endif
     if (mt == 1) hipLaunchKernelGGL(wt_down_kernel<1>, g, dim3(WT_BLOCK), 0, stream, p, it, down_off[l], down_off[l + 1]);
     else hipLaunchKernelGGL(wt_down_kernel<2>, g, dim3(WT_BLOCK), 0, stream, p, it, down_off[l], down_off[l + 1]);
   }
