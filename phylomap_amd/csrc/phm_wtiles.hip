@@ -557,88 +557,13 @@ __global__ __launch_bounds__(WT_BLOCK) void wt_root_kernel(WtParams p, int it) {
 }
 
 // child ~ e_ps^T B^(m-1) (.) PL[child]   (Tvmmp :431-436, :651); ks: tips too, against their parity mask (:1384-1397).
-// n <= 32 (wt_down_kernel): two passes over the lane's table row and the child's partial likelihoods, 8 states per round of loads:
-// the first forms the total, the second walks the running sum (the same products in the same order) and stops once every lane of
-// the wave has its state; 55 registers, eight waves per SIMD (C5: 4.1 ms per sweep).  n > 32: wt_down1_kernel below, one pass.
-template <int MT>
-__global__ __launch_bounds__(WT_BLOCK) void wt_down_kernel(WtParams p, int it, int begin, int end) {
-  constexpr int NP = 16 * MT;
-  constexpr int CH = 8;                                // states per round of loads (20 states: 4.1 / 4.4 ms per sweep with 8 / 16)
-  const int lane = threadIdx.x & 63;
-  const int item = blockIdx.x * (WT_BLOCK / 64) + (threadIdx.x >> 6);
-  const int n_lvl = end - begin;
-  if (item >= n_lvl * p.n_tiles) return;
-  const int n = p.n_states, ldt = p.ldt;
-  const int tile = item / n_lvl;
-  const DownStep ds = p.down[p.down_order[begin + item % n_lvl]];
-  const int b = ds.edge;
-  const double* __restrict__ PLt = p.PL + (size_t)tile * p.n_node * n * 64;
-  uint8_t* __restrict__ nst = p.nstate + (size_t)tile * p.n_node * 64;
-  const uint8_t* __restrict__ tips_t = p.tips_per_replica ? p.tips + (size_t)tile * p.n_tips * 64 : p.tips;
-  const uint32_t rep = (uint32_t)(p.replica_offset + tile * 64 + lane);
-  const int m = p.mcount[((size_t)tile * p.n_edge + b) * 64 + lane];
-  const int ps = nst[ds.parent * 64 + lane];
-  uint32_t err = 0;
-  int cs;
-  if (ds.child >= 0 || p.tip_masks) {
-    int kk = m - 1;
-    if (kk >= p.klong) { err |= DERR_CAPACITY; kk = p.klong - 1; }
-    const double2* __restrict__ src = reinterpret_cast<const double2*>(p.rowL + ((size_t)kk * n + ps) * ldt);
-    uint32_t node_id;
-    const double* __restrict__ PLc = PLt + (size_t)(ds.child >= 0 ? ds.child : 0) * n * 64 + lane;
-    int par = 0;
-    if (ds.child >= 0) node_id = (uint32_t)(ds.child + p.n_tips);
-    else { const int tip = ~ds.child; par = (p.tips_per_replica ? tips_t[tip * 64 + lane] : p.tips[tip]) & 1; node_id = (uint32_t)tip; }
-    const bool internal = ds.child >= 0;
-    const double u = stream_u(p.seed_lo, p.seed_hi, rep, (uint32_t)it, ENT_NODE | node_id, 0);
-    auto chunk = [&](const double2* __restrict__ row, int c0, double (&pr)[CH]) {      // products of states c0 .. c0 + CH - 1 (0 beyond n)
-      double2 r[CH / 2];
-      double pl[CH];
-#pragma unroll
-      for (int j = 0; j < CH / 2; ++j) { r[j].x = 0.0; r[j].y = 0.0; if (c0 + 2 * j < n) r[j] = row[(c0 >> 1) + j]; }
-#pragma unroll
-      for (int j = 0; j < CH; ++j) pl[j] = internal ? ((c0 + j < n) ? PLc[(size_t)(c0 + j) * 64] : 0.0) : ((((c0 + j) & 1) == par) ? 1.0 : 0.0);
-#pragma unroll
-      for (int j = 0; j < CH; ++j) pr[j] = (c0 + j < n) ? ((j & 1) ? r[j >> 1].y : r[j >> 1].x) * pl[j] : 0.0;
-    };
-    double total = 0.0;
-#pragma unroll
-    for (int c0 = 0; c0 < NP; c0 += CH) {
-      if (c0 < n) {
-        double pr[CH];
-        chunk(src, c0, pr);
-#pragma unroll
-        for (int j = 0; j < CH; ++j) total += pr[j];
-      }
-    }
-    if (!(total > 0.0) || isinf(total)) err |= DERR_ZERO_PROB;
-    const double thr = u * total;
-    double cum = 0.0;
-    cs = 0;
-    const double2* src2 = src;
-    asm volatile("" : "+v"(src2));                       // second pass: the row is read again (L1 / L2), not kept in 128 registers
-#pragma unroll
-    for (int c0 = 0; c0 < NP; c0 += CH) {
-      if (c0 < n && __any(!(thr <= cum))) {
-        double pr[CH];
-        chunk(src2, c0, pr);
-#pragma unroll
-        for (int j = 0; j < CH; ++j) { cum += pr[j]; cs += (c0 + j < n - 1 && !(thr <= cum)) ? 1 : 0; }
-      }
-    }
-    if (ds.child >= 0) nst[ds.child * 64 + lane] = (uint8_t)cs;                                   // :655
-  } else {
-    const int tip = ~ds.child;
-    cs = p.tips_per_replica ? tips_t[tip * 64 + lane] : p.tips[tip];            // :612
-  }
-  p.estate[((size_t)tile * p.n_edge + b) * 64 + lane] = (uint16_t)(ps | (cs << 8));   // updatenodestates :460-475
-  if (err) atomicOr(p.err, err);
-}
-
-// The same draw in ONE pass over the child's partial likelihoods and the lane's table row (n > 32, where a two-pass form reads
-// 2 x 31 KB per wave and gathers 2 x 30 sixteen-byte pieces per lane from the row table -- one cache-line look-up per lane and
-// piece: the gathers, not HBM, set its pace).  The running sums cum_c (the sampler's own left-to-right sums: cum_c = cum_{c-1} + p_c
-// from +0) are kept for every state -- states 0 .. 31 in LDS ([state][lane], 16 KB per wave), the rest in registers, so that nothing
+// The draw needs the total of its probability vector before it can walk the running sum.  Through round 3 that was two passes over
+// the child's partial likelihoods and the lane's row of the chain table (the total, then the walk); both kernels below make ONE
+// pass and keep the running sums cum_c (the sampler's own left-to-right sums: cum_c = cum_{c-1} + p_c from +0) for every state; the
+// state is then the number of c <= n - 2 with !(thr <= cum_c) -- the comparisons of the two-pass walk on the same numbers.
+// n > 32 (a two-pass form reads 2 x 31 KB per wave and gathers 2 x 30 sixteen-byte pieces per lane from the row table -- one
+// cache-line look-up per lane and piece: the gathers, not HBM, set its pace): the running sums are kept for every state -- states
+// 0 .. 31 in LDS ([state][lane], 16 KB per wave), the rest in registers, so that nothing
 // of the first half occupies registers while the second half's loads are in flight (144 registers: three waves per SIMD, ten per
 // CU by LDS) -- and the state is the number of c <= n - 2 with !(thr <= cum_c): the comparisons of the two-pass walk on the same
 // numbers.  A wave is a workgroup of its own.  C4 at 65 536 replicas: two passes (32 states per round of loads) 6.7 ms per sweep;
@@ -722,8 +647,8 @@ __global__ __launch_bounds__(64) void wt_down1_kernel(WtParams p, int it, int be
   if (err) atomicOr(p.err, err);
 }
 
-// ... and for n <= 32 the same one pass with every running sum in registers (NP = n rounded up to a multiple of four): no LDS, a
-// wave per (tile, edge), four waves per workgroup.
+// n <= 32: every running sum in registers (NP = n rounded up to a multiple of four; 98 registers at 20 states), no LDS, a wave per
+// (tile, edge), four waves per workgroup.  C5: 4.05 -> 3.49 ms per sweep against the two-pass form (55 registers, eight waves per SIMD).
 template <int NP>
 __global__ __launch_bounds__(WT_BLOCK) void wt_down1r_kernel(WtParams p, int it, int begin, int end) {
   const int lane = threadIdx.x & 63;
@@ -1280,16 +1205,11 @@ hipError_t launch_wtiles_sweep(const WtParams& p, const WtBand& band, const WtSp
       else hipLaunchKernelGGL(wt_down1_kernel<4>, g1, dim3(64), 32 * 64 * sizeof(double), stream, p, it, down_off[l], down_off[l + 1]);
       continue;
     }
-#ifdef WT_DOWN1R
     {
 #define PHM_D1R(NPQ) case NPQ: hipLaunchKernelGGL(wt_down1r_kernel<4 * NPQ>, g, dim3(WT_BLOCK), 0, stream, p, it, down_off[l], down_off[l + 1]); break;
       switch ((p.n_states + 3) / 4) { PHM_D1R(2) PHM_D1R(3) PHM_D1R(4) PHM_D1R(5) PHM_D1R(6) PHM_D1R(7) PHM_D1R(8) default: return hipErrorInvalidValue; }
 #undef PHM_D1R
-      continue;
     }
-#endif
-    if (mt == 1) hipLaunchKernelGGL(wt_down_kernel<1>, g, dim3(WT_BLOCK), 0, stream, p, it, down_off[l], down_off[l + 1]);
-    else hipLaunchKernelGGL(wt_down_kernel<2>, g, dim3(WT_BLOCK), 0, stream, p, it, down_off[l], down_off[l + 1]);
   }
   mark(2);
   {

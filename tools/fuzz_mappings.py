@@ -56,9 +56,11 @@ def run(seed, n_cases):
         wants = [O.maketreelistMCMC(z, Q, pid, B, Omega, nen, nodelist, root, N, variant=var, seed=seed, replica=r) for r in reps]
         for mapping in ["replicas", "branches", "tiles"]:
             form = int(rs.integers(3)) if mapping == "tiles" else 0      # pruning kernel of the 5..64-state tile mapping
-            sc = int(rs.choice([0, 0, 2])) if mapping == "tiles" else 0  # band kernels where the matrix offers a band / dense kernels
+            sc = int(rs.choice([0, 0, 2])) if mapping == "tiles" else 0  # band / pattern-generated kernels where the matrix offers zeros, or dense kernels
+            lg = int(rs.integers(4)) if mapping == "tiles" else 0        # round 4: tree passes per level / clusters by height / by subtree size (n <= 4)
+            extra = {"devices": [0, 0] if S < 70 else [0, 0, 0]} if (S > 1 and rs.random() < 0.25) else {}      # round 4: replicas sharded inside the call
             try:
-                got = getattr(api, fn)(z, Q, pid, Omega, N, seed=seed, n_replicas=S, mapping=mapping, pruning_form=form, sparse_chains=sc)
+                got = getattr(api, fn)(z, Q, pid, Omega, N, seed=seed, n_replicas=S, mapping=mapping, pruning_form=form, sparse_chains=sc, level_groups=lg, **extra)
                 if S == 1:
                     got = got[None]
                 err = None
@@ -78,7 +80,7 @@ def run(seed, n_cases):
                     if got is not None and rc == 0:
                         d = np.argwhere(~np.isclose(got[r], want, rtol=1e-10, atol=0, equal_nan=True))
                         print("   differing (row, col):", d[:6].tolist(), "got", [got[r][tuple(x)] for x in d[:3]], "want", [want[tuple(x)] for x in d[:3]])
-                    print(f"MISMATCH case {case}: n={n} band={band} tips={tips} S={S} N={N} {fn} mapping={mapping} form={form} sparse_chains={sc} replica={r} oracle_rc={rc} err={err}")
+                    print(f"MISMATCH case {case}: n={n} band={band} tips={tips} S={S} N={N} {fn} mapping={mapping} form={form} sparse_chains={sc} level_groups={lg} {extra} replica={r} oracle_rc={rc} err={err}")
     return bad
 
 
