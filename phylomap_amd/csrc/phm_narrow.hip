@@ -501,8 +501,6 @@ __device__ __forceinline__ void narrow_branch_body(const NarrowParams<NS>& p, in
     // middle of it would double it
     double pf_len = s_wlen[my_wb], pf_e = s_we[my_eb];
     uint32_t pf_map = s_wmap[my_wb];
-    double xf_len = 0.0, xf_e = 0.0;                 // ... and beyond the windows (below)
-    uint32_t xf_map = 0u;
     for (int i = 1; i <= m; ++i) {
       int si = -1;                                   // i == m: past the last old segment, the running one is complete
       double li = 0.0;
@@ -540,14 +538,8 @@ __device__ __forceinline__ void narrow_branch_body(const NarrowParams<NS>& p, in
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
-            xf_len = s_xlen[gbase]; xf_map = s_xmap[gbase];
           }
-          // as inside the windows, the entry of the NEXT step rides in registers: on a branch of thousands of segments (the
-          // reference's squamate analysis has one of 2 280) nearly every step is out here, and two LDS round trips in the middle
-          // of a step of a few dependent operations doubled it
-          li = xf_len; map_i = xf_map;
-          const int slot = past & (L - 1);
-          if (slot + 1 < L) { xf_len = s_xlen[gbase + slot + 1]; xf_map = s_xmap[gbase + slot + 1]; }
+          li = s_xlen[gbase + (past & (L - 1))]; map_i = s_xmap[gbase + (past & (L - 1))];
         }
         const uint32_t out_i = map_i >> (4 * cur_s);
         si = (int)(out_i & 3u);
@@ -584,11 +576,8 @@ __device__ __forceinline__ void narrow_branch_body(const NarrowParams<NS>& p, in
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
-                xf_e = s_xe[gbase];
               }
-              ev = xf_e;
-              const int eslot = (int)((edraw - (uint32_t)epre) & (L - 1));
-              if (eslot + 1 < L) xf_e = s_xe[gbase + eslot + 1];
+              ev = s_xe[gbase + (int)((edraw - (uint32_t)epre) & (L - 1))];
             }
             const double rl = scale * ev;                                      // :398
             ++edraw;

@@ -114,6 +114,17 @@ def test_one_chain_stays_on_the_first_device_of_the_list():
     np.testing.assert_array_equal(got, want)
 
 
+def test_fewer_chains_or_samples_than_devices():
+    """three chains over four devices: one each on three of them; five EXP samples over eight list entries"""
+    z, Q, pid, Omega = synth.config_problem(2, n_tips=100)
+    want = api.sumstatMCMC_bigtree(z, Q, pid, Omega, N, seed=2, n_replicas=3, device=0)
+    got = api.sumstatMCMC_bigtree(z, Q, pid, Omega, N, seed=2, n_replicas=3, devices=[0, 0, 0, 0])
+    np.testing.assert_array_equal(got[..., 4:], want[..., 4:])
+    np.testing.assert_allclose(got[..., :4], want[..., :4], rtol=1e-12, atol=0)
+    eig = api.eigen_decompose(Q)
+    np.testing.assert_array_equal(api.sumstatEXP(z, Q, pid, 5, eig=eig, seed=4, devices=8 * [0]), api.sumstatEXP(z, Q, pid, 5, eig=eig, seed=4, device=0))
+
+
 def test_bad_device_lists_are_refused():
     z, Q, pid, Omega = synth.config_problem(2, n_tips=50)
     with pytest.raises(_lib.PhmError) as e:

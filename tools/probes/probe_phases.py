@@ -13,7 +13,8 @@ if os.environ.get("PHM_PROBE_Q") == "neighbour":      # C5's tree size with an U
     Om = 1.25 * float(np.max(np.abs(np.diag(Q))))
     z = synth.make_tree(z["states"].size, Q, Om, 0x5EED0005, pid, init_segments=Q.shape[0])
 E = z["edge"].shape[0]
-eng = _lib.Engine(z, Q, pid, Om, N + 10, variant=var, seed=1, n_replicas=S, reduce=True, mapping="tiles", phase_timing=True, sparse_chains=sparse)
+eng = _lib.Engine(z, Q, pid, Om, N + 10, variant=var, seed=1, n_replicas=S, reduce=True, mapping="tiles", phase_timing=True, sparse_chains=sparse,
+                  pruning_form=int(os.environ.get("PHM_PROBE_FORM", "0")))      # PHM_PROBE_FORM: phm_debug_options.pruning_form
 eng.run(10); eng.sync()
 i0 = eng.info()
 eng.run(N); eng.sync()
