@@ -145,17 +145,88 @@ __device__ __forceinline__ void down_edge(const TileParams<NS>& p, int tile, int
   p.estate[((size_t)tile * p.n_edge + b) * 64 + lane] = (uint8_t)(ps | (cs << 4));   // updatenodestates :460-475
 }
 
+// what a node draw reads from memory that does not depend on anything it computes: requested one item ahead by tiles_down_kernel
+template <int NS>
+struct DownLoads {
+  int32_t tile, b, parent, child;
+  int32_t m, ps, tipst;
+  double pl[NS];
+};
+
+template <int NS>
+__device__ __forceinline__ DownLoads<NS> down_request(const TileParams<NS>& p, int item, int n_lvl, int begin, int lane) {
+  DownLoads<NS> d;
+  const DownStep ds = p.down[p.down_order[begin + item % n_lvl]];
+  d.tile = item / n_lvl; d.b = ds.edge; d.parent = ds.parent; d.child = ds.child;
+  d.m = p.mcount[((size_t)d.tile * p.n_edge + d.b) * 64 + lane];
+  d.ps = p.nstate[((size_t)d.tile * p.n_node + d.parent) * 64 + lane];
+  d.tipst = 0;
+  if (d.child >= 0) {
+    const double* __restrict__ PLc = p.PL + ((size_t)d.tile * p.n_node + d.child) * NS * 64 + lane;
+#pragma unroll
+    for (int c = 0; c < NS; ++c) d.pl[c] = PLc[c * 64];
+  } else {
+    const int tip = ~d.child;
+#pragma unroll
+    for (int c = 0; c < NS; ++c) d.pl[c] = 0.0;
+    d.tipst = p.tips_per_replica ? p.tips[((size_t)d.tile * p.n_tips + tip) * 64 + lane] : p.tips[tip];
+  }
+  return d;
+}
+
+// the draw itself on what down_request brought: the same expression as down_edge
+template <int NS>
+__device__ __forceinline__ void down_finish(const TileParams<NS>& p, const DownLoads<NS>& d, int it, int lane, uint32_t& err) {
+  const uint32_t rep = (uint32_t)(p.replica_offset + d.tile * 64 + lane);
+  int cs;
+  if (d.child >= 0 || (p.ks && p.tip_masks)) {
+    int kk = d.m - 1;
+    if (kk >= p.klong) { err |= DERR_CAPACITY; kk = p.klong - 1; }
+    const double* src = p.rowL + ((size_t)kk * NS + d.ps) * NS;
+    double w[NS];
+    uint32_t node_id;
+    if (d.child >= 0) {
+#pragma unroll
+      for (int c = 0; c < NS; ++c) w[c] = src[c] * d.pl[c];
+      node_id = (uint32_t)(d.child + p.n_tips);
+    } else {
+      const int par = d.tipst & 1;
+#pragma unroll
+      for (int c = 0; c < NS; ++c) w[c] = src[c] * (((c & 1) == par) ? 1.0 : 0.0);
+      node_id = (uint32_t)(~d.child);
+    }
+    const double u = stream_u(p.seed_lo, p.seed_hi, rep, (uint32_t)it, ENT_NODE | node_id, 0);
+    cs = sample_cat<NS>(w, u, err);                                            // :655
+    if (d.child >= 0) p.nstate[((size_t)d.tile * p.n_node + d.child) * 64 + lane] = (uint8_t)cs;
+  } else {
+    cs = d.tipst;                                                             // :612
+  }
+  p.estate[((size_t)d.tile * p.n_edge + d.b) * 64 + lane] = (uint8_t)(d.ps | (cs << 4));   // updatenodestates :460-475
+}
+
 template <int NS>
 __global__ __launch_bounds__(TILES_BLOCK) void tiles_down_kernel(TileParams<NS> p, int it, int begin, int end) {
   const int lane = threadIdx.x & 63;
   const int n_lvl = end - begin;
   const int n_items = n_lvl * p.n_tiles;
+  const int stride = gridDim.x * (TILES_BLOCK / 64);
   uint32_t err = 0;
-  // persistent waves: kernel arguments and wave set-up once per wave, not once per (edge, tile): 2.28 -> 2.01 ms per sweep on C3 (the pruning
-  // kernel above loses by the same change: 3.16 -> 3.7)
-  for (int item = blockIdx.x * (TILES_BLOCK / 64) + (threadIdx.x >> 6); item < n_items; item += gridDim.x * (TILES_BLOCK / 64)) {
-    const DownStep ds = p.down[p.down_order[begin + item % n_lvl]];
-    down_edge<NS>(p, item / n_lvl, it, ds.edge, ds.parent, ds.child, lane, err);
+  // Persistent waves (kernel arguments and wave set-up once per wave: 2.28 -> 2.01 ms per sweep on C3; the pruning kernel above loses by
+  // the same change: 3.16 -> 3.7), and -- round 4 -- the NEXT item's segment count, parent state and partial likelihoods are requested
+  // before the current item is drawn: an item is three dependent memory round trips and a dozen operations, the kernel waited 0.84 of
+  // its time (profiles/r04_pmc_C3_summary.json).  A level's items only read states drawn by the previous launch, so running ahead is safe.
+  int item = blockIdx.x * (TILES_BLOCK / 64) + (threadIdx.x >> 6);
+  if (item < n_items) {
+    DownLoads<NS> cur = down_request<NS>(p, item, n_lvl, begin, lane);
+    for (;;) {
+      const int next = item + stride;
+      const bool more = next < n_items;                // wave-uniform
+      DownLoads<NS> nxt = cur;
+      if (more) nxt = down_request<NS>(p, next, n_lvl, begin, lane);
+      down_finish<NS>(p, cur, it, lane, err);
+      if (!more) break;
+      cur = nxt; item = next;
+    }
   }
   if (err) atomicOr(p.err, err);
 }
