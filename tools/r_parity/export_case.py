@@ -8,11 +8,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from phylomap_amd import synth  # noqa: E402
 
 out = sys.argv[1] if len(sys.argv) > 1 else "r_parity_case"
+n_tips = int(sys.argv[2]) if len(sys.argv) > 2 else 12      # 12: the parity case; 1000 / 10000: BASELINE C2 / C3 sizes for time_reference.R
 os.makedirs(out, exist_ok=True)
 Q = synth.make2sQ(.1, .1, .2, .2, 10)
 Omega = 1.25 * float(np.max(np.abs(np.diag(Q))))
 pid = np.full(4, 0.25)
-z = synth.make_tree(12, Q, Omega, 20260101, pid)
+z = synth.make_tree(n_tips, Q, Omega, 20260101, pid)
 np.savetxt(os.path.join(out, "edge.csv"), z["edge"], fmt="%d", delimiter=",")
 np.savetxt(os.path.join(out, "edge_length.csv"), z["edge.length"], fmt="%.17g")
 np.savetxt(os.path.join(out, "states.csv"), z["states"], fmt="%d")
