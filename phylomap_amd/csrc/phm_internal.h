@@ -254,6 +254,7 @@ struct phm_engine {
   std::vector<int32_t> nw_up_off, nw_down_off;     // level boundaries into up_order / down_order
   std::vector<int64_t> nw_off;                     // CSR offsets of the branch slots
   int nw_klong = 0;
+  int nw_n_wide = 0;                           // branches that get a wavefront each in narrow_branch_kernel (narrow_setup)
   int64_t nw_total_cap = 0;
   DevBuf d_nw_up_off, d_nw_down_off, d_nw_up_order, d_nw_down_order, d_nw_border, d_nw_off, d_nw_colL, d_nw_rowL, d_nw_maskL, d_nw_mcount, d_nw_dwA, d_nw_dwB,
       d_nw_mstate, d_nw_mlen, d_nw_estate, d_nw_part, d_nw_rowbuf, d_nw_down_lv, d_nw_dmap, d_nw_dmap_edge, d_nw_walk_off, d_nw_edge_parent, d_nw_cl_nodes, d_nw_cl_item_off, d_nw_cl_lvl_ptr, d_nw_cl_lvl_off, d_ell_col, d_ell_val, d_ell2_col, d_ell2_val;

@@ -36,6 +36,11 @@ namespace phm {
 #ifndef PHM_NARROW_LONG
 #define PHM_NARROW_LONG 128
 #endif
+#ifndef PHM_NARROW_WIDE_SEGMENTS
+#define PHM_NARROW_WIDE_SEGMENTS 96
+#endif
+constexpr int NARROW_LONG = PHM_NARROW_LONG;                     // the branch kernel gives at least min(n_edge / 16, this many) branches a wave each,
+constexpr int NARROW_WIDE_SEGMENTS = PHM_NARROW_WIDE_SEGMENTS;   // and every branch expected to hold this many segments (1 + Omega t_b, or what the caller's path holds)
 constexpr int NARROW_CLUSTER_NODES = PHM_NARROW_CLUSTER_NODES;   // internal nodes per pruning cluster (their vectors: 8 KB of LDS at 4 states)
 constexpr int NARROW_CLUSTER_BLOCK = 512;   // eight lanes per node, 64 nodes per pass
 #ifndef PHM_NARROW_BRANCH_LANES
@@ -50,6 +55,7 @@ struct NarrowParams {
   int32_t n_rep, n_rep_pad, replica_offset, n_tiles;
   int32_t normalise, tips_per_replica, ks, tip_masks, reduce, n_cols;
   int32_t klong;                             // rows of the long chain tables (> every branch capacity)
+  int32_t n_wide;                            // branch kernel: the first n_wide branches of branch_order get a wavefront each
   uint32_t seed_lo, seed_hi;
   int64_t total_cap;                         // doubles per replica in one dwell buffer
   double B2[NS * NS], Bc[NS * NS], scale[NS], pid[NS];

@@ -630,6 +630,199 @@ __device__ __forceinline__ void narrow_branch_body(const NarrowParams<NS>& p, in
   }
 }
 
+// ONE branch, all 64 lanes of the wave (the branches that get a wave of their own): the walk of narrow_branch_body restated wave-wide.
+// A branch of thousands of segments -- the reference's squamate analysis runs Omega = 10 on a tree whose longest branch holds 2 280
+// of them -- spent a millisecond in the eight-lane state machine above, ~100 instructions per step of a lone wave.  Here, 64 old
+// segments at a time:
+//   * lane t computes the transition map of segment i0 + t (as above) and reads its length (one coalesced row);
+//   * the states come from an inclusive SCAN of map compositions over the lanes (maps are functions on NS states: integers, exact),
+//     entered with the state the previous block left;
+//   * transitions are counted by ballots;
+//   * what stays sequential is what the arithmetic specification makes sequential -- the left-to-right sums of a merged segment's
+//     lengths and of the exponential gaps inside it (:54, :391-410) -- as loops over lane indices on wave-uniform values
+//     (v_readlane + one addition per step); the variates are produced 64 at a time, one per lane, and the new pieces ARE those
+//     lanes' values (all but the last piece of a merged segment): they leave as one store per merged segment and variate block.
+// Same operations on the same operands in the same order as the eight-lane walk: same bits.
+__device__ __forceinline__ double readlane_f64(double v, int t) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, t), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), t);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+template <int NS>
+__device__ __forceinline__ uint32_t compose_maps(uint32_t first, uint32_t then) {      // apply `first`, then `then`; bit 2 of an entry: "all-zero probabilities" met on the way
+  uint32_t out = 0;
+#pragma unroll
+  for (int q = 0; q < NS; ++q) {
+    const uint32_t a = (first >> (4 * q)) & 7u;
+    const uint32_t b = (then >> (4 * (a & 3u))) & 7u;
+    out |= (b | (a & 4u)) << (4 * q);
+  }
+  return out;
+}
+
+template <int NS>
+__device__ __forceinline__ void narrow_branch_wide(const NarrowParams<NS>& p, int it, int idx, BranchLds<NS>& sh) {
+  double* s_ltab = sh.ltab;
+  const int lane = threadIdx.x;
+  const int r = blockIdx.y;
+  for (int i = lane; i < 2 * PHM_LOGTAB_N; i += NARROW_BLOCK) s_ltab[i] = logtab_entry(i);
+  const bool KS = p.ks != 0;
+  uint32_t err = 0;
+  const int b = p.branch_order[idx];
+  const uint32_t rep = (uint32_t)(p.replica_offset + r);
+  int32_t* __restrict__ mc = p.mcount + (size_t)r * p.n_edge;
+  const int m = mc[b];
+  const int ps = p.nstate[(size_t)r * p.n_node + p.edge_parent[b]];            // updatenodestates :460-475: the edge's end states
+  const uint32_t ends = (uint32_t)p.dmap_edge[(size_t)r * p.n_edge + b] >> (4 * ps);
+  const int cs = (int)(ends & 3u);
+  if (ends & 4u) err |= DERR_ZERO_PROB;
+  const int64_t o = p.off[b];
+  const int cap = (int)(p.off[b + 1] - o);
+  const double* __restrict__ in = p.dw[it & 1] + (size_t)r * p.total_cap + o;
+  double* __restrict__ out = p.dw[(it & 1) ^ 1] + (size_t)r * p.total_cap + o;
+  const uint32_t ent_s = ENT_BSTATE | (uint32_t)b, ent_e = ENT_BEXP | (uint32_t)b;
+  __syncthreads();
+
+  double acc[NS];
+  uint32_t cnt[NS * NS];
+#pragma unroll
+  for (int c = 0; c < NS; ++c) acc[c] = 0.0;
+#pragma unroll
+  for (int c = 0; c < NS * NS; ++c) cnt[c] = 0u;
+  int cur_s = (m == 1) ? cs : ps;                    // updatenodestates :469-472 (m == 1: the child end wins)
+  double cur_len = in[0];
+  int mnew = 0;
+  bool stuck = false;
+  uint32_t edraw = 0, eblock = 0xFFFFFFFFu;          // variates consumed; the block of 64 the wave holds (lane k: variate 64 eblock + k)
+  double evar = 0.0;
+
+  // the merged segment (sg, len) is complete: virtual jumps, gaps ~ Exp(Omega + q_ss) until it is used up (:391-410); a segment
+  // that is not positive leaves itself and everything after it untouched (the reference's iterators stop advancing, :397, :405-406).
+  // The running sum of the gaps (tot, :399-404) is the only thing taken one gap at a time; the pieces are the gaps themselves,
+  // each in its lane, except the last one (what is left of the segment), and leave as one store.  The dwell sum of the pieces
+  // (:752, added one by one from +0) goes through the same additions as tot up to the last piece: it is tot + (len - tot).
+  auto complete = [&](int sg, double len) {
+    double add;
+    if (stuck || !(0.0 < len)) {
+      stuck = true;
+      if (mnew < cap) { if (lane == 0) out[mnew] = len; } else err |= DERR_CAPACITY;
+      ++mnew;
+      add = len;
+    } else {
+      double scale = p.scale[0];
+#pragma unroll
+      for (int c = 1; c < NS; ++c) scale = (sg == c) ? p.scale[c] : scale;
+      double tot = 0.0;
+      for (;;) {
+        if ((edraw >> 6) != eblock) {
+          eblock = edraw >> 6;
+          evar = neglog_u32(stream_word(p.seed_lo, p.seed_hi, rep, (uint32_t)it, ent_e, (eblock << 6) + (uint32_t)lane), s_ltab);
+        }
+        const double rlv = scale * evar;             // :398, lane k: gap k of the block at this state's rate
+        const int k0 = (int)(edraw & 63u);
+        int k = k0;
+        bool stop = false;
+        while (k < NARROW_BLOCK) {
+          const double nt = tot + readlane_f64(rlv, k);
+          ++k;
+          if (!(nt < len)) { stop = true; break; }
+          tot = nt;
+        }
+        const int nuse = k - k0, j = lane - k0;      // gaps k0 .. k - 1 were used: pieces mnew .. mnew + nuse - 1
+        if (j >= 0 && j < nuse) {
+          const double piece = (stop && j == nuse - 1) ? len - tot : rlv;
+          if (mnew + j < cap) out[mnew + j] = piece; else err |= DERR_CAPACITY;
+        }
+        mnew += nuse;
+        edraw += (uint32_t)nuse;
+        if (stop) break;
+      }
+      add = tot + (len - tot);
+    }
+#pragma unroll
+    for (int c = 0; c < NS; ++c) acc[c] += (sg == c) ? add : 0.0;              // updatedwelltimes :752
+  };
+
+  for (int i0 = 1; i0 < m; i0 += NARROW_BLOCK) {     // old segments i0 .. i0 + 63, one per lane
+    const int ii = i0 + lane;
+    const bool valid = ii < m;
+    const int iic = min(ii, m - 1);
+    const double len = in[iic];
+    int kk = m - iic - 1;
+    if (kk >= p.klong) { if (ii < m - 1) err |= DERR_CAPACITY; kk = p.klong - 1; }
+    const double* beta = p.colL + ((size_t)kk * NS + cs) * NS;
+    double bv[NS];
+#pragma unroll
+    for (int c = 0; c < NS; ++c) bv[c] = beta[c];
+    const double u = u01(stream_word(p.seed_lo, p.seed_hi, rep, (uint32_t)it, ent_s, (uint32_t)max(iic - 1, 0)));
+    uint32_t code = 0;
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+      double pr[NS];
+#pragma unroll
+      for (int c = 0; c < NS; ++c) pr[c] = p.B2[q * NS + c] * bv[c];
+      uint32_t e2 = 0;
+      const int sq = sample_cat<NS>(pr, u, e2);
+      code |= ((uint32_t)sq | (e2 ? 4u : 0u)) << (4 * q);
+    }
+    if (iic == m - 1) code = (uint32_t)cs * 0x1111u;                            // the last segment ends in the child's state
+    if (!valid) code = 0x3210u;                                               // past the branch: the identity (never looked at)
+    uint32_t F = code;                               // inclusive scan: F_t = map_t o ... o map_0 (map_0 applied first)
+#pragma unroll
+    for (int off = 1; off < NARROW_BLOCK; off <<= 1) {
+      const uint32_t G = (uint32_t)__shfl_up((int)F, off, NARROW_BLOCK);
+      if (lane >= off) F = compose_maps<NS>(G, F);
+    }
+    const uint32_t mine = (F >> (4 * cur_s)) & 7u;   // the state after this lane's segment (entered with the wave's running state), and the flag
+    const int my_s = (int)(mine & 3u);
+    int prev_s = __shfl_up(my_s, 1, NARROW_BLOCK);
+    if (lane == 0) prev_s = cur_s;
+    if (valid && (mine & 4u)) err |= DERR_ZERO_PROB;
+    // transitions: shortenerbf :1010-1014 counts every consecutive pair, shortener :65-66 the changes
+#pragma unroll
+    for (int a = 0; a < NS; ++a)
+#pragma unroll
+      for (int c = 0; c < NS; ++c) {
+        if (!KS && a == c) continue;
+        const unsigned long long hit = __ballot(valid && prev_s == a && my_s == c);
+        const int col = KS ? a * NS + c : a * (NS - 1) + (c > a ? c - 1 : c);
+        cnt[col] += (uint32_t)__popcll(hit);
+      }
+    // merged segments: lengths added left to right (:54), completed where the state changes
+    const int nv = min(NARROW_BLOCK, m - i0);
+    const unsigned long long chg = __ballot(valid && my_s != prev_s);           // bit t: segment i0 + t opens a new merged segment
+    int t = 0;
+    while (t < nv) {
+      const unsigned long long rest = chg >> t;
+      if (rest & 1ull) {
+        complete(cur_s, cur_len);
+        cur_s = __builtin_amdgcn_readlane(my_s, t); cur_len = readlane_f64(len, t);
+        ++t;
+        continue;
+      }
+      const int tn = rest ? min(nv, t + (int)__builtin_ctzll(rest)) : nv;
+      for (; t < tn; ++t) cur_len = cur_len + readlane_f64(len, t);
+    }
+  }
+  complete(cur_s, cur_len);                          // i == m: the running merged segment is complete
+  if (mnew > cap) mnew = cap;
+  if (lane == 0) mc[b] = mnew;
+  if (err) atomicOr(p.err, err);
+
+  // one row per wavefront, as narrow_branch_body writes it
+  const int ncnt = KS ? NS * NS : NS * (NS - 1);
+  constexpr int PC = NS + NS * NS + 1;
+  double* part = p.part + ((size_t)r * gridDim.x + blockIdx.x) * PC;
+  if (lane == 0) {
+#pragma unroll
+    for (int c = 0; c < NS; ++c) part[c] = acc[c];
+#pragma unroll
+    for (int c = 0; c < NS * NS; ++c) if (c < ncnt) part[NS + c] = (double)cnt[c];
+    part[PC - 1] = (double)(m + mnew);               // segments read + written
+  }
+}
+
 // The longest branches set the duration of the kernel: the first n_long (sorted order) get a wave each -- one control flow, the
 // walk at its shortest --, the others go eight to a wave: group g of wave k takes position n_long + g * n_waves8 + k, one of
 // the longer branches and seven progressively shorter ones in every wave.
@@ -638,7 +831,7 @@ __global__ __launch_bounds__(NARROW_BLOCK) void narrow_branch_kernel(NarrowParam
   static_assert(NARROW_BLOCK == 64, "one wavefront per workgroup");
   __shared__ BranchLds<NS> sh;
   const int k = (int)blockIdx.x;
-  if (k < n_long) narrow_branch_body<NS, 64>(p, it, k, 0, sh);
+  if (k < n_long) narrow_branch_wide<NS>(p, it, k, sh);
   else narrow_branch_body<NS, 8>(p, it, n_long + (k - n_long), (int)gridDim.x - n_long, sh);
 }
 
@@ -704,7 +897,7 @@ __global__ void narrow_emit_kernel(NarrowParams<NS> p, int it) {
 
 template <int NS>
 static unsigned narrow_branch_waves(const NarrowParams<NS>& p, int& n_long) {
-  n_long = std::min(p.n_edge / 16, PHM_NARROW_LONG);
+  n_long = std::max(0, std::min(p.n_wide, p.n_edge));
   return (unsigned)(n_long + (p.n_edge - n_long + 7) / 8);
 }
 

@@ -107,6 +107,40 @@ def test_long_paths_beyond_the_branch_kernel_windows_two_and_three_states(n):
         _same(got[r], want, n)
 
 
+@pytest.mark.parametrize("fn,variant,n", [("sumstatMCMC", O.PLAIN, 2), ("sumstatMCMC_bigtree", O.BIGTREE, 4), ("sumstatMCMCks_sweep", O.KS, 4)])
+def test_one_branch_of_3000_segments_the_wave_wide_walk(fn, variant, n):
+    """The branches that get a wavefront of their own are walked 64 old segments at a time (narrow_branch_wide: a scan of composed
+    transition maps, ballots for the counts, the left-to-right sums as a loop over lanes).  One branch of 3 000 segments (47 blocks,
+    the last one ragged), one of 65 (one full block and a single lane), one whose path holds a zero-length segment (the reference's
+    iterators stop advancing there, src/phylomap.cpp:397, :405-406), the rest short; several sweeps, so that later sweeps read what
+    the wide walk wrote."""
+    Q = synth.config_Q(1) if n == 2 else synth.config_Q(2)
+    Omega = 1.25 * float(np.max(np.abs(np.diag(Q))))
+    pid = np.full(n, 1.0 / n)
+    z = synth.make_tree(40, Q, Omega, 17, pid, init_segments=3)
+    T = 40
+    if variant == O.KS:
+        z = dict(z, states=((z["states"] - 1) % 2 + 1).astype(np.int32))
+        for b, (p_, c_) in enumerate(z["edge"]):
+            if c_ <= T:
+                z["mapnames"][b][-1] = z["states"][c_ - 1]
+    order = np.argsort(-z["edge.length"])
+    for b, m in zip(order[:3], (3000, 65, 130)):
+        end = z["mapnames"][b][-1]
+        z["maps"][b] = np.full(m, z["edge.length"][b] / m)
+        z["mapnames"][b] = np.array([1] * (m - 1) + [end], dtype=np.int32)
+    b = order[2]
+    z["maps"][b][70] = 0.0                                           # the walk stops cutting here
+    z["edge.length"] = np.array([mp.sum() for mp in z["maps"]])
+    nen, nodelist, root = _orders(z)
+    S, N = 2, 4
+    got = getattr(api, fn)(z, Q, pid, Omega, N, seed=21, n_replicas=S, mapping="branches")
+    for r in range(S):
+        want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(n) + Q / Omega, Omega, nen, nodelist, root, N, variant=variant, seed=21, replica=r)
+        assert rc == 0
+        _same(got[r], want, n, ks=variant == O.KS)
+
+
 def test_automatic_mapping_follows_tree_size():
     """profiles/r04_probe_crossover.log: the branch mapping up to ~20 chains on 10 000 tips, ~90 on 1 000 tips, ~450 on 100 (the (tile, branch)
     mapping with a single tile got 2.5x faster in round 4: level clusters, counter copies)."""
