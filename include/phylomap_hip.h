@@ -159,7 +159,10 @@ typedef struct phm_options {
  * one-shot calls that thread creates afterwards (NULL resets to all-zero). */
 typedef struct phm_debug_options {
   int32_t pruning_form;        /* 5..64 states with PHM_MAP_TILES: form of the pruning kernel, 0 = by tile count, 1 = one wave per
-                                  (node, tile), 2 = one workgroup / wave per 16-replica block (same bits) */
+                                  (node, tile), 2 = one workgroup / wave per 16-replica block (same bits).
+                                  2..4 states with PHM_MAP_BRANCHES: the subtree clusters of the pruning sweep, 0 = by path length
+                                  (some branch expected to hold >= 96 segments: dependency-driven), 1 = a barrier per tree level,
+                                  2 = dependency-driven (same bits) */
   int32_t phase_timing;        /* 1 = record HIP events between the phases of a sweep (phm_engine_phase_ms) */
   int32_t fail_recovery;       /* 1 = every capacity recovery "does not fit" (exercises the dead-handle path) */
   int32_t branch_group;        /* > 0: branches per wave of the 5..64-state branch kernel (clamped to 1..64); 0 = automatic */

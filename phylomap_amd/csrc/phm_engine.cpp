@@ -317,7 +317,7 @@ void fill_narrow_params(phm_engine* e, phm::NarrowParams<NS>& p, const phm_optio
   p.n_rep = e->S; p.n_rep_pad = e->S_pad; p.replica_offset = o.replica_offset; p.n_tiles = e->tiles;
   p.normalise = e->normalise; p.tips_per_replica = e->tips_per_replica ? 1 : 0;
   p.ks = ks_layout(e->variant); p.tip_masks = hidden_rates(e->variant); p.reduce = e->reduce; p.n_cols = e->dcols;
-  p.klong = e->nw_klong; p.n_wide = e->nw_n_wide;
+  p.klong = e->nw_klong; p.n_wide = e->nw_n_wide; p.cluster_async = e->nw_cluster_async;
   p.seed_lo = (uint32_t)(o.seed & 0xFFFFFFFFull); p.seed_hi = (uint32_t)(o.seed >> 32);
   p.total_cap = e->nw_total_cap;
   for (int i = 0; i < NS * NS; ++i) { p.B2[i] = e->hB2[i]; p.Bc[i] = e->hBc[i]; }
@@ -425,6 +425,8 @@ int32_t narrow_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
     if (std::max(1.0 + model->Omega * tb, (double)m0) >= phm::NARROW_WIDE_SEGMENTS) ++n_wide;      // a long path: the wave-wide walk (phm_narrow.hip)
   }
   e->nw_n_wide = std::max(n_wide, std::min(E / 16, phm::NARROW_LONG));
+  // long chains: the pruning clusters without level barriers (phm_narrow.hip); debug pruning_form 1 / 2 = never / always
+  e->nw_cluster_async = e->dbg.pruning_form == 2 || (e->dbg.pruning_form == 0 && n_wide > 0);
   e->nw_total_cap = e->nw_off[E];
   e->nw_klong = max_cap + 1;
   e->rows = e->nw_total_cap;

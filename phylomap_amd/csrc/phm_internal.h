@@ -254,6 +254,7 @@ struct phm_engine {
   std::vector<int32_t> nw_up_off, nw_down_off;     // level boundaries into up_order / down_order
   std::vector<int64_t> nw_off;                     // CSR offsets of the branch slots
   int nw_klong = 0;
+  bool nw_cluster_async = false;               // pruning clusters of the branch mapping in their dependency-driven form
   int nw_n_wide = 0;                           // branches that get a wavefront each in narrow_branch_kernel (narrow_setup)
   int64_t nw_total_cap = 0;
   DevBuf d_nw_up_off, d_nw_down_off, d_nw_up_order, d_nw_down_order, d_nw_border, d_nw_off, d_nw_colL, d_nw_rowL, d_nw_maskL, d_nw_mcount, d_nw_dwA, d_nw_dwB,

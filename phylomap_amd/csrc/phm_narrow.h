@@ -42,7 +42,10 @@ namespace phm {
 constexpr int NARROW_LONG = PHM_NARROW_LONG;                     // the branch kernel gives at least min(n_edge / 16, this many) branches a wave each,
 constexpr int NARROW_WIDE_SEGMENTS = PHM_NARROW_WIDE_SEGMENTS;   // and every branch expected to hold this many segments (1 + Omega t_b, or what the caller's path holds)
 constexpr int NARROW_CLUSTER_NODES = PHM_NARROW_CLUSTER_NODES;   // internal nodes per pruning cluster (their vectors: 8 KB of LDS at 4 states)
-constexpr int NARROW_CLUSTER_BLOCK = 512;   // eight lanes per node, 64 nodes per pass
+#ifndef PHM_NARROW_CLUSTER_BLOCK
+#define PHM_NARROW_CLUSTER_BLOCK 512
+#endif
+constexpr int NARROW_CLUSTER_BLOCK = PHM_NARROW_CLUSTER_BLOCK;   // eight lanes per node, 64 nodes per pass
 #ifndef PHM_NARROW_BRANCH_LANES
 #define PHM_NARROW_BRANCH_LANES 8
 #endif
@@ -56,6 +59,7 @@ struct NarrowParams {
   int32_t normalise, tips_per_replica, ks, tip_masks, reduce, n_cols;
   int32_t klong;                             // rows of the long chain tables (> every branch capacity)
   int32_t n_wide;                            // branch kernel: the first n_wide branches of branch_order get a wavefront each
+  int32_t cluster_async;                     // pruning sweep: the dependency-driven form of the cluster kernel (long chains)
   uint32_t seed_lo, seed_hi;
   int64_t total_cap;                         // doubles per replica in one dwell buffer
   double B2[NS * NS], Bc[NS * NS], scale[NS], pid[NS];

@@ -57,7 +57,28 @@ __device__ __forceinline__ double swap_quads(double x) {
 //    neighbouring address and drops the value.
 // The vectors also go to the global PL array (the transition maps of the sampling sweep and the clusters above read them);
 // nobody in the kernel waits for those stores.
-template <int NS>
+// the phases of the dependency-driven form below
+enum : int { CL_NEED = 0, CL_WAIT = 1, CL_RUN = 2, CL_JOIN = 3, CL_EXIT = 4 };
+#ifndef PHM_CLUSTER_STRIDE
+#define PHM_CLUSTER_STRIDE 16
+#endif
+constexpr int NARROW_CLUSTER_STRIDE = PHM_CLUSTER_STRIDE;   // chain steps between two looks at the other phases
+
+__device__ __forceinline__ int swap_quads_int(int x) {
+  int t = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xf, 0x5, false);
+  return __builtin_amdgcn_update_dpp(t, x, 0x114, 0xf, 0xa, false);
+}
+
+// ASYNC: the same cluster without level barriers (long chains).  With level barriers a level costs its LONGEST chain, and the
+// sweep the sum of those over the levels; on a tree whose branches hold hundreds of segments (the reference's squamate analysis:
+// Omega = 10, ~111 segments per branch, 2 280 on the longest) that sum is 19 758 chain steps where the longest line of DEPENDENT
+// steps is 2 280.  Here the nodes of the cluster (listed by height, a topological order) are handed out in that order to whichever
+// group of eight lanes is free; a quad starts its child's chain as soon as that child's vector is there (a flag per node in LDS),
+// and the two quads of a group join when both chains are done.  A wave holds eight groups in different phases, so nothing in the
+// loop waits: every pass over the loop body gives each quad NARROW_CLUSTER_STRIDE chain steps or one look at a flag.  Progress:
+// the first unfinished node of the order has been handed out before any later one and its children are finished.
+// Every node is computed by the same instructions on the same operands as in the level form: same bits.
+template <int NS, bool ASYNC>
 __global__ __launch_bounds__(NARROW_CLUSTER_BLOCK) void narrow_cluster_kernel(NarrowParams<NS> p, int first_cluster, int n_clusters, int it, int stats_rows) {
   // Blocks beyond the tier's clusters (first tier of a sweep, stats_rows > 0): the statistics row of the PREVIOUS sweep, one
   // column each -- a launch of its own costs the sweep ~6 us of ramp-up for ~1 us of work, here it rides along for free.
@@ -74,6 +95,8 @@ __global__ __launch_bounds__(NARROW_CLUSTER_BLOCK) void narrow_cluster_kernel(Na
   __shared__ int32_t s_steps[NARROW_CLUSTER_NODES * 2];        // chain steps of (node, child): m - 1, 0 for a tip
   __shared__ int32_t s_slot[NARROW_CLUSTER_NODES * 2];         // child of the same cluster: its position; else -1
   __shared__ int32_t s_parent[NARROW_CLUSTER_NODES];
+  __shared__ int32_t s_done[ASYNC ? NARROW_CLUSTER_NODES : 1];  // ASYNC: the node's vector is in s_pl
+  __shared__ int32_t s_next;                                   // ASYNC: the next node to hand out
   const int cl = first_cluster + blockIdx.x;
   const int r = blockIdx.y;
   const int tid = threadIdx.x;
@@ -141,8 +164,73 @@ __global__ __launch_bounds__(NARROW_CLUSTER_BLOCK) void narrow_cluster_kernel(Na
       }
     }
   }
+  if (ASYNC) {
+    for (int i = tid; i < NARROW_CLUSTER_NODES; i += NARROW_CLUSTER_BLOCK) s_done[i] = 0;
+    if (tid == 0) s_next = 0;
+  }
   lds_barrier();
   PHM_CLK(n_items);
+
+  if (ASYNC) {
+    int phase = CL_NEED, local = 0, slot = -1, steps = 0, i = 0;
+    double v = 0.0;
+    while (__any(phase != CL_EXIT)) {                // wave-uniform: the DPP exchanges below see every lane
+      if (!__any(phase == CL_RUN)) __builtin_amdgcn_s_sleep(1);                // a wave that only waits leaves the SIMD to the one it shares it with
+      const int sib = swap_quads_int(phase);
+      if (phase == CL_NEED) {
+        int nxt = 0;
+        if ((tid & 7) == 0) nxt = atomicAdd(&s_next, 1);
+        local = __shfl(nxt, (tid & 63) & ~7, 64);
+        if (local >= n_items) phase = CL_EXIT;
+        else { slot = s_slot[local * 2 + c]; steps = s_steps[local * 2 + c]; phase = CL_WAIT; }
+      }
+      if (phase == CL_WAIT) {
+        const bool ready = slot < 0 || __hip_atomic_load(&s_done[max(slot, 0)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
+        if (ready) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+          v = (slot >= 0) ? s_pl[slot * NS + q] : s_v0[(local * 2 + c) * NS + q];
+          i = 0;
+          phase = CL_RUN;
+        }
+      }
+      if (phase == CL_RUN) {
+        auto chain_step = [&]() {                    // uniform over the quad
+          double acc = mrow[0] * quad_bcast<0>(v);
+          if (NS > 1) acc += mrow[NS > 1 ? 1 : 0] * quad_bcast<1>(v);
+          if (NS > 2) acc += mrow[NS > 2 ? 2 : 0] * quad_bcast<2>(v);
+          if (NS > 3) acc += mrow[NS > 3 ? 3 : 0] * quad_bcast<3>(v);
+          v = acc;
+        };
+        if (steps - i >= NARROW_CLUSTER_STRIDE) {    // the long chains: a stride without a look at the counter
+#pragma unroll
+          for (int u = 0; u < NARROW_CLUSTER_STRIDE; ++u) chain_step();
+          i += NARROW_CLUSTER_STRIDE;
+        } else {
+          for (; i < steps; ++i) chain_step();
+        }
+        if (i >= steps) phase = CL_JOIN;
+      } else if (phase == CL_JOIN && sib == CL_JOIN) {                         // both chains of the node were done a pass ago
+        const double other = swap_quads(v);
+        double x = c ? v * other : other * v;                                  // "first" (child[1]) times "second" (:510)
+        if (p.normalise) {                                                     // :525
+          double sum = quad_bcast<0>(x);
+          if (NS > 1) sum += quad_bcast<1>(x);
+          if (NS > 2) sum += quad_bcast<2>(x);
+          if (NS > 3) sum += quad_bcast<3>(x);
+          x = x / sum;
+        }
+        if (c == 0 && lane_on) {
+          s_pl[local * NS + q] = x;
+          PLr[(size_t)s_parent[local] * NS + q] = x;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        if ((tid & 7) == 0) __hip_atomic_store(&s_done[local], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        phase = CL_NEED;
+      }
+    }
+    if (err) atomicOr(p.err, err);
+    return;
+  }
 
   int lo = uniform_word(p.cl_lvl_off, lv0) - item0;
   for (int lv = lv0; lv < lv1; ++lv) {
@@ -914,8 +1002,12 @@ hipError_t launch_narrow_sweep(const NarrowParams<NS>& p, const std::vector<int3
   for (size_t t = 0; t + 1 < tier_off.size(); ++t) {
     const unsigned ncl = (unsigned)(tier_off[t + 1] - tier_off[t]);
     const bool carry = t == 0 && stats_pending && !p.reduce;   // reduce: the sweep added its own row below (a second pass would count its segments twice)
-    hipLaunchKernelGGL(narrow_cluster_kernel<NS>, dim3(ncl + (carry ? stat_cols : 0u), S), dim3(NARROW_CLUSTER_BLOCK), 0, stream, p,
-                       tier_off[t], (int)ncl, it, carry ? (int)n_waves : 0);
+    if (p.cluster_async)
+      hipLaunchKernelGGL((narrow_cluster_kernel<NS, true>), dim3(ncl + (carry ? stat_cols : 0u), S), dim3(NARROW_CLUSTER_BLOCK), 0, stream, p,
+                         tier_off[t], (int)ncl, it, carry ? (int)n_waves : 0);
+    else
+      hipLaunchKernelGGL((narrow_cluster_kernel<NS, false>), dim3(ncl + (carry ? stat_cols : 0u), S), dim3(NARROW_CLUSTER_BLOCK), 0, stream, p,
+                         tier_off[t], (int)ncl, it, carry ? (int)n_waves : 0);
   }
   hipLaunchKernelGGL(narrow_downmap_kernel<NS>, dim3((p.n_edge + NARROW_BLOCK - 1) / NARROW_BLOCK, S), dim3(NARROW_BLOCK), 0, stream,
                      p, it);

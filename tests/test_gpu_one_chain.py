@@ -141,6 +141,35 @@ def test_one_branch_of_3000_segments_the_wave_wide_walk(fn, variant, n):
         _same(got[r], want, n, ks=variant == O.KS)
 
 
+@pytest.mark.parametrize("case", ["ladder", "C2", "long"])
+def test_pruning_clusters_with_and_without_level_barriers_same_bits(case):
+    """The subtree clusters of the pruning sweep come in two forms (phm_narrow.hip): a barrier per tree level, or nodes handed out in
+    height order to whichever eight lanes are free, each quad starting when its child's vector is there (chosen when some branch is
+    expected to hold >= 96 segments).  Same instructions per node: identical statistics, on a caterpillar (every node waits for the
+    one below: 256-deep dependencies inside a cluster, three tiers), on C2 and on paths of 300 segments; the dependency-driven form
+    against the oracle as well."""
+    if case == "ladder":
+        Q = synth.config_Q(2); n = 4
+        Omega = 1.25 * float(np.max(np.abs(np.diag(Q))))
+        pid = np.full(4, 0.25)
+        edge, lens = _ladder(700, 1.0 / Omega, 5)
+        z = _tree_from_edges(edge, lens, Q, pid, seed=9)
+    elif case == "C2":
+        z, Q, pid, Omega = synth.config_problem(2); n = 4
+    else:
+        Q = np.array([[-.3, .2, .1], [.05, -.15, .1], [.2, .2, -.4]]); n = 3
+        Omega = 1.25 * float(np.max(np.abs(np.diag(Q))))
+        pid = np.full(3, 1.0 / 3)
+        z = synth.make_tree(60, Q, Omega, 31, pid, init_segments=300)
+    S, N = 3, 5
+    got = {f: api.sumstatMCMC_bigtree(z, Q, pid, Omega, N, seed=8, n_replicas=S, mapping="branches", pruning_form=f) for f in (1, 2)}
+    np.testing.assert_array_equal(got[1], got[2])
+    nen, nodelist, root = _orders(z)
+    want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(n) + Q / Omega, Omega, nen, nodelist, root, N, variant=O.BIGTREE, seed=8, replica=S - 1)
+    assert rc == 0
+    _same(got[2][S - 1], want, n)
+
+
 def test_automatic_mapping_follows_tree_size():
     """profiles/r04_probe_crossover.log: the branch mapping up to ~20 chains on 10 000 tips, ~90 on 1 000 tips, ~450 on 100 (the (tile, branch)
     mapping with a single tile got 2.5x faster in round 4: level clusters, counter copies)."""

@@ -2,6 +2,7 @@ import sys, time, os, numpy as np
 root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, root)
 from phylomap_amd import _lib
+FORM = {'pruning_form': int(os.environ['PHM_PROBE_FORM'])} if 'PHM_PROBE_FORM' in os.environ else {}   # 1 = level barriers, 2 = dependency-driven clusters
 d = np.load(root + '/tests/golden/squamate/seed101_tips.npz')
 E, T = d["edge"].shape[0], len(d["states"])
 z = {"edge": d["edge"], "Nnode": T - 1, "edge.length": d["edge_length"], "states": d["states"]}
@@ -10,7 +11,7 @@ z["mapnames"] = [np.ones(100, dtype=np.int32) if c > T else np.array([1, d["stat
 Q = np.array([[-0.001, 0.001], [0.006, -0.006]])
 for S in (1, 8):
     N = 60
-    eng = _lib.Engine(z, Q, [.5, .5], 10.0, N + 20, variant=_lib.PHM_MCMC_BIGTREE, seed=1, n_replicas=S, mapping="branches", reduce=S > 1)
+    eng = _lib.Engine(z, Q, [.5, .5], 10.0, N + 20, variant=_lib.PHM_MCMC_BIGTREE, seed=1, n_replicas=S, mapping="branches", reduce=S > 1, **FORM)
     eng.run(20); eng.sync()
     t = time.time(); eng.run(N); eng.sync(); dt = time.time() - t
     st = eng.stats(20, N)
