@@ -121,7 +121,10 @@ typedef struct phm_options {
                                   held per replica grows (slowly: a quantile) with max_iters */
   int32_t mapping;             /* phm_mapping: how a sweep is laid over the lanes (one tree); PHM_MAP_AUTO = by replica count.
                                   Same draws and counts in every mapping; dwell sums differ in the last bits between
-                                  PHM_MAP_REPLICAS and the other two (summation order). */
+                                  PHM_MAP_REPLICAS and the other two (summation order).  Path lengths: 65 535 segments per branch
+                                  in PHM_MAP_TILES, slot sizes in PHM_MAP_BRANCHES; PHM_MAP_REPLICAS with 5..64 states (never the
+                                  automatic choice for one tree) holds at most 128 segments per branch and replica and answers
+                                  PHM_ERR_UNSUPPORTED / PHM_ERR_CAPACITY beyond. */
   int32_t storage;             /* dwell-stream storage of PHM_MAP_REPLICAS: 0 = automatic, 1 = one ring per tile (half the HBM),
                                   2 = two buffers (5 % faster sweep for n <= 4) */
   int32_t rescale_pruning;     /* phm_maketreelistEXP: 1 = divide every internal partial-likelihood row by its sum in the pruning

@@ -1110,6 +1110,9 @@ int32_t phm_engine_create_impl(const phm_tree* trees, int32_t n_trees, const phm
       double tb = 0.0;
       for (int i = xt->map_off[d.edge]; i < xt->map_off[d.edge + 1]; ++i) tb += xt->maps[i];
       int m0 = xt->map_off[d.edge + 1] - xt->map_off[d.edge];
+      if (e->wide && m0 > phm::wide_maxseg(n))
+        return fail(PHM_ERR_UNSUPPORTED, "the replica mapping for 5..64 states holds at most " + std::to_string(phm::wide_maxseg(n)) +
+                                         " segments per branch (a path of " + std::to_string(m0) + " was given); use PHM_MAP_TILES or PHM_MAP_BRANCHES (the automatic choice for one tree)");
       init_row[j][k] = (int32_t)init_rows[j];
       init_rows[j] += m0;
       // a sweep keeps at most the m merged segments it was given and adds Poisson(<= Omega t_b) virtual jumps, so a
@@ -1430,8 +1433,11 @@ int32_t phm_engine_sync(phm_engine* e) {
   uint32_t derr = 0;
   std::memcpy(&derr, e->pin_status.p, sizeof derr);
   std::memcpy(&e->seg_total, e->pin_status.as<unsigned char>() + 8, sizeof(unsigned long long));
-  if ((derr & phm::DERR_CAPACITY) && !(derr & ~phm::DERR_CAPACITY) && e->recover && e->saved && !(e->wide && !e->narrow && !e->tiled))
-    return recover_capacity(e);      // (the state-per-lane tile kernel of phm_wide.hip has a fixed 128-segment scratch: not recoverable)
+  const bool wide_replicas = e->wide && !e->narrow && !e->tiled;      // phm_wide.hip: a fixed 128-segment state scratch per replica in LDS, not recoverable
+  if ((derr & phm::DERR_CAPACITY) && !(derr & ~phm::DERR_CAPACITY) && e->recover && e->saved && !wide_replicas) return recover_capacity(e);
+  if ((derr & phm::DERR_CAPACITY) && wide_replicas)
+    return fail(PHM_ERR_CAPACITY, "a branch outgrew the replica mapping for 5..64 states (at most " + std::to_string(phm::wide_maxseg(e->n)) +
+                                  " segments per branch and replica, or the dwell ring); use PHM_MAP_TILES or PHM_MAP_BRANCHES (the automatic choice for one tree)");
   return device_status(derr);
 }
 

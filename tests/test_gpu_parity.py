@@ -856,6 +856,24 @@ def test_random_cases_every_mapping_against_the_oracle():
     assert mod.run(20261003, 120) == 0
 
 
+def test_replica_mapping_for_5_to_64_states_refuses_paths_beyond_its_scratch():
+    """phm_wide.hip keeps the states of one branch in 128 LDS slots per replica: a longer caller-supplied path is refused up front
+    with the way out in the message (the automatic choice for one tree never takes this mapping), and works on the other two."""
+    Q = synth.dense_Q(6, 0.02, 0.3, seed=2)
+    Omega = 1.5 * float(np.max(np.abs(np.diag(Q))))
+    pid = np.full(6, 1.0 / 6)
+    z = synth.make_tree(12, Q, Omega, 5, pid, init_segments=140)
+    with pytest.raises(_lib.PhmError, match="at most 128 segments per branch"):
+        api.sumstatMCMC(z, Q, pid, Omega, 3, seed=1, n_replicas=2, mapping="replicas")
+    nen, nodelist, root = treeorder.pruningwiseedgeorder(z), treeorder.makenodelist(z), treeorder.myreorder(z)
+    want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(6) + Q / Omega, Omega, nen, nodelist, root, 3, seed=1, replica=1)
+    assert rc == 0
+    for mapping in ("tiles", "branches", "auto"):
+        got = api.sumstatMCMC(z, Q, pid, Omega, 3, seed=1, n_replicas=2, mapping=mapping)
+        np.testing.assert_array_equal(got[1][:, 6:], want[:, 6:])
+        np.testing.assert_allclose(got[1][:, :6], want[:, :6], rtol=1e-10, atol=0)
+
+
 @pytest.mark.parametrize("mapping", MAPPINGS)
 def test_capacity_overflow_is_recovered_like_an_unbounded_list(mapping):
     """The reference's std::list paths are unbounded (src/phylomap.cpp:18-21); a fixed HBM layout is not.  cap_tail = 0.9
