@@ -162,7 +162,9 @@ typedef struct phm_options {
  * one-shot calls that thread creates afterwards (NULL resets to all-zero). */
 typedef struct phm_debug_options {
   int32_t pruning_form;        /* 5..64 states with PHM_MAP_TILES: form of the pruning kernel, 0 = by tile count, 1 = one wave per
-                                  (node, tile), 2 = one workgroup / wave per 16-replica block (same bits).
+                                  (node, tile) with the chain matrix in registers, 2 = one workgroup / wave per 16-replica block,
+                                  3 = one wave per (node, tile) with the chain matrix in LDS and two waves per SIMD (33..64 states;
+                                  what 0 chooses there from 192 / 256 tiles on) (same bits).
                                   2..4 states with PHM_MAP_BRANCHES: the subtree clusters of the pruning sweep, 0 = by path length
                                   (some branch expected to hold >= 96 segments: dependency-driven), 1 = a barrier per tree level,
                                   2 = dependency-driven (same bits) */

@@ -249,6 +249,196 @@ __global__ __launch_bounds__(WT_BLOCK) void wt_up_kernel(WtParams p, int begin, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// The same kernel for 33 .. 64 states with TWO waves per SIMD.  wt_up_kernel keeps the chain matrix in registers as A-operand
+// fragments -- 128 registers at 61 states, which with the vectors leaves room for one wave per SIMD: while that wave divides
+// (:525), sorts its columns or waits for a child's vectors the matrix core of its SIMD idles (C4: 51 % of the f64 matrix
+// peak over the pruning launches, profiles/r04_pmc_C4bf_summary.json).  Here the fragments sit in LDS (32 KB per workgroup,
+// lane-contiguous: one conflict-free ds_read_b64 per MFMA, 256 LDS cycles per chain step against 4 096 on the matrix core), and the
+// vectors of the first child of a node with two internal children wait in the PARENT's row of PL (written, fenced, read back by
+// the same wave: it is about to be overwritten by the product anyway) instead of 31 KB of LDS per wave.  Same MFMAs on the same
+// operands in the same order: same bits.
+// ---------------------------------------------------------------------------------------------------------------------
+#ifndef PHM_UP2_WAVES
+#define PHM_UP2_WAVES 2
+#endif
+constexpr int WT_UP2_WAVES = PHM_UP2_WAVES;         // waves per SIMD the kernel is compiled for
+template <int MT, int KSU>                          // KSU = ceil(n / 4): the k-steps that hold a state (the others multiply zeros: skipped)
+__global__ __launch_bounds__(WT_BLOCK, WT_UP2_WAVES) void wt_up2_kernel(WtParams p, int begin, int end) {
+  constexpr int KS = 4 * MT;
+  __shared__ double s_A[MT * KS * 64];               // fragment (i, s): lane l holds Bc[16 i + (l & 15)][4 s + (l >> 4)]
+  __shared__ uint8_t s_perm_all[WT_BLOCK / 64][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int n = p.n_states, ldt = p.ldt;
+  uint8_t* s_perm = s_perm_all[wave];
+  for (int f = wave; f < MT * KS; f += WT_BLOCK / 64) {
+    const int row = 16 * (f / KS) + lr, k = 4 * (f % KS) + lk;
+    s_A[f * 64 + lane] = (row < n && k < n) ? p.Bc[row * n + k] : 0.0;
+  }
+  __syncthreads();
+  const int n_lvl = end - begin;
+  const int64_t items = (int64_t)n_lvl * p.n_tiles;
+  uint32_t err = 0;
+  for (int64_t item = (int64_t)blockIdx.x * (WT_BLOCK / 64) + wave; item < items; item += (int64_t)gridDim.x * (WT_BLOCK / 64)) {
+    const int tile = (int)(item % p.n_tiles), li = (int)(item / p.n_tiles);
+    const UpStep st = p.up[p.up_order[begin + li]];
+    double* __restrict__ PLt = p.PL + (size_t)tile * p.n_node * n * 64;
+    const uint16_t* __restrict__ mct = p.mcount + (size_t)tile * p.n_edge * 64;
+    const uint8_t* __restrict__ tips_t = p.tips_per_replica ? p.tips + (size_t)tile * p.n_tips * 64 : p.tips;
+
+    auto sort_by_chain = [&](int edge) -> int {        // as in wt_up_kernel
+      const int k = (int)mct[edge * 64 + lane] - 1;
+      int rank = 0;
+      for (int t = 0; t < 64; ++t) {
+        const int kt = __builtin_amdgcn_readlane(k, t);
+        rank += (kt < k || (kt == k && t < lane)) ? 1 : 0;
+      }
+      s_perm[rank] = (uint8_t)lane;
+      return k;
+    };
+    auto load_x = [&](int node, int j, d4_t (&X)[MT]) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = 16 * i + lk + 4 * q;
+          X[i][q] = (row < n) ? PLt[((size_t)node * n + row) * 64 + j] : 0.0;
+        }
+    };
+    // Bc^kj applied to the vectors in X, in place: kmax steps on the matrix cores, the lanes of column j stop taking the products
+    // after step kj (a lane's four-state slices all belong to ONE column, l & 15: the finished column rides along unchanged)
+    auto run_chain = [&](d4_t (&X)[MT], int kj) {
+      const int kmax = wave_max_count(kj);
+      // the next EIGHT fragments are requested before the eight MFMAs at hand are issued (a dependent MFMA holds the wave's
+      // instruction stream until its predecessor is done: a read issued behind it would wait out its LDS latency with the matrix
+      // core idle); fragment f of the flattened order belongs to row block f / KSU, k-step f % KSU
+      constexpr int NF = MT * KSU, CH = 8, NCH = (NF + CH - 1) / CH;
+      double af[2][CH];
+      auto fetch = [&](int c, double (&a)[CH]) {
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+          const int f = c * CH + u;
+          if (f < NF) a[u] = s_A[((f / KSU) * KS + f % KSU) * 64 + lane];
+        }
+      };
+      for (int step = 1; step <= kmax; ++step) {
+        __asm__ volatile("" ::: "memory");             // the fragments are read from LDS in every step (hoisted, they would take the registers back)
+        d4_t Y[MT];
+        fetch(0, af[0]);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (c + 1 < NCH) fetch(c + 1, af[(c + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < CH; ++u) {
+            const int f = c * CH + u;
+            if (f < NF) {
+              const int i = f / KSU, ks = f % KSU;
+              if (ks == 0) Y[i] = d4_t{0.0, 0.0, 0.0, 0.0};
+              Y[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[c & 1][u], X[ks >> 2][ks & 3], Y[i], 0, 0, 0);
+            }
+          }
+        }
+        const bool live = step <= kj;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) X[i][q] = live ? Y[i][q] : X[i][q];
+      }
+    };
+    auto tipvec = [&](int child, int edge, int j, d4_t (&R)[MT]) {
+      const int tip = ~child;
+      const int ts = p.tips_per_replica ? tips_t[tip * 64 + j] : p.tips[tip];
+      int k = (int)mct[edge * 64 + j] - 1;
+      if (k >= p.klong) { err |= DERR_CAPACITY; k = p.klong - 1; }
+      const double* __restrict__ src = p.tip_masks ? p.maskL + ((size_t)k * 2 + (ts & 1)) * ldt : p.colL + ((size_t)k * n + ts) * ldt;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = 16 * i + lk + 4 * q;
+          R[i][q] = (row < n) ? src[row] : 0.0;
+        }
+    };
+    auto store = [&](int j, const d4_t (&P)[MT]) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = 16 * i + lk + 4 * q;
+          if (row < n) PLt[((size_t)st.parent * n + row) * 64 + j] = P[i][q];
+        }
+    };
+    auto finish = [&](int j, const d4_t (&R0)[MT], const d4_t (&R1)[MT]) {      // first (.) second (:510), / sum (:525)
+      d4_t P[MT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) P[i] = R0[i] * R1[i];
+      if (p.normalise) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) t += P[i][q];
+        t = t + __shfl_xor(t, 16, 64);
+        t = t + __shfl_xor(t, 32, 64);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) P[i][q] = P[i][q] / t;
+      }
+      store(j, P);
+    };
+
+    const bool int_first = st.child[1] >= 0, int_second = st.child[0] >= 0;
+    if (!int_first && !int_second) {
+      for (int nt = 0; nt < 4; ++nt) {
+        const int j = 16 * nt + lr;
+        d4_t R0[MT], R1[MT];
+        tipvec(st.child[1], st.edge[1], j, R0);
+        tipvec(st.child[0], st.edge[0], j, R1);
+        finish(j, R0, R1);
+      }
+    } else if (int_first != int_second) {
+      const int ci = int_first ? 1 : 0;                // the internal child
+      const int k = sort_by_chain(st.edge[ci]);
+      for (int nt = 0; nt < 4; ++nt) {
+        const int j = s_perm[16 * nt + lr];
+        const int kj = __shfl(k, j, 64);
+        d4_t X[MT], Rt[MT];
+        load_x(st.child[ci], j, X);
+        run_chain(X, kj);
+        tipvec(st.child[1 - ci], st.edge[1 - ci], j, Rt);
+        if (int_first) finish(j, X, Rt); else finish(j, Rt, X);
+      }
+    } else {
+      const int k1 = sort_by_chain(st.edge[1]);
+      for (int nt = 0; nt < 4; ++nt) {
+        const int j = s_perm[16 * nt + lr];
+        const int kj = __shfl(k1, j, 64);
+        d4_t X[MT];
+        load_x(st.child[1], j, X);
+        run_chain(X, kj);
+        store(j, X);                                   // waits in the parent's row
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      const int k0 = sort_by_chain(st.edge[0]);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      for (int nt = 0; nt < 4; ++nt) {
+        const int j = s_perm[16 * nt + lr];
+        const int kj = __shfl(k0, j, 64);
+        d4_t X[MT], R0[MT];
+        load_x(st.child[0], j, X);
+        run_chain(X, kj);
+        load_x(st.parent, j, R0);
+        finish(j, R0, X);
+      }
+    }
+  }
+  if (err) atomicOr(p.err, err);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Pruning through a BANDED chain matrix (tridiagonal amino-acid-style or count-valued Q: half-bandwidth 1; the hidden-rates
 // Q of make2sQ: 2) -- what SPARSEmakePLrcpp / spmmmmvFORpl (src/phylomap.cpp:490-501, :451-457) exploit through sp_mat.
 // One LANE per replica, a wave per (node, tile): the lane keeps its child vector in registers and applies
@@ -1125,7 +1315,9 @@ hipError_t launch_up_levels(const WtParams& p, const std::vector<int32_t>& up_of
   }
   // Measured crossovers (profiles/r02_probe_few_tiles.log): the row-split workgroups win below about 64 tiles at 20 states and
   // below about 512 tiles at 61 states; the sorted blocks of the per-tile kernel beyond.
-  const int msplit_tiles = MT == 2 ? 64 : MT == 3 ? 192 : 512;
+  // Round 4: beyond 32 states the per-tile kernel runs two waves per SIMD (wt_up2_kernel) and takes over from 256 tiles at 61 states
+  // (profiles/r04_probe_c4_up2.log: 128 tiles 4.96 split / 6.40 ms, 256 tiles 9.46 / 9.03, 512 tiles 17.7 / 15.3, 1 024 tiles 32.7 / 28.8).
+  const int msplit_tiles = MT == 2 ? 64 : MT == 3 ? 192 : 256;
   const bool few_tiles = p.n_tiles < WT_FEW_TILES;      // n <= 16 (one row block): not enough (node, tile) items to fill the chip -> a wave per block
   for (size_t l = 0; l + 1 < up_off.size(); ++l) {
     const int cnt = up_off[l + 1] - up_off[l];
@@ -1139,6 +1331,16 @@ hipError_t launch_up_levels(const WtParams& p, const std::vector<int32_t>& up_of
       const int64_t items = (int64_t)cnt * p.n_tiles * 4;    // a wave per (node, tile, block)
       const unsigned grid = (unsigned)std::min<int64_t>((items + 3) / 4, 2048);
       hipLaunchKernelGGL(wt_up_blocks_kernel<MT>, dim3(grid), dim3(WT_BLOCK), 0, stream, p, up_off[l], up_off[l + 1]);
+    } else if (MT >= 3 && p.up_form != 1) {             // up_form 1 keeps the one-wave-per-SIMD kernel (measurement)
+      const int64_t items = (int64_t)cnt * p.n_tiles;        // a wave per (node, tile), two waves per SIMD
+      const unsigned grid = (unsigned)std::min<int64_t>((items + 3) / 4, 256 * WT_UP2_WAVES);      // persistent: WT_UP2_WAVES workgroups per CU
+      constexpr int M2 = MT >= 3 ? MT : 3;
+      switch ((p.n_states + 3) / 4 - 4 * (M2 - 1)) {         // k-steps in the last row block: 1 .. 4
+        case 1: hipLaunchKernelGGL((wt_up2_kernel<M2, 4 * M2 - 3>), dim3(grid), dim3(WT_BLOCK), 0, stream, p, up_off[l], up_off[l + 1]); break;
+        case 2: hipLaunchKernelGGL((wt_up2_kernel<M2, 4 * M2 - 2>), dim3(grid), dim3(WT_BLOCK), 0, stream, p, up_off[l], up_off[l + 1]); break;
+        case 3: hipLaunchKernelGGL((wt_up2_kernel<M2, 4 * M2 - 1>), dim3(grid), dim3(WT_BLOCK), 0, stream, p, up_off[l], up_off[l + 1]); break;
+        default: hipLaunchKernelGGL((wt_up2_kernel<M2, 4 * M2>), dim3(grid), dim3(WT_BLOCK), 0, stream, p, up_off[l], up_off[l + 1]); break;
+      }
     } else {
       const int64_t items = (int64_t)cnt * p.n_tiles;        // a wave per (node, tile)
       const unsigned grid = (unsigned)std::min<int64_t>((items + 3) / 4, 2048);      // persistent waves: the matrix fragments load once

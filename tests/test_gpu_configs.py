@@ -367,7 +367,7 @@ def test_exp_rescaled_pruning_at_c2_size_and_equal_to_plain_on_small_trees():
 
 # 16 / 10 tiles: a workgroup per 16-replica block, a wave per 16-state row block; 113 tiles: the same at 61 states, sorted blocks
 # per (node, tile) at 20; forms 1 / 2: each pruning kernel at a tile count the automatic choice gives to the other
-@pytest.mark.parametrize("cfg,S,form", [(4, 1024, 0), (5, 640, 0), (4, 7232, 0), (5, 7232, 0), (4, 7232, 1), (5, 7232, 2), (4, 192, 1)])
+@pytest.mark.parametrize("cfg,S,form", [(4, 1024, 0), (5, 640, 0), (4, 7232, 0), (5, 7232, 0), (4, 7232, 1), (5, 7232, 2), (4, 192, 1), (4, 7232, 3)])
 def test_wide_lane_per_replica_mapping_with_many_tiles(cfg, S, form):
     """phm_wtiles.hip beyond a couple of tiles: persistent pruning waves striding over (node, tile) items, branch groups per
     workgroup, per-tile accumulators -- C4 / C5 at their stated sizes with 16 / 10 tiles, replicas from different tiles and

@@ -319,12 +319,12 @@ def test_wide_kernel_matches_oracle(n, fn, variant, mapping):
     np.testing.assert_allclose(red[:, :n], got.sum(0)[:, :n], rtol=1e-12)
 
 
-@pytest.mark.parametrize("form", [1, 2])
-@pytest.mark.parametrize("n", [12, 24, 40, 61])
+@pytest.mark.parametrize("n,form", [(n, f) for n in (12, 24, 40, 61) for f in (1, 2)] + [(33, 3), (40, 3), (48, 3), (61, 3)])
 def test_wide_tiles_pruning_kernels_agree(n, form):
     """The pruning pass of the lane-per-replica mapping has three kernels chosen by tile count (a wave per (node, tile) with sorted
     blocks; for few tiles a workgroup per 16-replica block with a wave per row block, or a wave per block when n <= 16): each
-    forced (pruning_form) on a problem the automatic choice gives to another, 1 / 2 / 3 / 4 row blocks, against the oracle."""
+    forced (pruning_form) on a problem the automatic choice gives to another, 1 / 2 / 3 / 4 row blocks, against the oracle.  Form 3
+    (33 .. 64 states): the matrix fragments in LDS and two waves per SIMD, the first child's vectors parked in the parent's row."""
     Q = synth.dense_Q(n, 0.02, 0.08, seed=n)
     Omega = 1.25 * float(np.max(np.abs(np.diag(Q))))
     pid = np.full(n, 1.0 / n)

@@ -37,6 +37,8 @@ def main():
     opt = dict(mapping="replicas", storage=2, iters_per_launch=1) if name == "C2" else dict(mapping="tiles")
     if name == "C5dense":
         opt["sparse_chains"] = 2
+    if "PHM_PMC_FORM" in os.environ:      # phm_debug_options.pruning_form (kernel variants side by side)
+        opt["pruning_form"] = int(os.environ["PHM_PMC_FORM"])
     eng = _lib.Engine(z, Q, pid, Om, W + K, variant=variant, seed=0x5EED0000 + cfg, n_replicas=S, reduce=True, **opt)
     eng.run(W); eng.sync()
     eng.run(K); eng.sync()

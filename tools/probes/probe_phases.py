@@ -12,6 +12,13 @@ if os.environ.get("PHM_PROBE_Q") == "neighbour":      # C5's tree size with an U
     Q = synth.neighbour_Q(Q.shape[0], 6)
     Om = 1.25 * float(np.max(np.abs(np.diag(Q))))
     z = synth.make_tree(z["states"].size, Q, Om, 0x5EED0005, pid, init_segments=Q.shape[0])
+if "PHM_PROBE_N" in os.environ:                       # the configuration's tree size with a dense Q of another state count
+    import numpy as np
+    nn = int(os.environ["PHM_PROBE_N"])
+    Q = synth.dense_Q(nn, 0.005, 0.015, seed=nn)
+    Om = 1.25 * float(np.max(np.abs(np.diag(Q))))
+    pid = np.full(nn, 1.0 / nn)
+    z = synth.make_tree(z["states"].size, Q, Om, 0x5EED0000 + nn, pid, init_segments=2)
 E = z["edge"].shape[0]
 eng = _lib.Engine(z, Q, pid, Om, N + 10, variant=var, seed=1, n_replicas=S, reduce=True, mapping="tiles", phase_timing=True, sparse_chains=sparse,
                   pruning_form=int(os.environ.get("PHM_PROBE_FORM", "0")))      # PHM_PROBE_FORM: phm_debug_options.pruning_form
