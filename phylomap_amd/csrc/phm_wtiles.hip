@@ -261,9 +261,13 @@ __global__ __launch_bounds__(WT_BLOCK) void wt_up_kernel(WtParams p, int begin, 
 #ifndef PHM_UP2_WAVES
 #define PHM_UP2_WAVES 2
 #endif
-constexpr int WT_UP2_WAVES = PHM_UP2_WAVES;         // waves per SIMD the kernel is compiled for
+constexpr int WT_UP2_WAVES = PHM_UP2_WAVES;         // waves per SIMD the kernel is compiled for beyond 32 states (17 .. 32 states: four)
+#ifndef PHM_UP2_WAVES_SMALL
+#define PHM_UP2_WAVES_SMALL 3
+#endif
+constexpr int wt_up2_waves(int mt) { return mt <= 2 ? PHM_UP2_WAVES_SMALL : WT_UP2_WAVES; }
 template <int MT, int KSU>                          // KSU = ceil(n / 4): the k-steps that hold a state (the others multiply zeros: skipped)
-__global__ __launch_bounds__(WT_BLOCK, WT_UP2_WAVES) void wt_up2_kernel(WtParams p, int begin, int end) {
+__global__ __launch_bounds__(WT_BLOCK, wt_up2_waves(MT)) void wt_up2_kernel(WtParams p, int begin, int end) {
   constexpr int KS = 4 * MT;
   __shared__ double s_A[MT * KS * 64];               // fragment (i, s): lane l holds Bc[16 i + (l & 15)][4 s + (l >> 4)]
   __shared__ uint8_t s_perm_all[WT_BLOCK / 64][64];
@@ -286,12 +290,25 @@ __global__ __launch_bounds__(WT_BLOCK, WT_UP2_WAVES) void wt_up2_kernel(WtParams
     const uint16_t* __restrict__ mct = p.mcount + (size_t)tile * p.n_edge * 64;
     const uint8_t* __restrict__ tips_t = p.tips_per_replica ? p.tips + (size_t)tile * p.n_tips * 64 : p.tips;
 
-    auto sort_by_chain = [&](int edge) -> int {        // as in wt_up_kernel
+    // rank of (chain length, lane) as in wt_up_kernel; the lengths of a tile span a few values, so the ranks come from one ballot
+    // per VALUE (a counting sort: lanes of equal length keep their order) instead of one comparison per LANE
+    auto sort_by_chain = [&](int edge) -> int {
       const int k = (int)mct[edge * 64 + lane] - 1;
+      const int khi = wave_max_count(k), klo = 65535 - wave_max_count(65535 - k);
       int rank = 0;
-      for (int t = 0; t < 64; ++t) {
-        const int kt = __builtin_amdgcn_readlane(k, t);
-        rank += (kt < k || (kt == k && t < lane)) ? 1 : 0;
+      if (khi - klo < 40) {
+        int base = 0;
+        for (int v = klo; v <= khi; ++v) {
+          const unsigned long long mask = __ballot(k == v);
+          const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+          rank = (k == v) ? base + below : rank;
+          base += (int)__popcll(mask);
+        }
+      } else {
+        for (int t = 0; t < 64; ++t) {
+          const int kt = __builtin_amdgcn_readlane(k, t);
+          rank += (kt < k || (kt == k && t < lane)) ? 1 : 0;
+        }
       }
       s_perm[rank] = (uint8_t)lane;
       return k;
@@ -1331,10 +1348,10 @@ hipError_t launch_up_levels(const WtParams& p, const std::vector<int32_t>& up_of
       const int64_t items = (int64_t)cnt * p.n_tiles * 4;    // a wave per (node, tile, block)
       const unsigned grid = (unsigned)std::min<int64_t>((items + 3) / 4, 2048);
       hipLaunchKernelGGL(wt_up_blocks_kernel<MT>, dim3(grid), dim3(WT_BLOCK), 0, stream, p, up_off[l], up_off[l + 1]);
-    } else if (MT >= 3 && p.up_form != 1) {             // up_form 1 keeps the one-wave-per-SIMD kernel (measurement)
-      const int64_t items = (int64_t)cnt * p.n_tiles;        // a wave per (node, tile), two waves per SIMD
-      const unsigned grid = (unsigned)std::min<int64_t>((items + 3) / 4, 256 * WT_UP2_WAVES);      // persistent: WT_UP2_WAVES workgroups per CU
-      constexpr int M2 = MT >= 3 ? MT : 3;
+    } else if (MT >= 2 && p.up_form != 1) {             // up_form 1 keeps the kernel with the matrix in registers (measurement)
+      const int64_t items = (int64_t)cnt * p.n_tiles;        // a wave per (node, tile), two (17 .. 32 states: three) waves per SIMD
+      constexpr int M2 = MT >= 2 ? MT : 2;
+      const unsigned grid = (unsigned)std::min<int64_t>((items + 3) / 4, 256 * wt_up2_waves(M2));      // persistent workgroups
       switch ((p.n_states + 3) / 4 - 4 * (M2 - 1)) {         // k-steps in the last row block: 1 .. 4
         case 1: hipLaunchKernelGGL((wt_up2_kernel<M2, 4 * M2 - 3>), dim3(grid), dim3(WT_BLOCK), 0, stream, p, up_off[l], up_off[l + 1]); break;
         case 2: hipLaunchKernelGGL((wt_up2_kernel<M2, 4 * M2 - 2>), dim3(grid), dim3(WT_BLOCK), 0, stream, p, up_off[l], up_off[l + 1]); break;

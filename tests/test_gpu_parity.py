@@ -319,7 +319,7 @@ def test_wide_kernel_matches_oracle(n, fn, variant, mapping):
     np.testing.assert_allclose(red[:, :n], got.sum(0)[:, :n], rtol=1e-12)
 
 
-@pytest.mark.parametrize("n,form", [(n, f) for n in (12, 24, 40, 61) for f in (1, 2)] + [(33, 3), (40, 3), (48, 3), (61, 3)])
+@pytest.mark.parametrize("n,form", [(n, f) for n in (12, 24, 40, 61) for f in (1, 2)] + [(17, 3), (20, 3), (24, 3), (32, 3), (33, 3), (40, 3), (48, 3), (61, 3)])
 def test_wide_tiles_pruning_kernels_agree(n, form):
     """The pruning pass of the lane-per-replica mapping has three kernels chosen by tile count (a wave per (node, tile) with sorted
     blocks; for few tiles a workgroup per 16-replica block with a wave per row block, or a wave per block when n <= 16): each
