@@ -22,9 +22,14 @@ if "PHM_PROBE_N" in os.environ:                       # the configuration's tree
 E = z["edge"].shape[0]
 eng = _lib.Engine(z, Q, pid, Om, N + 10, variant=var, seed=1, n_replicas=S, reduce=True, mapping="tiles", phase_timing=True, sparse_chains=sparse,
                   pruning_form=int(os.environ.get("PHM_PROBE_FORM", "0")))      # PHM_PROBE_FORM: phm_debug_options.pruning_form
-eng.run(10); eng.sync()
+def sync():
+    try:
+        eng.sync()
+    except _lib.PhmError as ex:                        # a timing-only build of an experiment may leave the chains in a state the checks refuse
+        print("   (sync:", str(ex)[:80], ")")
+eng.run(10); sync()
 i0 = eng.info()
-eng.run(N); eng.sync()
+eng.run(N); sync()
 i1 = eng.info()
 ph = [x / N for x in eng.phase_ms()]
 seg = (i1.seg_read - i0.seg_read) / (E * S * N)
