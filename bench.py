@@ -333,7 +333,7 @@ def main():
                     e["valu_issue_frac"] = valu * scale * VALU_CLOCKS / (N_SIMD * NOMINAL_GHZ * 1e9 * ms / 1e3)
                 return e
             branch = kblock(("_branch_kernel",), br_ms, 12 * seg + 8, "resamplebranchstates + shortener + virtual jumps + dwell sums (src/phylomap.cpp:264-413, :44-73, :745-757); one launch per sweep")
-            prune = kblock(("_up_", "sparse_up"), up_ms, 12 * n + 12, "makePLrcpp* (src/phylomap.cpp:503-529), all height levels of one sweep")
+            prune = kblock(("_up_", "_up2_", "sparse_up"), up_ms, 12 * n + 12, "makePLrcpp* (src/phylomap.cpp:503-529), all height levels of one sweep")
             draws = kblock(("_down", "_root_kernel"), down_ms, 4 * n + 6, "sampleinternalnodes* + updatenodestates (src/phylomap.cpp:618-657, :460-475), all depth levels")
             red = kblock(("_stats_kernel", "_chunk_kernel"), st_ms, 0.0, "statistics rows (fixed-order reductions)")
             if n > 4 and eng.info().sparse_chains & 1 == 0:   # 5..64 states, dense B: the pruning chains run on the matrix cores
