@@ -1070,7 +1070,22 @@ int32_t phm_engine_create_impl(const phm_tree* trees, int32_t n_trees, const phm
     e->tiled = n_trees == 1 && (map_req == 3 || (auto_map && e->S > wbranch_auto_max_replicas(E)));
     e->narrow = n_trees == 1 && !e->tiled && (map_req == 2 || auto_map);
   } else {
-    e->narrow = small_n && (map_req == 2 || (auto_map && e->S <= narrow_auto_max_replicas(s)));
+    int narrow_cap = narrow_auto_max_replicas(s);
+    if (small_n && auto_map) {
+      // Paths of more than 64 segments leave the (tile, branch) kernel's two-pass form for its general loop, ~20 us per segment of
+      // ONE wave: the sweep cannot end before the longest branch has been walked (the reference's squamate tree at Omega = 10,
+      // 2 280 segments on one branch: 46-51 ms per sweep from 8 to 256 chains), while the branch mapping costs 4.4e-8 ms per
+      // segment and chain (0.68 ms at 8 chains, 10.2 ms at 256; profiles/r04_probe_squamate_crossover.log).  S* = floor / slope.
+      double max_seg = 0.0, tot_seg = 0.0;
+      for (int b = 0; b < E; ++b) {
+        double tb = 0.0;
+        for (int i = x->map_off[b]; i < x->map_off[b + 1]; ++i) tb += x->maps[i];
+        const double seg = std::max(1.0 + model->Omega * tb, (double)(x->map_off[b + 1] - x->map_off[b]));
+        max_seg = std::max(max_seg, seg); tot_seg += seg;
+      }
+      if (max_seg > 64.0) narrow_cap = std::max(narrow_cap, (int)std::min(65535.0, 2.0e-2 * max_seg / (4.4e-8 * tot_seg)));
+    }
+    e->narrow = small_n && (map_req == 2 || (auto_map && e->S <= narrow_cap));
     e->tiled = small_n && !e->narrow && (map_req == 3 || (auto_map && e->S <= TILES_AUTO_MAX_REPLICAS));
   }
   if (e->narrow && e->S > 65535) {      // the replica index is the grid's y dimension in these kernels

@@ -180,6 +180,21 @@ def test_automatic_mapping_follows_tree_size():
         eng.close()
 
 
+def test_automatic_mapping_keeps_the_branch_mapping_on_paths_of_hundreds_of_segments():
+    """Beyond 64 segments on a branch the (tile, branch) kernel leaves its two-pass form for a lane-sequential loop, ~20 us per segment of
+    one wave (the reference's squamate tree at Omega = 10: 46-51 ms per sweep from 8 to 256 chains against 0.7-10 ms on the branch
+    mapping, profiles/r04_probe_squamate_crossover.log): the automatic choice stays with the branch mapping up to floor / slope chains."""
+    Q = synth.config_Q(1)
+    Omega = 1.25 * float(np.max(np.abs(np.diag(Q))))
+    z = synth.make_tree(200, Q, Omega, 3, np.full(2, 0.5), init_segments=2)
+    long_z = dict(z, maps=[mp * 30.0 for mp in z["maps"]])               # Omega t_b = 120 on average
+    long_z["edge.length"] = z["edge.length"] * 30.0
+    for tree, S, want in [(z, 512, "tiles"), (long_z, 512, "branches"), (long_z, 20000, "tiles")]:
+        eng = _lib.Engine(tree, Q, np.full(2, 0.5), Omega, 2, variant=_lib.PHM_MCMC_BIGTREE, seed=1, n_replicas=S)
+        assert eng.info().mapping == _lib.MAPPING[want], (S, want)
+        eng.close()
+
+
 def test_one_chain_in_several_run_calls_and_single_row_reads():
     """run(2), read the last row (served from the row the statistics kernel left in host memory), run(3), read everything: the
     sweeps of one call hand their statistics to the next sweep's first launch, the last one of a call to a launch of its own."""
