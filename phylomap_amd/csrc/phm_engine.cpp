@@ -598,6 +598,7 @@ void fill_tile_params(phm_engine* e, phm::TileParams<NS>& p, const phm_options& 
   p.tips = e->d_tips.as<uint8_t>(); p.mcount = e->d_mcount.as<uint16_t>();
   p.dw[0] = e->d_dw0.as<double>(); p.dw[1] = e->d_dw1.as<double>();
   p.estate = e->d_tl_estate.as<uint8_t>(); p.PL = e->d_PL.as<double>(); p.nstate = e->d_nstate.as<uint8_t>();
+  p.mstate = e->d_wt_mstate.p ? e->d_wt_mstate.as<uint8_t>() : nullptr;      // long paths (tiles_setup)
   p.pdw = e->d_tl_pdw.as<double>(); p.pchunk = e->d_tl_pchunk.as<double>(); p.cnt = e->d_tl_cnt.as<uint32_t>();
   p.cnt_copies = tiles_cnt_copies(e->tiles);
   p.pseg = e->d_tl_pseg.as<uint32_t>(); p.segprev = e->d_tl_segprev.as<uint32_t>();
@@ -613,6 +614,7 @@ int32_t tiles_setup(phm_engine* e, const phm_tree* x, const phm_model* model, co
   e->tl_slot.assign(E + 1, 0);
   std::vector<int32_t> cap(E);
   int max_cap = 0;
+  double max_seg = 0.0;                             // most segments a branch is expected to hold (or holds in the caller's path)
   int64_t rows = 0;
   for (int b = 0; b < E; ++b) {
     double tb = 0.0;
@@ -620,6 +622,7 @@ int32_t tiles_setup(phm_engine* e, const phm_tree* x, const phm_model* model, co
     const int m0 = x->map_off[b + 1] - x->map_off[b];
     const int q = phm::poisson_capacity(model->Omega * tb, tail);
     cap[b] = (std::max(q, m0 + q - 1) + 2) * e->cap_boost;
+    max_seg = std::max(max_seg, std::max(1.0 + model->Omega * tb, (double)m0));
     if (cap[b] >= (1 << 23)) return fail(PHM_ERR_UNSUPPORTED, "branch too long: a slot of the (tile, branch) mapping exceeds 4 GB");   // 32-bit offsets, phm_tiles.hip
     max_cap = std::max(max_cap, cap[b]);
     rows += cap[b];
@@ -651,9 +654,13 @@ int32_t tiles_setup(phm_engine* e, const phm_tree* x, const phm_model* model, co
   const size_t tab = (size_t)e->nw_klong * n * n;
   const size_t pdw_bytes = sizeof(double) * (size_t)tiles * E * n * 64;
   const size_t pl_bytes = sizeof(double) * (size_t)tiles * Nn * n * 64;
+  // Paths of more than 64 segments on some branch (expected 48: a Poisson count of that mean passes 64 once in 70 draws): the branch
+  // kernel without its limit of 64 merged segments per branch and lane -- their states in a byte per (row, lane), an eighth of a dwell buffer
+  const bool long_paths = max_seg > 48.0;
+  const size_t ms_bytes = long_paths ? (size_t)tiles * rows * 64 : 0;
   size_t free_b = 0, total_b = 0;
   HIPCHK(hipMemGetInfo(&free_b, &total_b));
-  const size_t need = 2 * dw_bytes + pdw_bytes + pl_bytes + stats_bytes + sizeof(double) * 3 * tab + (size_t)tiles * (4 * (size_t)E + Nn) * 64;
+  const size_t need = 2 * dw_bytes + ms_bytes + pdw_bytes + pl_bytes + stats_bytes + sizeof(double) * 3 * tab + (size_t)tiles * (4 * (size_t)E + Nn) * 64;
   if (need + (64u << 20) > free_b) {
     char buf[256];
     std::snprintf(buf, sizeof buf, "engine needs %.2f GiB of HBM, %.2f GiB free (reduce n_replicas or max_iters)", need / 1073741824.0, free_b / 1073741824.0);
@@ -667,6 +674,7 @@ int32_t tiles_setup(phm_engine* e, const phm_tree* x, const phm_model* model, co
   HIPCHK(e->d_tips.alloc(e->tips_host.size()));
   HIPCHK(e->d_mcount.alloc(sizeof(uint16_t) * (size_t)tiles * E * 64));
   HIPCHK(e->d_dw0.alloc(dw_bytes)); HIPCHK(e->d_dw1.alloc(dw_bytes));
+  if (long_paths) HIPCHK(e->d_wt_mstate.alloc(ms_bytes));
   HIPCHK(e->d_tl_estate.alloc((size_t)tiles * E * 64));
   HIPCHK(e->d_PL.alloc(pl_bytes));
   HIPCHK(e->d_nstate.alloc((size_t)tiles * Nn * 64));
@@ -677,7 +685,7 @@ int32_t tiles_setup(phm_engine* e, const phm_tree* x, const phm_model* model, co
   HIPCHK(e->d_stats.alloc(stats_bytes));
   HIPCHK(e->d_err.alloc(sizeof(uint32_t))); HIPCHK(e->d_seg.alloc(sizeof(unsigned long long)));
   if (e->reduce) HIPCHK(e->d_red.alloc(sizeof(double) * (size_t)max_iters * e->dcols));
-  e->bytes = (int64_t)(2 * dw_bytes + pdw_bytes + pl_bytes + e->d_stats.bytes + e->d_red.bytes + e->d_mcount.bytes + e->d_tl_pchunk.bytes +
+  e->bytes = (int64_t)(2 * dw_bytes + ms_bytes + pdw_bytes + pl_bytes + e->d_stats.bytes + e->d_red.bytes + e->d_mcount.bytes + e->d_tl_pchunk.bytes +
                        sizeof(double) * 3 * tab);
   HIPCHK(hipMemcpy(e->d_up.p, s.up.data(), e->d_up.bytes, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(e->d_down.p, s.down.data(), e->d_down.bytes, hipMemcpyHostToDevice));
@@ -1072,10 +1080,10 @@ int32_t phm_engine_create_impl(const phm_tree* trees, int32_t n_trees, const phm
   } else {
     int narrow_cap = narrow_auto_max_replicas(s);
     if (small_n && auto_map) {
-      // Paths of more than 64 segments leave the (tile, branch) kernel's two-pass form for its general loop, ~20 us per segment of
-      // ONE wave: the sweep cannot end before the longest branch has been walked (the reference's squamate tree at Omega = 10,
-      // 2 280 segments on one branch: 46-51 ms per sweep from 8 to 256 chains), while the branch mapping costs 4.4e-8 ms per
-      // segment and chain (0.68 ms at 8 chains, 10.2 ms at 256; profiles/r04_probe_squamate_crossover.log).  S* = floor / slope.
+      // Long paths: the (tile, branch) mapping cannot end a sweep before ONE wave has walked the longest branch twice (its two passes,
+      // ~1.6 us per segment; the reference's squamate tree at Omega = 10, 2 280 segments on one branch: 3.6 ms per sweep up to 64
+      // chains, 4.5 at 256), while the branch mapping costs 4.4e-8 ms per segment and chain (0.68 ms at 8 chains, 2.8 at 64, 10.2 at
+      // 256; profiles/r04_probe_squamate_crossover.log).  S* = floor / slope.
       double max_seg = 0.0, tot_seg = 0.0;
       for (int b = 0; b < E; ++b) {
         double tb = 0.0;
@@ -1083,7 +1091,7 @@ int32_t phm_engine_create_impl(const phm_tree* trees, int32_t n_trees, const phm
         const double seg = std::max(1.0 + model->Omega * tb, (double)(x->map_off[b + 1] - x->map_off[b]));
         max_seg = std::max(max_seg, seg); tot_seg += seg;
       }
-      if (max_seg > 64.0) narrow_cap = std::max(narrow_cap, (int)std::min(65535.0, 2.0e-2 * max_seg / (4.4e-8 * tot_seg)));
+      if (max_seg > 64.0) narrow_cap = std::max(narrow_cap, (int)std::min(65535.0, 1.6e-3 * max_seg / (4.4e-8 * tot_seg)));
     }
     e->narrow = small_n && (map_req == 2 || (auto_map && e->S <= narrow_cap));
     e->tiled = small_n && !e->narrow && (map_req == 3 || (auto_map && e->S <= TILES_AUTO_MAX_REPLICAS));

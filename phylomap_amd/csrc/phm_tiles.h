@@ -68,6 +68,8 @@ struct TileParams {
   uint16_t* mcount;                          // [tile][n_edge][64]
   double* dw[2];                             // [tile][rows][64]; sweep `it` reads dw[it & 1], writes the other
   uint8_t* estate;                           // [tile][n_edge][64]: parent-side state | child-side state << 4
+  uint8_t* mstate;                           // long paths (not null): [tile][rows][64] states of the merged segments of the branch at hand,
+                                             //   a byte per (row, lane) beside the dwell rows (tiles_branch_kernel<NS, KS, true>)
   double* PL;                                // [tile][n_node][NS][64]
   uint8_t* nstate;                           // [tile][n_node][64]
   double* pdw;                               // [tile][n_edge][NS][64] dwell sums of every group of branches (n_groups rows used)

@@ -259,7 +259,14 @@ __global__ __launch_bounds__(TILES_CL_BLOCK) void tiles_down_cluster_kernel(Tile
 
 // One branch for the 64 replicas of a tile: resamplebranchstates :264-308, shortener :44-73 (shortenerbf :997-1030),
 // virtual jumps sampleabranch :391-410, dwell sums updatedwelltimes :745-757.
-template <int NS, bool KS>
+// LONG (paths of more than 64 segments expected on some branch -- the reference's squamate run holds 2 280 on one): the two passes
+// below without their limit of 64 merged segments per branch and lane.  The states of the merged segments, two bits apiece in
+// two registers otherwise, go to a byte per (row, lane) beside the dwell rows (TileParams::mstate: 64-byte coalesced rows, written
+// by pass A, read by pass B a step ahead), so the passes run to any length at the cost of a byte store and load per merged
+// segment; the lane-sequential general loop (~20 us per segment of ONE wave: 46-51 ms per sweep on that tree whatever the
+// chain count) is not compiled into this form.  On long paths the lanes of a wave also agree better: the longest of 64
+// Poisson(1 000) counts is 1.1x their mean where the longest of 64 Poisson(4) counts is 2.4x.
+template <int NS, bool KS, bool LONG>
 __global__ __launch_bounds__(TILES_BLOCK, KS ? 7 : 8) void tiles_branch_kernel(TileParams<NS> p, int it) {      // KS: NS*NS counters per lane -> 7 waves per SIMD
   constexpr int NCNT = KS ? NS * NS : NS * (NS - 1);
   __shared__ double s_dw_all[(TILES_BLOCK / 64) * NS * 64];
@@ -318,6 +325,8 @@ __global__ __launch_bounds__(TILES_BLOCK, KS ? 7 : 8) void tiles_branch_kernel(T
   double* __restrict__ in = p.dw[it & 1] + ((size_t)tile * p.rows + roff) * 64;
   double* __restrict__ out = p.dw[(it & 1) ^ 1] + ((size_t)tile * p.rows + roff) * 64;
   auto IN = [&](int k) -> double& { return at(in, (uint32_t)k * 512u + lane8); };
+  uint8_t* __restrict__ msrow = LONG ? p.mstate + ((size_t)tile * p.rows + roff) * 64 + lane : nullptr;
+  auto MS = [&](int k) -> uint8_t& { return msrow[(uint32_t)k * 64u]; };
 
   Stream su, se;
   su.open(ENT_BSTATE | (uint32_t)b, (uint32_t)it, rep, p.seed_lo, p.seed_hi);
@@ -346,7 +355,7 @@ __global__ __launch_bounds__(TILES_BLOCK, KS ? 7 : 8) void tiles_branch_kernel(T
   };
   auto draw_state = [&](int i, int sprev) -> int { return draw_state_w(i, sprev, su.draw_word((uint32_t)(i - 1))); };
 
-  if (mmax <= 64) {
+  if (LONG || mmax <= 64) {
     // Pass A: one old segment per step for every lane; merged segments written back in place over the consumed rows of the
     // slot, their states packed 2 bits apiece into two registers.
     uint64_t pk0 = 0, pk1 = 0;
@@ -374,20 +383,24 @@ __global__ __launch_bounds__(TILES_BLOCK, KS ? 7 : 8) void tiles_branch_kernel(T
         if (si == cur_s) cur_len = cur_len + di;                           // shortener :54
         else {
           if (w == 0) first_len = cur_len; else if (w == 1) second_len = cur_len; else IN(w) = cur_len;
-          if (w < 32) pk0 |= (uint64_t)cur_s << (2 * w); else pk1 |= (uint64_t)cur_s << (2 * (w - 32));
+          if (LONG) MS(w) = (uint8_t)cur_s;
+          else if (w < 32) pk0 |= (uint64_t)cur_s << (2 * w); else pk1 |= (uint64_t)cur_s << (2 * (w - 32));
           if (!KS) s_cnt[(cur_s * (NS - 1) + (si > cur_s ? si - 1 : si)) * 64 + lane] = (uint16_t)(s_cnt[(cur_s * (NS - 1) + (si > cur_s ? si - 1 : si)) * 64 + lane] + 1u);   // shortener :65-66
           ++w; cur_s = si; cur_len = di;
         }
       }
       }
     }
-    if (w < 32) pk0 |= (uint64_t)cur_s << (2 * w); else pk1 |= (uint64_t)cur_s << (2 * (w - 32));
+    if (LONG) MS(w) = (uint8_t)cur_s;
+    else if (w < 32) pk0 |= (uint64_t)cur_s << (2 * w); else pk1 |= (uint64_t)cur_s << (2 * (w - 32));
+    const int first_s = (w == 0) ? cur_s : (LONG ? (int)MS(0) : (int)(pk0 & 3u));
     const int nmerged = w + 1;
     const double len0 = (w == 0) ? cur_len : first_len;
 
     // Pass B: one new piece per step for every lane (virtual jumps :391-410, dwell sums :745-757).
     int j = 0;
-    int s = (int)(pk0 & 3u);
+    int s = first_s;
+    int snext = (LONG && nmerged > 1) ? (int)MS(1) : 0;      // LONG: the next merged segment's state rides a step ahead, like its length
     double len = len0;
     double lnext = (nmerged > 1) ? ((w == 1) ? cur_len : second_len) : 0.0;
     double tot = 0.0, scale = s_scale[s], acc = s_dw[s * 64 + lane];
@@ -418,13 +431,14 @@ __global__ __launch_bounds__(TILES_BLOCK, KS ? 7 : 8) void tiles_branch_kernel(T
           else {
             len = lnext;
             if (j + 1 < w) lnext = IN(j + 1); else lnext = cur_len;          // the last merged segment never left its register
-            s = (int)(((j < 32) ? (pk0 >> (2 * j)) : (pk1 >> (2 * (j - 32)))) & 3u);
+            if (LONG) { s = snext; if (j + 1 < nmerged) snext = (int)MS(j + 1); }
+            else s = (int)(((j < 32) ? (pk0 >> (2 * j)) : (pk1 >> (2 * (j - 32)))) & 3u);
             scale = s_scale[s]; tot = 0.0; acc = s_dw[s * 64 + lane];
           }
         }
       }
     }
-  } else {
+  } else if (!LONG) {
     // General path (a lane with more than 64 segments on this branch): the reference's loop nest as written.
     uint32_t edraw = 0;
     bool stuck = false;
@@ -653,8 +667,13 @@ hipError_t launch_tiles_sweep(const TileParams<NS>& p, const std::vector<int32_t
     }
   }
   mark(2);
-  if (p.ks) hipLaunchKernelGGL((tiles_branch_kernel<NS, true>), blocks((int64_t)p.n_groups * p.n_tiles), dim3(TILES_BLOCK), 0, stream, p, it);
-  else hipLaunchKernelGGL((tiles_branch_kernel<NS, false>), blocks((int64_t)p.n_groups * p.n_tiles), dim3(TILES_BLOCK), 0, stream, p, it);
+  if (p.mstate) {
+    if (p.ks) hipLaunchKernelGGL((tiles_branch_kernel<NS, true, true>), blocks((int64_t)p.n_groups * p.n_tiles), dim3(TILES_BLOCK), 0, stream, p, it);
+    else hipLaunchKernelGGL((tiles_branch_kernel<NS, false, true>), blocks((int64_t)p.n_groups * p.n_tiles), dim3(TILES_BLOCK), 0, stream, p, it);
+  } else {
+    if (p.ks) hipLaunchKernelGGL((tiles_branch_kernel<NS, true, false>), blocks((int64_t)p.n_groups * p.n_tiles), dim3(TILES_BLOCK), 0, stream, p, it);
+    else hipLaunchKernelGGL((tiles_branch_kernel<NS, false, false>), blocks((int64_t)p.n_groups * p.n_tiles), dim3(TILES_BLOCK), 0, stream, p, it);
+  }
   mark(3);
   hipLaunchKernelGGL(tiles_chunk_kernel<NS>, blocks((int64_t)p.n_chunks * p.n_tiles), dim3(TILES_BLOCK), 0, stream, p);
   if (p.ks) hipLaunchKernelGGL((tiles_stats_kernel<NS, true>), dim3(p.n_tiles), dim3(64 * TILES_STATS_WAVES), 0, stream, p, it);

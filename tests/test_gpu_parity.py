@@ -112,6 +112,54 @@ def test_mcmc_long_initial_paths_take_the_general_branch_path(storage):
         _same(got[r], want, 4, mapping)
 
 
+@pytest.mark.parametrize("fn,variant,n", [("sumstatMCMC", O.PLAIN, 2), ("sumstatMCMC_bigtree", O.BIGTREE, 4), ("sumstatMCMCks_sweep", O.KS, 4)])
+def test_tiles_mapping_on_paths_of_hundreds_of_segments(fn, variant, n):
+    """(tile, branch) mapping, 2 .. 4 states, a branch expected to hold more than 48 segments: the branch kernel without its limit of
+    64 merged segments per branch and lane (tiles_branch_kernel<NS, KS, true>: their states in a byte per (row, lane) instead of two
+    registers; 13x on the reference's squamate tree).  300-segment paths to start with, one branch of 1 500, several sweeps, two tiles."""
+    Q = synth.config_Q(1) if n == 2 else synth.config_Q(2)
+    Omega = 1.25 * float(np.max(np.abs(np.diag(Q))))
+    pid = np.full(n, 1.0 / n)
+    z = synth.make_tree(12, Q, Omega, 33, pid, init_segments=300)
+    if variant == O.KS:
+        z = dict(z, states=((z["states"] - 1) % 2 + 1).astype(np.int32))
+        for b, (p_, c_) in enumerate(z["edge"]):
+            if c_ <= 12:
+                z["mapnames"][b][-1] = z["states"][c_ - 1]
+    b = int(np.argmax(z["edge.length"]))
+    end = z["mapnames"][b][-1]
+    z["maps"][b] = np.full(1500, 60.0 * z["edge.length"][b] / 1500)       # a long branch: ~ 60 x 4 virtual jumps per sweep as well
+    z["mapnames"][b] = np.array([1] * 1499 + [end], dtype=np.int32)
+    z["edge.length"] = np.array([mp.sum() for mp in z["maps"]])
+    nen, nodelist, root = _orders(z)
+    S, N = 70, 5
+    got = getattr(api, fn)(z, Q, pid, Omega, N, seed=19, n_replicas=S, mapping="tiles")
+    for r in (0, 63, 64, S - 1):
+        want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(n) + Q / Omega, Omega, nen, nodelist, root, N, variant=variant, seed=19, replica=r)
+        assert rc == 0
+        _same(got[r], want, n, "tiles", ks=variant == O.KS)
+
+
+def test_tiles_mapping_general_loop_when_a_lane_outgrows_64_segments_unexpectedly():
+    """Expected path lengths below 48 on every branch keep the two-pass form with its states packed in registers; a lane that still
+    draws more than 64 segments (Poisson(45): 0.4 % of the draws -- a handful in 130 chains x 12 sweeps) sends its wave through
+    the lane-sequential general loop for that branch."""
+    Q = synth.config_Q(1)
+    Omega = 1.25 * float(np.max(np.abs(np.diag(Q))))
+    pid = np.full(2, 0.5)
+    z = synth.make_tree(6, Q, Omega, 8, pid, init_segments=2)
+    b = int(np.argmax(z["edge.length"]))
+    z["maps"][b] = z["maps"][b] * (45.0 / (Omega * z["edge.length"][b]))
+    z["edge.length"] = np.array([mp.sum() for mp in z["maps"]])
+    nen, nodelist, root = _orders(z)
+    S, N = 130, 12
+    got = api.sumstatMCMC(z, Q, pid, Omega, N, seed=23, n_replicas=S, mapping="tiles")
+    for r in (0, 5, 63, 64, 100, S - 1):
+        want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(2) + Q / Omega, Omega, nen, nodelist, root, N, seed=23, replica=r)
+        assert rc == 0
+        _same(got[r], want, 2, "tiles")
+
+
 def _two_tip_tree(states, lens=(1.5, 0.7), segs=(1, 1)):
     edge = np.array([[3, 1], [3, 2]], dtype=np.int32)
     maps = [np.full(segs[i], lens[i] / segs[i]) for i in range(2)]
