@@ -425,6 +425,65 @@ extern "C" int32_t phm_maketreelistMCMCksDICt(const phm_tree* x, int32_t n, cons
 }
 
 // ---- multi-tree drivers -----------------------------------------------------------------------------------------------
+// The list as one engine PER TREE (big trees; run_qupdate_mt decides): every iteration enqueues one sweep of every engine on a
+// handful of streams, waits for all of them and reads a row from each; the rate update and the new model go to all engines.
+static int32_t run_qupdate_mt_per_tree(int variant, const phm_tree* trees, int32_t n_trees, int32_t n, const phm_model& model,
+                                       const phm_options& o_in, const int32_t* nen_m, const int32_t* nodelist_m, const int32_t* roots,
+                                       int32_t N, const double* prior, double* out) {
+  const bool ksmt = variant == PHM_MCMC_KSMT;
+  struct Engines {
+    std::vector<phm_engine*> e;
+    std::vector<hipStream_t> streams;
+    ~Engines() {
+      for (phm_engine* x : e) if (x) phm_engine_destroy(x);
+      for (hipStream_t s : streams) if (s) (void)hipStreamDestroy(s);
+    }
+  } es;
+  es.e.assign(n_trees, nullptr);
+  std::string serr;
+  for (int j = 0; j < n_trees; ++j) {
+    phm_options o = o_in;
+    o.replica_offset = o_in.replica_offset + 64 * j;      // the list's engine keeps tree j's chain on replica tile j
+    o.mapping = PHM_MAP_BRANCHES;
+    const int32_t st = phm_engine_create(&trees[j], &model, &o, N, &es.e[j]);
+    if (st) return fail(st, "tree " + std::to_string(j) + ": " + g_phm_err);
+    const phm_engine* e = es.e[j];
+    const int Nn = e->sched.n_node;
+    if (nen_m || nodelist_m || roots) {      // R's matrices are column-major: row j = elements j, j + n_trees, ...
+      std::vector<int32_t> nen(2 * (size_t)Nn), nodelist(Nn > 1 ? Nn - 1 : 0);
+      if (nen_m) for (int i = 0; i < 2 * Nn; ++i) nen[i] = nen_m[j + (size_t)i * n_trees];
+      if (nodelist_m) for (int i = 0; i < Nn - 1; ++i) nodelist[i] = nodelist_m[j + (size_t)i * n_trees];
+      if (!phm::check_reference_orders(e->sched, trees[j].edge, nen_m ? nen.data() : nullptr, nodelist_m ? nodelist.data() : nullptr,
+                                       roots ? roots[j] : e->sched.root + e->sched.n_tips + 1, serr))
+        return fail(PHM_ERR_BAD_INPUT, "tree " + std::to_string(j) + ": " + serr);
+    }
+  }
+  const int n_streams = std::min(n_trees, 16);
+  es.streams.assign(n_streams, nullptr);
+  for (int k = 0; k < n_streams; ++k)
+    if (hipStreamCreateWithFlags(&es.streams[k], hipStreamNonBlocking) != hipSuccess) return fail(PHM_ERR_NO_DEVICE, "hipStreamCreate failed");
+  const int ecols = es.e[0]->cols;
+  const size_t nn = (size_t)n * n;
+  std::vector<double> Qw(model.Q, model.Q + nn), row(ecols);
+  for (int i = 0; i < N; ++i) {
+    int32_t st = PHM_OK;
+    for (int j = 0; j < n_trees && !st; ++j) st = phm_engine_run(es.e[j], 1, es.streams[j % n_streams]);
+    for (int j = 0; j < n_trees && !st; ++j) st = phm_engine_sync(es.e[j]);
+    if (st) return st;
+    const uint32_t pick = phm::pick_tree(n_trees, o_in.seed, (uint32_t)i);
+    if (pick >= (uint32_t)n_trees) return fail(PHM_ERR_ZERO_PROB, "sampleOnce ran past the last tree (src/phylomap.cpp:85-89)");
+    st = phm_engine_read_stats(es.e[pick], i, 1, row.data());
+    if (st) return st;
+    for (int c = 0; c + 1 < ecols; ++c) out[(size_t)c * N + i] = row[c];
+    out[(size_t)(ecols - 1) * N + i] = (double)pick;                   // :2350, 0-based as the reference stores it
+    if (ksmt) phm::ks_updates(Qw.data(), n, model.Omega, prior, row.data(), o_in.seed, (uint32_t)i, true);
+    else phm::mt_updates(Qw.data(), model.Omega, prior, row.data(), o_in.seed, (uint32_t)i);
+    if (i + 1 < N)
+      for (int j = 0; j < n_trees; ++j) { st = phm_engine_set_model(es.e[j], Qw.data()); if (st) return st; }
+  }
+  return PHM_OK;
+}
+
 // maketreelistMCMCmt src/phylomap.cpp:2267-2365 (R/sumstatMCMCmt.R) and maketreelistMCMCksmt :2722-2844 (R/sumstatMCMCksmt.R).
 // One engine over the whole list: tree j's chain lives on replica tile j, so one launch per iteration sweeps every tree with
 // the current Q (:2341-2345); the host then draws the tree whose row is kept (:2347-2350), updates Q from that row and
@@ -445,6 +504,21 @@ static int32_t run_qupdate_mt(int variant, const phm_tree* trees, int32_t n_tree
   o.n_replicas = 1; o.reduce = 0; o.tips_per_replica = 0; o.iters_per_launch = 1;
   phm_model model;
   model.n_states = n; model.Q = Q; model.pid = pid; model.B = nullptr; model.Omega = Omega; model.variant = variant;
+  // An engine per tree, or one engine over the list.  The one engine walks a whole tree in ONE lane and rebuilds its chain tables
+  // with every new model: 18 ms per iteration for 64 trees of 100 tips, 71 ms at 600 tips, seconds on a tree of thousands of tips,
+  // whatever the number of trees.  A tree's own engine in the branch mapping costs ~0.05 ms per tree and iteration, launches, wait
+  // and model upload included (64 trees: 3.1 / 3.0 ms at 100 / 600 tips; profiles/r04_probe_multi_tree.log).  Same streams: tree j's
+  // chain is replica 64 j of the list either way.  The list engine is kept for long lists of small trees and for
+  // PHM_MAP_REPLICAS (its dwell sums are added in the reference's order: bit-identical to the oracle, not just to 1e-10).
+  double segs = 0.0;
+  for (int b = 0; b < trees[0].n_edge; ++b) {
+    double tb = 0.0;
+    for (int i = trees[0].map_off[b]; i < trees[0].map_off[b + 1]; ++i) tb += trees[0].maps[i];
+    segs += std::max(1.0 + Omega * tb, (double)(trees[0].map_off[b + 1] - trees[0].map_off[b]));
+  }
+  const bool per_tree = o.mapping == PHM_MAP_BRANCHES ||
+                        (o.mapping == PHM_MAP_AUTO && o.storage == 0 && (n_trees <= 256 || 1.5e-3 * segs > 0.05 * n_trees));
+  if (per_tree) return run_qupdate_mt_per_tree(variant, trees, n_trees, n, model, o, nen_m, nodelist_m, roots, N, prior, out);
   phm_engine* e = nullptr;
   int32_t st = phm_engine_create_multi(trees, n_trees, &model, &o, N, &e);
   if (st) return st;

@@ -595,14 +595,14 @@ def _list_orders(treelist):
 
 
 def test_sumstatMCMCmt_list_of_trees_matches_oracle():
-    """R/sumstatMCMCmt.R: every iteration sweeps EVERY tree of the list (one launch, tree j on replica tile j), keeps a
-    uniformly drawn one, and updates (l01, l10) from it with the acceptance-testing mt updates."""
+    """R/sumstatMCMCmt.R: every iteration sweeps EVERY tree of the list (here the one engine over the list: one launch, tree j on
+    replica tile j), keeps a uniformly drawn one, and updates (l01, l10) from it with the acceptance-testing mt updates."""
     Q = np.array([[-.1, .1], [.1, -.1]])
     Omega, pid, prior = 2.0, np.array([.5, .5]), [.55, 1, .56, 1.01]
     trees = synth.make_treelist(7, 16, Q, 0.5, 314, pid)
     nen_m, nodelist_m, roots = _list_orders(trees)
     N = 40
-    got = api.sumstatMCMCmt(trees, Q, pid, Omega, N, prior, seed=2718)
+    got = api.sumstatMCMCmt(trees, Q, pid, Omega, N, prior, seed=2718, mapping="replicas")      # the list engine: bit-identical dwell sums
     want, rc = O.maketreelistMCMCmt(trees, Q, pid, np.eye(2) + Q / Omega, Omega, nen_m, nodelist_m, roots, N, prior, variant=O.MT, seed=2718)
     assert rc == 0 and got.shape == (N, 9)
     np.testing.assert_array_equal(got, want)
@@ -610,7 +610,7 @@ def test_sumstatMCMCmt_list_of_trees_matches_oracle():
     assert len(np.unique(got[:, 6])) > 10                                     # l01 moves (and some proposals are rejected)
     assert np.any(got[1:, 6] == got[:-1, 6])
     # one tree in the list: the single-tree sweep without normalisation; total time = that tree's length
-    one = api.sumstatMCMCmt(trees[:1], Q, pid, Omega, 5, prior, seed=3)
+    one = api.sumstatMCMCmt(trees[:1], Q, pid, Omega, 5, prior, seed=3)                         # automatic: an engine per tree
     np.testing.assert_allclose(one[:, :2].sum(1), trees[0]["edge.length"].sum(), rtol=1e-12)
     assert np.all(one[:, 8] == 0)
 
@@ -626,12 +626,40 @@ def test_sumstatMCMCksmt_list_of_trees_matches_oracle(n):
         z["states"] = ((z["states"] - 1) % 2 + 1).astype(np.int32)
     nen_m, nodelist_m, roots = _list_orders(trees)
     N = 20
-    got = api.sumstatMCMCksmt(trees, Q, pid, Omega, N, prior, seed=11)
+    got = api.sumstatMCMCksmt(trees, Q, pid, Omega, N, prior, seed=11, mapping="replicas")      # the list engine: bit-identical dwell sums
     want, rc = O.maketreelistMCMCmt(trees, Q, pid, np.eye(n) + Q / Omega, Omega, nen_m, nodelist_m, roots, N, prior, variant=O.KSMT, seed=11)
     k = n // 2 - 1
     assert rc == 0 and got.shape == (N, n + n * n + 2 + 3 * k + 1)
     np.testing.assert_array_equal(got, want)
     assert len(np.unique(got[:, -1])) >= 3
+
+
+@pytest.mark.parametrize("variant,n,tips,mapping", [("mt", 2, 16, "branches"), ("ksmt", 4, 14, "branches"), ("ksmt", 6, 14, "branches"),
+                                                    ("mt", 2, 300, "auto"), ("mt", 2, 300, "replicas")])
+def test_multi_tree_drivers_with_an_engine_per_tree(variant, n, tips, mapping):
+    """Lists of BIG trees: the one engine over the list walks a whole tree in one lane (seconds per sweep on the reference's squamate
+    tree), so the multi-tree drivers then run an engine per tree in the branch mapping -- tree j's chain on replica 64 j either way,
+    the same draws.  Forced on the small lists of the tests above, chosen automatically on 300-tip trees, against the oracle: counts,
+    tree numbers and root states exact, dwell sums and what the rate updates make of them to rounding."""
+    if variant == "mt":
+        Q = np.array([[-.1, .1], [.1, -.1]]); Omega, pid, prior = 2.0, np.array([.5, .5]), [.55, 1, .56, 1.01]
+        trees = synth.make_treelist(4 if tips > 100 else 7, tips, Q, 0.5, 314, pid)
+        fn, var = api.sumstatMCMCmt, O.MT
+    else:
+        Q = synth.make2sQ(.1, .1, .2, .2, 10) if n == 4 else synth.make2sQ(.1, .3, [.2, .4], [.5, .6], [2, 3])
+        Omega, pid, prior = 25.0, np.full(n, 1.0 / n), [1, 10, 1.5, 11, 2, 10, 20, 2]
+        trees = synth.make_treelist(5, tips, Q, Omega / 3, 2024, pid)
+        for z in trees:
+            z["states"] = ((z["states"] - 1) % 2 + 1).astype(np.int32)
+        fn, var = api.sumstatMCMCksmt, O.KSMT
+    nen_m, nodelist_m, roots = _list_orders(trees)
+    N = 15
+    got = fn(trees, Q, pid, Omega, N, prior, seed=77, mapping=mapping)
+    want, rc = O.maketreelistMCMCmt(trees, Q, pid, np.eye(n) + Q / Omega, Omega, nen_m, nodelist_m, roots, N, prior, variant=var, seed=77)
+    assert rc == 0 and got.shape == want.shape
+    np.testing.assert_array_equal(got[:, n:n + n * n], want[:, n:n + n * n])
+    np.testing.assert_array_equal(got[:, -1], want[:, -1])
+    np.testing.assert_allclose(got, want, rtol=1e-9, atol=0)
 
 
 def test_engine_over_a_list_of_trees_runs_each_tree_like_its_own_engine():
