@@ -656,7 +656,10 @@ int32_t tiles_setup(phm_engine* e, const phm_tree* x, const phm_model* model, co
   const size_t pl_bytes = sizeof(double) * (size_t)tiles * Nn * n * 64;
   // Paths of more than 64 segments on some branch (expected 48: a Poisson count of that mean passes 64 once in 70 draws): the branch
   // kernel without its limit of 64 merged segments per branch and lane -- their states in a byte per (row, lane), an eighth of a dwell buffer
-  const bool long_paths = max_seg > 48.0;
+#ifndef PHM_TILES_LONG_SEGMENTS
+#define PHM_TILES_LONG_SEGMENTS 48.0
+#endif
+  const bool long_paths = max_seg > PHM_TILES_LONG_SEGMENTS;
   const size_t ms_bytes = long_paths ? (size_t)tiles * rows * 64 : 0;
   size_t free_b = 0, total_b = 0;
   HIPCHK(hipMemGetInfo(&free_b, &total_b));
