@@ -1084,8 +1084,8 @@ int32_t phm_engine_create_impl(const phm_tree* trees, int32_t n_trees, const phm
     int narrow_cap = narrow_auto_max_replicas(s);
     if (small_n && auto_map) {
       // Long paths: the (tile, branch) mapping cannot end a sweep before ONE wave has walked the longest branch twice (its two passes,
-      // ~1.6 us per segment; the reference's squamate tree at Omega = 10, 2 280 segments on one branch: 3.6 ms per sweep up to 64
-      // chains, 4.5 at 256), while the branch mapping costs 4.4e-8 ms per segment and chain (0.68 ms at 8 chains, 2.8 at 64, 10.2 at
+      // ~1.35 us per segment; the reference's squamate tree at Omega = 10, 2 280 segments on one branch: 3.1 ms per sweep up to 64
+      // chains, 3.7 at 256), while the branch mapping costs 4.4e-8 ms per segment and chain (0.68 ms at 8 chains, 2.8 at 64, 10.2 at
       // 256; profiles/r04_probe_squamate_crossover.log).  S* = floor / slope.
       double max_seg = 0.0, tot_seg = 0.0;
       for (int b = 0; b < E; ++b) {
@@ -1094,7 +1094,7 @@ int32_t phm_engine_create_impl(const phm_tree* trees, int32_t n_trees, const phm
         const double seg = std::max(1.0 + model->Omega * tb, (double)(x->map_off[b + 1] - x->map_off[b]));
         max_seg = std::max(max_seg, seg); tot_seg += seg;
       }
-      if (max_seg > 64.0) narrow_cap = std::max(narrow_cap, (int)std::min(65535.0, 1.6e-3 * max_seg / (4.4e-8 * tot_seg)));
+      if (max_seg > 64.0) narrow_cap = std::max(narrow_cap, (int)std::min(65535.0, 1.35e-3 * max_seg / (4.4e-8 * tot_seg)));
     }
     e->narrow = small_n && (map_req == 2 || (auto_map && e->S <= narrow_cap));
     e->tiled = small_n && !e->narrow && (map_req == 3 || (auto_map && e->S <= TILES_AUTO_MAX_REPLICAS));

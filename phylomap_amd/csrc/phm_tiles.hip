@@ -267,7 +267,7 @@ __global__ __launch_bounds__(TILES_CL_BLOCK) void tiles_down_cluster_kernel(Tile
 // chain count) is not compiled into this form.  On long paths the lanes of a wave also agree better: the longest of 64
 // Poisson(1 000) counts is 1.1x their mean where the longest of 64 Poisson(4) counts is 2.4x.
 template <int NS, bool KS, bool LONG>
-__global__ __launch_bounds__(TILES_BLOCK, KS ? 7 : 8) void tiles_branch_kernel(TileParams<NS> p, int it) {      // KS: NS*NS counters per lane -> 7 waves per SIMD
+__global__ __launch_bounds__(TILES_BLOCK, LONG ? 5 : (KS ? 7 : 8)) void tiles_branch_kernel(TileParams<NS> p, int it) {      // KS: NS*NS counters per lane -> 7 waves per SIMD; LONG: the prefetch ring takes registers
   constexpr int NCNT = KS ? NS * NS : NS * (NS - 1);
   __shared__ double s_dw_all[(TILES_BLOCK / 64) * NS * 64];
   __shared__ uint16_t s_cnt_all[(TILES_BLOCK / 64) * NCNT * 64];      // counts of ONE branch (<= 65 535 segments): 16 bits keep the block under 20 KB of LDS, 8 waves per SIMD
@@ -366,7 +366,30 @@ __global__ __launch_bounds__(TILES_BLOCK, KS ? 7 : 8) void tiles_branch_kernel(T
     // (they all went through the rows: 17.2 -> 15.9 ms with two of them in registers, profiles/r03_probe_branch_ablation.log).
     double first_len = 0.0, second_len = 0.0;
     double cur_len = IN(0);
-    double dnext = (m > 1) ? IN(1) : 0.0;
+    double dnext = (!LONG && m > 1) ? IN(1) : 0.0;
+    // LONG: what a step reads from memory -- the old segment's length and, beyond the rows of the chain table kept in LDS, the row
+    // B^(m-i-1) e_end -- does not depend on the draws before it and is requested FOUR steps ahead (a branch of thousands of segments is
+    // walked by one wave: with the loads a step ahead a step costs a memory round trip)
+    double dq[4] = {0.0, 0.0, 0.0, 0.0}, bq[4][NS];
+    auto beta_row = [&](int i, double (&bv)[NS]) {
+      const int kk = min(max(m - i - 1, 0), p.klong - 1);
+      const double* bl = s_col + ((kk < ktab ? kk : ktab - 1) * NS + cs) * NS;
+#pragma unroll
+      for (int c = 0; c < NS; ++c) bv[c] = bl[c];
+      if (kk >= ktab) {
+        const double* __restrict__ bg = p.colL + ((size_t)kk * NS + cs) * NS;
+#pragma unroll
+        for (int c = 0; c < NS; ++c) bv[c] = bg[c];
+      }
+    };
+    if (LONG) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int c = 0; c < NS; ++c) bq[q][c] = 0.0;
+        if (1 + q < m) { dq[q] = IN(1 + q); beta_row(1 + q, bq[q]); }
+      }
+    }
     // Four steps per Philox block of the state stream (the step index is wave-uniform: draw i - 1 is a fixed word of it).
     for (int i0 = 1; i0 < mmax; i0 += 4) {
       uint32_t wd[4] = {0u, 0u, 0u, 0u};
@@ -376,9 +399,21 @@ __global__ __launch_bounds__(TILES_BLOCK, KS ? 7 : 8) void tiles_branch_kernel(T
       for (int q = 0; q < 4; ++q) {
       const int i = i0 + q;
       if (i < m) {
-        int si = (i == m - 1) ? cs : draw_state_w(i, cur_s, wd[q]);
-        double di = dnext;
-        if (i + 1 < m) dnext = IN(i + 1);
+        int si;
+        double di;
+        if (LONG) {
+          if (m - i - 1 >= p.klong) err |= DERR_CAPACITY;
+          double pr[NS];
+#pragma unroll
+          for (int c = 0; c < NS; ++c) pr[c] = s_B2[cur_s * NS + c] * bq[q][c];
+          si = (i == m - 1) ? cs : sample_cat<NS>(pr, u01(wd[q]), err);
+          di = dq[q];
+          if (i + 4 < m) { dq[q] = IN(i + 4); beta_row(i + 4, bq[q]); }
+        } else {
+          si = (i == m - 1) ? cs : draw_state_w(i, cur_s, wd[q]);
+          di = dnext;
+          if (i + 1 < m) dnext = IN(i + 1);
+        }
         if (KS) s_cnt[(cur_s * NS + si) * 64 + lane] = (uint16_t)(s_cnt[(cur_s * NS + si) * 64 + lane] + 1u);               // shortenerbf :1010-1014
         if (si == cur_s) cur_len = cur_len + di;                           // shortener :54
         else {
