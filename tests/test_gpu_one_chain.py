@@ -189,7 +189,7 @@ def test_automatic_mapping_keeps_the_branch_mapping_on_paths_of_hundreds_of_segm
     z = synth.make_tree(200, Q, Omega, 3, np.full(2, 0.5), init_segments=2)
     long_z = dict(z, maps=[mp * 30.0 for mp in z["maps"]])               # Omega t_b = 120 on average
     long_z["edge.length"] = z["edge.length"] * 30.0
-    for tree, S, want in [(z, 512, "tiles"), (long_z, 512, "branches"), (long_z, 20000, "tiles")]:
+    for tree, S, want in [(z, 300, "tiles"), (long_z, 300, "branches"), (long_z, 20000, "tiles")]:      # floor / slope = 432 chains on long_z
         eng = _lib.Engine(tree, Q, np.full(2, 0.5), Omega, 2, variant=_lib.PHM_MCMC_BIGTREE, seed=1, n_replicas=S)
         assert eng.info().mapping == _lib.MAPPING[want], (S, want)
         eng.close()
