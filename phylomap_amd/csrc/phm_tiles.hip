@@ -65,7 +65,13 @@ __global__ __launch_bounds__(TILES_BLOCK) void tiles_up_kernel(TileParams<NS> p,
 // The same pass over one TIER of subtree clusters: a workgroup per (cluster, tile) walks the cluster's height levels, its waves
 // sharing the nodes of a level, a workgroup barrier between levels (the waves of a workgroup share their CU's L1: what one wrote
 // before the barrier the others read after it).  Big clusters first.
-template <int NS>
+// ASYNC (long paths: TileParams::mstate is set): no barriers -- a level barrier charges the level its longest chain, and on paths of
+// hundreds of segments the sum of those is many times the longest line of dependent steps (phm_narrow.hip, narrow_cluster_kernel).
+// The waves take the cluster's nodes (listed by height: a topological order) off a counter as they get free and wait for the
+// children that belong to the cluster on a flag per node; the first unfinished node was handed out before any later one and its
+// children are finished, so some wave always runs.  A cluster of a band of eight levels holds at most 255 nodes.
+constexpr int TILES_CL_ASYNC_NODES = 256;
+template <int NS, bool ASYNC>
 __global__ __launch_bounds__(TILES_CL_BLOCK) void tiles_up_cluster_kernel(TileParams<NS> p, int cl_begin, int n_cl) {
   constexpr int W = TILES_CL_BLOCK / 64;
   const int lane = threadIdx.x & 63;
@@ -74,6 +80,33 @@ __global__ __launch_bounds__(TILES_CL_BLOCK) void tiles_up_cluster_kernel(TilePa
   const int tile = (int)(blockIdx.x / (unsigned)n_cl);
   const int l0 = p.cl_lvl_ptr[cl], l1 = p.cl_lvl_ptr[cl + 1] - 1;
   uint32_t err = 0;
+  if (ASYNC) {
+    __shared__ int32_t s_done[TILES_CL_ASYNC_NODES];
+    __shared__ int32_t s_next;
+    const int first = p.cl_lvl_off[l0], n_items = p.cl_lvl_off[l1] - first;
+    if (n_items <= TILES_CL_ASYNC_NODES) {             // (a bigger cluster -- not from the band plan -- walks its levels below)
+      for (int i = threadIdx.x; i < TILES_CL_ASYNC_NODES; i += TILES_CL_BLOCK) s_done[i] = 0;
+      if (threadIdx.x == 0) s_next = 0;
+      __syncthreads();
+      for (;;) {
+        int idx = 0;
+        if (lane == 0) idx = atomicAdd(&s_next, 1);
+        idx = __builtin_amdgcn_readfirstlane(idx);
+        if (idx >= n_items) break;
+        const ClusterNode nd = p.cl_nodes[first + idx];
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+          if (nd.slot[k] >= 0)
+            while (__hip_atomic_load(&s_done[nd.slot[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        up_node<NS>(p, tile, nd.parent, nd.child[0], nd.child[1], nd.edge[0], nd.edge[1], lane, err);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_store(&s_done[idx], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      if (err) atomicOr(p.err, err);
+      return;
+    }
+  }
   for (int l = l0; l < l1; ++l) {
     const int i1 = p.cl_lvl_off[l + 1];
     for (int i = p.cl_lvl_off[l] + wave; i < i1; i += W) {
@@ -681,7 +714,8 @@ hipError_t launch_tiles_sweep(const TileParams<NS>& p, const std::vector<int32_t
     const int n_tiers = (int)tier_off.size() - 1;
     for (int t = 0; t < n_tiers; ++t) {
       const int n_cl = tier_off[t + 1] - tier_off[t];
-      hipLaunchKernelGGL(tiles_up_cluster_kernel<NS>, dim3((unsigned)((int64_t)n_cl * p.n_tiles)), dim3(TILES_CL_BLOCK), 0, stream, p, tier_off[t], n_cl);
+      if (p.mstate) hipLaunchKernelGGL((tiles_up_cluster_kernel<NS, true>), dim3((unsigned)((int64_t)n_cl * p.n_tiles)), dim3(TILES_CL_BLOCK), 0, stream, p, tier_off[t], n_cl);
+      else hipLaunchKernelGGL((tiles_up_cluster_kernel<NS, false>), dim3((unsigned)((int64_t)n_cl * p.n_tiles)), dim3(TILES_CL_BLOCK), 0, stream, p, tier_off[t], n_cl);
     }
     mark(1);
     for (int t = n_tiers - 1; t >= 0; --t) {
