@@ -172,8 +172,9 @@ typedef struct phm_debug_options {
   int32_t fail_recovery;       /* 1 = every capacity recovery "does not fit" (exercises the dead-handle path) */
   int32_t branch_group;        /* > 0: branches per wave of the 5..64-state branch kernel (clamped to 1..64); 0 = automatic */
   int32_t level_groups;        /* (tile, branch) mapping, n <= 4: tree passes over clusters of tree levels (one launch per tier of eight
-                                  levels) instead of one launch per level: 0 = automatic (tiles x internal nodes <= 65 536), 1 = never,
-                                  2 = always, 3 = always with clusters cut by subtree size (measurement).  Same bits */
+                                  levels) instead of one launch per level: 0 = automatic (tiles x internal nodes <= 65 536; a deep, ladder-like
+                                  tree at any tile count, with clusters cut by subtree size), 1 = never, 2 = always, 3 = always with
+                                  clusters cut by subtree size.  Same bits */
   int32_t q_timing;            /* 1 = the rate-updating drivers print the mean host time of the phases of an iteration to stderr */
   double  pade_pivot_min;      /* > 0: smallest pivot phm_expm_pade_mfma's unpivoted block elimination accepts (default 1e-3;
                                   1e300 sends every matrix to the pivoted kernel) */

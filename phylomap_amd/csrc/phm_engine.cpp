@@ -715,10 +715,16 @@ int32_t tiles_setup(phm_engine* e, const phm_tree* x, const phm_model* model, co
   }
   // few tiles (the sites of an alignment): the two tree passes over clusters cut by height, one launch per tier, instead of one per
   // level (phm_tiles.h); phm_debug_options.level_groups: 1 = never, 2 = always, 3 = always, clusters cut by subtree size
+  // A DEEP tree (a ladder-like phylogeny: far more height levels than a balanced tree of its size would have) at any tile count:
+  // clusters cut by subtree size, a handful of tiers instead of a launch per level and pass (2 000-tip ladder at 8 192 replicas:
+  // 4 002 launches, 19.2 ms per sweep -> 19 launches, 9.0 ms; bands of eight levels 10.8).
   e->nw_tier_off.clear();
-  if (e->dbg.level_groups >= 2 || (e->dbg.level_groups == 0 && (int64_t)tiles * Nn <= phm::TILES_CL_MAX_WORK)) {
+  int lg2 = 0;
+  while ((1 << lg2) < Nn + 1) ++lg2;
+  const bool deep = (int)e->nw_up_off.size() - 1 > 4 * lg2 + 32;
+  if (e->dbg.level_groups >= 2 || (e->dbg.level_groups == 0 && (deep || (int64_t)tiles * Nn <= phm::TILES_CL_MAX_WORK))) {
     phm::ClusterPlan plan;
-    if (e->dbg.level_groups == 3) phm::build_cluster_plan(s, phm::TILES_CL_NODES, plan);      // (measured against: subtrees by size)
+    if (e->dbg.level_groups == 3 || (e->dbg.level_groups == 0 && deep)) phm::build_cluster_plan(s, phm::TILES_CL_NODES, plan);      // subtrees by size
     else phm::build_band_plan(s, TILES_CL_BAND, plan);
     e->nw_tier_off = plan.tier_off;
     HIPCHK(e->d_nw_cl_nodes.alloc(sizeof(phm::ClusterNode) * plan.nodes.size()));
