@@ -526,6 +526,27 @@ def main():
             blocks[f"C3_{Sm}_sites"] = {"mapping": "one wave per (tile, branch)", "ms_per_sweep": d1 / 40 * 1e3, "launches_per_sweep": nl,
                                         "realisations_per_s": z["edge"].shape[0] * Sm * 40 / d1}
 
+        # The reference's own flagship run: the 3 951-tip squamate tree at Omega = 10 (vignettes/Squamate_DIC_model_selection.Rnw:76-120):
+        # ~111 segments per branch, 2 280 on the longest -- one chain (what the R call gets) and 1 024 chains (automatic mapping)
+        sq = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "squamate", "seed101_tips.npz")
+        if os.path.exists(sq):
+            d = np.load(sq)
+            Tq = len(d["states"])
+            zq = {"edge": d["edge"], "Nnode": Tq - 1, "edge.length": d["edge_length"], "states": d["states"]}
+            zq["maps"] = [np.full(100, l / 100) if c > Tq else np.full(2, l / 2) for (p_, c), l in zip(d["edge"], d["edge_length"])]
+            zq["mapnames"] = [np.ones(100, dtype=np.int32) if c > Tq else np.array([1, d["states"][c - 1]], dtype=np.int32) for (p_, c) in d["edge"]]
+            Qq = np.array([[-0.001, 0.001], [0.006, -0.006]])
+            for key, Sq, Kq in (("squamate_one_chain", 1, 100), ("squamate_1024_chains", 1024, 12)):
+                mid = _lib.Engine(zq, Qq, [.5, .5], 10.0, Kq + 24, variant=_lib.PHM_MCMC_BIGTREE, seed=1, n_replicas=Sq, reduce=Sq > 1, device=local_rank)
+                mid.run(24); mid.sync()
+                i0 = mid.info()
+                t1 = time.perf_counter(); mid.run(Kq); mid.sync(); d1 = time.perf_counter() - t1
+                i1 = mid.info()
+                assert i1.recoveries == 0
+                blocks[key] = {"ms_per_sweep": d1 / Kq * 1e3, "realisations_per_s": d["edge"].shape[0] * Sq * Kq / d1,
+                               "segments_per_s": (i1.seg_read - i0.seg_read) / d1, "mapping": {v: k for k, v in _lib.MAPPING.items()}.get(i1.mapping, i1.mapping)}
+                mid.close()
+
         # sumstatEXP (src/phylomap.cpp:3001-3051): C1 as stated, and the 1 000-tip 4-state tree with the rescaled pruning pass
         L = _lib.load()
         for key, c, N, resc in (("EXP_C1", 1, 1 << 16, False), ("EXP_1000_tips", 2, 1 << 16, True)):
