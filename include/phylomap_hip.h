@@ -171,7 +171,8 @@ typedef struct phm_debug_options {
   int32_t phase_timing;        /* 1 = record HIP events between the phases of a sweep (phm_engine_phase_ms) */
   int32_t fail_recovery;       /* 1 = every capacity recovery "does not fit" (exercises the dead-handle path) */
   int32_t branch_group;        /* > 0: branches per wave of the 5..64-state branch kernel (clamped to 1..64); 0 = automatic */
-  int32_t level_groups;        /* (tile, branch) mapping, n <= 4: tree passes over clusters of tree levels (one launch per tier of eight
+  int32_t level_groups;        /* (tile, branch) mapping, n <= 4 (5..32 states: 2 / 3 = the node draws and the band pruning kernel over
+                                  subtree clusters; automatic on a deep tree): tree passes over clusters of tree levels (one launch per tier of eight
                                   levels) instead of one launch per level: 0 = automatic (tiles x internal nodes <= 65 536; a deep, ladder-like
                                   tree at any tile count, with clusters cut by subtree size), 1 = never, 2 = always, 3 = always with
                                   clusters cut by subtree size.  Same bits */

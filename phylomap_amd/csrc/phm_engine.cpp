@@ -806,6 +806,25 @@ int32_t wtiles_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
   }
   HIPCHK(e->d_up.alloc(sizeof(phm::UpStep) * Nn)); HIPCHK(e->d_down.alloc(sizeof(phm::DownStep) * E));
   { int32_t lst = build_level_orders(e); if (lst) return lst; }
+  // A DEEP tree (tiles_setup has the rule): the band pruning kernel and the node draws for n <= 32 run over subtree clusters, a launch per
+  // tier instead of one per level and pass (phm_wtiles.hip); phm_debug_options.level_groups: 1 = never, 2 / 3 = always
+  e->nw_tier_off.clear();
+  {
+    int lg2 = 0;
+    while ((1 << lg2) < Nn + 1) ++lg2;
+    const bool deep = (int)e->nw_up_off.size() - 1 > 4 * lg2 + 32;
+    if (n <= 32 && (e->dbg.level_groups >= 2 || (e->dbg.level_groups == 0 && deep))) {
+      phm::ClusterPlan plan;
+      phm::build_cluster_plan(s, phm::TILES_CL_NODES, plan);
+      e->nw_tier_off = plan.tier_off;
+      HIPCHK(e->d_nw_cl_nodes.alloc(sizeof(phm::ClusterNode) * plan.nodes.size()));
+      HIPCHK(e->d_nw_cl_lvl_ptr.alloc(sizeof(int32_t) * plan.lvl_ptr.size()));
+      HIPCHK(e->d_nw_cl_lvl_off.alloc(sizeof(int32_t) * plan.lvl_off.size()));
+      HIPCHK(hipMemcpy(e->d_nw_cl_nodes.p, plan.nodes.data(), e->d_nw_cl_nodes.bytes, hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(e->d_nw_cl_lvl_ptr.p, plan.lvl_ptr.data(), e->d_nw_cl_lvl_ptr.bytes, hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(e->d_nw_cl_lvl_off.p, plan.lvl_off.data(), e->d_nw_cl_lvl_off.bytes, hipMemcpyHostToDevice));
+    }
+  }
   HIPCHK(e->d_nw_border.alloc(sizeof(int32_t) * E)); HIPCHK(e->d_tl_slot.alloc(sizeof(int32_t) * (E + 1)));
   HIPCHK(e->d_nw_colL.alloc(sizeof(double) * tab)); HIPCHK(e->d_nw_rowL.alloc(sizeof(double) * tab));
   HIPCHK(e->d_nw_maskL.alloc(sizeof(double) * (size_t)e->nw_klong * 2 * ldt));
@@ -871,6 +890,8 @@ int32_t wtiles_setup(phm_engine* e, const phm_tree* x, const phm_model* model, c
   if (e->dbg.branch_group > 0) p.group = std::min(64, (int)e->dbg.branch_group);      // measurement aid (phm_debug_options)
   p.n_groups = (E + p.group - 1) / p.group;
   p.up_form = e->dbg.pruning_form & 3; p.band_up = 0; p.band_draw = 0; p.B2band = e->d_wt_B2band.as<double>();
+  p.cl_nodes = e->nw_tier_off.empty() ? nullptr : e->d_nw_cl_nodes.as<phm::ClusterNode>();
+  p.cl_lvl_ptr = e->d_nw_cl_lvl_ptr.as<int32_t>(); p.cl_lvl_off = e->d_nw_cl_lvl_off.as<int32_t>();
   e->sparse_req = o.sparse_chains;
   p.seed_lo = (uint32_t)(o.seed & 0xFFFFFFFFull); p.seed_hi = (uint32_t)(o.seed >> 32);
   p.rows = rows;
@@ -1360,10 +1381,14 @@ int32_t phm_engine_run(phm_engine* e, int32_t n_iters, void* hip_stream) {
       if (e->n == 2) le = phm::launch_tiles_sweep<2>(e->t2, e->nw_up_off, e->nw_down_off, e->nw_tier_off, it, stream, pev);
       if (e->n == 3) le = phm::launch_tiles_sweep<3>(e->t3, e->nw_up_off, e->nw_down_off, e->nw_tier_off, it, stream, pev);
       if (e->n == 4) le = phm::launch_tiles_sweep<4>(e->t4, e->nw_up_off, e->nw_down_off, e->nw_tier_off, it, stream, pev);
-      if (e->wide) le = phm::launch_wtiles_sweep(e->pwt, e->wt_band, e->wt_sparse, e->nw_up_off, e->nw_down_off, it, stream, pev);
-      const bool clusters = !e->wide && !e->nw_tier_off.empty();
-      launches += clusters ? 2 * ((int)e->nw_tier_off.size() - 1) + 3      // a launch per tier and pass, branch kernel, two reductions
-                           : (int)(e->nw_up_off.size() + e->nw_down_off.size()) + 2;
+      if (e->wide) le = phm::launch_wtiles_sweep(e->pwt, e->wt_band, e->wt_sparse, e->nw_up_off, e->nw_down_off, e->nw_tier_off, it, stream, pev);
+      const bool clusters = !e->nw_tier_off.empty();
+      const int tiers = (int)e->nw_tier_off.size() - 1;
+      if (clusters && e->wide)             // 5 .. 32 states on a deep tree: the node draws by tier, the pruning pass too when it runs on the band kernel
+        launches += (e->pwt.band_up > 0 && !e->wt_sparse.kernel ? tiers : (int)e->nw_up_off.size() - 1) + tiers + 4;
+      else
+        launches += clusters ? 2 * tiers + 3      // a launch per tier and pass, branch kernel, two reductions
+                             : (int)(e->nw_up_off.size() + e->nw_down_off.size()) + 2;
     }
     HIPCHK(le);
   }
@@ -1729,7 +1754,7 @@ extern "C" int32_t phm_engine_time_pruning(phm_engine* e, int32_t n_iters, void*
   hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
   HIPCHK(hipEventRecord(e->ev0, stream));
   hipError_t le = hipSuccess;
-  if (wt) for (int i = 0; i < n_iters && le == hipSuccess; ++i) le = phm::launch_wtiles_up(e->pwt, e->wt_band, e->wt_sparse, e->nw_up_off, stream);
+  if (wt) for (int i = 0; i < n_iters && le == hipSuccess; ++i) le = phm::launch_wtiles_up(e->pwt, e->wt_band, e->wt_sparse, e->nw_up_off, e->nw_tier_off, stream);
   // iteration index = iters_done keeps the dwell ping-pong parity; nothing but PL is written
   if (!wt && e->n == 2) { auto p = e->p2; p.prune_only = 1; for (int i = 0; i < n_iters && le == hipSuccess; ++i) le = phm::launch_mcmc<2>(p, e->iters_done, 1, stream); }
   if (e->n == 3) { auto p = e->p3; p.prune_only = 1; for (int i = 0; i < n_iters && le == hipSuccess; ++i) le = phm::launch_mcmc<3>(p, e->iters_done, 1, stream); }

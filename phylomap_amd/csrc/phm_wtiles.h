@@ -75,6 +75,9 @@ struct WtParams {
   const DownStep* down;
   const int32_t* up_order;
   const int32_t* down_order;
+  const ClusterNode* cl_nodes;               // deep trees (not null): the tree passes over subtree clusters (phm_sched.h ClusterPlan), tier by tier
+  const int32_t* cl_lvl_ptr;                 // [n_clusters + 1] into cl_lvl_off
+  const int32_t* cl_lvl_off;                 // per cluster: boundaries of its height levels (positions in cl_nodes)
   const int32_t* branch_order;               // edge rows, largest slot first
   const int32_t* slot;                       // [n_edge + 1] first row of every branch slot
   const double* colL;                        // [klong][n][ldt]  (Bc^k e_j)[r]
@@ -111,9 +114,12 @@ struct WtSparseUp {
 };
 
 // phase_ev: optional 5 events, as in launch_tiles_sweep
+// tier_off: boundaries of the cluster tiers (empty, or p.cl_nodes null: one launch per tree level)
 hipError_t launch_wtiles_sweep(const WtParams& p, const WtBand& band, const WtSparseUp& sparse, const std::vector<int32_t>& up_off,
-                               const std::vector<int32_t>& down_off, int it, hipStream_t stream, hipEvent_t* phase_ev = nullptr);
+                               const std::vector<int32_t>& down_off, const std::vector<int32_t>& tier_off, int it, hipStream_t stream,
+                               hipEvent_t* phase_ev = nullptr);
 // the pruning (up) sweep alone, for bench.py's roofline block
-hipError_t launch_wtiles_up(const WtParams& p, const WtBand& band, const WtSparseUp& sparse, const std::vector<int32_t>& up_off, hipStream_t stream);
+hipError_t launch_wtiles_up(const WtParams& p, const WtBand& band, const WtSparseUp& sparse, const std::vector<int32_t>& up_off,
+                            const std::vector<int32_t>& tier_off, hipStream_t stream);
 
 }  // namespace phm

@@ -468,19 +468,12 @@ __global__ __launch_bounds__(WT_BLOCK, wt_up2_waves(MT)) void wt_up2_kernel(WtPa
 // are the same number.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int NP, int HB>
-__global__ __launch_bounds__(WT_BLOCK) void wt_up_band_kernel(WtParams p, WtBand bd, int begin, int end) {
+__device__ __forceinline__ void wt_up_band_node(const WtParams& p, const WtBand& bd, int tile, const UpStep& st, int lane, uint32_t& err) {
   constexpr int W = 2 * HB + 1;
-  const int lane = threadIdx.x & 63;
-  const int n_lvl = end - begin;
-  const int64_t item = (int64_t)blockIdx.x * (WT_BLOCK / 64) + (threadIdx.x >> 6);
-  if (item >= (int64_t)n_lvl * p.n_tiles) return;
   const int n = p.n_states, ldt = p.ldt;
-  const int tile = (int)(item % p.n_tiles), li = (int)(item / p.n_tiles);
-  const UpStep st = p.up[p.up_order[begin + li]];
   double* __restrict__ PLt = p.PL + (size_t)tile * p.n_node * n * 64;
   const uint16_t* __restrict__ mct = p.mcount + (size_t)tile * p.n_edge * 64;
   const uint8_t* __restrict__ tips_t = p.tips_per_replica ? p.tips + (size_t)tile * p.n_tips * 64 : p.tips;
-  uint32_t err = 0;
   double R[2][NP];
 #pragma unroll
   for (int ch = 0; ch < 2; ++ch) {                     // ch 0: "first" = child[1] (:508); ch 1: "second" = child[0] (:509)
@@ -538,6 +531,45 @@ __global__ __launch_bounds__(WT_BLOCK) void wt_up_band_kernel(WtParams p, WtBand
 #pragma unroll
   for (int i = 0; i < NP; ++i)
     if (i < n) PLt[((size_t)st.parent * n + i) * 64 + lane] = P[i];
+}
+
+template <int NP, int HB>
+__global__ __launch_bounds__(WT_BLOCK) void wt_up_band_kernel(WtParams p, WtBand bd, int begin, int end) {
+  const int lane = threadIdx.x & 63;
+  const int n_lvl = end - begin;
+  const int64_t item = (int64_t)blockIdx.x * (WT_BLOCK / 64) + (threadIdx.x >> 6);
+  if (item >= (int64_t)n_lvl * p.n_tiles) return;
+  const int tile = (int)(item % p.n_tiles), li = (int)(item / p.n_tiles);
+  const UpStep st = p.up[p.up_order[begin + li]];
+  uint32_t err = 0;
+  wt_up_band_node<NP, HB>(p, bd, tile, st, lane, err);
+  if (err) atomicOr(p.err, err);
+}
+
+// DEEP trees (a ladder-like phylogeny: thousands of height levels, a launch per level and pass would be all the sweep does --
+// 2 000-tip ladder, 8 states, 4 096 replicas: 19.9 of 21.9 ms): the same step over one TIER of subtree clusters
+// (phm_sched.h ClusterPlan), a workgroup per (cluster, tile) walking the cluster's levels with a workgroup barrier between them,
+// as tiles_up_cluster_kernel does for 2 .. 4 states.
+constexpr int WT_CL_BLOCK = 512;
+template <int NP, int HB>
+__global__ __launch_bounds__(WT_CL_BLOCK) void wt_up_band_cluster_kernel(WtParams p, WtBand bd, int cl_begin, int n_cl) {
+  constexpr int NW = WT_CL_BLOCK / 64;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int cl = cl_begin + (int)(blockIdx.x % (unsigned)n_cl);
+  const int tile = (int)(blockIdx.x / (unsigned)n_cl);
+  const int l0 = p.cl_lvl_ptr[cl], l1 = p.cl_lvl_ptr[cl + 1] - 1;
+  uint32_t err = 0;
+  for (int l = l0; l < l1; ++l) {
+    const int i1 = p.cl_lvl_off[l + 1];
+    for (int i = p.cl_lvl_off[l] + wave; i < i1; i += NW) {
+      const ClusterNode nd = p.cl_nodes[i];
+      UpStep st;
+      st.parent = nd.parent; st.child[0] = nd.child[0]; st.child[1] = nd.child[1]; st.edge[0] = nd.edge[0]; st.edge[1] = nd.edge[1];
+      wt_up_band_node<NP, HB>(p, bd, tile, st, lane, err);
+    }
+    __syncthreads();
+  }
   if (err) atomicOr(p.err, err);
 }
 
@@ -857,14 +889,8 @@ __global__ __launch_bounds__(64) void wt_down1_kernel(WtParams p, int it, int be
 // n <= 32: every running sum in registers (NP = n rounded up to a multiple of four; 98 registers at 20 states), no LDS, a wave per
 // (tile, edge), four waves per workgroup.  C5: 4.05 -> 3.49 ms per sweep against the two-pass form (55 registers, eight waves per SIMD).
 template <int NP>
-__global__ __launch_bounds__(WT_BLOCK) void wt_down1r_kernel(WtParams p, int it, int begin, int end) {
-  const int lane = threadIdx.x & 63;
-  const int item = blockIdx.x * (WT_BLOCK / 64) + (threadIdx.x >> 6);
-  const int n_lvl = end - begin;
-  if (item >= n_lvl * p.n_tiles) return;
+__device__ __forceinline__ void wt_down1r_edge(const WtParams& p, int it, int tile, const DownStep& ds, int lane, uint32_t& err) {
   const int n = p.n_states, ldt = p.ldt;
-  const int tile = item / n_lvl;
-  const DownStep ds = p.down[p.down_order[begin + item % n_lvl]];
   const int b = ds.edge;
   const double* __restrict__ PLt = p.PL + (size_t)tile * p.n_node * n * 64;
   uint8_t* __restrict__ nst = p.nstate + (size_t)tile * p.n_node * 64;
@@ -872,7 +898,6 @@ __global__ __launch_bounds__(WT_BLOCK) void wt_down1r_kernel(WtParams p, int it,
   const uint32_t rep = (uint32_t)(p.replica_offset + tile * 64 + lane);
   const int m = p.mcount[((size_t)tile * p.n_edge + b) * 64 + lane];
   const int ps = nst[ds.parent * 64 + lane];
-  uint32_t err = 0;
   int cs;
   if (ds.child >= 0 || p.tip_masks) {
     int kk = m - 1;
@@ -908,6 +933,42 @@ __global__ __launch_bounds__(WT_BLOCK) void wt_down1r_kernel(WtParams p, int it,
     cs = p.tips_per_replica ? tips_t[tip * 64 + lane] : p.tips[tip];            // :612
   }
   p.estate[((size_t)tile * p.n_edge + b) * 64 + lane] = (uint16_t)(ps | (cs << 8));   // updatenodestates :460-475
+}
+
+template <int NP>
+__global__ __launch_bounds__(WT_BLOCK) void wt_down1r_kernel(WtParams p, int it, int begin, int end) {
+  const int lane = threadIdx.x & 63;
+  const int item = blockIdx.x * (WT_BLOCK / 64) + (threadIdx.x >> 6);
+  const int n_lvl = end - begin;
+  if (item >= n_lvl * p.n_tiles) return;
+  const int tile = item / n_lvl;
+  const DownStep ds = p.down[p.down_order[begin + item % n_lvl]];
+  uint32_t err = 0;
+  wt_down1r_edge<NP>(p, it, tile, ds, lane, err);
+  if (err) atomicOr(p.err, err);
+}
+
+// deep trees: the node draws over one tier of subtree clusters, top level first (a wave per (node of the level, child side));
+// the root has been drawn by wt_root_kernel
+template <int NP>
+__global__ __launch_bounds__(WT_CL_BLOCK) void wt_down1r_cluster_kernel(WtParams p, int it, int cl_begin, int n_cl) {
+  constexpr int NW = WT_CL_BLOCK / 64;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int cl = cl_begin + (int)(blockIdx.x % (unsigned)n_cl);
+  const int tile = (int)(blockIdx.x / (unsigned)n_cl);
+  const int l0 = p.cl_lvl_ptr[cl], l1 = p.cl_lvl_ptr[cl + 1] - 1;
+  uint32_t err = 0;
+  for (int l = l1 - 1; l >= l0; --l) {
+    const int i0 = p.cl_lvl_off[l], cnt = 2 * (p.cl_lvl_off[l + 1] - i0);
+    for (int j = wave; j < cnt; j += NW) {
+      const ClusterNode nd = p.cl_nodes[i0 + (j >> 1)];
+      DownStep ds;
+      ds.edge = nd.edge[j & 1]; ds.parent = nd.parent; ds.child = nd.child[j & 1];
+      wt_down1r_edge<NP>(p, it, tile, ds, lane, err);
+    }
+    __syncthreads();
+  }
   if (err) atomicOr(p.err, err);
 }
 
@@ -1370,7 +1431,14 @@ hipError_t launch_up_levels(const WtParams& p, const std::vector<int32_t>& up_of
 }  // namespace
 
 template <int NP, int HB>
-void launch_up_band(const WtParams& p, const WtBand& band, const std::vector<int32_t>& up_off, hipStream_t stream) {
+void launch_up_band(const WtParams& p, const WtBand& band, const std::vector<int32_t>& up_off, const std::vector<int32_t>& tier_off, hipStream_t stream) {
+  if (p.cl_nodes && tier_off.size() > 1) {           // deep tree: one launch per tier of subtree clusters
+    for (size_t t = 0; t + 1 < tier_off.size(); ++t) {
+      const int n_cl = tier_off[t + 1] - tier_off[t];
+      hipLaunchKernelGGL((wt_up_band_cluster_kernel<NP, HB>), dim3((unsigned)((int64_t)n_cl * p.n_tiles)), dim3(WT_CL_BLOCK), 0, stream, p, band, tier_off[t], n_cl);
+    }
+    return;
+  }
   for (size_t l = 0; l + 1 < up_off.size(); ++l) {
     const int cnt = up_off[l + 1] - up_off[l];
     if (cnt <= 0) continue;
@@ -1379,13 +1447,14 @@ void launch_up_band(const WtParams& p, const WtBand& band, const std::vector<int
   }
 }
 
-hipError_t launch_wtiles_up(const WtParams& p, const WtBand& band, const WtSparseUp& sparse, const std::vector<int32_t>& up_off, hipStream_t stream) {
+hipError_t launch_wtiles_up(const WtParams& p, const WtBand& band, const WtSparseUp& sparse, const std::vector<int32_t>& up_off,
+                            const std::vector<int32_t>& tier_off, hipStream_t stream) {
   if (sparse.kernel) return launch_sparse_up(*sparse.kernel, sparse.params, up_off, stream);      // unstructured sparse chain matrix: the kernel generated for its pattern
   if (p.band_up > 0) {                                  // banded chain matrix: per-lane FMAs over the band
     const int np = (p.n_states + 3) / 4;               // vectors padded to a multiple of four states
 #define PHM_BAND_CASE(NPQ)                                                                          \
-    case NPQ: if (p.band_up == 1) launch_up_band<4 * NPQ, 1>(p, band, up_off, stream);            \
-              else launch_up_band<4 * NPQ, 2>(p, band, up_off, stream);                            \
+    case NPQ: if (p.band_up == 1) launch_up_band<4 * NPQ, 1>(p, band, up_off, tier_off, stream);  \
+              else launch_up_band<4 * NPQ, 2>(p, band, up_off, tier_off, stream);                  \
               break;
     switch (np) {
       PHM_BAND_CASE(2) PHM_BAND_CASE(3) PHM_BAND_CASE(4) PHM_BAND_CASE(5) PHM_BAND_CASE(6) PHM_BAND_CASE(7) PHM_BAND_CASE(8)
@@ -1404,16 +1473,26 @@ hipError_t launch_wtiles_up(const WtParams& p, const WtBand& band, const WtSpars
 }
 
 hipError_t launch_wtiles_sweep(const WtParams& p, const WtBand& band, const WtSparseUp& sparse, const std::vector<int32_t>& up_off,
-                               const std::vector<int32_t>& down_off, int it, hipStream_t stream, hipEvent_t* phase_ev) {
+                               const std::vector<int32_t>& down_off, const std::vector<int32_t>& tier_off, int it, hipStream_t stream,
+                               hipEvent_t* phase_ev) {
   constexpr int WPB = WT_BLOCK / 64;
   auto blocks = [&](int64_t items) { return dim3((unsigned)((items + WPB - 1) / WPB)); };
   auto mark = [&](int i) { if (phase_ev) (void)hipEventRecord(phase_ev[i], stream); };
   mark(0);
-  hipError_t e = launch_wtiles_up(p, band, sparse, up_off, stream);
+  hipError_t e = launch_wtiles_up(p, band, sparse, up_off, tier_off, stream);
   if (e != hipSuccess) return e;
   mark(1);
   hipLaunchKernelGGL(wt_root_kernel, blocks(p.n_tiles), dim3(WT_BLOCK), 0, stream, p, it);
   const int mt = (p.n_states + 15) / 16;
+  if (p.cl_nodes && tier_off.size() > 1 && mt <= 2) {      // deep tree, n <= 32: the node draws tier by tier from the top
+    for (int t = (int)tier_off.size() - 2; t >= 0; --t) {
+      const int n_cl = tier_off[t + 1] - tier_off[t];
+      const dim3 g((unsigned)((int64_t)n_cl * p.n_tiles));
+#define PHM_D1RC(NPQ) case NPQ: hipLaunchKernelGGL(wt_down1r_cluster_kernel<4 * NPQ>, g, dim3(WT_CL_BLOCK), 0, stream, p, it, tier_off[t], n_cl); break;
+      switch ((p.n_states + 3) / 4) { PHM_D1RC(2) PHM_D1RC(3) PHM_D1RC(4) PHM_D1RC(5) PHM_D1RC(6) PHM_D1RC(7) PHM_D1RC(8) default: return hipErrorInvalidValue; }
+#undef PHM_D1RC
+    }
+  } else
   for (size_t l = 0; l + 1 < down_off.size(); ++l) {
     const int n = down_off[l + 1] - down_off[l];
     if (n <= 0) continue;

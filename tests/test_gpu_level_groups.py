@@ -59,3 +59,35 @@ def test_automatic_choice_follows_the_tile_count():
         eng.run(1); eng.sync()
         assert (eng.info().last_run_launches < 20) == few, (S, eng.info().last_run_launches)
         eng.close()
+
+
+@pytest.mark.parametrize("n,band", [(8, 1), (20, 1), (12, 2), (20, 0)])
+def test_deep_tree_with_5_to_32_states_tree_passes_over_subtree_clusters(n, band):
+    """phm_wtiles.hip on a ladder (one launch per tree level and pass is all a sweep would do: 4 002 launches, 19.9 of 21.9 ms at
+    2 000 tips, 8 states and 4 096 replicas): the band pruning kernel and the node draws for n <= 32 over subtree clusters, a launch
+    per tier -- chosen automatically on such a tree, forced by level_groups = 2, switched off by 1.  Same per-node code: bit for bit the
+    same statistics, and the oracle's.  band = 0: a dense Q (pruning on the matrix cores stays per level, the node draws use clusters)."""
+    Q = synth.dense_Q(n, 0.02, 0.3, seed=n)
+    if band:
+        idx = np.arange(n)
+        Q[np.abs(idx[:, None] - idx[None, :]) > band] = 0.0
+        np.fill_diagonal(Q, 0.0); np.fill_diagonal(Q, -Q.sum(1))
+    Omega = 1.25 * float(np.max(np.abs(np.diag(Q))))
+    pid = np.full(n, 1.0 / n)
+    edge, lens = _ladder(300, 2.0 / Omega, 5)
+    z = _tree_from_edges(edge, lens, Q, pid, seed=9, init_segments=n if band else 2)      # a banded B reaches state j from i in |i - j| / band steps
+    nen, nodelist, root = _orders(z)
+    S, N = 70, 4
+    got, launches = {}, {}
+    for lg in (1, 2, 0):
+        eng = _lib.Engine(z, Q, pid, Omega, N, variant=_lib.PHM_MCMC_BIGTREE, seed=19, n_replicas=S, mapping="tiles", level_groups=lg)
+        eng.run(N); eng.sync()
+        got[lg], launches[lg] = eng.stats(0, N), eng.info().last_run_launches
+        eng.close()
+    np.testing.assert_array_equal(got[1], got[2])
+    np.testing.assert_array_equal(got[1], got[0])
+    for r in (0, 63, 64, S - 1):
+        want, rc = O.maketreelistMCMC(z, Q, pid, np.eye(n) + Q / Omega, Omega, nen, nodelist, root, N, variant=O.BIGTREE, seed=19, replica=r)
+        assert rc == 0
+        _same(got[0][r], want, n)
+
