@@ -911,8 +911,9 @@ __device__ __forceinline__ void narrow_branch_wide(const NarrowParams<NS>& p, in
   }
 }
 
-// The longest branches set the duration of the kernel: the first n_long (sorted order) get a wave each -- one control flow, the
-// walk at its shortest --, the others go eight to a wave: group g of wave k takes position n_long + g * n_waves8 + k, one of
+// The longest branches set the duration of the kernel: the first n_long (sorted order: NarrowParams::n_wide -- at least the 128
+// longest, and every branch expected to hold 96 segments or more) get a wave each and are walked wave-wide (narrow_branch_wide),
+// the others go eight to a wave: group g of wave k takes position n_long + g * n_waves8 + k, one of
 // the longer branches and seven progressively shorter ones in every wave.
 template <int NS>
 __global__ __launch_bounds__(NARROW_BLOCK) void narrow_branch_kernel(NarrowParams<NS> p, int it, int n_long) {
