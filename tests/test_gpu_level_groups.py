@@ -61,7 +61,7 @@ def test_automatic_choice_follows_the_tile_count():
         eng.close()
 
 
-@pytest.mark.parametrize("n,band", [(8, 1), (20, 1), (12, 2), (20, 0)])
+@pytest.mark.parametrize("n,band", [(8, 1), (20, 1), (12, 2), (32, 2), (5, 1), (20, 0), (32, 0)])
 def test_deep_tree_with_5_to_32_states_tree_passes_over_subtree_clusters(n, band):
     """phm_wtiles.hip on a ladder (one launch per tree level and pass is all a sweep would do: 4 002 launches, 19.9 of 21.9 ms at
     2 000 tips, 8 states and 4 096 replicas): the band pruning kernel and the node draws for n <= 32 over subtree clusters, a launch
