@@ -38,7 +38,20 @@ constexpr int TILES_AUTO_MAX_REPLICAS = 262144;
 // C4, 0.81 ms on C5).  Round 3 (two waves per node, LDS-fed chains, transition maps, per-column statistics) moved the crossover
 // (profiles/r03_probe_small_S_C{4,5}.log): C4 (1 000 branches) 0.76 ms at one chain, + 9 us per further chain -> ~30 chains;
 // C5 (10 000 branches) 0.38 ms, + 60 us per chain -> ~7 chains.  The slope follows the branch count: 50 000 / E chains, at most 32.
-inline int wbranch_auto_max_replicas(int n_edge) { return std::max(1, std::min(32, 50000 / std::max(1, n_edge))); }
+// Late round 4 (tools/probes/probe_auto_choice.py, profiles/r04_probe_auto_choice.log): the cap of 32 chains handed small trees
+// (118 branches: crossover ~200 chains; 64 chains 0.15-0.42 ms against 0.26-0.89) and deep ones (a launch per tree level and pass is
+// the tile mapping's floor there: 1 200-tip ladder, 64 chains, 3.1 against 7.2 ms) to the tile mapping too early: 32 000 / E chains,
+// at most 256, eight times as many on a deep tree.
+inline int wbranch_auto_max_replicas(const phm::Schedule& s) {
+  std::vector<int32_t> depth(s.n_node, 0);
+  int levels = 1;
+  for (const phm::DownStep& d : s.down)              // parents before children
+    if (d.child >= 0) { depth[d.child] = depth[d.parent] + 1; levels = std::max(levels, depth[d.child] + 1); }
+  int lg2 = 0;
+  while ((1 << lg2) < s.n_node + 1) ++lg2;
+  const bool deep = levels > 4 * lg2 + 32;
+  return std::max(1, std::min(256, (deep ? 8 : 1) * (32000 / std::max(1, s.n_edge))));
+}
 
 // Tail at which the fixed slots of the branch-parallel mappings are provisioned, per (replica, branch, sweep).  A slot that
 // overflows costs a rebuild with doubled slots and a replay (recover_capacity), so the tail is set from the number of draws
@@ -1105,7 +1118,7 @@ int32_t phm_engine_create_impl(const phm_tree* trees, int32_t n_trees, const phm
   const bool auto_map = map_req == PHM_MAP_AUTO && o.storage == 0;      // a ring / two-buffer request names the replica layout
   if ((map_req == 2 || map_req == 3) && n_trees != 1) return fail(PHM_ERR_UNSUPPORTED, "the branch-parallel mappings take a single tree");
   if (e->wide) {      // 5..64 states: lane = replica, wave per (tile, item) (phm_wtiles.hip); a handful of chains: wave per (replica, branch)
-    e->tiled = n_trees == 1 && (map_req == 3 || (auto_map && e->S > wbranch_auto_max_replicas(E)));
+    e->tiled = n_trees == 1 && (map_req == 3 || (auto_map && e->S > wbranch_auto_max_replicas(s)));
     e->narrow = n_trees == 1 && !e->tiled && (map_req == 2 || auto_map);
   } else {
     int narrow_cap = narrow_auto_max_replicas(s);
