@@ -40,8 +40,8 @@ constexpr int TILES_AUTO_MAX_REPLICAS = 262144;
 // C5 (10 000 branches) 0.38 ms, + 60 us per chain -> ~7 chains.  The slope follows the branch count: 50 000 / E chains, at most 32.
 // Late round 4 (tools/probes/probe_auto_choice.py, profiles/r04_probe_auto_choice.log): the cap of 32 chains handed small trees
 // (118 branches: crossover ~200 chains; 64 chains 0.15-0.42 ms against 0.26-0.89) and deep ones (a launch per tree level and pass is
-// the tile mapping's floor there: 1 200-tip ladder, 64 chains, 3.1 against 7.2 ms) to the tile mapping too early: 32 000 / E chains,
-// at most 256, eight times as many on a deep tree.
+// the tile mapping's floor there: 1 200-tip ladder, 64 chains at 8 states 3.1 against 7.2 ms, 200 chains at 33 states 6.4 against
+// 17.9) to the tile mapping too early: 50 000 / E chains, at most 256; 256 on a deep tree.
 inline int wbranch_auto_max_replicas(const phm::Schedule& s) {
   std::vector<int32_t> depth(s.n_node, 0);
   int levels = 1;
@@ -50,7 +50,7 @@ inline int wbranch_auto_max_replicas(const phm::Schedule& s) {
   int lg2 = 0;
   while ((1 << lg2) < s.n_node + 1) ++lg2;
   const bool deep = levels > 4 * lg2 + 32;
-  return std::max(1, std::min(256, (deep ? 8 : 1) * (32000 / std::max(1, s.n_edge))));
+  return deep ? 256 : std::max(1, std::min(256, 50000 / std::max(1, s.n_edge)));
 }
 
 // Tail at which the fixed slots of the branch-parallel mappings are provisioned, per (replica, branch, sweep).  A slot that

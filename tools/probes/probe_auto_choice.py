@@ -48,14 +48,14 @@ def main():
     cases = int(sys.argv[2]) if len(sys.argv) > 2 else 40
     bad = 0
     for c in range(cases):
-        n = int(rs.choice([2, 4, 4, 8, 20]))
+        n = int(rs.choice([2, 3, 4, 4, 8, 20, 33, 61]))
         shape = str(rs.choice(["yule", "yule", "ladder"]))
         T = int(rs.choice([60, 300, 1200, 3000]))
         lam = float(rs.choice([0.5, 4.0, 4.0, 30.0, 200.0]))
-        S = int(rs.choice([1, 8, 64, 512, 4096]))
-        if 2.0 * T * (1 + lam) * S > 3e8 or (n > 4 and shape == "ladder" and T > 1200):      # keep a case within a second or so
+        S = int(rs.choice([1, 8, 32, 64, 200, 512, 4096, 16384]))
+        if 2.0 * T * (1 + lam) * S * (1 + n / 8.0) > 3e8 or (n > 4 and shape == "ladder" and T > 1200):      # keep a case within a second or so
             continue
-        Q = synth.dense_Q(n, 0.02, 0.3, seed=n) if n > 4 else synth.config_Q(1 if n == 2 else 2)
+        Q = synth.dense_Q(n, 0.02, 0.3, seed=n) if n > 4 or n == 3 else synth.config_Q(1 if n == 2 else 2)
         Omega = 1.25 * float(np.max(np.abs(np.diag(Q))))
         pid = np.full(n, 1.0 / n)
         z = tree(shape, T, Q, pid, Omega, lam, rs)
