@@ -1122,6 +1122,7 @@ int32_t phm_engine_create_impl(const phm_tree* trees, int32_t n_trees, const phm
     e->narrow = n_trees == 1 && !e->tiled && (map_req == 2 || auto_map);
   } else {
     int narrow_cap = narrow_auto_max_replicas(s);
+    bool long_paths = false;             // a branch expected to hold more than 64 segments: the replica mapping's lane-sequential loop is no place for it
     if (small_n && auto_map) {
       // Long paths: the (tile, branch) mapping cannot end a sweep before ONE wave has walked the longest branch twice (its two passes,
       // ~1.35 us per segment; the reference's squamate tree at Omega = 10, 2 280 segments on one branch: 3.1 ms per sweep up to 64
@@ -1135,9 +1136,10 @@ int32_t phm_engine_create_impl(const phm_tree* trees, int32_t n_trees, const phm
         max_seg = std::max(max_seg, seg); tot_seg += seg;
       }
       if (max_seg > 64.0) narrow_cap = std::max(narrow_cap, (int)std::min(65535.0, 1.35e-3 * max_seg / (4.4e-8 * tot_seg)));
+      long_paths = max_seg > 64.0;
     }
     e->narrow = small_n && (map_req == 2 || (auto_map && e->S <= narrow_cap));
-    e->tiled = small_n && !e->narrow && (map_req == 3 || (auto_map && e->S <= TILES_AUTO_MAX_REPLICAS));
+    e->tiled = small_n && !e->narrow && (map_req == 3 || (auto_map && (long_paths || e->S <= TILES_AUTO_MAX_REPLICAS)));      // (no room: the replica layout, below)
   }
   if (e->narrow && e->S > 65535) {      // the replica index is the grid's y dimension in these kernels
     if (!auto_map) return fail(PHM_ERR_UNSUPPORTED, "the one-lane-per-branch / wave-per-(replica, branch) mappings take at most 65 535 replicas");
