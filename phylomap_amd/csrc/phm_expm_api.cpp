@@ -159,7 +159,7 @@ static int32_t exp_oneshot(const phm_tree* x, int32_t n, const double* Q, const 
       B2[(size_t)i * n + j] = b;
     }
   std::vector<double> col, rowtab;
-  build_chain_tables(B2.data(), n, phm::UNIF_CAP + 1, col, rowtab, false);      // newunifSample :127: unfused sums for every n
+  build_chain_tables(B2.data(), n, phm::UNIF_CAP + 1, col, rowtab, false, false);      // newunifSample :127: unfused sums for every n; no row table
 
   st = select_device(o.device);
   if (st) return st;

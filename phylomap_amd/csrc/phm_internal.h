@@ -14,6 +14,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "phm_exp.h"
@@ -165,15 +166,27 @@ inline void host_chain_matTvec(const double* M, int n, const double* x, double* 
 // chain tables: col[k][j][:] = Bc^k e_j  (v <- Bc v), row[k][j][:] = (Bc^T)^k e_j (w <- Bc^T w);
 // the same sums as the kernels' own chains, so entries are bit-identical to running the chain.  `fused`: the MCMC sweep with
 // n > 4; the sumstatEXP path (newunifSample :127) keeps the unfused left-to-right sums for every n.
-inline void build_chain_tables(const double* Bc, int n, int ktab, std::vector<double>& col, std::vector<double>& row, bool fused) {
+// col[k][j] = Bc^k e_j, row[k][j] = (Bc^T)^k e_j (want_row).  The chain of a start vector j depends on nothing but itself, so the
+// start vectors are dealt to a few host threads when the tables are big (61 states, 301 rows for sumstatEXP: 2 x 68 M
+// multiply-adds, 57 ms of a call whose kernels take 1.5 ms) -- the same operations on the same operands per entry.
+inline void build_chain_tables(const double* Bc, int n, int ktab, std::vector<double>& col, std::vector<double>& row, bool fused,
+                               bool want_row = true) {
   col.assign((size_t)ktab * n * n, 0.0);
-  row.assign((size_t)ktab * n * n, 0.0);
-  for (int j = 0; j < n; ++j) { col[(size_t)j * n + j] = 1.0; row[(size_t)j * n + j] = 1.0; }
-  for (int k = 1; k < ktab; ++k)
-    for (int j = 0; j < n; ++j) {
-      host_chain_matvec(Bc, n, &col[((size_t)(k - 1) * n + j) * n], &col[((size_t)k * n + j) * n], fused);
-      host_chain_matTvec(Bc, n, &row[((size_t)(k - 1) * n + j) * n], &row[((size_t)k * n + j) * n], fused);
-    }
+  row.assign(want_row ? (size_t)ktab * n * n : 0, 0.0);
+  for (int j = 0; j < n; ++j) { col[(size_t)j * n + j] = 1.0; if (want_row) row[(size_t)j * n + j] = 1.0; }
+  auto chains = [&](int j0, int j1) {
+    for (int k = 1; k < ktab; ++k)
+      for (int j = j0; j < j1; ++j) {
+        host_chain_matvec(Bc, n, &col[((size_t)(k - 1) * n + j) * n], &col[((size_t)k * n + j) * n], fused);
+        if (want_row) host_chain_matTvec(Bc, n, &row[((size_t)(k - 1) * n + j) * n], &row[((size_t)k * n + j) * n], fused);
+      }
+  };
+  const double work = (double)ktab * n * n * n * (want_row ? 2 : 1);
+  const int nt = work < 4e6 ? 1 : std::min<int>({8, n, (int)std::max(1u, std::thread::hardware_concurrency())});
+  if (nt <= 1) { chains(0, n); return; }
+  std::vector<std::thread> th;
+  for (int t = 0; t < nt; ++t) th.emplace_back(chains, (int)((int64_t)n * t / nt), (int)((int64_t)n * (t + 1) / nt));
+  for (std::thread& t : th) t.join();
 }
 
 inline int32_t validate_tree_paths(const phm_tree* x, int n, int n_tip_vectors) {
