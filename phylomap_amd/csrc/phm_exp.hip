@@ -178,11 +178,16 @@ __global__ void exp_pl_kernel(int n, int n_node, int n_tips, const UpStep* __res
   }
 }
 
-// the same pass level by level: a thread per node of one height level (children strictly below); identical values
-__global__ void exp_pl_nodes_kernel(int n, int n_tips, const UpStep* __restrict__ up, const int32_t* __restrict__ order, int begin,
-                                    int end, const double* __restrict__ P, double* __restrict__ PL, int rescale) {
-  const int idx = begin + blockIdx.x * blockDim.x + threadIdx.x;
+// the same pass level by level: a WAVE per node of one height level (children strictly below), lane i computing row i of both
+// matrix-vector products with the sums in the order above -- identical values.  (One thread per node walked 2 n^2 dependent
+// multiply-adds: 1.2 ms per level at 61 states, 21 of the 38 ms of a sumstatEXP call on 300 tips.)  n <= 64.
+__global__ __launch_bounds__(64) void exp_pl_nodes_kernel(int n, int n_tips, const UpStep* __restrict__ up, const int32_t* __restrict__ order, int begin,
+                                                           int end, const double* __restrict__ P, double* __restrict__ PL, int rescale) {
+  __shared__ double s_row[64];
+  __shared__ double s_sum;
+  const int idx = begin + (int)blockIdx.x;
   if (idx >= end) return;
+  const int i = threadIdx.x;
   const UpStep st = up[order[idx]];
   const int ca = st.child[0] >= 0 ? st.child[0] + n_tips : ~st.child[0];
   const int cb = st.child[1] >= 0 ? st.child[1] + n_tips : ~st.child[1];
@@ -191,25 +196,34 @@ __global__ void exp_pl_nodes_kernel(int n, int n_tips, const UpStep* __restrict_
   const double* va = PL + (size_t)ca * n;
   const double* vb = PL + (size_t)cb * n;
   double* dst = PL + (size_t)(st.parent + n_tips) * n;
-  for (int i = 0; i < n; ++i) {
+  double r = 0.0;
+  if (i < n) {
     double a = Pa[i * n] * va[0];
     for (int j = 1; j < n; ++j) a += Pa[i * n + j] * va[j];
     double b = Pb[i * n] * vb[0];
     for (int j = 1; j < n; ++j) b += Pb[i * n + j] * vb[j];
-    dst[i] = a * b;                                                             // :2903
+    r = a * b;                                                                  // :2903
   }
   if (rescale) {
-    double sum = dst[0];
-    for (int i = 1; i < n; ++i) sum += dst[i];
-    for (int i = 0; i < n; ++i) dst[i] = dst[i] / sum;
+    s_row[i] = r;
+    __syncthreads();
+    if (i == 0) {
+      double sum = s_row[0];
+      for (int q = 1; q < n; ++q) sum += s_row[q];
+      s_sum = sum;
+    }
+    __syncthreads();
+    r = r / s_sum;
   }
+  if (i < n) dst[i] = r;
 }
 
 hipError_t launch_exp_pl_levels(int n, int n_tips, const UpStep* up, const int32_t* order, const std::vector<int32_t>& level_off,
                                 const double* P, double* PL, int rescale, hipStream_t stream) {
+  if (n > 64) return hipErrorInvalidValue;
   for (size_t l = 0; l + 1 < level_off.size(); ++l) {
     const int cnt = level_off[l + 1] - level_off[l];
-    if (cnt > 0) hipLaunchKernelGGL(exp_pl_nodes_kernel, dim3((cnt + 63) / 64), dim3(64), 0, stream, n, n_tips, up, order, level_off[l],
+    if (cnt > 0) hipLaunchKernelGGL(exp_pl_nodes_kernel, dim3(cnt), dim3(64), 0, stream, n, n_tips, up, order, level_off[l],
                                     level_off[l + 1], P, PL, rescale);
   }
   return hipGetLastError();
