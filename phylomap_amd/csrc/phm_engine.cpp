@@ -151,19 +151,28 @@ int32_t upload_model(phm_engine* e) {
         // eighth one is kept, and the total
       const int nb = e->pwt.nblk, ldb = e->pwt.ldb;
       std::vector<double> blk((size_t)ktab * n * n * ldb, 0.0);
-      for (int k = 0; k < ktab; ++k)
-        for (int sp = 0; sp < n; ++sp)
-          for (int en = 0; en < n; ++en) {
-            const double* beta = &col[((size_t)k * n + en) * n];
-            const double* brow = &e->hB2[(size_t)sp * n];
-            double* out = &blk[(((size_t)k * n + sp) * n + en) * ldb];
-            double t = brow[0] * beta[0];
-            for (int c = 1; c < n; ++c) {
-              if ((c & 7) == 0) out[(c >> 3) - 1] = t;      // the sum after state c - 1 = 8q + 7
-              t += brow[c] * beta[c];
+      auto rows_of = [&](int k0, int k1) {             // the rows of different k are independent: dealt to a few host threads when there are many
+        for (int k = k0; k < k1; ++k)
+          for (int sp = 0; sp < n; ++sp)
+            for (int en = 0; en < n; ++en) {
+              const double* beta = &col[((size_t)k * n + en) * n];
+              const double* brow = &e->hB2[(size_t)sp * n];
+              double* out = &blk[(((size_t)k * n + sp) * n + en) * ldb];
+              double t = brow[0] * beta[0];
+              for (int c = 1; c < n; ++c) {
+                if ((c & 7) == 0) out[(c >> 3) - 1] = t;      // the sum after state c - 1 = 8q + 7
+                t += brow[c] * beta[c];
+              }
+              out[nb - 1] = t;
             }
-            out[nb - 1] = t;
-          }
+      };
+      const int nt = (double)ktab * n * n * n < 4e6 ? 1 : std::min<int>({8, ktab, (int)std::max(1u, std::thread::hardware_concurrency())});
+      if (nt <= 1) rows_of(0, ktab);
+      else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; ++t) th.emplace_back(rows_of, (int)((int64_t)ktab * t / nt), (int)((int64_t)ktab * (t + 1) / nt));
+        for (std::thread& t : th) t.join();
+      }
       HIPCHK(hipMemcpy(e->d_wt_totL.p, blk.data(), sizeof(double) * blk.size(), hipMemcpyHostToDevice));
     }
     {   // transitions that can occur at all: a -> c with B2[a][c] != 0 (c != a unless self pairs are counted).  Few of them
@@ -1554,6 +1563,25 @@ int32_t phm_engine_read_stats(phm_engine* e, int32_t iter0, int32_t n, double* o
       HIPCHK(hipMemcpyAsync(e->pin_down.p, e->d_stats.as<double>() + (size_t)iter0 * dcols * e->S_pad, sizeof(double) * hn, hipMemcpyDeviceToHost, e->last_stream));
       HIPCHK(wait_stream(e->last_stream));
       h = e->pin_down.as<double>();
+    } else if (2 * (int64_t)e->S <= e->S_pad) {        // few replicas on padded tiles (one chain at 61 states, 100 sweeps: 194 MB of padding for 3 MB
+      // of statistics, 53 of the call's 96 ms): their columns are packed on the device first
+      std::vector<int32_t> pick(e->S);
+      for (int r = 0; r < e->S; ++r) pick[r] = e->pad_index(r);
+      DevBuf d_pick, d_pack;
+      const size_t n_rows = (size_t)n * dcols;
+      HIPCHK(d_pick.alloc(sizeof(int32_t) * pick.size())); HIPCHK(d_pack.alloc(sizeof(double) * n_rows * e->S));
+      HIPCHK(hipMemcpyAsync(d_pick.p, pick.data(), d_pick.bytes, hipMemcpyHostToDevice, e->last_stream));
+      HIPCHK(phm::launch_stats_gather(e->d_stats.as<double>() + (size_t)iter0 * dcols * e->S_pad, (int64_t)n_rows, e->S_pad, e->S, d_pick.as<int32_t>(),
+                                      d_pack.as<double>(), e->last_stream));
+      hv.resize(n_rows * e->S);
+      HIPCHK(hipMemcpyAsync(hv.data(), d_pack.p, sizeof(double) * hv.size(), hipMemcpyDeviceToHost, e->last_stream));
+      HIPCHK(hipStreamSynchronize(e->last_stream));
+      for (int r = 0; r < e->S; ++r) {
+        for (int c = 0; c < dcols; ++c)
+          for (int i = 0; i < n; ++i) out[((size_t)r * cols + out_col(c)) * n + i] = hv[((size_t)i * dcols + c) * e->S + r];
+        fill_params(out + (size_t)r * cols * n);
+      }
+      return PHM_OK;
     } else {
       hv.resize(hn);
       HIPCHK(hipMemcpy(hv.data(), e->d_stats.as<double>() + (size_t)iter0 * dcols * e->S_pad, sizeof(double) * hn, hipMemcpyDeviceToHost));

@@ -55,6 +55,8 @@ template <int NS> hipError_t launch_mcmc(const McmcParams<NS>& p, int iter0, int
 hipError_t launch_mcmc_init(int n_edge, int n_tiles, int64_t rows, const DownStep* down, const int32_t* init_row,
                             const int32_t* map_off, const double* maps, double* dwell0, uint16_t* mcount,
                             hipStream_t stream);
+// the statistics columns of the replicas that exist, packed (few replicas on padded tiles: a read of the padded rows moves 64x the data)
+hipError_t launch_stats_gather(const double* stats, int64_t n_rows, int n_rep_pad, int n_pick, const int32_t* pick, double* out, hipStream_t stream);
 hipError_t launch_stats_reduce(const double* partial, int n_iters, int n_tiles, int n_cols, double* out,
                                hipStream_t stream, const double* init = nullptr);
 

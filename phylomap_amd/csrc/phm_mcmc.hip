@@ -462,6 +462,16 @@ __global__ void stats_reduce_kernel(const double* __restrict__ partial, int n_it
   out[idx] = acc;
 }
 
+// per-replica statistics rows [row][n_rep_pad] -> the columns of the replicas that exist, packed: [row][n_pick] (pick[r] = padded index)
+__global__ void stats_gather_kernel(const double* __restrict__ stats, int64_t n_rows, int n_rep_pad, int n_pick, const int32_t* __restrict__ pick,
+                                    double* __restrict__ out) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_rows * n_pick) return;
+  const int64_t row = idx / n_pick;
+  const int r = (int)(idx - row * n_pick);
+  out[idx] = stats[row * n_rep_pad + pick[r]];
+}
+
 template <int NS>
 size_t mcmc_lds_bytes(int ktab, bool ks) {
   const size_t ncnt = ks ? NS * NS : NS * (NS - 1);
@@ -519,6 +529,12 @@ hipError_t launch_stats_reduce(const double* partial, int n_iters, int n_tiles, 
   int total = n_iters * n_cols;
   hipLaunchKernelGGL(stats_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, partial, n_iters, n_tiles,
                      n_cols, out, init);
+  return hipGetLastError();
+}
+
+hipError_t launch_stats_gather(const double* stats, int64_t n_rows, int n_rep_pad, int n_pick, const int32_t* pick, double* out, hipStream_t stream) {
+  const int64_t total = n_rows * n_pick;
+  hipLaunchKernelGGL(stats_gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, stats, n_rows, n_rep_pad, n_pick, pick, out);
   return hipGetLastError();
 }
 
